@@ -1,0 +1,543 @@
+/*
+ * sgn_oracle.c — CPU restatement (plain C, scalar loops) of the differentiable
+ * Gaussian-rasterizer hot path that street-gaussians-ns calls through gsplat.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, bench.py's
+ * cpu_baseline leg and __graft_entry__.smoke() may load it; the shipped path
+ * (street-gaussians-ns_amd/) never links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the algorithm lives in the third-party package `gsplat`
+ * (v0.1.x, most likely 0.1.11 — not pinned by the reference's pyproject.toml,
+ * not vendored under /root/reference, not installed here) and the reference
+ * has no tests / golden vectors for this path.  This file
+ * restates gsplat 0.1.x's published algorithm and is
+ * anchored on the reference's call sites:
+ *     street_gaussians_ns/sgn_splatfacto.py:860-873   project_gaussians
+ *     street_gaussians_ns/sgn_splatfacto.py:939       spherical_harmonics
+ *     street_gaussians_ns/sgn_splatfacto.py:954-967   rasterize_gaussians (rgb+alpha)
+ *     street_gaussians_ns/sgn_splatfacto.py:982-994   rasterize_gaussians (depth)
+ *     street_gaussians_ns/sgn_splatfacto_scene_graph.py:285  spherical_harmonics
+ * Self-consistency pins live in tests/ (fp64 autograd of oracle/torch_oracle.py
+ * against the analytic backward here, and committed fixtures in tests/golden/).
+ *
+ * Arithmetic contract (so integer outputs can be compared bit-for-bit with the
+ * HIP kernels): every expression is evaluated in IEEE binary32 exactly as it is
+ * written, left to right, with NO fused multiply-add unless fmaf() is spelled
+ * out.  Build with -ffp-contract=off (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SGO_API __attribute__((visibility("default")))
+
+/* ---------------------------------------------------------------- helpers */
+
+/* float -> int with the saturating behaviour of the GPU conversion
+ * (v_cvt_i32_f32): NaN -> 0, out of range -> INT_MIN / INT_MAX, else truncate. */
+static int f2i(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+static int g_exp_mode = 0; /* 0: libm expf;  1: portable polynomial exp (bit-matches the HIP "exact" build) */
+
+SGO_API void sgo_set_exp_mode(int mode) { g_exp_mode = mode; }
+
+/* Portable exp(x): 2^(x*log2e) with a fixed degree-6 polynomial on the fractional
+ * part, every step a single IEEE op (fmaf spelled out).  The HIP kernels carry an
+ * independently written copy of the same recipe for their "exact" build, which is
+ * what lets final_idx / images be compared bit-for-bit. */
+static float exp_portable(float x) {
+    float t = x * 1.44269504088896341f;
+    t = fminf(fmaxf(t, -126.0f), 126.0f);
+    float n = floorf(t);
+    float f = t - n;
+    float p = 1.53533063e-4f;
+    p = fmaf(p, f, 1.33988744e-3f);
+    p = fmaf(p, f, 9.61843736e-3f);
+    p = fmaf(p, f, 5.55035681e-2f);
+    p = fmaf(p, f, 2.40226488e-1f);
+    p = fmaf(p, f, 6.93147182e-1f);
+    p = fmaf(p, f, 1.0f);
+    return ldexpf(p, (int)n);
+}
+static float sgo_exp(float x) { return g_exp_mode ? exp_portable(x) : expf(x); }
+
+SGO_API float sgo_exp_eval(float x) { return sgo_exp(x); }
+
+static void tile_bbox(float cx, float cy, float radius, int tiles_x, int tiles_y, int block,
+                      int *minx, int *miny, int *maxx, int *maxy) {
+    /* gsplat helpers.cuh get_tile_bbox / get_bbox: tile-space centre and radius,
+     * C truncation, "+1" added BEFORE the cast for the max side, clamp to the grid. */
+    float tcx = cx / (float)block, tcy = cy / (float)block;
+    float tr = radius / (float)block;
+    *minx = imin(imax(0, f2i(tcx - tr)), tiles_x);
+    *maxx = imin(imax(0, f2i(tcx + tr + 1.0f)), tiles_x);
+    *miny = imin(imax(0, f2i(tcy - tr)), tiles_y);
+    *maxy = imin(imax(0, f2i(tcy + tr + 1.0f)), tiles_y);
+}
+
+static void quat_to_R(const float *q, float R[3][3]) {
+    /* (w,x,y,z), taken as given (the caller normalises: sgn_splatfacto.py:864) */
+    float w = q[0], x = q[1], y = q[2], z = q[3];
+    R[0][0] = 1.f - 2.f * (y * y + z * z);
+    R[0][1] = 2.f * (x * y - w * z);
+    R[0][2] = 2.f * (x * z + w * y);
+    R[1][0] = 2.f * (x * y + w * z);
+    R[1][1] = 1.f - 2.f * (x * x + z * z);
+    R[1][2] = 2.f * (y * z - w * x);
+    R[2][0] = 2.f * (x * z - w * y);
+    R[2][1] = 2.f * (y * z + w * x);
+    R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+/* ------------------------------------------------- project_gaussians forward
+ * gsplat forward.cu project_gaussians_forward_kernel;
+ * call site sgn_splatfacto.py:860-873.  Outputs must be zero-initialised by the
+ * caller (culled rows keep zeros). */
+SGO_API void sgo_project_fwd(int N, const float *means, const float *scales, float glob_scale,
+                             const float *quats, const float *V /*3x4 row-major*/, float fx,
+                             float fy, float cx, float cy, int H, int W, int block, float clip,
+                             float *cov3d, float *xys, float *depths, int *radii, float *conics,
+                             float *comp, int *num_tiles_hit) {
+    int tiles_x = (W + block - 1) / block, tiles_y = (H + block - 1) / block;
+    float tan_fovx = 0.5f * (float)W / fx, tan_fovy = 0.5f * (float)H / fy;
+    float lim_x = 1.3f * tan_fovx, lim_y = 1.3f * tan_fovy;
+    for (int i = 0; i < N; ++i) {
+        const float *p = means + 3 * i;
+        float pvx = V[0] * p[0] + V[1] * p[1] + V[2] * p[2] + V[3];
+        float pvy = V[4] * p[0] + V[5] * p[1] + V[6] * p[2] + V[7];
+        float pvz = V[8] * p[0] + V[9] * p[1] + V[10] * p[2] + V[11];
+        if (pvz <= clip) continue;
+
+        float R[3][3], M[3][3], S[3][3];
+        quat_to_R(quats + 4 * i, R);
+        for (int c = 0; c < 3; ++c) {
+            float s = glob_scale * scales[3 * i + c];
+            for (int r = 0; r < 3; ++r) M[r][c] = R[r][c] * s;
+        }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b)
+                S[a][b] = M[a][0] * M[b][0] + M[a][1] * M[b][1] + M[a][2] * M[b][2];
+        float *c3 = cov3d + 6 * i;
+        c3[0] = S[0][0]; c3[1] = S[0][1]; c3[2] = S[0][2];
+        c3[3] = S[1][1]; c3[4] = S[1][2]; c3[5] = S[2][2];
+
+        /* EWA: clamp the view-space point to 1.3x the frustum, J, T = J W, C = T S T^T */
+        float tz = pvz;
+        float tx = tz * fminf(lim_x, fmaxf(-lim_x, pvx / tz));
+        float ty = tz * fminf(lim_y, fmaxf(-lim_y, pvy / tz));
+        float rz = 1.f / tz, rz2 = rz * rz;
+        float J00 = fx * rz, J02 = -fx * tx * rz2, J11 = fy * rz, J12 = -fy * ty * rz2;
+        float T[2][3], U[2][3];
+        for (int j = 0; j < 3; ++j) {
+            T[0][j] = J00 * V[0 * 4 + j] + J02 * V[2 * 4 + j];
+            T[1][j] = J11 * V[1 * 4 + j] + J12 * V[2 * 4 + j];
+        }
+        for (int a = 0; a < 2; ++a)
+            for (int j = 0; j < 3; ++j)
+                U[a][j] = T[a][0] * S[0][j] + T[a][1] * S[1][j] + T[a][2] * S[2][j];
+        float c00 = U[0][0] * T[0][0] + U[0][1] * T[0][1] + U[0][2] * T[0][2];
+        float c01 = U[0][0] * T[1][0] + U[0][1] * T[1][1] + U[0][2] * T[1][2];
+        float c11 = U[1][0] * T[1][0] + U[1][1] * T[1][1] + U[1][2] * T[1][2];
+        float det0 = c00 * c11 - c01 * c01;
+        float a = c00 + 0.3f, b = c01, c = c11 + 0.3f;
+        float det = a * c - b * b;
+        float compensation = sqrtf(fmaxf(0.f, det0 / det));
+        if (det == 0.f) continue;
+        float inv_det = 1.f / det;
+        float con0 = c * inv_det, con1 = -b * inv_det, con2 = a * inv_det;
+        float mid = 0.5f * (a + c);
+        float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+        float v1 = mid + sq, v2 = mid - sq;
+        float radius = ceilf(3.f * sqrtf(fmaxf(v1, v2)));
+        /* upstream writes conics before the tile-area test */
+        conics[3 * i + 0] = con0; conics[3 * i + 1] = con1; conics[3 * i + 2] = con2;
+
+        float rw = 1.f / (pvz + 1e-6f);
+        float ux = pvx * rw * fx + cx, uy = pvy * rw * fy + cy;
+        int mnx, mny, mxx, mxy;
+        tile_bbox(ux, uy, radius, tiles_x, tiles_y, block, &mnx, &mny, &mxx, &mxy);
+        int area = (mxx - mnx) * (mxy - mny);
+        if (area <= 0) continue;
+        num_tiles_hit[i] = area;
+        depths[i] = pvz;
+        radii[i] = f2i(radius);
+        xys[2 * i] = ux; xys[2 * i + 1] = uy;
+        comp[i] = compensation;
+    }
+}
+
+/* ------------------------------------------------ project_gaussians backward
+ * gsplat backward.cu project_gaussians_backward_kernel + helpers.cuh vjps
+ * (SURVEY.md A.5).  Conventions kept from upstream: the EWA vjp uses the
+ * UN-clamped view-space point; v_conic[1] is upstream's "half" off-diagonal
+ * gradient (paired with the 0.5 factor in rasterize backward); quats are treated
+ * as unit.  Outputs zero-initialised by the caller; rows with radii<=0 stay 0. */
+SGO_API void sgo_project_bwd(int N, const float *means, const float *scales, float glob_scale,
+                             const float *quats, const float *V, float fx, float fy,
+                             const float *cov3d, const int *radii, const float *conics,
+                             const float *comp, const float *v_xy, const float *v_depth,
+                             const float *v_conic, const float *v_comp, float *v_cov2d,
+                             float *v_cov3d, float *v_mean, float *v_scale, float *v_quat) {
+    for (int i = 0; i < N; ++i) {
+        if (radii[i] <= 0) continue;
+        const float *p = means + 3 * i;
+        float pvx = V[0] * p[0] + V[1] * p[1] + V[2] * p[2] + V[3];
+        float pvy = V[4] * p[0] + V[5] * p[1] + V[6] * p[2] + V[7];
+        float pvz = V[8] * p[0] + V[9] * p[1] + V[10] * p[2] + V[11];
+        /* project_pix_vjp */
+        float rw = 1.f / (pvz + 1e-6f);
+        float vpx = fx * v_xy[2 * i], vpy = fy * v_xy[2 * i + 1];
+        float vv[3] = {vpx * rw, vpy * rw, -(vpx * pvx + vpy * pvy) * rw * rw};
+        float vm[3];
+        for (int j = 0; j < 3; ++j) vm[j] = V[0 + j] * vv[0] + V[4 + j] * vv[1] + V[8 + j] * vv[2];
+        float vz = v_depth[i];
+        vm[0] += V[8] * vz; vm[1] += V[9] * vz; vm[2] += V[10] * vz;
+
+        /* cov2d_to_conic_vjp: v_Sigma = -X G X with G = [[g0,g1],[g1,g2]] (upstream convention) */
+        float X00 = conics[3 * i], X01 = conics[3 * i + 1], X11 = conics[3 * i + 2];
+        float g0 = v_conic[3 * i], g1 = v_conic[3 * i + 1], g2 = v_conic[3 * i + 2];
+        /* A = X G */
+        float A00 = X00 * g0 + X01 * g1, A01 = X00 * g1 + X01 * g2;
+        float A10 = X01 * g0 + X11 * g1, A11 = X01 * g1 + X11 * g2;
+        float S00 = -(A00 * X00 + A01 * X01), S01 = -(A00 * X01 + A01 * X11);
+        float S10 = -(A10 * X00 + A11 * X01), S11 = -(A10 * X01 + A11 * X11);
+        float vc2[3] = {S00, S01 + S10, S11};
+        /* cov2d_to_compensation_vjp */
+        {
+            float cmp = comp[i];
+            float inv_det = X00 * X11 - X01 * X01;
+            float om = 1.f - cmp * cmp;
+            float vsq = v_comp[i] * 0.5f / (cmp + 1e-6f);
+            vc2[0] += vsq * (om * X00 - 0.3f * inv_det);
+            vc2[1] += 2.f * vsq * (om * X01);
+            vc2[2] += vsq * (om * X11 - 0.3f * inv_det);
+        }
+        v_cov2d[3 * i] = vc2[0]; v_cov2d[3 * i + 1] = vc2[1]; v_cov2d[3 * i + 2] = vc2[2];
+
+        /* project_cov3d_ewa_vjp (t un-clamped) */
+        float rz = 1.f / pvz, rz2 = rz * rz, rz3 = rz2 * rz;
+        float J00 = fx * rz, J02 = -fx * pvx * rz2, J11 = fy * rz, J12 = -fy * pvy * rz2;
+        float T[2][3];
+        for (int j = 0; j < 3; ++j) {
+            T[0][j] = J00 * V[j] + J02 * V[8 + j];
+            T[1][j] = J11 * V[4 + j] + J12 * V[8 + j];
+        }
+        const float *c3 = cov3d + 6 * i;
+        float S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+        float G[2][2] = {{vc2[0], 0.5f * vc2[1]}, {0.5f * vc2[1], vc2[2]}};
+        /* v_Sigma3 = T^T G T */
+        float GT[2][3];
+        for (int a = 0; a < 2; ++a)
+            for (int j = 0; j < 3; ++j) GT[a][j] = G[a][0] * T[0][j] + G[a][1] * T[1][j];
+        float vS[3][3];
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) vS[a][b] = T[0][a] * GT[0][b] + T[1][a] * GT[1][b];
+        float *vc3 = v_cov3d + 6 * i;
+        vc3[0] = vS[0][0]; vc3[1] = vS[0][1] + vS[1][0]; vc3[2] = vS[0][2] + vS[2][0];
+        vc3[3] = vS[1][1]; vc3[4] = vS[1][2] + vS[2][1]; vc3[5] = vS[2][2];
+        /* v_T = G T S^T + G^T T S = 2 (G T) S  (G, S symmetric) */
+        float vT[2][3];
+        for (int a = 0; a < 2; ++a)
+            for (int j = 0; j < 3; ++j)
+                vT[a][j] = 2.f * (GT[a][0] * S[0][j] + GT[a][1] * S[1][j] + GT[a][2] * S[2][j]);
+        /* v_J = v_T W^T  (only the entries J depends on) */
+        float vJ00 = vT[0][0] * V[0] + vT[0][1] * V[1] + vT[0][2] * V[2];
+        float vJ02 = vT[0][0] * V[8] + vT[0][1] * V[9] + vT[0][2] * V[10];
+        float vJ11 = vT[1][0] * V[4] + vT[1][1] * V[5] + vT[1][2] * V[6];
+        float vJ12 = vT[1][0] * V[8] + vT[1][1] * V[9] + vT[1][2] * V[10];
+        float vt[3] = {-fx * rz2 * vJ02, -fy * rz2 * vJ12,
+                       -fx * rz2 * vJ00 + 2.f * fx * pvx * rz3 * vJ02 - fy * rz2 * vJ11 +
+                           2.f * fy * pvy * rz3 * vJ12};
+        for (int j = 0; j < 3; ++j) vm[j] += V[0 + j] * vt[0] + V[4 + j] * vt[1] + V[8 + j] * vt[2];
+        v_mean[3 * i] = vm[0]; v_mean[3 * i + 1] = vm[1]; v_mean[3 * i + 2] = vm[2];
+
+        /* scale_rot_to_cov3d_vjp */
+        float vV[3][3] = {{vc3[0], 0.5f * vc3[1], 0.5f * vc3[2]},
+                          {0.5f * vc3[1], vc3[3], 0.5f * vc3[4]},
+                          {0.5f * vc3[2], 0.5f * vc3[4], vc3[5]}};
+        float R[3][3], M[3][3], sc[3];
+        quat_to_R(quats + 4 * i, R);
+        for (int c = 0; c < 3; ++c) {
+            sc[c] = glob_scale * scales[3 * i + c];
+            for (int r = 0; r < 3; ++r) M[r][c] = R[r][c] * sc[c];
+        }
+        float vM[3][3];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c)
+                vM[a][c] = 2.f * (vV[a][0] * M[0][c] + vV[a][1] * M[1][c] + vV[a][2] * M[2][c]);
+        for (int c = 0; c < 3; ++c)
+            v_scale[3 * i + c] =
+                (R[0][c] * vM[0][c] + R[1][c] * vM[1][c] + R[2][c] * vM[2][c]) * glob_scale;
+        float vR[3][3];
+        for (int a = 0; a < 3; ++a)
+            for (int c = 0; c < 3; ++c) vR[a][c] = vM[a][c] * sc[c];
+        const float *q = quats + 4 * i;
+        float w = q[0], x = q[1], y = q[2], z = q[3];
+        v_quat[4 * i + 0] = 2.f * (x * (vR[2][1] - vR[1][2]) + y * (vR[0][2] - vR[2][0]) +
+                                   z * (vR[1][0] - vR[0][1]));
+        v_quat[4 * i + 1] = 2.f * (-2.f * x * (vR[1][1] + vR[2][2]) + y * (vR[1][0] + vR[0][1]) +
+                                   z * (vR[2][0] + vR[0][2]) + w * (vR[2][1] - vR[1][2]));
+        v_quat[4 * i + 2] = 2.f * (x * (vR[1][0] + vR[0][1]) - 2.f * y * (vR[0][0] + vR[2][2]) +
+                                   z * (vR[2][1] + vR[1][2]) + w * (vR[0][2] - vR[2][0]));
+        v_quat[4 * i + 3] = 2.f * (x * (vR[2][0] + vR[0][2]) + y * (vR[2][1] + vR[1][2]) -
+                                   2.f * z * (vR[0][0] + vR[1][1]) + w * (vR[1][0] - vR[0][1]));
+    }
+}
+
+/* ------------------------------------------------------- spherical harmonics
+ * gsplat sh.cuh, method="fast" (Sloan-style recurrences), SURVEY.md A.6.
+ * The direction is normalised inside; no +0.5 (caller adds it,
+ * sgn_splatfacto.py:940).  coeffs [N,K,3] basis-major, channel-minor. */
+static int sh_bases(const float *d, int deg, float *b) {
+    b[0] = 0.2820947917738781f;
+    if (deg < 1) return 1;
+    float inorm = 1.f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    float x = d[0] * inorm, y = d[1] * inorm, z = d[2] * inorm;
+    float fTmp0A = 0.48860251190292f;
+    b[1] = -fTmp0A * y; b[2] = fTmp0A * z; b[3] = -fTmp0A * x;
+    if (deg < 2) return 4;
+    float z2 = z * z;
+    float fTmp0B = -1.092548430592079f * z;
+    float fTmp1A = 0.5462742152960395f;
+    float fC1 = x * x - y * y;
+    float fS1 = 2.f * x * y;
+    b[6] = 0.9461746957575601f * z2 - 0.3153915652525201f;
+    b[7] = fTmp0B * x; b[5] = fTmp0B * y; b[8] = fTmp1A * fC1; b[4] = fTmp1A * fS1;
+    if (deg < 3) return 9;
+    float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f;
+    float fTmp1B = 1.445305721320277f * z;
+    float fTmp2A = -0.5900435899266435f;
+    float fC2 = x * fC1 - y * fS1;
+    float fS2 = x * fS1 + y * fC1;
+    b[12] = z * (1.865881662950577f * z2 - 1.119528997770346f);
+    b[13] = fTmp0C * x; b[11] = fTmp0C * y; b[14] = fTmp1B * fC1; b[10] = fTmp1B * fS1;
+    b[15] = fTmp2A * fC2; b[9] = fTmp2A * fS2;
+    if (deg < 4) return 16;
+    float fTmp0D = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+    float fTmp1C = 3.31161143515146f * z2 - 0.47308734787878f;
+    float fTmp2B = -1.770130769779931f * z;
+    float fTmp3A = 0.6258357354491763f;
+    float fC3 = x * fC2 - y * fS2;
+    float fS3 = x * fS2 + y * fC2;
+    b[20] = 1.984313483298443f * z * b[12] + -1.006230589874905f * b[6];
+    b[21] = fTmp0D * x; b[19] = fTmp0D * y; b[22] = fTmp1C * fC1; b[18] = fTmp1C * fS1;
+    b[23] = fTmp2B * fC2; b[17] = fTmp2B * fS2; b[24] = fTmp3A * fC3; b[16] = fTmp3A * fS3;
+    return 25;
+}
+
+SGO_API void sgo_sh_fwd(int N, int K, int deg, const float *dirs, const float *coeffs,
+                        float *colors) {
+    for (int i = 0; i < N; ++i) {
+        float b[25];
+        int nb = sh_bases(dirs + 3 * i, deg, b);
+        const float *c = coeffs + (size_t)i * K * 3;
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int k = 0; k < nb; ++k)
+            for (int ch = 0; ch < 3; ++ch) acc[ch] += b[k] * c[3 * k + ch];
+        colors[3 * i] = acc[0]; colors[3 * i + 1] = acc[1]; colors[3 * i + 2] = acc[2];
+    }
+}
+
+SGO_API void sgo_sh_bwd(int N, int K, int deg, const float *dirs, const float *v_colors,
+                        float *v_coeffs) {
+    for (int i = 0; i < N; ++i) {
+        float b[25];
+        int nb = sh_bases(dirs + 3 * i, deg, b);
+        float *vc = v_coeffs + (size_t)i * K * 3;
+        for (int k = 0; k < K; ++k)
+            for (int ch = 0; ch < 3; ++ch)
+                vc[3 * k + ch] = (k < nb) ? b[k] * v_colors[3 * i + ch] : 0.f;
+    }
+}
+
+/* ------------------------------------------------------------------ binning
+ * gsplat utils.py compute_cumulative_intersects / bin_and_sort_gaussians and
+ * forward.cu map_gaussian_to_intersects / get_tile_bin_edges. */
+SGO_API void sgo_scan_i32(int N, const int *in, int *out) {
+    int s = 0;
+    for (int i = 0; i < N; ++i) { s += in[i]; out[i] = s; }
+}
+
+SGO_API void sgo_map_isect(int N, const float *xys, const float *depths, const int *radii,
+                           const int *cum, int tiles_x, int tiles_y, int block, int64_t *keys,
+                           int32_t *vals) {
+    for (int i = 0; i < N; ++i) {
+        if (radii[i] <= 0) continue;
+        int mnx, mny, mxx, mxy;
+        tile_bbox(xys[2 * i], xys[2 * i + 1], (float)radii[i], tiles_x, tiles_y, block, &mnx,
+                  &mny, &mxx, &mxy);
+        int cur = (i == 0) ? 0 : cum[i - 1];
+        int32_t dbits;
+        memcpy(&dbits, depths + i, 4);
+        int64_t depth_id = (int64_t)dbits; /* sign-extends like upstream; depths > 0 here */
+        for (int ty = mny; ty < mxy; ++ty)
+            for (int tx = mnx; tx < mxx; ++tx) {
+                int64_t tile_id = (int64_t)ty * tiles_x + tx;
+                keys[cur] = (tile_id << 32) | depth_id;
+                vals[cur] = i;
+                ++cur;
+            }
+    }
+}
+
+/* stable ascending sort on the signed 64-bit key (torch.sort on int64 upstream;
+ * equal keys keep emission order).  Stable LSD byte radix, bias on the top byte. */
+SGO_API void sgo_sort_pairs(int64_t I, const int64_t *keys_in, const int32_t *vals_in,
+                            int64_t *keys_out, int32_t *vals_out) {
+    if (I <= 0) return;
+    uint64_t *ka = (uint64_t *)malloc(sizeof(uint64_t) * I), *kb = (uint64_t *)malloc(sizeof(uint64_t) * I);
+    int32_t *va = (int32_t *)malloc(sizeof(int32_t) * I), *vb = (int32_t *)malloc(sizeof(int32_t) * I);
+    for (int64_t i = 0; i < I; ++i) { ka[i] = (uint64_t)keys_in[i] ^ 0x8000000000000000ull; va[i] = vals_in[i]; }
+    for (int pass = 0; pass < 8; ++pass) {
+        int64_t cnt[257];
+        memset(cnt, 0, sizeof(cnt));
+        int sh = pass * 8;
+        for (int64_t i = 0; i < I; ++i) cnt[((ka[i] >> sh) & 255) + 1]++;
+        for (int d = 0; d < 256; ++d) cnt[d + 1] += cnt[d];
+        for (int64_t i = 0; i < I; ++i) {
+            int64_t pos = cnt[(ka[i] >> sh) & 255]++;
+            kb[pos] = ka[i]; vb[pos] = va[i];
+        }
+        uint64_t *tk = ka; ka = kb; kb = tk;
+        int32_t *tv = va; va = vb; vb = tv;
+    }
+    for (int64_t i = 0; i < I; ++i) { keys_out[i] = (int64_t)(ka[i] ^ 0x8000000000000000ull); vals_out[i] = va[i]; }
+    free(ka); free(kb); free(va); free(vb);
+}
+
+/* tile_bins [n_tiles,2] zero-initialised by the caller */
+SGO_API void sgo_tile_bins(int64_t I, const int64_t *keys_sorted, int32_t *bins) {
+    for (int64_t idx = 0; idx < I; ++idx) {
+        int32_t cur = (int32_t)(keys_sorted[idx] >> 32);
+        if (idx == 0) bins[2 * cur] = 0;
+        if (idx == I - 1) bins[2 * cur + 1] = (int32_t)I;
+        if (idx == 0) continue;
+        int32_t prev = (int32_t)(keys_sorted[idx - 1] >> 32);
+        if (prev != cur) { bins[2 * prev + 1] = (int32_t)idx; bins[2 * cur] = (int32_t)idx; }
+    }
+}
+
+/* --------------------------------------------------------- rasterize forward
+ * gsplat forward.cu rasterize_forward (3-channel path), SURVEY.md A.3;
+ * call sites sgn_splatfacto.py:954-967, :982-994.
+ * Hot-loop arithmetic (shared contract with the HIP kernel):
+ *   dx = x - px; dy = y - py
+ *   s1 = (a*dx)*dx;  s2 = fmaf(c*dy, dy, s1);  s3 = 0.5f*s2;  sigma = fmaf(b*dx, dy, s3)
+ *   alpha = min(0.999, opac * exp(-sigma));  skip if sigma < 0 or alpha < 1/255
+ *   nT = T*(1-alpha); stop (NOT composited) if nT <= 1e-4
+ *   vis = alpha*T;  C_ch = fmaf(color_ch, vis, C_ch);  T = nT */
+SGO_API void sgo_raster_fwd(int H, int W, int block, const int32_t *ids, const int32_t *bins,
+                            const float *xys, const float *conics, const float *colors,
+                            const float *opac, const float *bg, float *out_img, float *final_T,
+                            int32_t *final_idx) {
+    int tiles_x = (W + block - 1) / block;
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            int tile = (i / block) * tiles_x + (j / block);
+            int start = bins[2 * tile], end = bins[2 * tile + 1];
+            float px = (float)j + 0.5f, py = (float)i + 0.5f;
+            float T = 1.f, C[3] = {0.f, 0.f, 0.f};
+            int last = 0;
+            for (int k = start; k < end; ++k) {
+                int g = ids[k];
+                float dx = xys[2 * g] - px, dy = xys[2 * g + 1] - py;
+                float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
+                float s = (a * dx) * dx;
+                s = fmaf(c * dy, dy, s);
+                s = 0.5f * s;
+                float sigma = fmaf(b * dx, dy, s);
+                float alpha = fminf(0.999f, opac[g] * sgo_exp(-sigma));
+                if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+                float nT = T * (1.f - alpha);
+                if (nT <= 1e-4f) break;
+                float vis = alpha * T;
+                for (int ch = 0; ch < 3; ++ch) C[ch] = fmaf(colors[3 * g + ch], vis, C[ch]);
+                T = nT;
+                last = k;
+            }
+            size_t pix = (size_t)i * W + j;
+            final_T[pix] = T;
+            final_idx[pix] = last;
+            for (int ch = 0; ch < 3; ++ch) out_img[3 * pix + ch] = fmaf(T, bg[ch], C[ch]);
+        }
+}
+
+/* -------------------------------------------------------- rasterize backward
+ * gsplat backward.cu rasterize_backward_kernel, SURVEY.md A.4.
+ * alpha_clamp_bwd: upstream 0.1.x clamps alpha at 0.99 here (0.999 in forward);
+ * pass 0.99f for upstream behaviour, 0.999f for the self-consistent variant
+ * used by the autograd cross-check.  v_conic[1] keeps upstream's 0.5 factor.
+ * Accumulates in double so the oracle is order-independent "truth"; outputs
+ * (zero-initialised by the caller) are float. */
+SGO_API void sgo_raster_bwd(int H, int W, int block, int N, const int32_t *ids,
+                            const int32_t *bins, const float *xys, const float *conics,
+                            const float *colors, const float *opac, const float *bg,
+                            const float *final_T, const int32_t *final_idx, const float *v_out,
+                            const float *v_out_alpha, float alpha_clamp_bwd, float *v_xy,
+                            float *v_conic, float *v_colors, float *v_opac) {
+    int tiles_x = (W + block - 1) / block;
+    double *acc = (double *)calloc((size_t)N * 9, sizeof(double));
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            int tile = (i / block) * tiles_x + (j / block);
+            int start = bins[2 * tile], end = bins[2 * tile + 1];
+            size_t pix = (size_t)i * W + j;
+            float px = (float)j + 0.5f, py = (float)i + 0.5f;
+            float T_final = final_T[pix], T = T_final;
+            float buf[3] = {0.f, 0.f, 0.f};
+            const float *vo = v_out + 3 * pix;
+            float voa = v_out_alpha[pix];
+            int kmax = final_idx[pix];
+            if (kmax > end - 1) kmax = end - 1;
+            for (int k = kmax; k >= start; --k) {
+                int g = ids[k];
+                float dx = xys[2 * g] - px, dy = xys[2 * g + 1] - py;
+                float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
+                float s = (a * dx) * dx;
+                s = fmaf(c * dy, dy, s);
+                s = 0.5f * s;
+                float sigma = fmaf(b * dx, dy, s);
+                float vis = sgo_exp(-sigma);
+                float o = opac[g];
+                float alpha = fminf(alpha_clamp_bwd, o * vis);
+                if (sigma < 0.f || alpha < 1.f / 255.f) continue;
+                float ra = 1.f / (1.f - alpha);
+                T *= ra;
+                float fac = alpha * T;
+                const float *col = colors + 3 * g;
+                float v_alpha = 0.f;
+                for (int ch = 0; ch < 3; ++ch)
+                    v_alpha += (col[ch] * T - buf[ch] * ra) * vo[ch];
+                v_alpha += T_final * ra * voa;
+                for (int ch = 0; ch < 3; ++ch) v_alpha += -T_final * ra * bg[ch] * vo[ch];
+                for (int ch = 0; ch < 3; ++ch) buf[ch] += col[ch] * fac;
+                float v_sigma = -o * vis * v_alpha;
+                double *A = acc + (size_t)g * 9;
+                A[0] += v_sigma * (a * dx + b * dy);
+                A[1] += v_sigma * (b * dx + c * dy);
+                A[2] += 0.5f * v_sigma * dx * dx;
+                A[3] += 0.5f * v_sigma * dx * dy;
+                A[4] += 0.5f * v_sigma * dy * dy;
+                A[5] += fac * vo[0];
+                A[6] += fac * vo[1];
+                A[7] += fac * vo[2];
+                A[8] += vis * v_alpha;
+            }
+        }
+    for (int g = 0; g < N; ++g) {
+        const double *A = acc + (size_t)g * 9;
+        v_xy[2 * g] = (float)A[0]; v_xy[2 * g + 1] = (float)A[1];
+        v_conic[3 * g] = (float)A[2]; v_conic[3 * g + 1] = (float)A[3]; v_conic[3 * g + 2] = (float)A[4];
+        v_colors[3 * g] = (float)A[5]; v_colors[3 * g + 1] = (float)A[6]; v_colors[3 * g + 2] = (float)A[7];
+        v_opac[g] = (float)A[8];
+    }
+    free(acc);
+}

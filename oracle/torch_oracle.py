@@ -1,0 +1,397 @@
+"""Pure-PyTorch CPU restatement of the gsplat 0.1.x rasterizer hot path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``, ``bench.py``'s
+``cpu_baseline`` leg and ``__graft_entry__.smoke()`` may import it; nothing under
+``street-gaussians-ns_amd/`` does.
+
+PARITY UNPINNED.  The algorithm lives in the third-party package ``gsplat``
+(v0.1.x, most likely 0.1.11; un-pinned by the reference's ``pyproject.toml``,
+not vendored, not installed here) and the reference ships no tests or golden
+vectors for this path.  This module restates the published
+algorithm and is anchored on the reference call sites:
+
+* ``street_gaussians_ns/sgn_splatfacto.py:860-873``  -> :func:`project_gaussians`
+* ``street_gaussians_ns/sgn_splatfacto.py:939``      -> :func:`spherical_harmonics`
+* ``street_gaussians_ns/sgn_splatfacto.py:954-967``  -> :func:`rasterize_gaussians`
+* ``street_gaussians_ns/sgn_splatfacto.py:982-994``  -> :func:`rasterize_gaussians`
+* ``street_gaussians_ns/sgn_splatfacto.py:685``      -> :func:`quat_to_rotmat`
+* ``street_gaussians_ns/sgn_splatfacto_scene_graph.py:285,404-433``
+
+Two uses:
+
+1. correctness oracle — everything is ordinary differentiable torch, dtype
+   generic (fp32 or fp64), so ``torch.autograd`` gives an independent check of the
+   analytic backward in ``oracle/c/sgn_oracle.c`` and of the HIP kernels;
+   projection is written component-wise in the *same operation order* as the C
+   oracle so fp32 results (and therefore radii / tile counts / depth-sort keys)
+   agree bit-for-bit;
+2. the "pure-PyTorch CPU rasterizer" that ``BASELINE.json`` asks to be timed on
+   the host cores beside every GPU number (tile-vectorised: one ``[256, G]``
+   alpha matrix + ``cumprod`` per tile).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+__all__ = [
+    "num_sh_bases",
+    "quat_to_rotmat",
+    "project_gaussians",
+    "spherical_harmonics",
+    "compute_cumulative_intersects",
+    "map_gaussian_to_intersects",
+    "get_tile_bin_edges",
+    "bin_and_sort_gaussians",
+    "rasterize_gaussians",
+    "object2world_gs",
+    "idft",
+]
+
+
+def num_sh_bases(degree: int) -> int:
+    """gsplat/sh.py num_sh_bases; reference use sgn_splatfacto.py:268."""
+    if degree > 4:
+        raise ValueError("SH degree must be <= 4")
+    return (degree + 1) ** 2
+
+
+def quat_to_rotmat(quat: torch.Tensor) -> torch.Tensor:
+    """gsplat/_torch_impl.py quat_to_rotmat (normalises; wxyz). sgn_splatfacto.py:685."""
+    assert quat.shape[-1] == 4, quat.shape
+    w, x, y, z = torch.unbind(torch.nn.functional.normalize(quat, dim=-1), dim=-1)
+    mat = torch.stack(
+        [
+            1 - 2 * (y**2 + z**2), 2 * (x * y - w * z), 2 * (x * z + w * y),
+            2 * (x * y + w * z), 1 - 2 * (x**2 + z**2), 2 * (y * z - w * x),
+            2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x**2 + y**2),
+        ],
+        dim=-1,
+    )
+    return mat.reshape(quat.shape[:-1] + (3, 3))
+
+
+def _trunc_i32(v: torch.Tensor) -> torch.Tensor:
+    """C float->int cast (truncate toward zero) with GPU-style saturation."""
+    v = torch.nan_to_num(v.detach(), nan=0.0)
+    return torch.clamp(torch.trunc(v), -2147483648.0, 2147483647.0).to(torch.int64).clamp(
+        -2147483648, 2147483647).to(torch.int32)
+
+
+def _tile_bbox(cx, cy, radius, tiles_x: int, tiles_y: int, block: int):
+    fb = float(block)
+    tcx, tcy, tr = cx / fb, cy / fb, radius / fb
+    mnx = _trunc_i32(tcx - tr).clamp(0, tiles_x)
+    mxx = _trunc_i32(tcx + tr + 1).clamp(0, tiles_x)
+    mny = _trunc_i32(tcy - tr).clamp(0, tiles_y)
+    mxy = _trunc_i32(tcy + tr + 1).clamp(0, tiles_y)
+    return mnx, mny, mxx, mxy
+
+
+def project_gaussians(
+    means3d: torch.Tensor, scales: torch.Tensor, glob_scale: float, quats: torch.Tensor,
+    viewmat: torch.Tensor, fx: float, fy: float, cx: float, cy: float, img_height: int,
+    img_width: int, block_width: int, clip_thresh: float = 0.01,
+):
+    """SURVEY.md A.1; returns (xys, depths, radii, conics, compensation, num_tiles_hit, cov3d)."""
+    dt = means3d.dtype
+    V = viewmat.to(dt).reshape(-1)[:12] if viewmat.numel() in (12, 16) else viewmat
+    V = [V[i] for i in range(12)]
+    px, py, pz = means3d[:, 0], means3d[:, 1], means3d[:, 2]
+    pvx = V[0] * px + V[1] * py + V[2] * pz + V[3]
+    pvy = V[4] * px + V[5] * py + V[6] * pz + V[7]
+    pvz = V[8] * px + V[9] * py + V[10] * pz + V[11]
+    ok = pvz > clip_thresh
+
+    w, x, y, z = quats[:, 0], quats[:, 1], quats[:, 2], quats[:, 3]
+    R = [
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)],
+    ]
+    sc = [glob_scale * scales[:, c] for c in range(3)]
+    M = [[R[r][c] * sc[c] for c in range(3)] for r in range(3)]
+    S = [[M[a][0] * M[b][0] + M[a][1] * M[b][1] + M[a][2] * M[b][2] for b in range(3)] for a in range(3)]
+    cov3d = torch.stack([S[0][0], S[0][1], S[0][2], S[1][1], S[1][2], S[2][2]], dim=-1)
+
+    tan_fovx = torch.tensor(0.5, dtype=dt) * float(img_width) / torch.tensor(fx, dtype=dt)
+    tan_fovy = torch.tensor(0.5, dtype=dt) * float(img_height) / torch.tensor(fy, dtype=dt)
+    lim_x = torch.tensor(1.3, dtype=dt) * tan_fovx
+    lim_y = torch.tensor(1.3, dtype=dt) * tan_fovy
+    fx_t, fy_t = torch.tensor(fx, dtype=dt), torch.tensor(fy, dtype=dt)
+    cx_t, cy_t = torch.tensor(cx, dtype=dt), torch.tensor(cy, dtype=dt)
+    tz = torch.where(ok, pvz, torch.ones_like(pvz))  # keep culled rows finite
+    tx = tz * torch.minimum(lim_x, torch.maximum(-lim_x, pvx / tz))
+    ty = tz * torch.minimum(lim_y, torch.maximum(-lim_y, pvy / tz))
+    rz = 1.0 / tz
+    rz2 = rz * rz
+    J00, J02 = fx_t * rz, -fx_t * tx * rz2
+    J11, J12 = fy_t * rz, -fy_t * ty * rz2
+    T = [[J00 * V[0 + j] + J02 * V[8 + j] for j in range(3)],
+         [J11 * V[4 + j] + J12 * V[8 + j] for j in range(3)]]
+    U = [[T[a][0] * S[0][j] + T[a][1] * S[1][j] + T[a][2] * S[2][j] for j in range(3)] for a in range(2)]
+    c00 = U[0][0] * T[0][0] + U[0][1] * T[0][1] + U[0][2] * T[0][2]
+    c01 = U[0][0] * T[1][0] + U[0][1] * T[1][1] + U[0][2] * T[1][2]
+    c11 = U[1][0] * T[1][0] + U[1][1] * T[1][1] + U[1][2] * T[1][2]
+    det0 = c00 * c11 - c01 * c01
+    a, b, c = c00 + 0.3, c01, c11 + 0.3
+    det = a * c - b * b
+    ok = ok & (det != 0)
+    det_s = torch.where(det != 0, det, torch.ones_like(det))
+    compensation = torch.sqrt(torch.clamp(det0 / det_s, min=0.0))
+    inv_det = 1.0 / det_s
+    conics = torch.stack([c * inv_det, -b * inv_det, a * inv_det], dim=-1)
+    mid = 0.5 * (a + c)
+    sq = torch.sqrt(torch.clamp(mid * mid - det, min=0.1))
+    radius = torch.ceil(3.0 * torch.sqrt(torch.maximum(mid + sq, mid - sq)))
+    rw = 1.0 / (pvz + 1e-6)
+    ux = pvx * rw * fx_t + cx_t
+    uy = pvy * rw * fy_t + cy_t
+    tiles_x = (img_width + block_width - 1) // block_width
+    tiles_y = (img_height + block_width - 1) // block_width
+    mnx, mny, mxx, mxy = _tile_bbox(ux.to(torch.float32), uy.to(torch.float32),
+                                    radius.to(torch.float32), tiles_x, tiles_y, block_width)
+    area = (mxx - mnx) * (mxy - mny)
+    conic_ok = ok  # upstream writes conics before the tile-area test
+    ok = ok & (area > 0)
+
+    zero = torch.zeros((), dtype=dt)
+    xys = torch.where(ok[:, None], torch.stack([ux, uy], dim=-1), zero)
+    depths = torch.where(ok, pvz, zero)
+    radii = torch.where(ok, _trunc_i32(radius), torch.zeros((), dtype=torch.int32))
+    conics = torch.where(conic_ok[:, None], conics, zero)
+    compensation = torch.where(ok, compensation, zero)
+    num_tiles_hit = torch.where(ok, area, torch.zeros((), dtype=torch.int32)).to(torch.int32)
+    cov3d = torch.where((pvz > clip_thresh)[:, None], cov3d, zero)
+    return xys, depths, radii, conics, compensation, num_tiles_hit, cov3d
+
+
+def _sh_bases(dirs: torch.Tensor, degree: int):
+    """gsplat sh.cuh "fast" evaluation. Returns list of [N] tensors."""
+    n = dirs.shape[0]
+    one = torch.ones(n, dtype=dirs.dtype)
+    b = [0.2820947917738781 * one]
+    if degree < 1:
+        return b
+    inorm = 1.0 / torch.sqrt(dirs[:, 0] * dirs[:, 0] + dirs[:, 1] * dirs[:, 1] + dirs[:, 2] * dirs[:, 2])
+    x, y, z = dirs[:, 0] * inorm, dirs[:, 1] * inorm, dirs[:, 2] * inorm
+    f0a = 0.48860251190292
+    b += [-f0a * y, f0a * z, -f0a * x]
+    if degree < 2:
+        return b
+    z2 = z * z
+    f0b = -1.092548430592079 * z
+    f1a = 0.5462742152960395
+    fc1 = x * x - y * y
+    fs1 = 2.0 * x * y
+    b += [f1a * fs1, f0b * y, 0.9461746957575601 * z2 - 0.3153915652525201, f0b * x, f1a * fc1]
+    if degree < 3:
+        return b
+    f0c = -2.285228997322329 * z2 + 0.4570457994644658
+    f1b = 1.445305721320277 * z
+    f2a = -0.5900435899266435
+    fc2 = x * fc1 - y * fs1
+    fs2 = x * fs1 + y * fc1
+    p12 = z * (1.865881662950577 * z2 - 1.119528997770346)
+    b += [f2a * fs2, f1b * fs1, f0c * y, p12, f0c * x, f1b * fc1, f2a * fc2]
+    if degree < 4:
+        return b
+    f0d = z * (-4.683325804901025 * z2 + 2.007139630671868)
+    f1c = 3.31161143515146 * z2 - 0.47308734787878
+    f2b = -1.770130769779931 * z
+    f3a = 0.6258357354491763
+    fc3 = x * fc2 - y * fs2
+    fs3 = x * fs2 + y * fc2
+    p20 = 1.984313483298443 * z * p12 + -1.006230589874905 * b[6]
+    b += [f3a * fs3, f2b * fs2, f1c * fs1, f0d * y, p20, f0d * x, f1c * fc1, f2b * fc2, f3a * fc3]
+    return b
+
+
+def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor) -> torch.Tensor:
+    """gsplat/sh.py spherical_harmonics; no gradient to viewdirs (upstream returns None)."""
+    assert coeffs.shape[-2] >= num_sh_bases(degrees_to_use)
+    bases = torch.stack(_sh_bases(viewdirs.detach(), degrees_to_use), dim=-1)  # [N, nb]
+    nb = bases.shape[-1]
+    return (bases[:, :, None] * coeffs[:, :nb, :]).sum(dim=1)
+
+
+# ------------------------------------------------------------------ binning
+def compute_cumulative_intersects(num_tiles_hit: torch.Tensor) -> Tuple[int, torch.Tensor]:
+    cum = torch.cumsum(num_tiles_hit, dim=0, dtype=torch.int32)
+    return (int(cum[-1].item()) if cum.numel() else 0), cum
+
+
+def map_gaussian_to_intersects(num_points, num_intersects, xys, depths, radii, cum_tiles_hit,
+                               tile_bounds, block_width):
+    tiles_x, tiles_y = int(tile_bounds[0]), int(tile_bounds[1])
+    mnx, mny, mxx, mxy = _tile_bbox(xys[:, 0].float(), xys[:, 1].float(), radii.float(),
+                                    tiles_x, tiles_y, block_width)
+    live = radii > 0
+    w = torch.where(live, mxx - mnx, torch.zeros_like(mnx)).to(torch.int64)
+    h = torch.where(live, mxy - mny, torch.zeros_like(mny)).to(torch.int64)
+    cnt = w * h
+    gid = torch.repeat_interleave(torch.arange(num_points, dtype=torch.int64), cnt)
+    assert gid.numel() == num_intersects, (gid.numel(), num_intersects)
+    cum64 = cum_tiles_hit.to(torch.int64)
+    base = torch.cat([torch.zeros(1, dtype=torch.int64), cum64[:-1]])
+    local = torch.arange(num_intersects, dtype=torch.int64) - base[gid]
+    wg = w[gid].clamp(min=1)
+    ty = mny[gid].to(torch.int64) + local // wg
+    tx = mnx[gid].to(torch.int64) + local % wg
+    depth_id = depths.detach().float().contiguous().view(torch.int32).to(torch.int64)[gid]
+    isect_ids = ((ty * tiles_x + tx) << 32) | depth_id
+    return isect_ids, gid.to(torch.int32)
+
+
+def get_tile_bin_edges(num_intersects: int, isect_ids_sorted: torch.Tensor, tile_bounds) -> torch.Tensor:
+    n_tiles = int(tile_bounds[0]) * int(tile_bounds[1])
+    bins = torch.zeros(n_tiles, 2, dtype=torch.int32)
+    if num_intersects == 0:
+        return bins
+    tile = (isect_ids_sorted >> 32).to(torch.int64)
+    idx = torch.arange(num_intersects, dtype=torch.int32)
+    first = torch.ones(num_intersects, dtype=torch.bool)
+    first[1:] = tile[1:] != tile[:-1]
+    last = torch.ones(num_intersects, dtype=torch.bool)
+    last[:-1] = first[1:]
+    bins[tile[first], 0] = idx[first]
+    bins[tile[last], 1] = idx[last] + 1
+    return bins
+
+
+def bin_and_sort_gaussians(num_points, num_intersects, xys, depths, radii, cum_tiles_hit,
+                           tile_bounds, block_width):
+    isect_ids, gaussian_ids = map_gaussian_to_intersects(
+        num_points, num_intersects, xys, depths, radii, cum_tiles_hit, tile_bounds, block_width)
+    isect_ids_sorted, order = torch.sort(isect_ids, stable=True)
+    gaussian_ids_sorted = torch.gather(gaussian_ids, 0, order)
+    tile_bins = get_tile_bin_edges(num_intersects, isect_ids_sorted, tile_bounds)
+    return isect_ids, gaussian_ids, isect_ids_sorted, gaussian_ids_sorted, tile_bins
+
+
+# ---------------------------------------------------------------- rasterize
+def rasterize_gaussians(
+    xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height: int, img_width: int,
+    block_width: int, background: Optional[torch.Tensor] = None, return_alpha: bool = False,
+    return_aux: bool = False, tile_rows: Optional[Tuple[int, int]] = None,
+):
+    """gsplat/rasterize.py rasterize_gaussians, tile-vectorised.
+
+    ``tile_rows=(r0, r1)`` renders only tile rows [r0, r1) (the bounded CPU-baseline
+    sample); the other pixels are left at the background.
+    """
+    assert 1 < block_width <= 16, "block_width must be between 2 and 16"
+    if colors.dtype == torch.uint8:
+        colors = colors.float() / 255
+    dt = colors.dtype
+    C = colors.shape[-1]
+    if background is not None:
+        assert background.shape[0] == C
+    else:
+        background = torch.ones(C, dtype=dt)
+    if xys.ndimension() != 2 or xys.size(1) != 2:
+        raise ValueError("xys must have dimensions (N, 2)")
+    if colors.ndimension() != 2:
+        raise ValueError("colors must have dimensions (N, D)")
+    H, W, B = img_height, img_width, block_width
+    tiles_x, tiles_y = (W + B - 1) // B, (H + B - 1) // B
+    num_intersects, cum = compute_cumulative_intersects(num_tiles_hit)
+    out_img = background.to(dt).expand(H, W, C).clone()
+    final_T = torch.ones(H, W, dtype=dt)
+    final_idx = torch.zeros(H, W, dtype=torch.int32)
+    if num_intersects >= 1:
+        _, _, _, ids_sorted, tile_bins = bin_and_sort_gaussians(
+            xys.shape[0], num_intersects, xys, depths, radii, cum, (tiles_x, tiles_y, 1), B)
+        ids64 = ids_sorted.to(torch.int64)
+        opac = opacity.reshape(-1)
+        r0, r1 = (0, tiles_y) if tile_rows is None else tile_rows
+        img_rows, T_rows, idx_rows = [], [], []
+        for ty in range(r0, r1):
+            y0, y1 = ty * B, min((ty + 1) * B, H)
+            img_cols, T_cols, idx_cols = [], [], []
+            for tx in range(tiles_x):
+                x0, x1 = tx * B, min((tx + 1) * B, W)
+                s, e = int(tile_bins[ty * tiles_x + tx, 0]), int(tile_bins[ty * tiles_x + tx, 1])
+                hh, ww = y1 - y0, x1 - x0
+                if e <= s:
+                    img_cols.append(background.to(dt).expand(hh, ww, C))
+                    T_cols.append(torch.ones(hh, ww, dtype=dt))
+                    idx_cols.append(torch.zeros(hh, ww, dtype=torch.int32))
+                    continue
+                g = ids64[s:e]
+                py, px = torch.meshgrid(torch.arange(y0, y1, dtype=dt) + 0.5,
+                                        torch.arange(x0, x1, dtype=dt) + 0.5, indexing="ij")
+                px, py = px.reshape(-1, 1), py.reshape(-1, 1)
+                gx, gy = xys[g, 0][None, :], xys[g, 1][None, :]
+                ca, cb, cc = conics[g, 0][None, :], conics[g, 1][None, :], conics[g, 2][None, :]
+                dx, dy = gx - px, gy - py
+                sigma = 0.5 * (ca * dx * dx + cc * dy * dy) + cb * dx * dy
+                alpha = torch.clamp(opac[g][None, :] * torch.exp(-sigma), max=0.999)
+                valid = (sigma >= 0) & (alpha >= 1.0 / 255.0)
+                om = torch.where(valid, 1.0 - alpha, torch.ones_like(alpha))
+                nT = torch.cumprod(om, dim=1)
+                Tb = torch.cat([torch.ones_like(nT[:, :1]), nT[:, :-1]], dim=1)
+                contrib = valid & (nT > 1e-4)
+                wgt = torch.where(contrib, alpha * Tb, torch.zeros_like(alpha))
+                col = wgt @ colors[g]
+                fT = torch.where(contrib, om, torch.ones_like(om)).prod(dim=1)
+                kk = torch.arange(s, e, dtype=torch.int32)[None, :].expand_as(contrib)
+                fi = torch.where(contrib, kk, torch.zeros_like(kk)).amax(dim=1)
+                img_cols.append((col + fT[:, None] * background.to(dt)[None, :]).reshape(hh, ww, C))
+                T_cols.append(fT.reshape(hh, ww))
+                idx_cols.append(fi.reshape(hh, ww))
+            img_rows.append(torch.cat(img_cols, dim=1))
+            T_rows.append(torch.cat(T_cols, dim=1))
+            idx_rows.append(torch.cat(idx_cols, dim=1))
+        ya, yb = r0 * B, min(r1 * B, H)
+        band = torch.cat(img_rows, dim=0)
+        out_img = torch.cat([out_img[:ya], band, out_img[yb:]], dim=0)
+        final_T = torch.cat([final_T[:ya], torch.cat(T_rows, dim=0), final_T[yb:]], dim=0)
+        final_idx = torch.cat([final_idx[:ya], torch.cat(idx_rows, dim=0), final_idx[yb:]], dim=0)
+    res = (out_img, 1 - final_T) if return_alpha else out_img
+    if return_aux:
+        return res, final_T.detach(), final_idx
+    return res
+
+
+# ------------------------------------------------- scene-graph extras (A.7)
+def object2world_gs(means_o, quats_o, R: torch.Tensor, t: torch.Tensor):
+    """sgn_splatfacto_scene_graph.py:404-417: means@R^T+t, q_o2w (x) q (Hamilton, real first)."""
+    means_w = means_o @ R.T + t
+    m = R
+    tr = m[0, 0] + m[1, 1] + m[2, 2]
+    # quaternion_from_matrix (w,x,y,z), branch-free on trace>0 for the test inputs
+    if tr > 0:
+        s = torch.sqrt(tr + 1.0) * 2
+        q = torch.stack([0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s])
+    else:
+        i = int(torch.argmax(torch.stack([m[0, 0], m[1, 1], m[2, 2]])))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = torch.sqrt(m[i, i] - m[j, j] - m[k, k] + 1.0) * 2
+        qv = [None, None, None]
+        qv[i] = 0.25 * s
+        qv[j] = (m[j, i] + m[i, j]) / s
+        qv[k] = (m[k, i] + m[i, k]) / s
+        q = torch.stack([(m[k, j] - m[j, k]) / s, qv[0], qv[1], qv[2]])
+    aw, ax, ay, az = q[0], q[1], q[2], q[3]
+    bw, bx, by, bz = quats_o[:, 0], quats_o[:, 1], quats_o[:, 2], quats_o[:, 3]
+    quats_w = torch.stack([
+        aw * bw - ax * bx - ay * by - az * bz,
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by - ax * bz + ay * bw + az * bx,
+        aw * bz + ax * by - ay * bx + az * bw], dim=-1)
+    return means_w, quats_w
+
+
+def idft(time: float, dim: int, dtype=torch.float32) -> torch.Tensor:
+    """sgn_splatfacto_scene_graph.py:420-433 IDFT basis."""
+    t = torch.as_tensor(time, dtype=dtype)
+    out = []
+    for k in range(dim):
+        if k % 2 == 0:
+            out.append(torch.cos(math.pi * 2 * t * k / dim))
+        else:
+            out.append(torch.sin(math.pi * 2 * t * (k + 1) / dim))
+    return torch.stack(out)
