@@ -1,0 +1,128 @@
+/*
+ * sgn_rast.h — C ABI of libsgnrast.so, the MI355X (gfx950) differentiable
+ * 3D-Gaussian rasterizer behind the gsplat `project_gaussians` /
+ * `rasterize_gaussians` / `spherical_harmonics` surface that
+ * street-gaussians-ns calls (sgn_splatfacto.py:860,939,954,982;
+ * sgn_splatfacto_scene_graph.py:285).
+ *
+ * Every entry point replaces one function of the reference's FFI for this path,
+ * i.e. of gsplat 0.1.x's `gsplat.cuda._C` pybind module (`gsplat/cuda/csrc/
+ * bindings.cu`; third-party, not vendored in /root/reference — names below are
+ * the upstream binding names).  Plain pointers + sizes, no torch types, no
+ * exceptions, no global state besides a thread-local error string.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers to contiguous arrays unless marked host;
+ *     fp32 unless noted; quats are (w,x,y,z); viewmat is the 3x4 row-major
+ *     world->camera matrix (12 floats); images are [H,W,C] row-major.
+ *   - `stream` is a hipStream_t (0 = default stream).  Calls only enqueue work.
+ *   - workspaces are caller-allocated (torch caching allocator on the Python
+ *     side) and sized by the matching *_workspace_bytes() query.
+ *   - return 0 on success, <0 for an argument error, >0 = hipError_t;
+ *     sgn_last_error() gives the message for the calling thread.
+ */
+#ifndef SGN_RAST_H
+#define SGN_RAST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *sgn_stream_t; /* hipStream_t */
+
+#define SGN_RECORD_FLOATS 12 /* one packed intersection record = 48 bytes */
+
+int sgn_version(void);
+const char *sgn_last_error(void);
+
+/* Parity-test switch: 1 = raster kernels use the portable polynomial exp (bit-identical to
+ * oracle/c/sgn_oracle.c exp_portable), 0 (default) = hardware v_exp_f32. Process-global. */
+void sgn_set_exact_exp(int on);
+int sgn_get_exact_exp(void);
+
+/* _C.project_gaussians_forward (gsplat/project_gaussians.py:_ProjectGaussians.forward;
+ * reference call site sgn_splatfacto.py:860-873).  Every output row is written
+ * (zeros for culled Gaussians), so the caller need not pre-zero. */
+int sgn_project_fwd(int n, const float *means3d, const float *scales, float glob_scale,
+                    const float *quats, const float *viewmat12, float fx, float fy, float cx,
+                    float cy, int img_h, int img_w, int block_width, float clip_thresh,
+                    float *cov3d /*[n,6]*/, float *xys /*[n,2]*/, float *depths /*[n]*/,
+                    int32_t *radii /*[n]*/, float *conics /*[n,3]*/, float *compensation /*[n]*/,
+                    int32_t *num_tiles_hit /*[n]*/, sgn_stream_t stream);
+
+/* _C.project_gaussians_backward (_ProjectGaussians.backward).  v_compensation may be NULL
+ * (treated as zeros: the reference discards compensation, sgn_splatfacto.py:860,947).
+ * v_cov2d / v_cov3d are optional scratch outputs (may be NULL).  All rows written. */
+int sgn_project_bwd(int n, const float *means3d, const float *scales, float glob_scale,
+                    const float *quats, const float *viewmat12, float fx, float fy,
+                    const float *cov3d, const int32_t *radii, const float *conics,
+                    const float *compensation, const float *v_xy, const float *v_depth,
+                    const float *v_conic, const float *v_compensation, float *v_cov2d,
+                    float *v_cov3d, float *v_mean3d, float *v_scale, float *v_quat,
+                    sgn_stream_t stream);
+
+/* _C.compute_sh_forward / _C.compute_sh_backward (gsplat/sh.py; reference call sites
+ * sgn_splatfacto.py:939, sgn_splatfacto_scene_graph.py:285).  coeffs [n,k,3], k in
+ * {1,4,9,16,25}; degree <= 4; directions are normalised inside; no +0.5. */
+int sgn_sh_fwd(int n, int k, int degree, const float *viewdirs, const float *coeffs,
+               float *colors /*[n,3]*/, sgn_stream_t stream);
+int sgn_sh_bwd(int n, int k, int degree, const float *viewdirs, const float *v_colors,
+               float *v_coeffs /*[n,k,3], fully written*/, sgn_stream_t stream);
+
+/* torch.cumsum(int32) inside gsplat/utils.py compute_cumulative_intersects. */
+size_t sgn_scan_workspace_bytes(int n);
+int sgn_scan_i32(int n, const int32_t *in, int32_t *out_inclusive, void *ws, size_t ws_bytes,
+                 sgn_stream_t stream);
+
+/* _C.map_gaussian_to_intersects: key = (tile_id << 32) | int32_bits(depth), val = gaussian id,
+ * emitted row-major over the tile bbox starting at cum[i-1]. */
+int sgn_map_isect(int n, const float *xys, const float *depths, const int32_t *radii,
+                  const int32_t *cum_tiles_hit, int tiles_x, int tiles_y, int block_width,
+                  int64_t *isect_keys, int32_t *isect_vals, sgn_stream_t stream);
+
+/* torch.sort(int64) + gather in gsplat/utils.py bin_and_sort_gaussians: stable LSD radix sort
+ * of (key,val) pairs over key bits [begin_bit,end_bit) (keys must be non-negative; bits outside
+ * the range must be equal across keys for the result to equal a full 64-bit sort). */
+size_t sgn_sort_workspace_bytes(int64_t n_isect);
+int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const int64_t *keys_in,
+                   const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out, void *ws,
+                   size_t ws_bytes, sgn_stream_t stream);
+
+/* _C.get_tile_bin_edges; tile_bins [n_tiles,2] is zero-filled here first. */
+int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_tiles, int32_t *tile_bins,
+                  sgn_stream_t stream);
+
+/* _C.rasterize_forward (3-channel path; reference call sites sgn_splatfacto.py:954-967,
+ * :982-994).  `recs_ws` (>= sgn_raster_workspace_bytes(n_isect)) receives the depth-ordered
+ * 48-byte record stream the kernels read through the scalar cache; keep it alive and pass
+ * recs_packed=1 to sgn_raster_bwd to skip re-packing. */
+size_t sgn_raster_workspace_bytes(int64_t n_isect);
+int sgn_raster_fwd(int img_h, int img_w, int block_width, int64_t n_isect,
+                   const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                   const float *conics, const float *colors /*[n,3]*/, const float *opacities /*[n]*/,
+                   const float *background3, float *out_img /*[H,W,3]*/, float *final_Ts /*[H,W]*/,
+                   int32_t *final_idx /*[H,W]*/, void *recs_ws, size_t recs_ws_bytes,
+                   sgn_stream_t stream);
+
+/* _C.rasterize_backward.  alpha_clamp_bwd: 0.99f reproduces gsplat 0.1.x (which clamps at
+ * 0.999 in forward and 0.99 in backward).  Outputs are fully written (zero-filled first).
+ * v_conic[:,1] follows upstream's convention (half the true off-diagonal derivative; it is
+ * consumed consistently by sgn_project_bwd). */
+size_t sgn_raster_bwd_workspace_bytes(int n);
+int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                   const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                   const float *conics, const float *colors, const float *opacities,
+                   const float *background3, const float *final_Ts, const int32_t *final_idx,
+                   const float *v_out_img /*[H,W,3]*/, const float *v_out_alpha /*[H,W]*/,
+                   float alpha_clamp_bwd, float *v_xy /*[n,2]*/, float *v_conic /*[n,3]*/,
+                   float *v_colors /*[n,3]*/, float *v_opacity /*[n]*/, void *recs_ws,
+                   size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
+                   sgn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGN_RAST_H */

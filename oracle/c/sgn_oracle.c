@@ -49,14 +49,14 @@ static int g_exp_mode = 0; /* 0: libm expf;  1: portable polynomial exp (bit-mat
 
 SGO_API void sgo_set_exp_mode(int mode) { g_exp_mode = mode; }
 
-/* Portable exp(x): 2^(x*log2e) with a fixed degree-6 polynomial on the fractional
- * part, every step a single IEEE op (fmaf spelled out).  The HIP kernels carry an
+/* Portable exp(x): 2^(x*log2e) with a fixed degree-6 polynomial (Cephes exp2f
+ * coefficients) on the rounded-off fractional part, every step a single IEEE op (fmaf spelled out).  The HIP kernels carry an
  * independently written copy of the same recipe for their "exact" build, which is
  * what lets final_idx / images be compared bit-for-bit. */
 static float exp_portable(float x) {
     float t = x * 1.44269504088896341f;
-    t = fminf(fmaxf(t, -126.0f), 126.0f);
-    float n = floorf(t);
+    t = fminf(fmaxf(t, -125.0f), 126.0f);
+    float n = rintf(t); /* round-half-even (default FP environment); f in [-0.5, 0.5] */
     float f = t - n;
     float p = 1.53533063e-4f;
     p = fmaf(p, f, 1.33988744e-3f);

@@ -1,0 +1,206 @@
+// binning.hip — tile binning around the sort: int32 inclusive scan, intersection emission,
+// tile bin edges.  gfx950.
+//
+// Replaces torch.cumsum in gsplat/utils.py:compute_cumulative_intersects and gsplat 0.1.x
+// forward.cu:map_gaussian_to_intersects / get_tile_bin_edges, reached from the
+// reference through rasterize_gaussians at sgn_splatfacto.py:954-967, :982-994.
+// Integer work: results are bit-exact with the oracle by construction.
+#include "sgn_common.h"
+
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;  // 2048 items per workgroup
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+// inclusive scan across a 256-thread block of one value per thread; returns inclusive prefix and
+// the block total through `total`.
+__device__ __forceinline__ int block_incl_scan(int v, int *lds4, int &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w = wave_incl_scan(v);
+    if (lane == 63) lds4[wave] = w;
+    __syncthreads();
+    int off = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int t = lds4[k];
+        if (k < wave) off += t;
+    }
+    total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return w + off;
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(int n, const int32_t *__restrict__ in,
+                                                                   int32_t *__restrict__ partial) {
+    __shared__ int lds4[4];
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) s += in[base + k];
+    int total;
+    block_incl_scan(s, lds4, total);
+    if (threadIdx.x == 0) partial[blockIdx.x] = total;
+}
+
+// single workgroup: in-place exclusive scan of the per-chunk totals
+__global__ __launch_bounds__(SCAN_THREADS) void scan_partials_kernel(int nb, int32_t *__restrict__ partial) {
+    __shared__ int lds4[4];
+    int carry = 0;
+    for (int b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
+        const int i = b0 + threadIdx.x;
+        const int v = (i < nb) ? partial[i] : 0;
+        int total;
+        const int inc = block_incl_scan(v, lds4, total);
+        if (i < nb) partial[i] = carry + inc - v;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(int n, const int32_t *__restrict__ in,
+                                                                  const int32_t *__restrict__ partial,
+                                                                  int32_t *__restrict__ out) {
+    __shared__ int lds4[4];
+    const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        s += v[k];
+    }
+    int total;
+    const int inc = block_incl_scan(s, lds4, total);
+    int run = partial[blockIdx.x] + inc - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        run += v[k];
+        if (base + k < n) out[base + k] = run;
+    }
+}
+
+// One lane per Gaussian; bboxes larger than BIG tiles are emitted by the whole wave so one huge
+// splat does not serialise 63 idle lanes.
+constexpr int MAP_BIG = 32;
+
+__global__ __launch_bounds__(256) void map_isect_kernel(int n, const float *__restrict__ xys,
+                                                        const float *__restrict__ depths,
+                                                        const int32_t *__restrict__ radii,
+                                                        const int32_t *__restrict__ cum, int tiles_x,
+                                                        int tiles_y, int block,
+                                                        int64_t *__restrict__ keys,
+                                                        int32_t *__restrict__ vals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int mnx = 0, mny = 0, mxx = 0, mxy = 0, cur = 0;
+    int64_t depth_id = 0;
+    bool live = false;
+    if (i < n) {
+        const int r = radii[i];
+        if (r > 0) {
+            live = true;
+            sgn_tile_bbox(xys[2 * i], xys[2 * i + 1], (float)r, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
+            cur = (i == 0) ? 0 : cum[i - 1];
+            depth_id = (int64_t)__float_as_int(depths[i]);  // sign-extends like upstream; depth > 0
+        }
+    }
+    const int w = mxx - mnx, h = mxy - mny;
+    const int area = live ? w * h : 0;
+    if (area > 0 && area <= MAP_BIG) {
+        for (int ty = mny; ty < mxy; ++ty)
+            for (int tx = mnx; tx < mxx; ++tx) {
+                keys[cur] = ((int64_t)(ty * tiles_x + tx) << 32) | depth_id;
+                vals[cur] = i;
+                ++cur;
+            }
+    }
+    unsigned long long big = __ballot(area > MAP_BIG);
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const int bw = __shfl(w, src, 64), bmnx = __shfl(mnx, src, 64), bmny = __shfl(mny, src, 64);
+        const int barea = __shfl(area, src, 64), bcur = __shfl(cur, src, 64), bi = __shfl(i, src, 64);
+        const int dlo = __shfl((int)(depth_id & 0xffffffffll), src, 64);
+        const int64_t bdepth = (int64_t)dlo;
+        for (int t = lane; t < barea; t += 64) {
+            const int ty = bmny + t / bw, tx = bmnx + t % bw;
+            keys[bcur + t] = ((int64_t)(ty * tiles_x + tx) << 32) | bdepth;
+            vals[bcur + t] = bi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tile_bins_kernel(int64_t n_isect, const int64_t *__restrict__ keys,
+                                                        int32_t *__restrict__ bins) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n_isect) return;
+    const int32_t cur = (int32_t)(keys[idx] >> 32);
+    if (idx == 0) bins[2 * cur] = 0;
+    if (idx == n_isect - 1) bins[2 * cur + 1] = (int32_t)n_isect;
+    if (idx == 0) return;
+    const int32_t prev = (int32_t)(keys[idx - 1] >> 32);
+    if (prev != cur) {
+        bins[2 * prev + 1] = (int32_t)idx;
+        bins[2 * cur] = (int32_t)idx;
+    }
+}
+
+}  // namespace
+
+SGN_EXPORT size_t sgn_scan_workspace_bytes(int n) {
+    return (size_t)(sgn_cdiv(n > 0 ? n : 1, SCAN_CHUNK) + 1) * sizeof(int32_t);
+}
+
+SGN_EXPORT int sgn_scan_i32(int n, const int32_t *in, int32_t *out, void *ws, size_t ws_bytes,
+                            sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(in && out && ws, -2);
+    SGN_ARG_CHECK(ws_bytes >= sgn_scan_workspace_bytes(n), -3);
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = sgn_cdiv(n, SCAN_CHUNK);
+    int32_t *partial = (int32_t *)ws;
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, n, in, partial);
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, partial);
+    hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, n, in, partial, out);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_map_isect(int n, const float *xys, const float *depths, const int32_t *radii,
+                             const int32_t *cum_tiles_hit, int tiles_x, int tiles_y, int block_width,
+                             int64_t *isect_keys, int32_t *isect_vals, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(xys && depths && radii && cum_tiles_hit, -3);
+    hipLaunchKernelGGL(map_isect_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, xys,
+                       depths, radii, cum_tiles_hit, tiles_x, tiles_y, block_width, isect_keys, isect_vals);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_tiles, int32_t *tile_bins,
+                             sgn_stream_t stream) {
+    SGN_ARG_CHECK(n_isect >= 0 && n_tiles > 0, -1);
+    SGN_ARG_CHECK(tile_bins != nullptr, -2);
+    hipStream_t s = (hipStream_t)stream;
+    SGN_HIP_CHECK(hipMemsetAsync(tile_bins, 0, (size_t)n_tiles * 2 * sizeof(int32_t), s));
+    if (n_isect == 0) return 0;
+    SGN_ARG_CHECK(keys_sorted != nullptr, -3);
+    hipLaunchKernelGGL(tile_bins_kernel, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, keys_sorted,
+                       tile_bins);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,317 @@
+// project.hip — EWA projection of 3D Gaussians (forward + backward), gfx950.
+//
+// Replaces gsplat 0.1.x forward.cu:project_gaussians_forward_kernel and
+// backward.cu:project_gaussians_backward_kernel (third-party, un-vendored; semantics in
+// SURVEY.md A.1 / A.5), reached from the reference at sgn_splatfacto.py:860-873.
+//
+// HBM-bound streaming kernels: one lane per Gaussian, AoS rows are consecutive across lanes so
+// every global_load_dwordx{2,3,4} of a wave covers one contiguous span (fwd: 40 B in / 60 B out
+// per Gaussian; bwd: 112 B in / 76 B out).  This TU is compiled with -ffp-contract=off and every
+// expression is written in the operation order of the arithmetic contract, so
+// xys / depths / radii / num_tiles_hit — and therefore the 64-bit sort keys — are bit-identical
+// to the CPU oracle.
+#include "sgn_common.h"
+
+namespace {
+
+struct Cam {
+    const float *V;  // device pointer to the 3x4 row-major view matrix (wave-uniform -> s_load)
+    float fx, fy, cx, cy;
+    float lim_x, lim_y;
+    int tiles_x, tiles_y, block;
+    float clip, glob_scale;
+};
+
+__device__ __forceinline__ void quat_to_R(float w, float x, float y, float z, float R[3][3]) {
+    R[0][0] = 1.f - 2.f * (y * y + z * z);
+    R[0][1] = 2.f * (x * y - w * z);
+    R[0][2] = 2.f * (x * z + w * y);
+    R[1][0] = 2.f * (x * y + w * z);
+    R[1][1] = 1.f - 2.f * (x * x + z * z);
+    R[1][2] = 2.f * (y * z - w * x);
+    R[2][0] = 2.f * (x * z - w * y);
+    R[2][1] = 2.f * (y * z + w * x);
+    R[2][2] = 1.f - 2.f * (x * x + y * y);
+}
+
+__global__ __launch_bounds__(256) void project_fwd_kernel(
+    int n, const float *__restrict__ means, const float *__restrict__ scales,
+    const float *__restrict__ quats, Cam cam, float *__restrict__ cov3d, float *__restrict__ xys,
+    float *__restrict__ depths, int32_t *__restrict__ radii, float *__restrict__ conics,
+    float *__restrict__ comp, int32_t *__restrict__ num_tiles_hit) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float V[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) V[k] = cam.V[k];
+    const float p0 = means[3 * i], p1 = means[3 * i + 1], p2 = means[3 * i + 2];
+    const float pvx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
+    const float pvy = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
+    const float pvz = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
+
+    float o_cov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float o_con[3] = {0.f, 0.f, 0.f};
+    float o_x = 0.f, o_y = 0.f, o_d = 0.f, o_comp = 0.f;
+    int o_r = 0, o_n = 0;
+
+    if (pvz > cam.clip) {
+        float R[3][3], M[3][3], S[3][3];
+        quat_to_R(quats[4 * i], quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], R);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float s = cam.glob_scale * scales[3 * i + c];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) M[r][c] = R[r][c] * s;
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                S[a][b] = M[a][0] * M[b][0] + M[a][1] * M[b][1] + M[a][2] * M[b][2];
+        o_cov[0] = S[0][0]; o_cov[1] = S[0][1]; o_cov[2] = S[0][2];
+        o_cov[3] = S[1][1]; o_cov[4] = S[1][2]; o_cov[5] = S[2][2];
+
+        const float tz = pvz;
+        const float tx = tz * fminf(cam.lim_x, fmaxf(-cam.lim_x, pvx / tz));
+        const float ty = tz * fminf(cam.lim_y, fmaxf(-cam.lim_y, pvy / tz));
+        const float rz = 1.f / tz, rz2 = rz * rz;
+        const float J00 = cam.fx * rz, J02 = -cam.fx * tx * rz2;
+        const float J11 = cam.fy * rz, J12 = -cam.fy * ty * rz2;
+        float T[2][3], U[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T[0][j] = J00 * V[j] + J02 * V[8 + j];
+            T[1][j] = J11 * V[4 + j] + J12 * V[8 + j];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                U[a][j] = T[a][0] * S[0][j] + T[a][1] * S[1][j] + T[a][2] * S[2][j];
+        const float c00 = U[0][0] * T[0][0] + U[0][1] * T[0][1] + U[0][2] * T[0][2];
+        const float c01 = U[0][0] * T[1][0] + U[0][1] * T[1][1] + U[0][2] * T[1][2];
+        const float c11 = U[1][0] * T[1][0] + U[1][1] * T[1][1] + U[1][2] * T[1][2];
+        const float det0 = c00 * c11 - c01 * c01;
+        const float a = c00 + 0.3f, b = c01, c = c11 + 0.3f;
+        const float det = a * c - b * b;
+        const float compensation = sqrtf(fmaxf(0.f, det0 / det));
+        if (det != 0.f) {
+            const float inv_det = 1.f / det;
+            o_con[0] = c * inv_det; o_con[1] = -b * inv_det; o_con[2] = a * inv_det;
+            const float mid = 0.5f * (a + c);
+            const float sq = sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float v1 = mid + sq, v2 = mid - sq;
+            const float radius = ceilf(3.f * sqrtf(fmaxf(v1, v2)));
+            const float rw = 1.f / (pvz + 1e-6f);
+            const float ux = pvx * rw * cam.fx + cam.cx, uy = pvy * rw * cam.fy + cam.cy;
+            int mnx, mny, mxx, mxy;
+            sgn_tile_bbox(ux, uy, radius, cam.tiles_x, cam.tiles_y, cam.block, mnx, mny, mxx, mxy);
+            const int area = (mxx - mnx) * (mxy - mny);
+            if (area > 0) {
+                o_n = area; o_d = pvz; o_r = sgn_f2i(radius); o_x = ux; o_y = uy;
+                o_comp = compensation;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3d[6 * i + k] = o_cov[k];
+    xys[2 * i] = o_x; xys[2 * i + 1] = o_y;
+    depths[i] = o_d;
+    radii[i] = o_r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) conics[3 * i + k] = o_con[k];
+    comp[i] = o_comp;
+    num_tiles_hit[i] = o_n;
+}
+
+__global__ __launch_bounds__(256) void project_bwd_kernel(
+    int n, const float *__restrict__ means, const float *__restrict__ scales,
+    const float *__restrict__ quats, Cam cam, const float *__restrict__ cov3d,
+    const int32_t *__restrict__ radii, const float *__restrict__ conics,
+    const float *__restrict__ comp, const float *__restrict__ v_xy,
+    const float *__restrict__ v_depth, const float *__restrict__ v_conic,
+    const float *__restrict__ v_comp, float *__restrict__ v_cov2d, float *__restrict__ v_cov3d,
+    float *__restrict__ v_mean, float *__restrict__ v_scale, float *__restrict__ v_quat) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float o_vm[3] = {0.f, 0.f, 0.f}, o_vs[3] = {0.f, 0.f, 0.f}, o_vq[4] = {0.f, 0.f, 0.f, 0.f};
+    float o_vc2[3] = {0.f, 0.f, 0.f}, o_vc3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (radii[i] > 0) {
+        float V[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) V[k] = cam.V[k];
+        const float fx = cam.fx, fy = cam.fy;
+        const float p0 = means[3 * i], p1 = means[3 * i + 1], p2 = means[3 * i + 2];
+        const float pvx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
+        const float pvy = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
+        const float pvz = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
+        const float rw = 1.f / (pvz + 1e-6f);
+        const float vpx = fx * v_xy[2 * i], vpy = fy * v_xy[2 * i + 1];
+        const float vv0 = vpx * rw, vv1 = vpy * rw, vv2 = -(vpx * pvx + vpy * pvy) * rw * rw;
+        float vm[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vm[j] = V[j] * vv0 + V[4 + j] * vv1 + V[8 + j] * vv2;
+        const float vz = v_depth[i];
+        vm[0] += V[8] * vz; vm[1] += V[9] * vz; vm[2] += V[10] * vz;
+
+        const float X00 = conics[3 * i], X01 = conics[3 * i + 1], X11 = conics[3 * i + 2];
+        const float g0 = v_conic[3 * i], g1 = v_conic[3 * i + 1], g2 = v_conic[3 * i + 2];
+        const float A00 = X00 * g0 + X01 * g1, A01 = X00 * g1 + X01 * g2;
+        const float A10 = X01 * g0 + X11 * g1, A11 = X01 * g1 + X11 * g2;
+        const float S00 = -(A00 * X00 + A01 * X01), S01 = -(A00 * X01 + A01 * X11);
+        const float S10 = -(A10 * X00 + A11 * X01), S11 = -(A10 * X01 + A11 * X11);
+        float vc2[3] = {S00, S01 + S10, S11};
+        if (v_comp != nullptr) {
+            const float cmp = comp[i];
+            const float inv_det = X00 * X11 - X01 * X01;
+            const float om = 1.f - cmp * cmp;
+            const float vsq = v_comp[i] * 0.5f / (cmp + 1e-6f);
+            vc2[0] += vsq * (om * X00 - 0.3f * inv_det);
+            vc2[1] += 2.f * vsq * (om * X01);
+            vc2[2] += vsq * (om * X11 - 0.3f * inv_det);
+        }
+        o_vc2[0] = vc2[0]; o_vc2[1] = vc2[1]; o_vc2[2] = vc2[2];
+
+        const float rz = 1.f / pvz, rz2 = rz * rz, rz3 = rz2 * rz;
+        const float J00 = fx * rz, J02 = -fx * pvx * rz2, J11 = fy * rz, J12 = -fy * pvy * rz2;
+        float T[2][3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T[0][j] = J00 * V[j] + J02 * V[8 + j];
+            T[1][j] = J11 * V[4 + j] + J12 * V[8 + j];
+        }
+        const float c0 = cov3d[6 * i], c1 = cov3d[6 * i + 1], c2 = cov3d[6 * i + 2];
+        const float c3 = cov3d[6 * i + 3], c4 = cov3d[6 * i + 4], c5 = cov3d[6 * i + 5];
+        const float S[3][3] = {{c0, c1, c2}, {c1, c3, c4}, {c2, c4, c5}};
+        const float G[2][2] = {{vc2[0], 0.5f * vc2[1]}, {0.5f * vc2[1], vc2[2]}};
+        float GT[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) GT[a][j] = G[a][0] * T[0][j] + G[a][1] * T[1][j];
+        float vS[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) vS[a][b] = T[0][a] * GT[0][b] + T[1][a] * GT[1][b];
+        o_vc3[0] = vS[0][0]; o_vc3[1] = vS[0][1] + vS[1][0]; o_vc3[2] = vS[0][2] + vS[2][0];
+        o_vc3[3] = vS[1][1]; o_vc3[4] = vS[1][2] + vS[2][1]; o_vc3[5] = vS[2][2];
+        float vT[2][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                vT[a][j] = 2.f * (GT[a][0] * S[0][j] + GT[a][1] * S[1][j] + GT[a][2] * S[2][j]);
+        const float vJ00 = vT[0][0] * V[0] + vT[0][1] * V[1] + vT[0][2] * V[2];
+        const float vJ02 = vT[0][0] * V[8] + vT[0][1] * V[9] + vT[0][2] * V[10];
+        const float vJ11 = vT[1][0] * V[4] + vT[1][1] * V[5] + vT[1][2] * V[6];
+        const float vJ12 = vT[1][0] * V[8] + vT[1][1] * V[9] + vT[1][2] * V[10];
+        const float vt0 = -fx * rz2 * vJ02, vt1 = -fy * rz2 * vJ12;
+        const float vt2 = -fx * rz2 * vJ00 + 2.f * fx * pvx * rz3 * vJ02 - fy * rz2 * vJ11 +
+                          2.f * fy * pvy * rz3 * vJ12;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) vm[j] += V[j] * vt0 + V[4 + j] * vt1 + V[8 + j] * vt2;
+        o_vm[0] = vm[0]; o_vm[1] = vm[1]; o_vm[2] = vm[2];
+
+        const float vV[3][3] = {{o_vc3[0], 0.5f * o_vc3[1], 0.5f * o_vc3[2]},
+                                {0.5f * o_vc3[1], o_vc3[3], 0.5f * o_vc3[4]},
+                                {0.5f * o_vc3[2], 0.5f * o_vc3[4], o_vc3[5]}};
+        const float w = quats[4 * i], x = quats[4 * i + 1], y = quats[4 * i + 2], z = quats[4 * i + 3];
+        float R[3][3], M[3][3], sc[3];
+        quat_to_R(w, x, y, z, R);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            sc[c] = cam.glob_scale * scales[3 * i + c];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) M[r][c] = R[r][c] * sc[c];
+        }
+        float vM[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                vM[a][c] = 2.f * (vV[a][0] * M[0][c] + vV[a][1] * M[1][c] + vV[a][2] * M[2][c]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            o_vs[c] = (R[0][c] * vM[0][c] + R[1][c] * vM[1][c] + R[2][c] * vM[2][c]) * cam.glob_scale;
+        float vR[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vR[a][c] = vM[a][c] * sc[c];
+        o_vq[0] = 2.f * (x * (vR[2][1] - vR[1][2]) + y * (vR[0][2] - vR[2][0]) + z * (vR[1][0] - vR[0][1]));
+        o_vq[1] = 2.f * (-2.f * x * (vR[1][1] + vR[2][2]) + y * (vR[1][0] + vR[0][1]) +
+                         z * (vR[2][0] + vR[0][2]) + w * (vR[2][1] - vR[1][2]));
+        o_vq[2] = 2.f * (x * (vR[1][0] + vR[0][1]) - 2.f * y * (vR[0][0] + vR[2][2]) +
+                         z * (vR[2][1] + vR[1][2]) + w * (vR[0][2] - vR[2][0]));
+        o_vq[3] = 2.f * (x * (vR[2][0] + vR[0][2]) + y * (vR[2][1] + vR[1][2]) -
+                         2.f * z * (vR[0][0] + vR[1][1]) + w * (vR[1][0] - vR[0][1]));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v_mean[3 * i + k] = o_vm[k]; v_scale[3 * i + k] = o_vs[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v_quat[4 * i + k] = o_vq[k];
+    if (v_cov2d != nullptr)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v_cov2d[3 * i + k] = o_vc2[k];
+    if (v_cov3d != nullptr)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) v_cov3d[6 * i + k] = o_vc3[k];
+}
+
+Cam make_cam(const float *V, float fx, float fy, float cx, float cy, int h, int w, int block,
+             float clip, float glob_scale) {
+    Cam c;
+    c.V = V;
+    c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy;
+    const float tan_fovx = 0.5f * (float)w / fx, tan_fovy = 0.5f * (float)h / fy;
+    c.lim_x = 1.3f * tan_fovx; c.lim_y = 1.3f * tan_fovy;
+    c.block = block;
+    c.tiles_x = (w + block - 1) / block; c.tiles_y = (h + block - 1) / block;
+    c.clip = clip; c.glob_scale = glob_scale;
+    return c;
+}
+
+}  // namespace
+
+// viewmat12 is a DEVICE pointer (the reference hands a device tensor, viewmat.squeeze()[:3,:],
+// sgn_splatfacto.py:865): the kernels read it through wave-uniform scalar loads, so no host sync.
+SGN_EXPORT int sgn_project_fwd(int n, const float *means3d, const float *scales, float glob_scale,
+                               const float *quats, const float *viewmat12, float fx, float fy,
+                               float cx, float cy, int img_h, int img_w, int block_width,
+                               float clip_thresh, float *cov3d, float *xys, float *depths,
+                               int32_t *radii, float *conics, float *compensation,
+                               int32_t *num_tiles_hit, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
+    SGN_ARG_CHECK(img_h > 0 && img_w > 0, -3);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(means3d && scales && quats && viewmat12 && cov3d && xys && depths && radii &&
+                      conics && compensation && num_tiles_hit, -4);
+    const Cam cam = make_cam(viewmat12, fx, fy, cx, cy, img_h, img_w, block_width, clip_thresh, glob_scale);
+    hipLaunchKernelGGL(project_fwd_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       means3d, scales, quats, cam, cov3d, xys, depths, radii, conics, compensation,
+                       num_tiles_hit);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_project_bwd(int n, const float *means3d, const float *scales, float glob_scale,
+                               const float *quats, const float *viewmat12, float fx, float fy,
+                               const float *cov3d, const int32_t *radii, const float *conics,
+                               const float *compensation, const float *v_xy, const float *v_depth,
+                               const float *v_conic, const float *v_compensation, float *v_cov2d,
+                               float *v_cov3d, float *v_mean3d, float *v_scale, float *v_quat,
+                               sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(means3d && scales && quats && viewmat12 && cov3d && radii && conics && v_xy &&
+                      v_depth && v_conic && v_mean3d && v_scale && v_quat, -4);
+    SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
+    const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
+    hipLaunchKernelGGL(project_bwd_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       means3d, scales, quats, cam, cov3d, radii, conics, compensation, v_xy, v_depth,
+                       v_conic, v_compensation, v_cov2d, v_cov3d, v_mean3d, v_scale, v_quat);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,225 @@
+// radix_sort.hip — on-device stable LSD radix sort of (int64 key, int32 value) pairs, gfx950.
+//
+// Replaces `torch.sort(isect_ids)` + `torch.gather(gaussian_ids)` (CUB radix sort) inside
+// gsplat/utils.py:bin_and_sort_gaussians, reached from the reference through
+// rasterize_gaussians (sgn_splatfacto.py:954-967, :982-994).  Stable => equal (tile, depth) keys
+// keep emission order exactly like upstream, so gaussian_ids_sorted is bit-exact.
+//
+// Shape: 8-bit digits, three kernels per pass —
+//   rs_hist    per-tile (4096 keys) digit histogram in LDS            -> table[digit][tile]
+//   rs_scan    one workgroup per digit: exclusive scan of its row     -> table (in place), total[digit]
+//   rs_scatter per tile: wave64 ballot "match" ranking (8 ballots/key, stable inside a wave),
+//              per-wave LDS counters, cross-wave prefix, then the tile is reordered in LDS so the
+//              global stores of one digit are consecutive lanes -> consecutive addresses.
+// HBM traffic per key per pass: 8 (hist) + 12 (read) + 12 (write) = 32 B; the caller restricts the
+// sort to the significant bits (32 depth bits + ceil(log2(n_tiles)) tile bits: 6 passes at
+// 1920x1280/16 instead of 8).
+#include "sgn_common.h"
+
+namespace {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = 4;
+constexpr int RS_IPT = 16;                     // keys per thread
+constexpr int RS_TILE = RS_THREADS * RS_IPT;   // 4096 keys per workgroup
+constexpr int RS_WAVE_ITEMS = 64 * RS_IPT;     // 1024 keys per wave
+
+__device__ __forceinline__ unsigned digit_of(uint64_t key, int shift, unsigned mask) {
+    return (unsigned)(key >> shift) & mask;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(uint32_t n, const uint64_t *__restrict__ keys,
+                                                             int shift, unsigned dmask, uint32_t nblk,
+                                                             uint32_t *__restrict__ table) {
+    __shared__ uint32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int k = 0; k < RS_IPT; ++k) {
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&hist[digit_of(keys[i], shift, dmask)], 1u);
+    }
+    __syncthreads();
+    table[threadIdx.x * nblk + blockIdx.x] = hist[threadIdx.x];
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t u = __shfl_up(v, d, 64);
+        if (lane >= d) v += u;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over a 256-thread block
+__device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *lds4, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t w = wave_incl_scan_u32(v);
+    if (lane == 63) lds4[wave] = w;
+    __syncthreads();
+    uint32_t off = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t t = lds4[k];
+        if (k < wave) off += t;
+    }
+    total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+    __syncthreads();
+    return w + off - v;
+}
+
+// grid = 256 (one workgroup per digit): table[d][0..nblk) -> exclusive prefix, total[d] = row sum
+__global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t nblk, uint32_t *__restrict__ table,
+                                                             uint32_t *__restrict__ totals) {
+    __shared__ uint32_t lds4[4];
+    uint32_t *row = table + (size_t)blockIdx.x * nblk;
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += RS_THREADS) {
+        const uint32_t i = b0 + threadIdx.x;
+        const uint32_t v = (i < nblk) ? row[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan_u32(v, lds4, total);
+        if (i < nblk) row[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
+    uint32_t n, const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
+    uint64_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int shift, unsigned dmask,
+    uint32_t nblk, const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals) {
+    __shared__ uint64_t skeys[RS_TILE];
+    __shared__ int32_t svals[RS_TILE];
+    __shared__ uint32_t wcnt[RS_WAVES][256];
+    __shared__ uint32_t dstart[256];
+    __shared__ uint32_t gbase[256];
+    __shared__ uint32_t lds4[4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t tile_base = blockIdx.x * RS_TILE;
+    const uint32_t tile_cnt = min((uint32_t)RS_TILE, n - tile_base);
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) wcnt[w][tid] = 0;
+    __syncthreads();
+
+    uint64_t key[RS_IPT];
+    int32_t val[RS_IPT];
+    uint32_t rank[RS_IPT];
+    volatile uint32_t *mycnt = wcnt[wave];
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) {
+        const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;  // index inside the tile
+        const bool valid = li < tile_cnt;
+        key[r] = valid ? keys_in[tile_base + li] : ~0ull;
+        val[r] = valid ? vals_in[tile_base + li] : 0;
+        const unsigned d = digit_of(key[r], shift, dmask);
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long vote = __ballot(valid && bit);
+            m &= bit ? vote : ~vote;
+        }
+        // lanes of one match group (same digit) read the wave's running counter, the first lane of
+        // the group bumps it.  LDS ops of one wave retire in order, `volatile` keeps program order.
+        uint32_t prev = 0;
+        if (valid) {
+            prev = mycnt[d];
+            if ((m & lt_mask) == 0ull) mycnt[d] = prev + (uint32_t)__popcll(m);
+        }
+        rank[r] = prev + (uint32_t)__popcll(m & lt_mask);
+    }
+    __syncthreads();
+
+    // thread t owns digit t: turn per-wave counts into exclusive per-wave offsets + digit total
+    uint32_t tot = 0;
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w) {
+        const uint32_t c = wcnt[w][tid];
+        wcnt[w][tid] = tot;
+        tot += c;
+    }
+    uint32_t dummy;
+    const uint32_t dst = block_excl_scan_u32(tot, lds4, dummy);        // start of digit t inside the tile
+    const uint32_t gst = block_excl_scan_u32(totals[tid], lds4, dummy);  // global start of digit t
+    dstart[tid] = dst;
+    gbase[tid] = gst + table[(size_t)tid * nblk + blockIdx.x] - dst;   // global pos = gbase[d] + local pos
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) {
+        const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;
+        if (li < tile_cnt) {
+            const unsigned d = digit_of(key[r], shift, dmask);
+            const uint32_t lp = dstart[d] + wcnt[wave][d] + rank[r];
+            skeys[lp] = key[r];
+            svals[lp] = val[r];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RS_IPT; ++k) {
+        const uint32_t lp = k * RS_THREADS + tid;
+        if (lp < tile_cnt) {
+            const uint64_t kk = skeys[lp];
+            const uint32_t pos = gbase[digit_of(kk, shift, dmask)] + lp;
+            keys_out[pos] = kk;
+            vals_out[pos] = svals[lp];
+        }
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+SGN_EXPORT size_t sgn_sort_workspace_bytes(int64_t n_isect) {
+    if (n_isect <= 0) return 256;
+    const size_t nblk = (size_t)sgn_cdiv(n_isect, RS_TILE);
+    return align256((size_t)n_isect * 8) + align256((size_t)n_isect * 4) + align256(256 * nblk * 4) +
+           align256(256 * 4);
+}
+
+SGN_EXPORT int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const int64_t *keys_in,
+                              const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out, void *ws,
+                              size_t ws_bytes, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
+    SGN_ARG_CHECK(begin_bit >= 0 && end_bit <= 64 && begin_bit < end_bit, -2);
+    if (n_isect == 0) return 0;
+    SGN_ARG_CHECK(keys_in && vals_in && keys_out && vals_out && ws, -3);
+    SGN_ARG_CHECK(ws_bytes >= sgn_sort_workspace_bytes(n_isect), -4);
+    SGN_ARG_CHECK((const void *)keys_in != (const void *)keys_out && vals_in != vals_out, -5);
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t n = (uint32_t)n_isect;
+    const uint32_t nblk = (uint32_t)sgn_cdiv(n_isect, RS_TILE);
+    char *p = (char *)ws;
+    uint64_t *alt_keys = (uint64_t *)p; p += align256((size_t)n * 8);
+    int32_t *alt_vals = (int32_t *)p;   p += align256((size_t)n * 4);
+    uint32_t *table = (uint32_t *)p;    p += align256((size_t)256 * nblk * 4);
+    uint32_t *totals = (uint32_t *)p;
+
+    const int npass = (end_bit - begin_bit + 7) / 8;
+    const uint64_t *src_k = (const uint64_t *)keys_in;
+    const int32_t *src_v = vals_in;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = begin_bit + 8 * pass;
+        const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+        const unsigned dmask = (1u << bits) - 1u;
+        const bool to_out = ((npass - 1 - pass) % 2) == 0;  // last pass lands in keys_out / vals_out
+        uint64_t *dst_k = to_out ? (uint64_t *)keys_out : alt_keys;
+        int32_t *dst_v = to_out ? vals_out : alt_vals;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, shift, dmask, nblk, table);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(RS_THREADS), 0, s, nblk, table, totals);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, src_v, dst_k, dst_v,
+                           shift, dmask, nblk, table, totals);
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

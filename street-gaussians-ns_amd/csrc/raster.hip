@@ -1,0 +1,398 @@
+// raster.hip — per-tile front-to-back alpha compositing (forward) and the reverse per-pixel walk
+// with per-Gaussian gradient reduction (backward), gfx950.
+//
+// Replaces gsplat 0.1.x forward.cu:rasterize_forward and backward.cu:rasterize_backward_kernel
+// (3-channel path), reached from the reference at
+// sgn_splatfacto.py:954-967 (rgb+alpha) and :982-994 (depth).
+//
+// CDNA4 design (not the upstream 256-thread-tile / shared-memory-batch shape):
+//   * ONE wave64 owns ONE 16x16 tile.  Each lane carries 4 pixels (one per 8x8 quadrant), so a
+//     workgroup is a single wave: no LDS staging, no __syncthreads, no cross-wave early-exit vote.
+//   * The tile's depth-ordered Gaussians are first gathered into a contiguous stream of 48-byte
+//     records (pack kernel).  The per-Gaussian operands of the hot loop are wave-uniform, so the
+//     compiler fetches each record with s_load_dwordx4 through the scalar cache into SGPRs and the
+//     VALU instructions take them as scalar operands: zero LDS traffic, zero VGPRs, and the next
+//     record is in flight while the current one is evaluated (software prefetch).
+//   * Per-quadrant wave-uniform skips (`__ballot`) give the early termination and the
+//     "nobody in this 8x8 block is touched" shortcut for free in the scalar branch unit.
+//   * Backward: the 4 pixels of a lane are accumulated in registers, so ONE wave reduction per
+//     (tile, Gaussian) replaces upstream's 8 warp reductions; lanes 0..8 then issue a single
+//     9-lane global_atomic_add_f32 into a packed 48-byte per-Gaussian gradient row (one cache
+//     line), unpacked into v_xy / v_conic / v_colors / v_opacity afterwards.
+//
+// Arithmetic contract of the hot loop (shared with oracle/c/sgn_oracle.c; this TU is built with
+// -ffp-contract=off and spells every fma):
+//   sigma = fma(b*dx, dy, fma(hc*dy, dy, (ha*dx)*dx))   with ha = a/2, hc = c/2  (exact scaling)
+//   alpha = min(0.999, opac * exp(-sigma));  skip if sigma < 0 or alpha < 1/255
+//   nT = T*(1-alpha); stop (not composited) if nT <= 1e-4;  C = fma(color, alpha*T, C)
+#include "sgn_common.h"
+
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+
+namespace {
+
+struct __attribute__((aligned(16))) Rec {
+    float x, y, opac, ha;   // ha = 0.5 * conic.x
+    float b, hc, r, g;      // b = conic.y, hc = 0.5 * conic.z
+    float bl;               // blue
+    int gid;                // Gaussian id (backward scatter target)
+    float pad0, pad1;
+};
+static_assert(sizeof(Rec) == SGN_RECORD_FLOATS * sizeof(float), "record size");
+
+__device__ __forceinline__ float exp_portable(float x) {
+    // same recipe as oracle/c/sgn_oracle.c exp_portable (written independently; bit-identical)
+    float t = x * 1.44269504088896341f;
+    t = fminf(fmaxf(t, -125.0f), 126.0f);
+    const float n = __builtin_rintf(t);
+    const float f = t - n;
+    float p = 1.53533063e-4f;
+    p = fmaf(p, f, 1.33988744e-3f);
+    p = fmaf(p, f, 9.61843736e-3f);
+    p = fmaf(p, f, 5.55035681e-2f);
+    p = fmaf(p, f, 2.40226488e-1f);
+    p = fmaf(p, f, 6.93147182e-1f);
+    p = fmaf(p, f, 1.0f);
+    return ldexpf(p, (int)n);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ float sgn_exp(float x) {
+    if constexpr (EXACT) return exp_portable(x);
+    else return __expf(x);
+}
+
+// thread per intersection: gather the per-Gaussian operands into the depth-ordered record stream
+__global__ __launch_bounds__(256) void pack_records_kernel(int64_t n_isect, const int32_t *__restrict__ ids,
+                                                           const float *__restrict__ xys,
+                                                           const float *__restrict__ conics,
+                                                           const float *__restrict__ colors,
+                                                           const float *__restrict__ opac,
+                                                           float4 *__restrict__ recs) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n_isect) return;
+    const int g = ids[p];
+    const float x = xys[2 * g], y = xys[2 * g + 1];
+    const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
+    const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
+    const float o = opac[g];
+    recs[3 * p + 0] = make_float4(x, y, o, 0.5f * a);
+    recs[3 * p + 1] = make_float4(b, 0.5f * c, r, gg);
+    recs[3 * p + 2] = make_float4(bl, __int_as_float(g), 0.f, 0.f);
+}
+
+// pixel of (slot q, lane) inside tile (tx,ty).  block 16: four 8x8 quadrants; otherwise linear.
+__device__ __forceinline__ void slot_pixel(int q, int lane, int B, int &ox, int &oy, bool &in_tile) {
+    if (B == 16) {
+        ox = (q & 1) * 8 + (lane & 7);
+        oy = (q >> 1) * 8 + (lane >> 3);
+        in_tile = true;
+    } else {
+        const int p = q * 64 + lane;
+        ox = p % B;
+        oy = p / B;
+        in_tile = p < B * B;
+    }
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int tiles_x,
+                                                        const int2 *__restrict__ bins,
+                                                        const Rec *__restrict__ recs,
+                                                        const float *__restrict__ bg, float *__restrict__ out_img,
+                                                        float *__restrict__ final_T,
+                                                        int32_t *__restrict__ final_idx) {
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int2 range = bins[tile];
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];  // wave-uniform -> scalar loads
+
+    float px[4], py[4], T[4], C0[4], C1[4], C2[4];
+    int last[4], pix[4];
+    bool inside[4], done[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int ox, oy;
+        bool in_tile;
+        slot_pixel(q, lane, B, ox, oy, in_tile);
+        const int j = tx * B + ox, i = ty * B + oy;
+        inside[q] = in_tile && j < W && i < H;
+        pix[q] = i * W + j;
+        px[q] = (float)j + 0.5f;
+        py[q] = (float)i + 0.5f;
+        T[q] = 1.f; C0[q] = 0.f; C1[q] = 0.f; C2[q] = 0.f;
+        last[q] = 0;
+        done[q] = !inside[q];
+    }
+
+    if (range.x < range.y) {
+        Rec cur = recs[range.x];
+        for (int k = range.x; k < range.y; ++k) {
+            const unsigned long long live0 = __ballot(!done[0]), live1 = __ballot(!done[1]);
+            const unsigned long long live2 = __ballot(!done[2]), live3 = __ballot(!done[3]);
+            if ((live0 | live1 | live2 | live3) == 0ull) break;
+            const int kn = (k + 1 < range.y) ? k + 1 : k;
+            const Rec nxt = recs[kn];  // scalar prefetch of the next record
+            const unsigned long long live[4] = {live0, live1, live2, live3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (live[q] == 0ull) continue;  // wave-uniform
+                const float dx = cur.x - px[q], dy = cur.y - py[q];
+                float s = (cur.ha * dx) * dx;
+                s = fmaf(cur.hc * dy, dy, s);
+                const float sigma = fmaf(cur.b * dx, dy, s);
+                const float alpha = fminf(0.999f, cur.opac * sgn_exp<EXACT>(-sigma));
+                const bool valid = !done[q] && sigma >= 0.f && alpha >= (1.f / 255.f);
+                // branch-free update: lanes that skip or stop add vis = 0 (fma(c, 0, C) == C exactly)
+                const float nT = T[q] * (1.f - alpha);
+                const bool stop = valid && nT <= 1e-4f;
+                const bool acc = valid && !stop;
+                done[q] = done[q] || stop;
+                const float vis = acc ? alpha * T[q] : 0.f;
+                C0[q] = fmaf(cur.r, vis, C0[q]);
+                C1[q] = fmaf(cur.g, vis, C1[q]);
+                C2[q] = fmaf(cur.bl, vis, C2[q]);
+                T[q] = acc ? nT : T[q];
+                last[q] = acc ? k : last[q];
+            }
+            cur = nxt;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (inside[q]) {
+            final_T[pix[q]] = T[q];
+            final_idx[pix[q]] = last[q];
+            out_img[3 * pix[q] + 0] = fmaf(T[q], bg0, C0[q]);
+            out_img[3 * pix[q] + 1] = fmaf(T[q], bg1, C1[q]);
+            out_img[3 * pix[q] + 2] = fmaf(T[q], bg2, C2[q]);
+        }
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// grad_ws row layout (12 floats / Gaussian): 0,1 v_xy | 2,3,4 v_conic | 5,6,7 v_rgb | 8 v_opacity
+template <bool EXACT>
+__global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int tiles_x,
+                                                        const int2 *__restrict__ bins,
+                                                        const Rec *__restrict__ recs,
+                                                        const float *__restrict__ bg,
+                                                        const float *__restrict__ final_T,
+                                                        const int32_t *__restrict__ final_idx,
+                                                        const float *__restrict__ v_out,
+                                                        const float *__restrict__ v_out_alpha,
+                                                        float alpha_clamp, float *__restrict__ grad_ws) {
+    const int tile = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int2 range = bins[tile];
+    if (range.x >= range.y) return;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+
+    float px[4], py[4], T[4], Tf[4], b0[4], b1[4], b2[4], vo0[4], vo1[4], vo2[4], voa[4];
+    int kfin[4];
+    int kmax_l = -1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int ox, oy;
+        bool in_tile;
+        slot_pixel(q, lane, B, ox, oy, in_tile);
+        const int j = tx * B + ox, i = ty * B + oy;
+        const bool inside = in_tile && j < W && i < H;
+        const int pix = inside ? i * W + j : 0;
+        px[q] = (float)j + 0.5f;
+        py[q] = (float)i + 0.5f;
+        Tf[q] = inside ? final_T[pix] : 1.f;
+        T[q] = Tf[q];
+        kfin[q] = inside ? final_idx[pix] : -1;  // -1: this slot never participates
+        vo0[q] = inside ? v_out[3 * pix] : 0.f;
+        vo1[q] = inside ? v_out[3 * pix + 1] : 0.f;
+        vo2[q] = inside ? v_out[3 * pix + 2] : 0.f;
+        voa[q] = inside ? v_out_alpha[pix] : 0.f;
+        b0[q] = 0.f; b1[q] = 0.f; b2[q] = 0.f;
+        kmax_l = max(kmax_l, kfin[q]);
+    }
+    int kmax = __builtin_amdgcn_readfirstlane(wave_max_i(kmax_l));
+    kmax = min(kmax, range.y - 1);
+    if (kmax < range.x) return;
+
+    Rec cur = recs[kmax];
+    for (int k = kmax; k >= range.x; --k) {
+        const int kn = (k - 1 >= range.x) ? k - 1 : k;
+        const Rec nxt = recs[kn];
+        float g_x = 0.f, g_y = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f;
+        float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_o = 0.f;
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (__ballot(k <= kfin[q]) == 0ull) continue;  // wave-uniform
+            const float dx = cur.x - px[q], dy = cur.y - py[q];
+            float s = (cur.ha * dx) * dx;
+            s = fmaf(cur.hc * dy, dy, s);
+            const float sigma = fmaf(cur.b * dx, dy, s);
+            const float vis = sgn_exp<EXACT>(-sigma);
+            const float alpha = fminf(alpha_clamp, cur.opac * vis);
+            const bool valid = (k <= kfin[q]) && sigma >= 0.f && alpha >= (1.f / 255.f);
+            // branch-free: everything is evaluated, invalid lanes are masked out by the selects
+            const float ra = 1.f / (1.f - alpha);
+            const float Tn = T[q] * ra;
+            const float fac = alpha * Tn;
+            float v_alpha = (cur.r * Tn - b0[q] * ra) * vo0[q];
+            v_alpha += (cur.g * Tn - b1[q] * ra) * vo1[q];
+            v_alpha += (cur.bl * Tn - b2[q] * ra) * vo2[q];
+            const float tfra = Tf[q] * ra;
+            v_alpha += tfra * voa[q];
+            v_alpha += -tfra * bg0 * vo0[q];
+            v_alpha += -tfra * bg1 * vo1[q];
+            v_alpha += -tfra * bg2 * vo2[q];
+            const float facm = valid ? fac : 0.f;
+            b0[q] = fmaf(cur.r, facm, b0[q]);   // oracle: b0 += r*fac (separate rounding); fma here, covered by the gradient tolerance
+            b1[q] = fmaf(cur.g, facm, b1[q]);
+            b2[q] = fmaf(cur.bl, facm, b2[q]);
+            T[q] = valid ? Tn : T[q];
+            const float v_sigma = valid ? -cur.opac * vis * v_alpha : 0.f;
+            // a*dx = 2*(ha*dx), c*dy = 2*(hc*dy): exact power-of-two scaling
+            g_x += v_sigma * (2.f * (cur.ha * dx) + cur.b * dy);
+            g_y += v_sigma * (cur.b * dx + 2.f * (cur.hc * dy));
+            const float hs = 0.5f * v_sigma;
+            g_ca += hs * dx * dx;
+            g_cb += hs * dx * dy;
+            g_cc += hs * dy * dy;
+            g_r += facm * vo0[q];
+            g_g += facm * vo1[q];
+            g_b += facm * vo2[q];
+            g_o += valid ? vis * v_alpha : 0.f;
+            any = any || valid;
+        }
+        if (__ballot(any) != 0ull) {  // wave-uniform
+            g_x = wave_sum(g_x); g_y = wave_sum(g_y);
+            g_ca = wave_sum(g_ca); g_cb = wave_sum(g_cb); g_cc = wave_sum(g_cc);
+            g_r = wave_sum(g_r); g_g = wave_sum(g_g); g_b = wave_sum(g_b);
+            g_o = wave_sum(g_o);
+            float mine = g_x;
+            mine = (lane == 1) ? g_y : mine;
+            mine = (lane == 2) ? g_ca : mine;
+            mine = (lane == 3) ? g_cb : mine;
+            mine = (lane == 4) ? g_cc : mine;
+            mine = (lane == 5) ? g_r : mine;
+            mine = (lane == 6) ? g_g : mine;
+            mine = (lane == 7) ? g_b : mine;
+            mine = (lane == 8) ? g_o : mine;
+            if (lane < 9) unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + lane, mine);
+        }
+        cur = nxt;
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *__restrict__ ws,
+                                                           float *__restrict__ v_xy, float *__restrict__ v_conic,
+                                                           float *__restrict__ v_colors,
+                                                           float *__restrict__ v_opac) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 a = reinterpret_cast<const float4 *>(ws)[3 * i + 0];
+    const float4 b = reinterpret_cast<const float4 *>(ws)[3 * i + 1];
+    const float4 c = reinterpret_cast<const float4 *>(ws)[3 * i + 2];
+    v_xy[2 * i] = a.x; v_xy[2 * i + 1] = a.y;
+    v_conic[3 * i] = a.z; v_conic[3 * i + 1] = a.w; v_conic[3 * i + 2] = b.x;
+    v_colors[3 * i] = b.y; v_colors[3 * i + 1] = b.z; v_colors[3 * i + 2] = b.w;
+    v_opac[i] = c.x;
+}
+
+int g_exact_exp = 0;
+
+}  // namespace
+
+SGN_EXPORT void sgn_set_exact_exp(int on) { g_exact_exp = on ? 1 : 0; }
+SGN_EXPORT int sgn_get_exact_exp(void) { return g_exact_exp; }
+
+SGN_EXPORT size_t sgn_raster_workspace_bytes(int64_t n_isect) {
+    return (size_t)(n_isect > 0 ? n_isect : 1) * sizeof(Rec);
+}
+
+SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
+    return (size_t)(n > 0 ? n : 1) * SGN_RECORD_FLOATS * sizeof(float);
+}
+
+static int pack_records(int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
+                        const float *colors, const float *opac, void *recs, hipStream_t s) {
+    hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, ids, xys,
+                       conics, colors, opac, (float4 *)recs);
+    return 0;
+}
+
+SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int64_t n_isect,
+                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                              const float *conics, const float *colors, const float *opacities,
+                              const float *background3, float *out_img, float *final_Ts, int32_t *final_idx,
+                              void *recs_ws, size_t recs_ws_bytes, sgn_stream_t stream) {
+    SGN_ARG_CHECK(img_h > 0 && img_w > 0, -1);
+    SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
+    SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -3);
+    SGN_ARG_CHECK(tile_bins && background3 && out_img && final_Ts && final_idx, -4);
+    SGN_ARG_CHECK(n_isect == 0 || (gaussian_ids_sorted && xys && conics && colors && opacities && recs_ws), -5);
+    SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n_isect), -6);
+    hipStream_t s = (hipStream_t)stream;
+    if (n_isect > 0) pack_records(n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, recs_ws, s);
+    const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
+    if (g_exact_exp)
+        hipLaunchKernelGGL(raster_fwd_kernel<true>, dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,
+                           block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3,
+                           out_img, final_Ts, final_idx);
+    else
+        hipLaunchKernelGGL(raster_fwd_kernel<false>, dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,
+                           block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3,
+                           out_img, final_Ts, final_idx);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                              const float *conics, const float *colors, const float *opacities,
+                              const float *background3, const float *final_Ts, const int32_t *final_idx,
+                              const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd,
+                              float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
+                              size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
+                              sgn_stream_t stream) {
+    SGN_ARG_CHECK(img_h > 0 && img_w > 0 && n >= 0, -1);
+    SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
+    SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -3);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(v_xy && v_conic && v_colors && v_opacity && grad_ws, -4);
+    SGN_ARG_CHECK(grad_ws_bytes >= sgn_raster_bwd_workspace_bytes(n), -5);
+    SGN_ARG_CHECK(alpha_clamp_bwd > 0.f && alpha_clamp_bwd < 1.f, -6);
+    hipStream_t s = (hipStream_t)stream;
+    SGN_HIP_CHECK(hipMemsetAsync(grad_ws, 0, (size_t)n * SGN_RECORD_FLOATS * sizeof(float), s));
+    if (n_isect > 0) {
+        SGN_ARG_CHECK(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background3 &&
+                          final_Ts && final_idx && v_out_img && v_out_alpha && recs_ws, -7);
+        SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n_isect), -8);
+        if (!recs_packed) pack_records(n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, recs_ws, s);
+        const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
+        if (g_exact_exp)
+            hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,
+                               block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3,
+                               final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws);
+        else
+            hipLaunchKernelGGL(raster_bwd_kernel<false>, dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,
+                               block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3,
+                               final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws);
+    }
+    hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, (const float *)grad_ws, v_xy,
+                       v_conic, v_colors, v_opacity);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,60 @@
+// Internal helpers shared by the HIP translation units of libsgnrast.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "sgn_rast.h"
+
+#define SGN_EXPORT extern "C" __attribute__((visibility("default")))
+
+void sgn_set_error(const char *fmt, ...);
+
+#define SGN_ARG_CHECK(cond, code)                                              \
+    do {                                                                       \
+        if (!(cond)) {                                                         \
+            sgn_set_error("%s: argument check failed: %s", __func__, #cond);   \
+            return (code);                                                     \
+        }                                                                      \
+    } while (0)
+
+#define SGN_HIP_CHECK(expr)                                                    \
+    do {                                                                       \
+        hipError_t e_ = (expr);                                                \
+        if (e_ != hipSuccess) {                                                \
+            sgn_set_error("%s: %s -> %s", __func__, #expr, hipGetErrorString(e_)); \
+            return (int)e_;                                                    \
+        }                                                                      \
+    } while (0)
+
+#define SGN_LAUNCH_CHECK()                                                     \
+    do {                                                                       \
+        hipError_t e_ = hipGetLastError();                                     \
+        if (e_ != hipSuccess) {                                                \
+            sgn_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return (int)e_;                                                    \
+        }                                                                      \
+    } while (0)
+
+static inline int sgn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// float -> int with v_cvt_i32_f32 semantics (saturating, NaN -> 0); the C oracle spells the
+// same rule out (oracle/c/sgn_oracle.c f2i).
+__device__ __forceinline__ int sgn_f2i(float v) {
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)v;
+}
+
+// gsplat helpers.cuh get_tile_bbox / get_bbox: inclusive min, exclusive max.
+__device__ __forceinline__ void sgn_tile_bbox(float cx, float cy, float radius, int tiles_x,
+                                              int tiles_y, int block, int &mnx, int &mny, int &mxx,
+                                              int &mxy) {
+    const float fb = (float)block;
+    const float tcx = cx / fb, tcy = cy / fb, tr = radius / fb;
+    mnx = min(max(0, sgn_f2i(tcx - tr)), tiles_x);
+    mxx = min(max(0, sgn_f2i(tcx + tr + 1.0f)), tiles_x);
+    mny = min(max(0, sgn_f2i(tcy - tr)), tiles_y);
+    mxy = min(max(0, sgn_f2i(tcy + tr + 1.0f)), tiles_y);
+}

@@ -1,0 +1,196 @@
+// sh.hip — view-dependent colour from real spherical harmonics (forward + backward), gfx950.
+//
+// Replaces gsplat 0.1.x sh.cuh compute_sh_forward_kernel / compute_sh_backward_kernel
+// (method="fast", Sloan recurrences), reached from the reference at
+// sgn_splatfacto.py:939 and sgn_splatfacto_scene_graph.py:285.
+//
+// Pure streaming, HBM-bound: 12 B dir + 12*K B coeffs -> 12 B colour per Gaussian (216 B at K=16).
+// Layout trick for 64-wide waves: the [n,K,3] coefficient block of 64 consecutive Gaussians is one
+// contiguous 64*K*12-byte span, so each wave copies its span to LDS with full-width
+// global_load_dwordx4 (lane-contiguous, every byte of every cache line used once) and then each
+// lane walks its own K*3 row from LDS; the row stride (3K+1 dwords) is odd, so the 64 lanes hit
+// distinct banks.  The backward writes v_coeffs the same way in reverse (row -> LDS -> coalesced
+// dwordx4 stores).
+#include "sgn_common.h"
+
+namespace {
+
+__device__ __forceinline__ int sh_bases(float dx, float dy, float dz, int deg, float *b) {
+    b[0] = 0.2820947917738781f;
+    if (deg < 1) return 1;
+    const float inorm = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx * inorm, y = dy * inorm, z = dz * inorm;
+    const float fTmp0A = 0.48860251190292f;
+    b[1] = -fTmp0A * y; b[2] = fTmp0A * z; b[3] = -fTmp0A * x;
+    if (deg < 2) return 4;
+    const float z2 = z * z;
+    const float fTmp0B = -1.092548430592079f * z;
+    const float fTmp1A = 0.5462742152960395f;
+    const float fC1 = x * x - y * y;
+    const float fS1 = 2.f * x * y;
+    b[6] = 0.9461746957575601f * z2 - 0.3153915652525201f;
+    b[7] = fTmp0B * x; b[5] = fTmp0B * y; b[8] = fTmp1A * fC1; b[4] = fTmp1A * fS1;
+    if (deg < 3) return 9;
+    const float fTmp0C = -2.285228997322329f * z2 + 0.4570457994644658f;
+    const float fTmp1B = 1.445305721320277f * z;
+    const float fTmp2A = -0.5900435899266435f;
+    const float fC2 = x * fC1 - y * fS1;
+    const float fS2 = x * fS1 + y * fC1;
+    b[12] = z * (1.865881662950577f * z2 - 1.119528997770346f);
+    b[13] = fTmp0C * x; b[11] = fTmp0C * y; b[14] = fTmp1B * fC1; b[10] = fTmp1B * fS1;
+    b[15] = fTmp2A * fC2; b[9] = fTmp2A * fS2;
+    if (deg < 4) return 16;
+    const float fTmp0D = z * (-4.683325804901025f * z2 + 2.007139630671868f);
+    const float fTmp1C = 3.31161143515146f * z2 - 0.47308734787878f;
+    const float fTmp2B = -1.770130769779931f * z;
+    const float fTmp3A = 0.6258357354491763f;
+    const float fC3 = x * fC2 - y * fS2;
+    const float fS3 = x * fS2 + y * fC2;
+    b[20] = 1.984313483298443f * z * b[12] + -1.006230589874905f * b[6];
+    b[21] = fTmp0D * x; b[19] = fTmp0D * y; b[22] = fTmp1C * fC1; b[18] = fTmp1C * fS1;
+    b[23] = fTmp2B * fC2; b[17] = fTmp2B * fS2; b[24] = fTmp3A * fC3; b[16] = fTmp3A * fS3;
+    return 25;
+}
+
+// One wave (64 lanes) per 64 Gaussians; a block is WAVES waves with private LDS slabs.
+// KC = K*3 dwords per row; LDS row stride KC+1 (odd) => conflict-free per-lane row walks.
+template <int K, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sh_fwd_kernel(int n, int deg, const float *__restrict__ dirs,
+                                                            const float *__restrict__ coeffs,
+                                                            float *__restrict__ colors) {
+    constexpr int KC = K * 3, LS = KC + 1;
+    __shared__ float lds[WAVES][64 * LS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * WAVES + wave) * 64;
+    const int cnt = max(0, min(64, n - g0));
+    float *my = lds[wave];
+    const float *src = coeffs + (size_t)g0 * KC;
+    const int total = cnt * KC;
+    if constexpr (KC % 4 == 0) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        for (int t = lane; t < total / 4; t += 64) {
+            const float4 v = src4[t];
+            const int e = t * 4, r = e / KC, c = e - r * KC;  // KC%4==0: a float4 never straddles rows
+            float *d = my + r * LS + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int e = lane; e < total; e += 64) {
+            const int r = e / KC, c = e - r * KC;
+            my[r * LS + c] = src[e];
+        }
+    }
+    __syncthreads();
+    if (lane >= cnt) return;
+    const int i = g0 + lane;
+    float b[25];
+    const int nb = sh_bases(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], deg, b);
+    const float *row = my + lane * LS;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (k < nb) {
+            a0 += b[k] * row[3 * k];
+            a1 += b[k] * row[3 * k + 1];
+            a2 += b[k] * row[3 * k + 2];
+        }
+    }
+    colors[3 * i] = a0; colors[3 * i + 1] = a1; colors[3 * i + 2] = a2;
+}
+
+template <int K, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sh_bwd_kernel(int n, int deg, const float *__restrict__ dirs,
+                                                            const float *__restrict__ v_colors,
+                                                            float *__restrict__ v_coeffs) {
+    constexpr int KC = K * 3, LS = KC + 1;
+    __shared__ float lds[WAVES][64 * LS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * WAVES + wave) * 64;
+    const int cnt = max(0, min(64, n - g0));
+    float *my = lds[wave];
+    if (lane < cnt) {
+        const int i = g0 + lane;
+        float b[25];
+        const int nb = sh_bases(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], deg, b);
+        const float v0 = v_colors[3 * i], v1 = v_colors[3 * i + 1], v2 = v_colors[3 * i + 2];
+        float *row = my + lane * LS;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float bk = (k < nb) ? b[k] : 0.f;
+            row[3 * k] = bk * v0; row[3 * k + 1] = bk * v1; row[3 * k + 2] = bk * v2;
+        }
+    }
+    __syncthreads();
+    float *dst = v_coeffs + (size_t)g0 * KC;
+    const int total = cnt * KC;
+    if constexpr (KC % 4 == 0) {
+        float4 *dst4 = reinterpret_cast<float4 *>(dst);
+        for (int t = lane; t < total / 4; t += 64) {
+            const int e = t * 4, r = e / KC, c = e - r * KC;
+            const float *s = my + r * LS + c;
+            dst4[t] = make_float4(s[0], s[1], s[2], s[3]);
+        }
+    } else {
+        for (int e = lane; e < total; e += 64) {
+            const int r = e / KC, c = e - r * KC;
+            dst[e] = my[r * LS + c];
+        }
+    }
+}
+
+template <int K>
+int launch_fwd(int n, int deg, const float *dirs, const float *coeffs, float *colors, hipStream_t s) {
+    constexpr int WAVES = (K > 16) ? 2 : 4;  // keep static LDS under 64 KiB
+    hipLaunchKernelGGL((sh_fwd_kernel<K, WAVES>), dim3(sgn_cdiv(n, WAVES * 64)), dim3(WAVES * 64), 0, s, n,
+                       deg, dirs, coeffs, colors);
+    return 0;
+}
+template <int K>
+int launch_bwd(int n, int deg, const float *dirs, const float *v_colors, float *v_coeffs, hipStream_t s) {
+    constexpr int WAVES = (K > 16) ? 2 : 4;
+    hipLaunchKernelGGL((sh_bwd_kernel<K, WAVES>), dim3(sgn_cdiv(n, WAVES * 64)), dim3(WAVES * 64), 0, s, n,
+                       deg, dirs, v_colors, v_coeffs);
+    return 0;
+}
+
+}  // namespace
+
+SGN_EXPORT int sgn_sh_fwd(int n, int k, int degree, const float *viewdirs, const float *coeffs,
+                          float *colors, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    SGN_ARG_CHECK(degree >= 0 && degree <= 4, -2);
+    SGN_ARG_CHECK(k == 1 || k == 4 || k == 9 || k == 16 || k == 25, -3);
+    SGN_ARG_CHECK((degree + 1) * (degree + 1) <= k, -4);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(viewdirs && coeffs && colors, -5);
+    hipStream_t s = (hipStream_t)stream;
+    switch (k) {
+        case 1: launch_fwd<1>(n, degree, viewdirs, coeffs, colors, s); break;
+        case 4: launch_fwd<4>(n, degree, viewdirs, coeffs, colors, s); break;
+        case 9: launch_fwd<9>(n, degree, viewdirs, coeffs, colors, s); break;
+        case 16: launch_fwd<16>(n, degree, viewdirs, coeffs, colors, s); break;
+        default: launch_fwd<25>(n, degree, viewdirs, coeffs, colors, s); break;
+    }
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_sh_bwd(int n, int k, int degree, const float *viewdirs, const float *v_colors,
+                          float *v_coeffs, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    SGN_ARG_CHECK(degree >= 0 && degree <= 4, -2);
+    SGN_ARG_CHECK(k == 1 || k == 4 || k == 9 || k == 16 || k == 25, -3);
+    SGN_ARG_CHECK((degree + 1) * (degree + 1) <= k, -4);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(viewdirs && v_colors && v_coeffs, -5);
+    hipStream_t s = (hipStream_t)stream;
+    switch (k) {
+        case 1: launch_bwd<1>(n, degree, viewdirs, v_colors, v_coeffs, s); break;
+        case 4: launch_bwd<4>(n, degree, viewdirs, v_colors, v_coeffs, s); break;
+        case 9: launch_bwd<9>(n, degree, viewdirs, v_colors, v_coeffs, s); break;
+        case 16: launch_bwd<16>(n, degree, viewdirs, v_colors, v_coeffs, s); break;
+        default: launch_bwd<25>(n, degree, viewdirs, v_colors, v_coeffs, s); break;
+    }
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,97 @@
+"""ctypes binding of libsgnrast.so (the C ABI declared in include/sgn_rast.h).
+
+There is NO fallback: if the HIP library is missing or a tensor is not on a ROCm
+device the call raises.  (The CPU oracle lives in ``oracle/`` and is test
+infrastructure only; nothing here imports it.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsgnrast.so")
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/sgn_rast.h line by line
+SIGNATURES = {
+    "sgn_version": (_i, []),
+    "sgn_last_error": (C.c_char_p, []),
+    "sgn_set_exact_exp": (None, [_i]),
+    "sgn_get_exact_exp": (_i, []),
+    "sgn_project_fwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f,
+                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_project_bwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                             _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_sh_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sgn_sh_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sgn_scan_workspace_bytes": (_sz, [_i]),
+    "sgn_scan_i32": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_map_isect": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sgn_sort_workspace_bytes": (_sz, [_i64]),
+    "sgn_sort_pairs": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_tile_bins": (_i, [_i64, _vp, _i, _vp, _vp]),
+    "sgn_raster_workspace_bytes": (_sz, [_i64]),
+    "sgn_raster_fwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_raster_bwd_workspace_bytes": (_sz, [_i]),
+    "sgn_raster_bwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f,
+                            _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+class SgnRastError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """dlopen libsgnrast.so and declare every prototype; raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SgnRastError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C street-gaussians-ns_amd/csrc`). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().sgn_last_error()
+        raise SgnRastError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def require_device(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise SgnRastError(
+                "sgn_rast operates on ROCm device tensors only (got a CPU tensor); there is no CPU fallback")
+        dev = dev or t.device
+        if t.device != dev:
+            raise SgnRastError("all tensors must live on the same device")
+    return dev
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

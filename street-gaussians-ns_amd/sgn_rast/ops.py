@@ -1,0 +1,351 @@
+"""Host side of the hot path: the gsplat 0.1.x operator surface over libsgnrast.so.
+
+Mirrors (names, argument order/meaning, return tuples, assertions) the third-party
+``gsplat`` modules the reference imports at ``sgn_splatfacto.py:11-14`` and
+``sgn_splatfacto_scene_graph.py:8``:
+
+* ``gsplat/project_gaussians.py``  -> :func:`project_gaussians`  (``_ProjectGaussians``)
+* ``gsplat/rasterize.py``          -> :func:`rasterize_gaussians` (``_RasterizeGaussians``)
+* ``gsplat/sh.py``                 -> :func:`spherical_harmonics`, :func:`num_sh_bases`
+* ``gsplat/utils.py``              -> binning helpers
+* ``gsplat/_torch_impl.py``        -> :func:`quat_to_rotmat` (the only symbol the reference uses)
+
+PyTorch is plumbing here (device memory, current stream, autograd graph); all
+arithmetic happens in the hand-written HIP kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+# gsplat 0.1.x clamps alpha at 0.999 in rasterize_forward and 0.99 in rasterize_backward.
+UPSTREAM_ALPHA_CLAMP_BWD = 0.99
+_alpha_clamp_bwd = UPSTREAM_ALPHA_CLAMP_BWD
+
+
+def set_alpha_clamp_bwd(value: float) -> None:
+    """0.99 (default) reproduces upstream; 0.999 is the self-consistent variant."""
+    global _alpha_clamp_bwd
+    _alpha_clamp_bwd = float(value)
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+# --------------------------------------------------------------------- sh
+def num_sh_bases(degree: int) -> int:
+    """gsplat/sh.py num_sh_bases (reference: sgn_splatfacto.py:268)."""
+    if degree == 0:
+        return 1
+    if degree == 1:
+        return 4
+    if degree == 2:
+        return 9
+    if degree == 3:
+        return 16
+    return 25
+
+
+def deg_from_sh(num_bases: int) -> int:
+    for d, n in enumerate((1, 4, 9, 16, 25)):
+        if n == num_bases:
+            return d
+    assert False, "Invalid number of SH bases"
+
+
+class _SphericalHarmonics(Function):
+    @staticmethod
+    def forward(ctx, degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor):
+        L.require_device(viewdirs, coeffs)
+        num_points, k = coeffs.shape[0], coeffs.shape[-2]
+        ctx.degrees_to_use, ctx.k = degrees_to_use, k
+        deg_from_sh(k)
+        viewdirs = _f32c(viewdirs)
+        coeffs_c = _f32c(coeffs)
+        colors = torch.empty(num_points, 3, dtype=torch.float32, device=coeffs.device)
+        L.check(L.load().sgn_sh_fwd(num_points, k, degrees_to_use, L.ptr(viewdirs), L.ptr(coeffs_c),
+                                    L.ptr(colors), L.stream_ptr()), "sgn_sh_fwd")
+        ctx.save_for_backward(viewdirs)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors: torch.Tensor):
+        (viewdirs,) = ctx.saved_tensors
+        n = v_colors.shape[0]
+        v_colors = _f32c(v_colors)
+        v_coeffs = torch.empty(n, ctx.k, 3, dtype=torch.float32, device=v_colors.device)
+        L.check(L.load().sgn_sh_bwd(n, ctx.k, ctx.degrees_to_use, L.ptr(viewdirs), L.ptr(v_colors),
+                                    L.ptr(v_coeffs), L.stream_ptr()), "sgn_sh_bwd")
+        return None, None, v_coeffs
+
+
+def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor,
+                        method: str = "fast") -> torch.Tensor:
+    """gsplat/sh.py spherical_harmonics (sgn_splatfacto.py:939; scene_graph.py:285).
+
+    ``coeffs`` [N, K, 3] with K in {1,4,9,16,25}; gradient flows to ``coeffs`` only.
+    ``method`` is accepted for signature parity ("poly" and "fast" are the same
+    polynomial; the kernel evaluates the "fast" recurrences)."""
+    assert coeffs.shape[-2] >= num_sh_bases(degrees_to_use)
+    assert method in ("poly", "fast"), "Invalid method."
+    return _SphericalHarmonics.apply(degrees_to_use, viewdirs.contiguous(), coeffs.contiguous())
+
+
+# ---------------------------------------------------------------- project
+class _ProjectGaussians(Function):
+    @staticmethod
+    def forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
+                block_width, clip_thresh=0.01):
+        num_points = means3d.shape[-2]
+        if num_points < 1 or means3d.shape[-1] != 3:
+            raise ValueError(f"Invalid shape for means3d: {means3d.shape}")
+        dev = L.require_device(means3d, scales, quats, viewmat)
+        means3d_c, scales_c, quats_c = _f32c(means3d), _f32c(scales), _f32c(quats)
+        viewmat_c = _f32c(viewmat).reshape(-1)[:12].contiguous()
+        n = num_points
+        f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+        cov3d = torch.empty(n, 6, **f32)
+        xys = torch.empty(n, 2, **f32)
+        depths = torch.empty(n, **f32)
+        radii = torch.empty(n, **i32)
+        conics = torch.empty(n, 3, **f32)
+        compensation = torch.empty(n, **f32)
+        num_tiles_hit = torch.empty(n, **i32)
+        L.check(L.load().sgn_project_fwd(
+            n, L.ptr(means3d_c), L.ptr(scales_c), float(glob_scale), L.ptr(quats_c), L.ptr(viewmat_c),
+            float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width), int(block_width),
+            float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
+            L.ptr(compensation), L.ptr(num_tiles_hit), L.stream_ptr()), "sgn_project_fwd")
+        ctx.glob_scale, ctx.fx, ctx.fy = float(glob_scale), float(fx), float(fy)
+        ctx.save_for_backward(means3d_c, scales_c, quats_c, viewmat_c, cov3d, radii, conics, compensation)
+        ctx.mark_non_differentiable(radii, num_tiles_hit)
+        return xys, depths, radii, conics, compensation, num_tiles_hit, cov3d
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_compensation, v_num_tiles_hit, v_cov3d):
+        means3d, scales, quats, viewmat, cov3d, radii, conics, compensation = ctx.saved_tensors
+        n, dev = means3d.shape[0], means3d.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        v_xys = _f32c(v_xys) if v_xys is not None else torch.zeros(n, 2, **f32)
+        v_depths = _f32c(v_depths) if v_depths is not None else torch.zeros(n, **f32)
+        v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros(n, 3, **f32)
+        v_comp = _f32c(v_compensation) if v_compensation is not None else None
+        v_mean = torch.empty(n, 3, **f32)
+        v_scale = torch.empty(n, 3, **f32)
+        v_quat = torch.empty(n, 4, **f32)
+        L.check(L.load().sgn_project_bwd(
+            n, L.ptr(means3d), L.ptr(scales), ctx.glob_scale, L.ptr(quats), L.ptr(viewmat), ctx.fx, ctx.fy,
+            L.ptr(cov3d), L.ptr(radii), L.ptr(conics), L.ptr(compensation), L.ptr(v_xys), L.ptr(v_depths),
+            L.ptr(v_conics), L.ptr(v_comp), None, None, L.ptr(v_mean), L.ptr(v_scale), L.ptr(v_quat),
+            L.stream_ptr()), "sgn_project_bwd")
+        # (means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block, clip)
+        # viewmat gradient: never requested by the reference (camera optimiser "off",
+        # sgn_config.py:44) -> None, as upstream returns when viewmat.requires_grad is False.
+        return v_mean, v_scale, None, v_quat, None, None, None, None, None, None, None, None, None
+
+
+def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
+                      block_width, clip_thresh: float = 0.01):
+    """gsplat/project_gaussians.py project_gaussians (sgn_splatfacto.py:860-873).
+
+    Returns ``(xys, depths, radii, conics, compensation, num_tiles_hit, cov3d)``;
+    ``viewmat`` is the world->camera matrix ([3,4] or [4,4]; only rows 0-2 are read)."""
+    assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
+    assert (quats.norm(dim=-1) - 1 < 1e-6).all(), "quats must be normalized"
+    return _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
+                                   viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
+                                   clip_thresh)
+
+
+# ----------------------------------------------------------------- binning
+def compute_cumulative_intersects(num_tiles_hit: torch.Tensor) -> Tuple[int, torch.Tensor]:
+    """gsplat/utils.py compute_cumulative_intersects: (num_intersects, cum_tiles_hit int32).
+    Reads the total back to the host (the buffers below are sized by it), as upstream does."""
+    dev = L.require_device(num_tiles_hit)
+    nth = num_tiles_hit.detach().to(torch.int32).contiguous()
+    n = nth.numel()
+    cum = torch.empty_like(nth)
+    if n == 0:
+        return 0, cum
+    lib = L.load()
+    ws = L.workspace(lib.sgn_scan_workspace_bytes(n), dev)
+    L.check(lib.sgn_scan_i32(n, L.ptr(nth), L.ptr(cum), L.ptr(ws), ws.numel(), L.stream_ptr()), "sgn_scan_i32")
+    return int(cum[-1].item()), cum
+
+
+def map_gaussian_to_intersects(num_points, num_intersects, xys, depths, radii, cum_tiles_hit, tile_bounds,
+                               block_width):
+    """gsplat/utils.py map_gaussian_to_intersects -> (isect_ids int64 [I], gaussian_ids int32 [I])."""
+    dev = L.require_device(xys, depths, radii, cum_tiles_hit)
+    keys = torch.empty(num_intersects, dtype=torch.int64, device=dev)
+    vals = torch.empty(num_intersects, dtype=torch.int32, device=dev)
+    if num_intersects > 0:
+        L.check(L.load().sgn_map_isect(
+            num_points, L.ptr(_f32c(xys)), L.ptr(_f32c(depths)), L.ptr(radii.contiguous()),
+            L.ptr(cum_tiles_hit.contiguous()), int(tile_bounds[0]), int(tile_bounds[1]), int(block_width),
+            L.ptr(keys), L.ptr(vals), L.stream_ptr()), "sgn_map_isect")
+    return keys, vals
+
+
+def sort_intersects(isect_ids: torch.Tensor, gaussian_ids: torch.Tensor, n_tiles: int):
+    """Stable (tile, depth) sort of the intersection pairs; replaces torch.sort + gather upstream."""
+    dev = L.require_device(isect_ids, gaussian_ids)
+    n = isect_ids.numel()
+    keys_sorted = torch.empty_like(isect_ids)
+    vals_sorted = torch.empty_like(gaussian_ids)
+    if n > 0:
+        lib = L.load()
+        ws = L.workspace(lib.sgn_sort_workspace_bytes(n), dev)
+        end_bit = 32 + max(1, int(n_tiles - 1).bit_length())
+        L.check(lib.sgn_sort_pairs(n, 0, end_bit, L.ptr(isect_ids), L.ptr(gaussian_ids), L.ptr(keys_sorted),
+                                   L.ptr(vals_sorted), L.ptr(ws), ws.numel(), L.stream_ptr()), "sgn_sort_pairs")
+    return keys_sorted, vals_sorted
+
+
+def get_tile_bin_edges(num_intersects, isect_ids_sorted, tile_bounds) -> torch.Tensor:
+    """gsplat/utils.py get_tile_bin_edges -> int32 [n_tiles, 2]."""
+    dev = L.require_device(isect_ids_sorted)
+    n_tiles = int(tile_bounds[0]) * int(tile_bounds[1])
+    bins = torch.empty(n_tiles, 2, dtype=torch.int32, device=dev)
+    L.check(L.load().sgn_tile_bins(num_intersects, L.ptr(isect_ids_sorted), n_tiles, L.ptr(bins),
+                                   L.stream_ptr()), "sgn_tile_bins")
+    return bins
+
+
+def bin_and_sort_gaussians(num_points, num_intersects, xys, depths, radii, cum_tiles_hit, tile_bounds,
+                           block_width):
+    """gsplat/utils.py bin_and_sort_gaussians ->
+    (isect_ids_unsorted, gaussian_ids_unsorted, isect_ids_sorted, gaussian_ids_sorted, tile_bins)."""
+    isect_ids, gaussian_ids = map_gaussian_to_intersects(
+        num_points, num_intersects, xys, depths, radii, cum_tiles_hit, tile_bounds, block_width)
+    n_tiles = int(tile_bounds[0]) * int(tile_bounds[1])
+    isect_ids_sorted, gaussian_ids_sorted = sort_intersects(isect_ids, gaussian_ids, n_tiles)
+    tile_bins = get_tile_bin_edges(num_intersects, isect_ids_sorted, tile_bounds)
+    return isect_ids, gaussian_ids, isect_ids_sorted, gaussian_ids_sorted, tile_bins
+
+
+# --------------------------------------------------------------- rasterize
+class _RasterizeGaussians(Function):
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
+                block_width, background=None, return_alpha=False):
+        dev = L.require_device(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
+        num_points = xys.size(0)
+        tile_bounds = ((img_width + block_width - 1) // block_width,
+                       (img_height + block_width - 1) // block_width, 1)
+        if colors.shape[-1] != 3:
+            raise NotImplementedError(
+                "only the 3-channel rasterize path is implemented (the reference never uses N-D colours: "
+                "sgn_splatfacto.py:988 repeats depth x3 to stay on it)")
+        num_intersects, cum_tiles_hit = compute_cumulative_intersects(num_tiles_hit)
+        xys_c, conics_c, colors_c = _f32c(xys), _f32c(conics), _f32c(colors)
+        opac_c, bg_c = _f32c(opacity).reshape(-1), _f32c(background)
+        f32 = dict(dtype=torch.float32, device=dev)
+        lib = L.load()
+        recs = None
+        if num_intersects < 1:
+            out_img = torch.ones(img_height, img_width, 3, **f32) * bg_c
+            gaussian_ids_sorted = torch.zeros(0, dtype=torch.int32, device=dev)
+            tile_bins = torch.zeros(tile_bounds[0] * tile_bounds[1], 2, dtype=torch.int32, device=dev)
+            final_Ts = torch.ones(img_height, img_width, **f32)
+            final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
+        else:
+            _, _, _, gaussian_ids_sorted, tile_bins = bin_and_sort_gaussians(
+                num_points, num_intersects, xys_c, depths, radii, cum_tiles_hit, tile_bounds, block_width)
+            out_img = torch.empty(img_height, img_width, 3, **f32)
+            final_Ts = torch.empty(img_height, img_width, **f32)
+            final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
+            recs = L.workspace(lib.sgn_raster_workspace_bytes(num_intersects), dev)
+            L.check(lib.sgn_raster_fwd(
+                img_height, img_width, block_width, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
+                L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), L.ptr(bg_c), L.ptr(out_img),
+                L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), L.stream_ptr()), "sgn_raster_fwd")
+        ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
+        ctx.num_intersects = num_intersects
+        ctx.opacity_shape = opacity.shape
+        ctx.recs = recs
+        ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys_c, conics_c, colors_c, opac_c, bg_c,
+                              final_Ts, final_idx)
+        if return_alpha:
+            out_alpha = 1 - final_Ts
+            return out_img, out_alpha
+        return out_img
+
+    @staticmethod
+    def backward(ctx, v_out_img, v_out_alpha=None):
+        (gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity, background, final_Ts,
+         final_idx) = ctx.saved_tensors
+        dev = xys.device
+        n = xys.shape[0]
+        H, W = ctx.img_height, ctx.img_width
+        f32 = dict(dtype=torch.float32, device=dev)
+        if v_out_alpha is None:
+            v_out_alpha = torch.zeros(H, W, **f32)
+        v_out_img, v_out_alpha = _f32c(v_out_img), _f32c(v_out_alpha)
+        v_xy = torch.empty(n, 2, **f32)
+        v_conic = torch.empty(n, 3, **f32)
+        v_colors = torch.empty(n, 3, **f32)
+        v_opacity = torch.empty(n, **f32)
+        if ctx.num_intersects < 1:
+            v_xy.zero_(); v_conic.zero_(); v_colors.zero_(); v_opacity.zero_()
+        else:
+            lib = L.load()
+            recs, packed = ctx.recs, 1
+            if recs is None:
+                recs, packed = L.workspace(lib.sgn_raster_workspace_bytes(ctx.num_intersects), dev), 0
+            gws = L.workspace(lib.sgn_raster_bwd_workspace_bytes(n), dev)
+            L.check(lib.sgn_raster_bwd(
+                H, W, ctx.block_width, n, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
+                L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity), L.ptr(background), L.ptr(final_Ts),
+                L.ptr(final_idx), L.ptr(v_out_img), L.ptr(v_out_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
+                L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
+                L.ptr(gws), gws.numel(), L.stream_ptr()), "sgn_raster_bwd")
+        v_opacity = v_opacity.reshape(ctx.opacity_shape)
+        # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha)
+        return v_xy, None, None, v_conic, None, v_colors, v_opacity, None, None, None, None, None
+
+
+def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height: int,
+                        img_width: int, block_width: int, background: Optional[torch.Tensor] = None,
+                        return_alpha: Optional[bool] = False):
+    """gsplat/rasterize.py rasterize_gaussians (sgn_splatfacto.py:954-967, :982-994).
+
+    Returns ``out_img [H,W,3]`` or ``(out_img, out_alpha [H,W])``."""
+    assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
+    if colors.dtype == torch.uint8:
+        colors = colors.float() / 255  # make sure colors are float [0,1]
+    if background is not None:
+        assert background.shape[0] == colors.shape[-1], \
+            f"incorrect shape of background color tensor, expected shape {colors.shape[-1]}"
+    else:
+        background = torch.ones(colors.shape[-1], dtype=torch.float32, device=colors.device)
+    if xys.ndimension() != 2 or xys.size(1) != 2:
+        raise ValueError("xys must have dimensions (N, 2)")
+    if colors.ndimension() != 2:
+        raise ValueError("colors must have dimensions (N, D)")
+    return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(),
+                                     conics.contiguous(), num_tiles_hit.contiguous(), colors.contiguous(),
+                                     opacity.contiguous(), img_height, img_width, block_width,
+                                     background.contiguous(), return_alpha)
+
+
+# -------------------------------------------------------------- _torch_impl
+def quat_to_rotmat(quat: torch.Tensor) -> torch.Tensor:
+    """gsplat/_torch_impl.py quat_to_rotmat (sgn_splatfacto.py:685; densification only, cold):
+    normalises, (w,x,y,z) -> [..., 3, 3].  Plain torch on whatever device the input lives on."""
+    assert quat.shape[-1] == 4, quat.shape
+    w, x, y, z = torch.unbind(torch.nn.functional.normalize(quat, dim=-1), dim=-1)
+    mat = torch.stack(
+        [
+            1 - 2 * (y**2 + z**2), 2 * (x * y - w * z), 2 * (x * z + w * y),
+            2 * (x * y + w * z), 1 - 2 * (x**2 + z**2), 2 * (y * z - w * x),
+            2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x**2 + y**2),
+        ],
+        dim=-1,
+    )
+    return mat.reshape(quat.shape[:-1] + (3, 3))

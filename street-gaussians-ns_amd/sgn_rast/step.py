@@ -1,0 +1,80 @@
+"""Call-site replay of the reference's per-step use of the hot path.
+
+``render`` reproduces, line for line, the argument construction of
+``SplatfactoModel.get_outputs`` / ``render_gaussian_attrs``
+(``street_gaussians_ns/sgn_splatfacto.py:857-873, 889-890, 933-996``) with
+``self.training=True``; ``train_step`` adds the synthetic loss of SURVEY.md §8d
+(fixed random weights on rgb and alpha) and the backward.  ``ops`` is the operator
+namespace: the product passes :mod:`sgn_rast.ops`; the parity tests run the very same
+function a second time with the CPU oracle's namespace to get the expected tensors.
+"""
+from __future__ import annotations
+
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+
+from . import ops as _hip_ops
+from .scenes import Camera
+
+
+def leaf_params(raw: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Raw scene tensors -> autograd leaves (what nn.Parameter would be in SplatfactoModel)."""
+    return {k: v.detach().clone().requires_grad_(True) for k, v in raw.items()}
+
+
+def render(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, block_width: int = 16,
+           background: Optional[torch.Tensor] = None, with_depth: bool = False, ops=_hip_ops,
+           retain_xys_grad: bool = True) -> SimpleNamespace:
+    dev = P["means"].device
+    H, W = cam.height, cam.width
+    if background is None:
+        background = torch.zeros(3, device=dev, dtype=P["means"].dtype)          # :311,931
+    scales = torch.exp(P["log_scales"])                                          # :857
+    colors = torch.cat((P["features_dc"], P["features_rest"]), dim=1)            # :858
+    quats = P["quats"] / P["quats"].norm(dim=-1, keepdim=True)                   # :864
+    xys, depths, radii, conics, _comp, num_tiles_hit, _cov3d = ops.project_gaussians(  # :860-873
+        P["means"], scales, 1, quats, cam.viewmat[:3, :], cam.fx, cam.fy, cam.cx, cam.cy, H, W, block_width)
+    out = SimpleNamespace(xys=xys, depths=depths, radii=radii, conics=conics, num_tiles_hit=num_tiles_hit)
+    if retain_xys_grad and xys.requires_grad:
+        xys.retain_grad()                                                        # :889-890
+    viewdirs = P["means"].detach() - cam.cam_pos.to(P["means"].dtype)            # :934
+    viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)                    # :935
+    rgbs = ops.spherical_harmonics(sh_degree_to_use, viewdirs, colors)           # :939
+    rgbs = torch.clamp(rgbs + 0.5, min=0.0)                                      # :940
+    opacities = torch.sigmoid(P["opacity_logits"])                               # :949
+    rgb, alpha = ops.rasterize_gaussians(                                        # :954-967
+        xys, depths, radii, conics, num_tiles_hit, rgbs, opacities, H, W, block_width,
+        background=background, return_alpha=True)
+    out.rgb, out.alpha, out.rgbs, out.opacities = rgb, alpha, rgbs, opacities
+    if with_depth:                                                               # :982-996
+        depth_im = ops.rasterize_gaussians(
+            xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3), opacities, H, W,
+            block_width, torch.zeros(3, device=dev, dtype=P["means"].dtype))[..., 0:1]
+        out.depth = torch.where(alpha[..., None] > 1e-3, depth_im / alpha[..., None], 10)
+    return out
+
+
+def loss_weights(cam: Camera, seed: int = 7, device="cpu", dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    w_img = torch.rand(cam.height, cam.width, 3, generator=g)
+    w_a = torch.rand(cam.height, cam.width, generator=g)
+    return w_img.to(device=device, dtype=dtype), w_a.to(device=device, dtype=dtype)
+
+
+def train_step(P: Dict[str, torch.Tensor], cam: Camera, w_img: torch.Tensor, w_a: torch.Tensor,
+               sh_degree_to_use: int = 3, block_width: int = 16, with_depth: bool = False, ops=_hip_ops,
+               reducer=None) -> SimpleNamespace:
+    """One "train-step image": project fwd -> SH fwd -> rasterize(return_alpha) fwd -> scalar loss ->
+    full backward to means / log-scales / raw quats / opacity logits / SH coefficients."""
+    for p in P.values():
+        p.grad = None
+    out = render(P, cam, sh_degree_to_use, block_width, with_depth=with_depth, ops=ops)
+    n_pix = cam.height * cam.width
+    loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum()) / n_pix
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+    out.loss = loss.detach()
+    return out

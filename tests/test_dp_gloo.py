@@ -1,0 +1,77 @@
+"""CPU: the N>1 path (world_size 2, gloo): overlapped gradient all-reduce, densification-stat
+reduction, parameter broadcast.  The render itself needs a GPU, so the per-rank gradients come
+from the CPU oracle here (tests may use it) — what is under test is the exchange step."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "street-gaussians-ns_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from oracle import torch_oracle as TO
+    from sgn_rast import dp, scenes, step
+    torch.set_num_threads(2)
+    r, w, _ = dp.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    cam = scenes.make_camera(64, 48, 64.0, yaw=0.15 * rank)       # rank r renders view r
+    raw = scenes.make_gaussians(400, scenes.make_camera(64, 48, 64.0), seed=0, z_range=(1.0, 4.0))
+    if rank != 0:                                                  # replicas start different ...
+        raw = {k: v + 1.0 for k, v in raw.items()}
+    P = step.leaf_params(raw)
+    dp.broadcast_params(P, src=0)                                  # ... and are made identical
+    w_img, w_a = step.loss_weights(cam, seed=7)
+    red = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], average=True)
+    out = step.train_step(P, cam, w_img, w_a, ops=TO, reducer=red)
+    stats = [torch.full((5,), float(rank + 1)), torch.full((5,), 2.0 * (rank + 1)),
+             torch.full((5,), 10.0 * (rank + 1))]
+    dp.sync_densify_stats(*stats)
+    torch.save((rank, {k: v.grad.clone() for k, v in P.items()}, {k: v.detach().clone() for k, v in P.items()},
+                [s.clone() for s in stats], float(out.loss)), os.path.join(outdir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_gradient_allreduce_matches_single_process(torch_oracle, tmp_path):
+    from sgn_rast import scenes, step
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=500)
+        assert p.exitcode == 0
+    res = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    (_, g0, p0, s0, l0), (_, g1, p1, s1, l1) = res
+    for k in g0:                       # replicas hold identical params and identical reduced grads
+        assert torch.equal(p0[k], p1[k]), k
+        assert torch.equal(g0[k], g1[k]), k
+    # single-process expectation: mean over the two views of the per-view gradients
+    raw = scenes.make_gaussians(400, scenes.make_camera(64, 48, 64.0), seed=0, z_range=(1.0, 4.0))
+    acc = None
+    for r in range(world):
+        cam = scenes.make_camera(64, 48, 64.0, yaw=0.15 * r)
+        P = step.leaf_params(raw)
+        w_img, w_a = step.loss_weights(cam, seed=7)
+        step.train_step(P, cam, w_img, w_a, ops=torch_oracle)
+        g = {k: v.grad for k, v in P.items()}
+        acc = g if acc is None else {k: acc[k] + g[k] for k in g}
+    for k in g0:
+        assert torch.allclose(g0[k], acc[k] / world, rtol=1e-5, atol=1e-7), k
+        assert g0[k].abs().sum() > 0, k
+    assert l0 != l1                    # the two ranks really rendered different views
+    assert torch.equal(s0[0], torch.full((5,), 3.0)) and torch.equal(s0[1], torch.full((5,), 6.0))
+    assert torch.equal(s0[2], torch.full((5,), 20.0)) and all(torch.equal(a, b) for a, b in zip(s0, s1))

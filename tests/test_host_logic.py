@@ -1,0 +1,92 @@
+"""CPU: host-side logic of the operator surface (argument validation mirrors upstream gsplat's
+error behaviour; helper functions; synthetic scenes; DP view sharding)."""
+import pytest
+import torch
+
+from sgn_rast import dp, ops, scenes
+
+
+def test_num_sh_bases_and_inverse():
+    assert [ops.num_sh_bases(d) for d in range(5)] == [1, 4, 9, 16, 25]
+    assert [ops.deg_from_sh(k) for k in (1, 4, 9, 16, 25)] == [0, 1, 2, 3, 4]
+    with pytest.raises(AssertionError):
+        ops.deg_from_sh(7)
+
+
+def test_quat_to_rotmat_matches_oracle_and_is_orthonormal(torch_oracle):
+    q = torch.randn(100, 4)
+    R = ops.quat_to_rotmat(q)
+    assert torch.allclose(R, torch_oracle.quat_to_rotmat(q))
+    assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3).expand(100, 3, 3), atol=1e-5)
+    assert torch.allclose(torch.linalg.det(R), torch.ones(100), atol=1e-5)
+    assert torch.allclose(ops.quat_to_rotmat(torch.tensor([[2.0, 0, 0, 0]])), torch.eye(3)[None])
+
+
+def test_rasterize_argument_validation_matches_upstream():
+    n = 4
+    good = dict(xys=torch.rand(n, 2), depths=torch.rand(n), radii=torch.ones(n, dtype=torch.int32),
+                conics=torch.rand(n, 3), num_tiles_hit=torch.ones(n, dtype=torch.int32),
+                colors=torch.rand(n, 3), opacity=torch.rand(n, 1))
+    with pytest.raises(AssertionError, match="block_width must be between 2 and 16"):
+        ops.rasterize_gaussians(*good.values(), 8, 8, 17)
+    with pytest.raises(AssertionError, match="block_width must be between 2 and 16"):
+        ops.rasterize_gaussians(*good.values(), 8, 8, 1)
+    with pytest.raises(AssertionError, match="incorrect shape of background"):
+        ops.rasterize_gaussians(*good.values(), 8, 8, 16, background=torch.zeros(4))
+    bad = dict(good, xys=torch.rand(n, 3))
+    with pytest.raises(ValueError, match=r"xys must have dimensions \(N, 2\)"):
+        ops.rasterize_gaussians(*bad.values(), 8, 8, 16)
+    bad = dict(good, colors=torch.rand(n, 3, 1))
+    with pytest.raises(ValueError, match=r"colors must have dimensions \(N, D\)"):
+        ops.rasterize_gaussians(*bad.values(), 8, 8, 16, background=torch.zeros(1))
+
+
+def test_project_argument_validation_matches_upstream():
+    n = 4
+    q = torch.zeros(n, 4); q[:, 0] = 1
+    args = [torch.rand(n, 3), torch.rand(n, 3), 1, q, torch.eye(4)[:3], 10., 10., 4., 4., 8, 8]
+    with pytest.raises(AssertionError, match="block_width must be between 2 and 16"):
+        ops.project_gaussians(*args, 32)
+    args[3] = q * 2
+    with pytest.raises(AssertionError, match="quats must be normalized"):
+        ops.project_gaussians(*args, 16)
+    args[3] = q
+    args[0] = torch.rand(n, 2)
+    with pytest.raises(ValueError, match="Invalid shape for means3d"):
+        ops.project_gaussians(*args, 16)
+
+
+def test_sh_argument_validation():
+    with pytest.raises(AssertionError):
+        ops.spherical_harmonics(3, torch.rand(4, 3), torch.rand(4, 9, 3))  # degree needs 16 bases
+    with pytest.raises(AssertionError, match="Invalid method"):
+        ops.spherical_harmonics(0, torch.rand(4, 3), torch.rand(4, 1, 3), method="nope")
+
+
+def test_scenes_are_deterministic_and_match_spec():
+    cam, P = scenes.make_scene("c1")
+    cam2, P2 = scenes.make_scene("c1")
+    assert all(torch.equal(P[k], P2[k]) for k in P)
+    assert P["means"].shape == (10_000, 3) and P["features_rest"].shape == (10_000, 15, 3)
+    assert cam.width == 128 and cam.fx == 128.0
+    o = torch.sigmoid(P["opacity_logits"])
+    assert 0.0199 < float(o.min()) and float(o.max()) < 0.9801
+    s = P["log_scales"].exp()
+    assert 0.0099 < float(s.min()) and float(s.max()) < 0.1001
+    z = P["means"][:, 2]
+    assert 1.0 <= float(z.min()) and float(z.max()) <= 5.0
+    assert scenes.SCENES["metric"][:3] == (1_000_000, 1920, 1280)
+    yawed = scenes.make_camera(64, 64, 64.0, yaw=0.3)
+    R = yawed.viewmat[:3, :3]
+    assert torch.allclose(R @ R.T, torch.eye(3), atol=1e-6)
+
+
+def test_view_sharding_covers_every_view_once_per_epoch():
+    n_views, world = 24, 8
+    seen = []
+    for step in range(n_views // world):
+        seen += [dp.view_for_rank(step, r, world, n_views, seed=3) for r in range(world)]
+    assert sorted(seen) == list(range(n_views))
+    nxt = [dp.view_for_rank(n_views // world, r, world, n_views, seed=3) for r in range(world)]
+    assert nxt != seen[:world]  # new permutation in the next epoch
+    assert dp.view_for_rank(5, 2, 4, 10, seed=1) == dp.view_for_rank(5, 2, 4, 10, seed=1)
