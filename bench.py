@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""bench.py — train-step images/sec (fwd+bwd) of the rasterizer hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one train-step image: project fwd -> SH fwd (deg 3) -> rasterize
+(return_alpha) fwd -> scalar loss -> full backward to means / log-scales / quats / opacity logits /
+SH coefficients, on BASELINE.json's metric workload (1 M synthetic Gaussians, 1920x1280), through the
+reference's own call-site argument construction (sgn_rast.step.render).  With N > 1 every rank holds
+the same Gaussians, renders its own (slightly yawed) view and the per-Gaussian gradients are
+all-reduced over RCCL inside the timed step (weak scaling: value = N*K / t).
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel, HIP-event timed on its launch stream)
+and, at N=1, `cpu_baseline` (the repo's pure-PyTorch oracle rasterizer on the host cores, bounded
+sample).  Inputs are resident in HBM before the timed region starts.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "street-gaussians-ns_amd")]
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scene", default="metric", choices=["c1", "c2", "metric", "c4"])
+    ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=4, help="tile rows rendered by the CPU baseline sample")
+    ap.add_argument("--with-depth", action="store_true", help="add the reference's depth pass (:982-996)")
+    return ap.parse_args()
+
+
+def cpu_baseline(scene: str, n_override: int, rows: int):
+    """Pure-PyTorch tile-vectorised rasterizer (oracle/torch_oracle.py, fp32) on the host cores.
+    Bounded sample: whole-scene projection + SH + binning (fwd+bwd), compositing fwd+bwd for `rows`
+    of the tile rows around the image centre; the compositing time is scaled to all tile rows."""
+    from oracle import torch_oracle as TO
+    from sgn_rast import scenes, step
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cam, raw = scenes.make_scene(scene, n_override=n_override)
+    P = step.leaf_params(raw)
+    tiles_y = (cam.height + 15) // 16
+    rows = min(rows, tiles_y)
+    r0 = max(0, tiles_y // 2 - rows // 2)
+    w_img, w_a = step.loss_weights(cam, seed=7)
+
+    class BandOps:  # same namespace, rasterize restricted to the sampled tile rows
+        project_gaussians = staticmethod(TO.project_gaussians)
+        spherical_harmonics = staticmethod(TO.spherical_harmonics)
+        t_raster = 0.0
+
+        @staticmethod
+        def rasterize_gaussians(*a, **k):
+            t = time.perf_counter()
+            out = TO.rasterize_gaussians(*a, tile_rows=(r0, r0 + rows), **k)
+            BandOps.t_raster += time.perf_counter() - t
+            return out
+
+    t0 = time.perf_counter()
+    out = step.render(P, cam, 3, 16, ops=BandOps)
+    loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum()) / (cam.height * cam.width)
+    t1 = time.perf_counter()
+    loss.backward()
+    t2 = time.perf_counter()
+    # forward: binning is inside rasterize; split it out by timing it alone
+    tb = time.perf_counter()
+    I, cum = TO.compute_cumulative_intersects(out.num_tiles_hit)
+    TO.bin_and_sort_gaussians(out.xys.shape[0], I, out.xys.detach(), out.depths.detach(), out.radii, cum,
+                              ((cam.width + 15) // 16, tiles_y, 1), 16)
+    t_bin = time.perf_counter() - tb
+    t_fwd, t_bwd = t1 - t0, t2 - t1
+    comp_fwd = max(BandOps.t_raster - t_bin, 0.0)
+    fixed_fwd = t_fwd - comp_fwd
+    # backward of the band is dominated by the compositing graph; scale it like the forward share
+    frac = comp_fwd / max(t_fwd, 1e-9)
+    comp_bwd, fixed_bwd = t_bwd * frac, t_bwd * (1 - frac)
+    scale = tiles_y / rows
+    t_full = fixed_fwd + fixed_bwd + (comp_fwd + comp_bwd) * scale
+    return {
+        "value": 1.0 / t_full, "unit": "images/sec", "cores": cores, "kind": "port",
+        "sample": (f"pure-PyTorch fp32 oracle, scene '{scene}' N={P['means'].shape[0]} {cam.width}x{cam.height}: "
+                   f"projection+SH+binning for the whole scene, compositing fwd+bwd on {rows}/{tiles_y} tile rows "
+                   f"(measured {t_fwd + t_bwd:.1f}s), compositing share scaled x{scale:.1f} -> {t_full:.1f}s/step"),
+    }
+
+
+def main():
+    args = parse()
+    from sgn_rast import _lib as L, dp, scenes, step
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback); run it under gpurun")
+    rank, world, local = dp.init_from_env()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    L.load()
+
+    cam, raw = scenes.make_scene(args.scene, seed=0, yaw=0.01 * rank, device=dev, n_override=args.n)
+    P = step.leaf_params(raw)
+    w_img, w_a = step.loss_weights(cam, seed=1000 + rank, device=dev)
+    reducer = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]]) if world > 1 else None
+    n_gauss = P["means"].shape[0]
+
+    def one_step():
+        return step.train_step(P, cam, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        out = one_step()
+    torch.cuda.synchronize()
+    n_isect = int(out.num_tiles_hit.sum().item()) if args.warmup else 0
+
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    n_isect = int(out.num_tiles_hit.sum().item())
+
+    # per-kernel HIP-event spans (library brackets each launch on its own stream), separate short pass
+    L.timing_enable(True)
+    k_steps = max(3, min(args.steps, 10))
+    for _ in range(k_steps):
+        one_step()
+    torch.cuda.synchronize()
+    rep = L.timing_report()
+    L.timing_enable(False)
+    kernels = {k: (c, (t / c if c else 0.0)) for k, (c, t) in rep.items()}  # avg ms per launch
+
+    if rank == 0:
+        n_pix = cam.height * cam.width
+        dom = max(("raster_bwd", "raster_fwd", "sort"), key=lambda k: kernels[k][1])
+        # algorithmic bytes per launch of the dominant kernel
+        alg = {"raster_bwd": 112 * n_isect + 24 * n_pix,      # gather 40 + grad scatter 72 per isect; 24 B/pixel
+               "raster_fwd": 40 * n_isect + 20 * n_pix,       # gather 40 per isect; 20 B/pixel written
+               "sort": 144 * n_isect}[dom]                    # 6 passes x (12 r + 12 w) per isect
+        dur_s = kernels[dom][1] * 1e-3
+        achieved = alg / dur_s / 1e9 if dur_s > 0 else 0.0
+        step_bytes = 748 * n_gauss + 316 * n_isect + 44 * n_pix
+        line = {
+            "metric": "train-step images/sec (fwd+bwd) @1M Gaussians 1920x1280",
+            "value": world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": (f"{args.scene}: {n_gauss} Gaussians, {cam.width}x{cam.height}, SH deg 3 (K=16), "
+                                    f"block 16, fwd+bwd{' + depth pass' if args.with_depth else ''}; "
+                                    f"measured I={n_isect} tile intersections/view"),
+                       "parallelism": f"dp{world} (view-parallel, RCCL grad all-reduce)" if world > 1 else "single",
+                       "n_gaussians": n_gauss, "n_isect": n_isect},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": kernels[dom][1], "alg_bytes_per_launch": alg,
+                         "step_alg_bytes": step_bytes,
+                         "step_hbm_frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+            "kernels_avg_ms": {k: round(v[1], 4) for k, v in kernels.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(args.scene, args.n, args.cpu_rows)
+            except Exception as e:  # the GPU number stands on its own
+                line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
+                                        "sample": f"failed: {e!r}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

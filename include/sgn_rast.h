@@ -43,6 +43,24 @@ const char *sgn_last_error(void);
 void sgn_set_exact_exp(int on);
 int sgn_get_exact_exp(void);
 
+/* Opt-in per-kernel timing for bench.py / profiles: when enabled, each timed launch is bracketed by
+ * hipEventRecord on the stream it is launched on; sgn_timing_get sums the finished spans of a slot. */
+#define SGN_T_PROJECT_FWD 0
+#define SGN_T_PROJECT_BWD 1
+#define SGN_T_SH_FWD 2
+#define SGN_T_SH_BWD 3
+#define SGN_T_SCAN 4
+#define SGN_T_MAP 5
+#define SGN_T_SORT 6
+#define SGN_T_BINS 7
+#define SGN_T_PACK 8
+#define SGN_T_RASTER_FWD 9
+#define SGN_T_RASTER_BWD 10
+#define SGN_T_UNPACK 11
+#define SGN_T_SLOTS 12
+void sgn_timing_enable(int on); /* also clears recorded spans */
+int sgn_timing_get(int slot, int *count /*host*/, float *total_ms /*host*/);
+
 /* _C.project_gaussians_forward (gsplat/project_gaussians.py:_ProjectGaussians.forward;
  * reference call site sgn_splatfacto.py:860-873).  Every output row is written
  * (zeros for culled Gaussians), so the caller need not pre-zero. */

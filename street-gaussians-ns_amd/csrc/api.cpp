@@ -2,6 +2,11 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
+
 #include "sgn_rast.h"
 
 static thread_local char g_err[512] = "";
@@ -15,3 +20,56 @@ void sgn_set_error(const char *fmt, ...) {
 
 extern "C" __attribute__((visibility("default"))) const char *sgn_last_error(void) { return g_err; }
 extern "C" __attribute__((visibility("default"))) int sgn_version(void) { return 100; }
+
+// ---------------------------------------------------------------- kernel timing (bench/profiles)
+// Opt-in: when enabled every timed launch is bracketed by hipEventRecord on the SAME stream the
+// kernel is launched on; sgn_timing_get() synchronises the recorded events and sums them.
+namespace {
+struct Span { hipEvent_t a, b; int slot; };
+std::mutex g_mu;
+std::vector<Span> g_spans;
+int g_timing = 0;
+}  // namespace
+
+int sgn_timing_enabled() { return g_timing; }
+
+void sgn_timing_begin(int slot, void *stream) {
+    if (!g_timing) return;
+    Span s;
+    s.slot = slot;
+    if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return;
+    (void)hipEventRecord(s.a, (hipStream_t)stream);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_spans.push_back(s);
+}
+
+void sgn_timing_end(int slot, void *stream) {
+    if (!g_timing) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = g_spans.size(); i-- > 0;)
+        if (g_spans[i].slot == slot) { (void)hipEventRecord(g_spans[i].b, (hipStream_t)stream); return; }
+}
+
+extern "C" __attribute__((visibility("default"))) void sgn_timing_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (auto &s : g_spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+    g_spans.clear();
+    g_timing = on ? 1 : 0;
+}
+
+extern "C" __attribute__((visibility("default"))) int sgn_timing_get(int slot, int *count, float *total_ms) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int c = 0;
+    float t = 0.f;
+    for (auto &s : g_spans) {
+        if (s.slot != slot) continue;
+        if (hipEventSynchronize(s.b) != hipSuccess) return 1;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) != hipSuccess) return 2;
+        t += ms;
+        ++c;
+    }
+    if (count) *count = c;
+    if (total_ms) *total_ms = t;
+    return 0;
+}

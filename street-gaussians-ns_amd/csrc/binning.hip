@@ -171,9 +171,11 @@ SGN_EXPORT int sgn_scan_i32(int n, const int32_t *in, int32_t *out, void *ws, si
     hipStream_t s = (hipStream_t)stream;
     const int nb = sgn_cdiv(n, SCAN_CHUNK);
     int32_t *partial = (int32_t *)ws;
+    sgn_timing_begin(SGN_T_SCAN, s);
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, n, in, partial);
     hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, partial);
     hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, n, in, partial, out);
+    sgn_timing_end(SGN_T_SCAN, s);
     SGN_LAUNCH_CHECK();
     return 0;
 }
@@ -185,8 +187,10 @@ SGN_EXPORT int sgn_map_isect(int n, const float *xys, const float *depths, const
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     if (n == 0) return 0;
     SGN_ARG_CHECK(xys && depths && radii && cum_tiles_hit, -3);
+    sgn_timing_begin(SGN_T_MAP, stream);
     hipLaunchKernelGGL(map_isect_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, xys,
                        depths, radii, cum_tiles_hit, tiles_x, tiles_y, block_width, isect_keys, isect_vals);
+    sgn_timing_end(SGN_T_MAP, stream);
     SGN_LAUNCH_CHECK();
     return 0;
 }
@@ -199,8 +203,10 @@ SGN_EXPORT int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_
     SGN_HIP_CHECK(hipMemsetAsync(tile_bins, 0, (size_t)n_tiles * 2 * sizeof(int32_t), s));
     if (n_isect == 0) return 0;
     SGN_ARG_CHECK(keys_sorted != nullptr, -3);
+    sgn_timing_begin(SGN_T_BINS, s);
     hipLaunchKernelGGL(tile_bins_kernel, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, keys_sorted,
                        tile_bins);
+    sgn_timing_end(SGN_T_BINS, s);
     SGN_LAUNCH_CHECK();
     return 0;
 }

@@ -289,9 +289,11 @@ SGN_EXPORT int sgn_project_fwd(int n, const float *means3d, const float *scales,
     SGN_ARG_CHECK(means3d && scales && quats && viewmat12 && cov3d && xys && depths && radii &&
                       conics && compensation && num_tiles_hit, -4);
     const Cam cam = make_cam(viewmat12, fx, fy, cx, cy, img_h, img_w, block_width, clip_thresh, glob_scale);
+    sgn_timing_begin(SGN_T_PROJECT_FWD, stream);
     hipLaunchKernelGGL(project_fwd_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means3d, scales, quats, cam, cov3d, xys, depths, radii, conics, compensation,
                        num_tiles_hit);
+    sgn_timing_end(SGN_T_PROJECT_FWD, stream);
     SGN_LAUNCH_CHECK();
     return 0;
 }
@@ -309,9 +311,11 @@ SGN_EXPORT int sgn_project_bwd(int n, const float *means3d, const float *scales,
                       v_depth && v_conic && v_mean3d && v_scale && v_quat, -4);
     SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
     const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
+    sgn_timing_begin(SGN_T_PROJECT_BWD, stream);
     hipLaunchKernelGGL(project_bwd_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means3d, scales, quats, cam, cov3d, radii, conics, compensation, v_xy, v_depth,
                        v_conic, v_compensation, v_cov2d, v_cov3d, v_mean3d, v_scale, v_quat);
+    sgn_timing_end(SGN_T_PROJECT_BWD, stream);
     SGN_LAUNCH_CHECK();
     return 0;
 }

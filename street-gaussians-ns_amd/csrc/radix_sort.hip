@@ -206,6 +206,7 @@ SGN_EXPORT int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const
     const int npass = (end_bit - begin_bit + 7) / 8;
     const uint64_t *src_k = (const uint64_t *)keys_in;
     const int32_t *src_v = vals_in;
+    sgn_timing_begin(SGN_T_SORT, s);
     for (int pass = 0; pass < npass; ++pass) {
         const int shift = begin_bit + 8 * pass;
         const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
@@ -220,6 +221,7 @@ SGN_EXPORT int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const
         src_k = dst_k;
         src_v = dst_v;
     }
+    sgn_timing_end(SGN_T_SORT, s);
     SGN_LAUNCH_CHECK();
     return 0;
 }

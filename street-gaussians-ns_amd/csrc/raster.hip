@@ -328,8 +328,10 @@ SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
 
 static int pack_records(int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
                         const float *colors, const float *opac, void *recs, hipStream_t s) {
+    sgn_timing_begin(SGN_T_PACK, s);
     hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, ids, xys,
                        conics, colors, opac, (float4 *)recs);
+    sgn_timing_end(SGN_T_PACK, s);
     return 0;
 }
 
@@ -347,14 +349,19 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int64_t n_i
     hipStream_t s = (hipStream_t)stream;
     if (n_isect > 0) pack_records(n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, recs_ws, s);
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
-    if (g_exact_exp)
+    if (g_exact_exp) {
+        sgn_timing_begin(SGN_T_RASTER_FWD, s);
         hipLaunchKernelGGL(raster_fwd_kernel<true>, dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,
                            block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3,
                            out_img, final_Ts, final_idx);
-    else
+        sgn_timing_end(SGN_T_RASTER_FWD, s);
+    } else {
+        sgn_timing_begin(SGN_T_RASTER_FWD, s);
         hipLaunchKernelGGL(raster_fwd_kernel<false>, dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,
                            block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3,
                            out_img, final_Ts, final_idx);
+        sgn_timing_end(SGN_T_RASTER_FWD, s);
+    }
     SGN_LAUNCH_CHECK();
     return 0;
 }
@@ -382,17 +389,24 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n_isect), -8);
         if (!recs_packed) pack_records(n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, recs_ws, s);
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
-        if (g_exact_exp)
+        if (g_exact_exp) {
+            sgn_timing_begin(SGN_T_RASTER_BWD, s);
             hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,
                                block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3,
                                final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws);
-        else
+            sgn_timing_end(SGN_T_RASTER_BWD, s);
+        } else {
+            sgn_timing_begin(SGN_T_RASTER_BWD, s);
             hipLaunchKernelGGL(raster_bwd_kernel<false>, dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,
                                block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3,
                                final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws);
+            sgn_timing_end(SGN_T_RASTER_BWD, s);
+        }
     }
+    sgn_timing_begin(SGN_T_UNPACK, s);
     hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, (const float *)grad_ws, v_xy,
                        v_conic, v_colors, v_opacity);
+    sgn_timing_end(SGN_T_UNPACK, s);
     SGN_LAUNCH_CHECK();
     return 0;
 }

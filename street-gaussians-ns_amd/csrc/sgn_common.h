@@ -9,6 +9,9 @@
 #define SGN_EXPORT extern "C" __attribute__((visibility("default")))
 
 void sgn_set_error(const char *fmt, ...);
+int sgn_timing_enabled();
+void sgn_timing_begin(int slot, void *stream);
+void sgn_timing_end(int slot, void *stream);
 
 #define SGN_ARG_CHECK(cond, code)                                              \
     do {                                                                       \

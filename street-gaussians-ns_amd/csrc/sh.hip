@@ -141,15 +141,19 @@ __global__ __launch_bounds__(WAVES * 64) void sh_bwd_kernel(int n, int deg, cons
 template <int K>
 int launch_fwd(int n, int deg, const float *dirs, const float *coeffs, float *colors, hipStream_t s) {
     constexpr int WAVES = (K > 16) ? 2 : 4;  // keep static LDS under 64 KiB
+    sgn_timing_begin(SGN_T_SH_FWD, s);
     hipLaunchKernelGGL((sh_fwd_kernel<K, WAVES>), dim3(sgn_cdiv(n, WAVES * 64)), dim3(WAVES * 64), 0, s, n,
                        deg, dirs, coeffs, colors);
+    sgn_timing_end(SGN_T_SH_FWD, s);
     return 0;
 }
 template <int K>
 int launch_bwd(int n, int deg, const float *dirs, const float *v_colors, float *v_coeffs, hipStream_t s) {
     constexpr int WAVES = (K > 16) ? 2 : 4;
+    sgn_timing_begin(SGN_T_SH_BWD, s);
     hipLaunchKernelGGL((sh_bwd_kernel<K, WAVES>), dim3(sgn_cdiv(n, WAVES * 64)), dim3(WAVES * 64), 0, s, n,
                        deg, dirs, v_colors, v_coeffs);
+    sgn_timing_end(SGN_T_SH_BWD, s);
     return 0;
 }
 

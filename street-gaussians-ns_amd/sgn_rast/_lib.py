@@ -22,6 +22,8 @@ SIGNATURES = {
     "sgn_last_error": (C.c_char_p, []),
     "sgn_set_exact_exp": (None, [_i]),
     "sgn_get_exact_exp": (_i, []),
+    "sgn_timing_enable": (None, [_i]),
+    "sgn_timing_get": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "sgn_project_fwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_project_bwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -95,3 +97,21 @@ def stream_ptr() -> C.c_void_p:
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+TIMING_SLOTS = ["project_fwd", "project_bwd", "sh_fwd", "sh_bwd", "scan", "map_isect", "sort", "tile_bins",
+                "pack_records", "raster_fwd", "raster_bwd", "unpack_grads"]
+
+
+def timing_enable(on: bool) -> None:
+    load().sgn_timing_enable(1 if on else 0)
+
+
+def timing_report() -> dict:
+    """{slot: (launches, total_ms)} from the library's HIP-event spans (synchronises them)."""
+    out = {}
+    for i, name in enumerate(TIMING_SLOTS):
+        c, t = C.c_int(0), C.c_float(0.0)
+        check(load().sgn_timing_get(i, C.byref(c), C.byref(t)), "sgn_timing_get")
+        out[name] = (c.value, t.value)
+    return out

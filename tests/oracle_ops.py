@@ -1,0 +1,87 @@
+"""The gsplat operator surface implemented on the C oracle (CPU), with upstream's analytic
+backward — the *expected-value generator* for end-to-end parity tests and golden fixtures.
+Test infrastructure: lives under tests/, never imported by the product."""
+import torch
+from torch.autograd import Function
+
+from oracle import c_oracle as CO
+
+ALPHA_CLAMP_BWD = 0.99  # gsplat 0.1.x backward clamp
+
+
+class _Project(Function):
+    @staticmethod
+    def forward(ctx, means, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block, clip):
+        out = CO.project_fwd(means, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block, clip)
+        xys, depths, radii, conics, comp, nth, cov3d = out
+        ctx.args = (glob_scale, fx, fy)
+        ctx.save_for_backward(means.detach(), scales.detach(), quats.detach(), viewmat.detach(), cov3d, radii,
+                              conics, comp)
+        ctx.mark_non_differentiable(radii, nth)
+        return xys, depths, radii, conics, comp, nth, cov3d
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_comp, v_nth, v_cov3d):
+        means, scales, quats, viewmat, cov3d, radii, conics, comp = ctx.saved_tensors
+        gs, fx, fy = ctx.args
+        n = means.shape[0]
+        z = lambda t, *s: torch.zeros(*s) if t is None else t
+        vm, vs, vq, _, _ = CO.project_bwd(means, scales, gs, quats, viewmat, fx, fy, cov3d, radii, conics, comp,
+                                          z(v_xys, n, 2), z(v_depths, n), z(v_conics, n, 3), z(v_comp, n))
+        return (vm, vs, None, vq) + (None,) * 9
+
+
+def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
+                      block_width, clip_thresh=0.01):
+    return _Project.apply(means3d, scales, float(glob_scale), quats, viewmat, fx, fy, cx, cy, img_height,
+                          img_width, block_width, clip_thresh)
+
+
+class _SH(Function):
+    @staticmethod
+    def forward(ctx, deg, dirs, coeffs):
+        ctx.deg, ctx.k = deg, coeffs.shape[1]
+        ctx.save_for_backward(dirs.detach())
+        return CO.sh_fwd(deg, dirs, coeffs)
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        (dirs,) = ctx.saved_tensors
+        return None, None, CO.sh_bwd(ctx.deg, ctx.k, dirs, v_colors)
+
+
+def spherical_harmonics(degrees_to_use, viewdirs, coeffs, method="fast"):
+    return _SH.apply(degrees_to_use, viewdirs, coeffs)
+
+
+class _Raster(Function):
+    @staticmethod
+    def forward(ctx, xys, depths, radii, conics, nth, colors, opacity, H, W, block, background, return_alpha):
+        cum, keys, vals, ks, vs, bins = CO.bin_and_sort(xys, depths, radii, nth, H, W, block)
+        img, fT, fi = CO.raster_fwd(H, W, block, vs, bins, xys, conics, colors, opacity, background)
+        ctx.dims = (H, W, block)
+        ctx.oshape = opacity.shape
+        ctx.save_for_backward(vs, bins, xys.detach(), conics.detach(), colors.detach(), opacity.detach(),
+                              background, fT, fi)
+        ctx.aux = (ks, vs, bins, fT, fi)
+        if return_alpha:
+            return img, 1 - fT
+        return img
+
+    @staticmethod
+    def backward(ctx, v_img, v_alpha=None):
+        vs, bins, xys, conics, colors, opacity, bg, fT, fi = ctx.saved_tensors
+        H, W, block = ctx.dims
+        if v_alpha is None:
+            v_alpha = torch.zeros(H, W)
+        v_xy, v_conic, v_col, v_op = CO.raster_bwd(H, W, block, vs, bins, xys, conics, colors, opacity, bg, fT, fi,
+                                                    v_img, v_alpha, ALPHA_CLAMP_BWD)
+        return (v_xy, None, None, v_conic, None, v_col, v_op.reshape(ctx.oshape)) + (None,) * 5
+
+
+def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
+                        block_width, background=None, return_alpha=False):
+    if background is None:
+        background = torch.ones(3)
+    return _Raster.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
+                         block_width, background, return_alpha)

@@ -1,0 +1,134 @@
+"""GPU (-m gpu): the reference's call-site replay end to end, and BASELINE.json-size properties."""
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _to_dev(cam, raw):
+    from sgn_rast import step
+    cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+    return step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+
+
+@pytest.mark.parametrize("sh_deg", [0, 3])
+def test_c1_train_step_matches_oracle(sh_deg):
+    """BASELINE.json configs[0] scene (10k Gaussians, 128x128), fwd+bwd, depth pass included."""
+    import oracle_ops
+    from sgn_rast import scenes, step
+    cam, raw = scenes.make_scene("c1")
+    w_img, w_a = step.loss_weights(cam, seed=7)
+    Pc = step.leaf_params(raw)
+    exp = step.train_step(Pc, cam, w_img, w_a, sh_degree_to_use=sh_deg, with_depth=True, ops=oracle_ops)
+    cam_d, _ = scenes.make_scene("c1")
+    Pd = _to_dev(cam_d, raw)
+    got = step.train_step(Pd, cam_d, w_img.to(DEV), w_a.to(DEV), sh_degree_to_use=sh_deg, with_depth=True)
+    assert torch.equal(got.radii.cpu(), exp.radii) and torch.equal(got.num_tiles_hit.cpu(), exp.num_tiles_hit)
+    assert torch.equal(got.xys.detach().cpu(), exp.xys.detach())
+    for name in ("rgb", "alpha"):
+        err = (getattr(got, name).detach().cpu() - getattr(exp, name).detach()).abs()
+        assert float(err.mean()) < 1e-6 and float((err > 1e-5).float().mean()) < 2e-3 and float(err.max()) < 2e-2
+    assert rel_l2(got.xys.grad.cpu(), exp.xys.grad) < 1e-4       # retained grad of the intermediate
+    for k in Pd:
+        assert rel_l2(Pd[k].grad.cpu(), Pc[k].grad) < 1e-4, k
+    if sh_deg == 0:                                              # inactive SH bands: exact zero gradient
+        assert float(Pd["features_rest"].grad.abs().max()) == 0.0
+
+
+def test_forward_is_deterministic_and_backward_is_linear():
+    from sgn_rast import scenes, step
+    cam, raw = scenes.make_scene("c1")
+    P = _to_dev(cam, raw)
+    a = step.render(P, cam)
+    b = step.render(P, cam)
+    assert torch.equal(a.rgb, b.rgb) and torch.equal(a.alpha, b.alpha)       # idempotent forward
+    w_img, w_a = step.loss_weights(cam, seed=3, device=DEV)
+    step.train_step(P, cam, w_img, w_a)
+    g1 = {k: v.grad.clone() for k, v in P.items()}
+    step.train_step(P, cam, 2 * w_img, 2 * w_a)
+    for k in P:                                                              # vjp is linear in v_out
+        assert rel_l2(P[k].grad, 2 * g1[k]) < 1e-5, k
+
+
+def test_c2_size_binning_properties_and_exact_forward(c_oracle):
+    """BASELINE.json configs[1] (500k Gaussians, 1920x1280, SH deg 3): size-independent properties
+    of the binning, plus a bit-exact forward against the C oracle (portable-exp mode both sides)."""
+    from sgn_rast import _lib as L, ops, scenes, step
+    cam, raw = scenes.make_scene("c2")
+    cam_cpu, _ = scenes.make_scene("c2")
+    P = _to_dev(cam, raw)
+    H, W = cam.height, cam.width
+    tb = ((W + 15) // 16, (H + 15) // 16, 1)
+    n_tiles = tb[0] * tb[1]
+    with torch.no_grad():
+        scales = torch.exp(P["log_scales"])
+        quats = P["quats"] / P["quats"].norm(dim=-1, keepdim=True)
+        xys, depths, radii, conics, comp, nth, cov3d = ops.project_gaussians(
+            P["means"], scales, 1, quats, cam.viewmat[:3, :], cam.fx, cam.fy, cam.cx, cam.cy, H, W, 16)
+        I, cum = ops.compute_cumulative_intersects(nth)
+        assert I == int(nth.sum().item()) and I > 1_000_000
+        keys, vals, ks, vs, bins = ops.bin_and_sort_gaussians(xys.shape[0], I, xys, depths, radii, cum, tb, 16)
+        assert bool((ks[1:] >= ks[:-1]).all())                                   # sortedness
+        assert torch.equal(torch.sort(keys).values, ks)                          # same multiset of keys
+        assert int(vals.long().sum()) == int(vs.long().sum())                    # checksum of payloads
+        assert int((vals.long() ** 2).sum()) == int((vs.long() ** 2).sum())
+        tile_of = (ks >> 32)
+        cnt = torch.bincount(tile_of, minlength=n_tiles)
+        assert torch.equal((bins[:, 1] - bins[:, 0]).long(), cnt)                # bins partition the list
+        nz = cnt > 0
+        assert torch.equal(bins[nz, 0].long(), (torch.cumsum(cnt, 0) - cnt)[nz])
+        assert torch.equal(depths[vs.long()].view(torch.int32).long(), ks & 0xFFFFFFFF)  # payload follows key
+        # exact-mode forward vs C oracle
+        coeffs = torch.cat((P["features_dc"], P["features_rest"]), dim=1)
+        dirs = P["means"] - cam.cam_pos
+        rgbs = torch.clamp(ops.spherical_harmonics(3, dirs, coeffs) + 0.5, min=0.0)
+        opac = torch.sigmoid(P["opacity_logits"])
+        bg = torch.tensor([0.05, 0.1, 0.15], device=DEV)
+        L.load().sgn_set_exact_exp(1)
+        c_oracle.set_exp_mode(1)
+        try:
+            img, alpha = ops.rasterize_gaussians(xys, depths, radii, conics, nth, rgbs, opac, H, W, 16, bg, True)
+            e_img, e_T, e_idx = c_oracle.raster_fwd(H, W, 16, vs.cpu(), bins.cpu(), xys.cpu(), conics.cpu(),
+                                                    rgbs.cpu(), opac.cpu(), bg.cpu())
+        finally:
+            L.load().sgn_set_exact_exp(0)
+            c_oracle.set_exp_mode(0)
+        assert torch.equal(img.cpu(), e_img)
+        assert torch.equal(alpha.cpu(), 1 - e_T)
+        assert float(alpha.min()) >= 0.0 and float(alpha.max()) <= 1.0
+
+
+def test_metric_size_train_step_runs_and_is_sane():
+    """The benchmark workload itself (1M Gaussians, 1920x1280, SH deg 3): finite outputs, gradients on
+    every parameter, culled Gaussians get exactly zero gradient."""
+    from sgn_rast import scenes, step
+    cam, raw = scenes.make_scene("metric")
+    P = _to_dev(cam, raw)
+    w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+    out = step.train_step(P, cam, w_img, w_a)
+    assert torch.isfinite(out.rgb).all() and torch.isfinite(out.alpha).all()
+    assert 0.0 <= float(out.alpha.min()) and float(out.alpha.max()) <= 1.0
+    culled = out.radii == 0
+    assert 0.05 < float(culled.float().mean()) < 0.6
+    for k, v in P.items():
+        assert v.grad is not None and torch.isfinite(v.grad).all(), k
+        assert float(v.grad.abs().sum()) > 0, k
+    for k in ("means", "log_scales", "quats"):
+        assert float(P[k].grad[culled].abs().max()) == 0.0, k
+    assert float(out.xys.grad[culled].abs().max()) == 0.0
+
+
+def test_single_rank_dp_reducer_is_a_noop():
+    from sgn_rast import dp, scenes, step
+    cam, raw = scenes.make_scene("c1", n_override=2000)
+    P = _to_dev(cam, raw)
+    red = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]])
+    w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+    step.train_step(P, cam, w_img, w_a, reducer=red)
+    g = {k: v.grad.clone() for k, v in P.items()}
+    step.train_step(P, cam, w_img, w_a)
+    for k in P:
+        assert rel_l2(P[k].grad, g[k]) < 1e-5

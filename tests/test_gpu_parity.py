@@ -1,0 +1,291 @@
+"""GPU (-m gpu): every HIP kernel, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Integer / index / key outputs must be bit-exact; floating point within the
+tolerance written next to each assert."""
+import pytest
+import torch
+
+from helpers import activated, rel_l2, small_scene
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from sgn_rast import _lib, ops
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    _lib.load()  # raises if libsgnrast.so is missing: no fallback
+    return ops
+
+
+def _project_args(cam, P, block=16, dev="cpu"):
+    scales, quats, _, _ = activated(P)
+    return (P["means"].to(dev), scales.to(dev), 1.0, quats.to(dev), cam.viewmat[:3, :].to(dev), cam.fx, cam.fy,
+            cam.cx, cam.cy, cam.height, cam.width, block)
+
+
+# --------------------------------------------------------------- projection
+@pytest.mark.parametrize("block", [16, 8, 5])
+@pytest.mark.parametrize("size", [(128, 128), (130, 70)])
+def test_project_forward_bit_exact(hip, c_oracle, block, size):
+    cam, P = small_scene(n=20000, w=size[0], h=size[1])
+    P["means"][:50, 2] = 0.005   # near-plane culls
+    P["means"][50:100, 0] = 1e4  # off-screen culls
+    exp = c_oracle.project_fwd(*_project_args(cam, P, block))
+    got = hip.project_gaussians(*_project_args(cam, P, block, DEV))
+    for name, a, b in zip(["xys", "depths", "radii", "conics", "compensation", "num_tiles_hit", "cov3d"], got, exp):
+        assert torch.equal(a.cpu(), b), f"{name} differs: {(a.cpu().float() - b.float()).abs().max()}"
+
+
+def test_project_backward(hip, c_oracle):
+    cam, P = small_scene(n=20000)
+    args = _project_args(cam, P)
+    xys, depths, radii, conics, comp, nth, cov3d = c_oracle.project_fwd(*args)
+    g = torch.Generator().manual_seed(1)
+    n = radii.numel()
+    v_xy, v_d, v_con, v_comp = (torch.randn(n, 2, generator=g), torch.randn(n, generator=g),
+                                torch.randn(n, 3, generator=g), torch.randn(n, generator=g))
+    exp = c_oracle.project_bwd(args[0], args[1], 1.0, args[3], args[4], cam.fx, cam.fy, cov3d, radii, conics, comp,
+                               v_xy, v_d, v_con, v_comp)
+    dargs = list(_project_args(cam, P, 16, DEV))
+    leaves = [dargs[0].requires_grad_(True), dargs[1].requires_grad_(True), dargs[3].requires_grad_(True)]
+    out = hip.project_gaussians(*dargs)
+    torch.autograd.backward([out[0], out[1], out[3], out[4]],
+                            [v_xy.to(DEV), v_d.to(DEV), v_con.to(DEV), v_comp.to(DEV)])
+    for name, leaf, e in zip(["v_mean", "v_scale", "v_quat"], leaves, exp[:3]):
+        got = leaf.grad.cpu()
+        assert rel_l2(got, e) < 1e-5, name                      # same formulas, fp32 both sides
+        assert (got[radii == 0] == 0).all(), name               # culled rows get exact zeros
+    # without a compensation gradient (the reference's case: output discarded)
+    for l in leaves:
+        l.grad = None
+    out = hip.project_gaussians(*dargs)
+    torch.autograd.backward([out[0], out[1], out[3]], [v_xy.to(DEV), v_d.to(DEV), v_con.to(DEV)])
+    exp0 = c_oracle.project_bwd(args[0], args[1], 1.0, args[3], args[4], cam.fx, cam.fy, cov3d, radii, conics, comp,
+                                v_xy, v_d, v_con, torch.zeros(n))
+    for leaf, e in zip(leaves, exp0[:3]):
+        assert rel_l2(leaf.grad.cpu(), e) < 1e-5
+
+
+# ----------------------------------------------------------------------- SH
+@pytest.mark.parametrize("k,deg", [(1, 0), (4, 1), (9, 2), (16, 3), (16, 0), (16, 2), (25, 4), (25, 3)])
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 4097])
+def test_sh_forward_backward(hip, c_oracle, k, deg, n):
+    g = torch.Generator().manual_seed(n * 31 + k)
+    dirs = torch.randn(n, 3, generator=g) * 2
+    coeffs = torch.randn(n, k, 3, generator=g)
+    v_col = torch.randn(n, 3, generator=g)
+    exp = c_oracle.sh_fwd(deg, dirs, coeffs)
+    cd = coeffs.to(DEV).requires_grad_(True)
+    got = hip.spherical_harmonics(deg, dirs.to(DEV), cd)
+    assert (got.cpu() - exp).abs().max() < 2e-5                 # fp32 sum of <=25 products, |terms| ~ 1
+    got.backward(v_col.to(DEV))
+    expb = c_oracle.sh_bwd(deg, k, dirs, v_col)
+    assert (cd.grad.cpu() - expb).abs().max() < 2e-6
+    assert (cd.grad[:, (deg + 1) ** 2:, :] == 0).all()          # inactive bands: exact zeros
+
+
+# ------------------------------------------------------------------ binning
+@pytest.mark.parametrize("n", [1, 5, 2047, 2048, 2049, 100_000, 1_000_003])
+def test_scan_bit_exact(hip, n):
+    g = torch.Generator().manual_seed(n)
+    x = torch.randint(0, 40, (n,), generator=g, dtype=torch.int32)
+    total, cum = hip.compute_cumulative_intersects(x.to(DEV))
+    ref = torch.cumsum(x, 0, dtype=torch.int32)
+    assert torch.equal(cum.cpu(), ref) and total == int(ref[-1])
+
+
+def test_map_intersects_bit_exact_including_big_splats(hip, c_oracle):
+    cam, P = small_scene(n=6000, w=320, h=200)
+    P["log_scales"][:40] += 3.0       # a few huge splats: > 32 tiles -> wave-cooperative emission path
+    xys, depths, radii, conics, comp, nth, cov3d = c_oracle.project_fwd(*_project_args(cam, P))
+    assert int(nth.max()) > 64
+    cum = c_oracle.scan_i32(nth)
+    tx, ty = (cam.width + 15) // 16, (cam.height + 15) // 16
+    ek, ev = c_oracle.map_isect(xys, depths, radii, cum, tx, ty, 16)
+    gk, gv = hip.map_gaussian_to_intersects(xys.shape[0], int(cum[-1]), xys.to(DEV), depths.to(DEV),
+                                            radii.to(DEV), cum.to(DEV), (tx, ty, 1), 16)
+    assert torch.equal(gk.cpu(), ek) and torch.equal(gv.cpu(), ev)
+
+
+@pytest.mark.parametrize("n", [1, 2, 100, 4095, 4096, 4097, 12289, 300_000])
+def test_sort_bit_exact_and_stable(hip, n):
+    from sgn_rast import ops
+    g = torch.Generator().manual_seed(n)
+    n_tiles = 9600
+    tile = torch.randint(0, n_tiles, (n,), generator=g, dtype=torch.int64)
+    # few distinct depths -> many (tile, depth) ties: stability decides the payload order
+    depth = torch.randint(0, 50, (n,), generator=g, dtype=torch.int64) * 1_000_003 + 0x3F000000
+    keys = (tile << 32) | depth
+    vals = torch.arange(n, dtype=torch.int32)
+    ks, vs = ops.sort_intersects(keys.to(DEV), vals.to(DEV), n_tiles)
+    rk, order = torch.sort(keys, stable=True)
+    assert torch.equal(ks.cpu(), rk)
+    assert torch.equal(vs.cpu(), vals[order])
+
+
+def test_sort_full_key_range_bits(hip):
+    """sgn_sort_pairs over an explicit bit range equals a full sort when the other bits are equal."""
+    from sgn_rast import _lib as L
+    n = 50_000
+    g = torch.Generator().manual_seed(9)
+    keys = torch.randint(0, 2 ** 40, (n,), generator=g, dtype=torch.int64)
+    vals = torch.arange(n, dtype=torch.int32)
+    kd, vd = keys.to(DEV), vals.to(DEV)
+    ko, vo = torch.empty_like(kd), torch.empty_like(vd)
+    lib = L.load()
+    ws = L.workspace(lib.sgn_sort_workspace_bytes(n), kd.device)
+    for end_bit in (40, 41, 47, 64):      # 5, 6, 6, 8 passes: both ping-pong parities
+        L.check(lib.sgn_sort_pairs(n, 0, end_bit, L.ptr(kd), L.ptr(vd), L.ptr(ko), L.ptr(vo), L.ptr(ws),
+                                   ws.numel(), L.stream_ptr()), "sort")
+        rk, order = torch.sort(keys, stable=True)
+        assert torch.equal(ko.cpu(), rk) and torch.equal(vo.cpu(), vals[order]), end_bit
+
+
+def test_bin_and_sort_pipeline_bit_exact(hip, c_oracle):
+    cam, P = small_scene(n=30000, w=640, h=360, focal=500.0)
+    xys, depths, radii, conics, comp, nth, cov3d = c_oracle.project_fwd(*_project_args(cam, P))
+    cum, keys, vals, ks, vs, bins = c_oracle.bin_and_sort(xys, depths, radii, nth, cam.height, cam.width, 16)
+    tb = ((cam.width + 15) // 16, (cam.height + 15) // 16, 1)
+    I, cum_d = hip.compute_cumulative_intersects(nth.to(DEV))
+    assert I == keys.numel() and torch.equal(cum_d.cpu(), cum)
+    gk, gv, gks, gvs, gbins = hip.bin_and_sort_gaussians(
+        xys.shape[0], I, xys.to(DEV), depths.to(DEV), radii.to(DEV), cum_d, tb, 16)
+    assert torch.equal(gk.cpu(), keys) and torch.equal(gv.cpu(), vals)
+    assert torch.equal(gks.cpu(), ks), "sorted (tile|depth) keys must be bit-exact"
+    assert torch.equal(gvs.cpu(), vs), "gaussian_ids_sorted must be bit-exact (stable ties)"
+    assert torch.equal(gbins.cpu(), bins)
+
+
+# ---------------------------------------------------------------- rasterize
+def _raster_inputs(c_oracle, cam, P, block=16, seed=2):
+    scales, quats, opac, coeffs = activated(P)
+    xys, depths, radii, conics, comp, nth, cov3d = c_oracle.project_fwd(*_project_args(cam, P, block))
+    _, _, _, _, vs, bins = c_oracle.bin_and_sort(xys, depths, radii, nth, cam.height, cam.width, block)
+    rgb = torch.clamp(c_oracle.sh_fwd(3, P["means"], coeffs) + 0.5, min=0)
+    g = torch.Generator().manual_seed(seed)
+    v_img = torch.randn(cam.height, cam.width, 3, generator=g)
+    v_alpha = torch.randn(cam.height, cam.width, generator=g)
+    return dict(xys=xys, depths=depths, radii=radii, conics=conics, nth=nth, rgb=rgb, opac=opac, ids=vs,
+                bins=bins, v_img=v_img, v_alpha=v_alpha)
+
+
+def _hip_raster(hip, cam, R, block, bg, need_grad=True):
+    d = {k: v.to(DEV) for k, v in R.items()}
+    leaves = dict(xys=d["xys"].clone().requires_grad_(need_grad), conics=d["conics"].clone().requires_grad_(need_grad),
+                  rgb=d["rgb"].clone().requires_grad_(need_grad), opac=d["opac"].clone().requires_grad_(need_grad))
+    img, alpha = hip.rasterize_gaussians(leaves["xys"], d["depths"], d["radii"], leaves["conics"], d["nth"],
+                                         leaves["rgb"], leaves["opac"], cam.height, cam.width, block,
+                                         background=bg.to(DEV), return_alpha=True)
+    return img, alpha, leaves, d
+
+
+@pytest.mark.parametrize("block,size", [(16, (128, 128)), (16, (130, 70)), (8, (100, 60)), (5, (64, 37)), (2, (20, 12))])
+def test_rasterize_forward_fast_exp(hip, c_oracle, block, size):
+    cam, P = small_scene(n=3000, w=size[0], h=size[1], focal=float(size[0]))
+    R = _raster_inputs(c_oracle, cam, P, block)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    exp_img, exp_T, exp_idx = c_oracle.raster_fwd(cam.height, cam.width, block, R["ids"], R["bins"], R["xys"],
+                                                  R["conics"], R["rgb"], R["opac"], bg)
+    img, alpha, _, _ = _hip_raster(hip, cam, R, block, bg, need_grad=False)
+    err = (img.cpu() - exp_img).abs()
+    # hardware v_exp_f32 vs libm expf differ by ~1 ulp: ordinary pixels agree to 1e-5; a pixel whose
+    # alpha >= 1/255 or T <= 1e-4 test sits on the threshold may flip one Gaussian (<= 1/255 * colour)
+    assert float(err.mean()) < 1e-6
+    assert float((err > 1e-5).float().mean()) < 2e-3
+    assert float(err.max()) < 2e-2
+    assert float((alpha.cpu() - (1 - exp_T)).abs().max()) < 2e-2
+    assert float(((alpha.cpu() - (1 - exp_T)).abs() > 1e-5).float().mean()) < 2e-3
+
+
+@pytest.mark.parametrize("block,size", [(16, (128, 128)), (16, (130, 70)), (7, (64, 37))])
+def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, size):
+    """With both sides on the portable polynomial exp, the whole forward (image, final T, index of
+    the last contributing Gaussian) must agree bit for bit: same op order, same decisions."""
+    from sgn_rast import _lib as L
+    cam, P = small_scene(n=3000, w=size[0], h=size[1], focal=float(size[0]))
+    R = _raster_inputs(c_oracle, cam, P, block)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    c_oracle.set_exp_mode(1)
+    L.load().sgn_set_exact_exp(1)
+    try:
+        exp_img, exp_T, exp_idx = c_oracle.raster_fwd(cam.height, cam.width, block, R["ids"], R["bins"], R["xys"],
+                                                      R["conics"], R["rgb"], R["opac"], bg)
+        d = {k: v.to(DEV) for k, v in R.items()}
+        from sgn_rast import ops
+        tb = ((cam.width + block - 1) // block, (cam.height + block - 1) // block, 1)
+        lib = L.load()
+        I = R["ids"].numel()
+        out_img = torch.empty(cam.height, cam.width, 3, device=DEV)
+        fT = torch.empty(cam.height, cam.width, device=DEV)
+        fi = torch.empty(cam.height, cam.width, dtype=torch.int32, device=DEV)
+        recs = L.workspace(lib.sgn_raster_workspace_bytes(I), out_img.device)
+        L.check(lib.sgn_raster_fwd(cam.height, cam.width, block, I, L.ptr(d["ids"]), L.ptr(d["bins"]),
+                                   L.ptr(d["xys"]), L.ptr(d["conics"]), L.ptr(d["rgb"]),
+                                   L.ptr(d["opac"].reshape(-1).contiguous()), L.ptr(bg.to(DEV)), L.ptr(out_img),
+                                   L.ptr(fT), L.ptr(fi), L.ptr(recs), recs.numel(), L.stream_ptr()), "raster_fwd")
+        assert torch.equal(fi.cpu(), exp_idx)
+        assert torch.equal(fT.cpu(), exp_T)
+        assert torch.equal(out_img.cpu(), exp_img)
+    finally:
+        c_oracle.set_exp_mode(0)
+        L.load().sgn_set_exact_exp(0)
+
+
+@pytest.mark.parametrize("block,size", [(16, (128, 128)), (16, (130, 70)), (8, (100, 60))])
+@pytest.mark.parametrize("clamp", [0.99, 0.999])
+def test_rasterize_backward(hip, c_oracle, block, size, clamp):
+    from sgn_rast import ops
+    cam, P = small_scene(n=3000, w=size[0], h=size[1], focal=float(size[0]))
+    P["opacity_logits"][:200] = 9.0   # opacity ~0.9999: exercises the 0.999 (fwd) / 0.99 (bwd) clamps
+    R = _raster_inputs(c_oracle, cam, P, block)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    ops.set_alpha_clamp_bwd(clamp)
+    try:
+        img, alpha, leaves, d = _hip_raster(hip, cam, R, block, bg)
+        torch.autograd.backward([img, alpha], [d["v_img"], d["v_alpha"]])
+    finally:
+        ops.set_alpha_clamp_bwd(ops.UPSTREAM_ALPHA_CLAMP_BWD)
+    # oracle backward from the oracle's own forward state
+    exp_img, exp_T, exp_idx = c_oracle.raster_fwd(cam.height, cam.width, block, R["ids"], R["bins"], R["xys"],
+                                                  R["conics"], R["rgb"], R["opac"], bg)
+    e_xy, e_con, e_col, e_op = c_oracle.raster_bwd(
+        cam.height, cam.width, block, R["ids"], R["bins"], R["xys"], R["conics"], R["rgb"], R["opac"], bg,
+        exp_T, exp_idx, R["v_img"], R["v_alpha"], clamp)
+    # fp32 atomics in arbitrary order + 1-ulp exp vs a double-accumulating oracle: rel-L2 <= 1e-4
+    # (SURVEY.md §8c); threshold flips of single pixels stay far below that in the norm
+    assert rel_l2(leaves["xys"].grad.cpu(), e_xy) < 1e-4
+    assert rel_l2(leaves["conics"].grad.cpu(), e_con) < 1e-4
+    assert rel_l2(leaves["rgb"].grad.cpu(), e_col) < 1e-4
+    assert rel_l2(leaves["opac"].grad.cpu(), e_op) < 1e-4
+    assert leaves["opac"].grad.shape == R["opac"].shape   # [N,1] like the input
+
+
+def test_rasterize_no_intersections(hip):
+    n = 16
+    bg = torch.tensor([0.3, 0.6, 0.9], device=DEV)
+    z = lambda *s, dt=torch.float32: torch.zeros(*s, dtype=dt, device=DEV)
+    col = torch.rand(n, 3, device=DEV, requires_grad=True)
+    img, alpha = hip.rasterize_gaussians(z(n, 2), z(n), z(n, dt=torch.int32), z(n, 3), z(n, dt=torch.int32), col,
+                                         torch.rand(n, 1, device=DEV), 40, 50, 16, background=bg, return_alpha=True)
+    assert torch.equal(img, bg.expand(40, 50, 3)) and float(alpha.abs().max()) == 0.0
+    img.sum().backward()
+    assert float(col.grad.abs().max()) == 0.0
+    img1 = hip.rasterize_gaussians(z(n, 2), z(n), z(n, dt=torch.int32), z(n, 3), z(n, dt=torch.int32), col.detach(),
+                                   torch.rand(n, 1, device=DEV), 40, 50, 16)     # default background = ones
+    assert torch.equal(img1, torch.ones(40, 50, 3, device=DEV))
+
+
+def test_uint8_colors_and_single_output(hip, c_oracle):
+    cam, P = small_scene(n=1500)
+    R = _raster_inputs(c_oracle, cam, P)
+    col8 = (R["rgb"].clamp(0, 1) * 255).to(torch.uint8)
+    bg = torch.zeros(3)
+    exp_img, _, _ = c_oracle.raster_fwd(cam.height, cam.width, 16, R["ids"], R["bins"], R["xys"], R["conics"],
+                                        col8.float() / 255, R["opac"], bg)
+    d = {k: v.to(DEV) for k, v in R.items()}
+    img = hip.rasterize_gaussians(d["xys"], d["depths"], d["radii"], d["conics"], d["nth"], col8.to(DEV), d["opac"],
+                                  cam.height, cam.width, 16, bg.to(DEV))
+    assert isinstance(img, torch.Tensor) and img.shape == (cam.height, cam.width, 3)
+    assert float((img.cpu() - exp_img).abs().mean()) < 1e-6
