@@ -41,21 +41,27 @@ def parse():
     ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=2, help="tile rows rendered by the CPU baseline sample")
+    ap.add_argument("--cpu-frac", type=int, default=8, help="CPU baseline uses the first N/frac Gaussians of the scene")
     ap.add_argument("--cpu-timeout", type=float, default=150.0, help="wall-clock bound of the CPU baseline leg [s]")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--with-depth", action="store_true", help="add the reference's depth pass (:982-996)")
     return ap.parse_args()
 
 
-def cpu_baseline(scene: str, n_override: int, rows: int):
+def cpu_baseline(scene: str, n_override: int, rows: int, frac: int = 8):
     """Pure-PyTorch tile-vectorised rasterizer (oracle/torch_oracle.py, fp32) on the host cores.
-    Bounded sample: whole-scene projection + SH + binning (fwd+bwd), compositing fwd+bwd for `rows`
-    of the tile rows around the image centre; the compositing time is scaled to all tile rows."""
+    Bounded sample of the same workload: the first N/frac Gaussians of the scene at full resolution
+    (per-Gaussian work and the intersection count both scale linearly with N for this i.i.d. scene);
+    projection + SH + binning for all of them (fwd+bwd), compositing fwd+bwd for `rows` of the tile
+    rows around the image centre.  Reported time = (fixed + compositing x tile_rows/rows) x frac."""
     from oracle import torch_oracle as TO
     from sgn_rast import scenes, step
     cores = min(os.cpu_count() or 1, 32)  # torch intra-op threads actually used
     torch.set_num_threads(cores)
     cam, raw = scenes.make_scene(scene, n_override=n_override)
+    n_full = raw["means"].shape[0]
+    n_s = max(1, n_full // max(1, frac))
+    raw = {k: v[:n_s].contiguous() for k, v in raw.items()}
     P = step.leaf_params(raw)
     tiles_y = (cam.height + 15) // 16
     rows = min(rows, tiles_y)
@@ -93,12 +99,13 @@ def cpu_baseline(scene: str, n_override: int, rows: int):
     frac = comp_fwd / max(t_fwd, 1e-9)
     comp_bwd, fixed_bwd = t_bwd * frac, t_bwd * (1 - frac)
     scale = tiles_y / rows
-    t_full = fixed_fwd + fixed_bwd + (comp_fwd + comp_bwd) * scale
+    t_full = (fixed_fwd + fixed_bwd + (comp_fwd + comp_bwd) * scale) * (n_full / n_s)
     return {
         "value": 1.0 / t_full, "unit": "images/sec", "cores": cores, "kind": "port",
-        "sample": (f"pure-PyTorch fp32 oracle, scene '{scene}' N={P['means'].shape[0]} {cam.width}x{cam.height}: "
-                   f"projection+SH+binning for the whole scene, compositing fwd+bwd on {rows}/{tiles_y} tile rows "
-                   f"(measured {t_fwd + t_bwd:.1f}s), compositing share scaled x{scale:.1f} -> {t_full:.1f}s/step"),
+        "sample": (f"pure-PyTorch fp32 oracle, scene '{scene}' {cam.width}x{cam.height}: first {n_s} of {n_full} "
+                   f"Gaussians (projection+SH+binning fwd+bwd), compositing fwd+bwd on {rows}/{tiles_y} tile rows "
+                   f"(measured {t_fwd + t_bwd:.1f}s); compositing share x{scale:.1f}, then x{n_full / n_s:.1f} "
+                   f"for the Gaussian subsample -> {t_full:.1f}s/step"),
     }
 
 
@@ -107,7 +114,7 @@ def cpu_baseline_bounded(args):
     stall the GPU run (the default bench must finish within minutes)."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--scene", args.scene, "--n", str(args.n),
-           "--cpu-rows", str(args.cpu_rows)]
+           "--cpu-rows", str(args.cpu_rows), "--cpu-frac", str(args.cpu_frac)]
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout)
         for ln in reversed(out.stdout.strip().splitlines()):
@@ -122,7 +129,7 @@ def cpu_baseline_bounded(args):
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(args.scene, args.n, args.cpu_rows)), flush=True)
+        print(json.dumps(cpu_baseline(args.scene, args.n, args.cpu_rows, args.cpu_frac)), flush=True)
         return
     from sgn_rast import _lib as L, dp, scenes, step
     if not torch.cuda.is_available():

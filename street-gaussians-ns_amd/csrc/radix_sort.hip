@@ -1,19 +1,21 @@
-// radix_sort.hip — on-device stable LSD radix sort of (int64 key, int32 value) pairs, gfx950.
+// radix_sort.hip — on-device stable LSD radix sorts, gfx950.
 //
 // Replaces `torch.sort(isect_ids)` + `torch.gather(gaussian_ids)` (CUB radix sort) inside
 // gsplat/utils.py:bin_and_sort_gaussians, reached from the reference through
-// rasterize_gaussians (sgn_splatfacto.py:954-967, :982-994).  Stable => equal (tile, depth) keys
-// keep emission order exactly like upstream, so gaussian_ids_sorted is bit-exact.
+// rasterize_gaussians (sgn_splatfacto.py:954-967, :982-994).  Stable => equal keys keep their input
+// order exactly like upstream, so gaussian_ids_sorted is bit-exact.
 //
-// Shape: 8-bit digits, three kernels per pass —
+// One template, three instantiations:
+//   <u64, int32 payload, 8-bit digits>  sgn_sort_pairs    upstream-shaped (tile<<32|depth, gaussian id)
+//   <u32, int32 payload, 8-bit digits>  sgn_sort_pairs32  per-Gaussian depth ranking (fused path)
+//   <u64, no payload,    9-bit digits>  sgn_sort_keys64   (tile<<rank_bits|depth_rank) keys (fused path)
+// Three kernels per pass —
 //   rs_hist    per-tile (4096 keys) digit histogram in LDS            -> table[digit][tile]
 //   rs_scan    one workgroup per digit: exclusive scan of its row     -> table (in place), total[digit]
-//   rs_scatter per tile: wave64 ballot "match" ranking (8 ballots/key, stable inside a wave),
-//              per-wave LDS counters, cross-wave prefix, then the tile is reordered in LDS so the
+//   rs_scatter per tile: wave64 ballot "match" ranking (one ballot per digit bit, stable inside a
+//              wave), per-wave LDS counters, cross-wave prefix, then the tile is reordered in LDS so the
 //              global stores of one digit are consecutive lanes -> consecutive addresses.
-// HBM traffic per key per pass: 8 (hist) + 12 (read) + 12 (write) = 32 B; the caller restricts the
-// sort to the significant bits (32 depth bits + ceil(log2(n_tiles)) tile bits: 6 passes at
-// 1920x1280/16 instead of 8).
+// HBM traffic per key per pass: sizeof(key) (hist) + 2 * (sizeof(key) + payload).
 #include "sgn_common.h"
 
 namespace {
@@ -24,24 +26,27 @@ constexpr int RS_IPT = 16;                     // keys per thread
 constexpr int RS_TILE = RS_THREADS * RS_IPT;   // 4096 keys per workgroup
 constexpr int RS_WAVE_ITEMS = 64 * RS_IPT;     // 1024 keys per wave
 
-__device__ __forceinline__ unsigned digit_of(uint64_t key, int shift, unsigned mask) {
+template <typename K>
+__device__ __forceinline__ unsigned digit_of(K key, int shift, unsigned mask) {
     return (unsigned)(key >> shift) & mask;
 }
 
-__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(uint32_t n, const uint64_t *__restrict__ keys,
-                                                             int shift, unsigned dmask, uint32_t nblk,
+template <typename K, int BITS>
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(uint32_t n, const K *__restrict__ keys, int shift,
+                                                             unsigned dmask, uint32_t nblk,
                                                              uint32_t *__restrict__ table) {
-    __shared__ uint32_t hist[256];
-    hist[threadIdx.x] = 0;
+    constexpr int NB = 1 << BITS;
+    __shared__ uint32_t hist[NB];
+    for (int d = threadIdx.x; d < NB; d += RS_THREADS) hist[d] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE;
 #pragma unroll
     for (int k = 0; k < RS_IPT; ++k) {
         const uint32_t i = base + k * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&hist[digit_of(keys[i], shift, dmask)], 1u);
+        if (i < n) atomicAdd(&hist[digit_of<K>(keys[i], shift, dmask)], 1u);
     }
     __syncthreads();
-    table[threadIdx.x * nblk + blockIdx.x] = hist[threadIdx.x];
+    for (int d = threadIdx.x; d < NB; d += RS_THREADS) table[(size_t)d * nblk + blockIdx.x] = hist[d];
 }
 
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
@@ -71,7 +76,8 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *ld
     return w + off - v;
 }
 
-// grid = 256 (one workgroup per digit): table[d][0..nblk) -> exclusive prefix, total[d] = row sum
+// grid = number of digits (one workgroup per digit): table[d][0..nblk) -> exclusive prefix,
+// totals[d] = row sum
 __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t nblk, uint32_t *__restrict__ table,
                                                              uint32_t *__restrict__ totals) {
     __shared__ uint32_t lds4[4];
@@ -88,25 +94,31 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t nblk, uint
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+template <typename K, bool HAS_VAL, int BITS>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
-    uint32_t n, const uint64_t *__restrict__ keys_in, const int32_t *__restrict__ vals_in,
-    uint64_t *__restrict__ keys_out, int32_t *__restrict__ vals_out, int shift, unsigned dmask,
-    uint32_t nblk, const uint32_t *__restrict__ table, const uint32_t *__restrict__ totals) {
-    __shared__ uint64_t skeys[RS_TILE];
-    __shared__ int32_t svals[RS_TILE];
-    __shared__ uint32_t wcnt[RS_WAVES][256];
-    __shared__ uint32_t dstart[256];
-    __shared__ uint32_t gbase[256];
+    uint32_t n, const K *__restrict__ keys_in, const int32_t *__restrict__ vals_in, K *__restrict__ keys_out,
+    int32_t *__restrict__ vals_out, int shift, unsigned dmask, uint32_t nblk, const uint32_t *__restrict__ table,
+    const uint32_t *__restrict__ totals) {
+    constexpr int NB = 1 << BITS;
+    constexpr int DPT = NB / RS_THREADS;  // digits owned per thread in the prefix phase (1 or 2)
+    static_assert(NB % RS_THREADS == 0, "digit count must be a multiple of the block size");
+    __shared__ K skeys[RS_TILE];
+    __shared__ int32_t svals[HAS_VAL ? RS_TILE : 1];
+    __shared__ uint32_t wcnt[RS_WAVES][NB];
+    __shared__ uint32_t dstart[NB];
+    __shared__ uint32_t gbase[NB];
     __shared__ uint32_t lds4[4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tile_base = blockIdx.x * RS_TILE;
     const uint32_t tile_cnt = min((uint32_t)RS_TILE, n - tile_base);
 #pragma unroll
-    for (int w = 0; w < RS_WAVES; ++w) wcnt[w][tid] = 0;
+    for (int w = 0; w < RS_WAVES; ++w)
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) wcnt[w][tid * DPT + j] = 0;
     __syncthreads();
 
-    uint64_t key[RS_IPT];
+    K key[RS_IPT];
     int32_t val[RS_IPT];
     uint32_t rank[RS_IPT];
     volatile uint32_t *mycnt = wcnt[wave];
@@ -115,12 +127,12 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     for (int r = 0; r < RS_IPT; ++r) {
         const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;  // index inside the tile
         const bool valid = li < tile_cnt;
-        key[r] = valid ? keys_in[tile_base + li] : ~0ull;
-        val[r] = valid ? vals_in[tile_base + li] : 0;
-        const unsigned d = digit_of(key[r], shift, dmask);
+        key[r] = valid ? keys_in[tile_base + li] : (K)~(K)0;
+        if constexpr (HAS_VAL) val[r] = valid ? vals_in[tile_base + li] : 0;
+        const unsigned d = digit_of<K>(key[r], shift, dmask);
         unsigned long long m = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
+        for (int b = 0; b < BITS; ++b) {
             const bool bit = (d >> b) & 1u;
             const unsigned long long vote = __ballot(valid && bit);
             m &= bit ? vote : ~vote;
@@ -136,29 +148,44 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     }
     __syncthreads();
 
-    // thread t owns digit t: turn per-wave counts into exclusive per-wave offsets + digit total
-    uint32_t tot = 0;
+    // thread t owns digits [t*DPT, t*DPT+DPT): per-wave counts -> exclusive per-wave offsets + totals
+    uint32_t tot[DPT], gtot[DPT], tsum = 0, gsum = 0;
 #pragma unroll
-    for (int w = 0; w < RS_WAVES; ++w) {
-        const uint32_t c = wcnt[w][tid];
-        wcnt[w][tid] = tot;
-        tot += c;
+    for (int j = 0; j < DPT; ++j) {
+        const int d = tid * DPT + j;
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < RS_WAVES; ++w) {
+            const uint32_t c = wcnt[w][d];
+            wcnt[w][d] = t;
+            t += c;
+        }
+        tot[j] = t;
+        gtot[j] = totals[d];
+        tsum += t;
+        gsum += gtot[j];
     }
     uint32_t dummy;
-    const uint32_t dst = block_excl_scan_u32(tot, lds4, dummy);        // start of digit t inside the tile
-    const uint32_t gst = block_excl_scan_u32(totals[tid], lds4, dummy);  // global start of digit t
-    dstart[tid] = dst;
-    gbase[tid] = gst + table[(size_t)tid * nblk + blockIdx.x] - dst;   // global pos = gbase[d] + local pos
+    uint32_t dst = block_excl_scan_u32(tsum, lds4, dummy);  // start of this thread's first digit in the tile
+    uint32_t gst = block_excl_scan_u32(gsum, lds4, dummy);  // global start of this thread's first digit
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+        const int d = tid * DPT + j;
+        dstart[d] = dst;
+        gbase[d] = gst + table[(size_t)d * nblk + blockIdx.x] - dst;  // global pos = gbase[d] + local pos
+        dst += tot[j];
+        gst += gtot[j];
+    }
     __syncthreads();
 
 #pragma unroll
     for (int r = 0; r < RS_IPT; ++r) {
         const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;
         if (li < tile_cnt) {
-            const unsigned d = digit_of(key[r], shift, dmask);
+            const unsigned d = digit_of<K>(key[r], shift, dmask);
             const uint32_t lp = dstart[d] + wcnt[wave][d] + rank[r];
             skeys[lp] = key[r];
-            svals[lp] = val[r];
+            if constexpr (HAS_VAL) svals[lp] = val[r];
         }
     }
     __syncthreads();
@@ -166,24 +193,70 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     for (int k = 0; k < RS_IPT; ++k) {
         const uint32_t lp = k * RS_THREADS + tid;
         if (lp < tile_cnt) {
-            const uint64_t kk = skeys[lp];
-            const uint32_t pos = gbase[digit_of(kk, shift, dmask)] + lp;
+            const K kk = skeys[lp];
+            const uint32_t pos = gbase[digit_of<K>(kk, shift, dmask)] + lp;
             keys_out[pos] = kk;
-            vals_out[pos] = svals[lp];
+            if constexpr (HAS_VAL) vals_out[pos] = svals[lp];
         }
     }
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+template <typename K, bool HAS_VAL, int BITS>
+size_t sort_ws_bytes(int64_t n) {
+    if (n <= 0) return 256;
+    const size_t nblk = (size_t)sgn_cdiv(n, RS_TILE);
+    return align256((size_t)n * sizeof(K)) + (HAS_VAL ? align256((size_t)n * 4) : 0) +
+           align256(((size_t)1 << BITS) * nblk * 4) + align256(((size_t)1 << BITS) * 4);
+}
+
+// ping-pong LSD passes; the last pass lands in keys_out / vals_out
+template <typename K, bool HAS_VAL, int BITS>
+void sort_launch(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const int32_t *vals_in, K *keys_out,
+                 int32_t *vals_out, void *ws, hipStream_t s) {
+    constexpr int NB = 1 << BITS;
+    const uint32_t nblk = (uint32_t)sgn_cdiv(n, RS_TILE);
+    char *p = (char *)ws;
+    K *alt_keys = (K *)p; p += align256((size_t)n * sizeof(K));
+    int32_t *alt_vals = nullptr;
+    if (HAS_VAL) { alt_vals = (int32_t *)p; p += align256((size_t)n * 4); }
+    uint32_t *table = (uint32_t *)p; p += align256((size_t)NB * nblk * 4);
+    uint32_t *totals = (uint32_t *)p;
+    const int npass = (end_bit - begin_bit + BITS - 1) / BITS;
+    const K *src_k = keys_in;
+    const int32_t *src_v = vals_in;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = begin_bit + BITS * pass;
+        const int bits = (end_bit - shift) < BITS ? (end_bit - shift) : BITS;
+        const unsigned dmask = (1u << bits) - 1u;
+        const bool to_out = ((npass - 1 - pass) % 2) == 0;
+        K *dst_k = to_out ? keys_out : alt_keys;
+        int32_t *dst_v = to_out ? vals_out : alt_vals;
+        hipLaunchKernelGGL((rs_hist_kernel<K, BITS>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, shift, dmask,
+                           nblk, table);
+        hipLaunchKernelGGL(rs_scan_kernel, dim3(NB), dim3(RS_THREADS), 0, s, nblk, table, totals);
+        hipLaunchKernelGGL((rs_scatter_kernel<K, HAS_VAL, BITS>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, src_v,
+                           dst_k, dst_v, shift, dmask, nblk, table, totals);
+        src_k = dst_k;
+        src_v = dst_v;
+    }
+}
+
 }  // namespace
 
-SGN_EXPORT size_t sgn_sort_workspace_bytes(int64_t n_isect) {
-    if (n_isect <= 0) return 256;
-    const size_t nblk = (size_t)sgn_cdiv(n_isect, RS_TILE);
-    return align256((size_t)n_isect * 8) + align256((size_t)n_isect * 4) + align256(256 * nblk * 4) +
-           align256(256 * 4);
+// internal (fused binning path, binning.hip)
+size_t sgn_sort_keys64_ws_bytes(int64_t n) { return sort_ws_bytes<uint64_t, false, 9>(n); }
+size_t sgn_sort_pairs32_ws_bytes(int64_t n) { return sort_ws_bytes<uint32_t, true, 8>(n); }
+void sgn_sort_keys64_launch(uint32_t n, int end_bit, const uint64_t *in, uint64_t *out, void *ws, hipStream_t s) {
+    sort_launch<uint64_t, false, 9>(n, 0, end_bit, in, nullptr, out, nullptr, ws, s);
 }
+void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const int32_t *vin, uint32_t *kout,
+                             int32_t *vout, void *ws, hipStream_t s) {
+    sort_launch<uint32_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s);
+}
+
+SGN_EXPORT size_t sgn_sort_workspace_bytes(int64_t n_isect) { return sort_ws_bytes<uint64_t, true, 8>(n_isect); }
 
 SGN_EXPORT int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const int64_t *keys_in,
                               const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out, void *ws,
@@ -195,32 +268,9 @@ SGN_EXPORT int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const
     SGN_ARG_CHECK(ws_bytes >= sgn_sort_workspace_bytes(n_isect), -4);
     SGN_ARG_CHECK((const void *)keys_in != (const void *)keys_out && vals_in != vals_out, -5);
     hipStream_t s = (hipStream_t)stream;
-    const uint32_t n = (uint32_t)n_isect;
-    const uint32_t nblk = (uint32_t)sgn_cdiv(n_isect, RS_TILE);
-    char *p = (char *)ws;
-    uint64_t *alt_keys = (uint64_t *)p; p += align256((size_t)n * 8);
-    int32_t *alt_vals = (int32_t *)p;   p += align256((size_t)n * 4);
-    uint32_t *table = (uint32_t *)p;    p += align256((size_t)256 * nblk * 4);
-    uint32_t *totals = (uint32_t *)p;
-
-    const int npass = (end_bit - begin_bit + 7) / 8;
-    const uint64_t *src_k = (const uint64_t *)keys_in;
-    const int32_t *src_v = vals_in;
     sgn_timing_begin(SGN_T_SORT, s);
-    for (int pass = 0; pass < npass; ++pass) {
-        const int shift = begin_bit + 8 * pass;
-        const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
-        const unsigned dmask = (1u << bits) - 1u;
-        const bool to_out = ((npass - 1 - pass) % 2) == 0;  // last pass lands in keys_out / vals_out
-        uint64_t *dst_k = to_out ? (uint64_t *)keys_out : alt_keys;
-        int32_t *dst_v = to_out ? vals_out : alt_vals;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, shift, dmask, nblk, table);
-        hipLaunchKernelGGL(rs_scan_kernel, dim3(256), dim3(RS_THREADS), 0, s, nblk, table, totals);
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, src_v, dst_k, dst_v,
-                           shift, dmask, nblk, table, totals);
-        src_k = dst_k;
-        src_v = dst_v;
-    }
+    sort_launch<uint64_t, true, 8>((uint32_t)n_isect, begin_bit, end_bit, (const uint64_t *)keys_in, vals_in,
+                                   (uint64_t *)keys_out, vals_out, ws, s);
     sgn_timing_end(SGN_T_SORT, s);
     SGN_LAUNCH_CHECK();
     return 0;

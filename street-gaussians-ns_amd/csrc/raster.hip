@@ -62,23 +62,34 @@ __device__ __forceinline__ float sgn_exp(float x) {
     else return __expf(x);
 }
 
-// thread per intersection: gather the per-Gaussian operands into the depth-ordered record stream
-__global__ __launch_bounds__(256) void pack_records_kernel(int64_t n_isect, const int32_t *__restrict__ ids,
-                                                           const float *__restrict__ xys,
-                                                           const float *__restrict__ conics,
-                                                           const float *__restrict__ colors,
-                                                           const float *__restrict__ opac,
-                                                           float4 *__restrict__ recs) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n_isect) return;
-    const int g = ids[p];
+// Packing is two streaming kernels: (1) per-Gaussian AoS rows (coalesced, N x 48 B), (2) a pure
+// 16-byte-granule gather of those rows into depth order: three lanes move one record, so the
+// stores of a wave are one contiguous 1 KiB span and each gathered row is one or two cache lines
+// (instead of four separate SoA gathers per intersection).
+__global__ __launch_bounds__(256) void build_grec_kernel(int n, const float *__restrict__ xys,
+                                                         const float *__restrict__ conics,
+                                                         const float *__restrict__ colors,
+                                                         const float *__restrict__ opac,
+                                                         float4 *__restrict__ grec) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n) return;
     const float x = xys[2 * g], y = xys[2 * g + 1];
     const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
     const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
     const float o = opac[g];
-    recs[3 * p + 0] = make_float4(x, y, o, 0.5f * a);
-    recs[3 * p + 1] = make_float4(b, 0.5f * c, r, gg);
-    recs[3 * p + 2] = make_float4(bl, __int_as_float(g), 0.f, 0.f);
+    grec[3 * g + 0] = make_float4(x, y, o, 0.5f * a);
+    grec[3 * g + 1] = make_float4(b, 0.5f * c, r, gg);
+    grec[3 * g + 2] = make_float4(bl, __int_as_float(g), 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void pack_records_kernel(int64_t n_isect, const int32_t *__restrict__ ids,
+                                                           const float4 *__restrict__ grec,
+                                                           float4 *__restrict__ recs) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of one record
+    if (t >= 3 * n_isect) return;
+    const int64_t p = t / 3;
+    const int j = (int)(t - 3 * p);
+    recs[t] = grec[3 * (int64_t)ids[p] + j];
 }
 
 // pixel of (slot q, lane) inside tile (tx,ty).  block 16: four 8x8 quadrants; otherwise linear.
@@ -177,6 +188,23 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// DPP wave reduction (no LDS crossbar traffic): quad swaps, row_half_mirror, row_mirror leave every
+// lane with its 16-lane row total; row_bcast15 / row_bcast31 then fold the four rows, so the full
+// 64-lane sum is valid in lanes 48..63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_dpp_row3(float v) {
+    v += dpp_get<0xB1, 0xf>(v);   // quad_perm:[1,0,3,2]
+    v += dpp_get<0x4E, 0xf>(v);   // quad_perm:[2,3,0,1]
+    v += dpp_get<0x141, 0xf>(v);  // row_half_mirror
+    v += dpp_get<0x140, 0xf>(v);  // row_mirror
+    v += dpp_get<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
+    v += dpp_get<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
@@ -184,7 +212,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 // grad_ws row layout (12 floats / Gaussian): 0,1 v_xy | 2,3,4 v_conic | 5,6,7 v_rgb | 8 v_opacity
-template <bool EXACT>
+template <bool EXACT, int REDUCE>
 __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int tiles_x,
                                                         const int2 *__restrict__ bins,
                                                         const Rec *__restrict__ recs,
@@ -277,20 +305,29 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
             any = any || valid;
         }
         if (__ballot(any) != 0ull) {  // wave-uniform
-            g_x = wave_sum(g_x); g_y = wave_sum(g_y);
-            g_ca = wave_sum(g_ca); g_cb = wave_sum(g_cb); g_cc = wave_sum(g_cc);
-            g_r = wave_sum(g_r); g_g = wave_sum(g_g); g_b = wave_sum(g_b);
-            g_o = wave_sum(g_o);
+            constexpr int L0 = (REDUCE == 1) ? 48 : 0;  // first lane holding the totals
+            if constexpr (REDUCE == 1) {
+                g_x = wave_sum_dpp_row3(g_x); g_y = wave_sum_dpp_row3(g_y);
+                g_ca = wave_sum_dpp_row3(g_ca); g_cb = wave_sum_dpp_row3(g_cb); g_cc = wave_sum_dpp_row3(g_cc);
+                g_r = wave_sum_dpp_row3(g_r); g_g = wave_sum_dpp_row3(g_g); g_b = wave_sum_dpp_row3(g_b);
+                g_o = wave_sum_dpp_row3(g_o);
+            } else {
+                g_x = wave_sum(g_x); g_y = wave_sum(g_y);
+                g_ca = wave_sum(g_ca); g_cb = wave_sum(g_cb); g_cc = wave_sum(g_cc);
+                g_r = wave_sum(g_r); g_g = wave_sum(g_g); g_b = wave_sum(g_b);
+                g_o = wave_sum(g_o);
+            }
             float mine = g_x;
-            mine = (lane == 1) ? g_y : mine;
-            mine = (lane == 2) ? g_ca : mine;
-            mine = (lane == 3) ? g_cb : mine;
-            mine = (lane == 4) ? g_cc : mine;
-            mine = (lane == 5) ? g_r : mine;
-            mine = (lane == 6) ? g_g : mine;
-            mine = (lane == 7) ? g_b : mine;
-            mine = (lane == 8) ? g_o : mine;
-            if (lane < 9) unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + lane, mine);
+            mine = (lane == L0 + 1) ? g_y : mine;
+            mine = (lane == L0 + 2) ? g_ca : mine;
+            mine = (lane == L0 + 3) ? g_cb : mine;
+            mine = (lane == L0 + 4) ? g_cc : mine;
+            mine = (lane == L0 + 5) ? g_r : mine;
+            mine = (lane == L0 + 6) ? g_g : mine;
+            mine = (lane == L0 + 7) ? g_b : mine;
+            mine = (lane == L0 + 8) ? g_o : mine;
+            if (lane >= L0 && lane < L0 + 9)
+                unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + (lane - L0), mine);
         }
         cur = nxt;
     }
@@ -312,30 +349,36 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *_
 }
 
 int g_exact_exp = 0;
+int g_reduce_mode = 0;  // 0: ds_bpermute shuffles, 1: DPP
 
 }  // namespace
 
 SGN_EXPORT void sgn_set_exact_exp(int on) { g_exact_exp = on ? 1 : 0; }
 SGN_EXPORT int sgn_get_exact_exp(void) { return g_exact_exp; }
+SGN_EXPORT void sgn_set_reduce_mode(int mode) { g_reduce_mode = mode ? 1 : 0; }
 
-SGN_EXPORT size_t sgn_raster_workspace_bytes(int64_t n_isect) {
-    return (size_t)(n_isect > 0 ? n_isect : 1) * sizeof(Rec);
+SGN_EXPORT size_t sgn_raster_workspace_bytes(int n, int64_t n_isect) {
+    // [n_isect depth-ordered records][n per-Gaussian rows]
+    return ((size_t)(n_isect > 0 ? n_isect : 1) + (size_t)(n > 0 ? n : 1)) * sizeof(Rec);
 }
 
 SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
     return (size_t)(n > 0 ? n : 1) * SGN_RECORD_FLOATS * sizeof(float);
 }
 
-static int pack_records(int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
+static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
                         const float *colors, const float *opac, void *recs, hipStream_t s) {
+    float4 *grec = (float4 *)recs + 3 * n_isect;
     sgn_timing_begin(SGN_T_PACK, s);
-    hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, ids, xys,
-                       conics, colors, opac, (float4 *)recs);
+    hipLaunchKernelGGL(build_grec_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, conics, colors, opac,
+                       grec);
+    hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(3 * n_isect, 256)), dim3(256), 0, s, n_isect, ids, grec,
+                       (float4 *)recs);
     sgn_timing_end(SGN_T_PACK, s);
     return 0;
 }
 
-SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int64_t n_isect,
+SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
                               const float *background3, float *out_img, float *final_Ts, int32_t *final_idx,
@@ -345,9 +388,9 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int64_t n_i
     SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -3);
     SGN_ARG_CHECK(tile_bins && background3 && out_img && final_Ts && final_idx, -4);
     SGN_ARG_CHECK(n_isect == 0 || (gaussian_ids_sorted && xys && conics && colors && opacities && recs_ws), -5);
-    SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n_isect), -6);
+    SGN_ARG_CHECK(n >= 0 && recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect), -6);
     hipStream_t s = (hipStream_t)stream;
-    if (n_isect > 0) pack_records(n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, recs_ws, s);
+    if (n_isect > 0) pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, recs_ws, s);
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     if (g_exact_exp) {
         sgn_timing_begin(SGN_T_RASTER_FWD, s);
@@ -386,22 +429,21 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     if (n_isect > 0) {
         SGN_ARG_CHECK(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background3 &&
                           final_Ts && final_idx && v_out_img && v_out_alpha && recs_ws, -7);
-        SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n_isect), -8);
-        if (!recs_packed) pack_records(n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, recs_ws, s);
+        SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect), -8);
+        if (!recs_packed) pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, recs_ws, s);
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
+        sgn_timing_begin(SGN_T_RASTER_BWD, s);
+#define SGN_LAUNCH_BWD(EX, RM)                                                                                  \
+    hipLaunchKernelGGL((raster_bwd_kernel<EX, RM>), dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,       \
+                       block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3, final_Ts, \
+                       final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws)
         if (g_exact_exp) {
-            sgn_timing_begin(SGN_T_RASTER_BWD, s);
-            hipLaunchKernelGGL(raster_bwd_kernel<true>, dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,
-                               block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3,
-                               final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws);
-            sgn_timing_end(SGN_T_RASTER_BWD, s);
+            if (g_reduce_mode) SGN_LAUNCH_BWD(true, 1); else SGN_LAUNCH_BWD(true, 0);
         } else {
-            sgn_timing_begin(SGN_T_RASTER_BWD, s);
-            hipLaunchKernelGGL(raster_bwd_kernel<false>, dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,
-                               block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3,
-                               final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws);
-            sgn_timing_end(SGN_T_RASTER_BWD, s);
+            if (g_reduce_mode) SGN_LAUNCH_BWD(false, 1); else SGN_LAUNCH_BWD(false, 0);
         }
+#undef SGN_LAUNCH_BWD
+        sgn_timing_end(SGN_T_RASTER_BWD, s);
     }
     sgn_timing_begin(SGN_T_UNPACK, s);
     hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, (const float *)grad_ws, v_xy,

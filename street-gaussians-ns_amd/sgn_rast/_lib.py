@@ -22,6 +22,7 @@ SIGNATURES = {
     "sgn_last_error": (C.c_char_p, []),
     "sgn_set_exact_exp": (None, [_i]),
     "sgn_get_exact_exp": (_i, []),
+    "sgn_set_reduce_mode": (None, [_i]),
     "sgn_timing_enable": (None, [_i]),
     "sgn_timing_get": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "sgn_project_fwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f,
@@ -36,14 +37,19 @@ SIGNATURES = {
     "sgn_sort_workspace_bytes": (_sz, [_i64]),
     "sgn_sort_pairs": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_tile_bins": (_i, [_i64, _vp, _i, _vp, _vp]),
-    "sgn_raster_workspace_bytes": (_sz, [_i64]),
-    "sgn_raster_fwd": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_bin_prepare_workspace_bytes": (_sz, [_i]),
+    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_bin_intersect_workspace_bytes": (_sz, [_i64]),
+    "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_raster_workspace_bytes": (_sz, [_i, _i64]),
+    "sgn_raster_fwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_raster_bwd_workspace_bytes": (_sz, [_i]),
     "sgn_raster_bwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f,
                             _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp]),
 }
 
 _lib = None
+DEFAULT_REDUCE_MODE = int(os.environ.get("SGN_REDUCE_MODE", "0"))
 
 
 class SgnRastError(RuntimeError):
@@ -63,6 +69,7 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
+        lib.sgn_set_reduce_mode(DEFAULT_REDUCE_MODE)
         _lib = lib
     return _lib
 

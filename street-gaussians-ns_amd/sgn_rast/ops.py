@@ -229,6 +229,38 @@ def bin_and_sort_gaussians(num_points, num_intersects, xys, depths, radii, cum_t
     return isect_ids, gaussian_ids, isect_ids_sorted, gaussian_ids_sorted, tile_bins
 
 
+def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width):
+    """The binning rasterize_gaussians actually runs: depth-rank the Gaussians, sort payload-free
+    (tile << rank_bits | rank) keys, emit gaussian_ids_sorted + tile_bins.  Bit-identical to
+    compute_cumulative_intersects + bin_and_sort_gaussians (see tests), ~40 % of the HBM traffic.
+    Returns (num_intersects, cum_tiles_hit, gaussian_ids_sorted, tile_bins)."""
+    dev = L.require_device(xys, depths, radii, num_tiles_hit)
+    lib = L.load()
+    n = int(num_points)
+    n_tiles = int(tile_bounds[0]) * int(tile_bounds[1])
+    i32 = dict(dtype=torch.int32, device=dev)
+    nth = num_tiles_hit.detach().to(torch.int32).contiguous()
+    radii_c = radii.detach().to(torch.int32).contiguous()
+    cum = torch.empty(n, **i32)
+    rank_of = torch.empty(n, **i32)
+    gid_by_rank = torch.empty(n, **i32)
+    tile_bins = torch.empty(n_tiles, 2, **i32)
+    if n == 0:
+        tile_bins.zero_()
+        return 0, cum, torch.zeros(0, **i32), tile_bins
+    ws = L.workspace(lib.sgn_bin_prepare_workspace_bytes(n), dev)
+    L.check(lib.sgn_bin_prepare(n, L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(nth), L.ptr(cum), L.ptr(rank_of),
+                                L.ptr(gid_by_rank), L.ptr(ws), ws.numel(), L.stream_ptr()), "sgn_bin_prepare")
+    num_intersects = int(cum[-1].item())  # host sync: sizes the intersection buffers (as upstream)
+    ids_sorted = torch.empty(num_intersects, **i32)
+    ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(num_intersects), dev)
+    L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(_f32c(xys)), L.ptr(radii_c), L.ptr(cum), L.ptr(rank_of),
+                                  L.ptr(gid_by_rank), int(tile_bounds[0]), int(tile_bounds[1]), int(block_width),
+                                  L.ptr(ids_sorted), L.ptr(tile_bins), L.ptr(ws2), ws2.numel(), L.stream_ptr()),
+            "sgn_bin_intersect")
+    return num_intersects, cum, ids_sorted, tile_bins
+
+
 # --------------------------------------------------------------- rasterize
 class _RasterizeGaussians(Function):
     @staticmethod
@@ -242,8 +274,9 @@ class _RasterizeGaussians(Function):
             raise NotImplementedError(
                 "only the 3-channel rasterize path is implemented (the reference never uses N-D colours: "
                 "sgn_splatfacto.py:988 repeats depth x3 to stay on it)")
-        num_intersects, cum_tiles_hit = compute_cumulative_intersects(num_tiles_hit)
         xys_c, conics_c, colors_c = _f32c(xys), _f32c(conics), _f32c(colors)
+        num_intersects, _cum, gaussian_ids_sorted, tile_bins = bin_gaussians_fused(
+            num_points, xys_c, depths, radii, num_tiles_hit, tile_bounds, block_width)
         opac_c, bg_c = _f32c(opacity).reshape(-1), _f32c(background)
         f32 = dict(dtype=torch.float32, device=dev)
         lib = L.load()
@@ -255,14 +288,12 @@ class _RasterizeGaussians(Function):
             final_Ts = torch.ones(img_height, img_width, **f32)
             final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
         else:
-            _, _, _, gaussian_ids_sorted, tile_bins = bin_and_sort_gaussians(
-                num_points, num_intersects, xys_c, depths, radii, cum_tiles_hit, tile_bounds, block_width)
             out_img = torch.empty(img_height, img_width, 3, **f32)
             final_Ts = torch.empty(img_height, img_width, **f32)
             final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
-            recs = L.workspace(lib.sgn_raster_workspace_bytes(num_intersects), dev)
+            recs = L.workspace(lib.sgn_raster_workspace_bytes(num_points, num_intersects), dev)
             L.check(lib.sgn_raster_fwd(
-                img_height, img_width, block_width, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
+                img_height, img_width, block_width, num_points, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), L.ptr(bg_c), L.ptr(out_img),
                 L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), L.stream_ptr()), "sgn_raster_fwd")
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
@@ -297,7 +328,7 @@ class _RasterizeGaussians(Function):
             lib = L.load()
             recs, packed = ctx.recs, 1
             if recs is None:
-                recs, packed = L.workspace(lib.sgn_raster_workspace_bytes(ctx.num_intersects), dev), 0
+                recs, packed = L.workspace(lib.sgn_raster_workspace_bytes(n, ctx.num_intersects), dev), 0
             gws = L.workspace(lib.sgn_raster_bwd_workspace_bytes(n), dev)
             L.check(lib.sgn_raster_bwd(
                 H, W, ctx.block_width, n, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),

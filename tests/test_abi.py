@@ -39,6 +39,7 @@ def test_header_declares_expected_entry_points():
     fns = _header_functions()
     for required in ["sgn_project_fwd", "sgn_project_bwd", "sgn_sh_fwd", "sgn_sh_bwd", "sgn_scan_i32",
                      "sgn_map_isect", "sgn_sort_pairs", "sgn_tile_bins", "sgn_raster_fwd", "sgn_raster_bwd",
+                     "sgn_bin_prepare", "sgn_bin_intersect",
                      "sgn_last_error", "sgn_version"]:
         assert required in fns
 
@@ -74,7 +75,7 @@ def test_argument_errors_are_reported_without_a_gpu(built_lib):
     rc = lib.sgn_sh_fwd(4, 7, 3, None, None, None, None)
     assert rc < 0
     assert lib.sgn_sort_workspace_bytes(1 << 20) > (1 << 20) * 12
-    assert lib.sgn_raster_workspace_bytes(10) == 480
+    assert lib.sgn_raster_workspace_bytes(5, 10) == 15 * 48
     assert lib.sgn_scan_workspace_bytes(5000) >= 12
 
 

@@ -158,6 +158,27 @@ def test_bin_and_sort_pipeline_bit_exact(hip, c_oracle):
     assert torch.equal(gbins.cpu(), bins)
 
 
+@pytest.mark.parametrize("n,size,focal", [(30000, (640, 360), 500.0), (5000, (130, 70), 100.0), (1, (64, 64), 64.0)])
+def test_fused_rank_binning_equals_upstream_shaped_path(hip, c_oracle, n, size, focal):
+    """The payload-free (tile << rank_bits | depth-rank) sort that rasterize_gaussians runs must give
+    the same gaussian_ids_sorted / tile_bins, bit for bit, as the upstream-shaped 64-bit pair sort
+    (and as the oracle) — including depth ties, which fall back to Gaussian-id order in both."""
+    from sgn_rast import ops
+    cam, P = small_scene(n=n, w=size[0], h=size[1], focal=focal)
+    if n > 100:
+        P["means"][100:140] = P["means"][60:100]      # exact depth ties between different Gaussians
+        P["log_scales"][:20] += 3.0                   # huge splats (wave-cooperative emission)
+    xys, depths, radii, conics, comp, nth, cov3d = c_oracle.project_fwd(*_project_args(cam, P))
+    cum, keys, vals, ks, vs, bins = c_oracle.bin_and_sort(xys, depths, radii, nth, cam.height, cam.width, 16)
+    tb = ((cam.width + 15) // 16, (cam.height + 15) // 16, 1)
+    I, cum_d, ids, tbins = ops.bin_gaussians_fused(xys.shape[0], xys.to(DEV), depths.to(DEV), radii.to(DEV),
+                                                   nth.to(DEV), tb, 16)
+    assert I == keys.numel()
+    assert torch.equal(cum_d.cpu(), cum)
+    assert torch.equal(ids.cpu(), vs), "gaussian_ids_sorted must be bit-exact"
+    assert torch.equal(tbins.cpu(), bins)
+
+
 # ---------------------------------------------------------------- rasterize
 def _raster_inputs(c_oracle, cam, P, block=16, seed=2):
     scales, quats, opac, coeffs = activated(P)
@@ -220,8 +241,9 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
         out_img = torch.empty(cam.height, cam.width, 3, device=DEV)
         fT = torch.empty(cam.height, cam.width, device=DEV)
         fi = torch.empty(cam.height, cam.width, dtype=torch.int32, device=DEV)
-        recs = L.workspace(lib.sgn_raster_workspace_bytes(I), out_img.device)
-        L.check(lib.sgn_raster_fwd(cam.height, cam.width, block, I, L.ptr(d["ids"]), L.ptr(d["bins"]),
+        n = R["xys"].shape[0]
+        recs = L.workspace(lib.sgn_raster_workspace_bytes(n, I), out_img.device)
+        L.check(lib.sgn_raster_fwd(cam.height, cam.width, block, n, I, L.ptr(d["ids"]), L.ptr(d["bins"]),
                                    L.ptr(d["xys"]), L.ptr(d["conics"]), L.ptr(d["rgb"]),
                                    L.ptr(d["opac"].reshape(-1).contiguous()), L.ptr(bg.to(DEV)), L.ptr(out_img),
                                    L.ptr(fT), L.ptr(fi), L.ptr(recs), recs.numel(), L.stream_ptr()), "raster_fwd")
@@ -235,8 +257,10 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
 
 @pytest.mark.parametrize("block,size", [(16, (128, 128)), (16, (130, 70)), (8, (100, 60))])
 @pytest.mark.parametrize("clamp", [0.99, 0.999])
-def test_rasterize_backward(hip, c_oracle, block, size, clamp):
-    from sgn_rast import ops
+@pytest.mark.parametrize("reduce_mode", [0, 1])
+def test_rasterize_backward(hip, c_oracle, block, size, clamp, reduce_mode):
+    from sgn_rast import _lib as L, ops
+    L.load().sgn_set_reduce_mode(reduce_mode)   # 0: ds_bpermute shuffles, 1: DPP row reduction
     cam, P = small_scene(n=3000, w=size[0], h=size[1], focal=float(size[0]))
     P["opacity_logits"][:200] = 9.0   # opacity ~0.9999: exercises the 0.999 (fwd) / 0.99 (bwd) clamps
     R = _raster_inputs(c_oracle, cam, P, block)
@@ -247,6 +271,7 @@ def test_rasterize_backward(hip, c_oracle, block, size, clamp):
         torch.autograd.backward([img, alpha], [d["v_img"], d["v_alpha"]])
     finally:
         ops.set_alpha_clamp_bwd(ops.UPSTREAM_ALPHA_CLAMP_BWD)
+        L.load().sgn_set_reduce_mode(L.DEFAULT_REDUCE_MODE)
     # oracle backward from the oracle's own forward state
     exp_img, exp_T, exp_idx = c_oracle.raster_fwd(cam.height, cam.width, block, R["ids"], R["bins"], R["xys"],
                                                   R["conics"], R["rgb"], R["opac"], bg)
