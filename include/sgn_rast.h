@@ -44,6 +44,9 @@ void sgn_set_exact_exp(int on);
 int sgn_get_exact_exp(void);
 /* Tuning switch for the backward's wave reduction: 0 = ds_bpermute shuffles, 1 = DPP row ops. */
 void sgn_set_reduce_mode(int mode);
+/* Timing ablations for profiles/ ONLY (results become wrong): bit0 = no gradient atomics,
+ * bit1 = no wave reduction.  0 = normal operation. */
+void sgn_set_debug_flags(int flags);
 
 /* Opt-in per-kernel timing for bench.py / profiles: when enabled, each timed launch is bracketed by
  * hipEventRecord on the stream it is launched on; sgn_timing_get sums the finished spans of a slot. */

@@ -221,7 +221,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                                                         const int32_t *__restrict__ final_idx,
                                                         const float *__restrict__ v_out,
                                                         const float *__restrict__ v_out_alpha,
-                                                        float alpha_clamp, float *__restrict__ grad_ws) {
+                                                        float alpha_clamp, float *__restrict__ grad_ws, int dbg) {
     const int tile = blockIdx.x;
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
@@ -306,7 +306,9 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         }
         if (__ballot(any) != 0ull) {  // wave-uniform
             constexpr int L0 = (REDUCE == 1) ? 48 : 0;  // first lane holding the totals
-            if constexpr (REDUCE == 1) {
+            if (dbg & 2) {
+                // ablation only: skip the wave reduction (results are wrong)
+            } else if constexpr (REDUCE == 1) {
                 g_x = wave_sum_dpp_row3(g_x); g_y = wave_sum_dpp_row3(g_y);
                 g_ca = wave_sum_dpp_row3(g_ca); g_cb = wave_sum_dpp_row3(g_cb); g_cc = wave_sum_dpp_row3(g_cc);
                 g_r = wave_sum_dpp_row3(g_r); g_g = wave_sum_dpp_row3(g_g); g_b = wave_sum_dpp_row3(g_b);
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
             mine = (lane == L0 + 6) ? g_g : mine;
             mine = (lane == L0 + 7) ? g_b : mine;
             mine = (lane == L0 + 8) ? g_o : mine;
-            if (lane >= L0 && lane < L0 + 9)
+            if (lane >= L0 && lane < L0 + 9 && !(dbg & 1))  // dbg bit0: ablation, no atomics
                 unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + (lane - L0), mine);
         }
         cur = nxt;
@@ -349,13 +351,15 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *_
 }
 
 int g_exact_exp = 0;
-int g_reduce_mode = 0;  // 0: ds_bpermute shuffles, 1: DPP
+int g_reduce_mode = 0;
+int g_debug = 0;         // timing ablations only (bit0: no atomics, bit1: no wave reduction)  // 0: ds_bpermute shuffles, 1: DPP
 
 }  // namespace
 
 SGN_EXPORT void sgn_set_exact_exp(int on) { g_exact_exp = on ? 1 : 0; }
 SGN_EXPORT int sgn_get_exact_exp(void) { return g_exact_exp; }
 SGN_EXPORT void sgn_set_reduce_mode(int mode) { g_reduce_mode = mode ? 1 : 0; }
+SGN_EXPORT void sgn_set_debug_flags(int flags) { g_debug = flags; }
 
 SGN_EXPORT size_t sgn_raster_workspace_bytes(int n, int64_t n_isect) {
     // [n_isect depth-ordered records][n per-Gaussian rows]
@@ -436,7 +440,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
 #define SGN_LAUNCH_BWD(EX, RM)                                                                                  \
     hipLaunchKernelGGL((raster_bwd_kernel<EX, RM>), dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,       \
                        block_width, tiles_x, (const int2 *)tile_bins, (const Rec *)recs_ws, background3, final_Ts, \
-                       final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws)
+                       final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws, g_debug)
         if (g_exact_exp) {
             if (g_reduce_mode) SGN_LAUNCH_BWD(true, 1); else SGN_LAUNCH_BWD(true, 0);
         } else {

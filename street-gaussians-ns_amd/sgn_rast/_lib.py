@@ -23,6 +23,7 @@ SIGNATURES = {
     "sgn_set_exact_exp": (None, [_i]),
     "sgn_get_exact_exp": (_i, []),
     "sgn_set_reduce_mode": (None, [_i]),
+    "sgn_set_debug_flags": (None, [_i]),
     "sgn_timing_enable": (None, [_i]),
     "sgn_timing_get": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "sgn_project_fwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f,
@@ -70,6 +71,7 @@ def load() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         lib.sgn_set_reduce_mode(DEFAULT_REDUCE_MODE)
+        lib.sgn_set_debug_flags(int(os.environ.get("SGN_DEBUG_FLAGS", "0")))
         _lib = lib
     return _lib
 
