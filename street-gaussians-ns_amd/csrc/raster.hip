@@ -119,9 +119,11 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];  // wave-uniform -> scalar loads
 
+    // Per-pixel state; "this pixel is finished (or outside the image)" is carried in the SIGN of T
+    // (T > 0 <=> still compositing), so liveness costs one v_cmp and no mask bookkeeping in VGPRs.
     float px[4], py[4], T[4], C0[4], C1[4], C2[4];
     int last[4], pix[4];
-    bool inside[4], done[4];
+    bool inside[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int ox, oy;
@@ -132,16 +134,16 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
         pix[q] = i * W + j;
         px[q] = (float)j + 0.5f;
         py[q] = (float)i + 0.5f;
-        T[q] = 1.f; C0[q] = 0.f; C1[q] = 0.f; C2[q] = 0.f;
+        T[q] = inside[q] ? 1.f : -1.f;
+        C0[q] = 0.f; C1[q] = 0.f; C2[q] = 0.f;
         last[q] = 0;
-        done[q] = !inside[q];
     }
 
     if (range.x < range.y) {
         Rec cur = recs[range.x];
         for (int k = range.x; k < range.y; ++k) {
-            const unsigned long long live0 = __ballot(!done[0]), live1 = __ballot(!done[1]);
-            const unsigned long long live2 = __ballot(!done[2]), live3 = __ballot(!done[3]);
+            const unsigned long long live0 = __ballot(T[0] > 0.f), live1 = __ballot(T[1] > 0.f);
+            const unsigned long long live2 = __ballot(T[2] > 0.f), live3 = __ballot(T[3] > 0.f);
             if ((live0 | live1 | live2 | live3) == 0ull) break;
             const int kn = (k + 1 < range.y) ? k + 1 : k;
             const Rec nxt = recs[kn];  // scalar prefetch of the next record
@@ -154,18 +156,18 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
                 s = fmaf(cur.hc * dy, dy, s);
                 const float sigma = fmaf(cur.b * dx, dy, s);
                 const float alpha = fminf(0.999f, cur.opac * sgn_exp<EXACT>(-sigma));
-                const bool valid = !done[q] && sigma >= 0.f && alpha >= (1.f / 255.f);
+                const bool valid = T[q] > 0.f && sigma >= 0.f && alpha >= (1.f / 255.f);
                 // branch-free update: lanes that skip or stop add vis = 0 (fma(c, 0, C) == C exactly)
                 const float nT = T[q] * (1.f - alpha);
                 const bool stop = valid && nT <= 1e-4f;
                 const bool acc = valid && !stop;
-                done[q] = done[q] || stop;
                 const float vis = acc ? alpha * T[q] : 0.f;
                 C0[q] = fmaf(cur.r, vis, C0[q]);
                 C1[q] = fmaf(cur.g, vis, C1[q]);
                 C2[q] = fmaf(cur.bl, vis, C2[q]);
-                T[q] = acc ? nT : T[q];
                 last[q] = acc ? k : last[q];
+                const float Tk = acc ? nT : T[q];
+                T[q] = stop ? -Tk : Tk;  // terminating Gaussian is NOT composited; T keeps its last value
             }
             cur = nxt;
         }
@@ -173,11 +175,12 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (inside[q]) {
-            final_T[pix[q]] = T[q];
+            const float Tq = fabsf(T[q]);
+            final_T[pix[q]] = Tq;
             final_idx[pix[q]] = last[q];
-            out_img[3 * pix[q] + 0] = fmaf(T[q], bg0, C0[q]);
-            out_img[3 * pix[q] + 1] = fmaf(T[q], bg1, C1[q]);
-            out_img[3 * pix[q] + 2] = fmaf(T[q], bg2, C2[q]);
+            out_img[3 * pix[q] + 0] = fmaf(Tq, bg0, C0[q]);
+            out_img[3 * pix[q] + 1] = fmaf(Tq, bg1, C1[q]);
+            out_img[3 * pix[q] + 2] = fmaf(Tq, bg2, C2[q]);
         }
     }
 }
@@ -229,7 +232,12 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-    float px[4], py[4], T[4], Tf[4], b0[4], b1[4], b2[4], vo0[4], vo1[4], vo2[4], voa[4];
+    // Per-pixel state.  Algebra: with dotc = sum_c color_c * v_out_c (per pixel x Gaussian)
+    // and bv = sum_c buffer_c * v_out_c (maintained incrementally: bv += fac * dotc), upstream's
+    //   v_alpha = sum_c (color_c*T - buffer_c*ra) * v_out_c + T_final*ra*v_out_alpha - T_final*ra*sum_c bg_c*v_out_c
+    // becomes  v_alpha = ra * (T_before * dotc - bv + c0),  c0 = T_final * (v_out_alpha - sum_c bg_c*v_out_c),
+    // i.e. 3 VALU ops instead of ~26, one running scalar instead of a 3-channel buffer.
+    float px[4], py[4], T[4], c0[4], bv[4], vo0[4], vo1[4], vo2[4];
     int kfin[4];
     int kmax_l = -1;
 #pragma unroll
@@ -242,14 +250,15 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         const int pix = inside ? i * W + j : 0;
         px[q] = (float)j + 0.5f;
         py[q] = (float)i + 0.5f;
-        Tf[q] = inside ? final_T[pix] : 1.f;
-        T[q] = Tf[q];
+        const float Tf = inside ? final_T[pix] : 1.f;
+        T[q] = Tf;
         kfin[q] = inside ? final_idx[pix] : -1;  // -1: this slot never participates
         vo0[q] = inside ? v_out[3 * pix] : 0.f;
         vo1[q] = inside ? v_out[3 * pix + 1] : 0.f;
         vo2[q] = inside ? v_out[3 * pix + 2] : 0.f;
-        voa[q] = inside ? v_out_alpha[pix] : 0.f;
-        b0[q] = 0.f; b1[q] = 0.f; b2[q] = 0.f;
+        const float voa = inside ? v_out_alpha[pix] : 0.f;
+        c0[q] = Tf * (voa - fmaf(bg0, vo0[q], fmaf(bg1, vo1[q], bg2 * vo2[q])));
+        bv[q] = 0.f;
         kmax_l = max(kmax_l, kfin[q]);
     }
     int kmax = __builtin_amdgcn_readfirstlane(wave_max_i(kmax_l));
@@ -267,41 +276,35 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         for (int q = 0; q < 4; ++q) {
             if (__ballot(k <= kfin[q]) == 0ull) continue;  // wave-uniform
             const float dx = cur.x - px[q], dy = cur.y - py[q];
-            float s = (cur.ha * dx) * dx;
-            s = fmaf(cur.hc * dy, dy, s);
-            const float sigma = fmaf(cur.b * dx, dy, s);
+            const float t1 = cur.ha * dx, t2 = cur.hc * dy, t3 = cur.b * dx;
+            const float sigma = fmaf(t3, dy, fmaf(t2, dy, t1 * dx));
             const float vis = sgn_exp<EXACT>(-sigma);
-            const float alpha = fminf(alpha_clamp, cur.opac * vis);
+            const float av = cur.opac * vis;
+            const float alpha = fminf(alpha_clamp, av);
             const bool valid = (k <= kfin[q]) && sigma >= 0.f && alpha >= (1.f / 255.f);
             // branch-free: everything is evaluated, invalid lanes are masked out by the selects
-            const float ra = 1.f / (1.f - alpha);
+            const float ra = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32 (1 ulp); oracle divides exactly
             const float Tn = T[q] * ra;
             const float fac = alpha * Tn;
-            float v_alpha = (cur.r * Tn - b0[q] * ra) * vo0[q];
-            v_alpha += (cur.g * Tn - b1[q] * ra) * vo1[q];
-            v_alpha += (cur.bl * Tn - b2[q] * ra) * vo2[q];
-            const float tfra = Tf[q] * ra;
-            v_alpha += tfra * voa[q];
-            v_alpha += -tfra * bg0 * vo0[q];
-            v_alpha += -tfra * bg1 * vo1[q];
-            v_alpha += -tfra * bg2 * vo2[q];
+            const float dotc = fmaf(cur.r, vo0[q], fmaf(cur.g, vo1[q], cur.bl * vo2[q]));
+            const float v_alpha = ra * fmaf(T[q], dotc, c0[q] - bv[q]);
+            const float vm = valid ? v_alpha : 0.f;
             const float facm = valid ? fac : 0.f;
-            b0[q] = fmaf(cur.r, facm, b0[q]);   // oracle: b0 += r*fac (separate rounding); fma here, covered by the gradient tolerance
-            b1[q] = fmaf(cur.g, facm, b1[q]);
-            b2[q] = fmaf(cur.bl, facm, b2[q]);
+            bv[q] = fmaf(facm, dotc, bv[q]);
             T[q] = valid ? Tn : T[q];
-            const float v_sigma = valid ? -cur.opac * vis * v_alpha : 0.f;
+            const float vs = -av * vm;                              // v_sigma (upstream: not zeroed by the clamp)
             // a*dx = 2*(ha*dx), c*dy = 2*(hc*dy): exact power-of-two scaling
-            g_x += v_sigma * (2.f * (cur.ha * dx) + cur.b * dy);
-            g_y += v_sigma * (cur.b * dx + 2.f * (cur.hc * dy));
-            const float hs = 0.5f * v_sigma;
-            g_ca += hs * dx * dx;
-            g_cb += hs * dx * dy;
-            g_cc += hs * dy * dy;
-            g_r += facm * vo0[q];
-            g_g += facm * vo1[q];
-            g_b += facm * vo2[q];
-            g_o += valid ? vis * v_alpha : 0.f;
+            g_x = fmaf(vs, fmaf(2.f, t1, cur.b * dy), g_x);
+            g_y = fmaf(vs, fmaf(2.f, t2, t3), g_y);
+            const float hs = 0.5f * vs;
+            const float hd = hs * dx, he = hs * dy;
+            g_ca = fmaf(hd, dx, g_ca);
+            g_cb = fmaf(hd, dy, g_cb);
+            g_cc = fmaf(he, dy, g_cc);
+            g_r = fmaf(facm, vo0[q], g_r);
+            g_g = fmaf(facm, vo1[q], g_g);
+            g_b = fmaf(facm, vo2[q], g_b);
+            g_o = fmaf(vis, vm, g_o);
             any = any || valid;
         }
         if (__ballot(any) != 0ull) {  // wave-uniform
