@@ -47,6 +47,9 @@ void sgn_set_reduce_mode(int mode);
 /* Timing ablations for profiles/ ONLY (results become wrong): bit0 = no gradient atomics,
  * bit1 = no wave reduction.  0 = normal operation. */
 void sgn_set_debug_flags(int flags);
+/* 0: raster kernels stream a depth-ordered 48-byte record per intersection (packed first);
+ * 1: they chase gaussian_ids_sorted[k] -> per-Gaussian row with dependent scalar loads (no pack pass). */
+void sgn_set_gather_mode(int on);
 
 /* Opt-in per-kernel timing for bench.py / profiles: when enabled, each timed launch is bracketed by
  * hipEventRecord on the stream it is launched on; sgn_timing_get sums the finished spans of a slot. */
@@ -119,18 +122,19 @@ int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_tiles, int3
                   sgn_stream_t stream);
 
 /* Fused binning (what rasterize_gaussians uses internally; same gaussian_ids_sorted / tile_bins as the
- * four upstream-shaped calls above, bit for bit, with ~40 % of their HBM traffic): Gaussians are first
- * ranked by depth (stable, ties by id = upstream's emission order), then only (tile << rank_bits | rank)
- * keys are sorted, without payload.  Two calls because the host must read n_isect = cum[n-1] in
- * between to size the buffers (upstream has the same `.item()` sync in compute_cumulative_intersects). */
+ * four upstream-shaped calls above, bit for bit, with ~1/3 of their HBM traffic): the Gaussians are ranked
+ * by depth once (stable, ties by id = upstream's emission order), intersections are emitted in rank order,
+ * and the list is then stably sorted by tile id only.  Two calls because the host must read
+ * n_isect = cum_by_rank[n-1] in between to size the buffers (upstream has the same `.item()` sync in
+ * compute_cumulative_intersects). */
 size_t sgn_bin_prepare_workspace_bytes(int n);
 int sgn_bin_prepare(int n, const float *depths, const int32_t *radii, const int32_t *num_tiles_hit,
-                    int32_t *cum_tiles_hit /*[n]*/, int32_t *rank_of /*[n]*/, int32_t *gid_by_rank /*[n]*/,
-                    void *ws, size_t ws_bytes, sgn_stream_t stream);
+                    int32_t *cum_by_rank /*[n] inclusive scan of tile counts in depth-rank order*/,
+                    int32_t *gid_by_rank /*[n]*/, void *ws, size_t ws_bytes, sgn_stream_t stream);
 size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect);
 int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const int32_t *radii,
-                      const int32_t *cum_tiles_hit, const int32_t *rank_of, const int32_t *gid_by_rank,
-                      int tiles_x, int tiles_y, int block_width, int32_t *gaussian_ids_sorted /*[n_isect]*/,
+                      const int32_t *cum_by_rank, const int32_t *gid_by_rank, int tiles_x, int tiles_y,
+                      int block_width, int32_t *gaussian_ids_sorted /*[n_isect]*/,
                       int32_t *tile_bins /*[tiles,2]*/, void *ws, size_t ws_bytes, sgn_stream_t stream);
 
 /* _C.rasterize_forward (3-channel path; reference call sites sgn_splatfacto.py:954-967,

@@ -156,12 +156,13 @@ __global__ __launch_bounds__(256) void tile_bins_kernel(int64_t n_isect, const i
     }
 }
 
-// ------------------------------------------------------------------ fused (rank-key) binning path
-// The (tile, depth, emission-order) order upstream gets from a stable 64-bit sort equals the order of
-// (tile, r) where r is the Gaussian's rank in a stable sort of all Gaussians by depth bits (ties by
-// id = emission order).  Ranking 1 M Gaussians is cheap; the per-intersection sort then needs only
-// tile_bits + rank_bits (34 at 1 M / 9600 tiles) key bits and NO payload: 4 passes x 24 B instead of
-// 6 passes x 32 B per intersection.  gaussian_ids_sorted / tile_bins come out bit-identical.
+// ------------------------------------------------------------------ fused (rank-order) binning path
+// Upstream's order — stable sort by (tile, depth bits), ties in emission (= Gaussian id) order — is an
+// LSD sort whose low digits can be had for free: rank the N Gaussians by depth once (stable, ties by
+// id), EMIT the intersections in rank order, and the list only needs a stable sort by the tile id
+// (14 bits at 1920x1280/16: two 8-bit passes over (u32 tile, i32 gaussian id) pairs, 40 B/intersection
+// instead of six passes x 32 B on 64-bit (tile|depth, id) pairs).  gaussian_ids_sorted / tile_bins come
+// out bit-identical to the upstream-shaped path (tests/test_gpu_parity.py, tests/test_gpu_e2e.py).
 __global__ __launch_bounds__(256) void depth_keys_kernel(int n, const float *__restrict__ depths,
                                                          const int32_t *__restrict__ radii,
                                                          uint32_t *__restrict__ dkeys,
@@ -172,68 +173,70 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(int n, const float *__r
     dvals[i] = i;
 }
 
-__global__ __launch_bounds__(256) void invert_perm_kernel(int n, const int32_t *__restrict__ gid_by_rank,
-                                                          int32_t *__restrict__ rank_of) {
+__global__ __launch_bounds__(256) void gather_counts_kernel(int n, const int32_t *__restrict__ gid_by_rank,
+                                                            const int32_t *__restrict__ radii,
+                                                            const int32_t *__restrict__ nth,
+                                                            int32_t *__restrict__ nth_r) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    rank_of[gid_by_rank[r]] = r;
+    const int g = gid_by_rank[r];
+    nth_r[r] = radii[g] > 0 ? nth[g] : 0;
 }
 
+// lane = depth rank r; emits (tile, gaussian id) pairs of Gaussian gid_by_rank[r] starting at cum_r[r-1]
 __global__ __launch_bounds__(256) void map_rank_kernel(int n, const float *__restrict__ xys,
                                                        const int32_t *__restrict__ radii,
-                                                       const int32_t *__restrict__ cum,
-                                                       const int32_t *__restrict__ rank_of, int tiles_x,
-                                                       int tiles_y, int block, int rank_bits,
-                                                       uint64_t *__restrict__ keys) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                       const int32_t *__restrict__ cum_r,
+                                                       const int32_t *__restrict__ gid_by_rank, int tiles_x,
+                                                       int tiles_y, int block, uint32_t *__restrict__ tkeys,
+                                                       int32_t *__restrict__ tvals) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    int mnx = 0, mny = 0, mxx = 0, mxy = 0, cur = 0;
-    uint32_t rk = 0;
+    int mnx = 0, mny = 0, mxx = 0, mxy = 0, cur = 0, gid = 0;
     bool live = false;
-    if (i < n) {
-        const int r = radii[i];
-        if (r > 0) {
+    if (r < n) {
+        gid = gid_by_rank[r];
+        const int rad = radii[gid];
+        if (rad > 0) {
             live = true;
-            sgn_tile_bbox(xys[2 * i], xys[2 * i + 1], (float)r, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
-            cur = (i == 0) ? 0 : cum[i - 1];
-            rk = (uint32_t)rank_of[i];
+            sgn_tile_bbox(xys[2 * gid], xys[2 * gid + 1], (float)rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
+            cur = (r == 0) ? 0 : cum_r[r - 1];
         }
     }
     const int w = mxx - mnx, h = mxy - mny;
     const int area = live ? w * h : 0;
     if (area > 0 && area <= MAP_BIG) {
         for (int ty = mny; ty < mxy; ++ty)
-            for (int tx = mnx; tx < mxx; ++tx)
-                keys[cur++] = ((uint64_t)(ty * tiles_x + tx) << rank_bits) | rk;
+            for (int tx = mnx; tx < mxx; ++tx) {
+                tkeys[cur] = (uint32_t)(ty * tiles_x + tx);
+                tvals[cur] = gid;
+                ++cur;
+            }
     }
     unsigned long long big = __ballot(area > MAP_BIG);
     while (big) {
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;
         const int bw = __shfl(w, src, 64), bmnx = __shfl(mnx, src, 64), bmny = __shfl(mny, src, 64);
-        const int barea = __shfl(area, src, 64), bcur = __shfl(cur, src, 64);
-        const uint32_t brk = (uint32_t)__shfl((int)rk, src, 64);
+        const int barea = __shfl(area, src, 64), bcur = __shfl(cur, src, 64), bgid = __shfl(gid, src, 64);
         for (int t = lane; t < barea; t += 64) {
             const int ty = bmny + t / bw, tx = bmnx + t % bw;
-            keys[bcur + t] = ((uint64_t)(ty * tiles_x + tx) << rank_bits) | brk;
+            tkeys[bcur + t] = (uint32_t)(ty * tiles_x + tx);
+            tvals[bcur + t] = bgid;
         }
     }
 }
 
-// sorted rank-keys -> gaussian_ids_sorted + tile_bins in one pass
-__global__ __launch_bounds__(256) void finalize_bins_kernel(int64_t n_isect, const uint64_t *__restrict__ keys,
-                                                            const int32_t *__restrict__ gid_by_rank,
-                                                            int rank_bits, int32_t *__restrict__ ids_sorted,
-                                                            int32_t *__restrict__ bins) {
+// sorted tile ids -> tile_bins
+__global__ __launch_bounds__(256) void tile_bins32_kernel(int64_t n_isect, const uint32_t *__restrict__ tkeys,
+                                                          int32_t *__restrict__ bins) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_isect) return;
-    const uint64_t k = keys[idx];
-    ids_sorted[idx] = gid_by_rank[(uint32_t)(k & ((1ull << rank_bits) - 1ull))];
-    const int32_t cur = (int32_t)(k >> rank_bits);
+    const int32_t cur = (int32_t)tkeys[idx];
     if (idx == 0) bins[2 * cur] = 0;
     if (idx == n_isect - 1) bins[2 * cur + 1] = (int32_t)n_isect;
     if (idx == 0) return;
-    const int32_t prev = (int32_t)(keys[idx - 1] >> rank_bits);
+    const int32_t prev = (int32_t)tkeys[idx - 1];
     if (prev != cur) {
         bins[2 * prev + 1] = (int32_t)idx;
         bins[2 * cur] = (int32_t)idx;
@@ -299,23 +302,21 @@ SGN_EXPORT int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_
 }
 
 // ---- fused path entry points (declared in sgn_rast.h) ------------------------------------------
-size_t sgn_sort_keys64_ws_bytes(int64_t n);
 size_t sgn_sort_pairs32_ws_bytes(int64_t n);
-void sgn_sort_keys64_launch(uint32_t n, int end_bit, const uint64_t *in, uint64_t *out, void *ws, hipStream_t s);
 void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const int32_t *vin, uint32_t *kout,
                              int32_t *vout, void *ws, hipStream_t s);
 
 SGN_EXPORT size_t sgn_bin_prepare_workspace_bytes(int n) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
-    return al256(sgn_scan_workspace_bytes(n)) + 3 * al256(nn * 4) + sgn_sort_pairs32_ws_bytes(n);
+    return al256(sgn_scan_workspace_bytes(n)) + 4 * al256(nn * 4) + sgn_sort_pairs32_ws_bytes(n);
 }
 
 SGN_EXPORT int sgn_bin_prepare(int n, const float *depths, const int32_t *radii, const int32_t *num_tiles_hit,
-                               int32_t *cum_tiles_hit, int32_t *rank_of, int32_t *gid_by_rank, void *ws,
-                               size_t ws_bytes, sgn_stream_t stream) {
+                               int32_t *cum_by_rank, int32_t *gid_by_rank, void *ws, size_t ws_bytes,
+                               sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     if (n == 0) return 0;
-    SGN_ARG_CHECK(depths && radii && num_tiles_hit && cum_tiles_hit && rank_of && gid_by_rank && ws, -2);
+    SGN_ARG_CHECK(depths && radii && num_tiles_hit && cum_by_rank && gid_by_rank && ws, -2);
     SGN_ARG_CHECK(ws_bytes >= sgn_bin_prepare_workspace_bytes(n), -3);
     hipStream_t s = (hipStream_t)stream;
     char *p = (char *)ws;
@@ -323,28 +324,26 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *depths, const int32_t *radii,
     uint32_t *dkeys = (uint32_t *)p; p += al256((size_t)n * 4);
     int32_t *dvals = (int32_t *)p;   p += al256((size_t)n * 4);
     uint32_t *dkeys_sorted = (uint32_t *)p; p += al256((size_t)n * 4);
+    int32_t *nth_r = (int32_t *)p;   p += al256((size_t)n * 4);
     void *sort_ws = p;
-    int rc = sgn_scan_i32(n, num_tiles_hit, cum_tiles_hit, scan_ws, sgn_scan_workspace_bytes(n), stream);
-    if (rc != 0) return rc;
     sgn_timing_begin(SGN_T_SORT, s);
     hipLaunchKernelGGL(depth_keys_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, depths, radii, dkeys, dvals);
     sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
-    hipLaunchKernelGGL(invert_perm_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, gid_by_rank, rank_of);
+    hipLaunchKernelGGL(gather_counts_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, gid_by_rank, radii,
+                       num_tiles_hit, nth_r);
     sgn_timing_end(SGN_T_SORT, s);
-    SGN_LAUNCH_CHECK();
-    return 0;
+    return sgn_scan_i32(n, nth_r, cum_by_rank, scan_ws, sgn_scan_workspace_bytes(n), stream);
 }
 
 SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
     const size_t ni = (size_t)(n_isect > 0 ? n_isect : 1);
-    return 2 * al256(ni * 8) + sgn_sort_keys64_ws_bytes(n_isect);
+    return 3 * al256(ni * 4) + sgn_sort_pairs32_ws_bytes(n_isect);
 }
 
 SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const int32_t *radii,
-                                 const int32_t *cum_tiles_hit, const int32_t *rank_of,
-                                 const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
-                                 int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *ws, size_t ws_bytes,
-                                 sgn_stream_t stream) {
+                                 const int32_t *cum_by_rank, const int32_t *gid_by_rank, int tiles_x,
+                                 int tiles_y, int block_width, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                                 void *ws, size_t ws_bytes, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0 && n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     SGN_ARG_CHECK(tile_bins != nullptr, -3);
@@ -352,24 +351,24 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const
     const int n_tiles = tiles_x * tiles_y;
     SGN_HIP_CHECK(hipMemsetAsync(tile_bins, 0, (size_t)n_tiles * 2 * sizeof(int32_t), s));
     if (n_isect == 0 || n == 0) return 0;
-    SGN_ARG_CHECK(xys && radii && cum_tiles_hit && rank_of && gid_by_rank && gaussian_ids_sorted && ws, -4);
+    SGN_ARG_CHECK(xys && radii && cum_by_rank && gid_by_rank && gaussian_ids_sorted && ws, -4);
     SGN_ARG_CHECK(ws_bytes >= sgn_bin_intersect_workspace_bytes(n_isect), -5);
-    const int rank_bits = bit_length((uint32_t)(n - 1)) > 0 ? bit_length((uint32_t)(n - 1)) : 1;
     const int tile_bits = bit_length((uint32_t)(n_tiles - 1)) > 0 ? bit_length((uint32_t)(n_tiles - 1)) : 1;
     char *p = (char *)ws;
-    uint64_t *keys = (uint64_t *)p;        p += al256((size_t)n_isect * 8);
-    uint64_t *keys_sorted = (uint64_t *)p; p += al256((size_t)n_isect * 8);
+    uint32_t *tkeys = (uint32_t *)p;        p += al256((size_t)n_isect * 4);
+    int32_t *tvals = (int32_t *)p;          p += al256((size_t)n_isect * 4);
+    uint32_t *tkeys_sorted = (uint32_t *)p; p += al256((size_t)n_isect * 4);
     void *sort_ws = p;
     sgn_timing_begin(SGN_T_MAP, s);
-    hipLaunchKernelGGL(map_rank_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii, cum_tiles_hit,
-                       rank_of, tiles_x, tiles_y, block_width, rank_bits, keys);
+    hipLaunchKernelGGL(map_rank_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii, cum_by_rank,
+                       gid_by_rank, tiles_x, tiles_y, block_width, tkeys, tvals);
     sgn_timing_end(SGN_T_MAP, s);
     sgn_timing_begin(SGN_T_SORT, s);
-    sgn_sort_keys64_launch((uint32_t)n_isect, rank_bits + tile_bits, keys, keys_sorted, sort_ws, s);
+    sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws, s);
     sgn_timing_end(SGN_T_SORT, s);
     sgn_timing_begin(SGN_T_BINS, s);
-    hipLaunchKernelGGL(finalize_bins_kernel, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, keys_sorted,
-                       gid_by_rank, rank_bits, gaussian_ids_sorted, tile_bins);
+    hipLaunchKernelGGL(tile_bins32_kernel, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, tkeys_sorted,
+                       tile_bins);
     sgn_timing_end(SGN_T_BINS, s);
     SGN_LAUNCH_CHECK();
     return 0;

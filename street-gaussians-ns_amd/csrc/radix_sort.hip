@@ -5,10 +5,10 @@
 // rasterize_gaussians (sgn_splatfacto.py:954-967, :982-994).  Stable => equal keys keep their input
 // order exactly like upstream, so gaussian_ids_sorted is bit-exact.
 //
-// One template, three instantiations:
+// One template, two instantiations:
 //   <u64, int32 payload, 8-bit digits>  sgn_sort_pairs    upstream-shaped (tile<<32|depth, gaussian id)
-//   <u32, int32 payload, 8-bit digits>  sgn_sort_pairs32  per-Gaussian depth ranking (fused path)
-//   <u64, no payload,    9-bit digits>  sgn_sort_keys64   (tile<<rank_bits|depth_rank) keys (fused path)
+//   <u32, int32 payload, 8-bit digits>  sgn_sort_pairs32  fused path: depth ranking of the N Gaussians
+//                                                         (32 bits) and the tile sort of the I pairs (14 bits)
 // Three kernels per pass —
 //   rs_hist    per-tile (4096 keys) digit histogram in LDS            -> table[digit][tile]
 //   rs_scan    one workgroup per digit: exclusive scan of its row     -> table (in place), total[digit]
@@ -246,11 +246,7 @@ void sort_launch(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const
 }  // namespace
 
 // internal (fused binning path, binning.hip)
-size_t sgn_sort_keys64_ws_bytes(int64_t n) { return sort_ws_bytes<uint64_t, false, 9>(n); }
 size_t sgn_sort_pairs32_ws_bytes(int64_t n) { return sort_ws_bytes<uint32_t, true, 8>(n); }
-void sgn_sort_keys64_launch(uint32_t n, int end_bit, const uint64_t *in, uint64_t *out, void *ws, hipStream_t s) {
-    sort_launch<uint64_t, false, 9>(n, 0, end_bit, in, nullptr, out, nullptr, ws, s);
-}
 void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const int32_t *vin, uint32_t *kout,
                              int32_t *vout, void *ws, hipStream_t s) {
     sort_launch<uint32_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s);

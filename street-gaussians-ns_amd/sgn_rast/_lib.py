@@ -24,6 +24,7 @@ SIGNATURES = {
     "sgn_get_exact_exp": (_i, []),
     "sgn_set_reduce_mode": (None, [_i]),
     "sgn_set_debug_flags": (None, [_i]),
+    "sgn_set_gather_mode": (None, [_i]),
     "sgn_timing_enable": (None, [_i]),
     "sgn_timing_get": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "sgn_project_fwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f,
@@ -39,9 +40,9 @@ SIGNATURES = {
     "sgn_sort_pairs": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_tile_bins": (_i, [_i64, _vp, _i, _vp, _vp]),
     "sgn_bin_prepare_workspace_bytes": (_sz, [_i]),
-    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_bin_intersect_workspace_bytes": (_sz, [_i64]),
-    "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sgn_raster_workspace_bytes": (_sz, [_i, _i64]),
     "sgn_raster_fwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_raster_bwd_workspace_bytes": (_sz, [_i]),
@@ -51,6 +52,7 @@ SIGNATURES = {
 
 _lib = None
 DEFAULT_REDUCE_MODE = int(os.environ.get("SGN_REDUCE_MODE", "0"))
+DEFAULT_GATHER_MODE = int(os.environ.get("SGN_RASTER_GATHER", "0"))
 
 
 class SgnRastError(RuntimeError):
@@ -71,6 +73,7 @@ def load() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         lib.sgn_set_reduce_mode(DEFAULT_REDUCE_MODE)
+        lib.sgn_set_gather_mode(DEFAULT_GATHER_MODE)
         lib.sgn_set_debug_flags(int(os.environ.get("SGN_DEBUG_FLAGS", "0")))
         _lib = lib
     return _lib

@@ -230,35 +230,34 @@ def bin_and_sort_gaussians(num_points, num_intersects, xys, depths, radii, cum_t
 
 
 def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width):
-    """The binning rasterize_gaussians actually runs: depth-rank the Gaussians, sort payload-free
-    (tile << rank_bits | rank) keys, emit gaussian_ids_sorted + tile_bins.  Bit-identical to
-    compute_cumulative_intersects + bin_and_sort_gaussians (see tests), ~40 % of the HBM traffic.
-    Returns (num_intersects, cum_tiles_hit, gaussian_ids_sorted, tile_bins)."""
+    """The binning rasterize_gaussians actually runs: rank the Gaussians by depth once, emit the
+    intersections in rank order, stable-sort them by tile id only, emit gaussian_ids_sorted + tile_bins.
+    Bit-identical to compute_cumulative_intersects + bin_and_sort_gaussians (see tests) at about a
+    third of the HBM traffic.  Returns (num_intersects, gaussian_ids_sorted, tile_bins)."""
     dev = L.require_device(xys, depths, radii, num_tiles_hit)
     lib = L.load()
     n = int(num_points)
     n_tiles = int(tile_bounds[0]) * int(tile_bounds[1])
     i32 = dict(dtype=torch.int32, device=dev)
-    nth = num_tiles_hit.detach().to(torch.int32).contiguous()
-    radii_c = radii.detach().to(torch.int32).contiguous()
-    cum = torch.empty(n, **i32)
-    rank_of = torch.empty(n, **i32)
-    gid_by_rank = torch.empty(n, **i32)
     tile_bins = torch.empty(n_tiles, 2, **i32)
     if n == 0:
         tile_bins.zero_()
-        return 0, cum, torch.zeros(0, **i32), tile_bins
+        return 0, torch.zeros(0, **i32), tile_bins
+    nth = num_tiles_hit.detach().to(torch.int32).contiguous()
+    radii_c = radii.detach().to(torch.int32).contiguous()
+    cum_r = torch.empty(n, **i32)
+    gid_by_rank = torch.empty(n, **i32)
     ws = L.workspace(lib.sgn_bin_prepare_workspace_bytes(n), dev)
-    L.check(lib.sgn_bin_prepare(n, L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(nth), L.ptr(cum), L.ptr(rank_of),
+    L.check(lib.sgn_bin_prepare(n, L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(nth), L.ptr(cum_r),
                                 L.ptr(gid_by_rank), L.ptr(ws), ws.numel(), L.stream_ptr()), "sgn_bin_prepare")
-    num_intersects = int(cum[-1].item())  # host sync: sizes the intersection buffers (as upstream)
+    num_intersects = int(cum_r[-1].item())  # host sync: sizes the intersection buffers (as upstream)
     ids_sorted = torch.empty(num_intersects, **i32)
     ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(num_intersects), dev)
-    L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(_f32c(xys)), L.ptr(radii_c), L.ptr(cum), L.ptr(rank_of),
+    L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(_f32c(xys)), L.ptr(radii_c), L.ptr(cum_r),
                                   L.ptr(gid_by_rank), int(tile_bounds[0]), int(tile_bounds[1]), int(block_width),
                                   L.ptr(ids_sorted), L.ptr(tile_bins), L.ptr(ws2), ws2.numel(), L.stream_ptr()),
             "sgn_bin_intersect")
-    return num_intersects, cum, ids_sorted, tile_bins
+    return num_intersects, ids_sorted, tile_bins
 
 
 # --------------------------------------------------------------- rasterize
@@ -275,7 +274,7 @@ class _RasterizeGaussians(Function):
                 "only the 3-channel rasterize path is implemented (the reference never uses N-D colours: "
                 "sgn_splatfacto.py:988 repeats depth x3 to stay on it)")
         xys_c, conics_c, colors_c = _f32c(xys), _f32c(conics), _f32c(colors)
-        num_intersects, _cum, gaussian_ids_sorted, tile_bins = bin_gaussians_fused(
+        num_intersects, gaussian_ids_sorted, tile_bins = bin_gaussians_fused(
             num_points, xys_c, depths, radii, num_tiles_hit, tile_bounds, block_width)
         opac_c, bg_c = _f32c(opacity).reshape(-1), _f32c(background)
         f32 = dict(dtype=torch.float32, device=dev)
