@@ -367,7 +367,7 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *_
 int g_exact_exp = 0;
 int g_reduce_mode = 0;   // 0: ds_bpermute shuffles, 1: DPP
 int g_debug = 0;         // timing ablations only (bit0: no atomics, bit1: no wave reduction)
-int g_gather = 0;        // 0: raster kernels stream packed records; 1: chase ids -> per-Gaussian rows
+int g_gather = 1;        // 1 (default): chase ids -> per-Gaussian rows; 0: stream packed records
 
 }  // namespace
 

@@ -52,7 +52,7 @@ SIGNATURES = {
 
 _lib = None
 DEFAULT_REDUCE_MODE = int(os.environ.get("SGN_REDUCE_MODE", "0"))
-DEFAULT_GATHER_MODE = int(os.environ.get("SGN_RASTER_GATHER", "0"))
+DEFAULT_GATHER_MODE = int(os.environ.get("SGN_RASTER_GATHER", "1"))
 
 
 class SgnRastError(RuntimeError):
