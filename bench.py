@@ -190,6 +190,13 @@ def main():
         dur_s = kernels[dom][1] * 1e-3
         achieved = alg / dur_s / 1e9 if dur_s > 0 else 0.0
         step_bytes = 748 * n_gauss + 316 * n_isect + 44 * n_pix
+        traffic = None  # PMC numbers come from separate rocprofv3 passes; committed under profiles/
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if args.scene == "metric" and not args.n and dom in tj:
+                traffic = tj[dom]["traffic_bytes"]
+        except Exception:
+            pass
         line = {
             "metric": "train-step images/sec (fwd+bwd) @1M Gaussians 1920x1280",
             "value": world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -201,7 +208,7 @@ def main():
                        "parallelism": f"dp{world} (view-parallel, RCCL grad all-reduce)" if world > 1 else "single",
                        "n_gaussians": n_gauss, "n_isect": n_isect},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": kernels[dom][1], "alg_bytes_per_launch": alg,
                          "step_alg_bytes": step_bytes,
                          "step_hbm_frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
