@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--cpu-timeout", type=float, default=150.0, help="wall-clock bound of the CPU baseline leg [s]")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--with-depth", action="store_true", help="add the reference's depth pass (:982-996)")
+    ap.add_argument("--path", default="dropin", choices=["dropin", "fused"],
+                    help="dropin: gsplat-shaped ops + the reference's torch glue (headline); fused: sgn_rast.fused")
+    ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-path measurement")
     return ap.parse_args()
 
 
@@ -145,8 +148,8 @@ def main():
     reducer = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]]) if world > 1 else None
     n_gauss = P["means"].shape[0]
 
-    def one_step():
-        return step.train_step(P, cam, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer)
+    def one_step(fused=(args.path == "fused")):
+        return step.train_step(P, cam, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer, fused=fused)
 
     def barrier():
         if world > 1:
@@ -168,6 +171,25 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     n_isect = int(out.num_tiles_hit.sum().item())
+
+    # the same function through the fused front ends (extension API), reported beside the headline
+    fused_extra = None
+    if args.path == "dropin" and not args.no_fused_extra:
+        for _ in range(max(2, args.warmup // 2)):
+            one_step(True)
+        barrier(); torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(True)
+        torch.cuda.synchronize(); barrier()
+        dtf = time.perf_counter() - tf0
+        if world > 1:
+            t = torch.tensor([dtf], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dtf = float(t.item())
+        fused_extra = {"value": world * args.steps / dtf, "unit": "images/sec", "ms_per_step": 1e3 * dtf / args.steps,
+                       "note": "same inputs/outputs through sgn_rast.fused (activations, view dirs, SH concat, "
+                               "sigmoid folded into the kernels); not the drop-in call path"}
 
     # per-kernel HIP-event spans (library brackets each launch on its own stream), separate short pass
     L.timing_enable(True)
@@ -214,6 +236,9 @@ def main():
                          "step_hbm_frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
             "kernels_avg_ms": {k: round(v[1], 4) for k, v in kernels.items()},
         }
+        line["config"]["path"] = args.path
+        if fused_extra is not None:
+            line["fused_path"] = fused_extra
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline_bounded(args)

@@ -90,6 +90,40 @@ int sgn_project_bwd(int n, const float *means3d, const float *scales, float glob
                     float *v_cov3d, float *v_mean3d, float *v_scale, float *v_quat,
                     sgn_stream_t stream);
 
+/* Fused front ends (extensions beyond gsplat's surface; SURVEY.md §8 a8, BASELINE.json north_star:
+ * "projection with the scene-graph's per-object rigid transform fused in").  Same outputs as
+ * sgn_project_fwd/bwd applied to  means_w = R_o m + t_o,  quats = normalize(q_o2w (x) q_raw),
+ * scales = exp(log_scales)  (sgn_splatfacto_scene_graph.py:404-417, sgn_splatfacto.py:857,864), and the
+ * gradients are returned w.r.t. the LOCAL means, the LOG scales and the RAW quaternions.
+ * poses: [n_objects,16] floats per row = R row-major (9), t (3), q_o2w wxyz (4); object_ids/poses may
+ * both be NULL (no rigid transform, activations only). */
+int sgn_project_fwd_fused(int n, const float *means_local, const float *log_scales, float glob_scale,
+                          const float *quats_raw, const int32_t *object_ids, const float *poses,
+                          const float *viewmat12, float fx, float fy, float cx, float cy, int img_h,
+                          int img_w, int block_width, float clip_thresh, float *cov3d, float *xys,
+                          float *depths, int32_t *radii, float *conics, float *compensation,
+                          int32_t *num_tiles_hit, sgn_stream_t stream);
+int sgn_project_bwd_fused(int n, const float *means_local, const float *log_scales, float glob_scale,
+                          const float *quats_raw, const int32_t *object_ids, const float *poses,
+                          const float *viewmat12, float fx, float fy, const float *cov3d,
+                          const int32_t *radii, const float *conics, const float *compensation,
+                          const float *v_xy, const float *v_depth, const float *v_conic,
+                          const float *v_compensation, float *v_means_local, float *v_log_scales,
+                          float *v_quats_raw, sgn_stream_t stream);
+
+/* colors = [clamp(. + 0.5, min 0)] SH(degree, means - cam_pos, [dc_eff | features_rest]),
+ * dc_eff = sum_f features_dc[:, f, :] * idft[object, f]  (Fourier DC term,
+ * sgn_splatfacto_scene_graph.py:239-247,420-433; n_fourier = 1 and idft = {1} for plain models).
+ * features_dc [n,n_fourier,3], features_rest [n,k-1,3] (never concatenated), idft [n_objects,n_fourier],
+ * cam_pos3 is a device pointer.  The backward needs the forward's `colors` for the clamp mask. */
+int sgn_sh_fwd_fused(int n, int k, int degree, const float *means, const float *cam_pos3,
+                     const float *features_dc, int n_fourier, const float *features_rest,
+                     const int32_t *object_ids, const float *idft, const float *poses /*nullable: means are local*/,
+                     int post_half_clamp, float *colors, sgn_stream_t stream);
+int sgn_sh_bwd_fused(int n, int k, int degree, const float *means, const float *cam_pos3, int n_fourier,
+                     const int32_t *object_ids, const float *idft, const float *poses, int post_half_clamp,
+                     const float *colors, const float *v_colors, float *v_features_dc, float *v_features_rest, sgn_stream_t stream);
+
 /* _C.compute_sh_forward / _C.compute_sh_backward (gsplat/sh.py; reference call sites
  * sgn_splatfacto.py:939, sgn_splatfacto_scene_graph.py:285).  coeffs [n,k,3], k in
  * {1,4,9,16,25}; degree <= 4; directions are normalised inside; no +0.5. */
@@ -145,6 +179,7 @@ size_t sgn_raster_workspace_bytes(int n, int64_t n_isect);
 int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                    const float *conics, const float *colors /*[n,3]*/, const float *opacities /*[n]*/,
+                   int opacity_is_logit /*0 = gsplat semantics; 1 = fuse torch.sigmoid (sgn_splatfacto.py:949)*/,
                    const float *background3, float *out_img /*[H,W,3]*/, float *final_Ts /*[H,W]*/,
                    int32_t *final_idx /*[H,W]*/, void *recs_ws, size_t recs_ws_bytes,
                    sgn_stream_t stream);
@@ -156,7 +191,7 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
 size_t sgn_raster_bwd_workspace_bytes(int n);
 int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
-                   const float *conics, const float *colors, const float *opacities,
+                   const float *conics, const float *colors, const float *opacities, int opacity_is_logit,
                    const float *background3, const float *final_Ts, const int32_t *final_idx,
                    const float *v_out_img /*[H,W,3]*/, const float *v_out_alpha /*[H,W]*/,
                    float alpha_clamp_bwd, float *v_xy /*[n,2]*/, float *v_conic /*[n,3]*/,

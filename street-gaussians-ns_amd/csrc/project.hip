@@ -34,9 +34,63 @@ __device__ __forceinline__ void quat_to_R(float w, float x, float y, float z, fl
     R[2][2] = 1.f - 2.f * (x * x + y * y);
 }
 
+// Optional fused front end (SURVEY.md §8 a8 / north star): the scene graph's per-object rigid transform
+// (sgn_splatfacto_scene_graph.py:404-417: means_w = R m + t, q_w = q_o2w (x) q), the quaternion
+// normalisation (sgn_splatfacto.py:864) and exp(log-scale) (:857) evaluated in registers on load,
+// instead of ~15 elementwise torch kernels and three N-sized concatenations per step.
+struct Fuse {
+    const int32_t *object_ids;  // [n] row of `poses` per Gaussian, or nullptr (no rigid transform)
+    const float *poses;         // [n_objects,16]: R row-major (9), t (3), q_o2w wxyz (4)
+};
+
+struct Loaded {
+    float p[3], q[4], s[3];
+    float qw[4], inv_norm;  // un-normalised (possibly rotated) quaternion and 1/|qw| (fused only)
+    float es[3];            // exp(log_scale) (fused only)
+};
+
+template <bool FUSED>
+__device__ __forceinline__ Loaded load_gaussian(int i, const float *__restrict__ means,
+                                                const float *__restrict__ scales,
+                                                const float *__restrict__ quats, float glob_scale, Fuse f) {
+    Loaded L;
+    const float m0 = means[3 * i], m1 = means[3 * i + 1], m2 = means[3 * i + 2];
+    const float q0 = quats[4 * i], q1 = quats[4 * i + 1], q2 = quats[4 * i + 2], q3 = quats[4 * i + 3];
+    if constexpr (!FUSED) {
+        L.p[0] = m0; L.p[1] = m1; L.p[2] = m2;
+        L.q[0] = q0; L.q[1] = q1; L.q[2] = q2; L.q[3] = q3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) L.s[c] = glob_scale * scales[3 * i + c];
+    } else {
+        float rw = q0, rx = q1, ry = q2, rz = q3;
+        L.p[0] = m0; L.p[1] = m1; L.p[2] = m2;
+        if (f.object_ids != nullptr) {
+            const float *P = f.poses + 16 * (size_t)f.object_ids[i];
+            L.p[0] = P[0] * m0 + P[1] * m1 + P[2] * m2 + P[9];
+            L.p[1] = P[3] * m0 + P[4] * m1 + P[5] * m2 + P[10];
+            L.p[2] = P[6] * m0 + P[7] * m1 + P[8] * m2 + P[11];
+            const float aw = P[12], ax = P[13], ay = P[14], az = P[15];
+            rw = aw * q0 - ax * q1 - ay * q2 - az * q3;
+            rx = aw * q1 + ax * q0 + ay * q3 - az * q2;
+            ry = aw * q2 - ax * q3 + ay * q0 + az * q1;
+            rz = aw * q3 + ax * q2 - ay * q1 + az * q0;
+        }
+        L.qw[0] = rw; L.qw[1] = rx; L.qw[2] = ry; L.qw[3] = rz;
+        L.inv_norm = 1.f / sqrtf(rw * rw + rx * rx + ry * ry + rz * rz);
+        L.q[0] = rw * L.inv_norm; L.q[1] = rx * L.inv_norm; L.q[2] = ry * L.inv_norm; L.q[3] = rz * L.inv_norm;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            L.es[c] = expf(scales[3 * i + c]);
+            L.s[c] = glob_scale * L.es[c];
+        }
+    }
+    return L;
+}
+
+template <bool FUSED>
 __global__ __launch_bounds__(256) void project_fwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ scales,
-    const float *__restrict__ quats, Cam cam, float *__restrict__ cov3d, float *__restrict__ xys,
+    const float *__restrict__ quats, Cam cam, Fuse fuse, float *__restrict__ cov3d, float *__restrict__ xys,
     float *__restrict__ depths, int32_t *__restrict__ radii, float *__restrict__ conics,
     float *__restrict__ comp, int32_t *__restrict__ num_tiles_hit) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -44,7 +98,8 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     float V[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) V[k] = cam.V[k];
-    const float p0 = means[3 * i], p1 = means[3 * i + 1], p2 = means[3 * i + 2];
+    const Loaded LG = load_gaussian<FUSED>(i, means, scales, quats, cam.glob_scale, fuse);
+    const float p0 = LG.p[0], p1 = LG.p[1], p2 = LG.p[2];
     const float pvx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
     const float pvy = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
     const float pvz = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
@@ -56,10 +111,10 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
 
     if (pvz > cam.clip) {
         float R[3][3], M[3][3], S[3][3];
-        quat_to_R(quats[4 * i], quats[4 * i + 1], quats[4 * i + 2], quats[4 * i + 3], R);
+        quat_to_R(LG.q[0], LG.q[1], LG.q[2], LG.q[3], R);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float s = cam.glob_scale * scales[3 * i + c];
+            const float s = LG.s[c];
 #pragma unroll
             for (int r = 0; r < 3; ++r) M[r][c] = R[r][c] * s;
         }
@@ -124,9 +179,10 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     num_tiles_hit[i] = o_n;
 }
 
+template <bool FUSED>
 __global__ __launch_bounds__(256) void project_bwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ scales,
-    const float *__restrict__ quats, Cam cam, const float *__restrict__ cov3d,
+    const float *__restrict__ quats, Cam cam, Fuse fuse, const float *__restrict__ cov3d,
     const int32_t *__restrict__ radii, const float *__restrict__ conics,
     const float *__restrict__ comp, const float *__restrict__ v_xy,
     const float *__restrict__ v_depth, const float *__restrict__ v_conic,
@@ -141,7 +197,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
 #pragma unroll
         for (int k = 0; k < 12; ++k) V[k] = cam.V[k];
         const float fx = cam.fx, fy = cam.fy;
-        const float p0 = means[3 * i], p1 = means[3 * i + 1], p2 = means[3 * i + 2];
+        const Loaded LG = load_gaussian<FUSED>(i, means, scales, quats, cam.glob_scale, fuse);
+        const float p0 = LG.p[0], p1 = LG.p[1], p2 = LG.p[2];
         const float pvx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
         const float pvy = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
         const float pvz = V[8] * p0 + V[9] * p1 + V[10] * p2 + V[11];
@@ -216,12 +273,12 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         const float vV[3][3] = {{o_vc3[0], 0.5f * o_vc3[1], 0.5f * o_vc3[2]},
                                 {0.5f * o_vc3[1], o_vc3[3], 0.5f * o_vc3[4]},
                                 {0.5f * o_vc3[2], 0.5f * o_vc3[4], o_vc3[5]}};
-        const float w = quats[4 * i], x = quats[4 * i + 1], y = quats[4 * i + 2], z = quats[4 * i + 3];
+        const float w = LG.q[0], x = LG.q[1], y = LG.q[2], z = LG.q[3];
         float R[3][3], M[3][3], sc[3];
         quat_to_R(w, x, y, z, R);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            sc[c] = cam.glob_scale * scales[3 * i + c];
+            sc[c] = LG.s[c];
 #pragma unroll
             for (int r = 0; r < 3; ++r) M[r][c] = R[r][c] * sc[c];
         }
@@ -246,6 +303,30 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
                          z * (vR[2][1] + vR[1][2]) + w * (vR[0][2] - vR[2][0]));
         o_vq[3] = 2.f * (x * (vR[2][0] + vR[0][2]) + y * (vR[2][1] + vR[1][2]) -
                          2.f * z * (vR[0][0] + vR[1][1]) + w * (vR[1][0] - vR[0][1]));
+        if constexpr (FUSED) {
+            // chain rules of the fused front end: exp, normalisation, Hamilton product, rigid transform
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o_vs[c] = o_vs[c] * LG.es[c];            // d/d log_scale
+            const float dq = LG.q[0] * o_vq[0] + LG.q[1] * o_vq[1] + LG.q[2] * o_vq[2] + LG.q[3] * o_vq[3];
+            float g[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = (o_vq[k] - LG.q[k] * dq) * LG.inv_norm;   // d/d (un-normalised q_w)
+            if (fuse.object_ids != nullptr) {
+                const float *P = fuse.poses + 16 * (size_t)fuse.object_ids[i];
+                const float aw = P[12], ax = P[13], ay = P[14], az = P[15];
+                o_vq[0] = aw * g[0] + ax * g[1] + ay * g[2] + az * g[3];
+                o_vq[1] = -ax * g[0] + aw * g[1] - az * g[2] + ay * g[3];
+                o_vq[2] = -ay * g[0] + az * g[1] + aw * g[2] - ax * g[3];
+                o_vq[3] = -az * g[0] - ay * g[1] + ax * g[2] + aw * g[3];
+                const float v0 = o_vm[0], v1 = o_vm[1], v2 = o_vm[2];           // v_means_local = R^T v_means_w
+                o_vm[0] = P[0] * v0 + P[3] * v1 + P[6] * v2;
+                o_vm[1] = P[1] * v0 + P[4] * v1 + P[7] * v2;
+                o_vm[2] = P[2] * v0 + P[5] * v1 + P[8] * v2;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o_vq[k] = g[k];
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { v_mean[3 * i + k] = o_vm[k]; v_scale[3 * i + k] = o_vs[k]; }
@@ -290,9 +371,9 @@ SGN_EXPORT int sgn_project_fwd(int n, const float *means3d, const float *scales,
                       conics && compensation && num_tiles_hit, -4);
     const Cam cam = make_cam(viewmat12, fx, fy, cx, cy, img_h, img_w, block_width, clip_thresh, glob_scale);
     sgn_timing_begin(SGN_T_PROJECT_FWD, stream);
-    hipLaunchKernelGGL(project_fwd_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
-                       means3d, scales, quats, cam, cov3d, xys, depths, radii, conics, compensation,
-                       num_tiles_hit);
+    hipLaunchKernelGGL(project_fwd_kernel<false>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       means3d, scales, quats, cam, Fuse{nullptr, nullptr}, cov3d, xys, depths, radii, conics,
+                       compensation, num_tiles_hit);
     sgn_timing_end(SGN_T_PROJECT_FWD, stream);
     SGN_LAUNCH_CHECK();
     return 0;
@@ -312,9 +393,57 @@ SGN_EXPORT int sgn_project_bwd(int n, const float *means3d, const float *scales,
     SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
     const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
     sgn_timing_begin(SGN_T_PROJECT_BWD, stream);
-    hipLaunchKernelGGL(project_bwd_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
-                       means3d, scales, quats, cam, cov3d, radii, conics, compensation, v_xy, v_depth,
-                       v_conic, v_compensation, v_cov2d, v_cov3d, v_mean3d, v_scale, v_quat);
+    hipLaunchKernelGGL(project_bwd_kernel<false>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       means3d, scales, quats, cam, Fuse{nullptr, nullptr}, cov3d, radii, conics, compensation, v_xy,
+                       v_depth, v_conic, v_compensation, v_cov2d, v_cov3d, v_mean3d, v_scale, v_quat);
+    sgn_timing_end(SGN_T_PROJECT_BWD, stream);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fused front end (extension beyond gsplat's surface) --------------------------
+SGN_EXPORT int sgn_project_fwd_fused(int n, const float *means_local, const float *log_scales, float glob_scale,
+                                     const float *quats_raw, const int32_t *object_ids, const float *poses,
+                                     const float *viewmat12, float fx, float fy, float cx, float cy, int img_h,
+                                     int img_w, int block_width, float clip_thresh, float *cov3d, float *xys,
+                                     float *depths, int32_t *radii, float *conics, float *compensation,
+                                     int32_t *num_tiles_hit, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
+    SGN_ARG_CHECK(img_h > 0 && img_w > 0, -3);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(means_local && log_scales && quats_raw && viewmat12 && cov3d && xys && depths && radii && conics &&
+                      compensation && num_tiles_hit, -4);
+    SGN_ARG_CHECK((object_ids == nullptr) == (poses == nullptr), -5);
+    const Cam cam = make_cam(viewmat12, fx, fy, cx, cy, img_h, img_w, block_width, clip_thresh, glob_scale);
+    sgn_timing_begin(SGN_T_PROJECT_FWD, stream);
+    hipLaunchKernelGGL(project_fwd_kernel<true>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       means_local, log_scales, quats_raw, cam, Fuse{object_ids, poses}, cov3d, xys, depths, radii,
+                       conics, compensation, num_tiles_hit);
+    sgn_timing_end(SGN_T_PROJECT_FWD, stream);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_project_bwd_fused(int n, const float *means_local, const float *log_scales, float glob_scale,
+                                     const float *quats_raw, const int32_t *object_ids, const float *poses,
+                                     const float *viewmat12, float fx, float fy, const float *cov3d,
+                                     const int32_t *radii, const float *conics, const float *compensation,
+                                     const float *v_xy, const float *v_depth, const float *v_conic,
+                                     const float *v_compensation, float *v_means_local, float *v_log_scales,
+                                     float *v_quats_raw, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(means_local && log_scales && quats_raw && viewmat12 && cov3d && radii && conics && v_xy && v_depth &&
+                      v_conic && v_means_local && v_log_scales && v_quats_raw, -4);
+    SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
+    SGN_ARG_CHECK((object_ids == nullptr) == (poses == nullptr), -6);
+    const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
+    sgn_timing_begin(SGN_T_PROJECT_BWD, stream);
+    hipLaunchKernelGGL(project_bwd_kernel<true>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       means_local, log_scales, quats_raw, cam, Fuse{object_ids, poses}, cov3d, radii, conics,
+                       compensation, v_xy, v_depth, v_conic, v_compensation, nullptr, nullptr, v_means_local,
+                       v_log_scales, v_quats_raw);
     sgn_timing_end(SGN_T_PROJECT_BWD, stream);
     SGN_LAUNCH_CHECK();
     return 0;

@@ -69,14 +69,15 @@ __device__ __forceinline__ float sgn_exp(float x) {
 __global__ __launch_bounds__(256) void build_grec_kernel(int n, const float *__restrict__ xys,
                                                          const float *__restrict__ conics,
                                                          const float *__restrict__ colors,
-                                                         const float *__restrict__ opac,
+                                                         const float *__restrict__ opac, int opac_is_logit,
                                                          float4 *__restrict__ grec) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= n) return;
     const float x = xys[2 * g], y = xys[2 * g + 1];
     const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
     const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
-    const float o = opac[g];
+    float o = opac[g];
+    if (opac_is_logit) o = 1.f / (1.f + expf(-o));  // fused torch.sigmoid (sgn_splatfacto.py:949)
     grec[3 * g + 0] = make_float4(x, y, o, 0.5f * a);
     grec[3 * g + 1] = make_float4(b, 0.5f * c, r, gg);
     grec[3 * g + 2] = make_float4(bl, __int_as_float(g), 0.f, 0.f);
@@ -350,6 +351,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
 }
 
 __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *__restrict__ ws,
+                                                           const float *__restrict__ opac, int opac_is_logit,
                                                            float *__restrict__ v_xy, float *__restrict__ v_conic,
                                                            float *__restrict__ v_colors,
                                                            float *__restrict__ v_opac) {
@@ -361,7 +363,12 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *_
     v_xy[2 * i] = a.x; v_xy[2 * i + 1] = a.y;
     v_conic[3 * i] = a.z; v_conic[3 * i + 1] = a.w; v_conic[3 * i + 2] = b.x;
     v_colors[3 * i] = b.y; v_colors[3 * i + 1] = b.z; v_colors[3 * i + 2] = b.w;
-    v_opac[i] = c.x;
+    float vo = c.x;
+    if (opac_is_logit) {  // chain through the fused sigmoid
+        const float sg = 1.f / (1.f + expf(-opac[i]));
+        vo = vo * sg * (1.f - sg);
+    }
+    v_opac[i] = vo;
 }
 
 int g_exact_exp = 0;
@@ -388,11 +395,11 @@ SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
 
 // builds the per-Gaussian rows and (stream mode) the depth-ordered record stream
 static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
-                        const float *colors, const float *opac, void *recs, hipStream_t s) {
+                        const float *colors, const float *opac, int opac_is_logit, void *recs, hipStream_t s) {
     float4 *grec = (float4 *)recs + 3 * n_isect;
     sgn_timing_begin(SGN_T_PACK, s);
     hipLaunchKernelGGL(build_grec_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, conics, colors, opac,
-                       grec);
+                       opac_is_logit, grec);
     if (!g_gather)
         hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(3 * n_isect, 256)), dim3(256), 0, s, n_isect, ids,
                            grec, (float4 *)recs);
@@ -403,8 +410,8 @@ static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float 
 SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
-                              const float *background3, float *out_img, float *final_Ts, int32_t *final_idx,
-                              void *recs_ws, size_t recs_ws_bytes, sgn_stream_t stream) {
+                              int opacity_is_logit, const float *background3, float *out_img, float *final_Ts,
+                              int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes, sgn_stream_t stream) {
     SGN_ARG_CHECK(img_h > 0 && img_w > 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
     SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -3);
@@ -412,7 +419,8 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     SGN_ARG_CHECK(n_isect == 0 || (gaussian_ids_sorted && xys && conics && colors && opacities && recs_ws), -5);
     SGN_ARG_CHECK(n >= 0 && recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect), -6);
     hipStream_t s = (hipStream_t)stream;
-    if (n_isect > 0) pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, recs_ws, s);
+    if (n_isect > 0)
+        pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, recs_ws, s);
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     const Rec *stream_recs = (const Rec *)recs_ws;
     const Rec *rows = stream_recs + n_isect;
@@ -435,7 +443,8 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
 SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
-                              const float *background3, const float *final_Ts, const int32_t *final_idx,
+                              int opacity_is_logit, const float *background3, const float *final_Ts,
+                              const int32_t *final_idx,
                               const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd,
                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
                               size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
@@ -444,7 +453,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
     SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -3);
     if (n == 0) return 0;
-    SGN_ARG_CHECK(v_xy && v_conic && v_colors && v_opacity && grad_ws, -4);
+    SGN_ARG_CHECK(v_xy && v_conic && v_colors && v_opacity && grad_ws && opacities, -4);
     SGN_ARG_CHECK(grad_ws_bytes >= sgn_raster_bwd_workspace_bytes(n), -5);
     SGN_ARG_CHECK(alpha_clamp_bwd > 0.f && alpha_clamp_bwd < 1.f, -6);
     hipStream_t s = (hipStream_t)stream;
@@ -453,7 +462,8 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         SGN_ARG_CHECK(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background3 &&
                           final_Ts && final_idx && v_out_img && v_out_alpha && recs_ws, -7);
         SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect), -8);
-        if (!recs_packed) pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, recs_ws, s);
+        if (!recs_packed)
+            pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, recs_ws, s);
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
         const Rec *stream_recs = (const Rec *)recs_ws;
         const Rec *rows = stream_recs + n_isect;
@@ -474,8 +484,8 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         sgn_timing_end(SGN_T_RASTER_BWD, s);
     }
     sgn_timing_begin(SGN_T_UNPACK, s);
-    hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, (const float *)grad_ws, v_xy,
-                       v_conic, v_colors, v_opacity);
+    hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, (const float *)grad_ws,
+                       opacities, opacity_is_logit, v_xy, v_conic, v_colors, v_opacity);
     sgn_timing_end(SGN_T_UNPACK, s);
     SGN_LAUNCH_CHECK();
     return 0;

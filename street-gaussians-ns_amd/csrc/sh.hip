@@ -138,6 +138,128 @@ __global__ __launch_bounds__(WAVES * 64) void sh_bwd_kernel(int n, int deg, cons
     }
 }
 
+__device__ __forceinline__ void fused_viewdir(int i, const float *__restrict__ means,
+                                              const float *__restrict__ cam_pos,
+                                              const int32_t *__restrict__ object_ids,
+                                              const float *__restrict__ poses, float &dx, float &dy, float &dz) {
+    float m0 = means[3 * i], m1 = means[3 * i + 1], m2 = means[3 * i + 2];
+    if (poses != nullptr && object_ids != nullptr) {  // local -> world (scene_graph.py:414)
+        const float *P = poses + 16 * (size_t)object_ids[i];
+        const float w0 = P[0] * m0 + P[1] * m1 + P[2] * m2 + P[9];
+        const float w1 = P[3] * m0 + P[4] * m1 + P[5] * m2 + P[10];
+        const float w2 = P[6] * m0 + P[7] * m1 + P[8] * m2 + P[11];
+        m0 = w0; m1 = w1; m2 = w2;
+    }
+    dx = m0 - cam_pos[0]; dy = m1 - cam_pos[1]; dz = m2 - cam_pos[2];
+}
+
+// ---- fused SH front end (extension) ------------------------------------------------
+// colour = clamp( SH(deg, means - cam_pos, [dc_eff | rest]) + 0.5, min 0 )  with
+// dc_eff = sum_f features_dc[:, f, :] * idft[object, f]   (Fourier "4D-SH" DC term,
+// sgn_splatfacto_scene_graph.py:239-247; F = 1 and idft = [1] for the background model).
+// Replaces, per call: view-dir subtract + norm + divide, the Fourier sum, torch.cat((dc, rest)) (192 MB at
+// 1 M Gaussians), the SH op, +0.5 and clamp — and the matching backward kernels — by one pass.
+template <int K, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sh_fwd_fused_kernel(
+    int n, int deg, const float *__restrict__ means, const float *__restrict__ cam_pos,
+    const float *__restrict__ dc, int F, const float *__restrict__ rest, const int32_t *__restrict__ object_ids,
+    const float *__restrict__ idft, const float *__restrict__ poses, int post, float *__restrict__ colors) {
+    constexpr int KC = (K - 1) * 3, LS = (KC | 1);
+    __shared__ float lds[WAVES][64 * (KC > 0 ? LS : 1)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * WAVES + wave) * 64;
+    const int cnt = max(0, min(64, n - g0));
+    float *my = lds[wave];
+    if constexpr (KC > 0) {
+        const float *src = rest + (size_t)g0 * KC;
+        const int total = cnt * KC;
+        for (int e = lane; e < total; e += 64) {
+            const int r = e / KC, c = e - r * KC;
+            my[r * LS + c] = src[e];
+        }
+    }
+    __syncthreads();
+    if (lane >= cnt) return;
+    const int i = g0 + lane;
+    float b[25];
+    float vx, vy, vz;
+    fused_viewdir(i, means, cam_pos, object_ids, poses, vx, vy, vz);
+    const int nb = sh_bases(vx, vy, vz, deg, b);
+    const float *w = idft + (size_t)(object_ids ? object_ids[i] : 0) * F;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int f = 0; f < F; ++f) {
+        const float wf = w[f];
+        d0 += dc[((size_t)i * F + f) * 3 + 0] * wf;
+        d1 += dc[((size_t)i * F + f) * 3 + 1] * wf;
+        d2 += dc[((size_t)i * F + f) * 3 + 2] * wf;
+    }
+    float a0 = b[0] * d0, a1 = b[0] * d1, a2 = b[0] * d2;
+    if constexpr (KC > 0) {
+        const float *row = my + lane * LS;
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+            if (k < nb) {
+                a0 += b[k] * row[3 * (k - 1)];
+                a1 += b[k] * row[3 * (k - 1) + 1];
+                a2 += b[k] * row[3 * (k - 1) + 2];
+            }
+        }
+    }
+    if (post) { a0 = fmaxf(a0 + 0.5f, 0.f); a1 = fmaxf(a1 + 0.5f, 0.f); a2 = fmaxf(a2 + 0.5f, 0.f); }
+    colors[3 * i] = a0; colors[3 * i + 1] = a1; colors[3 * i + 2] = a2;
+}
+
+template <int K, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sh_bwd_fused_kernel(
+    int n, int deg, const float *__restrict__ means, const float *__restrict__ cam_pos, int F,
+    const int32_t *__restrict__ object_ids, const float *__restrict__ idft, const float *__restrict__ poses,
+    int post, const float *__restrict__ colors, const float *__restrict__ v_colors, float *__restrict__ v_dc,
+    float *__restrict__ v_rest) {
+    constexpr int KC = (K - 1) * 3, LS = (KC | 1);
+    __shared__ float lds[WAVES][64 * (KC > 0 ? LS : 1)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * WAVES + wave) * 64;
+    const int cnt = max(0, min(64, n - g0));
+    float *my = lds[wave];
+    if (lane < cnt) {
+        const int i = g0 + lane;
+        float b[25];
+        float vx, vy, vz;
+        fused_viewdir(i, means, cam_pos, object_ids, poses, vx, vy, vz);
+        const int nb = sh_bases(vx, vy, vz, deg, b);
+        float v0 = v_colors[3 * i], v1 = v_colors[3 * i + 1], v2 = v_colors[3 * i + 2];
+        if (post) {  // clamp(x + 0.5, min=0): gradient passes where the output is positive
+            v0 = colors[3 * i] > 0.f ? v0 : 0.f;
+            v1 = colors[3 * i + 1] > 0.f ? v1 : 0.f;
+            v2 = colors[3 * i + 2] > 0.f ? v2 : 0.f;
+        }
+        const float *w = idft + (size_t)(object_ids ? object_ids[i] : 0) * F;
+        for (int f = 0; f < F; ++f) {
+            const float wf = w[f] * b[0];
+            v_dc[((size_t)i * F + f) * 3 + 0] = wf * v0;
+            v_dc[((size_t)i * F + f) * 3 + 1] = wf * v1;
+            v_dc[((size_t)i * F + f) * 3 + 2] = wf * v2;
+        }
+        if constexpr (KC > 0) {
+            float *row = my + lane * LS;
+#pragma unroll
+            for (int k = 1; k < K; ++k) {
+                const float bk = (k < nb) ? b[k] : 0.f;
+                row[3 * (k - 1)] = bk * v0; row[3 * (k - 1) + 1] = bk * v1; row[3 * (k - 1) + 2] = bk * v2;
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (KC > 0) {
+        float *dst = v_rest + (size_t)g0 * KC;
+        const int total = cnt * KC;
+        for (int e = lane; e < total; e += 64) {
+            const int r = e / KC, c = e - r * KC;
+            dst[e] = my[r * LS + c];
+        }
+    }
+}
+
 template <int K>
 int launch_fwd(int n, int deg, const float *dirs, const float *coeffs, float *colors, hipStream_t s) {
     constexpr int WAVES = (K > 16) ? 2 : 4;  // keep static LDS under 64 KiB
@@ -195,6 +317,73 @@ SGN_EXPORT int sgn_sh_bwd(int n, int k, int degree, const float *viewdirs, const
         case 16: launch_bwd<16>(n, degree, viewdirs, v_colors, v_coeffs, s); break;
         default: launch_bwd<25>(n, degree, viewdirs, v_colors, v_coeffs, s); break;
     }
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int K>
+static void launch_fwd_fused(int n, int deg, const float *means, const float *cam_pos, const float *dc, int F,
+                             const float *rest, const int32_t *oid, const float *idft, const float *poses, int post,
+                             float *colors, hipStream_t s) {
+    constexpr int WAVES = (K > 16) ? 2 : 4;
+    hipLaunchKernelGGL((sh_fwd_fused_kernel<K, WAVES>), dim3(sgn_cdiv(n, WAVES * 64)), dim3(WAVES * 64), 0, s, n, deg,
+                       means, cam_pos, dc, F, rest, oid, idft, poses, post, colors);
+}
+template <int K>
+static void launch_bwd_fused(int n, int deg, const float *means, const float *cam_pos, int F, const int32_t *oid,
+                             const float *idft, const float *poses, int post, const float *colors, const float *v_colors, float *v_dc,
+                             float *v_rest, hipStream_t s) {
+    constexpr int WAVES = (K > 16) ? 2 : 4;
+    hipLaunchKernelGGL((sh_bwd_fused_kernel<K, WAVES>), dim3(sgn_cdiv(n, WAVES * 64)), dim3(WAVES * 64), 0, s, n, deg,
+                       means, cam_pos, F, oid, idft, poses, post, colors, v_colors, v_dc, v_rest);
+}
+
+SGN_EXPORT int sgn_sh_fwd_fused(int n, int k, int degree, const float *means, const float *cam_pos3,
+                                const float *features_dc, int n_fourier, const float *features_rest,
+                                const int32_t *object_ids, const float *idft, const float *poses, int post_half_clamp,
+                                float *colors, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    SGN_ARG_CHECK(degree >= 0 && degree <= 4, -2);
+    SGN_ARG_CHECK(k == 1 || k == 4 || k == 9 || k == 16 || k == 25, -3);
+    SGN_ARG_CHECK((degree + 1) * (degree + 1) <= k, -4);
+    SGN_ARG_CHECK(n_fourier >= 1 && n_fourier <= 16, -5);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(means && cam_pos3 && features_dc && idft && colors && (k == 1 || features_rest), -6);
+    hipStream_t s = (hipStream_t)stream;
+    sgn_timing_begin(SGN_T_SH_FWD, s);
+    switch (k) {
+        case 1: launch_fwd_fused<1>(n, degree, means, cam_pos3, features_dc, n_fourier, features_rest, object_ids, idft, poses, post_half_clamp, colors, s); break;
+        case 4: launch_fwd_fused<4>(n, degree, means, cam_pos3, features_dc, n_fourier, features_rest, object_ids, idft, poses, post_half_clamp, colors, s); break;
+        case 9: launch_fwd_fused<9>(n, degree, means, cam_pos3, features_dc, n_fourier, features_rest, object_ids, idft, poses, post_half_clamp, colors, s); break;
+        case 16: launch_fwd_fused<16>(n, degree, means, cam_pos3, features_dc, n_fourier, features_rest, object_ids, idft, poses, post_half_clamp, colors, s); break;
+        default: launch_fwd_fused<25>(n, degree, means, cam_pos3, features_dc, n_fourier, features_rest, object_ids, idft, poses, post_half_clamp, colors, s); break;
+    }
+    sgn_timing_end(SGN_T_SH_FWD, s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_sh_bwd_fused(int n, int k, int degree, const float *means, const float *cam_pos3, int n_fourier,
+                                const int32_t *object_ids, const float *idft, const float *poses, int post_half_clamp,
+                                const float *colors, const float *v_colors, float *v_features_dc,
+                                float *v_features_rest, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    SGN_ARG_CHECK(degree >= 0 && degree <= 4, -2);
+    SGN_ARG_CHECK(k == 1 || k == 4 || k == 9 || k == 16 || k == 25, -3);
+    SGN_ARG_CHECK((degree + 1) * (degree + 1) <= k, -4);
+    SGN_ARG_CHECK(n_fourier >= 1 && n_fourier <= 16, -5);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(means && cam_pos3 && idft && colors && v_colors && v_features_dc && (k == 1 || v_features_rest), -6);
+    hipStream_t s = (hipStream_t)stream;
+    sgn_timing_begin(SGN_T_SH_BWD, s);
+    switch (k) {
+        case 1: launch_bwd_fused<1>(n, degree, means, cam_pos3, n_fourier, object_ids, idft, poses, post_half_clamp, colors, v_colors, v_features_dc, v_features_rest, s); break;
+        case 4: launch_bwd_fused<4>(n, degree, means, cam_pos3, n_fourier, object_ids, idft, poses, post_half_clamp, colors, v_colors, v_features_dc, v_features_rest, s); break;
+        case 9: launch_bwd_fused<9>(n, degree, means, cam_pos3, n_fourier, object_ids, idft, poses, post_half_clamp, colors, v_colors, v_features_dc, v_features_rest, s); break;
+        case 16: launch_bwd_fused<16>(n, degree, means, cam_pos3, n_fourier, object_ids, idft, poses, post_half_clamp, colors, v_colors, v_features_dc, v_features_rest, s); break;
+        default: launch_bwd_fused<25>(n, degree, means, cam_pos3, n_fourier, object_ids, idft, poses, post_half_clamp, colors, v_colors, v_features_dc, v_features_rest, s); break;
+    }
+    sgn_timing_end(SGN_T_SH_BWD, s);
     SGN_LAUNCH_CHECK();
     return 0;
 }

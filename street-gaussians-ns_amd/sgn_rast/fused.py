@@ -1,0 +1,178 @@
+"""Fused front ends — the caller-side glue of the reference folded into the kernels.
+
+``BASELINE.json:north_star`` asks for "covariance projection with the scene-graph's per-object rigid
+transform fused in".  The reference does that glue in Python around the gsplat ops
+(``sgn_splatfacto.py:857-864, 934-940, 949``; ``sgn_splatfacto_scene_graph.py:239-247, 355-360,
+404-433``): exp / normalise / sigmoid / +0.5 / clamp, view directions, the Fourier DC sum, the
+quaternion product and ``means @ R.T + t`` per object, and three N-sized ``torch.cat``s per step.
+These ops take the *raw* parameters (local means, log-scales, raw quats, opacity logits, un-concatenated
+``features_dc`` / ``features_rest``) plus a per-Gaussian ``object_ids`` row index into small per-object
+tables and do all of it in registers, forward and backward.  They are extensions: the drop-in
+gsplat-shaped ops in :mod:`sgn_rast.ops` stay the reference-faithful path.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from .ops import _RasterizeGaussians, _f32c
+
+
+def make_pose_table(rotations: torch.Tensor, translations: torch.Tensor) -> torch.Tensor:
+    """[M,3,3] object->world rotations + [M,3] translations -> [M,16] rows (R row-major, t, q_o2w wxyz).
+    Row 0 is conventionally the background (identity).  ``quaternion_from_matrix`` as in
+    ``sgn_splatfacto_scene_graph.py:413`` (trace / largest-diagonal branches, real part first)."""
+    R = rotations.to(torch.float64)
+    M = R.shape[0]
+    q = torch.zeros(M, 4, dtype=torch.float64)
+    for m in range(M):
+        r = R[m]
+        tr = float(r[0, 0] + r[1, 1] + r[2, 2])
+        if tr > 0:
+            s = (tr + 1.0) ** 0.5 * 2
+            q[m] = torch.tensor([0.25 * s, (r[2, 1] - r[1, 2]) / s, (r[0, 2] - r[2, 0]) / s, (r[1, 0] - r[0, 1]) / s])
+        else:
+            i = int(torch.argmax(torch.stack([r[0, 0], r[1, 1], r[2, 2]])))
+            j, k = (i + 1) % 3, (i + 2) % 3
+            s = float(r[i, i] - r[j, j] - r[k, k] + 1.0) ** 0.5 * 2
+            v = [0.0, 0.0, 0.0]
+            v[i] = 0.25 * s
+            v[j] = float(r[j, i] + r[i, j]) / s
+            v[k] = float(r[k, i] + r[i, k]) / s
+            q[m] = torch.tensor([float(r[k, j] - r[j, k]) / s, v[0], v[1], v[2]])
+    table = torch.cat([R.reshape(M, 9), translations.to(torch.float64).reshape(M, 3), q], dim=1)
+    return table.to(torch.float32).contiguous()
+
+
+class _ProjectFused(Function):
+    @staticmethod
+    def forward(ctx, means, log_scales, quats_raw, object_ids, poses, viewmat, fx, fy, cx, cy, img_height,
+                img_width, block_width, clip_thresh, glob_scale):
+        dev = L.require_device(means, log_scales, quats_raw, viewmat, object_ids, poses)
+        n = means.shape[0]
+        if n < 1 or means.shape[-1] != 3:
+            raise ValueError(f"Invalid shape for means3d: {means.shape}")
+        means_c, ls_c, q_c = _f32c(means), _f32c(log_scales), _f32c(quats_raw)
+        vm = _f32c(viewmat).reshape(-1)[:12].contiguous()
+        oid = None if object_ids is None else object_ids.detach().to(torch.int32).contiguous()
+        pos = None if poses is None else _f32c(poses)
+        f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+        cov3d, xys, depths = torch.empty(n, 6, **f32), torch.empty(n, 2, **f32), torch.empty(n, **f32)
+        radii, conics = torch.empty(n, **i32), torch.empty(n, 3, **f32)
+        comp, nth = torch.empty(n, **f32), torch.empty(n, **i32)
+        L.check(L.load().sgn_project_fwd_fused(
+            n, L.ptr(means_c), L.ptr(ls_c), float(glob_scale), L.ptr(q_c), L.ptr(oid), L.ptr(pos), L.ptr(vm),
+            float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width), int(block_width),
+            float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics), L.ptr(comp),
+            L.ptr(nth), L.stream_ptr()), "sgn_project_fwd_fused")
+        ctx.consts = (float(glob_scale), float(fx), float(fy))
+        ctx.has_obj = oid is not None
+        saved = [means_c, ls_c, q_c, vm, cov3d, radii, conics, comp]
+        if ctx.has_obj:
+            saved += [oid, pos]
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(radii, nth)
+        return xys, depths, radii, conics, comp, nth, cov3d
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_comp, v_nth, v_cov3d):
+        saved = ctx.saved_tensors
+        means, ls, q, vm, cov3d, radii, conics, comp = saved[:8]
+        oid, pos = (saved[8], saved[9]) if ctx.has_obj else (None, None)
+        gs, fx, fy = ctx.consts
+        n, dev = means.shape[0], means.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        v_xys = _f32c(v_xys) if v_xys is not None else torch.zeros(n, 2, **f32)
+        v_depths = _f32c(v_depths) if v_depths is not None else torch.zeros(n, **f32)
+        v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros(n, 3, **f32)
+        v_comp = _f32c(v_comp) if v_comp is not None else None
+        v_m, v_s, v_q = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32)
+        L.check(L.load().sgn_project_bwd_fused(
+            n, L.ptr(means), L.ptr(ls), gs, L.ptr(q), L.ptr(oid), L.ptr(pos), L.ptr(vm), fx, fy, L.ptr(cov3d),
+            L.ptr(radii), L.ptr(conics), L.ptr(comp), L.ptr(v_xys), L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comp),
+            L.ptr(v_m), L.ptr(v_s), L.ptr(v_q), L.stream_ptr()), "sgn_project_bwd_fused")
+        return (v_m, v_s, v_q) + (None,) * 12
+
+
+def project_gaussians_fused(means, log_scales, quats_raw, viewmat, fx, fy, cx, cy, img_height, img_width,
+                            block_width, object_ids: Optional[torch.Tensor] = None,
+                            poses: Optional[torch.Tensor] = None, clip_thresh: float = 0.01,
+                            glob_scale: float = 1.0):
+    """``project_gaussians(R_o m + t_o, exp(log_scales), glob_scale, normalize(q_o2w (x) q_raw), ...)`` in one
+    kernel; gradients w.r.t. the local means, log-scales and raw quaternions.  Same 7-tuple as upstream."""
+    assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
+    assert (object_ids is None) == (poses is None), "object_ids and poses go together"
+    return _ProjectFused.apply(means.contiguous(), log_scales.contiguous(), quats_raw.contiguous(), object_ids, poses,
+                               viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width, clip_thresh,
+                               glob_scale)
+
+
+class _SHFused(Function):
+    @staticmethod
+    def forward(ctx, degree, means, cam_pos, features_dc, features_rest, object_ids, idft, poses, post):
+        dev = L.require_device(means, cam_pos, features_dc, features_rest, object_ids, idft, poses)
+        n, F = features_dc.shape[0], features_dc.shape[1]
+        k = 1 + (features_rest.shape[1] if features_rest is not None else 0)
+        means_c, cam_c, dc_c = _f32c(means), _f32c(cam_pos).reshape(-1)[:3].contiguous(), _f32c(features_dc)
+        rest_c = _f32c(features_rest) if features_rest is not None else None
+        oid = None if object_ids is None else object_ids.detach().to(torch.int32).contiguous()
+        idft_c = _f32c(idft).reshape(-1, F) if idft is not None else torch.ones(1, F, dtype=torch.float32, device=dev)
+        pos = _f32c(poses) if (poses is not None and oid is not None) else None
+        colors = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        L.check(L.load().sgn_sh_fwd_fused(n, k, int(degree), L.ptr(means_c), L.ptr(cam_c), L.ptr(dc_c), F,
+                                          L.ptr(rest_c), L.ptr(oid), L.ptr(idft_c), L.ptr(pos), int(bool(post)), L.ptr(colors),
+                                          L.stream_ptr()), "sgn_sh_fwd_fused")
+        ctx.meta = (int(degree), k, F, int(bool(post)), features_rest is not None)
+        ctx.has_obj, ctx.has_pose = oid is not None, pos is not None
+        saved = [means_c, cam_c, idft_c, colors]
+        if ctx.has_obj:
+            saved.append(oid)
+        if ctx.has_pose:
+            saved.append(pos)
+        ctx.save_for_backward(*saved)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        saved = ctx.saved_tensors
+        means, cam, idft, colors = saved[:4]
+        oid = saved[4] if ctx.has_obj else None
+        pos = saved[5] if ctx.has_pose else None
+        degree, k, F, post, has_rest = ctx.meta
+        n, dev = means.shape[0], means.device
+        v_dc = torch.empty(n, F, 3, dtype=torch.float32, device=dev)
+        v_rest = torch.empty(n, k - 1, 3, dtype=torch.float32, device=dev) if has_rest else None
+        L.check(L.load().sgn_sh_bwd_fused(n, k, degree, L.ptr(means), L.ptr(cam), F, L.ptr(oid), L.ptr(idft), L.ptr(pos), post,
+                                          L.ptr(colors), L.ptr(_f32c(v_colors)), L.ptr(v_dc), L.ptr(v_rest),
+                                          L.stream_ptr()), "sgn_sh_bwd_fused")
+        return None, None, None, v_dc, v_rest, None, None, None, None
+
+
+def spherical_harmonics_fused(degrees_to_use: int, means, cam_pos, features_dc, features_rest,
+                              object_ids: Optional[torch.Tensor] = None, idft: Optional[torch.Tensor] = None,
+                              poses: Optional[torch.Tensor] = None, post_half_clamp: bool = True) -> torch.Tensor:
+    """``clamp(spherical_harmonics(n, normalize(means - cam_pos), cat(dc_eff, rest)) + 0.5, min=0)`` with
+    ``dc_eff = sum_f features_dc[:, f] * idft[object, f]`` — view directions, Fourier DC, concat, SH and
+    the colour post-processing in one pass; with ``poses`` the means are LOCAL and moved to the world frame
+    in-kernel (no gradient to ``means``, as in the reference: ``.detach()``
+    at sgn_splatfacto.py:934)."""
+    k = 1 + (features_rest.shape[1] if features_rest is not None else 0)
+    assert k >= (degrees_to_use + 1) ** 2
+    return _SHFused.apply(degrees_to_use, means.detach(), cam_pos, features_dc.contiguous(),
+                          None if features_rest is None else features_rest.contiguous(), object_ids, idft, poses,
+                          post_half_clamp)
+
+
+def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors, opacity_logits, img_height,
+                              img_width, block_width, background=None, return_alpha=False):
+    """``rasterize_gaussians(..., torch.sigmoid(opacity_logits), ...)`` with the sigmoid (and its backward)
+    folded into the record build / gradient unpack kernels."""
+    assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
+    if background is None:
+        background = torch.ones(3, dtype=torch.float32, device=colors.device)
+    return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(), conics.contiguous(),
+                                     num_tiles_hit.contiguous(), colors.contiguous(), opacity_logits.contiguous(),
+                                     img_height, img_width, block_width, background.contiguous(), return_alpha, True)

@@ -56,6 +56,40 @@ def render(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, b
     return out
 
 
+def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, block_width: int = 16,
+                 background: Optional[torch.Tensor] = None, with_depth: bool = False,
+                 object_ids: Optional[torch.Tensor] = None, poses: Optional[torch.Tensor] = None,
+                 idft: Optional[torch.Tensor] = None) -> SimpleNamespace:
+    """Same result as :func:`render` on the scene-graph-aggregated parameters, through the fused front
+    ends (:mod:`sgn_rast.fused`): raw parameters in, no activation / concat / transform kernels.
+    ``P["means"]`` / ``P["quats"]`` are in each object's LOCAL frame when ``object_ids``/``poses`` are given;
+    ``P["features_dc"]`` is [N,F,3] with F Fourier coefficients weighted by ``idft[object]``."""
+    from . import fused
+    dev = P["means"].device
+    H, W = cam.height, cam.width
+    if background is None:
+        background = torch.zeros(3, device=dev, dtype=torch.float32)
+    xys, depths, radii, conics, _comp, num_tiles_hit, _cov3d = fused.project_gaussians_fused(
+        P["means"], P["log_scales"], P["quats"], cam.viewmat[:3, :], cam.fx, cam.fy, cam.cx, cam.cy, H, W,
+        block_width, object_ids=object_ids, poses=poses)
+    out = SimpleNamespace(xys=xys, depths=depths, radii=radii, conics=conics, num_tiles_hit=num_tiles_hit)
+    if xys.requires_grad:
+        xys.retain_grad()
+    # SH view directions use WORLD means (scene_graph.py:355): the kernel applies the pose itself
+    rgbs = fused.spherical_harmonics_fused(sh_degree_to_use, P["means"], cam.cam_pos, P["features_dc"],
+                                           P["features_rest"], object_ids=object_ids, idft=idft, poses=poses)
+    rgb, alpha = fused.rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, rgbs,
+                                                 P["opacity_logits"], H, W, block_width, background=background,
+                                                 return_alpha=True)
+    out.rgb, out.alpha, out.rgbs = rgb, alpha, rgbs
+    if with_depth:
+        depth_im = fused.rasterize_gaussians_fused(
+            xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3), P["opacity_logits"], H, W,
+            block_width, torch.zeros(3, device=dev, dtype=torch.float32))[..., 0:1]
+        out.depth = torch.where(alpha[..., None] > 1e-3, depth_im / alpha[..., None], 10)
+    return out
+
+
 def loss_weights(cam: Camera, seed: int = 7, device="cpu", dtype=torch.float32):
     g = torch.Generator().manual_seed(seed)
     w_img = torch.rand(cam.height, cam.width, 3, generator=g)
@@ -65,12 +99,15 @@ def loss_weights(cam: Camera, seed: int = 7, device="cpu", dtype=torch.float32):
 
 def train_step(P: Dict[str, torch.Tensor], cam: Camera, w_img: torch.Tensor, w_a: torch.Tensor,
                sh_degree_to_use: int = 3, block_width: int = 16, with_depth: bool = False, ops=_hip_ops,
-               reducer=None) -> SimpleNamespace:
+               reducer=None, fused: bool = False, **fused_kw) -> SimpleNamespace:
     """One "train-step image": project fwd -> SH fwd -> rasterize(return_alpha) fwd -> scalar loss ->
     full backward to means / log-scales / raw quats / opacity logits / SH coefficients."""
     for p in P.values():
         p.grad = None
-    out = render(P, cam, sh_degree_to_use, block_width, with_depth=with_depth, ops=ops)
+    if fused:
+        out = render_fused(P, cam, sh_degree_to_use, block_width, with_depth=with_depth, **fused_kw)
+    else:
+        out = render(P, cam, sh_degree_to_use, block_width, with_depth=with_depth, ops=ops)
     n_pix = cam.height * cam.width
     loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum()) / n_pix
     loss.backward()

@@ -135,3 +135,39 @@ def test_single_rank_dp_reducer_is_a_noop():
     step.train_step(P, cam, w_img, w_a)
     for k in P:
         assert rel_l2(P[k].grad, g[k]) < 1e-5
+
+
+def test_binning_cache_reuse_and_invalidation():
+    """RGB pass then depth pass on the same projection share one binning; a changed xys (new version
+    or new tensor) must not hit the cache."""
+    from sgn_rast import ops, scenes, step
+    cam, raw = scenes.make_scene("c1", n_override=3000)
+    P = _to_dev(cam, raw)
+    calls = {"n": 0}
+    orig = ops.bin_gaussians_fused
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+
+    ops.bin_gaussians_fused = counting
+    try:
+        ops.clear_binning_cache()
+        with torch.no_grad():
+            out = step.render(P, cam, with_depth=True)
+            assert calls["n"] == 1                                  # depth pass reused the RGB pass's binning
+            ref = ops.rasterize_gaussians(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
+                                          out.opacities, cam.height, cam.width, 16, torch.zeros(3, device=DEV))
+            assert calls["n"] == 1
+            out.xys.add_(3.0)                                       # in-place edit bumps the version counter
+            moved = ops.rasterize_gaussians(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
+                                            out.opacities, cam.height, cam.width, 16, torch.zeros(3, device=DEV))
+            assert calls["n"] == 2 and not torch.equal(moved, ref)
+            ops.binning_cache_enabled = False
+            again = ops.rasterize_gaussians(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
+                                            out.opacities, cam.height, cam.width, 16, torch.zeros(3, device=DEV))
+            assert calls["n"] == 3 and torch.equal(again, moved)
+    finally:
+        ops.bin_gaussians_fused = orig
+        ops.binning_cache_enabled = True
+        ops.clear_binning_cache()
