@@ -159,14 +159,18 @@ def test_binning_cache_reuse_and_invalidation():
             ref = ops.rasterize_gaussians(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
                                           out.opacities, cam.height, cam.width, 16, torch.zeros(3, device=DEV))
             assert calls["n"] == 1
-            out.xys.add_(3.0)                                       # in-place edit bumps the version counter
-            moved = ops.rasterize_gaussians(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
+            out.xys.mul_(1.0)                                       # in-place op bumps the version counter
+            same = ops.rasterize_gaussians(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
+                                           out.opacities, cam.height, cam.width, 16, torch.zeros(3, device=DEV))
+            assert calls["n"] == 2 and torch.equal(same, ref)       # re-binned (version changed), same picture
+            xys2 = out.xys.clone()                                  # a different tensor with equal bytes
+            again = ops.rasterize_gaussians(xys2, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
                                             out.opacities, cam.height, cam.width, 16, torch.zeros(3, device=DEV))
-            assert calls["n"] == 2 and not torch.equal(moved, ref)
+            assert calls["n"] == 3 and torch.equal(again, ref)
             ops.binning_cache_enabled = False
-            again = ops.rasterize_gaussians(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
-                                            out.opacities, cam.height, cam.width, 16, torch.zeros(3, device=DEV))
-            assert calls["n"] == 3 and torch.equal(again, moved)
+            off = ops.rasterize_gaussians(xys2, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
+                                          out.opacities, cam.height, cam.width, 16, torch.zeros(3, device=DEV))
+            assert calls["n"] == 4 and torch.equal(off, ref)
     finally:
         ops.bin_gaussians_fused = orig
         ops.binning_cache_enabled = True
