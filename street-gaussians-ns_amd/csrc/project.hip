@@ -315,9 +315,9 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
                 const float *P = fuse.poses + 16 * (size_t)fuse.object_ids[i];
                 const float aw = P[12], ax = P[13], ay = P[14], az = P[15];
                 o_vq[0] = aw * g[0] + ax * g[1] + ay * g[2] + az * g[3];
-                o_vq[1] = -ax * g[0] + aw * g[1] - az * g[2] + ay * g[3];
-                o_vq[2] = -ay * g[0] + az * g[1] + aw * g[2] - ax * g[3];
-                o_vq[3] = -az * g[0] - ay * g[1] + ax * g[2] + aw * g[3];
+                o_vq[1] = -ax * g[0] + aw * g[1] + az * g[2] - ay * g[3];
+                o_vq[2] = -ay * g[0] - az * g[1] + aw * g[2] + ax * g[3];
+                o_vq[3] = -az * g[0] + ay * g[1] - ax * g[2] + aw * g[3];
                 const float v0 = o_vm[0], v1 = o_vm[1], v2 = o_vm[2];           // v_means_local = R^T v_means_w
                 o_vm[0] = P[0] * v0 + P[3] * v1 + P[6] * v2;
                 o_vm[1] = P[1] * v0 + P[4] * v1 + P[7] * v2;

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _scene_graph_scene(n_bg=2500, n_obj=(600, 400), F=5, seed=4):
+def _scene_graph_scene(n_bg=2500, n_obj=(600, 400), F=5, seed=4, local_objects=True):
     """Background + two rigid objects, each Gaussian stored in its object's LOCAL frame."""
     from sgn_rast import fused, scenes
     cam = scenes.make_camera(160, 96, 140.0)
@@ -27,7 +27,8 @@ def _scene_graph_scene(n_bg=2500, n_obj=(600, 400), F=5, seed=4):
         Rx = torch.tensor([[1, 0, 0], [0, math.cos(pitch), -math.sin(pitch)], [0, math.sin(pitch), math.cos(pitch)]])
         Rs.append((Ry @ Rx).float())
         ts.append(torch.tensor([0.6 * (k + 1) - 1.0, 0.1 * k, 4.0 + k]))
-        raw["means"][start:start + cnt] = torch.randn(cnt, 3, generator=g) * 0.4     # local object frame
+        if local_objects:
+            raw["means"][start:start + cnt] = torch.randn(cnt, 3, generator=g) * 0.4  # local object frame
         object_ids[start:start + cnt] = k + 1
         start += cnt
     dc = torch.randn(n, F, 3, generator=g) * 0.3
@@ -65,9 +66,9 @@ def _composite_params(raw, object_ids, poses, idft, TO):
 @pytest.mark.parametrize("with_objects", [False, True])
 def test_fused_train_step_matches_reference_composition(torch_oracle, with_objects):
     from sgn_rast import step
-    cam, raw, object_ids, poses, idft = _scene_graph_scene()
+    cam, raw, object_ids, poses, idft = _scene_graph_scene(local_objects=with_objects)
     if not with_objects:
-        object_ids = torch.zeros_like(object_ids)
+        object_ids = torch.zeros_like(object_ids)   # everything is "background": identity pose, idft = e0
     w_img, w_a = step.loss_weights(cam, seed=7)
     # expected: reference composition on the CPU oracle (fp32), autograd through the glue
     Pc, comp = _composite_params(raw, object_ids, poses, idft, torch_oracle)
