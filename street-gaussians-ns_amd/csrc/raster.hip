@@ -385,8 +385,9 @@ SGN_EXPORT void sgn_set_debug_flags(int flags) { g_debug = flags; }
 SGN_EXPORT void sgn_set_gather_mode(int on) { g_gather = on ? 1 : 0; }
 
 SGN_EXPORT size_t sgn_raster_workspace_bytes(int n, int64_t n_isect) {
-    // [n_isect depth-ordered records][n per-Gaussian rows]
-    return ((size_t)(n_isect > 0 ? n_isect : 1) + (size_t)(n > 0 ? n : 1)) * sizeof(Rec);
+    // [n per-Gaussian rows][n_isect depth-ordered records (stream mode only)]
+    const size_t stream = g_gather ? 0 : (size_t)(n_isect > 0 ? n_isect : 1);
+    return ((size_t)(n > 0 ? n : 1) + stream) * sizeof(Rec);
 }
 
 SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
@@ -396,13 +397,14 @@ SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
 // builds the per-Gaussian rows and (stream mode) the depth-ordered record stream
 static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
                         const float *colors, const float *opac, int opac_is_logit, void *recs, hipStream_t s) {
-    float4 *grec = (float4 *)recs + 3 * n_isect;
+    float4 *grec = (float4 *)recs;                       // rows first,
+    float4 *stream_recs = (float4 *)recs + 3 * (size_t)n; // then the optional depth-ordered stream
     sgn_timing_begin(SGN_T_PACK, s);
     hipLaunchKernelGGL(build_grec_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, conics, colors, opac,
                        opac_is_logit, grec);
     if (!g_gather)
         hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(3 * n_isect, 256)), dim3(256), 0, s, n_isect, ids,
-                           grec, (float4 *)recs);
+                           grec, stream_recs);
     sgn_timing_end(SGN_T_PACK, s);
     return 0;
 }
@@ -422,8 +424,8 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     if (n_isect > 0)
         pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, recs_ws, s);
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
-    const Rec *stream_recs = (const Rec *)recs_ws;
-    const Rec *rows = stream_recs + n_isect;
+    const Rec *rows = (const Rec *)recs_ws;
+    const Rec *stream_recs = rows + n;
     sgn_timing_begin(SGN_T_RASTER_FWD, s);
 #define SGN_LAUNCH_FWD(EX, GA)                                                                                    \
     hipLaunchKernelGGL((raster_fwd_kernel<EX, GA>), dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,         \
@@ -465,8 +467,8 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         if (!recs_packed)
             pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, recs_ws, s);
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
-        const Rec *stream_recs = (const Rec *)recs_ws;
-        const Rec *rows = stream_recs + n_isect;
+        const Rec *rows = (const Rec *)recs_ws;
+        const Rec *stream_recs = rows + n;
         sgn_timing_begin(SGN_T_RASTER_BWD, s);
 #define SGN_LAUNCH_BWD(EX, RM, GA)                                                                               \
     hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA>), dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,    \

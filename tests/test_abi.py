@@ -75,7 +75,11 @@ def test_argument_errors_are_reported_without_a_gpu(built_lib):
     rc = lib.sgn_sh_fwd(4, 7, 3, None, None, None, None)
     assert rc < 0
     assert lib.sgn_sort_workspace_bytes(1 << 20) > (1 << 20) * 12
-    assert lib.sgn_raster_workspace_bytes(5, 10) == 15 * 48
+    lib.sgn_set_gather_mode(1)
+    assert lib.sgn_raster_workspace_bytes(5, 10) == 5 * 48        # per-Gaussian rows only
+    lib.sgn_set_gather_mode(0)
+    assert lib.sgn_raster_workspace_bytes(5, 10) == 15 * 48       # + depth-ordered record stream
+    lib.sgn_set_gather_mode(built_lib.DEFAULT_GATHER_MODE)
     assert lib.sgn_scan_workspace_bytes(5000) >= 12
 
 
