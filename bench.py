@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--path", default="dropin", choices=["dropin", "fused"],
                     help="dropin: gsplat-shaped ops + the reference's torch glue (headline); fused: sgn_rast.fused")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-path measurement")
+    ap.add_argument("--dp-exchange", default="lowrank", choices=["lowrank", "dense"],
+                    help="N>1: SH gradient via all-gathered low-rank factors (default) or dense all-reduce")
     return ap.parse_args()
 
 
@@ -145,7 +147,12 @@ def main():
     cam, raw = scenes.make_scene(args.scene, seed=0, yaw=0.01 * rank, device=dev, n_override=args.n)
     P = step.leaf_params(raw)
     w_img, w_a = step.loss_weights(cam, seed=1000 + rank, device=dev)
-    reducer = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]]) if world > 1 else None
+    reducer = None
+    if world > 1:
+        ex = None
+        if args.dp_exchange == "lowrank":
+            ex = dp.SHGradExchange(P["features_dc"], P["features_rest"]).install()
+        reducer = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex)
     n_gauss = P["means"].shape[0]
 
     def one_step(fused=(args.path == "fused")):
@@ -227,7 +234,9 @@ def main():
             "config": {"workload": (f"{args.scene}: {n_gauss} Gaussians, {cam.width}x{cam.height}, SH deg 3 (K=16), "
                                     f"block 16, fwd+bwd{' + depth pass' if args.with_depth else ''}; "
                                     f"measured I={n_isect} tile intersections/view"),
-                       "parallelism": f"dp{world} (view-parallel, RCCL grad all-reduce)" if world > 1 else "single",
+                       "parallelism": (f"dp{world} (view-parallel; RCCL all-reduce of geometry grads, SH grads "
+                                       f"{'all-gathered as low-rank factors' if args.dp_exchange == 'lowrank' else 'dense all-reduce'})"
+                                       if world > 1 else "single"),
                        "n_gaussians": n_gauss, "n_isect": n_isect},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

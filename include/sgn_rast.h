@@ -124,6 +124,14 @@ int sgn_sh_bwd_fused(int n, int k, int degree, const float *means, const float *
                      const int32_t *object_ids, const float *idft, const float *poses, int post_half_clamp,
                      const float *colors, const float *v_colors, float *v_features_dc, float *v_features_rest, sgn_stream_t stream);
 
+/* Data-parallel SH gradient: v_coeffs[n,k,c] = scale * sum_r basis_k(dir_{r,n}) * v_colors_all[r,n,c]
+ * over the n_views ranks' all-gathered colour gradients.  Directions come either from viewdirs_all [R,n,3]
+ * (drop-in path) or from means [n,3] (+ optional object_ids/poses) and cam_pos_all [R,3] (fused path); exactly one
+ * of the two must be given.  Replaces the dense [n,k,3] all-reduce: 2-4x less traffic on the xGMI links. */
+int sgn_sh_bwd_multi(int n, int k, int degree, int n_views, const float *viewdirs_all, const float *means,
+                     const float *cam_pos_all, const int32_t *object_ids, const float *poses,
+                     const float *v_colors_all, float scale, float *v_coeffs /*[n,k,3]*/, sgn_stream_t stream);
+
 /* _C.compute_sh_forward / _C.compute_sh_backward (gsplat/sh.py; reference call sites
  * sgn_splatfacto.py:939, sgn_splatfacto_scene_graph.py:285).  coeffs [n,k,3], k in
  * {1,4,9,16,25}; degree <= 4; directions are normalised inside; no +0.5. */

@@ -260,6 +260,61 @@ __global__ __launch_bounds__(WAVES * 64) void sh_bwd_fused_kernel(
     }
 }
 
+// ---- multi-view SH backward for data-parallel training ---------------------------------
+// v_coeffs[n,k,c] = sum_r basis_k(dir_{r,n}) * v_colors[r,n,c]: the SH gradient of ONE view is a rank-1 outer
+// product (K bases x 3 channels) of two things that are tiny on the wire — the 3-float colour gradient and the
+// view direction (or just the camera position).  Instead of all-reducing the dense [N,K,3] gradient
+// (192 B/Gaussian, 2*(R-1)/R of it over xGMI), ranks all-gather v_colors (+ viewdirs or cam_pos) and every rank
+// rebuilds the summed gradient locally with this kernel: 4x (cam_pos) or 2x (viewdirs) less traffic on the
+// point-to-point links, and the extra compute is hidden behind the 192 B/Gaussian store this kernel does anyway.
+template <int K, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sh_bwd_multi_kernel(
+    int n, int deg, int n_views, const float *__restrict__ dirs_all /*[R,n,3] or null*/,
+    const float *__restrict__ means /*[n,3] or null*/, const float *__restrict__ cam_pos /*[R,3] or null*/,
+    const int32_t *__restrict__ object_ids, const float *__restrict__ poses,
+    const float *__restrict__ v_colors_all /*[R,n,3]*/, float scale, float *__restrict__ v_coeffs) {
+    constexpr int KC = K * 3, LS = (KC | 1);
+    __shared__ float lds[WAVES][64 * LS];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * WAVES + wave) * 64;
+    const int cnt = max(0, min(64, n - g0));
+    float *my = lds[wave];
+    if (lane < cnt) {
+        const int i = g0 + lane;
+        float acc[KC];
+#pragma unroll
+        for (int e = 0; e < KC; ++e) acc[e] = 0.f;
+        for (int r = 0; r < n_views; ++r) {
+            float dx, dy, dz;
+            if (dirs_all != nullptr) {
+                const float *d = dirs_all + ((size_t)r * n + i) * 3;
+                dx = d[0]; dy = d[1]; dz = d[2];
+            } else {
+                fused_viewdir(i, means, cam_pos + 3 * r, object_ids, poses, dx, dy, dz);
+            }
+            float b[25];
+            const int nb = sh_bases(dx, dy, dz, deg, b);
+            const float *v = v_colors_all + ((size_t)r * n + i) * 3;
+            const float v0 = v[0], v1 = v[1], v2 = v[2];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const float bk = (k < nb) ? b[k] : 0.f;
+                acc[3 * k] += bk * v0; acc[3 * k + 1] += bk * v1; acc[3 * k + 2] += bk * v2;
+            }
+        }
+        float *row = my + lane * LS;
+#pragma unroll
+        for (int e = 0; e < KC; ++e) row[e] = acc[e] * scale;
+    }
+    __syncthreads();
+    float *dst = v_coeffs + (size_t)g0 * KC;
+    const int total = cnt * KC;
+    for (int e = lane; e < total; e += 64) {
+        const int r = e / KC, c = e - r * KC;
+        dst[e] = my[r * LS + c];
+    }
+}
+
 template <int K>
 int launch_fwd(int n, int deg, const float *dirs, const float *coeffs, float *colors, hipStream_t s) {
     constexpr int WAVES = (K > 16) ? 2 : 4;  // keep static LDS under 64 KiB
@@ -382,6 +437,39 @@ SGN_EXPORT int sgn_sh_bwd_fused(int n, int k, int degree, const float *means, co
         case 9: launch_bwd_fused<9>(n, degree, means, cam_pos3, n_fourier, object_ids, idft, poses, post_half_clamp, colors, v_colors, v_features_dc, v_features_rest, s); break;
         case 16: launch_bwd_fused<16>(n, degree, means, cam_pos3, n_fourier, object_ids, idft, poses, post_half_clamp, colors, v_colors, v_features_dc, v_features_rest, s); break;
         default: launch_bwd_fused<25>(n, degree, means, cam_pos3, n_fourier, object_ids, idft, poses, post_half_clamp, colors, v_colors, v_features_dc, v_features_rest, s); break;
+    }
+    sgn_timing_end(SGN_T_SH_BWD, s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int K>
+static void launch_bwd_multi(int n, int deg, int R, const float *dirs_all, const float *means, const float *cam_pos,
+                             const int32_t *oid, const float *poses, const float *v_all, float scale, float *out,
+                             hipStream_t s) {
+    constexpr int WAVES = (K > 16) ? 2 : 4;
+    hipLaunchKernelGGL((sh_bwd_multi_kernel<K, WAVES>), dim3(sgn_cdiv(n, WAVES * 64)), dim3(WAVES * 64), 0, s, n, deg, R,
+                       dirs_all, means, cam_pos, oid, poses, v_all, scale, out);
+}
+
+SGN_EXPORT int sgn_sh_bwd_multi(int n, int k, int degree, int n_views, const float *viewdirs_all, const float *means,
+                                const float *cam_pos_all, const int32_t *object_ids, const float *poses,
+                                const float *v_colors_all, float scale, float *v_coeffs, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0 && n_views >= 1, -1);
+    SGN_ARG_CHECK(degree >= 0 && degree <= 4, -2);
+    SGN_ARG_CHECK(k == 1 || k == 4 || k == 9 || k == 16 || k == 25, -3);
+    SGN_ARG_CHECK((degree + 1) * (degree + 1) <= k, -4);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(v_colors_all && v_coeffs, -5);
+    SGN_ARG_CHECK((viewdirs_all != nullptr) != (means != nullptr && cam_pos_all != nullptr), -6);
+    hipStream_t s = (hipStream_t)stream;
+    sgn_timing_begin(SGN_T_SH_BWD, s);
+    switch (k) {
+        case 1: launch_bwd_multi<1>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, s); break;
+        case 4: launch_bwd_multi<4>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, s); break;
+        case 9: launch_bwd_multi<9>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, s); break;
+        case 16: launch_bwd_multi<16>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, s); break;
+        default: launch_bwd_multi<25>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, s); break;
     }
     sgn_timing_end(SGN_T_SH_BWD, s);
     SGN_LAUNCH_CHECK();

@@ -37,6 +37,7 @@ SIGNATURES = {
                                    _vp, _vp, _vp, _vp]),
     "sgn_sh_fwd_fused": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sgn_sh_bwd_fused": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_sh_bwd_multi": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "sgn_sh_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_sh_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_scan_workspace_bytes": (_sz, [_i]),

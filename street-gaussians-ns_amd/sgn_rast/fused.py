@@ -110,6 +110,11 @@ def project_gaussians_fused(means, log_scales, quats_raw, viewmat, fx, fy, cx, c
                                glob_scale)
 
 
+# tap for sgn_rast.dp.SHGradExchange (see ops._sh_bwd_tap); receives
+# (means, cam_pos, v_colors_effective, degree, K, object_ids, poses, idft)
+_sh_bwd_tap = None
+
+
 class _SHFused(Function):
     @staticmethod
     def forward(ctx, degree, means, cam_pos, features_dc, features_rest, object_ids, idft, poses, post):
@@ -143,6 +148,11 @@ class _SHFused(Function):
         pos = saved[5] if ctx.has_pose else None
         degree, k, F, post, has_rest = ctx.meta
         n, dev = means.shape[0], means.device
+        if _sh_bwd_tap is not None:
+            v_eff = _f32c(v_colors)
+            if post:
+                v_eff = v_eff * (colors > 0)
+            _sh_bwd_tap(means, cam, v_eff, degree, k, oid, pos, idft)
         v_dc = torch.empty(n, F, 3, dtype=torch.float32, device=dev)
         v_rest = torch.empty(n, k - 1, 3, dtype=torch.float32, device=dev) if has_rest else None
         L.check(L.load().sgn_sh_bwd_fused(n, k, degree, L.ptr(means), L.ptr(cam), F, L.ptr(oid), L.ptr(idft), L.ptr(pos), post,

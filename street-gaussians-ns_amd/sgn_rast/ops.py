@@ -58,6 +58,12 @@ def deg_from_sh(num_bases: int) -> int:
     assert False, "Invalid number of SH bases"
 
 
+# Optional tap for data-parallel training (sgn_rast.dp.SHGradExchange): called from the SH backward with
+# (viewdirs, v_colors, degrees_to_use, K) so the low-rank factors of the SH gradient can be exchanged
+# instead of the dense [N,K,3] tensor.  None in normal operation.
+_sh_bwd_tap = None
+
+
 class _SphericalHarmonics(Function):
     @staticmethod
     def forward(ctx, degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor):
@@ -78,6 +84,8 @@ class _SphericalHarmonics(Function):
         (viewdirs,) = ctx.saved_tensors
         n = v_colors.shape[0]
         v_colors = _f32c(v_colors)
+        if _sh_bwd_tap is not None:
+            _sh_bwd_tap(viewdirs, v_colors, ctx.degrees_to_use, ctx.k)
         v_coeffs = torch.empty(n, ctx.k, 3, dtype=torch.float32, device=v_colors.device)
         L.check(L.load().sgn_sh_bwd(n, ctx.k, ctx.degrees_to_use, L.ptr(viewdirs), L.ptr(v_colors),
                                     L.ptr(v_coeffs), L.stream_ptr()), "sgn_sh_bwd")

@@ -75,3 +75,72 @@ def test_two_rank_gradient_allreduce_matches_single_process(torch_oracle, tmp_pa
     assert l0 != l1                    # the two ranks really rendered different views
     assert torch.equal(s0[0], torch.full((5,), 3.0)) and torch.equal(s0[1], torch.full((5,), 6.0))
     assert torch.equal(s0[2], torch.full((5,), 20.0)) and all(torch.equal(a, b) for a, b in zip(s0, s1))
+
+
+def _sh_multi_torch(degree, k, dirs_all, means, cam_all, object_ids, poses, v_all, scale):
+    """Reference for sgn_sh_bwd_multi on the CPU (tests only): sum_r basis(dir_r) (x) v_r."""
+    from oracle import torch_oracle as TO
+    R, n = v_all.shape[0], v_all.shape[1]
+    out = torch.zeros(n, k, 3)
+    for r in range(R):
+        dirs = dirs_all[r] if dirs_all is not None else means - cam_all[r]
+        b = torch.stack(TO._sh_bases(dirs, degree), dim=-1)
+        out[:, : b.shape[1], :] += b[:, :, None] * v_all[r][:, None, :]
+    return out * scale
+
+
+def _exchange_worker(rank, world, port, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "street-gaussians-ns_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from oracle import torch_oracle as TO
+    from sgn_rast import dp
+    torch.set_num_threads(2)
+    dp.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(100 + rank)                  # per-rank view and colour gradient
+    n, k, deg = 300, 16, 3
+    gp = torch.Generator().manual_seed(7)                           # replicated parameters
+    means = torch.randn(n, 3, generator=gp) * 3
+    dc = torch.randn(n, 1, 3, generator=gp).requires_grad_(True)
+    rest = torch.randn(n, k - 1, 3, generator=gp).requires_grad_(True)
+    cam_pos = torch.randn(3, generator=g)
+    dirs = means - cam_pos
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    v_rgb = torch.randn(n, 3, generator=g)
+    # local dense gradient the ordinary way (autograd through cat + SH)
+    rgb = TO.spherical_harmonics(deg, dirs, torch.cat((dc, rest), dim=1))
+    rgb.backward(v_rgb)
+    local = torch.cat((dc.grad, rest.grad), dim=1).clone()
+    for mode in ("dirs", "cam"):
+        ex = dp.SHGradExchange(dc, rest, average=True, multi_fn=_sh_multi_torch)
+        red = dp.GradAllReducer([dc, rest], big=[rest], sh_exchange=ex)
+        assert red.params == [] and not red._handles               # SH leaves are left to the exchange
+        if mode == "dirs":
+            ex._tap_dirs(dirs, v_rgb, deg, k)
+        else:
+            ex._tap_fused(means, cam_pos, v_rgb, deg, k, None, None, torch.ones(1, 1))
+        red.finish()
+        torch.save((local, torch.cat((dc.grad, rest.grad), dim=1).clone()), os.path.join(outdir, f"{mode}{rank}.pt"))
+        dc.grad.copy_(local[:, :1]); rest.grad.copy_(local[:, 1:])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sh_low_rank_exchange_equals_dense_allreduce(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_exchange_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=500)
+        assert p.exitcode == 0
+    for mode in ("dirs", "cam"):
+        res = [torch.load(os.path.join(tmp_path, f"{mode}{r}.pt")) for r in range(world)]
+        dense_mean = (res[0][0] + res[1][0]) / world               # what a dense all-reduce (average) would give
+        for r in range(world):
+            assert torch.allclose(res[r][1], dense_mean, rtol=1e-5, atol=1e-6), (mode, r)
+        assert torch.equal(res[0][1], res[1][1])                    # replicas agree bit-for-bit
