@@ -80,3 +80,38 @@ def make_scene(name: str, seed: int = 0, yaw: float = 0.0, device="cpu", n_overr
     cam0 = make_camera(w, h, f, yaw=0.0)
     params = make_gaussians(n, cam0, seed=seed, z_range=zr, device=device)
     return cam, params
+
+
+def make_scene_graph(n_total: int, cam: Camera, n_objects: int = 8, object_frac: float = 0.1, fourier_dim: int = 5,
+                     seed: int = 0, z_range=(2.0, 60.0), device="cpu"):
+    """Background + ``n_objects`` rigid objects (configs[2] shape: scene-graph dynamic objects).  Returns
+    (models, poses [M,16], idft [M,F]); object parameters are in the object's local frame, its Gaussians
+    spread ~1.5 m around the pose centre; ``features_dc`` of objects carries ``fourier_dim`` coefficients
+    (sgn_config.py:66), the background one (sgn_config.py:56)."""
+    from .fused import make_pose_table
+    g = torch.Generator().manual_seed(seed + 17)
+    n_obj = int(n_total * object_frac) // max(1, n_objects)
+    n_bg = n_total - n_obj * n_objects
+    cam0 = make_camera(cam.width, cam.height, cam.fx)
+    models = [make_gaussians(n_bg, cam0, seed=seed, z_range=z_range)]
+    Rs, ts, idfts = [torch.eye(3)], [torch.zeros(3)], [torch.cat([torch.ones(1), torch.zeros(fourier_dim - 1)])]
+    for k in range(n_objects):
+        m = make_gaussians(n_obj, cam0, seed=seed + 1 + k, z_range=z_range)
+        m["means"] = torch.randn(n_obj, 3, generator=g) * torch.tensor([1.0, 0.6, 1.5])
+        dc = torch.randn(n_obj, fourier_dim, 3, generator=g) * 0.1
+        dc[:, 0] += m["features_dc"][:, 0]
+        m["features_dc"] = dc
+        models.append(m)
+        yaw = float(torch.rand(1, generator=g)) * 6.28
+        c, s = math.cos(yaw), math.sin(yaw)
+        Rs.append(torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]]))
+        z = 8.0 + 40.0 * float(torch.rand(1, generator=g))
+        x = (float(torch.rand(1, generator=g)) * 2 - 1) * 0.8 * z * (cam.width / 2.0 / cam.fx)
+        ts.append(torch.tensor([x, 0.4 * z * (cam.height / 2.0 / cam.fy) * 0.5, z]))
+        t_norm = float(torch.rand(1, generator=g))
+        w = [math.cos(2 * math.pi * t_norm * kk / fourier_dim) if kk % 2 == 0
+             else math.sin(2 * math.pi * t_norm * (kk + 1) / fourier_dim) for kk in range(fourier_dim)]
+        idfts.append(torch.tensor(w))
+    poses = make_pose_table(torch.stack(Rs), torch.stack(ts))
+    models = [{k: v.to(device) for k, v in m.items()} for m in models]
+    return models, poses.to(device), torch.stack(idfts).to(device)

@@ -90,6 +90,84 @@ def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int 
     return out
 
 
+def _quaternion_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """pytorch3d.transforms.quaternion_multiply (Hamilton product, real part first), used by
+    object2world_gs at sgn_splatfacto_scene_graph.py:416."""
+    aw, ax, ay, az = torch.unbind(a, -1)
+    bw, bx, by, bz = torch.unbind(b, -1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
+
+
+def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Camera, sh_degree_to_use: int = 3,
+                       block_width: int = 16, ops=_hip_ops, fused: bool = False) -> SimpleNamespace:
+    """Replay of ``SplatfactoSceneGraphModel.get_outputs`` in training mode
+    (``sgn_splatfacto_scene_graph.py:305-366``): ``models[0]`` is the background, ``models[i>0]`` rigid objects
+    whose parameters live in the object's local frame; ``poses[i]`` = [R(9) t(3) q_o2w(4)], ``idft[i]`` = Fourier
+    weights of the frame.  Four raster passes like the reference: rgb+alpha, depth, objects-only accumulation,
+    background-only accumulation.  ``fused=True`` runs the main pass through :mod:`sgn_rast.fused` (no transform /
+    activation / concat kernels) and skips the SH evaluation whose result the reference throws away in the two
+    accumulation passes (``:285``)."""
+    dev = models[0]["means"].device
+    H, W = cam.height, cam.width
+    counts = [m["means"].shape[0] for m in models]
+    bg_zero = torch.zeros(3, device=dev, dtype=torch.float32)
+    cat = lambda key: torch.cat([m[key] for m in models], dim=0)                        # :355-360
+    if fused:
+        from . import fused as F_
+        Fmax = max(m["features_dc"].shape[1] for m in models)
+        pad = lambda d: d if d.shape[1] == Fmax else torch.cat(
+            [d, torch.zeros(d.shape[0], Fmax - d.shape[1], 3, device=dev, dtype=d.dtype)], dim=1)
+        P = dict(means=cat("means"), log_scales=cat("log_scales"), quats=cat("quats"),
+                 opacity_logits=cat("opacity_logits"), features_rest=cat("features_rest"),
+                 features_dc=torch.cat([pad(m["features_dc"]) for m in models], dim=0))
+        object_ids = torch.repeat_interleave(torch.arange(len(models), device=dev, dtype=torch.int32),
+                                             torch.tensor(counts, device=dev))
+        idft_p = torch.zeros(len(models), Fmax, device=dev)
+        for i, m in enumerate(models):
+            idft_p[i, : m["features_dc"].shape[1]] = idft[i][: m["features_dc"].shape[1]]
+        out = render_fused(P, cam, sh_degree_to_use, block_width, with_depth=True, object_ids=object_ids,
+                           poses=poses, idft=idft_p)
+        opac_arg, raster = P["opacity_logits"], F_.rasterize_gaussians_fused
+    else:
+        world_means, world_quats, dcs = [], [], []
+        for i, m in enumerate(models):
+            Fi = m["features_dc"].shape[1]
+            dcs.append((m["features_dc"] * idft[i][:Fi, None]).sum(dim=1, keepdim=True) if Fi > 1
+                       else m["features_dc"])                                          # :239-247
+            if i == 0:
+                world_means.append(m["means"]); world_quats.append(m["quats"])
+            else:
+                R, t, q = poses[i, :9].reshape(3, 3), poses[i, 9:12], poses[i, 12:16]
+                world_means.append(m["means"] @ R.T + t[None, :])                      # :415
+                world_quats.append(_quaternion_multiply(q[None, :], m["quats"]))       # :416
+        P = dict(means=torch.cat(world_means), quats=torch.cat(world_quats), features_dc=torch.cat(dcs),
+                 opacity_logits=cat("opacity_logits"), features_rest=cat("features_rest"),
+                 log_scales=cat("log_scales"))
+        out = render(P, cam, sh_degree_to_use, block_width, with_depth=True, ops=ops)  # :363
+        opac_arg, raster = out.opacities, ops.rasterize_gaussians
+
+    def submodel_acc(lo: int, hi: int):                                                 # :255-303
+        sl = slice(lo, hi)
+        if hi <= lo:
+            return torch.zeros(H, W, device=dev)
+        if fused:
+            rgbs = torch.zeros(hi - lo, 3, device=dev)   # colour is irrelevant for an accumulation-only pass
+        else:
+            colors = torch.cat((P["features_dc"][sl], P["features_rest"][sl]), dim=1)
+            viewdirs = P["means"][sl].detach() - cam.cam_pos
+            viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+            rgbs = torch.clamp(ops.spherical_harmonics(sh_degree_to_use, viewdirs, colors) + 0.5, min=0.0)
+        _, acc = raster(out.xys[sl], out.depths[sl], out.radii[sl], out.conics[sl], out.num_tiles_hit[sl], rgbs,
+                        opac_arg[sl], H, W, block_width, background=bg_zero, return_alpha=True)
+        return acc
+
+    n_bg = counts[0]
+    out.object_acc = submodel_acc(n_bg, sum(counts))                                     # :364-365
+    out.background_acc = submodel_acc(0, n_bg)                                           # :366
+    return out
+
+
 def loss_weights(cam: Camera, seed: int = 7, device="cpu", dtype=torch.float32):
     g = torch.Generator().manual_seed(seed)
     w_img = torch.rand(cam.height, cam.width, 3, generator=g)
