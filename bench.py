@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--path", default="dropin", choices=["dropin", "fused"],
                     help="dropin: gsplat-shaped ops + the reference's torch glue (headline); fused: sgn_rast.fused")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-path measurement")
+    ap.add_argument("--street", action="store_true",
+                    help="non-uniform 'street' content (empty sky, ground, facades, dense low-opacity clusters) at the "
+                         "scene's N and resolution: load-balance profiling, not the headline metric")
     ap.add_argument("--scene-graph", action="store_true",
                     help="reference-faithful scene-graph step (SURVEY.md §8d): background + 8 rigid objects, four "
                          "raster passes (rgb+alpha, depth, object acc, background acc); not the headline metric")
@@ -148,6 +151,8 @@ def main():
     L.load()
 
     cam, raw = scenes.make_scene(args.scene, seed=0, yaw=0.01 * rank, device=dev, n_override=args.n)
+    if args.street:
+        raw = scenes.make_street_gaussians(raw["means"].shape[0], cam, seed=0, device=dev)
     P = step.leaf_params(raw)
     w_img, w_a = step.loss_weights(cam, seed=1000 + rank, device=dev)
     reducer = None
@@ -270,6 +275,9 @@ def main():
             "kernels_avg_ms": {k: round(v[1], 4) for k, v in kernels.items()},
         }
         line["config"]["path"] = args.path
+        if args.street:
+            line["metric"] = "train-step images/sec (fwd+bwd), non-uniform street-like content (profiling workload)"
+            line["config"]["workload"] = "street: " + line["config"]["workload"]
         if args.scene_graph:
             line["metric"] = "scene-graph train-step images/sec (4 raster passes, fwd+bwd) @1M Gaussians 1920x1280"
             line["config"]["workload"] = ("scene graph: " + line["config"]["workload"] +

@@ -50,6 +50,9 @@ void sgn_set_debug_flags(int flags);
 /* 0: raster kernels stream a depth-ordered 48-byte record per intersection (packed first);
  * 1: they chase gaussian_ids_sorted[k] -> per-Gaussian row with dependent scalar loads (no pack pass). */
 void sgn_set_gather_mode(int on);
+/* 1 (default): one wave64 per tile, 4 pixels per lane; 4: four waves per tile, one 8x8 quadrant each
+ * (shorter per-tile critical path for scenes with very long depth lists). */
+void sgn_set_waves_per_tile(int w);
 
 /* Opt-in per-kernel timing for bench.py / profiles: when enabled, each timed launch is bracketed by
  * hipEventRecord on the stream it is launched on; sgn_timing_get sums the finished spans of a slot. */

@@ -112,7 +112,10 @@ __device__ __forceinline__ void slot_pixel(int q, int lane, int B, int &ox, int 
 //                 ids[k] -> row with two dependent scalar loads, the id two records ahead and the row
 //                 one record ahead, so only the (tile, Gaussian) pairs that are actually walked before
 //                 the tile terminates are ever fetched (12 % of them on the benchmark scene).
-template <bool EXACT, bool GATHER>
+// QPW = quadrants per wave: 4 -> one wave owns the whole 16x16 tile (fewest scalar fetches and, in the
+// backward, one reduction per (tile, Gaussian)); 1 -> four waves per tile, one 8x8 quadrant each (4x
+// shorter critical path per tile: for scenes whose longest depth lists dominate the kernel's tail).
+template <bool EXACT, bool GATHER, int QPW>
 __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int tiles_x,
                                                         const int2 *__restrict__ bins,
                                                         const Rec *__restrict__ recs,
@@ -120,7 +123,9 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
                                                         const float *__restrict__ bg, float *__restrict__ out_img,
                                                         float *__restrict__ final_T,
                                                         int32_t *__restrict__ final_idx) {
-    const int tile = blockIdx.x;
+    constexpr int WPT = 4 / QPW;               // waves per tile
+    const int tile = blockIdx.x / WPT;
+    const int q0 = (blockIdx.x % WPT) * QPW;   // first quadrant (pixel slot) of this wave
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -128,14 +133,14 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
 
     // Per-pixel state; "this pixel is finished (or outside the image)" is carried in the SIGN of T
     // (T > 0 <=> still compositing), so liveness costs one v_cmp and no mask bookkeeping in VGPRs.
-    float px[4], py[4], T[4], C0[4], C1[4], C2[4];
-    int last[4], pix[4];
-    bool inside[4];
+    float px[QPW], py[QPW], T[QPW], C0[QPW], C1[QPW], C2[QPW];
+    int last[QPW], pix[QPW];
+    bool inside[QPW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QPW; ++q) {
         int ox, oy;
         bool in_tile;
-        slot_pixel(q, lane, B, ox, oy, in_tile);
+        slot_pixel(q0 + q, lane, B, ox, oy, in_tile);
         const int j = tx * B + ox, i = ty * B + oy;
         inside[q] = in_tile && j < W && i < H;
         pix[q] = i * W + j;
@@ -150,15 +155,18 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
         Rec cur = recs[GATHER ? ids[range.x] : range.x];
         int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
         for (int k = range.x; k < range.y; ++k) {
-            const unsigned long long live0 = __ballot(T[0] > 0.f), live1 = __ballot(T[1] > 0.f);
-            const unsigned long long live2 = __ballot(T[2] > 0.f), live3 = __ballot(T[3] > 0.f);
-            if ((live0 | live1 | live2 | live3) == 0ull) break;
+            unsigned long long live[QPW], any_live = 0ull;
+#pragma unroll
+            for (int q = 0; q < QPW; ++q) {
+                live[q] = __ballot(T[q] > 0.f);
+                any_live |= live[q];
+            }
+            if (any_live == 0ull) break;
             const int kn = (k + 1 < range.y) ? k + 1 : k;
             const Rec nxt = recs[GATHER ? idn : kn];  // scalar prefetch of the next record
             if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
-            const unsigned long long live[4] = {live0, live1, live2, live3};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < QPW; ++q) {
                 if (live[q] == 0ull) continue;  // wave-uniform
                 const float dx = cur.x - px[q], dy = cur.y - py[q];
                 float s = (cur.ha * dx) * dx;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
         }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QPW; ++q) {
         if (inside[q]) {
             const float Tq = fabsf(T[q]);
             final_T[pix[q]] = Tq;
@@ -224,7 +232,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 // grad_ws row layout (12 floats / Gaussian): 0,1 v_xy | 2,3,4 v_conic | 5,6,7 v_rgb | 8 v_opacity
-template <bool EXACT, int REDUCE, bool GATHER>
+template <bool EXACT, int REDUCE, bool GATHER, int QPW>
 __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int tiles_x,
                                                         const int2 *__restrict__ bins,
                                                         const Rec *__restrict__ recs,
@@ -235,7 +243,9 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                                                         const float *__restrict__ v_out,
                                                         const float *__restrict__ v_out_alpha,
                                                         float alpha_clamp, float *__restrict__ grad_ws, int dbg) {
-    const int tile = blockIdx.x;
+    constexpr int WPT = 4 / QPW;
+    const int tile = blockIdx.x / WPT;
+    const int q0 = (blockIdx.x % WPT) * QPW;
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
     if (range.x >= range.y) return;
@@ -247,14 +257,14 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
     //   v_alpha = sum_c (color_c*T - buffer_c*ra) * v_out_c + T_final*ra*v_out_alpha - T_final*ra*sum_c bg_c*v_out_c
     // becomes  v_alpha = ra * (T_before * dotc - bv + c0),  c0 = T_final * (v_out_alpha - sum_c bg_c*v_out_c),
     // i.e. 3 VALU ops instead of ~26, one running scalar instead of a 3-channel buffer.
-    float px[4], py[4], T[4], c0[4], bv[4], vo0[4], vo1[4], vo2[4];
-    int kfin[4];
+    float px[QPW], py[QPW], T[QPW], c0[QPW], bv[QPW], vo0[QPW], vo1[QPW], vo2[QPW];
+    int kfin[QPW];
     int kmax_l = -1;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < QPW; ++q) {
         int ox, oy;
         bool in_tile;
-        slot_pixel(q, lane, B, ox, oy, in_tile);
+        slot_pixel(q0 + q, lane, B, ox, oy, in_tile);
         const int j = tx * B + ox, i = ty * B + oy;
         const bool inside = in_tile && j < W && i < H;
         const int pix = inside ? i * W + j : 0;
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_o = 0.f;
         bool any = false;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < QPW; ++q) {
             if (__ballot(k <= kfin[q]) == 0ull) continue;  // wave-uniform
             const float dx = cur.x - px[q], dy = cur.y - py[q];
             const float t1 = cur.ha * dx, t2 = cur.hc * dy, t3 = cur.b * dx;
@@ -374,6 +384,7 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *_
 int g_exact_exp = 0;
 int g_reduce_mode = 0;   // 0: ds_bpermute shuffles, 1: DPP
 int g_debug = 0;         // timing ablations only (bit0: no atomics, bit1: no wave reduction)
+int g_wpt = 1;           // waves per tile: 1 (4 quadrants per wave) or 4 (one quadrant per wave)
 int g_gather = 1;        // 1 (default): chase ids -> per-Gaussian rows; 0: stream packed records
 
 }  // namespace
@@ -383,6 +394,7 @@ SGN_EXPORT int sgn_get_exact_exp(void) { return g_exact_exp; }
 SGN_EXPORT void sgn_set_reduce_mode(int mode) { g_reduce_mode = mode ? 1 : 0; }
 SGN_EXPORT void sgn_set_debug_flags(int flags) { g_debug = flags; }
 SGN_EXPORT void sgn_set_gather_mode(int on) { g_gather = on ? 1 : 0; }
+SGN_EXPORT void sgn_set_waves_per_tile(int w) { g_wpt = (w == 4) ? 4 : 1; }
 
 SGN_EXPORT size_t sgn_raster_workspace_bytes(int n, int64_t n_isect) {
     // [n per-Gaussian rows][n_isect depth-ordered records (stream mode only)]
@@ -427,15 +439,17 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     const Rec *rows = (const Rec *)recs_ws;
     const Rec *stream_recs = rows + n;
     sgn_timing_begin(SGN_T_RASTER_FWD, s);
-#define SGN_LAUNCH_FWD(EX, GA)                                                                                    \
-    hipLaunchKernelGGL((raster_fwd_kernel<EX, GA>), dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,         \
-                       block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, \
+#define SGN_LAUNCH_FWD(EX, GA, Q)                                                                                    \
+    hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q>), dim3(tiles_x * tiles_y * (4 / Q)), dim3(64), 0, s, img_w, img_h, \
+                       block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted,    \
                        background3, out_img, final_Ts, final_idx)
+#define SGN_LAUNCH_FWD2(EX, GA) do { if (g_wpt == 4) SGN_LAUNCH_FWD(EX, GA, 1); else SGN_LAUNCH_FWD(EX, GA, 4); } while (0)
     if (g_exact_exp) {
-        if (g_gather) SGN_LAUNCH_FWD(true, true); else SGN_LAUNCH_FWD(true, false);
+        if (g_gather) SGN_LAUNCH_FWD2(true, true); else SGN_LAUNCH_FWD2(true, false);
     } else {
-        if (g_gather) SGN_LAUNCH_FWD(false, true); else SGN_LAUNCH_FWD(false, false);
+        if (g_gather) SGN_LAUNCH_FWD2(false, true); else SGN_LAUNCH_FWD2(false, false);
     }
+#undef SGN_LAUNCH_FWD2
 #undef SGN_LAUNCH_FWD
     sgn_timing_end(SGN_T_RASTER_FWD, s);
     SGN_LAUNCH_CHECK();
@@ -471,7 +485,9 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         const Rec *stream_recs = rows + n;
         sgn_timing_begin(SGN_T_RASTER_BWD, s);
 #define SGN_LAUNCH_BWD(EX, RM, GA)                                                                               \
-    hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA>), dim3(tiles_x * tiles_y), dim3(64), 0, s, img_w, img_h,    \
+    do { if (g_wpt == 4) SGN_LAUNCH_BWDQ(EX, RM, GA, 1); else SGN_LAUNCH_BWDQ(EX, RM, GA, 4); } while (0)
+#define SGN_LAUNCH_BWDQ(EX, RM, GA, Q)                                                                           \
+    hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q>), dim3(tiles_x * tiles_y * (4 / Q)), dim3(64), 0, s, img_w, img_h, \
                        block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, \
                        background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws, \
                        g_debug)
@@ -483,6 +499,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         }
 #undef SGN_LAUNCH_BWD2
 #undef SGN_LAUNCH_BWD
+#undef SGN_LAUNCH_BWDQ
         sgn_timing_end(SGN_T_RASTER_BWD, s);
     }
     sgn_timing_begin(SGN_T_UNPACK, s);

@@ -115,3 +115,25 @@ def make_scene_graph(n_total: int, cam: Camera, n_objects: int = 8, object_frac:
     poses = make_pose_table(torch.stack(Rs), torch.stack(ts))
     models = [{k: v.to(device) for k, v in m.items()} for m in models]
     return models, poses.to(device), torch.stack(idfts).to(device)
+
+
+def make_street_gaussians(n: int, cam: Camera, seed: int = 0, device="cpu") -> Dict[str, torch.Tensor]:
+    """A deliberately NON-uniform scene for load-balance profiling (not a BASELINE config): empty sky in the
+    upper part of the image, a ground plane, two facades, and 30 % of the Gaussians packed into 20 small
+    semi-transparent "foliage" clusters, so a handful of tiles carry very long depth lists that do not saturate."""
+    g = torch.Generator().manual_seed(seed + 99)
+    raw = make_gaussians(n, cam, seed=seed)
+    n_ground, n_wall = int(0.4 * n), int(0.3 * n)
+    n_clu = n - n_ground - n_wall
+    u = lambda k, lo, hi: torch.rand(k, generator=g) * (hi - lo) + lo
+    ground = torch.stack([u(n_ground, -20, 20), torch.full((n_ground,), 1.6), u(n_ground, 2, 80)], -1)
+    side = (torch.rand(n_wall, generator=g) > 0.5).float() * 2 - 1
+    wall = torch.stack([side * 12.0, u(n_wall, -6, 1.6), u(n_wall, 4, 80)], -1)
+    centres = torch.stack([u(20, -8, 8), u(20, -3, 0.5), u(20, 20, 60)], -1)
+    which = torch.randint(0, 20, (n_clu,), generator=g)
+    clu = centres[which] + torch.randn(n_clu, 3, generator=g) * 0.6
+    raw["means"] = torch.cat([ground, wall, clu])
+    raw["log_scales"][: n_ground, 1] -= 2.0                    # flat on the ground
+    raw["log_scales"][n_ground + n_wall:] -= 0.7               # small leaves
+    raw["opacity_logits"][n_ground + n_wall:] = -2.0           # alpha ~ 0.12: long lists, no early termination
+    return {k: v.to(device) for k, v in raw.items()}

@@ -19,14 +19,17 @@ def hip():
     return ops
 
 
-@pytest.fixture(autouse=True, params=[0, 1], ids=["stream", "gather"])
+@pytest.fixture(autouse=True, params=[(0, 1), (1, 1), (1, 4)], ids=["stream", "gather", "gather-4waves"])
 def raster_record_mode(request):
-    """Every test in this module runs with both record-fetch modes of the raster kernels
-    (packed depth-ordered stream vs. ids -> per-Gaussian rows chased with scalar loads)."""
+    """Every test in this module runs with the record-fetch modes of the raster kernels (packed depth-ordered
+    stream vs. ids -> per-Gaussian rows chased with scalar loads) and with 1 or 4 waves per tile."""
     from sgn_rast import _lib as L
-    L.load().sgn_set_gather_mode(request.param)
+    gather, wpt = request.param
+    L.load().sgn_set_gather_mode(gather)
+    L.load().sgn_set_waves_per_tile(wpt)
     yield request.param
     L.load().sgn_set_gather_mode(L.DEFAULT_GATHER_MODE)
+    L.load().sgn_set_waves_per_tile(1)
 
 
 def _project_args(cam, P, block=16, dev="cpu"):
