@@ -50,9 +50,12 @@ void sgn_set_debug_flags(int flags);
 /* 0: raster kernels stream a depth-ordered 48-byte record per intersection (packed first);
  * 1: they chase gaussian_ids_sorted[k] -> per-Gaussian row with dependent scalar loads (no pack pass). */
 void sgn_set_gather_mode(int on);
-/* 1 (default): one wave64 per tile, 4 pixels per lane; 4: four waves per tile, one 8x8 quadrant each
- * (shorter per-tile critical path for scenes with very long depth lists). */
+/* 1: one wave64 per tile, 4 pixels per lane; 4: four waves per tile, one 8x8 quadrant each; 0 (default):
+ * adaptive — tiles whose depth list (forward) / reverse walk (backward) is at least the threshold are split
+ * over four waves, the rest are done by one (shorter critical path where the list is long, fewest fetches and
+ * reductions where it is short). */
 void sgn_set_waves_per_tile(int w);
+void sgn_set_adaptive_thresholds(int fwd_entries, int bwd_entries); /* <= 0 keeps the current value */
 
 /* Opt-in per-kernel timing for bench.py / profiles: when enabled, each timed launch is bracketed by
  * hipEventRecord on the stream it is launched on; sgn_timing_get sums the finished spans of a slot. */

@@ -115,19 +115,29 @@ __device__ __forceinline__ void slot_pixel(int q, int lane, int B, int &ox, int 
 // QPW = quadrants per wave: 4 -> one wave owns the whole 16x16 tile (fewest scalar fetches and, in the
 // backward, one reduction per (tile, Gaussian)); 1 -> four waves per tile, one 8x8 quadrant each (4x
 // shorter critical path per tile: for scenes whose longest depth lists dominate the kernel's tail).
-template <bool EXACT, bool GATHER, int QPW>
+// ADAPT (with QPW = 4, grid = 4 waves per tile): a tile whose depth list is shorter than `adapt_thresh` is
+// done by its wave 0 alone (the other three exit at once); a longer one is split, one quadrant per wave.
+template <bool EXACT, bool GATHER, int QPW, bool ADAPT>
 __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int tiles_x,
                                                         const int2 *__restrict__ bins,
                                                         const Rec *__restrict__ recs,
                                                         const int32_t *__restrict__ ids,
                                                         const float *__restrict__ bg, float *__restrict__ out_img,
                                                         float *__restrict__ final_T,
-                                                        int32_t *__restrict__ final_idx) {
-    constexpr int WPT = 4 / QPW;               // waves per tile
+                                                        int32_t *__restrict__ final_idx, int adapt_thresh) {
+    static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
+    constexpr int WPT = ADAPT ? 4 : 4 / QPW;   // waves launched per tile
     const int tile = blockIdx.x / WPT;
-    const int q0 = (blockIdx.x % WPT) * QPW;   // first quadrant (pixel slot) of this wave
+    const int wv = blockIdx.x % WPT;
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
+    int q0 = ADAPT ? 0 : wv * QPW;             // first quadrant (pixel slot) of this wave
+    int qlo = 0, qhi = QPW;                    // active slots of this wave (wave-uniform)
+    if constexpr (ADAPT) {
+        const bool split = (range.y - range.x) >= adapt_thresh;
+        if (!split && wv != 0) return;
+        if (split) { qlo = wv; qhi = wv + 1; }
+    }
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];  // wave-uniform -> scalar loads
 
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
         bool in_tile;
         slot_pixel(q0 + q, lane, B, ox, oy, in_tile);
         const int j = tx * B + ox, i = ty * B + oy;
-        inside[q] = in_tile && j < W && i < H;
+        inside[q] = in_tile && j < W && i < H && q >= qlo && q < qhi;
         pix[q] = i * W + j;
         px[q] = (float)j + 0.5f;
         py[q] = (float)i + 0.5f;
@@ -232,7 +242,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 // grad_ws row layout (12 floats / Gaussian): 0,1 v_xy | 2,3,4 v_conic | 5,6,7 v_rgb | 8 v_opacity
-template <bool EXACT, int REDUCE, bool GATHER, int QPW>
+template <bool EXACT, int REDUCE, bool GATHER, int QPW, bool ADAPT>
 __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int tiles_x,
                                                         const int2 *__restrict__ bins,
                                                         const Rec *__restrict__ recs,
@@ -242,10 +252,13 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                                                         const int32_t *__restrict__ final_idx,
                                                         const float *__restrict__ v_out,
                                                         const float *__restrict__ v_out_alpha,
-                                                        float alpha_clamp, float *__restrict__ grad_ws, int dbg) {
-    constexpr int WPT = 4 / QPW;
+                                                        float alpha_clamp, float *__restrict__ grad_ws, int dbg,
+                                                        int adapt_thresh) {
+    static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
+    constexpr int WPT = ADAPT ? 4 : 4 / QPW;
     const int tile = blockIdx.x / WPT;
-    const int q0 = (blockIdx.x % WPT) * QPW;
+    const int wv = blockIdx.x % WPT;
+    const int q0 = ADAPT ? 0 : wv * QPW;
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
     if (range.x >= range.y) return;
@@ -258,32 +271,50 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
     // becomes  v_alpha = ra * (T_before * dotc - bv + c0),  c0 = T_final * (v_out_alpha - sum_c bg_c*v_out_c),
     // i.e. 3 VALU ops instead of ~26, one running scalar instead of a 3-channel buffer.
     float px[QPW], py[QPW], T[QPW], c0[QPW], bv[QPW], vo0[QPW], vo1[QPW], vo2[QPW];
-    int kfin[QPW];
+    int kfin[QPW], pixi[QPW];
     int kmax_l = -1;
 #pragma unroll
-    for (int q = 0; q < QPW; ++q) {
+    for (int q = 0; q < QPW; ++q) {          // phase 1: where does each pixel's walk start?
         int ox, oy;
         bool in_tile;
         slot_pixel(q0 + q, lane, B, ox, oy, in_tile);
         const int j = tx * B + ox, i = ty * B + oy;
         const bool inside = in_tile && j < W && i < H;
-        const int pix = inside ? i * W + j : 0;
+        pixi[q] = inside ? i * W + j : -1;
         px[q] = (float)j + 0.5f;
         py[q] = (float)i + 0.5f;
+        kfin[q] = inside ? final_idx[pixi[q]] : -1;  // -1: this slot never participates
+        kmax_l = max(kmax_l, kfin[q]);
+    }
+    int kmax = __builtin_amdgcn_readfirstlane(wave_max_i(kmax_l));
+    kmax = min(kmax, range.y - 1);
+    if (kmax < range.x) return;
+    if constexpr (ADAPT) {                   // split tiles whose reverse walk is long, one quadrant per wave
+        const bool split = (kmax - range.x + 1) >= adapt_thresh;
+        if (!split && wv != 0) return;
+        if (split) {
+            int km = -1;
+#pragma unroll
+            for (int q = 0; q < QPW; ++q) {
+                if (q != wv) { kfin[q] = -1; pixi[q] = -1; } else km = kfin[q];
+            }
+            kmax = min(__builtin_amdgcn_readfirstlane(wave_max_i(km)), range.y - 1);
+            if (kmax < range.x) return;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {          // phase 2: per-pixel state of the active slots
+        const bool inside = pixi[q] >= 0;
+        const int pix = inside ? pixi[q] : 0;
         const float Tf = inside ? final_T[pix] : 1.f;
         T[q] = Tf;
-        kfin[q] = inside ? final_idx[pix] : -1;  // -1: this slot never participates
         vo0[q] = inside ? v_out[3 * pix] : 0.f;
         vo1[q] = inside ? v_out[3 * pix + 1] : 0.f;
         vo2[q] = inside ? v_out[3 * pix + 2] : 0.f;
         const float voa = inside ? v_out_alpha[pix] : 0.f;
         c0[q] = Tf * (voa - fmaf(bg0, vo0[q], fmaf(bg1, vo1[q], bg2 * vo2[q])));
         bv[q] = 0.f;
-        kmax_l = max(kmax_l, kfin[q]);
     }
-    int kmax = __builtin_amdgcn_readfirstlane(wave_max_i(kmax_l));
-    kmax = min(kmax, range.y - 1);
-    if (kmax < range.x) return;
 
     Rec cur = recs[GATHER ? ids[kmax] : kmax];
     int idn = GATHER ? ids[max(kmax - 1, range.x)] : 0;
@@ -384,7 +415,9 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *_
 int g_exact_exp = 0;
 int g_reduce_mode = 0;   // 0: ds_bpermute shuffles, 1: DPP
 int g_debug = 0;         // timing ablations only (bit0: no atomics, bit1: no wave reduction)
-int g_wpt = 1;           // waves per tile: 1 (4 quadrants per wave) or 4 (one quadrant per wave)
+int g_wpt = 0;           // waves per tile: 1, 4, or 0 = adaptive (split long lists, default)
+int g_adapt_fwd = 6144;  // forward: split tiles with >= this many list entries
+int g_adapt_bwd = 1536;  // backward: split tiles whose reverse walk covers >= this many entries
 int g_gather = 1;        // 1 (default): chase ids -> per-Gaussian rows; 0: stream packed records
 
 }  // namespace
@@ -394,7 +427,11 @@ SGN_EXPORT int sgn_get_exact_exp(void) { return g_exact_exp; }
 SGN_EXPORT void sgn_set_reduce_mode(int mode) { g_reduce_mode = mode ? 1 : 0; }
 SGN_EXPORT void sgn_set_debug_flags(int flags) { g_debug = flags; }
 SGN_EXPORT void sgn_set_gather_mode(int on) { g_gather = on ? 1 : 0; }
-SGN_EXPORT void sgn_set_waves_per_tile(int w) { g_wpt = (w == 4) ? 4 : 1; }
+SGN_EXPORT void sgn_set_waves_per_tile(int w) { g_wpt = (w == 4 || w == 1) ? w : 0; }
+SGN_EXPORT void sgn_set_adaptive_thresholds(int fwd_entries, int bwd_entries) {
+    if (fwd_entries > 0) g_adapt_fwd = fwd_entries;
+    if (bwd_entries > 0) g_adapt_bwd = bwd_entries;
+}
 
 SGN_EXPORT size_t sgn_raster_workspace_bytes(int n, int64_t n_isect) {
     // [n per-Gaussian rows][n_isect depth-ordered records (stream mode only)]
@@ -439,11 +476,16 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     const Rec *rows = (const Rec *)recs_ws;
     const Rec *stream_recs = rows + n;
     sgn_timing_begin(SGN_T_RASTER_FWD, s);
-#define SGN_LAUNCH_FWD(EX, GA, Q)                                                                                    \
-    hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q>), dim3(tiles_x * tiles_y * (4 / Q)), dim3(64), 0, s, img_w, img_h, \
-                       block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted,    \
-                       background3, out_img, final_Ts, final_idx)
-#define SGN_LAUNCH_FWD2(EX, GA) do { if (g_wpt == 4) SGN_LAUNCH_FWD(EX, GA, 1); else SGN_LAUNCH_FWD(EX, GA, 4); } while (0)
+#define SGN_LAUNCH_FWD(EX, GA, Q, AD)                                                                                \
+    hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
+                       img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
+                       gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, g_adapt_fwd)
+#define SGN_LAUNCH_FWD2(EX, GA)                                                     \
+    do {                                                                            \
+        if (g_wpt == 4) SGN_LAUNCH_FWD(EX, GA, 1, false);                           \
+        else if (g_wpt == 1) SGN_LAUNCH_FWD(EX, GA, 4, false);                      \
+        else SGN_LAUNCH_FWD(EX, GA, 4, true);                                       \
+    } while (0)
     if (g_exact_exp) {
         if (g_gather) SGN_LAUNCH_FWD2(true, true); else SGN_LAUNCH_FWD2(true, false);
     } else {
@@ -485,12 +527,16 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         const Rec *stream_recs = rows + n;
         sgn_timing_begin(SGN_T_RASTER_BWD, s);
 #define SGN_LAUNCH_BWD(EX, RM, GA)                                                                               \
-    do { if (g_wpt == 4) SGN_LAUNCH_BWDQ(EX, RM, GA, 1); else SGN_LAUNCH_BWDQ(EX, RM, GA, 4); } while (0)
-#define SGN_LAUNCH_BWDQ(EX, RM, GA, Q)                                                                           \
-    hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q>), dim3(tiles_x * tiles_y * (4 / Q)), dim3(64), 0, s, img_w, img_h, \
+    do {                                                                                                         \
+        if (g_wpt == 4) SGN_LAUNCH_BWDQ(EX, RM, GA, 1, false);                                                   \
+        else if (g_wpt == 1) SGN_LAUNCH_BWDQ(EX, RM, GA, 4, false);                                              \
+        else SGN_LAUNCH_BWDQ(EX, RM, GA, 4, true);                                                               \
+    } while (0)
+#define SGN_LAUNCH_BWDQ(EX, RM, GA, Q, AD)                                                                       \
+    hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, img_w, img_h, \
                        block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, \
                        background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws, \
-                       g_debug)
+                       g_debug, g_adapt_bwd)
 #define SGN_LAUNCH_BWD2(EX, RM) do { if (g_gather) SGN_LAUNCH_BWD(EX, RM, true); else SGN_LAUNCH_BWD(EX, RM, false); } while (0)
         if (g_exact_exp) {
             if (g_reduce_mode) SGN_LAUNCH_BWD2(true, 1); else SGN_LAUNCH_BWD2(true, 0);

@@ -19,7 +19,8 @@ def hip():
     return ops
 
 
-@pytest.fixture(autouse=True, params=[(0, 1), (1, 1), (1, 4)], ids=["stream", "gather", "gather-4waves"])
+@pytest.fixture(autouse=True, params=[(0, 1), (1, 1), (1, 4), (1, 0)],
+                ids=["stream", "gather", "gather-4waves", "gather-adaptive"])
 def raster_record_mode(request):
     """Every test in this module runs with the record-fetch modes of the raster kernels (packed depth-ordered
     stream vs. ids -> per-Gaussian rows chased with scalar loads) and with 1 or 4 waves per tile."""
@@ -27,9 +28,12 @@ def raster_record_mode(request):
     gather, wpt = request.param
     L.load().sgn_set_gather_mode(gather)
     L.load().sgn_set_waves_per_tile(wpt)
+    if wpt == 0:
+        L.load().sgn_set_adaptive_thresholds(96, 48)   # small scenes: make some tiles split, others not
     yield request.param
     L.load().sgn_set_gather_mode(L.DEFAULT_GATHER_MODE)
-    L.load().sgn_set_waves_per_tile(1)
+    L.load().sgn_set_waves_per_tile(0)
+    L.load().sgn_set_adaptive_thresholds(6144, 1536)
 
 
 def _project_args(cam, P, block=16, dev="cpu"):
