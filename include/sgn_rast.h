@@ -56,6 +56,8 @@ void sgn_set_gather_mode(int on);
  * reductions where it is short). */
 void sgn_set_waves_per_tile(int w);
 void sgn_set_adaptive_thresholds(int fwd_entries, int bwd_entries); /* <= 0 keeps the current value */
+/* XCD-aware tile -> workgroup order in the raster kernels (contiguous tile band per XCD / L2). */
+void sgn_set_xcd_swizzle(int on);
 
 /* Opt-in per-kernel timing for bench.py / profiles: when enabled, each timed launch is bracketed by
  * hipEventRecord on the stream it is launched on; sgn_timing_get sums the finished spans of a slot. */

@@ -107,6 +107,15 @@ __device__ __forceinline__ void slot_pixel(int q, int lane, int B, int &ox, int 
     }
 }
 
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); giving XCD x the contiguous
+// tile band [x*n/8, (x+1)*n/8) keeps the per-Gaussian rows a band touches in that XCD's own 4 MiB L2
+// (neighbouring tiles share most of their Gaussians).  Bijective for any n (remainder tiles go first).
+__device__ __forceinline__ int xcd_tile(int b, int n, int enable) {
+    if (!enable) return b;
+    const int q = n >> 3, r = n & 7, x = b & 7, j = b >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
 // GATHER = false: `recs` is the depth-ordered record stream (pack_records ran first).
 // GATHER = true : `recs` is the per-Gaussian row table and `ids` the sorted id list; the wave chases
 //                 ids[k] -> row with two dependent scalar loads, the id two records ahead and the row
@@ -124,11 +133,14 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
                                                         const int32_t *__restrict__ ids,
                                                         const float *__restrict__ bg, float *__restrict__ out_img,
                                                         float *__restrict__ final_T,
-                                                        int32_t *__restrict__ final_idx, int adapt_thresh) {
+                                                        int32_t *__restrict__ final_idx, int adapt_thresh, int swz) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
     constexpr int WPT = ADAPT ? 4 : 4 / QPW;   // waves launched per tile
-    const int tile = blockIdx.x / WPT;
-    const int wv = blockIdx.x % WPT;
+    // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile) so the waves that do the
+    // work of un-split tiles are spread over all 8 XCDs (block b runs on XCD b % 8), not on every 4th block.
+    const int n_tiles_ = gridDim.x / WPT;
+    const int tile = xcd_tile(ADAPT ? (int)(blockIdx.x % n_tiles_) : (int)(blockIdx.x / WPT), n_tiles_, swz);
+    const int wv = ADAPT ? (int)(blockIdx.x / n_tiles_) : (int)(blockIdx.x % WPT);
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
     int q0 = ADAPT ? 0 : wv * QPW;             // first quadrant (pixel slot) of this wave
@@ -253,11 +265,12 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                                                         const float *__restrict__ v_out,
                                                         const float *__restrict__ v_out_alpha,
                                                         float alpha_clamp, float *__restrict__ grad_ws, int dbg,
-                                                        int adapt_thresh) {
+                                                        int adapt_thresh, int swz) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
     constexpr int WPT = ADAPT ? 4 : 4 / QPW;
-    const int tile = blockIdx.x / WPT;
-    const int wv = blockIdx.x % WPT;
+    const int n_tiles_ = gridDim.x / WPT;      // ADAPT: wave-major numbering, see the forward kernel
+    const int tile = xcd_tile(ADAPT ? (int)(blockIdx.x % n_tiles_) : (int)(blockIdx.x / WPT), n_tiles_, swz);
+    const int wv = ADAPT ? (int)(blockIdx.x / n_tiles_) : (int)(blockIdx.x % WPT);
     const int q0 = ADAPT ? 0 : wv * QPW;
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
@@ -418,6 +431,7 @@ int g_debug = 0;         // timing ablations only (bit0: no atomics, bit1: no wa
 int g_wpt = 0;           // waves per tile: 1, 4, or 0 = adaptive (split long lists, default)
 int g_adapt_fwd = 6144;  // forward: split tiles with >= this many list entries
 int g_adapt_bwd = 1536;  // backward: split tiles whose reverse walk covers >= this many entries
+int g_xcd_swizzle = 0;   // XCD-aware tile order in the raster kernels
 int g_gather = 1;        // 1 (default): chase ids -> per-Gaussian rows; 0: stream packed records
 
 }  // namespace
@@ -427,6 +441,7 @@ SGN_EXPORT int sgn_get_exact_exp(void) { return g_exact_exp; }
 SGN_EXPORT void sgn_set_reduce_mode(int mode) { g_reduce_mode = mode ? 1 : 0; }
 SGN_EXPORT void sgn_set_debug_flags(int flags) { g_debug = flags; }
 SGN_EXPORT void sgn_set_gather_mode(int on) { g_gather = on ? 1 : 0; }
+SGN_EXPORT void sgn_set_xcd_swizzle(int on) { g_xcd_swizzle = on ? 1 : 0; }
 SGN_EXPORT void sgn_set_waves_per_tile(int w) { g_wpt = (w == 4 || w == 1) ? w : 0; }
 SGN_EXPORT void sgn_set_adaptive_thresholds(int fwd_entries, int bwd_entries) {
     if (fwd_entries > 0) g_adapt_fwd = fwd_entries;
@@ -479,7 +494,7 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
 #define SGN_LAUNCH_FWD(EX, GA, Q, AD)                                                                                \
     hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
                        img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
-                       gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, g_adapt_fwd)
+                       gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, g_adapt_fwd, g_xcd_swizzle)
 #define SGN_LAUNCH_FWD2(EX, GA)                                                     \
     do {                                                                            \
         if (g_wpt == 4) SGN_LAUNCH_FWD(EX, GA, 1, false);                           \
@@ -536,7 +551,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, img_w, img_h, \
                        block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, \
                        background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws, \
-                       g_debug, g_adapt_bwd)
+                       g_debug, g_adapt_bwd, g_xcd_swizzle)
 #define SGN_LAUNCH_BWD2(EX, RM) do { if (g_gather) SGN_LAUNCH_BWD(EX, RM, true); else SGN_LAUNCH_BWD(EX, RM, false); } while (0)
         if (g_exact_exp) {
             if (g_reduce_mode) SGN_LAUNCH_BWD2(true, 1); else SGN_LAUNCH_BWD2(true, 0);
