@@ -33,7 +33,7 @@ def raster_record_mode(request):
     yield request.param
     L.load().sgn_set_gather_mode(L.DEFAULT_GATHER_MODE)
     L.load().sgn_set_waves_per_tile(0)
-    L.load().sgn_set_adaptive_thresholds(6144, 1536)
+    L.load().sgn_set_adaptive_thresholds(3072, 1536)
 
 
 def _project_args(cam, P, block=16, dev="cpu"):
