@@ -173,58 +173,119 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(int n, const float *__r
     dvals[i] = i;
 }
 
-__global__ __launch_bounds__(256) void gather_counts_kernel(int n, const int32_t *__restrict__ gid_by_rank,
-                                                            const int32_t *__restrict__ radii,
-                                                            const int32_t *__restrict__ nth,
-                                                            int32_t *__restrict__ nth_r) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= n) return;
-    const int g = gid_by_rank[r];
-    nth_r[r] = radii[g] > 0 ? nth[g] : 0;
+// Exact tile culling (fused path only).  Upstream bins a Gaussian into every tile of the square that bounds
+// its 3-sigma CIRCLE; a tile can only receive colour from it if some pixel centre has
+// alpha = min(0.999, o * exp(-sigma)) >= 1/255, i.e. sigma <= ln(255 o).  `tile_hits` minimises the quadratic
+// form sigma over the rectangle of the tile's pixel centres (exact: interior point or one of the four clamped
+// edge minimisers) and keeps the tile iff min sigma <= ln(255 o) + margin.  Dropped (tile, Gaussian) pairs
+// have no valid pixel in forward or backward, so images and gradients are bit-identical with and without
+// culling (tests), while the intersection count roughly halves on the benchmark scene (17.2 M -> 8.3 M).
+struct Cull {
+    const float *conics;  // [n,3]
+    const float *opac;    // [n]
+    int opac_is_logit;
+    int enable;
+};
+
+__device__ __forceinline__ float cull_smax(const Cull &c, int gid) {
+    float o = c.opac[gid];
+    if (c.opac_is_logit) o = 1.f / (1.f + expf(-o));
+    // margin 0.01 in sigma (1 % in alpha) >> fp32 error of either evaluation order of the quadratic form
+    return (o * 255.f > 0.f) ? logf(255.f * o) + 0.01f : -1.f;
 }
 
-// lane = depth rank r; emits (tile, gaussian id) pairs of Gaussian gid_by_rank[r] starting at cum_r[r-1]
-__global__ __launch_bounds__(256) void map_rank_kernel(int n, const float *__restrict__ xys,
-                                                       const int32_t *__restrict__ radii,
-                                                       const int32_t *__restrict__ cum_r,
-                                                       const int32_t *__restrict__ gid_by_rank, int tiles_x,
-                                                       int tiles_y, int block, uint32_t *__restrict__ tkeys,
-                                                       int32_t *__restrict__ tvals) {
+__device__ __forceinline__ bool tile_hits(float x, float y, float a, float b, float c, float smax, int tx, int ty,
+                                          int block) {
+    if (!(smax >= 0.f)) return false;
+    if (!(a > 0.f) || !(c > 0.f)) return true;  // not a proper ellipse: stay conservative
+    const float x0 = (float)(tx * block) + 0.5f - x, x1 = x0 + (float)(block - 1);
+    const float y0 = (float)(ty * block) + 0.5f - y, y1 = y0 + (float)(block - 1);
+    if (x0 <= 0.f && 0.f <= x1 && y0 <= 0.f && 0.f <= y1) return true;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const float X = e ? x1 : x0;
+        const float ys = fminf(fmaxf(-b * X / c, y0), y1);
+        best = fminf(best, 0.5f * (a * X * X + c * ys * ys) + b * X * ys);
+        const float Y = e ? y1 : y0;
+        const float xs = fminf(fmaxf(-b * Y / a, x0), x1);
+        best = fminf(best, 0.5f * (a * xs * xs + c * Y * Y) + b * xs * Y);
+    }
+    return best <= smax;
+}
+
+// lane = depth rank r.  EMIT = false: counts[r] = number of (kept) tiles of Gaussian gid_by_rank[r];
+// EMIT = true: writes its (tile, gaussian id) pairs, row-major over the bbox, starting at cum_r[r-1].
+template <bool EMIT>
+__global__ __launch_bounds__(256) void rank_tiles_kernel(int n, const float *__restrict__ xys,
+                                                         const int32_t *__restrict__ radii,
+                                                         const int32_t *__restrict__ cum_r,
+                                                         const int32_t *__restrict__ gid_by_rank, Cull cull,
+                                                         int tiles_x, int tiles_y, int block,
+                                                         int32_t *__restrict__ counts, uint32_t *__restrict__ tkeys,
+                                                         int32_t *__restrict__ tvals) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int mnx = 0, mny = 0, mxx = 0, mxy = 0, cur = 0, gid = 0;
+    float gx = 0.f, gy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, smax = 0.f;
     bool live = false;
     if (r < n) {
         gid = gid_by_rank[r];
         const int rad = radii[gid];
         if (rad > 0) {
             live = true;
-            sgn_tile_bbox(xys[2 * gid], xys[2 * gid + 1], (float)rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
-            cur = (r == 0) ? 0 : cum_r[r - 1];
+            gx = xys[2 * gid]; gy = xys[2 * gid + 1];
+            sgn_tile_bbox(gx, gy, (float)rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
+            if (EMIT) cur = (r == 0) ? 0 : cum_r[r - 1];
+            if (cull.enable) {
+                ca = cull.conics[3 * gid]; cb = cull.conics[3 * gid + 1]; cc = cull.conics[3 * gid + 2];
+                smax = cull_smax(cull, gid);
+            }
         }
     }
     const int w = mxx - mnx, h = mxy - mny;
     const int area = live ? w * h : 0;
+    int cnt = 0;
     if (area > 0 && area <= MAP_BIG) {
         for (int ty = mny; ty < mxy; ++ty)
             for (int tx = mnx; tx < mxx; ++tx) {
-                tkeys[cur] = (uint32_t)(ty * tiles_x + tx);
-                tvals[cur] = gid;
-                ++cur;
+                if (cull.enable && !tile_hits(gx, gy, ca, cb, cc, smax, tx, ty, block)) continue;
+                if (EMIT) {
+                    tkeys[cur] = (uint32_t)(ty * tiles_x + tx);
+                    tvals[cur] = gid;
+                    ++cur;
+                }
+                ++cnt;
             }
     }
+    // big bboxes: the whole wave tests / emits 64 tiles at a time (ballot prefix keeps row-major order)
     unsigned long long big = __ballot(area > MAP_BIG);
     while (big) {
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;
         const int bw = __shfl(w, src, 64), bmnx = __shfl(mnx, src, 64), bmny = __shfl(mny, src, 64);
-        const int barea = __shfl(area, src, 64), bcur = __shfl(cur, src, 64), bgid = __shfl(gid, src, 64);
-        for (int t = lane; t < barea; t += 64) {
+        const int barea = __shfl(area, src, 64), bgid = __shfl(gid, src, 64);
+        int bcur = __shfl(cur, src, 64);
+        const float bx = __shfl(gx, src, 64), by = __shfl(gy, src, 64), ba = __shfl(ca, src, 64);
+        const float bb = __shfl(cb, src, 64), bc = __shfl(cc, src, 64), bs = __shfl(smax, src, 64);
+        int total = 0;
+        for (int t0 = 0; t0 < barea; t0 += 64) {
+            const int t = t0 + lane;
             const int ty = bmny + t / bw, tx = bmnx + t % bw;
-            tkeys[bcur + t] = (uint32_t)(ty * tiles_x + tx);
-            tvals[bcur + t] = bgid;
+            const bool keep = t < barea && (!cull.enable || tile_hits(bx, by, ba, bb, bc, bs, tx, ty, block));
+            const unsigned long long m = __ballot(keep);
+            if (EMIT && keep) {
+                const int pos = bcur + __popcll(m & ((1ull << lane) - 1ull));
+                tkeys[pos] = (uint32_t)(ty * tiles_x + tx);
+                tvals[pos] = bgid;
+            }
+            const int c = __popcll(m);
+            bcur += c;
+            total += c;
         }
+        if (lane == src) cnt = total;
     }
+    if (!EMIT && r < n) counts[r] = cnt;
 }
 
 // sorted tile ids -> tile_bins
@@ -311,28 +372,41 @@ SGN_EXPORT size_t sgn_bin_prepare_workspace_bytes(int n) {
     return al256(sgn_scan_workspace_bytes(n)) + 4 * al256(nn * 4) + sgn_sort_pairs32_ws_bytes(n);
 }
 
-SGN_EXPORT int sgn_bin_prepare(int n, const float *depths, const int32_t *radii, const int32_t *num_tiles_hit,
-                               int32_t *cum_by_rank, int32_t *gid_by_rank, void *ws, size_t ws_bytes,
-                               sgn_stream_t stream) {
+static Cull make_cull(const float *conics, const float *opac, int opac_is_logit, int cull) {
+    Cull c;
+    c.conics = conics; c.opac = opac; c.opac_is_logit = opac_is_logit;
+    c.enable = (cull && conics && opac) ? 1 : 0;
+    return c;
+}
+
+SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii,
+                               const float *conics, const float *opacities, int opacity_is_logit, int cull,
+                               int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
+                               int32_t *gid_by_rank, void *ws, size_t ws_bytes, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
+    SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     if (n == 0) return 0;
-    SGN_ARG_CHECK(depths && radii && num_tiles_hit && cum_by_rank && gid_by_rank && ws, -2);
-    SGN_ARG_CHECK(ws_bytes >= sgn_bin_prepare_workspace_bytes(n), -3);
+    SGN_ARG_CHECK(xys && depths && radii && cum_by_rank && gid_by_rank && ws, -3);
+    SGN_ARG_CHECK(ws_bytes >= sgn_bin_prepare_workspace_bytes(n), -4);
     hipStream_t s = (hipStream_t)stream;
     char *p = (char *)ws;
     void *scan_ws = p; p += al256(sgn_scan_workspace_bytes(n));
     uint32_t *dkeys = (uint32_t *)p; p += al256((size_t)n * 4);
     int32_t *dvals = (int32_t *)p;   p += al256((size_t)n * 4);
     uint32_t *dkeys_sorted = (uint32_t *)p; p += al256((size_t)n * 4);
-    int32_t *nth_r = (int32_t *)p;   p += al256((size_t)n * 4);
+    int32_t *cnt_r = (int32_t *)p;   p += al256((size_t)n * 4);
     void *sort_ws = p;
+    const Cull c = make_cull(conics, opacities, opacity_is_logit, cull);
     sgn_timing_begin(SGN_T_SORT, s);
     hipLaunchKernelGGL(depth_keys_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, depths, radii, dkeys, dvals);
     sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
-    hipLaunchKernelGGL(gather_counts_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, gid_by_rank, radii,
-                       num_tiles_hit, nth_r);
     sgn_timing_end(SGN_T_SORT, s);
-    return sgn_scan_i32(n, nth_r, cum_by_rank, scan_ws, sgn_scan_workspace_bytes(n), stream);
+    sgn_timing_begin(SGN_T_MAP, s);
+    hipLaunchKernelGGL(rank_tiles_kernel<false>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii,
+                       (const int32_t *)nullptr, gid_by_rank, c, tiles_x, tiles_y, block_width, cnt_r,
+                       (uint32_t *)nullptr, (int32_t *)nullptr);
+    sgn_timing_end(SGN_T_MAP, s);
+    return sgn_scan_i32(n, cnt_r, cum_by_rank, scan_ws, sgn_scan_workspace_bytes(n), stream);
 }
 
 SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
@@ -341,6 +415,7 @@ SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
 }
 
 SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const int32_t *radii,
+                                 const float *conics, const float *opacities, int opacity_is_logit, int cull,
                                  const int32_t *cum_by_rank, const int32_t *gid_by_rank, int tiles_x,
                                  int tiles_y, int block_width, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
                                  void *ws, size_t ws_bytes, sgn_stream_t stream) {
@@ -359,9 +434,10 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const
     int32_t *tvals = (int32_t *)p;          p += al256((size_t)n_isect * 4);
     uint32_t *tkeys_sorted = (uint32_t *)p; p += al256((size_t)n_isect * 4);
     void *sort_ws = p;
+    const Cull c = make_cull(conics, opacities, opacity_is_logit, cull);
     sgn_timing_begin(SGN_T_MAP, s);
-    hipLaunchKernelGGL(map_rank_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii, cum_by_rank,
-                       gid_by_rank, tiles_x, tiles_y, block_width, tkeys, tvals);
+    hipLaunchKernelGGL(rank_tiles_kernel<true>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii, cum_by_rank,
+                       gid_by_rank, c, tiles_x, tiles_y, block_width, (int32_t *)nullptr, tkeys, tvals);
     sgn_timing_end(SGN_T_MAP, s);
     sgn_timing_begin(SGN_T_SORT, s);
     sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws, s);

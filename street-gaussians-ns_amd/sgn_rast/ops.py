@@ -237,34 +237,45 @@ def bin_and_sort_gaussians(num_points, num_intersects, xys, depths, radii, cum_t
     return isect_ids, gaussian_ids, isect_ids_sorted, gaussian_ids_sorted, tile_bins
 
 
-def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width):
+tile_culling_enabled = True   # exact alpha-cutoff tile culling inside rasterize_gaussians (results unchanged)
+
+
+def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics=None,
+                        opacity=None, opacity_is_logit=False, cull=False):
     """The binning rasterize_gaussians actually runs: rank the Gaussians by depth once, emit the
     intersections in rank order, stable-sort them by tile id only, emit gaussian_ids_sorted + tile_bins.
-    Bit-identical to compute_cumulative_intersects + bin_and_sort_gaussians (see tests) at about a
-    third of the HBM traffic.  Returns (num_intersects, gaussian_ids_sorted, tile_bins)."""
-    dev = L.require_device(xys, depths, radii, num_tiles_hit)
+    With ``cull=False`` the result is bit-identical to compute_cumulative_intersects + bin_and_sort_gaussians
+    (see tests) at about a third of the HBM traffic.  With ``cull=True`` (needs ``conics`` and ``opacity``)
+    (tile, Gaussian) pairs that cannot reach alpha >= 1/255 on any pixel centre of the tile are dropped: the
+    list becomes a sub-sequence of upstream's and the rasterizer's outputs are unchanged.
+    Returns (num_intersects, gaussian_ids_sorted, tile_bins)."""
+    dev = L.require_device(xys, depths, radii, num_tiles_hit, conics, opacity)
     lib = L.load()
     n = int(num_points)
-    n_tiles = int(tile_bounds[0]) * int(tile_bounds[1])
+    tx, ty = int(tile_bounds[0]), int(tile_bounds[1])
     i32 = dict(dtype=torch.int32, device=dev)
-    tile_bins = torch.empty(n_tiles, 2, **i32)
+    tile_bins = torch.empty(tx * ty, 2, **i32)
     if n == 0:
         tile_bins.zero_()
         return 0, torch.zeros(0, **i32), tile_bins
-    nth = num_tiles_hit.detach().to(torch.int32).contiguous()
     radii_c = radii.detach().to(torch.int32).contiguous()
+    xys_c = _f32c(xys)
+    do_cull = int(bool(cull and conics is not None and opacity is not None))
+    conics_c = _f32c(conics) if do_cull else None
+    opac_c = _f32c(opacity).reshape(-1) if do_cull else None
     cum_r = torch.empty(n, **i32)
     gid_by_rank = torch.empty(n, **i32)
     ws = L.workspace(lib.sgn_bin_prepare_workspace_bytes(n), dev)
-    L.check(lib.sgn_bin_prepare(n, L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(nth), L.ptr(cum_r),
+    L.check(lib.sgn_bin_prepare(n, L.ptr(xys_c), L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(conics_c), L.ptr(opac_c),
+                                int(bool(opacity_is_logit)), do_cull, tx, ty, int(block_width), L.ptr(cum_r),
                                 L.ptr(gid_by_rank), L.ptr(ws), ws.numel(), L.stream_ptr()), "sgn_bin_prepare")
     num_intersects = int(cum_r[-1].item())  # host sync: sizes the intersection buffers (as upstream)
     ids_sorted = torch.empty(num_intersects, **i32)
     ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(num_intersects), dev)
-    L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(_f32c(xys)), L.ptr(radii_c), L.ptr(cum_r),
-                                  L.ptr(gid_by_rank), int(tile_bounds[0]), int(tile_bounds[1]), int(block_width),
-                                  L.ptr(ids_sorted), L.ptr(tile_bins), L.ptr(ws2), ws2.numel(), L.stream_ptr()),
-            "sgn_bin_intersect")
+    L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(xys_c), L.ptr(radii_c), L.ptr(conics_c), L.ptr(opac_c),
+                                  int(bool(opacity_is_logit)), do_cull, L.ptr(cum_r), L.ptr(gid_by_rank), tx, ty,
+                                  int(block_width), L.ptr(ids_sorted), L.ptr(tile_bins), L.ptr(ws2), ws2.numel(),
+                                  L.stream_ptr()), "sgn_bin_intersect")
     return num_intersects, ids_sorted, tile_bins
 
 
@@ -279,25 +290,29 @@ _bin_cache = {"key": None, "keep": None, "val": None}
 binning_cache_enabled = True
 
 
-def _bin_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width):
-    return tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype)
-                 for t in (xys, depths, radii, num_tiles_hit)) + (
-        tuple(int(b) for b in tile_bounds), int(block_width), torch.cuda.current_stream().cuda_stream)
+def _bin_key(tensors, tile_bounds, block_width, flags):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors) + (
+        tuple(int(b) for b in tile_bounds), int(block_width), flags, torch.cuda.current_stream().cuda_stream)
 
 
 def clear_binning_cache() -> None:
     _bin_cache["key"] = _bin_cache["keep"] = _bin_cache["val"] = None
 
 
-def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width):
+def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics,
+                          opacity, opacity_is_logit):
+    cull = tile_culling_enabled
+    args = (num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
+            opacity_is_logit, cull)
     if not binning_cache_enabled:
-        return bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width)
-    key = _bin_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width)
+        return bin_gaussians_fused(*args)
+    tensors = (xys, depths, radii, num_tiles_hit) + ((conics, opacity) if cull else ())
+    key = _bin_key(tensors, tile_bounds, block_width, (bool(opacity_is_logit), cull))
     if _bin_cache["key"] == key:
         return _bin_cache["val"]
-    val = bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width)
+    val = bin_gaussians_fused(*args)
     _bin_cache["key"], _bin_cache["val"] = key, val
-    _bin_cache["keep"] = tuple(t.detach() for t in (xys, depths, radii, num_tiles_hit))
+    _bin_cache["keep"] = tuple(t.detach() for t in tensors)
     return val
 
 
@@ -316,7 +331,8 @@ class _RasterizeGaussians(Function):
                 "sgn_splatfacto.py:988 repeats depth x3 to stay on it)")
         xys_c, conics_c, colors_c = _f32c(xys), _f32c(conics), _f32c(colors)
         num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
-            num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width)
+            num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
+            opacity_is_logit)
         opac_c, bg_c = _f32c(opacity).reshape(-1), _f32c(background)
         f32 = dict(dtype=torch.float32, device=dev)
         lib = L.load()

@@ -124,6 +124,32 @@ def test_metric_size_train_step_runs_and_is_sane():
     assert float(out.xys.grad[culled].abs().max()) == 0.0
 
 
+def test_tile_culling_does_not_change_results():
+    """Exact-exp mode: image, alpha and every gradient source (final T, contributing Gaussian of each pixel)
+    are bit-identical with and without the exact tile culling; only the (internal) list positions differ."""
+    from sgn_rast import _lib as L, ops, scenes, step
+    cam, raw = scenes.make_scene("c1")
+    P = _to_dev(cam, raw)
+    w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+    L.load().sgn_set_exact_exp(1)
+    try:
+        res = {}
+        for cull in (False, True):
+            ops.tile_culling_enabled = cull
+            ops.clear_binning_cache()
+            out = step.train_step(P, cam, w_img, w_a, with_depth=True)
+            res[cull] = (out.rgb.detach().clone(), out.alpha.detach().clone(), out.depth.detach().clone(),
+                         {k: v.grad.clone() for k, v in P.items()})
+    finally:
+        ops.tile_culling_enabled = True
+        L.load().sgn_set_exact_exp(0)
+        ops.clear_binning_cache()
+    for a, b in zip(res[False][:3], res[True][:3]):
+        assert torch.equal(a, b)
+    for k in P:   # backward sums the same contributions (atomics order differs): fp32 rounding only
+        assert rel_l2(res[True][3][k], res[False][3][k]) < 1e-5, k
+
+
 def test_single_rank_dp_reducer_is_a_noop():
     from sgn_rast import dp, scenes, step
     cam, raw = scenes.make_scene("c1", n_override=2000)

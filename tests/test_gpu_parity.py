@@ -193,6 +193,30 @@ def test_fused_rank_binning_equals_upstream_shaped_path(hip, c_oracle, n, size, 
     assert I == keys.numel()
     assert torch.equal(ids.cpu(), vs), "gaussian_ids_sorted must be bit-exact"
     assert torch.equal(tbins.cpu(), bins)
+    # exact tile culling: the kept list is a sub-sequence of upstream's, tile by tile, and every dropped
+    # (tile, Gaussian) pair has no pixel centre with alpha >= 1/255 (checked against the definition)
+    opac = torch.sigmoid(P["opacity_logits"]).reshape(-1)
+    Ic, idc, binc = ops.bin_gaussians_fused(xys.shape[0], xys.to(DEV), depths.to(DEV), radii.to(DEV), nth.to(DEV), tb,
+                                            16, conics=conics.to(DEV), opacity=opac.to(DEV), cull=True)
+    idc, binc = idc.cpu(), binc.cpu()
+    assert Ic <= I and (n < 100 or Ic < 0.9 * I)
+    rng = torch.Generator().manual_seed(0)
+    for t in torch.randperm(tb[0] * tb[1], generator=rng)[:40].tolist():
+        full = vs[int(bins[t, 0]):int(bins[t, 1])].tolist()
+        kept = idc[int(binc[t, 0]):int(binc[t, 1])].tolist()
+        it = iter(full)
+        assert all(g in it for g in kept), "culled list must be a sub-sequence of the upstream list"
+        dropped = sorted(set(full) - set(kept))
+        if dropped:
+            g = torch.tensor(dropped)
+            px = (t % tb[0]) * 16 + torch.arange(16) + 0.5
+            py = (t // tb[0]) * 16 + torch.arange(16) + 0.5
+            dx = xys[g, 0][:, None, None] - px[None, None, :]
+            dy = xys[g, 1][:, None, None] - py[None, :, None]
+            sig = 0.5 * (conics[g, 0][:, None, None] * dx * dx + conics[g, 2][:, None, None] * dy * dy) + \
+                conics[g, 1][:, None, None] * dx * dy
+            alpha = torch.clamp(opac[g][:, None, None] * torch.exp(-sig), max=0.999)
+            assert not bool(((sig >= 0) & (alpha >= 1.0 / 255.0)).any()), "a dropped pair had a valid pixel"
 
 
 # ---------------------------------------------------------------- rasterize
