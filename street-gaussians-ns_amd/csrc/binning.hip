@@ -194,8 +194,9 @@ __device__ __forceinline__ float cull_smax(const Cull &c, int gid) {
     return (o * 255.f > 0.f) ? logf(255.f * o) + 0.01f : -1.f;
 }
 
-__device__ __forceinline__ bool tile_hits(float x, float y, float a, float b, float c, float smax, int tx, int ty,
-                                          int block) {
+// nbc = -b/c and nba = -b/a (the unconstrained edge minimisers' slopes) are computed once per Gaussian.
+__device__ __forceinline__ bool tile_hits(float x, float y, float a, float b, float c, float nbc, float nba,
+                                          float smax, int tx, int ty, int block) {
     if (!(smax >= 0.f)) return false;
     if (!(a > 0.f) || !(c > 0.f)) return true;  // not a proper ellipse: stay conservative
     const float x0 = (float)(tx * block) + 0.5f - x, x1 = x0 + (float)(block - 1);
@@ -205,10 +206,10 @@ __device__ __forceinline__ bool tile_hits(float x, float y, float a, float b, fl
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
         const float X = e ? x1 : x0;
-        const float ys = fminf(fmaxf(-b * X / c, y0), y1);
+        const float ys = fminf(fmaxf(nbc * X, y0), y1);
         best = fminf(best, 0.5f * (a * X * X + c * ys * ys) + b * X * ys);
         const float Y = e ? y1 : y0;
-        const float xs = fminf(fmaxf(-b * Y / a, x0), x1);
+        const float xs = fminf(fmaxf(nba * Y, x0), x1);
         best = fminf(best, 0.5f * (a * xs * xs + c * Y * Y) + b * xs * Y);
     }
     return best <= smax;
@@ -222,12 +223,12 @@ __global__ __launch_bounds__(256) void rank_tiles_kernel(int n, const float *__r
                                                          const int32_t *__restrict__ cum_r,
                                                          const int32_t *__restrict__ gid_by_rank, Cull cull,
                                                          int tiles_x, int tiles_y, int block,
-                                                         int32_t *__restrict__ counts, uint32_t *__restrict__ tkeys,
-                                                         int32_t *__restrict__ tvals) {
+                                                         int32_t *__restrict__ counts, uint32_t *__restrict__ masks,
+                                                         uint32_t *__restrict__ tkeys, int32_t *__restrict__ tvals) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int mnx = 0, mny = 0, mxx = 0, mxy = 0, cur = 0, gid = 0;
-    float gx = 0.f, gy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, smax = 0.f;
+    float gx = 0.f, gy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, nbc = 0.f, nba = 0.f, smax = 0.f;
     bool live = false;
     if (r < n) {
         gid = gid_by_rank[r];
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(256) void rank_tiles_kernel(int n, const float *__r
             if (EMIT) cur = (r == 0) ? 0 : cum_r[r - 1];
             if (cull.enable) {
                 ca = cull.conics[3 * gid]; cb = cull.conics[3 * gid + 1]; cc = cull.conics[3 * gid + 2];
+                nbc = -cb / cc; nba = -cb / ca;
                 smax = cull_smax(cull, gid);
             }
         }
@@ -247,16 +249,27 @@ __global__ __launch_bounds__(256) void rank_tiles_kernel(int n, const float *__r
     const int area = live ? w * h : 0;
     int cnt = 0;
     if (area > 0 && area <= MAP_BIG) {
+        // small bbox (<= 32 tiles): the count pass leaves a bit mask of the kept tiles, the emit pass replays it
+        uint32_t mask = (EMIT && cull.enable) ? masks[r] : 0u;
+        int bit = 0;
         for (int ty = mny; ty < mxy; ++ty)
-            for (int tx = mnx; tx < mxx; ++tx) {
-                if (cull.enable && !tile_hits(gx, gy, ca, cb, cc, smax, tx, ty, block)) continue;
+            for (int tx = mnx; tx < mxx; ++tx, ++bit) {
+                bool keep = true;
+                if (cull.enable) {
+                    if (EMIT) keep = (mask >> bit) & 1u;
+                    else keep = tile_hits(gx, gy, ca, cb, cc, nbc, nba, smax, tx, ty, block);
+                }
+                if (!keep) continue;
                 if (EMIT) {
                     tkeys[cur] = (uint32_t)(ty * tiles_x + tx);
                     tvals[cur] = gid;
                     ++cur;
+                } else {
+                    mask |= 1u << bit;
                 }
                 ++cnt;
             }
+        if (!EMIT && cull.enable) masks[r] = mask;
     }
     // big bboxes: the whole wave tests / emits 64 tiles at a time (ballot prefix keeps row-major order)
     unsigned long long big = __ballot(area > MAP_BIG);
@@ -268,11 +281,12 @@ __global__ __launch_bounds__(256) void rank_tiles_kernel(int n, const float *__r
         int bcur = __shfl(cur, src, 64);
         const float bx = __shfl(gx, src, 64), by = __shfl(gy, src, 64), ba = __shfl(ca, src, 64);
         const float bb = __shfl(cb, src, 64), bc = __shfl(cc, src, 64), bs = __shfl(smax, src, 64);
+        const float bnbc = __shfl(nbc, src, 64), bnba = __shfl(nba, src, 64);
         int total = 0;
         for (int t0 = 0; t0 < barea; t0 += 64) {
             const int t = t0 + lane;
             const int ty = bmny + t / bw, tx = bmnx + t % bw;
-            const bool keep = t < barea && (!cull.enable || tile_hits(bx, by, ba, bb, bc, bs, tx, ty, block));
+            const bool keep = t < barea && (!cull.enable || tile_hits(bx, by, ba, bb, bc, bnbc, bnba, bs, tx, ty, block));
             const unsigned long long m = __ballot(keep);
             if (EMIT && keep) {
                 const int pos = bcur + __popcll(m & ((1ull << lane) - 1ull));
@@ -382,11 +396,12 @@ static Cull make_cull(const float *conics, const float *opac, int opac_is_logit,
 SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii,
                                const float *conics, const float *opacities, int opacity_is_logit, int cull,
                                int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
-                               int32_t *gid_by_rank, void *ws, size_t ws_bytes, sgn_stream_t stream) {
+                               int32_t *gid_by_rank, uint32_t *keep_masks, void *ws, size_t ws_bytes,
+                               sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     if (n == 0) return 0;
-    SGN_ARG_CHECK(xys && depths && radii && cum_by_rank && gid_by_rank && ws, -3);
+    SGN_ARG_CHECK(xys && depths && radii && cum_by_rank && gid_by_rank && keep_masks && ws, -3);
     SGN_ARG_CHECK(ws_bytes >= sgn_bin_prepare_workspace_bytes(n), -4);
     hipStream_t s = (hipStream_t)stream;
     char *p = (char *)ws;
@@ -403,7 +418,7 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     sgn_timing_end(SGN_T_SORT, s);
     sgn_timing_begin(SGN_T_MAP, s);
     hipLaunchKernelGGL(rank_tiles_kernel<false>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii,
-                       (const int32_t *)nullptr, gid_by_rank, c, tiles_x, tiles_y, block_width, cnt_r,
+                       (const int32_t *)nullptr, gid_by_rank, c, tiles_x, tiles_y, block_width, cnt_r, keep_masks,
                        (uint32_t *)nullptr, (int32_t *)nullptr);
     sgn_timing_end(SGN_T_MAP, s);
     return sgn_scan_i32(n, cnt_r, cum_by_rank, scan_ws, sgn_scan_workspace_bytes(n), stream);
@@ -416,8 +431,9 @@ SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
 
 SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const int32_t *radii,
                                  const float *conics, const float *opacities, int opacity_is_logit, int cull,
-                                 const int32_t *cum_by_rank, const int32_t *gid_by_rank, int tiles_x,
-                                 int tiles_y, int block_width, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                                 const int32_t *cum_by_rank, const int32_t *gid_by_rank,
+                                 const uint32_t *keep_masks, int tiles_x, int tiles_y, int block_width,
+                                 int32_t *gaussian_ids_sorted, int32_t *tile_bins,
                                  void *ws, size_t ws_bytes, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0 && n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
@@ -426,7 +442,7 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const
     const int n_tiles = tiles_x * tiles_y;
     SGN_HIP_CHECK(hipMemsetAsync(tile_bins, 0, (size_t)n_tiles * 2 * sizeof(int32_t), s));
     if (n_isect == 0 || n == 0) return 0;
-    SGN_ARG_CHECK(xys && radii && cum_by_rank && gid_by_rank && gaussian_ids_sorted && ws, -4);
+    SGN_ARG_CHECK(xys && radii && cum_by_rank && gid_by_rank && keep_masks && gaussian_ids_sorted && ws, -4);
     SGN_ARG_CHECK(ws_bytes >= sgn_bin_intersect_workspace_bytes(n_isect), -5);
     const int tile_bits = bit_length((uint32_t)(n_tiles - 1)) > 0 ? bit_length((uint32_t)(n_tiles - 1)) : 1;
     char *p = (char *)ws;
@@ -437,7 +453,8 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const
     const Cull c = make_cull(conics, opacities, opacity_is_logit, cull);
     sgn_timing_begin(SGN_T_MAP, s);
     hipLaunchKernelGGL(rank_tiles_kernel<true>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii, cum_by_rank,
-                       gid_by_rank, c, tiles_x, tiles_y, block_width, (int32_t *)nullptr, tkeys, tvals);
+                       gid_by_rank, c, tiles_x, tiles_y, block_width, (int32_t *)nullptr, (uint32_t *)keep_masks, tkeys,
+                       tvals);
     sgn_timing_end(SGN_T_MAP, s);
     sgn_timing_begin(SGN_T_SORT, s);
     sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws, s);
