@@ -179,19 +179,18 @@ int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_tiles, int3
  * compute_cumulative_intersects). */
 size_t sgn_bin_prepare_workspace_bytes(int n);
 /* `cull` != 0 (with conics and opacities given): exact tile culling — a (tile, Gaussian) pair is only emitted
- * if some pixel centre of the tile can reach alpha >= 1/255 (min of sigma over the tile's pixel-centre rectangle
- * <= ln(255*opacity) + margin).  Dropped pairs contribute nothing in forward or backward, so rasterize results
+ * if some pixel centre of the tile can reach alpha >= 1/255 (the convex set sigma <= ln(255*opacity) + margin meets
+ * the tile's pixel-centre rectangle; evaluated per tile row as one interval).  Dropped pairs contribute nothing in forward or backward, so rasterize results
  * are unchanged; the list is then a sub-sequence of upstream's.  With cull == 0 the list equals upstream's. */
 int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii, const float *conics,
                     const float *opacities, int opacity_is_logit, int cull, int tiles_x, int tiles_y,
                     int block_width, int32_t *cum_by_rank /*[n] inclusive scan of kept-tile counts, rank order*/,
-                    int32_t *gid_by_rank /*[n]*/, uint32_t *keep_masks /*[n] scratch carried to sgn_bin_intersect*/,
-                    void *ws, size_t ws_bytes, sgn_stream_t stream);
+                    int32_t *gid_by_rank /*[n]*/, void *ws, size_t ws_bytes, sgn_stream_t stream);
 size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect);
 int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const int32_t *radii, const float *conics,
                       const float *opacities, int opacity_is_logit, int cull, const int32_t *cum_by_rank,
-                      const int32_t *gid_by_rank, const uint32_t *keep_masks, int tiles_x, int tiles_y,
-                      int block_width, int32_t *gaussian_ids_sorted /*[n_isect]*/, int32_t *tile_bins /*[tiles,2]*/, void *ws,
+                      const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
+                      int32_t *gaussian_ids_sorted /*[n_isect]*/, int32_t *tile_bins /*[tiles,2]*/, void *ws,
                       size_t ws_bytes, sgn_stream_t stream);
 
 /* _C.rasterize_forward (3-channel path; reference call sites sgn_splatfacto.py:954-967,

@@ -175,11 +175,13 @@ __global__ __launch_bounds__(256) void depth_keys_kernel(int n, const float *__r
 
 // Exact tile culling (fused path only).  Upstream bins a Gaussian into every tile of the square that bounds
 // its 3-sigma CIRCLE; a tile can only receive colour from it if some pixel centre has
-// alpha = min(0.999, o * exp(-sigma)) >= 1/255, i.e. sigma <= ln(255 o).  `tile_hits` minimises the quadratic
-// form sigma over the rectangle of the tile's pixel centres (exact: interior point or one of the four clamped
-// edge minimisers) and keeps the tile iff min sigma <= ln(255 o) + margin.  Dropped (tile, Gaussian) pairs
-// have no valid pixel in forward or backward, so images and gradients are bit-identical with and without
-// culling (tests), while the intersection count roughly halves on the benchmark scene (17.2 M -> 8.3 M).
+// alpha = min(0.999, o * exp(-sigma)) >= 1/255, i.e. sigma <= s := ln(255 o).  The ellipse {sigma <= s} is
+// convex, so in every tile ROW the tiles it can touch form one interval: for the row's pixel-centre band
+// Y in [y0, y1] the ellipse's x-extent is X_right(Y) = (-bY + sqrt(2as - DY^2))/a maximised (concave) and
+// X_left(Y) minimised (convex) over the band, each at its clamped unconstrained optimum; a tile is kept iff
+// its pixel-centre span [x0, x0+B-1] meets [x_min, x_max].  O(rows) per Gaussian instead of O(tiles).
+// Dropped (tile, Gaussian) pairs have no valid pixel in forward or backward, so images and gradients are
+// unchanged (tests), while the intersection count roughly halves on the benchmark scene (17.2 M -> 8.3 M).
 struct Cull {
     const float *conics;  // [n,3]
     const float *opac;    // [n]
@@ -187,115 +189,136 @@ struct Cull {
     int enable;
 };
 
-__device__ __forceinline__ float cull_smax(const Cull &c, int gid) {
-    float o = c.opac[gid];
-    if (c.opac_is_logit) o = 1.f / (1.f + expf(-o));
-    // margin 0.01 in sigma (1 % in alpha) >> fp32 error of either evaluation order of the quadratic form
-    return (o * 255.f > 0.f) ? logf(255.f * o) + 0.01f : -1.f;
+struct Ellipse {       // per-Gaussian constants of the row-interval test
+    float gx, gy;      // centre (pixels)
+    float a, b;        // conic a, b
+    float inv_a;       // 1/a
+    float two_as;      // 2 a s
+    float D;           // a c - b^2
+    float y_ext;       // sqrt(2 a s / D): |Y| extent of the ellipse
+    float y_at_xmax;   // Y where X is maximal  (= -(b/c) X_max); X minimal at -y_at_xmax
+    int valid;         // 0: nothing can be hit; 1: use the test; 2: degenerate conic -> keep everything
+};
+
+__device__ __forceinline__ Ellipse make_ellipse(const Cull &cu, int gid, float gx, float gy) {
+    Ellipse E;
+    E.gx = gx; E.gy = gy;
+    const float a = cu.conics[3 * gid], b = cu.conics[3 * gid + 1], c = cu.conics[3 * gid + 2];
+    float o = cu.opac[gid];
+    if (cu.opac_is_logit) o = 1.f / (1.f + expf(-o));
+    // margin 0.01 in sigma (1 % in alpha) >> fp32 error of any evaluation order of the quadratic form
+    const float s = (o * 255.f > 0.f) ? logf(255.f * o) + 0.01f : -1.f;
+    const float D = a * c - b * b;
+    E.a = a; E.b = b; E.inv_a = 1.f / a; E.two_as = 2.f * a * s; E.D = D;
+    E.valid = !(s >= 0.f) ? 0 : ((a > 0.f && c > 0.f && D > 0.f) ? 1 : 2);
+    E.y_ext = sqrtf(fmaxf(E.two_as / D, 0.f));
+    const float x_max = sqrtf(fmaxf(2.f * c * s / D, 0.f));
+    E.y_at_xmax = -(b / c) * x_max;
+    return E;
 }
 
-// nbc = -b/c and nba = -b/a (the unconstrained edge minimisers' slopes) are computed once per Gaussian.
-__device__ __forceinline__ bool tile_hits(float x, float y, float a, float b, float c, float nbc, float nba,
-                                          float smax, int tx, int ty, int block) {
-    if (!(smax >= 0.f)) return false;
-    if (!(a > 0.f) || !(c > 0.f)) return true;  // not a proper ellipse: stay conservative
-    const float x0 = (float)(tx * block) + 0.5f - x, x1 = x0 + (float)(block - 1);
-    const float y0 = (float)(ty * block) + 0.5f - y, y1 = y0 + (float)(block - 1);
-    if (x0 <= 0.f && 0.f <= x1 && y0 <= 0.f && 0.f <= y1) return true;
-    float best = 3.0e38f;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const float X = e ? x1 : x0;
-        const float ys = fminf(fmaxf(nbc * X, y0), y1);
-        best = fminf(best, 0.5f * (a * X * X + c * ys * ys) + b * X * ys);
-        const float Y = e ? y1 : y0;
-        const float xs = fminf(fmaxf(nba * Y, x0), x1);
-        best = fminf(best, 0.5f * (a * xs * xs + c * Y * Y) + b * xs * Y);
-    }
-    return best <= smax;
+// kept tile interval [lo, hi] (inclusive, may be empty: hi < lo) of tile row `ty`, clamped to [mnx, mxx)
+__device__ __forceinline__ void row_interval(const Ellipse &E, int ty, int block, int mnx, int mxx, int &lo,
+                                             int &hi) {
+    lo = mnx; hi = mxx - 1;
+    if (E.valid == 2) return;
+    if (E.valid == 0) { hi = lo - 1; return; }
+    const float y0 = (float)(ty * block) + 0.5f - E.gy, y1 = y0 + (float)(block - 1);
+    const float ya = fmaxf(y0, -E.y_ext), yb = fminf(y1, E.y_ext);   // band clipped to the ellipse's Y extent
+    if (ya > yb) { hi = lo - 1; return; }
+    const float yr = fminf(fmaxf(E.y_at_xmax, ya), yb);               // maximiser of X_right on the band
+    const float yl = fminf(fmaxf(-E.y_at_xmax, ya), yb);              // minimiser of X_left on the band
+    const float x_max = (-E.b * yr + sqrtf(fmaxf(E.two_as - E.D * yr * yr, 0.f))) * E.inv_a + 1e-3f;
+    const float x_min = (-E.b * yl - sqrtf(fmaxf(E.two_as - E.D * yl * yl, 0.f))) * E.inv_a - 1e-3f;
+    // tile tx spans pixel centres [tx*B + 0.5, tx*B + B - 0.5]; keep it iff that span meets [x_min, x_max] + gx
+    const float fb = (float)block;
+    const int t_hi = sgn_f2i(floorf((x_max + E.gx - 0.5f) / fb));
+    const int t_lo = sgn_f2i(ceilf((x_min + E.gx + 0.5f - fb) / fb));
+    lo = max(lo, t_lo);
+    hi = min(hi, t_hi);
 }
 
-// lane = depth rank r.  EMIT = false: counts[r] = number of (kept) tiles of Gaussian gid_by_rank[r];
+// lane = depth rank r.  EMIT = false: counts[r] = number of kept tiles of Gaussian gid_by_rank[r];
 // EMIT = true: writes its (tile, gaussian id) pairs, row-major over the bbox, starting at cum_r[r-1].
+constexpr int ROWS_BIG = 6;   // bboxes taller than this are handled by the whole wave (lane <-> tile row)
+
 template <bool EMIT>
 __global__ __launch_bounds__(256) void rank_tiles_kernel(int n, const float *__restrict__ xys,
                                                          const int32_t *__restrict__ radii,
                                                          const int32_t *__restrict__ cum_r,
                                                          const int32_t *__restrict__ gid_by_rank, Cull cull,
                                                          int tiles_x, int tiles_y, int block,
-                                                         int32_t *__restrict__ counts, uint32_t *__restrict__ masks,
-                                                         uint32_t *__restrict__ tkeys, int32_t *__restrict__ tvals) {
+                                                         int32_t *__restrict__ counts, uint32_t *__restrict__ tkeys,
+                                                         int32_t *__restrict__ tvals) {
     const int r = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int mnx = 0, mny = 0, mxx = 0, mxy = 0, cur = 0, gid = 0;
-    float gx = 0.f, gy = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, nbc = 0.f, nba = 0.f, smax = 0.f;
+    Ellipse E;
+    E.valid = 2; E.gx = 0.f; E.gy = 0.f; E.a = 1.f; E.b = 0.f; E.inv_a = 1.f; E.two_as = 0.f; E.D = 1.f;
+    E.y_ext = 0.f; E.y_at_xmax = 0.f;
     bool live = false;
     if (r < n) {
         gid = gid_by_rank[r];
         const int rad = radii[gid];
         if (rad > 0) {
             live = true;
-            gx = xys[2 * gid]; gy = xys[2 * gid + 1];
+            const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
             sgn_tile_bbox(gx, gy, (float)rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
             if (EMIT) cur = (r == 0) ? 0 : cum_r[r - 1];
-            if (cull.enable) {
-                ca = cull.conics[3 * gid]; cb = cull.conics[3 * gid + 1]; cc = cull.conics[3 * gid + 2];
-                nbc = -cb / cc; nba = -cb / ca;
-                smax = cull_smax(cull, gid);
-            }
+            if (cull.enable) E = make_ellipse(cull, gid, gx, gy);
         }
     }
-    const int w = mxx - mnx, h = mxy - mny;
-    const int area = live ? w * h : 0;
+    const int w = mxx - mnx, h = (live && w > 0) ? mxy - mny : 0;
     int cnt = 0;
-    if (area > 0 && area <= MAP_BIG) {
-        // small bbox (<= 32 tiles): the count pass leaves a bit mask of the kept tiles, the emit pass replays it
-        uint32_t mask = (EMIT && cull.enable) ? masks[r] : 0u;
-        int bit = 0;
-        for (int ty = mny; ty < mxy; ++ty)
-            for (int tx = mnx; tx < mxx; ++tx, ++bit) {
-                bool keep = true;
-                if (cull.enable) {
-                    if (EMIT) keep = (mask >> bit) & 1u;
-                    else keep = tile_hits(gx, gy, ca, cb, cc, nbc, nba, smax, tx, ty, block);
-                }
-                if (!keep) continue;
+    if (h > 0 && h <= ROWS_BIG) {
+        for (int ty = mny; ty < mxy; ++ty) {
+            int lo, hi;
+            row_interval(E, ty, block, mnx, mxx, lo, hi);
+            for (int tx = lo; tx <= hi; ++tx) {
                 if (EMIT) {
                     tkeys[cur] = (uint32_t)(ty * tiles_x + tx);
                     tvals[cur] = gid;
                     ++cur;
-                } else {
-                    mask |= 1u << bit;
                 }
                 ++cnt;
             }
-        if (!EMIT && cull.enable) masks[r] = mask;
+        }
     }
-    // big bboxes: the whole wave tests / emits 64 tiles at a time (ballot prefix keeps row-major order)
-    unsigned long long big = __ballot(area > MAP_BIG);
+    // tall bboxes: one Gaussian at a time, lane <-> tile row, wave prefix sum of the row counts
+    unsigned long long big = __ballot(h > ROWS_BIG);
     while (big) {
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;
-        const int bw = __shfl(w, src, 64), bmnx = __shfl(mnx, src, 64), bmny = __shfl(mny, src, 64);
-        const int barea = __shfl(area, src, 64), bgid = __shfl(gid, src, 64);
-        int bcur = __shfl(cur, src, 64);
-        const float bx = __shfl(gx, src, 64), by = __shfl(gy, src, 64), ba = __shfl(ca, src, 64);
-        const float bb = __shfl(cb, src, 64), bc = __shfl(cc, src, 64), bs = __shfl(smax, src, 64);
-        const float bnbc = __shfl(nbc, src, 64), bnba = __shfl(nba, src, 64);
+        Ellipse B;
+        B.gx = __shfl(E.gx, src, 64); B.gy = __shfl(E.gy, src, 64); B.a = __shfl(E.a, src, 64);
+        B.b = __shfl(E.b, src, 64); B.inv_a = __shfl(E.inv_a, src, 64); B.two_as = __shfl(E.two_as, src, 64);
+        B.D = __shfl(E.D, src, 64); B.y_ext = __shfl(E.y_ext, src, 64); B.y_at_xmax = __shfl(E.y_at_xmax, src, 64);
+        B.valid = __shfl(E.valid, src, 64);
+        const int bmnx = __shfl(mnx, src, 64), bmxx = __shfl(mxx, src, 64), bmny = __shfl(mny, src, 64);
+        const int bh = __shfl(h, src, 64), bgid = __shfl(gid, src, 64);
+        int base = __shfl(cur, src, 64);
         int total = 0;
-        for (int t0 = 0; t0 < barea; t0 += 64) {
-            const int t = t0 + lane;
-            const int ty = bmny + t / bw, tx = bmnx + t % bw;
-            const bool keep = t < barea && (!cull.enable || tile_hits(bx, by, ba, bb, bc, bnbc, bnba, bs, tx, ty, block));
-            const unsigned long long m = __ballot(keep);
-            if (EMIT && keep) {
-                const int pos = bcur + __popcll(m & ((1ull << lane) - 1ull));
-                tkeys[pos] = (uint32_t)(ty * tiles_x + tx);
-                tvals[pos] = bgid;
+        for (int r0 = 0; r0 < bh; r0 += 64) {
+            const int ty = bmny + r0 + lane;
+            int lo = 0, hi = -1;
+            if (r0 + lane < bh) row_interval(B, ty, block, bmnx, bmxx, lo, hi);
+            const int c = max(hi - lo + 1, 0);
+            int incl = c;                                   // inclusive prefix over the 64 rows of this chunk
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int u = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += u;
             }
-            const int c = __popcll(m);
-            bcur += c;
-            total += c;
+            if (EMIT) {
+                int pos = base + incl - c;
+                for (int tx = lo; tx <= hi; ++tx, ++pos) {
+                    tkeys[pos] = (uint32_t)(ty * tiles_x + tx);
+                    tvals[pos] = bgid;
+                }
+            }
+            const int chunk_total = __shfl(incl, 63, 64);
+            base += chunk_total;
+            total += chunk_total;
         }
         if (lane == src) cnt = total;
     }
@@ -396,12 +419,11 @@ static Cull make_cull(const float *conics, const float *opac, int opac_is_logit,
 SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii,
                                const float *conics, const float *opacities, int opacity_is_logit, int cull,
                                int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
-                               int32_t *gid_by_rank, uint32_t *keep_masks, void *ws, size_t ws_bytes,
-                               sgn_stream_t stream) {
+                               int32_t *gid_by_rank, void *ws, size_t ws_bytes, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     if (n == 0) return 0;
-    SGN_ARG_CHECK(xys && depths && radii && cum_by_rank && gid_by_rank && keep_masks && ws, -3);
+    SGN_ARG_CHECK(xys && depths && radii && cum_by_rank && gid_by_rank && ws, -3);
     SGN_ARG_CHECK(ws_bytes >= sgn_bin_prepare_workspace_bytes(n), -4);
     hipStream_t s = (hipStream_t)stream;
     char *p = (char *)ws;
@@ -418,7 +440,7 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     sgn_timing_end(SGN_T_SORT, s);
     sgn_timing_begin(SGN_T_MAP, s);
     hipLaunchKernelGGL(rank_tiles_kernel<false>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii,
-                       (const int32_t *)nullptr, gid_by_rank, c, tiles_x, tiles_y, block_width, cnt_r, keep_masks,
+                       (const int32_t *)nullptr, gid_by_rank, c, tiles_x, tiles_y, block_width, cnt_r,
                        (uint32_t *)nullptr, (int32_t *)nullptr);
     sgn_timing_end(SGN_T_MAP, s);
     return sgn_scan_i32(n, cnt_r, cum_by_rank, scan_ws, sgn_scan_workspace_bytes(n), stream);
@@ -431,9 +453,8 @@ SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
 
 SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const int32_t *radii,
                                  const float *conics, const float *opacities, int opacity_is_logit, int cull,
-                                 const int32_t *cum_by_rank, const int32_t *gid_by_rank,
-                                 const uint32_t *keep_masks, int tiles_x, int tiles_y, int block_width,
-                                 int32_t *gaussian_ids_sorted, int32_t *tile_bins,
+                                 const int32_t *cum_by_rank, const int32_t *gid_by_rank, int tiles_x,
+                                 int tiles_y, int block_width, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
                                  void *ws, size_t ws_bytes, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0 && n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
@@ -442,7 +463,7 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const
     const int n_tiles = tiles_x * tiles_y;
     SGN_HIP_CHECK(hipMemsetAsync(tile_bins, 0, (size_t)n_tiles * 2 * sizeof(int32_t), s));
     if (n_isect == 0 || n == 0) return 0;
-    SGN_ARG_CHECK(xys && radii && cum_by_rank && gid_by_rank && keep_masks && gaussian_ids_sorted && ws, -4);
+    SGN_ARG_CHECK(xys && radii && cum_by_rank && gid_by_rank && gaussian_ids_sorted && ws, -4);
     SGN_ARG_CHECK(ws_bytes >= sgn_bin_intersect_workspace_bytes(n_isect), -5);
     const int tile_bits = bit_length((uint32_t)(n_tiles - 1)) > 0 ? bit_length((uint32_t)(n_tiles - 1)) : 1;
     char *p = (char *)ws;
@@ -453,8 +474,7 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const
     const Cull c = make_cull(conics, opacities, opacity_is_logit, cull);
     sgn_timing_begin(SGN_T_MAP, s);
     hipLaunchKernelGGL(rank_tiles_kernel<true>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii, cum_by_rank,
-                       gid_by_rank, c, tiles_x, tiles_y, block_width, (int32_t *)nullptr, (uint32_t *)keep_masks, tkeys,
-                       tvals);
+                       gid_by_rank, c, tiles_x, tiles_y, block_width, (int32_t *)nullptr, tkeys, tvals);
     sgn_timing_end(SGN_T_MAP, s);
     sgn_timing_begin(SGN_T_SORT, s);
     sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws, s);
