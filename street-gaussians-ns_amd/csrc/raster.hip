@@ -36,7 +36,7 @@ struct __attribute__((aligned(16))) Rec {
     float b, hc, r, g;      // b = conic.y, hc = 0.5 * conic.z
     float bl;               // blue
     int gid;                // Gaussian id (backward scatter target)
-    float pad0, pad1;
+    float ex, ey;           // half-extents of the bbox of {alpha >= 1/255} (+margin); < 0: never visible
 };
 static_assert(sizeof(Rec) == SGN_RECORD_FLOATS * sizeof(float), "record size");
 
@@ -78,9 +78,20 @@ __global__ __launch_bounds__(256) void build_grec_kernel(int n, const float *__r
     const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
     float o = opac[g];
     if (opac_is_logit) o = 1.f / (1.f + expf(-o));  // fused torch.sigmoid (sgn_splatfacto.py:949)
+    // bbox of the region where alpha = o*exp(-sigma) can reach 1/255: sigma <= s = ln(255 o) (+1 % margin);
+    // x half-extent sqrt(2 s c / D), y half-extent sqrt(2 s a / D), D = ac - b^2.  Used by the raster kernels
+    // to skip 8x8 quadrants the Gaussian cannot touch (no valid pixel there => results unchanged).
+    const float s = (o * 255.f > 0.f) ? logf(255.f * o) + 0.01f : -1.f;
+    const float D = a * c - b * b;
+    float ex = -1.f, ey = -1.f;
+    if (s >= 0.f) {
+        const bool proper = a > 0.f && c > 0.f && D > 0.f;
+        ex = proper ? sqrtf(2.f * s * c / D) + 1e-3f : 3.0e38f;
+        ey = proper ? sqrtf(2.f * s * a / D) + 1e-3f : 3.0e38f;
+    }
     grec[3 * g + 0] = make_float4(x, y, o, 0.5f * a);
     grec[3 * g + 1] = make_float4(b, 0.5f * c, r, gg);
-    grec[3 * g + 2] = make_float4(bl, __int_as_float(g), 0.f, 0.f);
+    grec[3 * g + 2] = make_float4(bl, __int_as_float(g), ex, ey);
 }
 
 __global__ __launch_bounds__(256) void pack_records_kernel(int64_t n_isect, const int32_t *__restrict__ ids,
@@ -114,6 +125,15 @@ __device__ __forceinline__ int xcd_tile(int b, int n, int enable) {
     if (!enable) return b;
     const int q = n >> 3, r = n & 7, x = b & 7, j = b >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+// Which of the tile's four 8x8 quadrants can this Gaussian touch?  Lanes 0..3 each test one quadrant
+// (|centre distance| <= half-extent + 3.5 px, the half-span of the quadrant's pixel centres), the ballot
+// turns the answers into a wave-uniform 4-bit mask that the per-quadrant branches test in the scalar unit.
+__device__ __forceinline__ unsigned quadrant_mask(const Rec &g, float qcx, float qcy, bool enable) {
+    if (!enable) return 0xFu;
+    const bool hit = fabsf(g.x - qcx) <= g.ex + 3.5f && fabsf(g.y - qcy) <= g.ey + 3.5f;
+    return (unsigned)(__ballot(hit) & 0xFull);
 }
 
 // GATHER = false: `recs` is the depth-ordered record stream (pack_records ran first).
@@ -173,6 +193,10 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
         last[q] = 0;
     }
 
+    // centre of quadrant (lane & 3)'s pixel centres, for the quadrant-reject test (16x16 tiles only)
+    const bool qtest = (B == 16);
+    const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
+
     if (range.x < range.y) {
         Rec cur = recs[GATHER ? ids[range.x] : range.x];
         int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
@@ -187,9 +211,10 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
             const int kn = (k + 1 < range.y) ? k + 1 : k;
             const Rec nxt = recs[GATHER ? idn : kn];  // scalar prefetch of the next record
             if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
+            const unsigned qm = quadrant_mask(cur, qcx, qcy, qtest);
 #pragma unroll
             for (int q = 0; q < QPW; ++q) {
-                if (live[q] == 0ull) continue;  // wave-uniform
+                if (live[q] == 0ull || !((qm >> (q0 + q)) & 1u)) continue;  // wave-uniform
                 const float dx = cur.x - px[q], dy = cur.y - py[q];
                 float s = (cur.ha * dx) * dx;
                 s = fmaf(cur.hc * dy, dy, s);
@@ -329,6 +354,9 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         bv[q] = 0.f;
     }
 
+    const bool qtest = (B == 16);
+    const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
+
     Rec cur = recs[GATHER ? ids[kmax] : kmax];
     int idn = GATHER ? ids[max(kmax - 1, range.x)] : 0;
     for (int k = kmax; k >= range.x; --k) {
@@ -338,9 +366,10 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         float g_x = 0.f, g_y = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f;
         float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_o = 0.f;
         bool any = false;
+        const unsigned qm = quadrant_mask(cur, qcx, qcy, qtest);
 #pragma unroll
         for (int q = 0; q < QPW; ++q) {
-            if (__ballot(k <= kfin[q]) == 0ull) continue;  // wave-uniform
+            if (!((qm >> (q0 + q)) & 1u) || __ballot(k <= kfin[q]) == 0ull) continue;  // wave-uniform
             const float dx = cur.x - px[q], dy = cur.y - py[q];
             const float t1 = cur.ha * dx, t2 = cur.hc * dy, t3 = cur.b * dx;
             const float sigma = fmaf(t3, dy, fmaf(t2, dy, t1 * dx));
