@@ -58,6 +58,10 @@ void sgn_set_waves_per_tile(int w);
 void sgn_set_adaptive_thresholds(int fwd_entries, int bwd_entries); /* <= 0 keeps the current value */
 /* XCD-aware tile -> workgroup order in the raster kernels (contiguous tile band per XCD / L2). */
 void sgn_set_xcd_swizzle(int on);
+/* Depth lists (forward) / reverse walks (backward) with at least this many entries are read through 64-entry
+ * batches staged in wave-private LDS (vector gather a batch ahead) instead of the one-entry scalar look-ahead,
+ * which is latency-bound for a lone wave on a long list.  <= 0 keeps the current value; a huge value disables. */
+void sgn_set_batch_thresholds(int fwd_entries, int bwd_entries);
 
 /* Opt-in per-kernel timing for bench.py / profiles: when enabled, each timed launch is bracketed by
  * hipEventRecord on the stream it is launched on; sgn_timing_get sums the finished spans of a slot. */

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
                                                         const int32_t *__restrict__ ids,
                                                         const float *__restrict__ bg, float *__restrict__ out_img,
                                                         float *__restrict__ final_T,
-                                                        int32_t *__restrict__ final_idx, int adapt_thresh, int swz) {
+                                                        int32_t *__restrict__ final_idx, int adapt_thresh, int swz,
+                                                        int batch_thresh) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
     constexpr int WPT = ADAPT ? 4 : 4 / QPW;   // waves launched per tile
     // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile) so the waves that do the
@@ -197,43 +198,86 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
     const bool qtest = (B == 16);
     const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
 
-    if (range.x < range.y) {
+    // one depth-list entry for this wave's pixels; returns false once every pixel of the wave is finished
+    auto entry = [&](const Rec &cur, int k) __attribute__((always_inline)) -> bool {
+        unsigned long long live[QPW], any_live = 0ull;
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) {
+            live[q] = __ballot(T[q] > 0.f);
+            any_live |= live[q];
+        }
+        if (any_live == 0ull) return false;
+        const unsigned qm = quadrant_mask(cur, qcx, qcy, qtest);
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) {
+            if (live[q] == 0ull || !((qm >> (q0 + q)) & 1u)) continue;  // wave-uniform
+            const float dx = cur.x - px[q], dy = cur.y - py[q];
+            float s = (cur.ha * dx) * dx;
+            s = fmaf(cur.hc * dy, dy, s);
+            const float sigma = fmaf(cur.b * dx, dy, s);
+            const float alpha = fminf(0.999f, cur.opac * sgn_exp<EXACT>(-sigma));
+            const bool valid = T[q] > 0.f && sigma >= 0.f && alpha >= (1.f / 255.f);
+            // branch-free update: lanes that skip or stop add vis = 0 (fma(c, 0, C) == C exactly)
+            const float nT = T[q] * (1.f - alpha);
+            const bool stop = valid && nT <= 1e-4f;
+            const bool acc = valid && !stop;
+            const float vis = acc ? alpha * T[q] : 0.f;
+            C0[q] = fmaf(cur.r, vis, C0[q]);
+            C1[q] = fmaf(cur.g, vis, C1[q]);
+            C2[q] = fmaf(cur.bl, vis, C2[q]);
+            last[q] = acc ? k : last[q];
+            const float Tk = acc ? nT : T[q];
+            T[q] = stop ? -Tk : Tk;  // terminating Gaussian is NOT composited; T keeps its last value
+        }
+        return true;
+    };
+
+    const int L = range.y - range.x;
+    if (L > 0 && L < batch_thresh) {
+        // short list: chase ids -> rows with scalar loads, one entry ahead (operands arrive in SGPRs)
         Rec cur = recs[GATHER ? ids[range.x] : range.x];
         int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
         for (int k = range.x; k < range.y; ++k) {
-            unsigned long long live[QPW], any_live = 0ull;
-#pragma unroll
-            for (int q = 0; q < QPW; ++q) {
-                live[q] = __ballot(T[q] > 0.f);
-                any_live |= live[q];
-            }
-            if (any_live == 0ull) break;
             const int kn = (k + 1 < range.y) ? k + 1 : k;
             const Rec nxt = recs[GATHER ? idn : kn];  // scalar prefetch of the next record
             if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
-            const unsigned qm = quadrant_mask(cur, qcx, qcy, qtest);
-#pragma unroll
-            for (int q = 0; q < QPW; ++q) {
-                if (live[q] == 0ull || !((qm >> (q0 + q)) & 1u)) continue;  // wave-uniform
-                const float dx = cur.x - px[q], dy = cur.y - py[q];
-                float s = (cur.ha * dx) * dx;
-                s = fmaf(cur.hc * dy, dy, s);
-                const float sigma = fmaf(cur.b * dx, dy, s);
-                const float alpha = fminf(0.999f, cur.opac * sgn_exp<EXACT>(-sigma));
-                const bool valid = T[q] > 0.f && sigma >= 0.f && alpha >= (1.f / 255.f);
-                // branch-free update: lanes that skip or stop add vis = 0 (fma(c, 0, C) == C exactly)
-                const float nT = T[q] * (1.f - alpha);
-                const bool stop = valid && nT <= 1e-4f;
-                const bool acc = valid && !stop;
-                const float vis = acc ? alpha * T[q] : 0.f;
-                C0[q] = fmaf(cur.r, vis, C0[q]);
-                C1[q] = fmaf(cur.g, vis, C1[q]);
-                C2[q] = fmaf(cur.bl, vis, C2[q]);
-                last[q] = acc ? k : last[q];
-                const float Tk = acc ? nT : T[q];
-                T[q] = stop ? -Tk : Tk;  // terminating Gaussian is NOT composited; T keeps its last value
-            }
+            if (!entry(cur, k)) break;
             cur = nxt;
+        }
+    } else if (L > 0) {
+        // long list: the one-entry scalar look-ahead leaves a lone wave latency-bound (a dependent id -> row
+        // load pair per entry), so stage 64-entry batches through wave-private LDS instead: lane l gathers
+        // row ids[k0+l] with vector loads a whole batch ahead, entries are then read back with broadcast
+        // ds_read_b128 (no barrier: the workgroup is this one wave and its LDS ops retire in order).
+        __shared__ float4 stage[2][64 * 3];
+        const int nb = (L + 63) >> 6;
+        auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
+            const int k = range.x + (bidx << 6) + lane;
+            if (k < range.y) {
+                const float4 *p = reinterpret_cast<const float4 *>(recs + (GATHER ? ids[k] : k));
+                r0 = p[0]; r1 = p[1]; r2 = p[2];
+            }
+        };
+        float4 r0, r1, r2;
+        fetch(0, r0, r1, r2);
+        stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
+        bool go = true;
+        for (int bi = 0; bi < nb && go; ++bi) {
+            if (bi + 1 < nb) fetch(bi + 1, r0, r1, r2);  // in flight while this batch is composited
+            const int cnt = min(64, L - (bi << 6));
+            const float4 *sb = stage[bi & 1];
+            for (int j = 0; j < cnt; ++j) {
+                Rec cur;
+                const float4 a0 = sb[j * 3 + 0], a1 = sb[j * 3 + 1], a2 = sb[j * 3 + 2];
+                cur.x = a0.x; cur.y = a0.y; cur.opac = a0.z; cur.ha = a0.w;
+                cur.b = a1.x; cur.hc = a1.y; cur.r = a1.z; cur.g = a1.w;
+                cur.bl = a2.x; cur.gid = __float_as_int(a2.y); cur.ex = a2.z; cur.ey = a2.w;
+                if (!entry(cur, range.x + (bi << 6) + j)) { go = false; break; }
+            }
+            if (go && bi + 1 < nb) {
+                float4 *sn = stage[(bi + 1) & 1];
+                sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
+            }
         }
     }
 #pragma unroll
@@ -290,7 +334,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                                                         const float *__restrict__ v_out,
                                                         const float *__restrict__ v_out_alpha,
                                                         float alpha_clamp, float *__restrict__ grad_ws, int dbg,
-                                                        int adapt_thresh, int swz) {
+                                                        int adapt_thresh, int swz, int batch_thresh) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
     constexpr int WPT = ADAPT ? 4 : 4 / QPW;
     const int n_tiles_ = gridDim.x / WPT;      // ADAPT: wave-major numbering, see the forward kernel
@@ -357,12 +401,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
     const bool qtest = (B == 16);
     const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
 
-    Rec cur = recs[GATHER ? ids[kmax] : kmax];
-    int idn = GATHER ? ids[max(kmax - 1, range.x)] : 0;
-    for (int k = kmax; k >= range.x; --k) {
-        const int kn = (k - 1 >= range.x) ? k - 1 : k;
-        const Rec nxt = recs[GATHER ? idn : kn];
-        if constexpr (GATHER) idn = ids[max(k - 2, range.x)];
+    // one depth-list entry (reverse walk) for this wave's pixels
+    auto entry = [&](const Rec &cur, int k) __attribute__((always_inline)) {
         float g_x = 0.f, g_y = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f;
         float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_o = 0.f;
         bool any = false;
@@ -429,7 +469,50 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
             if (lane >= L0 && lane < L0 + 9 && !(dbg & 1))  // dbg bit0: ablation, no atomics
                 unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + (lane - L0), mine);
         }
-        cur = nxt;
+    };
+
+    const int L = kmax - range.x + 1;   // entries of the reverse walk
+    if (L < batch_thresh) {
+        Rec cur = recs[GATHER ? ids[kmax] : kmax];
+        int idn = GATHER ? ids[max(kmax - 1, range.x)] : 0;
+        for (int k = kmax; k >= range.x; --k) {
+            const int kn = (k - 1 >= range.x) ? k - 1 : k;
+            const Rec nxt = recs[GATHER ? idn : kn];
+            if constexpr (GATHER) idn = ids[max(k - 2, range.x)];
+            entry(cur, k);
+            cur = nxt;
+        }
+    } else {
+        // long walk: 64-entry batches staged through wave-private LDS (see the forward kernel)
+        __shared__ float4 stage[2][64 * 3];
+        const int nb = (L + 63) >> 6;
+        auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
+            const int k = kmax - (bidx << 6) - lane;
+            if (k >= range.x) {
+                const float4 *p = reinterpret_cast<const float4 *>(recs + (GATHER ? ids[k] : k));
+                r0 = p[0]; r1 = p[1]; r2 = p[2];
+            }
+        };
+        float4 r0, r1, r2;
+        fetch(0, r0, r1, r2);
+        stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
+        for (int bi = 0; bi < nb; ++bi) {
+            if (bi + 1 < nb) fetch(bi + 1, r0, r1, r2);
+            const int cnt = min(64, L - (bi << 6));
+            const float4 *sb = stage[bi & 1];
+            for (int j = 0; j < cnt; ++j) {
+                Rec cur;
+                const float4 a0 = sb[j * 3 + 0], a1 = sb[j * 3 + 1], a2 = sb[j * 3 + 2];
+                cur.x = a0.x; cur.y = a0.y; cur.opac = a0.z; cur.ha = a0.w;
+                cur.b = a1.x; cur.hc = a1.y; cur.r = a1.z; cur.g = a1.w;
+                cur.bl = a2.x; cur.gid = __float_as_int(a2.y); cur.ex = a2.z; cur.ey = a2.w;
+                entry(cur, kmax - (bi << 6) - j);
+            }
+            if (bi + 1 < nb) {
+                float4 *sn = stage[(bi + 1) & 1];
+                sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
+            }
+        }
     }
 }
 
@@ -460,6 +543,8 @@ int g_debug = 0;         // timing ablations only (bit0: no atomics, bit1: no wa
 int g_wpt = 0;           // waves per tile: 1, 4, or 0 = adaptive (split long lists, default)
 int g_adapt_fwd = 3072;  // forward: split tiles with >= this many list entries
 int g_adapt_bwd = 1536;  // backward: split tiles whose reverse walk covers >= this many entries
+int g_batch_fwd = 2048;  // forward: lists with >= this many entries go through the LDS-batched path
+int g_batch_bwd = 512;   // backward: reverse walks with >= this many entries go through the LDS-batched path
 int g_xcd_swizzle = 0;   // XCD-aware tile order in the raster kernels
 int g_gather = 1;        // 1 (default): chase ids -> per-Gaussian rows; 0: stream packed records
 
@@ -471,6 +556,10 @@ SGN_EXPORT void sgn_set_reduce_mode(int mode) { g_reduce_mode = mode ? 1 : 0; }
 SGN_EXPORT void sgn_set_debug_flags(int flags) { g_debug = flags; }
 SGN_EXPORT void sgn_set_gather_mode(int on) { g_gather = on ? 1 : 0; }
 SGN_EXPORT void sgn_set_xcd_swizzle(int on) { g_xcd_swizzle = on ? 1 : 0; }
+SGN_EXPORT void sgn_set_batch_thresholds(int fwd_entries, int bwd_entries) {
+    if (fwd_entries > 0) g_batch_fwd = fwd_entries;
+    if (bwd_entries > 0) g_batch_bwd = bwd_entries;
+}
 SGN_EXPORT void sgn_set_waves_per_tile(int w) { g_wpt = (w == 4 || w == 1) ? w : 0; }
 SGN_EXPORT void sgn_set_adaptive_thresholds(int fwd_entries, int bwd_entries) {
     if (fwd_entries > 0) g_adapt_fwd = fwd_entries;
@@ -523,7 +612,7 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
 #define SGN_LAUNCH_FWD(EX, GA, Q, AD)                                                                                \
     hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
                        img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
-                       gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, g_adapt_fwd, g_xcd_swizzle)
+                       gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, g_adapt_fwd, g_xcd_swizzle, g_batch_fwd)
 #define SGN_LAUNCH_FWD2(EX, GA)                                                     \
     do {                                                                            \
         if (g_wpt == 4) SGN_LAUNCH_FWD(EX, GA, 1, false);                           \
@@ -580,7 +669,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, img_w, img_h, \
                        block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, \
                        background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws, \
-                       g_debug, g_adapt_bwd, g_xcd_swizzle)
+                       g_debug, g_adapt_bwd, g_xcd_swizzle, g_batch_bwd)
 #define SGN_LAUNCH_BWD2(EX, RM) do { if (g_gather) SGN_LAUNCH_BWD(EX, RM, true); else SGN_LAUNCH_BWD(EX, RM, false); } while (0)
         if (g_exact_exp) {
             if (g_reduce_mode) SGN_LAUNCH_BWD2(true, 1); else SGN_LAUNCH_BWD2(true, 0);

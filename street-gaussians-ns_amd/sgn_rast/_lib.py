@@ -28,6 +28,7 @@ SIGNATURES = {
     "sgn_set_waves_per_tile": (None, [_i]),
     "sgn_set_adaptive_thresholds": (None, [_i, _i]),
     "sgn_set_xcd_swizzle": (None, [_i]),
+    "sgn_set_batch_thresholds": (None, [_i, _i]),
     "sgn_timing_enable": (None, [_i]),
     "sgn_timing_get": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "sgn_project_fwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f,
@@ -85,6 +86,7 @@ def load() -> C.CDLL:
         lib.sgn_set_reduce_mode(DEFAULT_REDUCE_MODE)
         lib.sgn_set_gather_mode(DEFAULT_GATHER_MODE)
         lib.sgn_set_waves_per_tile(int(os.environ.get("SGN_WAVES_PER_TILE", "0")))
+        lib.sgn_set_batch_thresholds(int(os.environ.get("SGN_BATCH_FWD", "0")), int(os.environ.get("SGN_BATCH_BWD", "0")))
         lib.sgn_set_xcd_swizzle(int(os.environ.get("SGN_XCD_SWIZZLE", "0")))
         lib.sgn_set_adaptive_thresholds(int(os.environ.get("SGN_ADAPT_FWD", "0")), int(os.environ.get("SGN_ADAPT_BWD", "0")))
         lib.sgn_set_debug_flags(int(os.environ.get("SGN_DEBUG_FLAGS", "0")))

@@ -19,13 +19,16 @@ def hip():
     return ops
 
 
-@pytest.fixture(autouse=True, params=[(0, 1), (1, 1), (1, 4), (1, 0)],
-                ids=["stream", "gather", "gather-4waves", "gather-adaptive"])
+@pytest.fixture(autouse=True, params=[(0, 1, 0), (1, 1, 0), (1, 4, 0), (1, 0, 0), (1, 0, 1), (0, 1, 1)],
+                ids=["stream", "gather", "gather-4waves", "gather-adaptive", "gather-adaptive-ldsbatch",
+                     "stream-ldsbatch"])
 def raster_record_mode(request):
     """Every test in this module runs with the record-fetch modes of the raster kernels (packed depth-ordered
-    stream vs. ids -> per-Gaussian rows chased with scalar loads) and with 1 or 4 waves per tile."""
+    stream vs. ids -> per-Gaussian rows chased with scalar loads) with 1 / 4 / adaptive waves per tile, and with the LDS-batched
+    long-list path forced on or off."""
     from sgn_rast import _lib as L
-    gather, wpt = request.param
+    gather, wpt, batch = request.param
+    L.load().sgn_set_batch_thresholds(*((24, 24) if batch else (1 << 30, 1 << 30)))  # force / forbid the LDS path
     L.load().sgn_set_gather_mode(gather)
     L.load().sgn_set_waves_per_tile(wpt)
     if wpt == 0:
@@ -34,6 +37,7 @@ def raster_record_mode(request):
     L.load().sgn_set_gather_mode(L.DEFAULT_GATHER_MODE)
     L.load().sgn_set_waves_per_tile(0)
     L.load().sgn_set_adaptive_thresholds(3072, 1536)
+    L.load().sgn_set_batch_thresholds(2048, 512)
 
 
 def _project_args(cam, P, block=16, dev="cpu"):
