@@ -136,6 +136,20 @@ __device__ __forceinline__ unsigned quadrant_mask(const Rec &g, float qcx, float
     return (unsigned)(__ballot(hit) & 0xFull);
 }
 
+// Batched path: every lane holds ONE row of the batch and tests all four quadrants for it (lane-parallel over
+// 64 entries instead of once per entry), so entries that cannot touch this wave's pixels are never visited.
+__device__ __forceinline__ unsigned row_quadrants(float gx, float gy, float ex, float ey, int tile_x0, int tile_y0,
+                                                  bool enable) {
+    if (!enable) return 0xFu;
+    unsigned m = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float cx = (float)(tile_x0 + (q & 1) * 8) + 4.0f, cy = (float)(tile_y0 + (q >> 1) * 8) + 4.0f;
+        if (fabsf(gx - cx) <= ex + 3.5f && fabsf(gy - cy) <= ey + 3.5f) m |= 1u << q;
+    }
+    return m;
+}
+
 // GATHER = false: `recs` is the depth-ordered record stream (pack_records ran first).
 // GATHER = true : `recs` is the per-Gaussian row table and `ids` the sorted id list; the wave chases
 //                 ids[k] -> row with two dependent scalar loads, the id two records ahead and the row
@@ -199,7 +213,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
     const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
 
     // one depth-list entry for this wave's pixels; returns false once every pixel of the wave is finished
-    auto entry = [&](const Rec &cur, int k) __attribute__((always_inline)) -> bool {
+    auto entry = [&](const Rec &cur, int k, unsigned qm) __attribute__((always_inline)) -> bool {
         unsigned long long live[QPW], any_live = 0ull;
 #pragma unroll
         for (int q = 0; q < QPW; ++q) {
@@ -207,7 +221,6 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
             any_live |= live[q];
         }
         if (any_live == 0ull) return false;
-        const unsigned qm = quadrant_mask(cur, qcx, qcy, qtest);
 #pragma unroll
         for (int q = 0; q < QPW; ++q) {
             if (live[q] == 0ull || !((qm >> (q0 + q)) & 1u)) continue;  // wave-uniform
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
             const int kn = (k + 1 < range.y) ? k + 1 : k;
             const Rec nxt = recs[GATHER ? idn : kn];  // scalar prefetch of the next record
             if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
-            if (!entry(cur, k)) break;
+            if (!entry(cur, k, quadrant_mask(cur, qcx, qcy, qtest))) break;
             cur = nxt;
         }
     } else if (L > 0) {
@@ -258,25 +271,37 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
             }
         };
-        float4 r0, r1, r2;
+        // this wave's quadrants as a bit mask (all four, or the single one of a split tile)
+        unsigned mine_q = 0u;
+#pragma unroll
+        for (int q = 0; q < QPW; ++q)
+            if (q >= qlo && q < qhi) mine_q |= 1u << (q0 + q);
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
+        unsigned qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
         bool go = true;
         for (int bi = 0; bi < nb && go; ++bi) {
-            if (bi + 1 < nb) fetch(bi + 1, r0, r1, r2);  // in flight while this batch is composited
             const int cnt = min(64, L - (bi << 6));
+            unsigned long long todo = __ballot(lane < cnt && qrow != 0u);  // entries that can touch my pixels
+            const unsigned qcur = qrow;
+            if (bi + 1 < nb) fetch(bi + 1, r0, r1, r2);   // next batch: in flight while this one is composited
             const float4 *sb = stage[bi & 1];
-            for (int j = 0; j < cnt; ++j) {
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
                 Rec cur;
                 const float4 a0 = sb[j * 3 + 0], a1 = sb[j * 3 + 1], a2 = sb[j * 3 + 2];
                 cur.x = a0.x; cur.y = a0.y; cur.opac = a0.z; cur.ha = a0.w;
                 cur.b = a1.x; cur.hc = a1.y; cur.r = a1.z; cur.g = a1.w;
                 cur.bl = a2.x; cur.gid = __float_as_int(a2.y); cur.ex = a2.z; cur.ey = a2.w;
-                if (!entry(cur, range.x + (bi << 6) + j)) { go = false; break; }
+                const unsigned qm = (unsigned)__builtin_amdgcn_readlane((int)qcur, j);
+                if (!entry(cur, range.x + (bi << 6) + j, qm)) { go = false; break; }
             }
-            if (go && bi + 1 < nb) {
+            if (go && bi + 1 < nb) {                      // first use of the prefetched registers
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
+                qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
             }
         }
     }
@@ -400,13 +425,15 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
 
     const bool qtest = (B == 16);
     const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
+    bool kfin_active[QPW];   // wave-uniform: does any pixel of this slot take part in the reverse walk?
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) kfin_active[q] = __ballot(kfin[q] >= range.x) != 0ull;
 
     // one depth-list entry (reverse walk) for this wave's pixels
-    auto entry = [&](const Rec &cur, int k) __attribute__((always_inline)) {
+    auto entry = [&](const Rec &cur, int k, unsigned qm) __attribute__((always_inline)) {
         float g_x = 0.f, g_y = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f;
         float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_o = 0.f;
         bool any = false;
-        const unsigned qm = quadrant_mask(cur, qcx, qcy, qtest);
 #pragma unroll
         for (int q = 0; q < QPW; ++q) {
             if (!((qm >> (q0 + q)) & 1u) || __ballot(k <= kfin[q]) == 0ull) continue;  // wave-uniform
@@ -479,7 +506,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
             const int kn = (k - 1 >= range.x) ? k - 1 : k;
             const Rec nxt = recs[GATHER ? idn : kn];
             if constexpr (GATHER) idn = ids[max(k - 2, range.x)];
-            entry(cur, k);
+            entry(cur, k, quadrant_mask(cur, qcx, qcy, qtest));
             cur = nxt;
         }
     } else {
@@ -493,24 +520,34 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
             }
         };
-        float4 r0, r1, r2;
+        unsigned mine_q = 0u;
+#pragma unroll
+        for (int q = 0; q < QPW; ++q)
+            if (kfin_active[q]) mine_q |= 1u << (q0 + q);
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
+        unsigned qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
         for (int bi = 0; bi < nb; ++bi) {
-            if (bi + 1 < nb) fetch(bi + 1, r0, r1, r2);
             const int cnt = min(64, L - (bi << 6));
+            unsigned long long todo = __ballot(lane < cnt && qrow != 0u);
+            const unsigned qcur = qrow;
+            if (bi + 1 < nb) fetch(bi + 1, r0, r1, r2);
             const float4 *sb = stage[bi & 1];
-            for (int j = 0; j < cnt; ++j) {
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
                 Rec cur;
                 const float4 a0 = sb[j * 3 + 0], a1 = sb[j * 3 + 1], a2 = sb[j * 3 + 2];
                 cur.x = a0.x; cur.y = a0.y; cur.opac = a0.z; cur.ha = a0.w;
                 cur.b = a1.x; cur.hc = a1.y; cur.r = a1.z; cur.g = a1.w;
                 cur.bl = a2.x; cur.gid = __float_as_int(a2.y); cur.ex = a2.z; cur.ey = a2.w;
-                entry(cur, kmax - (bi << 6) - j);
+                entry(cur, kmax - (bi << 6) - j, (unsigned)__builtin_amdgcn_readlane((int)qcur, j));
             }
             if (bi + 1 < nb) {
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
+                qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
             }
         }
     }
