@@ -580,8 +580,8 @@ int g_debug = 0;         // timing ablations only (bit0: no atomics, bit1: no wa
 int g_wpt = 0;           // waves per tile: 1, 4, or 0 = adaptive (split long lists, default)
 int g_adapt_fwd = 3072;  // forward: split tiles with >= this many list entries
 int g_adapt_bwd = 1536;  // backward: split tiles whose reverse walk covers >= this many entries
-int g_batch_fwd = 2048;  // forward: lists with >= this many entries go through the LDS-batched path
-int g_batch_bwd = 512;   // backward: reverse walks with >= this many entries go through the LDS-batched path
+int g_batch_fwd = 256;   // forward: lists with >= this many entries go through the LDS-batched path
+int g_batch_bwd = 128;   // backward: reverse walks with >= this many entries go through the LDS-batched path
 int g_xcd_swizzle = 0;   // XCD-aware tile order in the raster kernels
 int g_gather = 1;        // 1 (default): chase ids -> per-Gaussian rows; 0: stream packed records
 

@@ -37,7 +37,7 @@ def raster_record_mode(request):
     L.load().sgn_set_gather_mode(L.DEFAULT_GATHER_MODE)
     L.load().sgn_set_waves_per_tile(0)
     L.load().sgn_set_adaptive_thresholds(3072, 1536)
-    L.load().sgn_set_batch_thresholds(2048, 512)
+    L.load().sgn_set_batch_thresholds(256, 128)
 
 
 def _project_args(cam, P, block=16, dev="cpu"):
