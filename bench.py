@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--scene-graph", action="store_true",
                     help="reference-faithful scene-graph step (SURVEY.md §8d): background + 8 rigid objects, four "
                          "raster passes (rgb+alpha, depth, object acc, background acc); not the headline metric")
+    ap.add_argument("--sky", action="store_true",
+                    help="add the reference's sky-sphere branch (EnvLight 1024^2 cube map lookup + blend, "
+                         "sgn_splatfacto.py:875-876,969-972) to the step")
     ap.add_argument("--dp-exchange", default="lowrank", choices=["lowrank", "dense"],
                     help="N>1: SH gradient via all-gathered low-rank factors (default) or dense all-reduce")
     return ap.parse_args()
@@ -172,10 +175,20 @@ def main():
                 reducer.sh_exchange.remove()
             reducer = dp.GradAllReducer([p for m in sg[0] for p in m.values()])
 
+    sky = None
+    if args.sky:
+        c2w = torch.zeros(3, 4, device=dev)
+        c2w[:, :3] = cam.viewmat[:3, :3].T
+        sky = {"base": (0.5 * torch.ones(6, 1024, 1024, 3, device=dev)).requires_grad_(True), "c2w": c2w}
+        if world > 1:
+            reducer.remove()
+            reducer = dp.GradAllReducer(list(P.values()) + [sky["base"]], big=[P["features_rest"], sky["base"]],
+                                        sh_exchange=reducer.sh_exchange)
+
     def one_step(fused=(args.path == "fused")):
         if sg is None:
             return step.train_step(P, cam, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer,
-                                   fused=fused)
+                                   fused=fused, sky=sky)
         for m in sg[0]:
             for p in m.values():
                 p.grad = None
@@ -283,6 +296,9 @@ def main():
             line["config"]["workload"] = ("scene graph: " + line["config"]["workload"] +
                                           "; background + 8 rigid objects (10 % of the Gaussians, Fourier dim 5), "
                                           "passes: rgb+alpha, depth, object acc (in the loss), background acc")
+        if args.sky:
+            line["metric"] = "train-step images/sec (fwd+bwd + sky cube map) @1M Gaussians 1920x1280"
+            line["config"]["workload"] += "; + EnvLight 6x1024x1024x3 lookup/blend fwd+bwd"
         if fused_extra is not None:
             line["fused_path"] = fused_extra
         if world == 1 and not args.no_cpu_baseline:

@@ -77,7 +77,9 @@ void sgn_set_batch_thresholds(int fwd_entries, int bwd_entries);
 #define SGN_T_RASTER_FWD 9
 #define SGN_T_RASTER_BWD 10
 #define SGN_T_UNPACK 11
-#define SGN_T_SLOTS 12
+#define SGN_T_SKY_FWD 12
+#define SGN_T_SKY_BWD 13
+#define SGN_T_SLOTS 14
 void sgn_timing_enable(int on); /* also clears recorded spans */
 int sgn_timing_get(int slot, int *count /*host*/, float *total_ms /*host*/);
 
@@ -224,6 +226,36 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    float *v_colors /*[n,3]*/, float *v_opacity /*[n]*/, void *recs_ws,
                    size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
                    sgn_stream_t stream);
+
+/* Sky cube-map lookup: replaces nvdiffrast `dr.texture(tex[None], dirs, filter_mode='linear',
+ * boundary_mode='cube')` used by EnvLight (sgn_splatfacto.py:109-150).  tex [6,R,R,C] (faces +x,-x,+y,-y,+z,-z),
+ * dirs [n,3] (need not be normalised), out [n,C].  The backward returns the texture gradient only (the directions
+ * come from the camera and carry no gradient in the reference) and zero-fills v_tex first. */
+int sgn_cube_texture_fwd(int64_t n, int resolution, int channels, const float *tex, const float *dirs,
+                         float *out, sgn_stream_t stream);
+int sgn_cube_texture_bwd(int64_t n, int resolution, int channels, const float *dirs, const float *v_out,
+                         float *v_tex, sgn_stream_t stream);
+
+/* Fused EnvLight.forward (sgn_splatfacto.py:117-150): per-pixel camera ray -> world (c2w: DEVICE pointer to a
+ * row-major rotation with row stride c2w_ld, e.g. 4 for camera_to_worlds[0]) -> GL axes -> cube lookup; no
+ * direction tensor is materialised.  jitter: device [2,h,w] sub-pixel offsets (training, torch.rand_like) or
+ * NULL for the +0.5 pixel centres (eval).  out [h*w, C]. */
+int sgn_sky_fwd(int h, int w, float fx, float fy, float cx, float cy, const float *c2w, int c2w_ld,
+                const float *jitter, int resolution, int channels, const float *tex, float *out,
+                sgn_stream_t stream);
+int sgn_sky_bwd(int h, int w, float fx, float fy, float cx, float cy, const float *c2w, int c2w_ld,
+                const float *jitter, int resolution, int channels, const float *v_out, float *v_tex,
+                sgn_stream_t stream);
+
+/* Sky lookup fused with the reference's compositing (sgn_splatfacto.py:969-972):
+ * out = min(rgb,1)*alpha + sky*(1-alpha); rgb/out [h*w,3], alpha [h*w], 3-channel texture.  sky_out (optional,
+ * may be NULL) receives the raw sky colour (the reference's "sky" output).  The backward recomputes the lookup. */
+int sgn_sky_blend_fwd(int h, int w, float fx, float fy, float cx, float cy, const float *c2w, int c2w_ld,
+                      const float *jitter, int resolution, const float *tex, const float *rgb, const float *alpha,
+                      float *out, float *sky_out, sgn_stream_t stream);
+int sgn_sky_blend_bwd(int h, int w, float fx, float fy, float cx, float cy, const float *c2w, int c2w_ld,
+                      const float *jitter, int resolution, const float *tex, const float *rgb, const float *alpha,
+                      const float *v_out, float *v_rgb, float *v_alpha, float *v_tex, sgn_stream_t stream);
 
 #ifdef __cplusplus
 }

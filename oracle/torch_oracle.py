@@ -395,3 +395,86 @@ def idft(time: float, dim: int, dtype=torch.float32) -> torch.Tensor:
         else:
             out.append(torch.sin(math.pi * 2 * t * (k + 1) / dim))
     return torch.stack(out)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Sky cube map.  Restates nvdiffrast `dr.texture(..., filter_mode='linear',
+# boundary_mode='cube')` as used by EnvLight (street_gaussians_ns/sgn_splatfacto.py:109-150).  nvdiffrast is an
+# un-vendored submodule (dependencies/nvdiffrast is empty in the reference checkout): PARITY UNPINNED — this is
+# the documented behaviour restated (GL face order and (s,t) table, texel-centre bilinear taps, seamless edges,
+# corner taps dropped and renormalised), anchored on the reference's call site only.
+# --------------------------------------------------------------------------------------------------------------
+def _cube_face_uv(d: torch.Tensor):
+    x, y, z = d.unbind(-1)
+    ax, ay, az = x.abs(), y.abs(), z.abs()
+    is_z = az > torch.maximum(ax, ay)
+    is_y = (~is_z) & (ay > ax)
+    c = torch.where(is_z, z, torch.where(is_y, y, x))
+    sx = torch.where(is_z | is_y, x, z)
+    sy = torch.where(is_y, z, y)
+    idx = torch.where(is_z, 4, torch.where(is_y, 2, 0)) + (c < 0).long()
+    m = 0.5 / c.abs()
+    m0 = torch.where((idx == 0) | (idx == 5), -m, m)
+    m1 = torch.where(idx != 2, -m, m)
+    u, v = sx * m0 + 0.5, sy * m1 + 0.5
+    valid = torch.isfinite(u) & torch.isfinite(v)
+    return idx, u.clamp(0, 1), v.clamp(0, 1), valid
+
+
+def _cube_dir(face: torch.Tensor, u: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    s, t = 2 * u - 1, 2 * v - 1
+    one = torch.ones_like(s)
+    table = [(one, -t, -s), (-one, -t, s), (s, one, t), (s, -one, -t), (s, -t, one), (-s, -t, -one)]
+    out = torch.zeros(s.shape + (3,), dtype=s.dtype)
+    for f, (x, y, z) in enumerate(table):
+        sel = face == f
+        out[sel] = torch.stack([x, y, z], -1)[sel]
+    return out
+
+
+def cube_texture(tex: torch.Tensor, dirs: torch.Tensor) -> torch.Tensor:
+    """tex [6,R,R,C], dirs [...,3] -> [...,C]; differentiable w.r.t. ``tex`` (plain autograd)."""
+    R, C = tex.shape[1], tex.shape[3]
+    d = dirs.reshape(-1, 3).to(torch.float32)
+    face, u, v, valid = _cube_face_uv(d)
+    fu, fv = u * R - 0.5, v * R - 0.5
+    flu, flv = torch.floor(fu), torch.floor(fv)
+    au, av = fu - flu, fv - flv
+    iu0, iv0 = flu.long(), flv.long()
+    flat = tex.reshape(-1, C)
+    acc = torch.zeros(d.shape[0], C, dtype=torch.float32)
+    ws, offs, keeps = [], [], []
+    for k in range(4):
+        iu, iv = iu0 + (k & 1), iv0 + (k >> 1)
+        w = (au if (k & 1) else 1 - au) * (av if (k >> 1) else 1 - av)
+        ou, ov = (iu < 0) | (iu >= R), (iv < 0) | (iv >= R)
+        keep = valid & ~(ou & ov)
+        d2 = _cube_dir(face, (iu.float() + 0.5) / R, (iv.float() + 0.5) / R)
+        f2, u2, v2, _ = _cube_face_uv(d2)
+        ix2 = torch.floor(u2 * R).long().clamp(0, R - 1)
+        iy2 = torch.floor(v2 * R).long().clamp(0, R - 1)
+        edge = ou | ov
+        f = torch.where(edge, f2, face)
+        ix = torch.where(edge, ix2, iu).clamp(0, R - 1)
+        iy = torch.where(edge, iy2, iv).clamp(0, R - 1)
+        ws.append(torch.where(keep, w, torch.zeros_like(w)))
+        offs.append((f * R + iy) * R + ix)
+        keeps.append(keep)
+    wsum = ws[0] + ws[1] + ws[2] + ws[3]
+    renorm = (wsum > 0) & (wsum < 1)
+    inv = torch.where(renorm, 1.0 / wsum.clamp_min(1e-30), torch.ones_like(wsum))
+    for k in range(4):
+        acc = acc + (ws[k] * inv)[:, None] * flat[offs[k]] * keeps[k][:, None]
+    return acc.reshape(dirs.shape[:-1] + (C,))
+
+
+def env_light_directions(h: int, w: int, fx: float, fy: float, cx: float, cy: float, c2w: torch.Tensor,
+                         jitter: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """EnvLight.get_world_directions + the to_opengl change of axes (sgn_splatfacto.py:117-143) -> [h,w,3]."""
+    v, u = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    ju, jv = (0.5, 0.5) if jitter is None else (jitter[0], jitter[1])
+    d = torch.stack([(u - cx + ju) / fx, (v - cy + jv) / fy, torch.ones_like(u)], 0)
+    d = torch.nn.functional.normalize(d, dim=0)
+    wdir = (c2w[:3, :3].to(torch.float32) @ d.reshape(3, -1)).reshape(3, h, w).permute(1, 2, 0)
+    to_gl = torch.tensor([[1, 0, 0], [0, 0, 1], [0, -1, 0]], dtype=torch.float32)
+    return (wdir.reshape(-1, 3) @ to_gl.T).reshape(h, w, 3)

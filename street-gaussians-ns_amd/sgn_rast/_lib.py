@@ -41,6 +41,12 @@ SIGNATURES = {
                                    _vp, _vp, _vp, _vp]),
     "sgn_sh_fwd_fused": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sgn_sh_bwd_fused": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_cube_texture_fwd": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "sgn_cube_texture_bwd": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "sgn_sky_fwd": (_i, [_i, _i, _f, _f, _f, _f, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "sgn_sky_bwd": (_i, [_i, _i, _f, _f, _f, _f, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    "sgn_sky_blend_fwd": (_i, [_i, _i, _f, _f, _f, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_sky_blend_bwd": (_i, [_i, _i, _f, _f, _f, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_sh_bwd_multi": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "sgn_sh_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_sh_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -127,7 +133,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 
 TIMING_SLOTS = ["project_fwd", "project_bwd", "sh_fwd", "sh_bwd", "scan", "map_isect", "sort", "tile_bins",
-                "pack_records", "raster_fwd", "raster_bwd", "unpack_grads"]
+                "pack_records", "raster_fwd", "raster_bwd", "unpack_grads", "sky_fwd", "sky_bwd"]
 
 
 def timing_enable(on: bool) -> None:

@@ -175,17 +175,44 @@ def loss_weights(cam: Camera, seed: int = 7, device="cpu", dtype=torch.float32):
     return w_img.to(device=device, dtype=dtype), w_a.to(device=device, dtype=dtype)
 
 
+def composite_sky(out: SimpleNamespace, cam: Camera, sky_base: torch.Tensor, c2w: torch.Tensor,
+                  train: bool = True, fused: bool = False, sky_fn=None) -> None:
+    """use_sky_sphere branch of the reference (sgn_splatfacto.py:875-876, 969-972): look the sky colour up in the
+    cube map and blend it behind the splats, in place on ``out.rgb``.  ``fused`` does lookup + blend in one kernel
+    (``sky.sky_blend``); ``sky_fn(base, H, W, fx, fy, cx, cy, c2w, jitter)`` lets the parity tests substitute the
+    oracle's lookup."""
+    from . import sky as _sky
+    H, W = cam.height, cam.width
+    jitter = torch.rand(2, H, W, device=sky_base.device) if train else None
+    out.sky_jitter = jitter
+    if fused:
+        out.rgb, out.sky = _sky.sky_blend(sky_base, out.rgb, out.alpha, cam.fx, cam.fy, cam.cx, cam.cy, c2w, jitter)
+        return
+    fn = sky_fn or _sky.sky_color
+    sky_capture = fn(sky_base, H, W, cam.fx, cam.fy, cam.cx, cam.cy, c2w, jitter)      # :876
+    alpha = out.alpha[..., None]                                                       # :968
+    rgb = torch.clamp(out.rgb, max=1.0)                                                # :969
+    out.rgb = rgb * alpha + sky_capture * (1 - alpha)                                  # :972
+    out.sky = sky_capture
+
+
 def train_step(P: Dict[str, torch.Tensor], cam: Camera, w_img: torch.Tensor, w_a: torch.Tensor,
                sh_degree_to_use: int = 3, block_width: int = 16, with_depth: bool = False, ops=_hip_ops,
-               reducer=None, fused: bool = False, **fused_kw) -> SimpleNamespace:
+               reducer=None, fused: bool = False, sky: Optional[dict] = None, **fused_kw) -> SimpleNamespace:
     """One "train-step image": project fwd -> SH fwd -> rasterize(return_alpha) fwd -> scalar loss ->
-    full backward to means / log-scales / raw quats / opacity logits / SH coefficients."""
+    full backward to means / log-scales / raw quats / opacity logits / SH coefficients.  ``sky`` =
+    {"base": cube map leaf [6,R,R,3], "c2w": [3,4]} adds the reference's sky-sphere branch."""
     for p in P.values():
         p.grad = None
+    if sky is not None:
+        sky["base"].grad = None
     if fused:
         out = render_fused(P, cam, sh_degree_to_use, block_width, with_depth=with_depth, **fused_kw)
     else:
         out = render(P, cam, sh_degree_to_use, block_width, with_depth=with_depth, ops=ops)
+    if sky is not None:
+        composite_sky(out, cam, sky["base"], sky["c2w"], train=sky.get("train", True), fused=fused,
+                      sky_fn=sky.get("fn"))
     n_pix = cam.height * cam.width
     loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum()) / n_pix
     loss.backward()
