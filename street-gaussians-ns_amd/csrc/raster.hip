@@ -324,21 +324,29 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// DPP wave reduction (no LDS crossbar traffic): quad swaps, row_half_mirror, row_mirror leave every
-// lane with its 16-lane row total; row_bcast15 / row_bcast31 then fold the four rows, so the full
-// 64-lane sum is valid in lanes 48..63.
-template <int CTRL, int ROW_MASK>
+// Transposed wave reduction of the nine per-Gaussian partial gradients (REDUCE == 1).  gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows BETWEEN two registers, so one swap +
+// one add folds two values at once: after the 32- and 16-lane stages three registers hold, per 16-lane row,
+// t0 = [v0 v2 v1 v3], t1 = [v4 v6 v5 v7], t2 = [v8 0 0 0]; four DPP adds finish each row.  28 cross-lane
+// ops instead of 54 shuffles.
+template <int CTRL>
 __device__ __forceinline__ float dpp_get(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_sum_dpp_row3(float v) {
-    v += dpp_get<0xB1, 0xf>(v);   // quad_perm:[1,0,3,2]
-    v += dpp_get<0x4E, 0xf>(v);   // quad_perm:[2,3,0,1]
-    v += dpp_get<0x141, 0xf>(v);  // row_half_mirror
-    v += dpp_get<0x140, 0xf>(v);  // row_mirror
-    v += dpp_get<0x142, 0xa>(v);  // row_bcast:15 -> rows 1,3
-    v += dpp_get<0x143, 0xc>(v);  // row_bcast:31 -> rows 2,3
+__device__ __forceinline__ float row_sum_dpp(float v) {   // every lane ends with its 16-lane row total
+    v += dpp_get<0xB1>(v);    // quad_perm:[1,0,3,2]
+    v += dpp_get<0x4E>(v);    // quad_perm:[2,3,0,1]
+    v += dpp_get<0x141>(v);   // row_half_mirror
+    v += dpp_get<0x140>(v);   // row_mirror
     return v;
+}
+__device__ __forceinline__ float fold32(float a, float b) {   // lanes 0-31: a[l]+a[l+32]; lanes 32-63: same of b
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold16(float a, float b) {   // rows: [a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3]
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 __device__ __forceinline__ int wave_max_i(int v) {
@@ -470,31 +478,35 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
             any = any || valid;
         }
         if (__ballot(any) != 0ull) {  // wave-uniform
-            constexpr int L0 = (REDUCE == 1) ? 48 : 0;  // first lane holding the totals
-            if (dbg & 2) {
-                // ablation only: skip the wave reduction (results are wrong)
-            } else if constexpr (REDUCE == 1) {
-                g_x = wave_sum_dpp_row3(g_x); g_y = wave_sum_dpp_row3(g_y);
-                g_ca = wave_sum_dpp_row3(g_ca); g_cb = wave_sum_dpp_row3(g_cb); g_cc = wave_sum_dpp_row3(g_cc);
-                g_r = wave_sum_dpp_row3(g_r); g_g = wave_sum_dpp_row3(g_g); g_b = wave_sum_dpp_row3(g_b);
-                g_o = wave_sum_dpp_row3(g_o);
+            if constexpr (REDUCE == 1) {
+                float t0 = fold16(fold32(g_x, g_y), fold32(g_ca, g_cb));     // rows: x, ca, y, cb
+                float t1 = fold16(fold32(g_cc, g_r), fold32(g_g, g_b));      // rows: cc, g, r, b
+                float t2 = fold16(fold32(g_o, 0.f), 0.f);                    // rows: o, 0, 0, 0
+                t0 = row_sum_dpp(t0); t1 = row_sum_dpp(t1); t2 = row_sum_dpp(t2);
+                const int c = lane & 15, row = lane >> 4;
+                const int rowmap = ((row & 1) << 1) | (row >> 1);            // rows 0,1,2,3 hold values 0,2,1,3
+                const float mine = (c == 0) ? t0 : (c == 1) ? t1 : t2;
+                if ((c < 2 || lane == 2) && !(dbg & 1))
+                    unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + (c * 4 + rowmap), mine);
             } else {
-                g_x = wave_sum(g_x); g_y = wave_sum(g_y);
-                g_ca = wave_sum(g_ca); g_cb = wave_sum(g_cb); g_cc = wave_sum(g_cc);
-                g_r = wave_sum(g_r); g_g = wave_sum(g_g); g_b = wave_sum(g_b);
-                g_o = wave_sum(g_o);
+                if (!(dbg & 2)) {          // dbg bit1: ablation only, skip the wave reduction (results are wrong)
+                    g_x = wave_sum(g_x); g_y = wave_sum(g_y);
+                    g_ca = wave_sum(g_ca); g_cb = wave_sum(g_cb); g_cc = wave_sum(g_cc);
+                    g_r = wave_sum(g_r); g_g = wave_sum(g_g); g_b = wave_sum(g_b);
+                    g_o = wave_sum(g_o);
+                }
+                float mine = g_x;
+                mine = (lane == 1) ? g_y : mine;
+                mine = (lane == 2) ? g_ca : mine;
+                mine = (lane == 3) ? g_cb : mine;
+                mine = (lane == 4) ? g_cc : mine;
+                mine = (lane == 5) ? g_r : mine;
+                mine = (lane == 6) ? g_g : mine;
+                mine = (lane == 7) ? g_b : mine;
+                mine = (lane == 8) ? g_o : mine;
+                if (lane < 9 && !(dbg & 1))  // dbg bit0: ablation, no atomics
+                    unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + lane, mine);
             }
-            float mine = g_x;
-            mine = (lane == L0 + 1) ? g_y : mine;
-            mine = (lane == L0 + 2) ? g_ca : mine;
-            mine = (lane == L0 + 3) ? g_cb : mine;
-            mine = (lane == L0 + 4) ? g_cc : mine;
-            mine = (lane == L0 + 5) ? g_r : mine;
-            mine = (lane == L0 + 6) ? g_g : mine;
-            mine = (lane == L0 + 7) ? g_b : mine;
-            mine = (lane == L0 + 8) ? g_o : mine;
-            if (lane >= L0 && lane < L0 + 9 && !(dbg & 1))  // dbg bit0: ablation, no atomics
-                unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + (lane - L0), mine);
         }
     };
 
@@ -575,7 +587,7 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *_
 }
 
 int g_exact_exp = 0;
-int g_reduce_mode = 0;   // 0: ds_bpermute shuffles, 1: DPP
+int g_reduce_mode = 0;   // 0: butterfly shuffles, 1: transposed permlane-swap reduction
 int g_debug = 0;         // timing ablations only (bit0: no atomics, bit1: no wave reduction)
 int g_wpt = 0;           // waves per tile: 1, 4, or 0 = adaptive (split long lists, default)
 int g_adapt_fwd = 3072;  // forward: split tiles with >= this many list entries
