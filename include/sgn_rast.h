@@ -229,11 +229,12 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
 
 /* Sky cube-map lookup: replaces nvdiffrast `dr.texture(tex[None], dirs, filter_mode='linear',
  * boundary_mode='cube')` used by EnvLight (sgn_splatfacto.py:109-150).  tex [6,R,R,C] (faces +x,-x,+y,-y,+z,-z),
- * dirs [n,3] (need not be normalised), out [n,C].  The backward returns the texture gradient only (the directions
+ * dirs [h,w,3] (the [H,W] grid of uv; need not be normalised; use h = 1 for a flat list), out [h,w,C];
+ * resolution <= 16384.  The backward works in 16x16 tiles of that grid (neighbouring pixels share texels).  The backward returns the texture gradient only (the directions
  * come from the camera and carry no gradient in the reference) and zero-fills v_tex first. */
-int sgn_cube_texture_fwd(int64_t n, int resolution, int channels, const float *tex, const float *dirs,
+int sgn_cube_texture_fwd(int h, int w, int resolution, int channels, const float *tex, const float *dirs,
                          float *out, sgn_stream_t stream);
-int sgn_cube_texture_bwd(int64_t n, int resolution, int channels, const float *dirs, const float *v_out,
+int sgn_cube_texture_bwd(int h, int w, int resolution, int channels, const float *dirs, const float *v_out,
                          float *v_tex, sgn_stream_t stream);
 
 /* Fused EnvLight.forward (sgn_splatfacto.py:117-150): per-pixel camera ray -> world (c2w: DEVICE pointer to a

@@ -13,6 +13,9 @@
 //   * non-finite directions give 0.
 // One lane per direction; HBM/L2-bound gather of 4 x C floats.
 #include "sgn_common.h"
+#ifndef SKY_ABL
+#define SKY_ABL 0   // timing ablations (scripts only): 1 = plain LDS stores, 2 = plain global stores in the flush
+#endif
 
 namespace {
 
@@ -51,13 +54,14 @@ __device__ __forceinline__ void cube_dir(int face, float u, float v, float &x, f
 
 struct Taps {
     int off[4];     // texel offsets (face*R*R + iy*R + ix), -1 = dropped
+    int fxy[4];     // the same texel as face << 28 | iy << 14 | ix (R <= 16384), for the tile accumulator
     float w[4];
 };
 
 __device__ __forceinline__ Taps cube_taps(float dx, float dy, float dz, int R) {
     Taps T;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { T.off[k] = -1; T.w[k] = 0.f; }
+    for (int k = 0; k < 4; ++k) { T.off[k] = -1; T.fxy[k] = -1; T.w[k] = 0.f; }
     float u, v;
     const int face = cube_face_uv(dx, dy, dz, u, v);
     if (face < 0) return T;
@@ -81,6 +85,7 @@ __device__ __forceinline__ Taps cube_taps(float dx, float dy, float dz, int R) {
             iy = min(max((int)floorf(v2 * (float)R), 0), R - 1);
         }
         T.off[k] = (f * R + iy) * R + ix;
+        T.fxy[k] = (f << 28) | (iy << 14) | ix;
         T.w[k] = w;
         wsum += w;
     }
@@ -91,6 +96,101 @@ __device__ __forceinline__ Taps cube_taps(float dx, float dy, float dz, int R) {
     }
     return T;
 }
+
+// Texture-gradient scatter for a 16x16 pixel tile.  At the reference's settings (1920x1280 view, 1024^2 faces) a
+// texel is ~4 pixels wide, so the 256 pixels of a tile hit the same few dozen texels ~64 times each: summing
+// them in an LDS window first (ds_add_f32) and flushing the window's non-zero cells once cuts the global atomics
+// by that factor (1.32 ms -> see DESIGN.md).  Taps outside the window (face seams, minified lookups) go to
+// global memory directly.
+constexpr int SKY_TW = 24, SKY_TH = 24, SKY_CMAX = 4;
+
+struct TileAcc {
+    float *acc;            // LDS [SKY_TH*SKY_TW*C]
+    int *hdr;              // LDS: [0] face, [1] ix_min, [2] iy_min
+    int R, C;
+    float *v_tex;
+
+    // The window is centred on the first texel of the tile's corner pixel (always inside the image): no
+    // block-wide min/max reduction, one barrier.  +-12 texels cover a 16-pixel tile up to ~0.75 texel/pixel.
+    __device__ __forceinline__ void begin(const Taps &T) {
+        const int tid = threadIdx.x;
+        if (tid == 0) {
+            int t = -1;
+#pragma unroll
+            for (int k = 3; k >= 0; --k)
+                if (T.fxy[k] >= 0) t = T.fxy[k];
+            hdr[0] = t < 0 ? -1 : (t >> 28);
+            hdr[1] = (t & 0x3fff) - SKY_TW / 2;
+            hdr[2] = ((t >> 14) & 0x3fff) - SKY_TH / 2;
+        }
+        const int Cl = (C <= SKY_CMAX) ? C : 0;          // wider textures bypass the LDS window
+        for (int e = tid; e < SKY_TH * SKY_TW * Cl; e += 256) acc[e] = 0.f;
+        __syncthreads();
+    }
+    __device__ __forceinline__ void add(const Taps &T, int k, int c, float v) {
+        const int dx = (T.fxy[k] & 0x3fff) - hdr[1], dy = ((T.fxy[k] >> 14) & 0x3fff) - hdr[2];
+        if (C <= SKY_CMAX && (T.fxy[k] >> 28) == hdr[0] && (unsigned)dx < (unsigned)SKY_TW &&
+            (unsigned)dy < (unsigned)SKY_TH)
+            // explicit LDS address space: keeps the compiler from merging the two arms into one flat atomic
+#if SKY_ABL != 1
+            __hip_atomic_fetch_add((__attribute__((address_space(3))) float *)&acc[(dy * SKY_TW + dx) * C + c], v,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+            acc[(dy * SKY_TW + dx) * C + c] = v;
+#endif
+        else
+            __hip_atomic_fetch_add((__attribute__((address_space(1))) float *)(v_tex + (size_t)T.off[k] * C + c), v,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // Same as add(), after summing runs of neighbouring lanes that hit the same texel: the 16 lanes of a DPP row
+    // are one pixel row of the tile and the pixel -> texel map is monotone along it, so equal keys form a few runs;
+    // a 4-step segmented scan (row_shr 1,2,4,8, head flags) leaves each run's total in its last lane.  LDS float atomics
+    // serialise on equal addresses (~4 cycles per lane measured), so fewer lanes per atomic is the whole game.
+    // Must be called by all 64 lanes (dropped taps carry key -1 and add nothing).
+    template <int SH>
+    static __device__ __forceinline__ int row_shr_i(int v, int fill) {
+        return __builtin_amdgcn_update_dpp(fill, v, 0x110 + SH, 0xf, 0xf, false);
+    }
+    template <int SH>
+    static __device__ __forceinline__ void seg_step(int &head, float &v) {   // head: a run starts in (lane-SH, lane]
+        const int ph = row_shr_i<SH>(head, 1);
+        const float pv = __int_as_float(row_shr_i<SH>(__float_as_int(v), 0));
+        v += head ? 0.f : pv;
+        head |= ph;
+    }
+    __device__ __forceinline__ void add_seg(const Taps &T, int k, int c, float v) {
+        const int key = T.fxy[k];
+        int head = row_shr_i<1>(key, -2) != key;            // runs = maximal stretches of equal consecutive keys
+        seg_step<1>(head, v); seg_step<2>(head, v); seg_step<4>(head, v); seg_step<8>(head, v);
+        const int nk = __builtin_amdgcn_update_dpp(-2, key, 0x101, 0xf, 0xf, false);   // row_shl:1 = next lane's key
+        if (key >= 0 && nk != key && v != 0.f) add(T, k, c, v);
+    }
+    __device__ __forceinline__ void flush() {
+        __syncthreads();
+        if (hdr[0] < 0 || C > SKY_CMAX) return;
+        const int face = hdr[0], ix0 = hdr[1], iy0 = hdr[2];
+        for (int e = threadIdx.x; e < SKY_TH * SKY_TW * C; e += 256) {
+            const float v = acc[e];
+            if (v == 0.f) continue;
+            const int cell = e / C, c = e - cell * C;
+            const int dy = cell / SKY_TW, dx = cell - dy * SKY_TW;
+#if SKY_ABL != 2
+            atomicAdd(v_tex + ((size_t)(face * R + iy0 + dy) * R + ix0 + dx) * C + c, v);
+#else
+            v_tex[((size_t)(face * R + iy0 + dy) * R + ix0 + dx) * C + c] = v;
+#endif
+        }
+    }
+};
+
+// pixel owned by this thread: 16x16 tiles over an h x w grid; returns -1 outside
+__device__ __forceinline__ int64_t tile_pixel(int h, int w) {
+    const int tiles_x = (w + 15) >> 4;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int px = tx * 16 + (threadIdx.x & 15), py = ty * 16 + (threadIdx.x >> 4);
+    return (px < w && py < h) ? (int64_t)py * w + px : -1;
+}
+__host__ inline unsigned tile_blocks(int h, int w) { return (unsigned)(((w + 15) >> 4) * ((h + 15) >> 4)); }
 
 __global__ __launch_bounds__(256) void cube_fwd_kernel(int64_t n, int R, int C, const float *__restrict__ tex,
                                                        const float *__restrict__ dirs, float *__restrict__ out) {
@@ -106,17 +206,21 @@ __global__ __launch_bounds__(256) void cube_fwd_kernel(int64_t n, int R, int C, 
     }
 }
 
-__global__ __launch_bounds__(256) void cube_bwd_kernel(int64_t n, int R, int C, const float *__restrict__ dirs,
+__global__ __launch_bounds__(256) void cube_bwd_kernel(int h, int w, int R, int C, const float *__restrict__ dirs,
                                                        const float *__restrict__ v_out, float *__restrict__ v_tex) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const Taps T = cube_taps(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], R);
+    __shared__ float acc[SKY_TH * SKY_TW * SKY_CMAX];
+    __shared__ int hdr[3];
+    const int64_t i = tile_pixel(h, w);
+    Taps T = cube_taps(0.f, 0.f, 0.f, R);      // all taps dropped
+    if (i >= 0) T = cube_taps(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], R);
+    TileAcc A{acc, hdr, R, C, v_tex};
+    A.begin(T);
     for (int c = 0; c < C; ++c) {
-        const float g = v_out[i * C + c];
+        const float g = (i >= 0) ? v_out[i * C + c] : 0.f;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (T.off[k] >= 0) atomicAdd(v_tex + (size_t)T.off[k] * C + c, T.w[k] * g);
+        for (int k = 0; k < 4; ++k) A.add_seg(T, k, c, T.w[k] * g);
     }
+    A.flush();
 }
 
 // Fused EnvLight: pixel -> camera ray -> world -> GL axes -> cube lookup, no [H,W,3] direction tensor in HBM.
@@ -164,19 +268,23 @@ __global__ __launch_bounds__(256) void sky_fwd_kernel(SkyCam cam, int R, int C, 
 
 __global__ __launch_bounds__(256) void sky_bwd_kernel(SkyCam cam, int R, int C, const float *__restrict__ v_out,
                                                       float *__restrict__ v_tex) {
-    const int64_t n = (int64_t)cam.h * cam.w;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float lx, ly, lz;
-    sky_dir(cam, i, lx, ly, lz);
-    const Taps T = cube_taps(lx, ly, lz, R);
-    for (int c = 0; c < C; ++c) {
-        const float g = v_out[i * C + c];
-        if (g == 0.f) continue;                       // pixels fully covered by Gaussians contribute nothing
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (T.off[k] >= 0) atomicAdd(v_tex + (size_t)T.off[k] * C + c, T.w[k] * g);
+    __shared__ float acc[SKY_TH * SKY_TW * SKY_CMAX];
+    __shared__ int hdr[3];
+    const int64_t i = tile_pixel(cam.h, cam.w);
+    Taps T = cube_taps(0.f, 0.f, 0.f, R);
+    if (i >= 0) {
+        float lx, ly, lz;
+        sky_dir(cam, i, lx, ly, lz);
+        T = cube_taps(lx, ly, lz, R);
     }
+    TileAcc A{acc, hdr, R, C, v_tex};
+    A.begin(T);
+    for (int c = 0; c < C; ++c) {
+        const float g = (i >= 0) ? v_out[i * C + c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) A.add_seg(T, k, c, T.w[k] * g);
+    }
+    A.flush();
 }
 
 // Fused sky + compositing (sgn_splatfacto.py:969-972): out = min(rgb,1)*alpha + sky*(1-alpha), C == 3.
@@ -208,13 +316,18 @@ __global__ __launch_bounds__(256) void sky_blend_bwd_kernel(SkyCam cam, int R, c
                                                             const float *__restrict__ v_out,
                                                             float *__restrict__ v_rgb, float *__restrict__ v_alpha,
                                                             float *__restrict__ v_tex) {
-    const int64_t n = (int64_t)cam.h * cam.w;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float lx, ly, lz;
-    sky_dir(cam, i, lx, ly, lz);
-    const Taps T = cube_taps(lx, ly, lz, R);
-    const float a = alpha[i];
+    __shared__ float acc[SKY_TH * SKY_TW * SKY_CMAX];
+    __shared__ int hdr[3];
+    const int64_t i = tile_pixel(cam.h, cam.w);
+    Taps T = cube_taps(0.f, 0.f, 0.f, R);
+    if (i >= 0) {
+        float lx, ly, lz;
+        sky_dir(cam, i, lx, ly, lz);
+        T = cube_taps(lx, ly, lz, R);
+    }
+    TileAcc A{acc, hdr, R, 3, v_tex};
+    A.begin(T);
+    const float a = (i >= 0) ? alpha[i] : 0.f;
     float va = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -222,17 +335,15 @@ __global__ __launch_bounds__(256) void sky_blend_bwd_kernel(SkyCam cam, int R, c
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (T.off[k] >= 0) sky = fmaf(T.w[k], tex[(size_t)T.off[k] * 3 + c], sky);
-        const float g = v_out[i * 3 + c], r = rgb[i * 3 + c];
-        v_rgb[i * 3 + c] = (r <= 1.f) ? g * a : 0.f;          // torch.clamp(max=1) passes the gradient at r == 1
+        const float g = (i >= 0) ? v_out[i * 3 + c] : 0.f, r = (i >= 0) ? rgb[i * 3 + c] : 0.f;
+        if (i >= 0) v_rgb[i * 3 + c] = (r <= 1.f) ? g * a : 0.f;   // torch.clamp(max=1) passes the gradient at r == 1
         va = fmaf(g, fminf(r, 1.f) - sky, va);
         const float gs = g * (1.f - a);
-        if (gs != 0.f) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (T.off[k] >= 0) atomicAdd(v_tex + (size_t)T.off[k] * 3 + c, T.w[k] * gs);
-        }
+        for (int k = 0; k < 4; ++k) A.add_seg(T, k, c, T.w[k] * gs);
     }
-    v_alpha[i] = va;
+    if (i >= 0) v_alpha[i] = va;
+    A.flush();
 }
 
 }  // namespace
@@ -240,7 +351,7 @@ __global__ __launch_bounds__(256) void sky_blend_bwd_kernel(SkyCam cam, int R, c
 SGN_EXPORT int sgn_sky_blend_fwd(int h, int w, float fx, float fy, float cx, float cy, const float *c2w, int c2w_ld,
                                  const float *jitter, int resolution, const float *tex, const float *rgb,
                                  const float *alpha, float *out, float *sky_out, sgn_stream_t stream) {
-    SGN_ARG_CHECK(h >= 0 && w >= 0 && resolution > 0 && c2w_ld >= 3, -1);
+    SGN_ARG_CHECK(h >= 0 && w >= 0 && resolution > 0 && resolution <= 16384 && c2w_ld >= 3, -1);
     if ((int64_t)h * w == 0) return 0;
     SGN_ARG_CHECK(c2w && tex && rgb && alpha && out, -2);
     SkyCam cam{h, w, fx, fy, cx, cy, c2w, c2w_ld, jitter};
@@ -256,7 +367,7 @@ SGN_EXPORT int sgn_sky_blend_bwd(int h, int w, float fx, float fy, float cx, flo
                                  const float *jitter, int resolution, const float *tex, const float *rgb,
                                  const float *alpha, const float *v_out, float *v_rgb, float *v_alpha, float *v_tex,
                                  sgn_stream_t stream) {
-    SGN_ARG_CHECK(h >= 0 && w >= 0 && resolution > 0 && c2w_ld >= 3, -1);
+    SGN_ARG_CHECK(h >= 0 && w >= 0 && resolution > 0 && resolution <= 16384 && c2w_ld >= 3, -1);
     SGN_ARG_CHECK(v_tex != nullptr, -2);
     hipStream_t s = (hipStream_t)stream;
     SGN_HIP_CHECK(hipMemsetAsync(v_tex, 0, (size_t)6 * resolution * resolution * 3 * sizeof(float), s));
@@ -264,8 +375,8 @@ SGN_EXPORT int sgn_sky_blend_bwd(int h, int w, float fx, float fy, float cx, flo
     SGN_ARG_CHECK(c2w && tex && rgb && alpha && v_out && v_rgb && v_alpha, -3);
     SkyCam cam{h, w, fx, fy, cx, cy, c2w, c2w_ld, jitter};
     sgn_timing_begin(SGN_T_SKY_BWD, (void *)s);
-    hipLaunchKernelGGL(sky_blend_bwd_kernel, dim3(sgn_cdiv((int64_t)h * w, 256)), dim3(256), 0, s, cam, resolution,
-                       tex, rgb, alpha, v_out, v_rgb, v_alpha, v_tex);
+    hipLaunchKernelGGL(sky_blend_bwd_kernel, dim3(tile_blocks(h, w)), dim3(256), 0, s, cam, resolution, tex, rgb,
+                       alpha, v_out, v_rgb, v_alpha, v_tex);
     sgn_timing_end(SGN_T_SKY_BWD, (void *)s);
     SGN_LAUNCH_CHECK();
     return 0;
@@ -274,7 +385,7 @@ SGN_EXPORT int sgn_sky_blend_bwd(int h, int w, float fx, float fy, float cx, flo
 SGN_EXPORT int sgn_sky_fwd(int h, int w, float fx, float fy, float cx, float cy, const float *c2w, int c2w_ld,
                            const float *jitter, int resolution, int channels, const float *tex, float *out,
                            sgn_stream_t stream) {
-    SGN_ARG_CHECK(h >= 0 && w >= 0 && resolution > 0 && channels > 0 && c2w_ld >= 3, -1);
+    SGN_ARG_CHECK(h >= 0 && w >= 0 && resolution > 0 && resolution <= 16384 && channels > 0 && c2w_ld >= 3, -1);
     if ((int64_t)h * w == 0) return 0;
     SGN_ARG_CHECK(c2w && tex && out, -2);
     SkyCam cam{h, w, fx, fy, cx, cy, c2w, c2w_ld, jitter};
@@ -289,7 +400,7 @@ SGN_EXPORT int sgn_sky_fwd(int h, int w, float fx, float fy, float cx, float cy,
 SGN_EXPORT int sgn_sky_bwd(int h, int w, float fx, float fy, float cx, float cy, const float *c2w, int c2w_ld,
                            const float *jitter, int resolution, int channels, const float *v_out, float *v_tex,
                            sgn_stream_t stream) {
-    SGN_ARG_CHECK(h >= 0 && w >= 0 && resolution > 0 && channels > 0 && c2w_ld >= 3, -1);
+    SGN_ARG_CHECK(h >= 0 && w >= 0 && resolution > 0 && resolution <= 16384 && channels > 0 && c2w_ld >= 3, -1);
     SGN_ARG_CHECK(v_tex != nullptr, -2);
     hipStream_t s = (hipStream_t)stream;
     SGN_HIP_CHECK(hipMemsetAsync(v_tex, 0, (size_t)6 * resolution * resolution * channels * sizeof(float), s));
@@ -297,16 +408,17 @@ SGN_EXPORT int sgn_sky_bwd(int h, int w, float fx, float fy, float cx, float cy,
     SGN_ARG_CHECK(c2w && v_out, -3);
     SkyCam cam{h, w, fx, fy, cx, cy, c2w, c2w_ld, jitter};
     sgn_timing_begin(SGN_T_SKY_BWD, (void *)s);
-    hipLaunchKernelGGL(sky_bwd_kernel, dim3(sgn_cdiv((int64_t)h * w, 256)), dim3(256), 0, s, cam, resolution,
-                       channels, v_out, v_tex);
+    hipLaunchKernelGGL(sky_bwd_kernel, dim3(tile_blocks(h, w)), dim3(256), 0, s, cam, resolution, channels, v_out,
+                       v_tex);
     sgn_timing_end(SGN_T_SKY_BWD, (void *)s);
     SGN_LAUNCH_CHECK();
     return 0;
 }
 
-SGN_EXPORT int sgn_cube_texture_fwd(int64_t n, int resolution, int channels, const float *tex,
+SGN_EXPORT int sgn_cube_texture_fwd(int h, int w, int resolution, int channels, const float *tex,
                                     const float *dirs, float *out, sgn_stream_t stream) {
-    SGN_ARG_CHECK(n >= 0 && resolution > 0 && channels > 0, -1);
+    SGN_ARG_CHECK(h >= 0 && w >= 0 && resolution > 0 && resolution <= 16384 && channels > 0, -1);
+    const int64_t n = (int64_t)h * w;
     if (n == 0) return 0;
     SGN_ARG_CHECK(tex && dirs && out, -2);
     sgn_timing_begin(SGN_T_SKY_FWD, (void *)stream);
@@ -317,17 +429,17 @@ SGN_EXPORT int sgn_cube_texture_fwd(int64_t n, int resolution, int channels, con
     return 0;
 }
 
-SGN_EXPORT int sgn_cube_texture_bwd(int64_t n, int resolution, int channels, const float *dirs,
+SGN_EXPORT int sgn_cube_texture_bwd(int h, int w, int resolution, int channels, const float *dirs,
                                     const float *v_out, float *v_tex, sgn_stream_t stream) {
-    SGN_ARG_CHECK(n >= 0 && resolution > 0 && channels > 0, -1);
+    SGN_ARG_CHECK(h >= 0 && w >= 0 && resolution > 0 && resolution <= 16384 && channels > 0, -1);
     SGN_ARG_CHECK(v_tex != nullptr, -2);
     hipStream_t s = (hipStream_t)stream;
     SGN_HIP_CHECK(hipMemsetAsync(v_tex, 0, (size_t)6 * resolution * resolution * channels * sizeof(float), s));
-    if (n == 0) return 0;
+    if ((int64_t)h * w == 0) return 0;
     SGN_ARG_CHECK(dirs && v_out, -3);
     sgn_timing_begin(SGN_T_SKY_BWD, (void *)s);
-    hipLaunchKernelGGL(cube_bwd_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, resolution, channels, dirs, v_out,
-                       v_tex);
+    hipLaunchKernelGGL(cube_bwd_kernel, dim3(tile_blocks(h, w)), dim3(256), 0, s, h, w, resolution, channels, dirs,
+                       v_out, v_tex);
     sgn_timing_end(SGN_T_SKY_BWD, (void *)s);
     SGN_LAUNCH_CHECK();
     return 0;

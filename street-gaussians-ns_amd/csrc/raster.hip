@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *_
 }
 
 int g_exact_exp = 0;
-int g_reduce_mode = 0;   // 0: butterfly shuffles, 1: transposed permlane-swap reduction
+int g_reduce_mode = 1;   // 0: butterfly shuffles, 1: transposed permlane-swap reduction (default)
 int g_debug = 0;         // timing ablations only (bit0: no atomics, bit1: no wave reduction)
 int g_wpt = 0;           // waves per tile: 1, 4, or 0 = adaptive (split long lists, default)
 int g_adapt_fwd = 3072;  // forward: split tiles with >= this many list entries

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsgnrast.so")
+LIB_PATH = os.environ.get("SGN_RAST_LIB") or os.path.join(_HERE, "libsgnrast.so")  # override: debugging builds
 
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -41,8 +41,8 @@ SIGNATURES = {
                                    _vp, _vp, _vp, _vp]),
     "sgn_sh_fwd_fused": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sgn_sh_bwd_fused": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
-    "sgn_cube_texture_fwd": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp]),
-    "sgn_cube_texture_bwd": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp]),
+    "sgn_cube_texture_fwd": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sgn_cube_texture_bwd": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_sky_fwd": (_i, [_i, _i, _f, _f, _f, _f, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "sgn_sky_bwd": (_i, [_i, _i, _f, _f, _f, _f, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),
     "sgn_sky_blend_fwd": (_i, [_i, _i, _f, _f, _f, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -68,7 +68,7 @@ SIGNATURES = {
 }
 
 _lib = None
-DEFAULT_REDUCE_MODE = int(os.environ.get("SGN_REDUCE_MODE", "0"))
+DEFAULT_REDUCE_MODE = int(os.environ.get("SGN_REDUCE_MODE", "1"))
 DEFAULT_GATHER_MODE = int(os.environ.get("SGN_RASTER_GATHER", "1"))
 
 

@@ -26,10 +26,13 @@ class _CubeTexture(torch.autograd.Function):
         tex_c = tex.contiguous().float()
         d = dirs.reshape(-1, 3).contiguous().float()
         n, R, C = d.shape[0], tex.shape[1], tex.shape[3]
+        # the [H,W] grid of uv: the backward tiles it 16x16 so neighbouring pixels share texels in LDS
+        h, w = (dirs.shape[-3], dirs.shape[-2]) if dirs.dim() >= 3 and dirs.shape[-3] * dirs.shape[-2] == n else (1, n)
         out = torch.empty(n, C, dtype=torch.float32, device=tex.device)
-        L.check(L.load().sgn_cube_texture_fwd(n, R, C, L.ptr(tex_c), L.ptr(d), L.ptr(out), L.stream_ptr()),
+        L.check(L.load().sgn_cube_texture_fwd(h, w, R, C, L.ptr(tex_c), L.ptr(d), L.ptr(out), L.stream_ptr()),
                 "sgn_cube_texture_fwd")
         ctx.save_for_backward(d)
+        ctx.grid = (h, w)
         ctx.shape = tuple(tex.shape)
         return out.reshape(dirs.shape[:-1] + (C,))
 
@@ -39,8 +42,8 @@ class _CubeTexture(torch.autograd.Function):
         _, R, _, C = ctx.shape
         v = v_out.reshape(-1, C).contiguous().float()
         v_tex = torch.empty(ctx.shape, dtype=torch.float32, device=v.device)
-        L.check(L.load().sgn_cube_texture_bwd(d.shape[0], R, C, L.ptr(d), L.ptr(v), L.ptr(v_tex), L.stream_ptr()),
-                "sgn_cube_texture_bwd")
+        L.check(L.load().sgn_cube_texture_bwd(ctx.grid[0], ctx.grid[1], R, C, L.ptr(d), L.ptr(v), L.ptr(v_tex),
+                                              L.stream_ptr()), "sgn_cube_texture_bwd")
         return v_tex, None
 
 
