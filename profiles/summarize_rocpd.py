@@ -24,6 +24,10 @@ def kernels(path):
     print("|---|---:|---:|---:|---:|")
     for name, calls, total, avg, pct in rows:
         print(f"| `{short(name)}` | {calls} | {total:.1f} | {avg:.2f} | {pct:.2f} |")
+    tot = sum(r[2] for r in rows)
+    ours = sum(r[2] for r in rows if not r[0].startswith(("at::", "void at::", "__amd", "void (anonymous namespace)::elementwise"))
+               and "at::native" not in r[0])
+    print(f"\nall kernels: {tot:.1f} us; library (non-torch) kernels: {ours:.1f} us; torch/runtime kernels: {tot - ours:.1f} us")
 
 
 def pmc(path, flt=""):
