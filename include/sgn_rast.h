@@ -188,13 +188,17 @@ size_t sgn_bin_prepare_workspace_bytes(int n);
  * if some pixel centre of the tile can reach alpha >= 1/255 (the convex set sigma <= ln(255*opacity) + margin meets
  * the tile's pixel-centre rectangle; evaluated per tile row as one interval).  Dropped pairs contribute nothing in forward or backward, so rasterize results
  * are unchanged; the list is then a sub-sequence of upstream's.  With cull == 0 the list equals upstream's. */
+/* bin_records [n, SGN_BIN_RECORD_FLOATS] (32 B per Gaussian: centre, conic, alpha-cutoff threshold, radius, kept-tile
+ * count) is written by sgn_bin_prepare in id order and read back by sgn_bin_intersect: the rank-order emission
+ * gathers one sector per Gaussian instead of five arrays. */
+#define SGN_BIN_RECORD_FLOATS 8
 int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii, const float *conics,
                     const float *opacities, int opacity_is_logit, int cull, int tiles_x, int tiles_y,
                     int block_width, int32_t *cum_by_rank /*[n] inclusive scan of kept-tile counts, rank order*/,
-                    int32_t *gid_by_rank /*[n]*/, void *ws, size_t ws_bytes, sgn_stream_t stream);
+                    int32_t *gid_by_rank /*[n]*/, float *bin_records /*[n,8] out*/, void *ws, size_t ws_bytes,
+                    sgn_stream_t stream);
 size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect);
-int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const int32_t *radii, const float *conics,
-                      const float *opacities, int opacity_is_logit, int cull, const int32_t *cum_by_rank,
+int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                       const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
                       int32_t *gaussian_ids_sorted /*[n_isect]*/, int32_t *tile_bins /*[tiles,2]*/, void *ws,
                       size_t ws_bytes, sgn_stream_t stream);

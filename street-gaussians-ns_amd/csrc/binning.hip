@@ -163,16 +163,6 @@ __global__ __launch_bounds__(256) void tile_bins_kernel(int64_t n_isect, const i
 // (14 bits at 1920x1280/16: two 8-bit passes over (u32 tile, i32 gaussian id) pairs, 40 B/intersection
 // instead of six passes x 32 B on 64-bit (tile|depth, id) pairs).  gaussian_ids_sorted / tile_bins come
 // out bit-identical to the upstream-shaped path (tests/test_gpu_parity.py, tests/test_gpu_e2e.py).
-__global__ __launch_bounds__(256) void depth_keys_kernel(int n, const float *__restrict__ depths,
-                                                         const int32_t *__restrict__ radii,
-                                                         uint32_t *__restrict__ dkeys,
-                                                         int32_t *__restrict__ dvals) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    dkeys[i] = radii[i] > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;  // culled splats sort last
-    dvals[i] = i;
-}
-
 // Exact tile culling (fused path only).  Upstream bins a Gaussian into every tile of the square that bounds
 // its 3-sigma CIRCLE; a tile can only receive colour from it if some pixel centre has
 // alpha = min(0.999, o * exp(-sigma)) >= 1/255, i.e. sigma <= s := ln(255 o).  The ellipse {sigma <= s} is
@@ -200,17 +190,31 @@ struct Ellipse {       // per-Gaussian constants of the row-interval test
     int valid;         // 0: nothing can be hit; 1: use the test; 2: degenerate conic -> keep everything
 };
 
-__device__ __forceinline__ Ellipse make_ellipse(const Cull &cu, int gid, float gx, float gy) {
-    Ellipse E;
-    E.gx = gx; E.gy = gy;
-    const float a = cu.conics[3 * gid], b = cu.conics[3 * gid + 1], c = cu.conics[3 * gid + 2];
+// 32-byte per-Gaussian bin record, written in id order by bin_count_kernel and gathered ONCE (one sector) by the
+// rank-order emission instead of five separate random gathers (xys, radii, conics x3, opacity).
+struct BinRec {
+    float gx, gy;      // projected centre
+    float a, b, c;     // conic
+    float s;           // ln(255 o) + margin; < 0: never visible; +inf: culling off (keep every bbox tile)
+    int rad;           // radius in pixels (0: culled by projection)
+    int cnt;           // kept tiles
+};
+static_assert(sizeof(BinRec) == SGN_BIN_RECORD_FLOATS * 4, "bin record size");
+
+__device__ __forceinline__ float cull_threshold(const Cull &cu, int gid) {
+    if (!cu.enable) return __builtin_inff();
     float o = cu.opac[gid];
     if (cu.opac_is_logit) o = 1.f / (1.f + expf(-o));
     // margin 0.01 in sigma (1 % in alpha) >> fp32 error of any evaluation order of the quadratic form
-    const float s = (o * 255.f > 0.f) ? logf(255.f * o) + 0.01f : -1.f;
+    return (o * 255.f > 0.f) ? logf(255.f * o) + 0.01f : -1.f;
+}
+
+__device__ __forceinline__ Ellipse make_ellipse(float gx, float gy, float a, float b, float c, float s) {
+    Ellipse E;
+    E.gx = gx; E.gy = gy;
     const float D = a * c - b * b;
     E.a = a; E.b = b; E.inv_a = 1.f / a; E.two_as = 2.f * a * s; E.D = D;
-    E.valid = !(s >= 0.f) ? 0 : ((a > 0.f && c > 0.f && D > 0.f) ? 1 : 2);
+    E.valid = !(s >= 0.f) ? 0 : ((s < 3.0e38f && a > 0.f && c > 0.f && D > 0.f) ? 1 : 2);
     E.y_ext = sqrtf(fmaxf(E.two_as / D, 0.f));
     const float x_max = sqrtf(fmaxf(2.f * c * s / D, 0.f));
     E.y_at_xmax = -(b / c) * x_max;
@@ -238,36 +242,16 @@ __device__ __forceinline__ void row_interval(const Ellipse &E, int ty, int block
     hi = min(hi, t_hi);
 }
 
-// lane = depth rank r.  EMIT = false: counts[r] = number of kept tiles of Gaussian gid_by_rank[r];
-// EMIT = true: writes its (tile, gaussian id) pairs, row-major over the bbox, starting at cum_r[r-1].
 constexpr int ROWS_BIG = 6;   // bboxes taller than this are handled by the whole wave (lane <-> tile row)
 
+// Tiles of one Gaussian per lane (row-major over the bbox, one kept interval per tile row).  EMIT = false: returns
+// the number of kept tiles; EMIT = true: also writes the (tile, gaussian id) pairs starting at `cur`.
+// Must be called by all 64 lanes of the wave (tall bboxes are shared out over the lanes).
 template <bool EMIT>
-__global__ __launch_bounds__(256) void rank_tiles_kernel(int n, const float *__restrict__ xys,
-                                                         const int32_t *__restrict__ radii,
-                                                         const int32_t *__restrict__ cum_r,
-                                                         const int32_t *__restrict__ gid_by_rank, Cull cull,
-                                                         int tiles_x, int tiles_y, int block,
-                                                         int32_t *__restrict__ counts, uint32_t *__restrict__ tkeys,
-                                                         int32_t *__restrict__ tvals) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ int tiles_of(bool live, const Ellipse &E, int mnx, int mny, int mxx, int mxy, int gid,
+                                        int cur, int tiles_x, int block, uint32_t *__restrict__ tkeys,
+                                        int32_t *__restrict__ tvals) {
     const int lane = threadIdx.x & 63;
-    int mnx = 0, mny = 0, mxx = 0, mxy = 0, cur = 0, gid = 0;
-    Ellipse E;
-    E.valid = 2; E.gx = 0.f; E.gy = 0.f; E.a = 1.f; E.b = 0.f; E.inv_a = 1.f; E.two_as = 0.f; E.D = 1.f;
-    E.y_ext = 0.f; E.y_at_xmax = 0.f;
-    bool live = false;
-    if (r < n) {
-        gid = gid_by_rank[r];
-        const int rad = radii[gid];
-        if (rad > 0) {
-            live = true;
-            const float gx = xys[2 * gid], gy = xys[2 * gid + 1];
-            sgn_tile_bbox(gx, gy, (float)rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
-            if (EMIT) cur = (r == 0) ? 0 : cum_r[r - 1];
-            if (cull.enable) E = make_ellipse(cull, gid, gx, gy);
-        }
-    }
     const int w = mxx - mnx, h = (live && w > 0) ? mxy - mny : 0;
     int cnt = 0;
     if (h > 0 && h <= ROWS_BIG) {
@@ -322,7 +306,72 @@ __global__ __launch_bounds__(256) void rank_tiles_kernel(int n, const float *__r
         }
         if (lane == src) cnt = total;
     }
-    if (!EMIT && r < n) counts[r] = cnt;
+    return cnt;
+}
+
+// lane = Gaussian id (coalesced reads): depth sort key, bin record and its kept-tile count in one pass
+__global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__restrict__ xys,
+                                                        const float *__restrict__ depths,
+                                                        const int32_t *__restrict__ radii, Cull cull, int tiles_x,
+                                                        int tiles_y, int block, uint32_t *__restrict__ dkeys,
+                                                        int32_t *__restrict__ dvals, BinRec *__restrict__ recs) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int mnx = 0, mny = 0, mxx = 0, mxy = 0;
+    BinRec R;
+    R.gx = 0.f; R.gy = 0.f; R.a = 1.f; R.b = 0.f; R.c = 1.f; R.s = -1.f; R.rad = 0; R.cnt = 0;
+    bool live = false;
+    if (i < n) {
+        R.rad = radii[i];
+        if (R.rad > 0) {
+            live = true;
+            R.gx = xys[2 * i]; R.gy = xys[2 * i + 1];
+            sgn_tile_bbox(R.gx, R.gy, (float)R.rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
+            R.s = cull_threshold(cull, i);
+            if (cull.enable) { R.a = cull.conics[3 * i]; R.b = cull.conics[3 * i + 1]; R.c = cull.conics[3 * i + 2]; }
+        }
+    }
+    const Ellipse E = make_ellipse(R.gx, R.gy, R.a, R.b, R.c, R.s);
+    R.cnt = tiles_of<false>(live, E, mnx, mny, mxx, mxy, i, 0, tiles_x, block, nullptr, nullptr);
+    if (i < n) {
+        dkeys[i] = R.rad > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;  // culled splats sort last
+        dvals[i] = i;
+        float4 *o = reinterpret_cast<float4 *>(recs + i);
+        o[0] = make_float4(R.gx, R.gy, R.a, R.b);
+        o[1] = make_float4(R.c, R.s, __int_as_float(R.rad), __int_as_float(R.cnt));
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_counts_kernel(int n, const int32_t *__restrict__ gid_by_rank,
+                                                            const BinRec *__restrict__ recs,
+                                                            int32_t *__restrict__ cnt_r) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r < n) cnt_r[r] = recs[gid_by_rank[r]].cnt;
+}
+
+// lane = depth rank r: writes the (tile, gaussian id) pairs of Gaussian gid_by_rank[r] starting at cum_r[r-1]
+__global__ __launch_bounds__(256) void bin_emit_kernel(int n, const int32_t *__restrict__ gid_by_rank,
+                                                       const int32_t *__restrict__ cum_r,
+                                                       const BinRec *__restrict__ recs, int tiles_x, int tiles_y,
+                                                       int block, uint32_t *__restrict__ tkeys,
+                                                       int32_t *__restrict__ tvals) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    int mnx = 0, mny = 0, mxx = 0, mxy = 0, cur = 0, gid = 0;
+    float gx = 0.f, gy = 0.f, a = 1.f, b = 0.f, c = 1.f, s = -1.f;
+    bool live = false;
+    if (r < n) {
+        gid = gid_by_rank[r];
+        const float4 *q = reinterpret_cast<const float4 *>(recs + gid);
+        const float4 q0 = q[0], q1 = q[1];
+        const int rad = __float_as_int(q1.z);
+        if (rad > 0 && __float_as_int(q1.w) > 0) {
+            live = true;
+            gx = q0.x; gy = q0.y; a = q0.z; b = q0.w; c = q1.x; s = q1.y;
+            sgn_tile_bbox(gx, gy, (float)rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
+            cur = (r == 0) ? 0 : cum_r[r - 1];
+        }
+    }
+    const Ellipse E = make_ellipse(gx, gy, a, b, c, s);
+    tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, tkeys, tvals);
 }
 
 // sorted tile ids -> tile_bins
@@ -419,11 +468,12 @@ static Cull make_cull(const float *conics, const float *opac, int opac_is_logit,
 SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii,
                                const float *conics, const float *opacities, int opacity_is_logit, int cull,
                                int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
-                               int32_t *gid_by_rank, void *ws, size_t ws_bytes, sgn_stream_t stream) {
+                               int32_t *gid_by_rank, float *bin_records, void *ws, size_t ws_bytes,
+                               sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     if (n == 0) return 0;
-    SGN_ARG_CHECK(xys && depths && radii && cum_by_rank && gid_by_rank && ws, -3);
+    SGN_ARG_CHECK(xys && depths && radii && cum_by_rank && gid_by_rank && bin_records && ws, -3);
     SGN_ARG_CHECK(ws_bytes >= sgn_bin_prepare_workspace_bytes(n), -4);
     hipStream_t s = (hipStream_t)stream;
     char *p = (char *)ws;
@@ -434,14 +484,16 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     int32_t *cnt_r = (int32_t *)p;   p += al256((size_t)n * 4);
     void *sort_ws = p;
     const Cull c = make_cull(conics, opacities, opacity_is_logit, cull);
+    BinRec *recs = reinterpret_cast<BinRec *>(bin_records);
+    sgn_timing_begin(SGN_T_MAP, s);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, depths, radii, c, tiles_x,
+                       tiles_y, block_width, dkeys, dvals, recs);
+    sgn_timing_end(SGN_T_MAP, s);
     sgn_timing_begin(SGN_T_SORT, s);
-    hipLaunchKernelGGL(depth_keys_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, depths, radii, dkeys, dvals);
     sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
     sgn_timing_end(SGN_T_SORT, s);
     sgn_timing_begin(SGN_T_MAP, s);
-    hipLaunchKernelGGL(rank_tiles_kernel<false>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii,
-                       (const int32_t *)nullptr, gid_by_rank, c, tiles_x, tiles_y, block_width, cnt_r,
-                       (uint32_t *)nullptr, (int32_t *)nullptr);
+    hipLaunchKernelGGL(gather_counts_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, gid_by_rank, recs, cnt_r);
     sgn_timing_end(SGN_T_MAP, s);
     return sgn_scan_i32(n, cnt_r, cum_by_rank, scan_ws, sgn_scan_workspace_bytes(n), stream);
 }
@@ -451,11 +503,10 @@ SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
     return 3 * al256(ni * 4) + sgn_sort_pairs32_ws_bytes(n_isect);
 }
 
-SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const int32_t *radii,
-                                 const float *conics, const float *opacities, int opacity_is_logit, int cull,
-                                 const int32_t *cum_by_rank, const int32_t *gid_by_rank, int tiles_x,
-                                 int tiles_y, int block_width, int32_t *gaussian_ids_sorted, int32_t *tile_bins,
-                                 void *ws, size_t ws_bytes, sgn_stream_t stream) {
+SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
+                                 const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
+                                 int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *ws, size_t ws_bytes,
+                                 sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0 && n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     SGN_ARG_CHECK(tile_bins != nullptr, -3);
@@ -463,7 +514,7 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const
     const int n_tiles = tiles_x * tiles_y;
     SGN_HIP_CHECK(hipMemsetAsync(tile_bins, 0, (size_t)n_tiles * 2 * sizeof(int32_t), s));
     if (n_isect == 0 || n == 0) return 0;
-    SGN_ARG_CHECK(xys && radii && cum_by_rank && gid_by_rank && gaussian_ids_sorted && ws, -4);
+    SGN_ARG_CHECK(bin_records && cum_by_rank && gid_by_rank && gaussian_ids_sorted && ws, -4);
     SGN_ARG_CHECK(ws_bytes >= sgn_bin_intersect_workspace_bytes(n_isect), -5);
     const int tile_bits = bit_length((uint32_t)(n_tiles - 1)) > 0 ? bit_length((uint32_t)(n_tiles - 1)) : 1;
     char *p = (char *)ws;
@@ -471,10 +522,9 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *xys, const
     int32_t *tvals = (int32_t *)p;          p += al256((size_t)n_isect * 4);
     uint32_t *tkeys_sorted = (uint32_t *)p; p += al256((size_t)n_isect * 4);
     void *sort_ws = p;
-    const Cull c = make_cull(conics, opacities, opacity_is_logit, cull);
     sgn_timing_begin(SGN_T_MAP, s);
-    hipLaunchKernelGGL(rank_tiles_kernel<true>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, radii, cum_by_rank,
-                       gid_by_rank, c, tiles_x, tiles_y, block_width, (int32_t *)nullptr, tkeys, tvals);
+    hipLaunchKernelGGL(bin_emit_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, gid_by_rank, cum_by_rank,
+                       reinterpret_cast<const BinRec *>(bin_records), tiles_x, tiles_y, block_width, tkeys, tvals);
     sgn_timing_end(SGN_T_MAP, s);
     sgn_timing_begin(SGN_T_SORT, s);
     sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws, s);

@@ -57,9 +57,9 @@ SIGNATURES = {
     "sgn_sort_pairs": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_tile_bins": (_i, [_i64, _vp, _i, _vp, _vp]),
     "sgn_bin_prepare_workspace_bytes": (_sz, [_i]),
-    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_bin_intersect_workspace_bytes": (_sz, [_i64]),
-    "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sgn_raster_workspace_bytes": (_sz, [_i, _i64]),
     "sgn_raster_fwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_raster_bwd_workspace_bytes": (_sz, [_i]),

@@ -265,16 +265,16 @@ def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_boun
     opac_c = _f32c(opacity).reshape(-1) if do_cull else None
     cum_r = torch.empty(n, **i32)
     gid_by_rank = torch.empty(n, **i32)
+    bin_recs = torch.empty(n, 8, dtype=torch.float32, device=dev)
     ws = L.workspace(lib.sgn_bin_prepare_workspace_bytes(n), dev)
     L.check(lib.sgn_bin_prepare(n, L.ptr(xys_c), L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(conics_c), L.ptr(opac_c),
                                 int(bool(opacity_is_logit)), do_cull, tx, ty, int(block_width), L.ptr(cum_r),
-                                L.ptr(gid_by_rank), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                                L.ptr(gid_by_rank), L.ptr(bin_recs), L.ptr(ws), ws.numel(), L.stream_ptr()),
             "sgn_bin_prepare")
     num_intersects = int(cum_r[-1].item())  # host sync: sizes the intersection buffers (as upstream)
     ids_sorted = torch.empty(num_intersects, **i32)
     ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(num_intersects), dev)
-    L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(xys_c), L.ptr(radii_c), L.ptr(conics_c), L.ptr(opac_c),
-                                  int(bool(opacity_is_logit)), do_cull, L.ptr(cum_r), L.ptr(gid_by_rank), tx, ty,
+    L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(bin_recs), L.ptr(cum_r), L.ptr(gid_by_rank), tx, ty,
                                   int(block_width), L.ptr(ids_sorted), L.ptr(tile_bins), L.ptr(ws2), ws2.numel(),
                                   L.stream_ptr()), "sgn_bin_intersect")
     return num_intersects, ids_sorted, tile_bins
