@@ -212,6 +212,9 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                    const float *conics, const float *colors /*[n,3]*/, const float *opacities /*[n]*/,
                    int opacity_is_logit /*0 = gsplat semantics; 1 = fuse torch.sigmoid (sgn_splatfacto.py:949)*/,
+                   int id_lo, int id_hi /*only Gaussians with id in [id_lo, id_hi) take part (0, n = all): a sub-model
+                                          pass of the scene graph (sgn_splatfacto_scene_graph.py:364-366) over the
+                                          depth list binned once for the whole scene*/,
                    const float *background3, float *out_img /*[H,W,3]*/, float *final_Ts /*[H,W]*/,
                    int32_t *final_idx /*[H,W]*/, void *recs_ws, size_t recs_ws_bytes,
                    sgn_stream_t stream);
@@ -224,7 +227,7 @@ size_t sgn_raster_bwd_workspace_bytes(int n);
 int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                    const float *conics, const float *colors, const float *opacities, int opacity_is_logit,
-                   const float *background3, const float *final_Ts, const int32_t *final_idx,
+                   int id_lo, int id_hi, const float *background3, const float *final_Ts, const int32_t *final_idx,
                    const float *v_out_img /*[H,W,3]*/, const float *v_out_alpha /*[H,W]*/,
                    float alpha_clamp_bwd, float *v_xy /*[n,2]*/, float *v_conic /*[n,3]*/,
                    float *v_colors /*[n,3]*/, float *v_opacity /*[n]*/, void *recs_ws,

@@ -70,9 +70,17 @@ __global__ __launch_bounds__(256) void build_grec_kernel(int n, const float *__r
                                                          const float *__restrict__ conics,
                                                          const float *__restrict__ colors,
                                                          const float *__restrict__ opac, int opac_is_logit,
-                                                         float4 *__restrict__ grec) {
+                                                         int id_lo, int id_hi, float4 *__restrict__ grec) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= n) return;
+    if (g < id_lo || g >= id_hi) {
+        // sub-model pass over a shared depth list (scene graph): Gaussians outside [id_lo, id_hi) become inert
+        // rows — zero opacity (alpha < 1/255 on every pixel) and a bbox no quadrant test can pass
+        grec[3 * g + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+        grec[3 * g + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+        grec[3 * g + 2] = make_float4(0.f, __int_as_float(g), -3.0e38f, -3.0e38f);
+        return;
+    }
     const float x = xys[2 * g], y = xys[2 * g + 1];
     const float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
     const float r = colors[3 * g], gg = colors[3 * g + 1], bl = colors[3 * g + 2];
@@ -627,12 +635,13 @@ SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
 
 // builds the per-Gaussian rows and (stream mode) the depth-ordered record stream
 static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
-                        const float *colors, const float *opac, int opac_is_logit, void *recs, hipStream_t s) {
+                        const float *colors, const float *opac, int opac_is_logit, int id_lo, int id_hi, void *recs,
+                        hipStream_t s) {
     float4 *grec = (float4 *)recs;                       // rows first,
     float4 *stream_recs = (float4 *)recs + 3 * (size_t)n; // then the optional depth-ordered stream
     sgn_timing_begin(SGN_T_PACK, s);
     hipLaunchKernelGGL(build_grec_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, conics, colors, opac,
-                       opac_is_logit, grec);
+                       opac_is_logit, id_lo, id_hi, grec);
     if (!g_gather)
         hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(3 * n_isect, 256)), dim3(256), 0, s, n_isect, ids,
                            grec, stream_recs);
@@ -643,8 +652,9 @@ static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float 
 SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
-                              int opacity_is_logit, const float *background3, float *out_img, float *final_Ts,
-                              int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes, sgn_stream_t stream) {
+                              int opacity_is_logit, int id_lo, int id_hi, const float *background3, float *out_img,
+                              float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes,
+                              sgn_stream_t stream) {
     SGN_ARG_CHECK(img_h > 0 && img_w > 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
     SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -3);
@@ -653,7 +663,8 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     SGN_ARG_CHECK(n >= 0 && recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect), -6);
     hipStream_t s = (hipStream_t)stream;
     if (n_isect > 0)
-        pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, recs_ws, s);
+        pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
+                     recs_ws, s);
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     const Rec *rows = (const Rec *)recs_ws;
     const Rec *stream_recs = rows + n;
@@ -683,8 +694,8 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
 SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
-                              int opacity_is_logit, const float *background3, const float *final_Ts,
-                              const int32_t *final_idx,
+                              int opacity_is_logit, int id_lo, int id_hi, const float *background3,
+                              const float *final_Ts, const int32_t *final_idx,
                               const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd,
                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
                               size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
@@ -703,7 +714,8 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
                           final_Ts && final_idx && v_out_img && v_out_alpha && recs_ws, -7);
         SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect), -8);
         if (!recs_packed)
-            pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, recs_ws, s);
+            pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
+                         recs_ws, s);
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
         const Rec *rows = (const Rec *)recs_ws;
         const Rec *stream_recs = rows + n;

@@ -321,9 +321,10 @@ def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bo
 class _RasterizeGaussians(Function):
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
-                block_width, background=None, return_alpha=False, opacity_is_logit=False):
+                block_width, background=None, return_alpha=False, opacity_is_logit=False, id_range=None):
         dev = L.require_device(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
         num_points = xys.size(0)
+        id_lo, id_hi = (0, num_points) if id_range is None else (int(id_range[0]), int(id_range[1]))
         tile_bounds = ((img_width + block_width - 1) // block_width,
                        (img_height + block_width - 1) // block_width, 1)
         if colors.shape[-1] != 3:
@@ -351,12 +352,13 @@ class _RasterizeGaussians(Function):
             recs = L.workspace(lib.sgn_raster_workspace_bytes(num_points, num_intersects), dev)
             L.check(lib.sgn_raster_fwd(
                 img_height, img_width, block_width, num_points, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
-                L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), L.ptr(bg_c),
-                L.ptr(out_img),
+                L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), id_lo, id_hi,
+                L.ptr(bg_c), L.ptr(out_img),
                 L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), L.stream_ptr()), "sgn_raster_fwd")
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
         ctx.num_intersects = num_intersects
         ctx.opacity_is_logit = int(bool(opacity_is_logit))
+        ctx.id_range = (id_lo, id_hi)
         ctx.opacity_shape = opacity.shape
         ctx.recs = recs
         ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys_c, conics_c, colors_c, opac_c, bg_c,
@@ -391,14 +393,14 @@ class _RasterizeGaussians(Function):
             gws = L.workspace(lib.sgn_raster_bwd_workspace_bytes(n), dev)
             L.check(lib.sgn_raster_bwd(
                 H, W, ctx.block_width, n, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
-                L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity), ctx.opacity_is_logit, L.ptr(background),
-                L.ptr(final_Ts),
+                L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity), ctx.opacity_is_logit, ctx.id_range[0],
+                ctx.id_range[1], L.ptr(background), L.ptr(final_Ts),
                 L.ptr(final_idx), L.ptr(v_out_img), L.ptr(v_out_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
                 L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
                 L.ptr(gws), gws.numel(), L.stream_ptr()), "sgn_raster_bwd")
         v_opacity = v_opacity.reshape(ctx.opacity_shape)
         # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha)
-        return v_xy, None, None, v_conic, None, v_colors, v_opacity, None, None, None, None, None, None
+        return v_xy, None, None, v_conic, None, v_colors, v_opacity, None, None, None, None, None, None, None
 
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height: int,

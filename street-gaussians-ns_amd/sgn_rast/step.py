@@ -152,12 +152,16 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
         if hi <= lo:
             return torch.zeros(H, W, device=dev)
         if fused:
-            rgbs = torch.zeros(hi - lo, 3, device=dev)   # colour is irrelevant for an accumulation-only pass
-        else:
-            colors = torch.cat((P["features_dc"][sl], P["features_rest"][sl]), dim=1)
-            viewdirs = P["means"][sl].detach() - cam.cam_pos
-            viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
-            rgbs = torch.clamp(ops.spherical_harmonics(sh_degree_to_use, viewdirs, colors) + 0.5, min=0.0)
+            # colour is irrelevant for an accumulation-only pass; the full geometry tensors + id_range reuse the
+            # main pass's binning (one-entry cache) instead of slicing and sorting again
+            rgbs = torch.zeros(sum(counts), 3, device=dev)
+            _, acc = raster(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit, rgbs, opac_arg, H, W,
+                            block_width, background=bg_zero, return_alpha=True, id_range=(lo, hi))
+            return acc
+        colors = torch.cat((P["features_dc"][sl], P["features_rest"][sl]), dim=1)
+        viewdirs = P["means"][sl].detach() - cam.cam_pos
+        viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+        rgbs = torch.clamp(ops.spherical_harmonics(sh_degree_to_use, viewdirs, colors) + 0.5, min=0.0)
         _, acc = raster(out.xys[sl], out.depths[sl], out.radii[sl], out.conics[sl], out.num_tiles_hit[sl], rgbs,
                         opac_arg[sl], H, W, block_width, background=bg_zero, return_alpha=True)
         return acc

@@ -140,3 +140,47 @@ def test_scene_graph_replay_fused_vs_dropin_vs_oracle(torch_oracle):
             for k in mg:
                 assert rel_l2(mg[k].grad.cpu(), me[k].grad) < 2e-3, k
     assert float(exp.object_acc.max()) > 0.5 and float(exp.background_acc.max()) > 0.5
+
+
+@pytest.mark.parametrize("batch", [False, True])
+def test_id_range_pass_equals_sliced_pass(batch):
+    """A sub-model pass given as (full tensors, id_range) == the reference's way (slice, re-bin, render), forward
+    and backward, with the long-list LDS path forced on and off."""
+    from sgn_rast import _lib as L, fused, ops, scenes, step
+    L.load().sgn_set_batch_thresholds(*((24, 24) if batch else (1 << 30, 1 << 30)))
+    try:
+        cam, raw = scenes.make_scene("c1", seed=5, device=DEV, n_override=4000)
+        P = step.leaf_params(raw)
+        xys, depths, radii, conics, _c, nth, _ = fused.project_gaussians_fused(
+            P["means"], P["log_scales"], P["quats"], cam.viewmat[:3, :], cam.fx, cam.fy, cam.cx, cam.cy, cam.height,
+            cam.width, 16)
+        g = torch.Generator().manual_seed(3)
+        rgbs = torch.rand(4000, 3, generator=g).to(DEV).requires_grad_(True)
+        w_img, w_a = step.loss_weights(cam, seed=9, device=DEV)
+        bg = torch.tensor([0.2, 0.1, 0.3], device=DEV)
+        lo, hi = 1300, 2900
+        res = []
+        for mode in ("range", "slice"):
+            for t in (P["means"], P["log_scales"], P["quats"], P["opacity_logits"], rgbs):
+                t.grad = None
+            if mode == "range":
+                # main pass first, like the scene graph: the sub-model pass must hit the binning cache
+                fused.rasterize_gaussians_fused(xys, depths, radii, conics, nth, rgbs, P["opacity_logits"], cam.height,
+                                                cam.width, 16, bg, True)
+                key = ops._bin_cache["key"]
+                img, a = fused.rasterize_gaussians_fused(xys, depths, radii, conics, nth, rgbs, P["opacity_logits"],
+                                                         cam.height, cam.width, 16, bg, True, id_range=(lo, hi))
+                assert ops._bin_cache["key"] == key
+            else:
+                sl = slice(lo, hi)
+                img, a = fused.rasterize_gaussians_fused(xys[sl], depths[sl], radii[sl], conics[sl], nth[sl], rgbs[sl],
+                                                         P["opacity_logits"][sl], cam.height, cam.width, 16, bg, True)
+            ((img * w_img).sum() + (a * w_a).sum()).backward(retain_graph=True)
+            res.append((img.detach(), a.detach(), rgbs.grad.clone(), P["opacity_logits"].grad.clone(),
+                        P["means"].grad.clone(), P["log_scales"].grad.clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])   # same list order, same math
+        assert float(res[0][2][:lo].abs().max()) == 0 and float(res[0][2][hi:].abs().max()) == 0
+        for x, y in zip(res[0][2:], res[1][2:]):
+            assert rel_l2(x, y) < 1e-5
+    finally:
+        L.load().sgn_set_batch_thresholds(256, 128)
