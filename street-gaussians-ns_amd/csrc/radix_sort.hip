@@ -22,20 +22,23 @@ namespace {
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = 4;
-constexpr int RS_IPT = 16;                     // keys per thread
-constexpr int RS_TILE = RS_THREADS * RS_IPT;   // 4096 keys per workgroup
-constexpr int RS_WAVE_ITEMS = 64 * RS_IPT;     // 1024 keys per wave
+// keys per thread: 16 (4096-key tiles) for large inputs; 4 (1024-key tiles) below RS_SMALL_N keys, where 4096-key
+// tiles would leave most of the 256 CUs idle (1 M keys = 245 tiles) and every pass latency-bound
+constexpr int RS_IPT_LARGE = 16, RS_IPT_SMALL = 4;
+constexpr uint32_t RS_SMALL_N = 3u << 20;
+inline int rs_pick_ipt(int64_t n) { return n < (int64_t)RS_SMALL_N ? RS_IPT_SMALL : RS_IPT_LARGE; }
 
 template <typename K>
 __device__ __forceinline__ unsigned digit_of(K key, int shift, unsigned mask) {
     return (unsigned)(key >> shift) & mask;
 }
 
-template <typename K, int BITS>
+template <typename K, int BITS, int RS_IPT>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(uint32_t n, const K *__restrict__ keys, int shift,
                                                              unsigned dmask, uint32_t nblk,
                                                              uint32_t *__restrict__ table) {
     constexpr int NB = 1 << BITS;
+    constexpr int RS_TILE = RS_THREADS * RS_IPT;
     __shared__ uint32_t hist[NB];
     for (int d = threadIdx.x; d < NB; d += RS_THREADS) hist[d] = 0;
     __syncthreads();
@@ -94,13 +97,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t nblk, uint
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-template <typename K, bool HAS_VAL, int BITS>
+template <typename K, bool HAS_VAL, int BITS, int RS_IPT>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     uint32_t n, const K *__restrict__ keys_in, const int32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     int32_t *__restrict__ vals_out, int shift, unsigned dmask, uint32_t nblk, const uint32_t *__restrict__ table,
     const uint32_t *__restrict__ totals) {
     constexpr int NB = 1 << BITS;
     constexpr int DPT = NB / RS_THREADS;  // digits owned per thread in the prefix phase (1 or 2)
+    constexpr int RS_TILE = RS_THREADS * RS_IPT;   // keys per workgroup
+    constexpr int RS_WAVE_ITEMS = 64 * RS_IPT;     // keys per wave
     static_assert(NB % RS_THREADS == 0, "digit count must be a multiple of the block size");
     __shared__ K skeys[RS_TILE];
     __shared__ int32_t svals[HAS_VAL ? RS_TILE : 1];
@@ -206,17 +211,17 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 template <typename K, bool HAS_VAL, int BITS>
 size_t sort_ws_bytes(int64_t n) {
     if (n <= 0) return 256;
-    const size_t nblk = (size_t)sgn_cdiv(n, RS_TILE);
+    const size_t nblk = (size_t)sgn_cdiv(n, RS_THREADS * rs_pick_ipt(n));
     return align256((size_t)n * sizeof(K)) + (HAS_VAL ? align256((size_t)n * 4) : 0) +
            align256(((size_t)1 << BITS) * nblk * 4) + align256(((size_t)1 << BITS) * 4);
 }
 
 // ping-pong LSD passes; the last pass lands in keys_out / vals_out
-template <typename K, bool HAS_VAL, int BITS>
-void sort_launch(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const int32_t *vals_in, K *keys_out,
-                 int32_t *vals_out, void *ws, hipStream_t s) {
+template <typename K, bool HAS_VAL, int BITS, int RS_IPT>
+void sort_launch_ipt(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const int32_t *vals_in, K *keys_out,
+                     int32_t *vals_out, void *ws, hipStream_t s) {
     constexpr int NB = 1 << BITS;
-    const uint32_t nblk = (uint32_t)sgn_cdiv(n, RS_TILE);
+    const uint32_t nblk = (uint32_t)sgn_cdiv(n, RS_THREADS * RS_IPT);
     char *p = (char *)ws;
     K *alt_keys = (K *)p; p += align256((size_t)n * sizeof(K));
     int32_t *alt_vals = nullptr;
@@ -224,23 +229,34 @@ void sort_launch(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const
     uint32_t *table = (uint32_t *)p; p += align256((size_t)NB * nblk * 4);
     uint32_t *totals = (uint32_t *)p;
     const int npass = (end_bit - begin_bit + BITS - 1) / BITS;
+    // balanced digits (14 tile bits -> 7 + 7, not 8 + 6): fewer buckets per pass = longer contiguous store runs
+    const int bpp = (end_bit - begin_bit + npass - 1) / npass;
     const K *src_k = keys_in;
     const int32_t *src_v = vals_in;
     for (int pass = 0; pass < npass; ++pass) {
-        const int shift = begin_bit + BITS * pass;
-        const int bits = (end_bit - shift) < BITS ? (end_bit - shift) : BITS;
+        const int shift = begin_bit + bpp * pass;
+        const int bits = (end_bit - shift) < bpp ? (end_bit - shift) : bpp;
         const unsigned dmask = (1u << bits) - 1u;
         const bool to_out = ((npass - 1 - pass) % 2) == 0;
         K *dst_k = to_out ? keys_out : alt_keys;
         int32_t *dst_v = to_out ? vals_out : alt_vals;
-        hipLaunchKernelGGL((rs_hist_kernel<K, BITS>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, shift, dmask,
+        hipLaunchKernelGGL((rs_hist_kernel<K, BITS, RS_IPT>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, shift, dmask,
                            nblk, table);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(NB), dim3(RS_THREADS), 0, s, nblk, table, totals);
-        hipLaunchKernelGGL((rs_scatter_kernel<K, HAS_VAL, BITS>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, src_v,
+        hipLaunchKernelGGL((rs_scatter_kernel<K, HAS_VAL, BITS, RS_IPT>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, src_v,
                            dst_k, dst_v, shift, dmask, nblk, table, totals);
         src_k = dst_k;
         src_v = dst_v;
     }
+}
+
+template <typename K, bool HAS_VAL, int BITS>
+void sort_launch(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const int32_t *vals_in, K *keys_out,
+                 int32_t *vals_out, void *ws, hipStream_t s) {
+    if (rs_pick_ipt(n) == RS_IPT_SMALL)
+        sort_launch_ipt<K, HAS_VAL, BITS, RS_IPT_SMALL>(n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out, ws, s);
+    else
+        sort_launch_ipt<K, HAS_VAL, BITS, RS_IPT_LARGE>(n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out, ws, s);
 }
 
 }  // namespace
