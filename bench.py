@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--sky", action="store_true",
                     help="add the reference's sky-sphere branch (EnvLight 1024^2 cube map lookup + blend, "
                          "sgn_splatfacto.py:875-876,969-972) to the step")
+    ap.add_argument("--photometric", action="store_true",
+                    help="use the reference's photometric loss (0.8 L1 + 0.2 (1 - SSIM) against a random target image, "
+                         "sgn_splatfacto.py:1084-1087) through the fused HIP loss instead of the synthetic linear loss")
     ap.add_argument("--dp-exchange", default="lowrank", choices=["lowrank", "dense"],
                     help="N>1: SH gradient via all-gathered low-rank factors (default) or dense all-reduce")
     return ap.parse_args()
@@ -185,10 +188,14 @@ def main():
             reducer = dp.GradAllReducer(list(P.values()) + [sky["base"]], big=[P["features_rest"], sky["base"]],
                                         sh_exchange=reducer.sh_exchange)
 
+    gt_img = None
+    if args.photometric:
+        gt_img = torch.rand(cam.height, cam.width, 3, generator=torch.Generator().manual_seed(5 + rank)).to(dev)
+
     def one_step(fused=(args.path == "fused")):
         if sg is None:
             return step.train_step(P, cam, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer,
-                                   fused=fused, sky=sky)
+                                   fused=fused, sky=sky, gt=gt_img)
         for m in sg[0]:
             for p in m.values():
                 p.grad = None
@@ -299,6 +306,9 @@ def main():
         if args.sky:
             line["metric"] = "train-step images/sec (fwd+bwd + sky cube map) @1M Gaussians 1920x1280"
             line["config"]["workload"] += "; + EnvLight 6x1024x1024x3 lookup/blend fwd+bwd"
+        if args.photometric:
+            line["metric"] = line["metric"].replace("(fwd+bwd", "(photometric L1+SSIM loss, fwd+bwd")
+            line["config"]["workload"] += "; loss = 0.8 L1 + 0.2 (1 - SSIM 11x11) vs a random target (fused HIP loss)"
         if fused_extra is not None:
             line["fused_path"] = fused_extra
         if world == 1 and not args.no_cpu_baseline:

@@ -79,7 +79,9 @@ void sgn_set_batch_thresholds(int fwd_entries, int bwd_entries);
 #define SGN_T_UNPACK 11
 #define SGN_T_SKY_FWD 12
 #define SGN_T_SKY_BWD 13
-#define SGN_T_SLOTS 14
+#define SGN_T_LOSS_FWD 14
+#define SGN_T_LOSS_BWD 15
+#define SGN_T_SLOTS 16
 void sgn_timing_enable(int on); /* also clears recorded spans */
 int sgn_timing_get(int slot, int *count /*host*/, float *total_ms /*host*/);
 
@@ -264,6 +266,18 @@ int sgn_sky_blend_fwd(int h, int w, float fx, float fy, float cx, float cy, cons
 int sgn_sky_blend_bwd(int h, int w, float fx, float fy, float cx, float cy, const float *c2w, int c2w_ld,
                       const float *jitter, int resolution, const float *tex, const float *rgb, const float *alpha,
                       const float *v_out, float *v_rgb, float *v_alpha, float *v_tex, sgn_stream_t stream);
+
+/* Fused photometric loss (sgn_splatfacto.py:1084-1087): Ll1 = mean |gt - pred| and
+ * ssim = pytorch_msssim.SSIM(data_range, size_average=True, channel=3) of two [h,w,3] images (11-tap Gaussian window,
+ * sigma 1.5, no padding, K = (0.01, 0.03)); h, w > 10.  sums2 (device, 2 floats) receives the two SUMS: the caller
+ * divides by 3hw and 3(h-10)(w-10).  ws (>= sgn_l1_ssim_workspace_bytes) holds per-workgroup partial sums and, with
+ * with_grad != 0, the SSIM partials sgn_l1_ssim_bwd needs (pass the same ws); the backward writes d loss / d pred
+ * given gscale2 = (d loss/d Ll1, d loss/d ssim) as two DEVICE floats (no host sync between backward nodes). */
+size_t sgn_l1_ssim_workspace_bytes(int h, int w, int with_grad);
+int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt, float data_range, float *sums2, int with_grad,
+                    void *ws, size_t ws_bytes, sgn_stream_t stream);
+int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt, const void *ws, const float *gscale2,
+                    float *v_pred, sgn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -478,3 +478,46 @@ def env_light_directions(h: int, w: int, fx: float, fy: float, cx: float, cy: fl
     wdir = (c2w[:3, :3].to(torch.float32) @ d.reshape(3, -1)).reshape(3, h, w).permute(1, 2, 0)
     to_gl = torch.tensor([[1, 0, 0], [0, 0, 1], [0, -1, 0]], dtype=torch.float32)
     return (wdir.reshape(-1, 3) @ to_gl.T).reshape(h, w, 3)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# Photometric loss: L1 + SSIM as the reference computes it, `sgn_splatfacto.py:1084-1087`:
+#   Ll1 = |gt - rgb|.mean();  simloss = 1 - SSIM(data_range=1.0, size_average=True, channel=3)(gt, rgb)
+# SSIM is `pytorch_msssim.SSIM` (PyPI package, not vendored by the reference and not installed here: PARITY
+# UNPINNED).  Restated from its published definition: 11-tap Gaussian window (sigma 1.5, normalised), separable
+# depthwise filtering WITHOUT padding (valid region only, (H-10) x (W-10)), K = (0.01, 0.03),
+# sigma^2 = E[x^2] - mu^2, ssim_map = (2 mu1 mu2 + C1)/(mu1^2 + mu2^2 + C1) * (2 sigma12 + C2)/(sigma1^2 + sigma2^2 + C2),
+# mean over space per channel, then mean over channels.
+# --------------------------------------------------------------------------------------------------------------
+def ssim_window(size: int = 11, sigma: float = 1.5, dtype=torch.float32) -> torch.Tensor:
+    coords = torch.arange(size, dtype=dtype) - size // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def ssim(X: torch.Tensor, Y: torch.Tensor, data_range: float = 1.0, win_size: int = 11, win_sigma: float = 1.5,
+         K=(0.01, 0.03)) -> torch.Tensor:
+    """X, Y [B,C,H,W] -> scalar mean SSIM (size_average=True)."""
+    C = X.shape[1]
+    win = ssim_window(win_size, win_sigma, X.dtype).to(X.device)
+
+    def filt(t):
+        t = torch.nn.functional.conv2d(t, win.view(1, 1, -1, 1).repeat(C, 1, 1, 1), groups=C)
+        return torch.nn.functional.conv2d(t, win.view(1, 1, 1, -1).repeat(C, 1, 1, 1), groups=C)
+
+    C1, C2 = (K[0] * data_range) ** 2, (K[1] * data_range) ** 2
+    mu1, mu2 = filt(X), filt(Y)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    sigma1_sq = filt(X * X) - mu1_sq
+    sigma2_sq = filt(Y * Y) - mu2_sq
+    sigma12 = filt(X * Y) - mu1_mu2
+    cs_map = (2 * sigma12 + C2) / (sigma1_sq + sigma2_sq + C2)
+    ssim_map = ((2 * mu1_mu2 + C1) / (mu1_sq + mu2_sq + C1)) * cs_map
+    return torch.flatten(ssim_map, 2).mean(-1).mean()
+
+
+def l1_ssim_losses(rgb: torch.Tensor, gt: torch.Tensor):
+    """rgb, gt [H,W,3] -> (Ll1, ssim) exactly as sgn_splatfacto.py:1084-1085 builds them."""
+    Ll1 = torch.abs(gt - rgb).mean()
+    s = ssim(gt.permute(2, 0, 1)[None, ...], rgb.permute(2, 0, 1)[None, ...])
+    return Ll1, s

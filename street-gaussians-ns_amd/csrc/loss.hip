@@ -1,0 +1,257 @@
+// loss.hip — fused photometric loss of the reference's training step: L1 + SSIM (forward + gradient), gfx950.
+//
+// SURVEY.md §8f row 3.  Replaces, at 1920x1280x3, `torch.abs(gt - rgb).mean()` plus
+// `pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3)(gt, rgb)` — ten depthwise conv2d launches
+// forward and their autograd graph backward — reached at street_gaussians_ns/sgn_splatfacto.py:1084-1087.
+// pytorch_msssim is a PyPI dependency that is not vendored by the reference (PARITY UNPINNED); the definition
+// restated here and in oracle/torch_oracle.py:ssim: 11-tap Gaussian window (sigma 1.5), separable, NO padding
+// (valid region (H-10) x (W-10)), K = (0.01, 0.03), data_range 1, mean over space then channels.
+//
+// One workgroup per 16x16 pixel tile, HWC images as the rasterizer produces them (no NCHW permute copy):
+//   forward : 26x26 input patch -> LDS, horizontal then vertical 11-tap pass for the five moments
+//             (x, y, x^2, y^2, xy), SSIM per pixel, block-reduced sums (one atomic per block), and the three
+//             partial derivatives dS/d mu_x, dS/d E[x^2], dS/d E[xy] stored for the backward;
+//   backward: 26x26 patch of those three maps -> LDS, same separable filter (transposed valid correlation:
+//             zero outside the valid domain), grad = G*A + 2x G*B + y G*C, fused with the L1 sign term.
+// HBM-bound by design: forward reads 2 images and writes 3 maps, backward reads 3 maps + 2 images and writes 1.
+#include "sgn_common.h"
+
+namespace {
+
+constexpr int WIN = 11, HALO = WIN - 1, TS = 16, PS = TS + HALO;   // tile 16, patch 26
+
+struct Win { float g[WIN]; };
+
+__device__ __forceinline__ float block_sum(float v, float *lds4) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds4[wave] = v;
+    __syncthreads();
+    return lds4[0] + lds4[1] + lds4[2] + lds4[3];
+}
+
+constexpr int ROWF = PS * 3;          // floats per patch row with the three channels interleaved (HWC)
+constexpr int ROWS_ = ROWF + 3;       // LDS row stride (odd: 3q + c walks distinct banks, rows shifted)
+
+// pred/gt [H,W,3]; per-workgroup partial sums of |gt - pred| (all pixels) and of ssim_map (valid region);
+// dmaps [3 maps][3 channels][H-10][W-10]: dS/d mu_pred, dS/d E[pred^2], dS/d E[pred*gt] (NULL: no backward wanted)
+__global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(int H, int W, Win win, float C1, float C2,
+                                                          const float *__restrict__ pred,
+                                                          const float *__restrict__ gt,
+                                                          float *__restrict__ partials,
+                                                          float *__restrict__ dmaps) {
+    __shared__ float px[PS][ROWS_], py[PS][ROWS_];            // HWC patch, all three channels: contiguous row loads
+    __shared__ float hm[5][PS][TS + 1];
+    __shared__ float lds4[4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int Ho = H - HALO, Wo = W - HALO;
+    const int ox = x0 + tx, oy = y0 + ty;                     // pixel (L1) = output position (SSIM)
+    const bool in_img = ox < W && oy < H, in_out = ox < Wo && oy < Ho;
+    const int rowlen = W * 3;
+    for (int e = tid; e < PS * ROWF; e += 256) {
+        const int r = e / ROWF, j = e - r * ROWF;
+        const int iy = y0 + r, gx = x0 * 3 + j;
+        const bool ok = iy < H && gx < rowlen;
+        const size_t idx = (size_t)iy * rowlen + gx;
+        px[r][j] = ok ? pred[idx] : 0.f;
+        py[r][j] = ok ? gt[idx] : 0.f;
+    }
+    __syncthreads();
+    float l1 = 0.f, ss = 0.f;
+    if (in_img) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) l1 += fabsf(py[ty][tx * 3 + c] - px[ty][tx * 3 + c]);
+    }
+    const size_t plane = (size_t)Ho * Wo;
+    for (int c = 0; c < 3; ++c) {
+        if (c) __syncthreads();                               // hm of the previous channel fully consumed
+        for (int e = tid; e < PS * TS; e += 256) {            // horizontal pass: 26 rows x 16 output columns
+            const int r = e >> 4, q = e & 15;
+            float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) {
+                const float a = px[r][(q + k) * 3 + c], b = py[r][(q + k) * 3 + c], g = win.g[k];
+                const float ga = g * a, gb = g * b;
+                sx += ga; sy += gb;
+                sxx = fmaf(ga, a, sxx); syy = fmaf(gb, b, syy); sxy = fmaf(ga, b, sxy);
+            }
+            hm[0][r][q] = sx; hm[1][r][q] = sy; hm[2][r][q] = sxx; hm[3][r][q] = syy; hm[4][r][q] = sxy;
+        }
+        __syncthreads();
+        if (in_out) {
+            float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) {
+                const float g = win.g[k];
+                mu1 = fmaf(g, hm[0][ty + k][tx], mu1);
+                mu2 = fmaf(g, hm[1][ty + k][tx], mu2);
+                e11 = fmaf(g, hm[2][ty + k][tx], e11);
+                e22 = fmaf(g, hm[3][ty + k][tx], e22);
+                e12 = fmaf(g, hm[4][ty + k][tx], e12);
+            }
+            const float s1 = e11 - mu1 * mu1, s2 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+            const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2;
+            const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s1 + s2 + C2;
+            const float iB1 = 1.f / B1, iB2 = 1.f / B2;
+            const float S = A1 * A2 * iB1 * iB2;
+            ss += S;
+            if (dmaps) {
+                // partials w.r.t. the filtered moments of `pred` (mu1, E[x^2], E[xy]); sigma's depend on mu1 too
+                const float dS_ds1 = -S * iB2;                  // via sigma1^2
+                const float dS_ds12 = 2.f * A1 * iB1 * iB2;     // via sigma12
+                const float dS_dmu1 = 2.f * mu2 * A2 * iB1 * iB2 - 2.f * mu1 * S * iB1 - 2.f * mu1 * dS_ds1 -
+                                      mu2 * dS_ds12;
+                const size_t o = (size_t)c * plane + (size_t)oy * Wo + ox;   // planar: row stores are contiguous
+                dmaps[o] = dS_dmu1;
+                dmaps[3 * plane + o] = dS_ds1;
+                dmaps[6 * plane + o] = dS_ds12;
+            }
+        }
+    }
+    const float bl1 = block_sum(l1, lds4);
+    const float bss = block_sum(ss, lds4);
+    if (tid == 0) {   // one slot per workgroup: 9600 same-address float atomics cost more than the whole kernel
+        const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        partials[2 * b] = bl1;
+        partials[2 * b + 1] = bss;
+    }
+}
+
+__global__ __launch_bounds__(256) void l1_ssim_reduce_kernel(int nblk, const float *__restrict__ partials,
+                                                             float *__restrict__ sums) {
+    __shared__ float lds4[4];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 256) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+    a = block_sum(a, lds4);
+    b = block_sum(b, lds4);
+    if (threadIdx.x == 0) { sums[0] = a; sums[1] = b; }
+}
+
+// v_pred [H,W,3] = gl1 * sign(pred - gt) / (3HW) + gss / (3 Ho Wo) * (G*A + 2 pred G*B + gt G*C)
+// gscale (device, 2 floats): upstream gradients of the two means (d loss / d Ll1, d loss / d ssim)
+__global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(int H, int W, Win win, const float *__restrict__ pred,
+                                                          const float *__restrict__ gt,
+                                                          const float *__restrict__ dmaps,
+                                                          const float *__restrict__ gscale,
+                                                          float *__restrict__ v_pred) {
+    __shared__ float pm[3][PS][PS + 1];
+    __shared__ float hm[3][PS][TS + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
+    const int Ho = H - HALO, Wo = W - HALO;
+    const int qx = x0 + tx, qy = y0 + ty;
+    const bool in_img = qx < W && qy < H;
+    const float w_l1 = gscale[0] / (3.f * (float)H * (float)W);
+    const float w_ss = gscale[1] / (3.f * (float)Ho * (float)Wo);
+    const size_t plane = (size_t)Ho * Wo;
+    const size_t pix = ((size_t)qy * W + qx) * 3;
+    float out[3] = {0.f, 0.f, 0.f};
+    for (int c = 0; c < 3; ++c) {
+        __syncthreads();
+        // outputs p that see pixel q: p in [q - 10, q]; patch row r <-> p_y = y0 - 10 + r
+        for (int e = tid; e < PS * PS; e += 256) {
+            const int r = e / PS, q = e - r * PS;
+            const int py_ = y0 - HALO + r, px_ = x0 - HALO + q;
+            const bool ok = py_ >= 0 && px_ >= 0 && py_ < Ho && px_ < Wo;
+            const size_t o = (size_t)c * plane + (size_t)py_ * Wo + px_;
+            pm[0][r][q] = ok ? dmaps[o] : 0.f;
+            pm[1][r][q] = ok ? dmaps[3 * plane + o] : 0.f;
+            pm[2][r][q] = ok ? dmaps[6 * plane + o] : 0.f;
+        }
+        __syncthreads();
+        for (int e = tid; e < PS * TS; e += 256) {
+            const int r = e >> 4, q = e & 15;
+            float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) {      // p_x = q_x - 10 + k  has weight g[10 - k] (window tap q - p)
+                const float g = win.g[WIN - 1 - k];
+                a = fmaf(g, pm[0][r][q + k], a);
+                b = fmaf(g, pm[1][r][q + k], b);
+                d = fmaf(g, pm[2][r][q + k], d);
+            }
+            hm[0][r][q] = a; hm[1][r][q] = b; hm[2][r][q] = d;
+        }
+        __syncthreads();
+        if (in_img) {
+            float a = 0.f, b = 0.f, d = 0.f;
+#pragma unroll
+            for (int k = 0; k < WIN; ++k) {
+                const float g = win.g[WIN - 1 - k];
+                a = fmaf(g, hm[0][ty + k][tx], a);
+                b = fmaf(g, hm[1][ty + k][tx], b);
+                d = fmaf(g, hm[2][ty + k][tx], d);
+            }
+            const float x = pred[pix + c], y = gt[pix + c];
+            const float df = x - y;
+            const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            out[c] = fmaf(w_l1, sgn, w_ss * (a + 2.f * x * b + y * d));
+        }
+    }
+    if (in_img) {
+        v_pred[pix] = out[0]; v_pred[pix + 1] = out[1]; v_pred[pix + 2] = out[2];
+    }
+}
+
+Win make_window(float sigma) {
+    Win w;
+    float fs = 0.f;
+    for (int k = 0; k < WIN; ++k) {
+        // same fp32 recipe as pytorch_msssim._fspecial_gauss_1d (fp32 exp, fp32 normalisation)
+        const float c = (float)(k - WIN / 2);
+        w.g[k] = expf(-(c * c) / (2.f * sigma * sigma));
+        fs += w.g[k];
+    }
+    for (int k = 0; k < WIN; ++k) w.g[k] /= fs;
+    return w;
+}
+
+}  // namespace
+
+static size_t partial_bytes(int h, int w) {
+    return (((size_t)sgn_cdiv(w, TS) * sgn_cdiv(h, TS) * 2 * sizeof(float)) + 255) & ~(size_t)255;
+}
+
+// workspace = [per-workgroup partial sums][3 maps x 3 channels x (h-10) x (w-10) floats]
+SGN_EXPORT size_t sgn_l1_ssim_workspace_bytes(int h, int w, int with_grad) {
+    if (h <= HALO || w <= HALO) return 256;
+    return partial_bytes(h, w) + (with_grad ? (size_t)9 * (h - HALO) * (w - HALO) * sizeof(float) : 0);
+}
+
+SGN_EXPORT int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt, float data_range,
+                               float *sums2 /*device: [sum |gt-pred|, sum ssim_map]*/, int with_grad, void *ws,
+                               size_t ws_bytes, sgn_stream_t stream) {
+    SGN_ARG_CHECK(h > HALO && w > HALO, -1);      // pytorch_msssim asserts the image is larger than the window
+    SGN_ARG_CHECK(pred && gt && sums2 && ws, -2);
+    SGN_ARG_CHECK(ws_bytes >= sgn_l1_ssim_workspace_bytes(h, w, with_grad), -3);
+    hipStream_t s = (hipStream_t)stream;
+    float *partials = (float *)ws;
+    float *dmaps = with_grad ? (float *)((char *)ws + partial_bytes(h, w)) : nullptr;
+    const Win win = make_window(1.5f);
+    const float C1 = (0.01f * data_range) * (0.01f * data_range), C2 = (0.03f * data_range) * (0.03f * data_range);
+    const dim3 grid(sgn_cdiv(w, TS), sgn_cdiv(h, TS));
+    sgn_timing_begin(SGN_T_LOSS_FWD, (void *)s);
+    hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, s, h, w, win, C1, C2, pred, gt, partials, dmaps);
+    hipLaunchKernelGGL(l1_ssim_reduce_kernel, dim3(1), dim3(256), 0, s, (int)(grid.x * grid.y), partials, sums2);
+    sgn_timing_end(SGN_T_LOSS_FWD, (void *)s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt, const void *ws,
+                               const float *gscale2 /*device: [d loss/d Ll1, d loss/d ssim]*/, float *v_pred,
+                               sgn_stream_t stream) {
+    SGN_ARG_CHECK(h > HALO && w > HALO, -1);
+    SGN_ARG_CHECK(pred && gt && ws && gscale2 && v_pred, -2);
+    hipStream_t s = (hipStream_t)stream;
+    const float *dmaps = (const float *)((const char *)ws + partial_bytes(h, w));
+    const Win win = make_window(1.5f);
+    sgn_timing_begin(SGN_T_LOSS_BWD, (void *)s);
+    hipLaunchKernelGGL(l1_ssim_bwd_kernel, dim3(sgn_cdiv(w, TS), sgn_cdiv(h, TS)), dim3(256), 0, s, h, w, win, pred, gt,
+                       dmaps, gscale2, v_pred);
+    sgn_timing_end(SGN_T_LOSS_BWD, (void *)s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,97 @@
+"""Photometric loss of the reference's training step on MI355X: L1 + SSIM, one kernel each way.
+
+SURVEY.md §8f row 3.  The reference computes (``street_gaussians_ns/sgn_splatfacto.py:1084-1087``)
+
+    Ll1 = torch.abs(gt_img - rgb).mean()
+    simloss = 1 - self.ssim(gt_img.permute(2, 0, 1)[None, ...], rgb.permute(2, 0, 1)[None, ...])
+    loss = (1 - ssim_lambda) * Ll1 + ssim_lambda * simloss
+
+with ``self.ssim = pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3)`` (``:330``): ten depthwise
+``conv2d`` launches forward plus their autograd graph.  Here both terms come out of ``csrc/loss.hip`` through the C
+ABI (``sgn_l1_ssim_fwd/bwd``) directly on the rasterizer's HWC image; fails loudly without the HIP library.
+
+* :func:`l1_ssim` — ``(Ll1, ssim)`` of two [H,W,3] images, gradient to ``pred``.
+* :class:`SSIM` — ``pytorch_msssim.SSIM`` call shape (``forward(X, Y)`` on [1,3,H,W]) for the import shim; the
+  permuted views the reference passes are recognised and used in place (no NCHW copy).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+
+
+class _L1SSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, gt, data_range):
+        L.require_device(pred, gt)
+        if pred.dim() != 3 or pred.shape[-1] != 3 or pred.shape != gt.shape:
+            raise ValueError(f"l1_ssim expects two [H,W,3] images, got {tuple(pred.shape)} and {tuple(gt.shape)}")
+        h, w = pred.shape[0], pred.shape[1]
+        if min(h, w) <= 10:
+            raise ValueError("images must be larger than the 11-tap SSIM window")   # pytorch_msssim asserts too
+        p, g = pred.contiguous().float(), gt.contiguous().float()
+        lib = L.load()
+        sums = torch.empty(2, dtype=torch.float32, device=p.device)
+        need_grad = int(bool(ctx.needs_input_grad[0]))
+        maps = L.workspace(lib.sgn_l1_ssim_workspace_bytes(h, w, need_grad), p.device)
+        L.check(lib.sgn_l1_ssim_fwd(h, w, L.ptr(p), L.ptr(g), float(data_range), L.ptr(sums), need_grad, L.ptr(maps),
+                                    maps.numel(), L.stream_ptr()), "sgn_l1_ssim_fwd")
+        ctx.hw = (h, w)
+        ctx.maps = maps
+        ctx.save_for_backward(p, g)
+        return sums[0] / (3.0 * h * w), sums[1] / (3.0 * (h - 10) * (w - 10))
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        p, g = ctx.saved_tensors
+        h, w = ctx.hw
+        gscale = torch.stack([g_l1.reshape(()), g_ssim.reshape(())]).float().contiguous()
+        v = torch.empty_like(p)
+        L.check(L.load().sgn_l1_ssim_bwd(h, w, L.ptr(p), L.ptr(g), L.ptr(ctx.maps), L.ptr(gscale), L.ptr(v),
+                                         L.stream_ptr()), "sgn_l1_ssim_bwd")
+        return v, None, None
+
+
+def l1_ssim(pred: torch.Tensor, gt: torch.Tensor, data_range: float = 1.0):
+    """(mean |gt - pred|, SSIM(gt, pred)) for [H,W,3] images; differentiable w.r.t. ``pred``."""
+    return _L1SSIM.apply(pred, gt, data_range)
+
+
+def photometric_loss(pred: torch.Tensor, gt: torch.Tensor, ssim_lambda: float = 0.2) -> torch.Tensor:
+    """``(1 - l) * Ll1 + l * (1 - ssim)`` — the sum of losses["Ll1"] and losses["simloss"] (``:1086-1087``)."""
+    Ll1, s = l1_ssim(pred, gt)
+    return (1.0 - ssim_lambda) * Ll1 + ssim_lambda * (1.0 - s)
+
+
+def _as_hwc(t: torch.Tensor) -> torch.Tensor:
+    """[1,3,H,W] -> [H,W,3] without a copy when ``t`` is the permuted view of an HWC image (the reference's case)."""
+    if t.dim() != 4 or t.shape[0] != 1 or t.shape[1] != 3:
+        raise ValueError(f"SSIM expects [1,3,H,W] inputs, got {tuple(t.shape)}")
+    return t[0].permute(1, 2, 0)
+
+
+class SSIM(torch.nn.Module):
+    """``pytorch_msssim.SSIM`` for the configuration the reference builds (``sgn_splatfacto.py:330``):
+    ``data_range`` free, ``size_average=True``, ``channel=3``, 11-tap window, sigma 1.5, 2-D images, batch 1.
+    Anything else raises.  SSIM is symmetric, so the gradient goes to whichever argument requires it."""
+
+    def __init__(self, data_range: float = 255, size_average: bool = True, win_size: int = 11,
+                 win_sigma: float = 1.5, channel: int = 3, spatial_dims: int = 2, K=(0.01, 0.03),
+                 nonnegative_ssim: bool = False):
+        super().__init__()
+        if not size_average or win_size != 11 or win_sigma != 1.5 or channel != 3 or spatial_dims != 2 \
+                or tuple(K) != (0.01, 0.03) or nonnegative_ssim:
+            raise NotImplementedError("sgn_rast.loss.SSIM implements the reference's configuration only")
+        self.data_range = float(data_range)
+
+    def forward(self, X: torch.Tensor, Y: torch.Tensor) -> torch.Tensor:
+        x, y = _as_hwc(X), _as_hwc(Y)
+        if x.requires_grad and y.requires_grad:
+            # both sides differentiable: d/dX from f(X, Y.detach()), d/dY from f(Y, X.detach()) (symmetry)
+            a = l1_ssim(x, y.detach(), self.data_range)[1]
+            b = l1_ssim(y, x.detach(), self.data_range)[1]
+            return a + b - a.detach()
+        if x.requires_grad:
+            return l1_ssim(x, y, self.data_range)[1]
+        return l1_ssim(y, x, self.data_range)[1]

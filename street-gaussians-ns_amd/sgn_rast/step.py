@@ -202,10 +202,13 @@ def composite_sky(out: SimpleNamespace, cam: Camera, sky_base: torch.Tensor, c2w
 
 def train_step(P: Dict[str, torch.Tensor], cam: Camera, w_img: torch.Tensor, w_a: torch.Tensor,
                sh_degree_to_use: int = 3, block_width: int = 16, with_depth: bool = False, ops=_hip_ops,
-               reducer=None, fused: bool = False, sky: Optional[dict] = None, **fused_kw) -> SimpleNamespace:
+               reducer=None, fused: bool = False, sky: Optional[dict] = None, gt: Optional[torch.Tensor] = None,
+               ssim_lambda: float = 0.2, loss_fn=None, **fused_kw) -> SimpleNamespace:
     """One "train-step image": project fwd -> SH fwd -> rasterize(return_alpha) fwd -> scalar loss ->
     full backward to means / log-scales / raw quats / opacity logits / SH coefficients.  ``sky`` =
-    {"base": cube map leaf [6,R,R,3], "c2w": [3,4]} adds the reference's sky-sphere branch."""
+    {"base": cube map leaf [6,R,R,3], "c2w": [3,4]} adds the reference's sky-sphere branch.  ``gt`` [H,W,3] swaps the
+    synthetic linear image loss for the reference's photometric loss (``sgn_splatfacto.py:1084-1087``: (1-l) L1 + l
+    (1 - SSIM) on ``rgb.clamp(max=1)``), through ``sgn_rast.loss`` or the ``loss_fn(rgb, gt, l)`` the tests pass."""
     for p in P.values():
         p.grad = None
     if sky is not None:
@@ -218,7 +221,13 @@ def train_step(P: Dict[str, torch.Tensor], cam: Camera, w_img: torch.Tensor, w_a
         composite_sky(out, cam, sky["base"], sky["c2w"], train=sky.get("train", True), fused=fused,
                       sky_fn=sky.get("fn"))
     n_pix = cam.height * cam.width
-    loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum()) / n_pix
+    if gt is not None:
+        if loss_fn is None:
+            from .loss import photometric_loss as loss_fn
+        rgb = out.rgb if sky is not None else torch.clamp(out.rgb, max=1.0)            # :969 (sky path clamps inside)
+        loss = loss_fn(rgb, gt, ssim_lambda) + (out.alpha * w_a).sum() / n_pix
+    else:
+        loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum()) / n_pix
     loss.backward()
     if reducer is not None:
         reducer.finish()

@@ -1,0 +1,40 @@
+"""SSIM oracle (oracle/torch_oracle.py:ssim) — properties of the published pytorch_msssim definition.
+PARITY UNPINNED (pytorch_msssim is neither vendored by the reference nor installed here)."""
+import torch
+
+from oracle import torch_oracle as O
+
+
+def test_window_is_normalised_gaussian():
+    g = O.ssim_window()
+    assert g.shape == (11,) and abs(float(g.sum()) - 1) < 1e-6
+    assert torch.allclose(g, g.flip(0)) and float(g[5]) == float(g.max())
+    assert abs(float(g[4] / g[5]) - float(torch.exp(torch.tensor(-1 / 4.5)))) < 1e-6
+
+
+def test_ssim_identity_symmetry_and_range():
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(1, 3, 40, 56, generator=g)
+    b = (a + 0.2 * torch.randn(1, 3, 40, 56, generator=g)).clamp(0, 1)
+    assert abs(float(O.ssim(a, a)) - 1) < 1e-6
+    assert abs(float(O.ssim(a, b)) - float(O.ssim(b, a))) < 1e-6
+    assert 0 < float(O.ssim(a, b)) < 1
+    assert float(O.ssim(a, 1 - a)) < 0.05          # anti-correlated structure
+
+
+def test_ssim_uses_valid_region_only():
+    """No padding: changing a border pixel only moves the windows that contain it; a constant image pair gives
+    (2 mu1 mu2 + C1)/(mu1^2 + mu2^2 + C1) exactly."""
+    x = torch.full((1, 3, 20, 20), 0.5)
+    y = torch.full((1, 3, 20, 20), 0.25)
+    C1 = 0.01 ** 2
+    expect = (2 * 0.5 * 0.25 + C1) / (0.25 + 0.0625 + C1)
+    assert abs(float(O.ssim(x, y)) - expect) < 1e-6
+
+
+def test_reference_loss_composition():
+    g = torch.Generator().manual_seed(1)
+    rgb, gt = torch.rand(32, 48, 3, generator=g), torch.rand(32, 48, 3, generator=g)
+    l1, s = O.l1_ssim_losses(rgb, gt)
+    assert abs(float(l1) - float((gt - rgb).abs().mean())) < 1e-7
+    assert abs(float(s) - float(O.ssim(gt.permute(2, 0, 1)[None], rgb.permute(2, 0, 1)[None]))) < 1e-7
