@@ -81,7 +81,8 @@ void sgn_set_batch_thresholds(int fwd_entries, int bwd_entries);
 #define SGN_T_SKY_BWD 13
 #define SGN_T_LOSS_FWD 14
 #define SGN_T_LOSS_BWD 15
-#define SGN_T_SLOTS 16
+#define SGN_T_ADAM 16
+#define SGN_T_SLOTS 17
 void sgn_timing_enable(int on); /* also clears recorded spans */
 int sgn_timing_get(int slot, int *count /*host*/, float *total_ms /*host*/);
 
@@ -278,6 +279,15 @@ int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt, float data
                     void *ws, size_t ws_bytes, sgn_stream_t stream);
 int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt, const void *ws, const float *gscale2,
                     float *v_pred, sgn_stream_t stream);
+
+/* One torch.optim.Adam step (amsgrad = False, weight_decay = 0, maximize = False) over `count` tensors in a single
+ * launch (optimiser set-up at sgn_config.py:71-108, eps = 1e-15).  Every array argument is a HOST
+ * array of length `count`; params / grads / exp_avgs / exp_avg_sqs hold DEVICE pointers to contiguous fp32 tensors of
+ * numel[i] elements; hyper-parameters are doubles (torch's Python scalars; rounded to fp32 once, where torch does);
+ * steps[i] is the step count after the increment (>= 1). */
+int sgn_adam_step(int count, float *const *params, const float *const *grads, float *const *exp_avgs,
+                  float *const *exp_avg_sqs, const int64_t *numel, const double *lr, const double *beta1,
+                  const double *beta2, const double *eps, const int64_t *steps, sgn_stream_t stream);
 
 #ifdef __cplusplus
 }

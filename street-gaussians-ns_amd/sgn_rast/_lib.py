@@ -50,6 +50,7 @@ SIGNATURES = {
     "sgn_l1_ssim_workspace_bytes": (_sz, [_i, _i, _i]),
     "sgn_l1_ssim_fwd": (_i, [_i, _i, _vp, _vp, _f, _vp, _i, _vp, _sz, _vp]),
     "sgn_l1_ssim_bwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_adam_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_sh_bwd_multi": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp]),
     "sgn_sh_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_sh_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
@@ -137,7 +138,7 @@ def workspace(nbytes: int, device) -> torch.Tensor:
 
 
 TIMING_SLOTS = ["project_fwd", "project_bwd", "sh_fwd", "sh_bwd", "scan", "map_isect", "sort", "tile_bins",
-                "pack_records", "raster_fwd", "raster_bwd", "unpack_grads", "sky_fwd", "sky_bwd", "loss_fwd", "loss_bwd"]
+                "pack_records", "raster_fwd", "raster_bwd", "unpack_grads", "sky_fwd", "sky_bwd", "loss_fwd", "loss_bwd", "adam"]
 
 
 def timing_enable(on: bool) -> None:
