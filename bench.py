@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--photometric", action="store_true",
                     help="use the reference's photometric loss (0.8 L1 + 0.2 (1 - SSIM) against a random target image, "
                          "sgn_splatfacto.py:1084-1087) through the fused HIP loss instead of the synthetic linear loss")
+    ap.add_argument("--adam", action="store_true",
+                    help="also take the optimiser step inside the timed region (multi-tensor Adam over the six "
+                         "parameter groups, lr/eps of sgn_config.py:71-108)")
     ap.add_argument("--dp-exchange", default="lowrank", choices=["lowrank", "dense"],
                     help="N>1: SH gradient via all-gathered low-rank factors (default) or dense all-reduce")
     return ap.parse_args()
@@ -192,10 +195,22 @@ def main():
     if args.photometric:
         gt_img = torch.rand(cam.height, cam.width, 3, generator=torch.Generator().manual_seed(5 + rank)).to(dev)
 
+    adam = None
+    if args.adam:
+        from sgn_rast import optim
+        lrs = {"means": 1.6e-4, "features_dc": 0.0025, "features_rest": 0.0025 / 20, "opacity_logits": 0.05,
+               "log_scales": 0.005, "quats": 0.001}
+        adam = [optim.FusedAdam([P[k]], lr=lrs[k], eps=1e-15) for k in P]
+        if sky is not None:
+            adam.append(optim.FusedAdam([sky["base"]], lr=0.01, eps=1e-15))
+
     def one_step(fused=(args.path == "fused")):
         if sg is None:
-            return step.train_step(P, cam, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer,
-                                   fused=fused, sky=sky, gt=gt_img)
+            out = step.train_step(P, cam, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer,
+                                  fused=fused, sky=sky, gt=gt_img)
+            if adam is not None:
+                optim.step_many(adam)
+            return out
         for m in sg[0]:
             for p in m.values():
                 p.grad = None
@@ -309,6 +324,9 @@ def main():
         if args.photometric:
             line["metric"] = line["metric"].replace("(fwd+bwd", "(photometric L1+SSIM loss, fwd+bwd")
             line["config"]["workload"] += "; loss = 0.8 L1 + 0.2 (1 - SSIM 11x11) vs a random target (fused HIP loss)"
+        if args.adam:
+            line["metric"] = line["metric"].replace("fwd+bwd", "fwd+bwd+Adam step")
+            line["config"]["workload"] += "; + multi-tensor Adam step over all parameter groups"
         if fused_extra is not None:
             line["fused_path"] = fused_extra
         if world == 1 and not args.no_cpu_baseline:
