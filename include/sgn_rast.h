@@ -289,6 +289,13 @@ int sgn_adam_step(int count, float *const *params, const float *const *grads, fl
                   float *const *exp_avg_sqs, const int64_t *numel, const double *lr, const double *beta1,
                   const double *beta2, const double *eps, const int64_t *steps, sgn_stream_t stream);
 
+/* Per-step densification statistics, SplatfactoModel.after_train (sgn_splatfacto.py:513-541), in one pass and without
+ * the host syncs of boolean-mask indexing.  first != 0 initialises the three running buffers (the reference's
+ * `is None` branches); max_dim = max(H, W) of the last rendered size. */
+int sgn_densify_stats(int n, const float *xys_grad /*[n,2]*/, const int32_t *radii /*[n]*/, float max_dim, int first,
+                      float *xys_grad_norm /*[n]*/, float *vis_counts /*[n]*/, float *max_2dsize /*[n]*/,
+                      sgn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,3 +123,46 @@ SGN_EXPORT int sgn_adam_step(int count, float *const *params, const float *const
     SGN_LAUNCH_CHECK();
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-step densification statistics (SplatfactoModel.after_train, street_gaussians_ns/sgn_splatfacto.py:513-541):
+//   grads = xys.grad.norm(dim=-1); visible = radii > 0
+//   first call : xys_grad_norm = grads (every Gaussian), vis_counts = 1, max_2Dsize = 0 then the max below
+//   afterwards : vis_counts[visible] += 1; xys_grad_norm[visible] += grads[visible]
+//   always     : max_2Dsize[visible] = max(max_2Dsize[visible], radii[visible] / max(H, W))
+// The reference does this with boolean-mask indexing (nonzero + index_put: several kernels and a host sync per
+// line); here it is one coalesced pass with no sync.
+namespace {
+__global__ __launch_bounds__(256) void densify_stats_kernel(int n, const float *__restrict__ xys_grad,
+                                                            const int32_t *__restrict__ radii, float max_dim,
+                                                            int first, float *__restrict__ grad_norm,
+                                                            float *__restrict__ vis_counts,
+                                                            float *__restrict__ max_2dsize) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float gx = xys_grad[2 * i], gy = xys_grad[2 * i + 1];
+    const float g = sqrtf(gx * gx + gy * gy);
+    const int rad = radii[i];
+    const bool vis = rad > 0;
+    if (first) {
+        grad_norm[i] = g;
+        vis_counts[i] = 1.f;
+        max_2dsize[i] = vis ? fmaxf(0.f, (float)rad / max_dim) : 0.f;
+    } else if (vis) {
+        vis_counts[i] = vis_counts[i] + 1.f;
+        grad_norm[i] = g + grad_norm[i];
+        max_2dsize[i] = fmaxf(max_2dsize[i], (float)rad / max_dim);
+    }
+}
+}  // namespace
+
+SGN_EXPORT int sgn_densify_stats(int n, const float *xys_grad, const int32_t *radii, float max_dim, int first,
+                                 float *xys_grad_norm, float *vis_counts, float *max_2dsize, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0 && max_dim > 0.f, -1);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(xys_grad && radii && xys_grad_norm && vis_counts && max_2dsize, -2);
+    hipLaunchKernelGGL(densify_stats_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, xys_grad,
+                       radii, max_dim, first, xys_grad_norm, vis_counts, max_2dsize);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

@@ -100,3 +100,39 @@ def test_more_tensors_than_one_table():
         oh.step(); orf.step()
     for p, r in zip(ps, rs):
         assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-7)
+
+
+def _after_train_reference(state, xys_grad, radii, last_size):
+    """SplatfactoModel.after_train restated line by line (sgn_splatfacto.py:520-541), plain torch on the CPU."""
+    visible_mask = (radii > 0).flatten()
+    grads = xys_grad.detach().norm(dim=-1)
+    if state["xys_grad_norm"] is None:
+        state["xys_grad_norm"] = grads
+        state["vis_counts"] = torch.ones_like(state["xys_grad_norm"])
+    else:
+        state["vis_counts"][visible_mask] = state["vis_counts"][visible_mask] + 1
+        state["xys_grad_norm"][visible_mask] = grads[visible_mask] + state["xys_grad_norm"][visible_mask]
+    if state["max_2Dsize"] is None:
+        state["max_2Dsize"] = torch.zeros_like(radii, dtype=torch.float32)
+    newradii = radii.detach()[visible_mask]
+    state["max_2Dsize"][visible_mask] = torch.maximum(state["max_2Dsize"][visible_mask],
+                                                      newradii / float(max(last_size[0], last_size[1])))
+
+
+def test_densify_stats_match_after_train():
+    from sgn_rast import densify
+    g = torch.Generator().manual_seed(2)
+    n = 5000
+    st_ref = {"xys_grad_norm": None, "vis_counts": None, "max_2Dsize": None}
+    st = densify.Stats()
+    for it in range(5):
+        xys_grad = torch.randn(n, 2, generator=g) * 1e-3
+        radii = torch.randint(-1, 40, (n,), generator=g, dtype=torch.int32).clamp(min=0)
+        radii[torch.rand(n, generator=g) < 0.3] = 0
+        _after_train_reference(st_ref, xys_grad.clone(), radii.clone(), (1280, 1920))
+        st.update(xys_grad.cuda(), radii.cuda(), (1280, 1920))
+    assert torch.equal(st.vis_counts.cpu(), st_ref["vis_counts"])
+    assert torch.allclose(st.xys_grad_norm.cpu(), st_ref["xys_grad_norm"], rtol=1e-6, atol=0)
+    assert torch.equal(st.max_2Dsize.cpu(), st_ref["max_2Dsize"])
+    st.reset()
+    assert st.xys_grad_norm is None
