@@ -168,7 +168,8 @@ def main():
     if world > 1:
         ex = None
         if args.dp_exchange == "lowrank":
-            ex = dp.SHGradExchange(P["features_dc"], P["features_rest"]).install()
+            # the harness knows its camera: gather 12 B of camera position instead of [N,3] view directions
+            ex = dp.SHGradExchange(P["features_dc"], P["features_rest"]).install().set_view(P["means"], cam.cam_pos)
         reducer = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex)
     n_gauss = P["means"].shape[0]
 

@@ -145,6 +145,15 @@ class SHGradExchange:
         self.active = self.world > 1 or (force and dist.is_initialized())  # force: exercise the path at world 1
         self._stash = None
         self._works = []
+        self._view = None
+
+    def set_view(self, means: torch.Tensor, cam_pos: torch.Tensor) -> "SHGradExchange":
+        """Drop-in ops only see view directions; a trainer that knows its camera can say so: with the (replicated)
+        world means and this rank's camera position registered, the exchange gathers the 12-byte camera position
+        instead of the [N,3] directions — half the bytes of the direction form.  ``means`` may be the parameter leaf
+        itself (read at exchange time); call again when the camera changes."""
+        self._view = (means, cam_pos)
+        return self
 
     def leaf_ids(self):
         return {id(self.dc), id(self.rest)}
@@ -173,6 +182,13 @@ class SHGradExchange:
 
     def _tap_dirs(self, viewdirs, v_colors, degree, k):
         if not self.active:
+            return
+        if self._view is not None and self._view[0].shape[0] == v_colors.shape[0]:
+            means, cam_pos = self._view
+            cam_pos = cam_pos.detach().reshape(3).to(v_colors.device, torch.float32)
+            self._stash = dict(kind="cam", degree=degree, k=k, v_all=self._gather(v_colors),
+                               cam_all=self._gather(cam_pos), means=means.detach().contiguous(), object_ids=None,
+                               poses=None, idft=None, keep=(v_colors, cam_pos))
             return
         self._stash = dict(kind="dirs", degree=degree, k=k, v_all=self._gather(v_colors),
                            dirs_all=self._gather(viewdirs), keep=(viewdirs, v_colors))

@@ -113,12 +113,16 @@ def _exchange_worker(rank, world, port, outdir):
     rgb = TO.spherical_harmonics(deg, dirs, torch.cat((dc, rest), dim=1))
     rgb.backward(v_rgb)
     local = torch.cat((dc.grad, rest.grad), dim=1).clone()
-    for mode in ("dirs", "cam"):
+    for mode in ("dirs", "cam", "view"):
         ex = dp.SHGradExchange(dc, rest, average=True, multi_fn=_sh_multi_torch)
         red = dp.GradAllReducer([dc, rest], big=[rest], sh_exchange=ex)
         assert red.params == [] and not red._handles               # SH leaves are left to the exchange
         if mode == "dirs":
             ex._tap_dirs(dirs, v_rgb, deg, k)
+        elif mode == "view":                                        # drop-in tap, camera registered by the trainer
+            ex.set_view(means, cam_pos)
+            ex._tap_dirs(dirs, v_rgb, deg, k)
+            assert ex._stash["kind"] == "cam"
         else:
             ex._tap_fused(means, cam_pos, v_rgb, deg, k, None, None, torch.ones(1, 1))
         red.finish()
@@ -138,7 +142,7 @@ def test_sh_low_rank_exchange_equals_dense_allreduce(tmp_path):
     for p in procs:
         p.join(timeout=500)
         assert p.exitcode == 0
-    for mode in ("dirs", "cam"):
+    for mode in ("dirs", "cam", "view"):
         res = [torch.load(os.path.join(tmp_path, f"{mode}{r}.pt")) for r in range(world)]
         dense_mean = (res[0][0] + res[1][0]) / world               # what a dense all-reduce (average) would give
         for r in range(world):
