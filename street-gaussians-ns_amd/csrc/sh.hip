@@ -52,6 +52,48 @@ __device__ __forceinline__ int sh_bases(float dx, float dy, float dz, int deg, f
     return 25;
 }
 
+// Copy this wave's `cnt` contiguous coefficient rows (KC floats each, 16-byte aligned span) into its LDS slab with
+// row stride LS.  ALL global loads are issued before the first LDS write: written as a plain `for (t...) { load;
+// store }` loop the compiler emits load -> s_waitcnt vmcnt(0) -> ds_write per iteration, i.e. 12 serialised HBM
+// round trips per wave (sh_fwd: 68 us -> see DESIGN.md).
+template <int KC, int LS>
+__device__ __forceinline__ void stage_rows(float *__restrict__ my, const float *__restrict__ src, int cnt, int lane) {
+    constexpr int NIT = (16 * KC + 63) / 64;          // float4 loads per lane for a full wave of 64 rows
+    const int total = cnt * KC;
+    if (reinterpret_cast<uintptr_t>(src) & 15) {      // a view with an odd storage offset: plain dword copy
+        for (int e = lane; e < total; e += 64) {
+            const int r = e / KC, c = e - r * KC;
+            my[r * LS + c] = src[e];
+        }
+        return;
+    }
+    const int n4 = total >> 2;
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+    float4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int t = lane + 64 * it;
+        v[it] = (t < n4) ? src4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int t = lane + 64 * it;
+        if (t < n4) {
+            const float f[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = 4 * t + j, r = e / KC, c = e - r * KC;
+                my[r * LS + c] = f[j];
+            }
+        }
+    }
+    const int e = (n4 << 2) + lane;                   // up to three trailing floats of a partial wave
+    if (lane < (total & 3)) {
+        const int r = e / KC, c = e - r * KC;
+        my[r * LS + c] = src[e];
+    }
+}
+
 // One wave (64 lanes) per 64 Gaussians; a block is WAVES waves with private LDS slabs.
 // KC = K*3 dwords per row; LDS row stride KC+1 (odd) => conflict-free per-lane row walks.
 template <int K, int WAVES>
@@ -64,22 +106,7 @@ __global__ __launch_bounds__(WAVES * 64) void sh_fwd_kernel(int n, int deg, cons
     const int g0 = (blockIdx.x * WAVES + wave) * 64;
     const int cnt = max(0, min(64, n - g0));
     float *my = lds[wave];
-    const float *src = coeffs + (size_t)g0 * KC;
-    const int total = cnt * KC;
-    if constexpr (KC % 4 == 0) {
-        const float4 *src4 = reinterpret_cast<const float4 *>(src);
-        for (int t = lane; t < total / 4; t += 64) {
-            const float4 v = src4[t];
-            const int e = t * 4, r = e / KC, c = e - r * KC;  // KC%4==0: a float4 never straddles rows
-            float *d = my + r * LS + c;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-    } else {
-        for (int e = lane; e < total; e += 64) {
-            const int r = e / KC, c = e - r * KC;
-            my[r * LS + c] = src[e];
-        }
-    }
+    stage_rows<KC, LS>(my, coeffs + (size_t)g0 * KC, cnt, lane);
     __syncthreads();
     if (lane >= cnt) return;
     const int i = g0 + lane;
@@ -170,14 +197,7 @@ __global__ __launch_bounds__(WAVES * 64) void sh_fwd_fused_kernel(
     const int g0 = (blockIdx.x * WAVES + wave) * 64;
     const int cnt = max(0, min(64, n - g0));
     float *my = lds[wave];
-    if constexpr (KC > 0) {
-        const float *src = rest + (size_t)g0 * KC;
-        const int total = cnt * KC;
-        for (int e = lane; e < total; e += 64) {
-            const int r = e / KC, c = e - r * KC;
-            my[r * LS + c] = src[e];
-        }
-    }
+    if constexpr (KC > 0) stage_rows<KC, LS>(my, rest + (size_t)g0 * KC, cnt, lane);
     __syncthreads();
     if (lane >= cnt) return;
     const int i = g0 + lane;
