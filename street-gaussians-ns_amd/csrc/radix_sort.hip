@@ -43,10 +43,16 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(uint32_t n, const K
     for (int d = threadIdx.x; d < NB; d += RS_THREADS) hist[d] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE;
+    K kk[RS_IPT];                       // all loads first: a load -> LDS-atomic loop waits out HBM once per key
 #pragma unroll
     for (int k = 0; k < RS_IPT; ++k) {
         const uint32_t i = base + k * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&hist[digit_of<K>(keys[i], shift, dmask)], 1u);
+        kk[k] = (i < n) ? keys[i] : (K)0;
+    }
+#pragma unroll
+    for (int k = 0; k < RS_IPT; ++k) {
+        const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&hist[digit_of<K>(kk[k], shift, dmask)], 1u);
     }
     __syncthreads();
     for (int d = threadIdx.x; d < NB; d += RS_THREADS) table[(size_t)d * nblk + blockIdx.x] = hist[d];
@@ -128,12 +134,19 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     uint32_t rank[RS_IPT];
     volatile uint32_t *mycnt = wcnt[wave];
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // every key / value of the tile is requested before the first ranking step: the volatile LDS counters below
+    // pin program order, so loads left inside the ranking loop are waited for one HBM round trip at a time
 #pragma unroll
     for (int r = 0; r < RS_IPT; ++r) {
         const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;  // index inside the tile
         const bool valid = li < tile_cnt;
         key[r] = valid ? keys_in[tile_base + li] : (K)~(K)0;
         if constexpr (HAS_VAL) val[r] = valid ? vals_in[tile_base + li] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) {
+        const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;
+        const bool valid = li < tile_cnt;
         const unsigned d = digit_of<K>(key[r], shift, dmask);
         unsigned long long m = __ballot(valid);
 #pragma unroll
