@@ -51,13 +51,29 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(int H, int W, Win win,
     const int ox = x0 + tx, oy = y0 + ty;                     // pixel (L1) = output position (SSIM)
     const bool in_img = ox < W && oy < H, in_out = ox < Wo && oy < Ho;
     const int rowlen = W * 3;
-    for (int e = tid; e < PS * ROWF; e += 256) {
-        const int r = e / ROWF, j = e - r * ROWF;
-        const int iy = y0 + r, gx = x0 * 3 + j;
-        const bool ok = iy < H && gx < rowlen;
-        const size_t idx = (size_t)iy * rowlen + gx;
-        px[r][j] = ok ? pred[idx] : 0.f;
-        py[r][j] = ok ? gt[idx] : 0.f;
+    {   // all patch loads are issued before the first LDS write (a load -> store loop is compiled to one HBM round
+        // trip per iteration: s_waitcnt vmcnt(0) after every global_load)
+        constexpr int NL = (PS * ROWF + 255) / 256;
+        float va[NL], vb[NL];
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            const int e = tid + it * 256;
+            const int r = e / ROWF, j = e - r * ROWF;
+            const int iy = y0 + r, gx = x0 * 3 + j;
+            const bool ok = e < PS * ROWF && iy < H && gx < rowlen;
+            const size_t idx = (size_t)iy * rowlen + gx;
+            va[it] = ok ? pred[idx] : 0.f;
+            vb[it] = ok ? gt[idx] : 0.f;
+        }
+#pragma unroll
+        for (int it = 0; it < NL; ++it) {
+            const int e = tid + it * 256;
+            if (e < PS * ROWF) {
+                const int r = e / ROWF, j = e - r * ROWF;
+                px[r][j] = va[it];
+                py[r][j] = vb[it];
+            }
+        }
     }
     __syncthreads();
     float l1 = 0.f, ss = 0.f;
@@ -152,14 +168,28 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(int H, int W, Win win,
     for (int c = 0; c < 3; ++c) {
         __syncthreads();
         // outputs p that see pixel q: p in [q - 10, q]; patch row r <-> p_y = y0 - 10 + r
-        for (int e = tid; e < PS * PS; e += 256) {
-            const int r = e / PS, q = e - r * PS;
-            const int py_ = y0 - HALO + r, px_ = x0 - HALO + q;
-            const bool ok = py_ >= 0 && px_ >= 0 && py_ < Ho && px_ < Wo;
-            const size_t o = (size_t)c * plane + (size_t)py_ * Wo + px_;
-            pm[0][r][q] = ok ? dmaps[o] : 0.f;
-            pm[1][r][q] = ok ? dmaps[3 * plane + o] : 0.f;
-            pm[2][r][q] = ok ? dmaps[6 * plane + o] : 0.f;
+        {
+            constexpr int NL = (PS * PS + 255) / 256;
+            float v0[NL], v1[NL], v2[NL];
+#pragma unroll
+            for (int it = 0; it < NL; ++it) {
+                const int e = tid + it * 256;
+                const int r = e / PS, q = e - r * PS;
+                const int py_ = y0 - HALO + r, px_ = x0 - HALO + q;
+                const bool ok = e < PS * PS && py_ >= 0 && px_ >= 0 && py_ < Ho && px_ < Wo;
+                const size_t o = (size_t)c * plane + (size_t)py_ * Wo + px_;
+                v0[it] = ok ? dmaps[o] : 0.f;
+                v1[it] = ok ? dmaps[3 * plane + o] : 0.f;
+                v2[it] = ok ? dmaps[6 * plane + o] : 0.f;
+            }
+#pragma unroll
+            for (int it = 0; it < NL; ++it) {
+                const int e = tid + it * 256;
+                if (e < PS * PS) {
+                    const int r = e / PS, q = e - r * PS;
+                    pm[0][r][q] = v0[it]; pm[1][r][q] = v1[it]; pm[2][r][q] = v2[it];
+                }
+            }
         }
         __syncthreads();
         for (int e = tid; e < PS * TS; e += 256) {
