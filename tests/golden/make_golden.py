@@ -1,4 +1,4 @@
-"""Regenerates tests/golden/step_c1small.npz from the CPU oracle.
+"""Regenerates tests/golden/step_c1small.npz and tests/golden/aux_sky_loss.npz from the CPU oracle.
 
     python tests/golden/make_golden.py
 
@@ -36,8 +36,29 @@ def build():
     return {k: v.detach().cpu().numpy() for k, v in d.items()}
 
 
+def build_aux():
+    """Sky cube map + photometric loss: same status — snapshots of the oracle
+    restatements of nvdiffrast / pytorch_msssim behaviour, neither of which is available here."""
+    from oracle import torch_oracle as O
+    g = torch.Generator().manual_seed(21)
+    tex = torch.rand(6, 8, 8, 3, generator=g).requires_grad_(True)
+    c2w = torch.tensor([[0.36, -0.48, 0.8, 1.0], [0.8, 0.6, 0.0, 2.0], [-0.48, 0.64, 0.6, 3.0]])
+    dirs = O.env_light_directions(24, 40, 14.0, 13.0, 20.0, 12.0, c2w)        # wide FOV: several faces
+    sky = O.cube_texture(tex, dirs)
+    w = torch.rand(24, 40, 3, generator=g)
+    (sky * w).sum().backward()
+    pred = torch.rand(40, 56, 3, generator=g).requires_grad_(True)
+    gt = (pred.detach() + 0.2 * torch.randn(40, 56, 3, generator=g)).clamp(0, 1)
+    l1, s = O.l1_ssim_losses(pred, gt)
+    (0.8 * l1 + 0.2 * (1 - s)).backward()
+    d = dict(sky_tex=tex, sky_c2w=c2w, sky_dirs=dirs, sky_out=sky, sky_w=w, sky_tex_grad=tex.grad,
+             loss_pred=pred, loss_gt=gt, loss_l1=l1.reshape(1), loss_ssim=s.reshape(1), loss_pred_grad=pred.grad)
+    return {k: v.detach().cpu().numpy() for k, v in d.items()}
+
+
 if __name__ == "__main__":
-    d = build()
-    path = os.path.join(HERE, "step_c1small.npz")
-    np.savez_compressed(path, **d)
-    print("wrote", path, os.path.getsize(path), "bytes;", {k: v.shape for k, v in d.items()})
+    for name, fn in (("step_c1small.npz", build), ("aux_sky_loss.npz", build_aux)):
+        d = fn()
+        path = os.path.join(HERE, name)
+        np.savez_compressed(path, **d)
+        print("wrote", path, os.path.getsize(path), "bytes;", {k: v.shape for k, v in d.items()})
