@@ -87,15 +87,21 @@ class GradAllReducer:
         self._pending.append((work, p))
 
     def finish(self) -> None:
-        """Call after ``loss.backward()``: reduces the small bucket, waits for the async ones."""
+        """Call after ``loss.backward()``: reduces the small bucket, waits for the async ones.  The bucket's
+        all-reduce is launched first and runs on the collective stream while the SH exchange rebuilds the dense SH
+        gradient on the compute stream."""
+        small, flat, work = [], None, None
+        if self.world > 1:
+            small = [p for p in self.params if id(p) not in self.big_ids and p.grad is not None]
+            if small:
+                flat = torch.cat([p.grad.reshape(-1) for p in small])
+                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.sh_exchange is not None:
             self.sh_exchange.finish()
         if self.world == 1:
             return
-        small = [p for p in self.params if id(p) not in self.big_ids and p.grad is not None]
-        if small:
-            flat = torch.cat([p.grad.reshape(-1) for p in small])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if work is not None:
+            work.wait()
             if self.average:
                 flat /= self.world
             off = 0
