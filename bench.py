@@ -63,6 +63,9 @@ def parse():
     ap.add_argument("--adam", action="store_true",
                     help="also take the optimiser step inside the timed region (multi-tensor Adam over the six "
                          "parameter groups, lr/eps of sgn_config.py:71-108)")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="single process: still create a 1-rank RCCL group and run the data-parallel exchange "
+                         "(self-test of the N>1 code path on one GPU; not a scaling number)")
     ap.add_argument("--dp-exchange", default="lowrank", choices=["lowrank", "dense"],
                     help="N>1: SH gradient via all-gathered low-rank factors (default) or dense all-reduce")
     return ap.parse_args()
@@ -151,6 +154,12 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(args.scene, args.n, args.cpu_rows, args.cpu_frac)), flush=True)
         return
+    # The contract is ONE JSON line on stdout.  RCCL prints a version banner through C stdio (buffered, flushed at
+    # exit, i.e. AFTER a Python print), on every rank.  Keep the real stdout aside and point fd 1 at stderr for the
+    # whole run; rank 0 writes the line to the saved descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     from sgn_rast import _lib as L, dp, scenes, step
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); run it under gpurun")
@@ -158,6 +167,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L.load()
+    force_dp = args.force_dp and world == 1
+    if force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
 
     cam, raw = scenes.make_scene(args.scene, seed=0, yaw=0.01 * rank, device=dev, n_override=args.n)
     if args.street:
@@ -165,12 +179,13 @@ def main():
     P = step.leaf_params(raw)
     w_img, w_a = step.loss_weights(cam, seed=1000 + rank, device=dev)
     reducer = None
-    if world > 1:
+    if world > 1 or force_dp:
         ex = None
         if args.dp_exchange == "lowrank":
             # the harness knows its camera: gather 12 B of camera position instead of [N,3] view directions
-            ex = dp.SHGradExchange(P["features_dc"], P["features_rest"]).install().set_view(P["means"], cam.cam_pos)
-        reducer = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex)
+            ex = dp.SHGradExchange(P["features_dc"], P["features_rest"], force=force_dp).install().set_view(
+                P["means"], cam.cam_pos)
+        reducer = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex, force=force_dp)
     n_gauss = P["means"].shape[0]
 
     sg = None
@@ -336,8 +351,8 @@ def main():
             except Exception as e:  # the GPU number stands on its own
                 line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {e!r}"}
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if world > 1 or force_dp:
         torch.distributed.destroy_process_group()
 
 

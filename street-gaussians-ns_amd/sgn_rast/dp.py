@@ -67,7 +67,8 @@ class GradAllReducer:
     mean, so DP over views averages)."""
 
     def __init__(self, params: Sequence[torch.Tensor], big: Iterable[torch.Tensor] = (),
-                 average: bool = True, group=None, sh_exchange: "Optional[SHGradExchange]" = None):
+                 average: bool = True, group=None, sh_exchange: "Optional[SHGradExchange]" = None,
+                 force: bool = False):
         self.sh_exchange = sh_exchange
         skip = sh_exchange.leaf_ids() if sh_exchange is not None else set()
         self.params = [p for p in params if id(p) not in skip]
@@ -75,9 +76,10 @@ class GradAllReducer:
         self.average = average
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())   # force: run the collectives at world 1
         self._pending: List = []
         self._handles = []
-        if self.world > 1:
+        if self.active:
             for p in self.params:
                 if id(p) in self.big_ids:
                     self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
@@ -91,14 +93,14 @@ class GradAllReducer:
         all-reduce is launched first and runs on the collective stream while the SH exchange rebuilds the dense SH
         gradient on the compute stream."""
         small, flat, work = [], None, None
-        if self.world > 1:
+        if self.active:
             small = [p for p in self.params if id(p) not in self.big_ids and p.grad is not None]
             if small:
                 flat = torch.cat([p.grad.reshape(-1) for p in small])
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.sh_exchange is not None:
             self.sh_exchange.finish()
-        if self.world == 1:
+        if not self.active:
             return
         if work is not None:
             work.wait()
