@@ -147,7 +147,10 @@ int sgn_sh_bwd_fused(int n, int k, int degree, const float *means, const float *
  * of the two must be given.  Replaces the dense [n,k,3] all-reduce: 2-4x less traffic on the xGMI links. */
 int sgn_sh_bwd_multi(int n, int k, int degree, int n_views, const float *viewdirs_all, const float *means,
                      const float *cam_pos_all, const int32_t *object_ids, const float *poses,
-                     const float *v_colors_all, float scale, float *v_coeffs /*[n,k,3]*/, sgn_stream_t stream);
+                     const float *v_colors_all, float scale, float *v_coeffs /*[n,k,3]; [n,k-1,3] when v_dc is given*/,
+                     float *v_dc /*NULL, or [n,3]: band 0 goes here (the reference keeps features_dc and
+                                   features_rest as separate leaves, sgn_splatfacto.py:251-268)*/,
+                     sgn_stream_t stream);
 
 /* _C.compute_sh_forward / _C.compute_sh_backward (gsplat/sh.py; reference call sites
  * sgn_splatfacto.py:939, sgn_splatfacto_scene_graph.py:285).  coeffs [n,k,3], k in

@@ -292,7 +292,8 @@ __global__ __launch_bounds__(WAVES * 64) void sh_bwd_multi_kernel(
     int n, int deg, int n_views, const float *__restrict__ dirs_all /*[R,n,3] or null*/,
     const float *__restrict__ means /*[n,3] or null*/, const float *__restrict__ cam_pos /*[R,3] or null*/,
     const int32_t *__restrict__ object_ids, const float *__restrict__ poses,
-    const float *__restrict__ v_colors_all /*[R,n,3]*/, float scale, float *__restrict__ v_coeffs) {
+    const float *__restrict__ v_colors_all /*[R,n,3]*/, float scale, float *__restrict__ v_coeffs,
+    float *__restrict__ v_dc /*null: v_coeffs is [n,K,3]; else v_dc [n,3] takes band 0, v_coeffs [n,K-1,3] the rest*/) {
     constexpr int KC = K * 3, LS = (KC | 1);
     __shared__ float lds[WAVES][64 * LS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -327,11 +328,23 @@ __global__ __launch_bounds__(WAVES * 64) void sh_bwd_multi_kernel(
         for (int e = 0; e < KC; ++e) row[e] = acc[e] * scale;
     }
     __syncthreads();
-    float *dst = v_coeffs + (size_t)g0 * KC;
     const int total = cnt * KC;
-    for (int e = lane; e < total; e += 64) {
-        const int r = e / KC, c = e - r * KC;
-        dst[e] = my[r * LS + c];
+    if (v_dc == nullptr) {
+        float *dst = v_coeffs + (size_t)g0 * KC;
+        for (int e = lane; e < total; e += 64) {
+            const int r = e / KC, c = e - r * KC;
+            dst[e] = my[r * LS + c];
+        }
+    } else {                       // the two leaves of the reference (features_dc, features_rest) get their own tensor
+        for (int e = lane; e < cnt * 3; e += 64) v_dc[(size_t)g0 * 3 + e] = my[(e / 3) * LS + (e % 3)];
+        if constexpr (KC > 3) {
+            constexpr int RC = KC - 3;
+            float *dst = v_coeffs + (size_t)g0 * RC;
+            for (int e = lane; e < cnt * RC; e += 64) {
+                const int r = e / RC, c = e - r * RC;
+                dst[e] = my[r * LS + 3 + c];
+            }
+        }
     }
 }
 
@@ -466,30 +479,31 @@ SGN_EXPORT int sgn_sh_bwd_fused(int n, int k, int degree, const float *means, co
 template <int K>
 static void launch_bwd_multi(int n, int deg, int R, const float *dirs_all, const float *means, const float *cam_pos,
                              const int32_t *oid, const float *poses, const float *v_all, float scale, float *out,
-                             hipStream_t s) {
+                             float *out_dc, hipStream_t s) {
     constexpr int WAVES = (K > 16) ? 2 : 4;
     hipLaunchKernelGGL((sh_bwd_multi_kernel<K, WAVES>), dim3(sgn_cdiv(n, WAVES * 64)), dim3(WAVES * 64), 0, s, n, deg, R,
-                       dirs_all, means, cam_pos, oid, poses, v_all, scale, out);
+                       dirs_all, means, cam_pos, oid, poses, v_all, scale, out, out_dc);
 }
 
 SGN_EXPORT int sgn_sh_bwd_multi(int n, int k, int degree, int n_views, const float *viewdirs_all, const float *means,
                                 const float *cam_pos_all, const int32_t *object_ids, const float *poses,
-                                const float *v_colors_all, float scale, float *v_coeffs, sgn_stream_t stream) {
+                                const float *v_colors_all, float scale, float *v_coeffs, float *v_dc,
+                                sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0 && n_views >= 1, -1);
     SGN_ARG_CHECK(degree >= 0 && degree <= 4, -2);
     SGN_ARG_CHECK(k == 1 || k == 4 || k == 9 || k == 16 || k == 25, -3);
     SGN_ARG_CHECK((degree + 1) * (degree + 1) <= k, -4);
     if (n == 0) return 0;
-    SGN_ARG_CHECK(v_colors_all && v_coeffs, -5);
+    SGN_ARG_CHECK(v_colors_all && (v_coeffs || (v_dc && k == 1)), -5);
     SGN_ARG_CHECK((viewdirs_all != nullptr) != (means != nullptr && cam_pos_all != nullptr), -6);
     hipStream_t s = (hipStream_t)stream;
     sgn_timing_begin(SGN_T_SH_BWD, s);
     switch (k) {
-        case 1: launch_bwd_multi<1>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, s); break;
-        case 4: launch_bwd_multi<4>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, s); break;
-        case 9: launch_bwd_multi<9>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, s); break;
-        case 16: launch_bwd_multi<16>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, s); break;
-        default: launch_bwd_multi<25>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, s); break;
+        case 1: launch_bwd_multi<1>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, v_dc, s); break;
+        case 4: launch_bwd_multi<4>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, v_dc, s); break;
+        case 9: launch_bwd_multi<9>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, v_dc, s); break;
+        case 16: launch_bwd_multi<16>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, v_dc, s); break;
+        default: launch_bwd_multi<25>(n, degree, n_views, viewdirs_all, means, cam_pos_all, object_ids, poses, v_colors_all, scale, v_coeffs, v_dc, s); break;
     }
     sgn_timing_end(SGN_T_SH_BWD, s);
     SGN_LAUNCH_CHECK();

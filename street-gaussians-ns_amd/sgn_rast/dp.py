@@ -124,14 +124,16 @@ class GradAllReducer:
 
 
 def _sh_multi_hip(degree, k, dirs_all, means, cam_all, object_ids, poses, v_all, scale):
-    """[R,N,3] gathered factors -> summed [N,K,3] SH gradient on the GPU (sgn_sh_bwd_multi)."""
+    """[R,N,3] gathered factors -> summed SH gradient on the GPU (sgn_sh_bwd_multi), already split into the two
+    leaves the reference keeps: (band 0 [N,1,3], bands 1.. [N,K-1,3]) — no slicing copies afterwards."""
     from . import _lib as L
     R, n = v_all.shape[0], v_all.shape[1]
-    out = torch.empty(n, k, 3, dtype=torch.float32, device=v_all.device)
+    dc = torch.empty(n, 1, 3, dtype=torch.float32, device=v_all.device)
+    rest = torch.empty(n, k - 1, 3, dtype=torch.float32, device=v_all.device)
     L.check(L.load().sgn_sh_bwd_multi(n, k, degree, R, L.ptr(dirs_all), L.ptr(means), L.ptr(cam_all),
                                       L.ptr(object_ids), L.ptr(poses), L.ptr(v_all.contiguous()), float(scale),
-                                      L.ptr(out), L.stream_ptr()), "sgn_sh_bwd_multi")
-    return out
+                                      L.ptr(rest) if k > 1 else None, L.ptr(dc), L.stream_ptr()), "sgn_sh_bwd_multi")
+    return dc, rest
 
 
 class SHGradExchange:
@@ -189,23 +191,27 @@ class SHGradExchange:
         return out
 
     def _tap_dirs(self, viewdirs, v_colors, degree, k):
+        """Returns True when the exchange takes the SH gradient over: the caller then skips its own dense backward
+        (the local [N,K,3] gradient would be overwritten by the cross-rank sum anyway)."""
         if not self.active:
-            return
+            return False
         if self._view is not None and self._view[0].shape[0] == v_colors.shape[0]:
             means, cam_pos = self._view
             cam_pos = cam_pos.detach().reshape(3).to(v_colors.device, torch.float32)
             self._stash = dict(kind="cam", degree=degree, k=k, v_all=self._gather(v_colors),
                                cam_all=self._gather(cam_pos), means=means.detach().contiguous(), object_ids=None,
                                poses=None, idft=None, keep=(v_colors, cam_pos))
-            return
+            return True
         self._stash = dict(kind="dirs", degree=degree, k=k, v_all=self._gather(v_colors),
                            dirs_all=self._gather(viewdirs), keep=(viewdirs, v_colors))
+        return True
 
     def _tap_fused(self, means, cam_pos, v_eff, degree, k, object_ids, poses, idft):
         if not self.active:
-            return
+            return False
         self._stash = dict(kind="cam", degree=degree, k=k, v_all=self._gather(v_eff), cam_all=self._gather(cam_pos),
                            means=means, object_ids=object_ids, poses=poses, idft=idft, keep=(v_eff, cam_pos))
+        return True
 
     def finish(self) -> None:
         if not self.active or self._stash is None:
@@ -220,16 +226,21 @@ class SHGradExchange:
         else:
             v = self.multi_fn(s["degree"], s["k"], None, s["means"], s["cam_all"], s["object_ids"], s["poses"],
                               s["v_all"], scale)
+        if isinstance(v, tuple):                       # already split into the two leaves (HIP path)
+            v0, v_rest = v
+        else:                                          # dense [N,K,3] (the torch stand-in used by the gloo tests)
+            v0, v_rest = v[:, 0:1, :], v[:, 1:, :]
         F = self.dc.shape[1]
         if F == 1:
-            dc_grad = v[:, 0:1, :]
+            dc_grad = v0
         else:  # Fourier DC: d dc_eff / d features_dc[:, f] = idft[object, f]
             idft, oid = s["idft"], s["object_ids"]
-            w = idft[oid.long()] if oid is not None else idft[:1].expand(v.shape[0], F)
-            dc_grad = w[:, :, None] * v[:, 0:1, :]
-        for leaf, g in ((self.dc, dc_grad), (self.rest, v[:, 1:, :])):
+            w = idft[oid.long()] if oid is not None else idft[:1].expand(v0.shape[0], F)
+            dc_grad = w[:, :, None] * v0
+        for leaf, g in ((self.dc, dc_grad), (self.rest, v_rest)):
+            g = g if g.is_contiguous() else g.contiguous()
             if leaf.grad is None:
-                leaf.grad = g.contiguous().clone()
+                leaf.grad = g if g.shape == leaf.shape else g.reshape(leaf.shape)
             else:
                 leaf.grad.copy_(g)
 

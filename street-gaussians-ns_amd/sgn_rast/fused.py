@@ -152,7 +152,8 @@ class _SHFused(Function):
             v_eff = _f32c(v_colors)
             if post:
                 v_eff = v_eff * (colors > 0)
-            _sh_bwd_tap(means, cam, v_eff, degree, k, oid, pos, idft)
+            if _sh_bwd_tap(means, cam, v_eff, degree, k, oid, pos, idft):
+                return (None,) * 9       # the data-parallel exchange rebuilds the (summed) gradient itself
         v_dc = torch.empty(n, F, 3, dtype=torch.float32, device=dev)
         v_rest = torch.empty(n, k - 1, 3, dtype=torch.float32, device=dev) if has_rest else None
         L.check(L.load().sgn_sh_bwd_fused(n, k, degree, L.ptr(means), L.ptr(cam), F, L.ptr(oid), L.ptr(idft), L.ptr(pos), post,

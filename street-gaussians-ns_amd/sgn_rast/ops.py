@@ -84,8 +84,8 @@ class _SphericalHarmonics(Function):
         (viewdirs,) = ctx.saved_tensors
         n = v_colors.shape[0]
         v_colors = _f32c(v_colors)
-        if _sh_bwd_tap is not None:
-            _sh_bwd_tap(viewdirs, v_colors, ctx.degrees_to_use, ctx.k)
+        if _sh_bwd_tap is not None and _sh_bwd_tap(viewdirs, v_colors, ctx.degrees_to_use, ctx.k):
+            return None, None, None      # the data-parallel exchange rebuilds the (summed) gradient itself
         v_coeffs = torch.empty(n, ctx.k, 3, dtype=torch.float32, device=v_colors.device)
         L.check(L.load().sgn_sh_bwd(n, ctx.k, ctx.degrees_to_use, L.ptr(viewdirs), L.ptr(v_colors),
                                     L.ptr(v_coeffs), L.stream_ptr()), "sgn_sh_bwd")

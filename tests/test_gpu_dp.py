@@ -28,8 +28,10 @@ def test_sh_bwd_multi_equals_sum_of_single_view_backwards(k, deg, R):
         L.check(lib.sgn_sh_bwd(n, k, deg, L.ptr(dirs_all[r].contiguous()), L.ptr(v_all[r].contiguous()), L.ptr(one),
                                L.stream_ptr()), "sh_bwd")
         ref += one
-    a = dp._sh_multi_hip(deg, k, dirs_all.contiguous(), None, None, None, None, v_all, 0.5)
-    b = dp._sh_multi_hip(deg, k, None, means, cams.contiguous(), None, None, v_all, 0.5)
+    # the product returns the two leaves of the reference (band 0, bands 1..) separately
+    a = torch.cat(dp._sh_multi_hip(deg, k, dirs_all.contiguous(), None, None, None, None, v_all, 0.5), dim=1)
+    b = torch.cat(dp._sh_multi_hip(deg, k, None, means, cams.contiguous(), None, None, v_all, 0.5), dim=1)
+    assert a.shape == (n, k, 3)
     assert rel_l2(a, 0.5 * ref) < 1e-6 and rel_l2(b, 0.5 * ref) < 1e-6
     assert float(a[:, (deg + 1) ** 2:, :].abs().max() if (deg + 1) ** 2 < k else 0.0) == 0.0
 
@@ -54,8 +56,8 @@ def test_exchange_and_reducer_over_single_rank_rccl_group(fused):
         step.train_step(Pa, cam, w_img, w_a, fused=fused)
         Pb = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
         ex = dp.SHGradExchange(Pb["features_dc"], Pb["features_rest"], force=True).install()
-        red = dp.GradAllReducer(list(Pb.values()), big=[Pb["features_rest"]], sh_exchange=ex)
-        red.world = 2  # pretend, so the flat-bucket path runs too; SUM over 1 rank then /2
+        red = dp.GradAllReducer(list(Pb.values()), big=[Pb["features_rest"]], sh_exchange=ex, force=True)
+        red.world = 2  # pretend: SUM over 1 rank, then the averaging divides the flat bucket by 2
         try:
             step.train_step(Pb, cam, w_img, w_a, fused=fused, reducer=red)
         finally:
