@@ -42,7 +42,9 @@ const char *sgn_last_error(void);
  * oracle/c/sgn_oracle.c exp_portable), 0 (default) = hardware v_exp_f32. Process-global. */
 void sgn_set_exact_exp(int on);
 int sgn_get_exact_exp(void);
-/* Tuning switch for the backward's wave reduction: 0 = ds_bpermute shuffles, 1 = DPP row ops. */
+/* Backward wave reduction: 1 (default) = transposed reduction on v_permlane32_swap / v_permlane16_swap + DPP row
+ * adds (8 swaps + 12 DPP adds for the nine per-Gaussian sums); 0 = nine butterfly reductions (54 shuffles), kept for
+ * A/B measurements and tests. */
 void sgn_set_reduce_mode(int mode);
 /* Timing ablations for profiles/ ONLY (results become wrong): bit0 = no gradient atomics,
  * bit1 = no wave reduction.  0 = normal operation. */

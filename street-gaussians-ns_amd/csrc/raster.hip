@@ -8,17 +8,19 @@
 // CDNA4 design (not the upstream 256-thread-tile / shared-memory-batch shape):
 //   * ONE wave64 owns ONE 16x16 tile.  Each lane carries 4 pixels (one per 8x8 quadrant), so a
 //     workgroup is a single wave: no LDS staging, no __syncthreads, no cross-wave early-exit vote.
-//   * The tile's depth-ordered Gaussians are first gathered into a contiguous stream of 48-byte
-//     records (pack kernel).  The per-Gaussian operands of the hot loop are wave-uniform, so the
-//     compiler fetches each record with s_load_dwordx4 through the scalar cache into SGPRs and the
-//     VALU instructions take them as scalar operands: zero LDS traffic, zero VGPRs, and the next
-//     record is in flight while the current one is evaluated (software prefetch).
+//   * Per-Gaussian operands live in 48-byte rows (build_grec).  They are wave-uniform in the hot loop, so the
+//     wave chases gaussian_ids_sorted[k] -> row with scalar loads (s_load_dword, s_load_dwordx8 + x4) into
+//     SGPRs one entry ahead and the VALU instructions take them as scalar operands: no LDS traffic, no VGPRs,
+//     and only the (tile, Gaussian) pairs actually walked are ever fetched.  (Alternative kept for A/B:
+//     pack_records copies the rows into depth order first and the kernels stream them.)  Lists long enough to
+//     leave a lone wave latency-bound go through 64-entry batches staged in wave-private LDS instead.
 //   * Per-quadrant wave-uniform skips (`__ballot`) give the early termination and the
 //     "nobody in this 8x8 block is touched" shortcut for free in the scalar branch unit.
 //   * Backward: the 4 pixels of a lane are accumulated in registers, so ONE wave reduction per
-//     (tile, Gaussian) replaces upstream's 8 warp reductions; lanes 0..8 then issue a single
-//     9-lane global_atomic_add_f32 into a packed 48-byte per-Gaussian gradient row (one cache
-//     line), unpacked into v_xy / v_conic / v_colors / v_opacity afterwards.
+//     (tile, Gaussian) replaces upstream's 8 warp reductions — a transposed reduction on gfx950's
+//     v_permlane32_swap / v_permlane16_swap (two values folded per swap) — and nine lanes then issue a
+//     single global_atomic_add_f32 into a packed 48-byte per-Gaussian gradient row (one cache line),
+//     unpacked into v_xy / v_conic / v_colors / v_opacity afterwards.
 //
 // Arithmetic contract of the hot loop (shared with oracle/c/sgn_oracle.c; this TU is built with
 // -ffp-contract=off and spells every fma):
