@@ -280,10 +280,12 @@ int sgn_sky_blend_bwd(int h, int w, float fx, float fy, float cx, float cy, cons
  * with_grad != 0, the SSIM partials sgn_l1_ssim_bwd needs (pass the same ws); the backward writes d loss / d pred
  * given gscale2 = (d loss/d Ll1, d loss/d ssim) as two DEVICE floats (no host sync between backward nodes). */
 size_t sgn_l1_ssim_workspace_bytes(int h, int w, int with_grad);
-int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt, float data_range, float *sums2, int with_grad,
-                    void *ws, size_t ws_bytes, sgn_stream_t stream);
-int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt, const void *ws, const float *gscale2,
-                    float *v_pred, sgn_stream_t stream);
+int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt, float data_range,
+                    float clamp_max /*pred is read as min(pred, clamp_max): the caller's rgb.clamp(max=1),
+                                      sgn_splatfacto.py:969, folded in; pass INFINITY for none*/,
+                    float *sums2, int with_grad, void *ws, size_t ws_bytes, sgn_stream_t stream);
+int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt, float clamp_max, const void *ws,
+                    const float *gscale2, float *v_pred, sgn_stream_t stream);
 
 /* One torch.optim.Adam step (amsgrad = False, weight_decay = 0, maximize = False) over `count` tensors in a single
  * launch (optimiser set-up at sgn_config.py:71-108, eps = 1e-15).  Every array argument is a HOST

@@ -37,7 +37,7 @@ constexpr int ROWS_ = ROWF + 3;       // LDS row stride (odd: 3q + c walks disti
 
 // pred/gt [H,W,3]; per-workgroup partial sums of |gt - pred| (all pixels) and of ssim_map (valid region);
 // dmaps [3 maps][3 channels][H-10][W-10]: dS/d mu_pred, dS/d E[pred^2], dS/d E[pred*gt] (NULL: no backward wanted)
-__global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(int H, int W, Win win, float C1, float C2,
+__global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(int H, int W, Win win, float C1, float C2, float cmax,
                                                           const float *__restrict__ pred,
                                                           const float *__restrict__ gt,
                                                           float *__restrict__ partials,
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(int H, int W, Win win,
             const int iy = y0 + r, gx = x0 * 3 + j;
             const bool ok = e < PS * ROWF && iy < H && gx < rowlen;
             const size_t idx = (size_t)iy * rowlen + gx;
-            va[it] = ok ? pred[idx] : 0.f;
+            va[it] = ok ? fminf(pred[idx], cmax) : 0.f;      // fused torch.clamp(rgb, max=1) (sgn_splatfacto.py:969)
             vb[it] = ok ? gt[idx] : 0.f;
         }
 #pragma unroll
@@ -148,7 +148,8 @@ __global__ __launch_bounds__(256) void l1_ssim_reduce_kernel(int nblk, const flo
 
 // v_pred [H,W,3] = gl1 * sign(pred - gt) / (3HW) + gss / (3 Ho Wo) * (G*A + 2 pred G*B + gt G*C)
 // gscale (device, 2 floats): upstream gradients of the two means (d loss / d Ll1, d loss / d ssim)
-__global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(int H, int W, Win win, const float *__restrict__ pred,
+__global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(int H, int W, Win win, float cmax,
+                                                          const float *__restrict__ pred,
                                                           const float *__restrict__ gt,
                                                           const float *__restrict__ dmaps,
                                                           const float *__restrict__ gscale,
@@ -214,10 +215,12 @@ __global__ __launch_bounds__(256) void l1_ssim_bwd_kernel(int H, int W, Win win,
                 b = fmaf(g, hm[1][ty + k][tx], b);
                 d = fmaf(g, hm[2][ty + k][tx], d);
             }
-            const float x = pred[pix + c], y = gt[pix + c];
+            const float raw = pred[pix + c], y = gt[pix + c];
+            const float x = fminf(raw, cmax);
             const float df = x - y;
             const float sgn = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-            out[c] = fmaf(w_l1, sgn, w_ss * (a + 2.f * x * b + y * d));
+            const float gval = fmaf(w_l1, sgn, w_ss * (a + 2.f * x * b + y * d));
+            out[c] = (raw <= cmax) ? gval : 0.f;          // clamp passes the gradient where raw <= max
         }
     }
     if (in_img) {
@@ -250,7 +253,7 @@ SGN_EXPORT size_t sgn_l1_ssim_workspace_bytes(int h, int w, int with_grad) {
     return partial_bytes(h, w) + (with_grad ? (size_t)9 * (h - HALO) * (w - HALO) * sizeof(float) : 0);
 }
 
-SGN_EXPORT int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt, float data_range,
+SGN_EXPORT int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt, float data_range, float clamp_max,
                                float *sums2 /*device: [sum |gt-pred|, sum ssim_map]*/, int with_grad, void *ws,
                                size_t ws_bytes, sgn_stream_t stream) {
     SGN_ARG_CHECK(h > HALO && w > HALO, -1);      // pytorch_msssim asserts the image is larger than the window
@@ -263,14 +266,15 @@ SGN_EXPORT int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt,
     const float C1 = (0.01f * data_range) * (0.01f * data_range), C2 = (0.03f * data_range) * (0.03f * data_range);
     const dim3 grid(sgn_cdiv(w, TS), sgn_cdiv(h, TS));
     sgn_timing_begin(SGN_T_LOSS_FWD, (void *)s);
-    hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, s, h, w, win, C1, C2, pred, gt, partials, dmaps);
+    hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, s, h, w, win, C1, C2, clamp_max, pred, gt, partials,
+                       dmaps);
     hipLaunchKernelGGL(l1_ssim_reduce_kernel, dim3(1), dim3(256), 0, s, (int)(grid.x * grid.y), partials, sums2);
     sgn_timing_end(SGN_T_LOSS_FWD, (void *)s);
     SGN_LAUNCH_CHECK();
     return 0;
 }
 
-SGN_EXPORT int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt, const void *ws,
+SGN_EXPORT int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt, float clamp_max, const void *ws,
                                const float *gscale2 /*device: [d loss/d Ll1, d loss/d ssim]*/, float *v_pred,
                                sgn_stream_t stream) {
     SGN_ARG_CHECK(h > HALO && w > HALO, -1);
@@ -279,8 +283,8 @@ SGN_EXPORT int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt,
     const float *dmaps = (const float *)((const char *)ws + partial_bytes(h, w));
     const Win win = make_window(1.5f);
     sgn_timing_begin(SGN_T_LOSS_BWD, (void *)s);
-    hipLaunchKernelGGL(l1_ssim_bwd_kernel, dim3(sgn_cdiv(w, TS), sgn_cdiv(h, TS)), dim3(256), 0, s, h, w, win, pred, gt,
-                       dmaps, gscale2, v_pred);
+    hipLaunchKernelGGL(l1_ssim_bwd_kernel, dim3(sgn_cdiv(w, TS), sgn_cdiv(h, TS)), dim3(256), 0, s, h, w, win,
+                       clamp_max, pred, gt, dmaps, gscale2, v_pred);
     sgn_timing_end(SGN_T_LOSS_BWD, (void *)s);
     SGN_LAUNCH_CHECK();
     return 0;

@@ -23,7 +23,7 @@ from . import _lib as L
 
 class _L1SSIM(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, gt, data_range):
+    def forward(ctx, pred, gt, data_range, clamp_max):
         L.require_device(pred, gt)
         if pred.dim() != 3 or pred.shape[-1] != 3 or pred.shape != gt.shape:
             raise ValueError(f"l1_ssim expects two [H,W,3] images, got {tuple(pred.shape)} and {tuple(gt.shape)}")
@@ -35,9 +35,11 @@ class _L1SSIM(torch.autograd.Function):
         sums = torch.empty(2, dtype=torch.float32, device=p.device)
         need_grad = int(bool(ctx.needs_input_grad[0]))
         maps = L.workspace(lib.sgn_l1_ssim_workspace_bytes(h, w, need_grad), p.device)
-        L.check(lib.sgn_l1_ssim_fwd(h, w, L.ptr(p), L.ptr(g), float(data_range), L.ptr(sums), need_grad, L.ptr(maps),
-                                    maps.numel(), L.stream_ptr()), "sgn_l1_ssim_fwd")
+        cmax = float("inf") if clamp_max is None else float(clamp_max)
+        L.check(lib.sgn_l1_ssim_fwd(h, w, L.ptr(p), L.ptr(g), float(data_range), cmax, L.ptr(sums), need_grad,
+                                    L.ptr(maps), maps.numel(), L.stream_ptr()), "sgn_l1_ssim_fwd")
         ctx.hw = (h, w)
+        ctx.cmax = cmax
         ctx.maps = maps
         ctx.save_for_backward(p, g)
         return sums[0] / (3.0 * h * w), sums[1] / (3.0 * (h - 10) * (w - 10))
@@ -48,19 +50,21 @@ class _L1SSIM(torch.autograd.Function):
         h, w = ctx.hw
         gscale = torch.stack([g_l1.reshape(()), g_ssim.reshape(())]).float().contiguous()
         v = torch.empty_like(p)
-        L.check(L.load().sgn_l1_ssim_bwd(h, w, L.ptr(p), L.ptr(g), L.ptr(ctx.maps), L.ptr(gscale), L.ptr(v),
+        L.check(L.load().sgn_l1_ssim_bwd(h, w, L.ptr(p), L.ptr(g), ctx.cmax, L.ptr(ctx.maps), L.ptr(gscale), L.ptr(v),
                                          L.stream_ptr()), "sgn_l1_ssim_bwd")
-        return v, None, None
+        return v, None, None, None
 
 
-def l1_ssim(pred: torch.Tensor, gt: torch.Tensor, data_range: float = 1.0):
-    """(mean |gt - pred|, SSIM(gt, pred)) for [H,W,3] images; differentiable w.r.t. ``pred``."""
-    return _L1SSIM.apply(pred, gt, data_range)
+def l1_ssim(pred: torch.Tensor, gt: torch.Tensor, data_range: float = 1.0, clamp_max=None):
+    """(mean |gt - pred|, SSIM(gt, pred)) for [H,W,3] images; differentiable w.r.t. ``pred``.
+    ``clamp_max`` folds the caller's ``torch.clamp(rgb, max=clamp_max)`` (``sgn_splatfacto.py:969``) into the kernels:
+    ``pred`` is read as ``min(pred, clamp_max)`` and the gradient is zero where ``pred > clamp_max``."""
+    return _L1SSIM.apply(pred, gt, data_range, clamp_max)
 
 
-def photometric_loss(pred: torch.Tensor, gt: torch.Tensor, ssim_lambda: float = 0.2) -> torch.Tensor:
+def photometric_loss(pred: torch.Tensor, gt: torch.Tensor, ssim_lambda: float = 0.2, clamp_max=None) -> torch.Tensor:
     """``(1 - l) * Ll1 + l * (1 - ssim)`` — the sum of losses["Ll1"] and losses["simloss"] (``:1086-1087``)."""
-    Ll1, s = l1_ssim(pred, gt)
+    Ll1, s = l1_ssim(pred, gt, clamp_max=clamp_max)
     return (1.0 - ssim_lambda) * Ll1 + ssim_lambda * (1.0 - s)
 
 

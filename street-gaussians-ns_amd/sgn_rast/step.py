@@ -222,10 +222,13 @@ def train_step(P: Dict[str, torch.Tensor], cam: Camera, w_img: torch.Tensor, w_a
                       sky_fn=sky.get("fn"))
     n_pix = cam.height * cam.width
     if gt is not None:
-        if loss_fn is None:
-            from .loss import photometric_loss as loss_fn
-        rgb = out.rgb if sky is not None else torch.clamp(out.rgb, max=1.0)            # :969 (sky path clamps inside)
-        loss = loss_fn(rgb, gt, ssim_lambda) + (out.alpha * w_a).sum() / n_pix
+        if loss_fn is not None:                                                        # tests: the oracle's loss
+            rgb = out.rgb if sky is not None else torch.clamp(out.rgb, max=1.0)        # :969 (sky path clamps inside)
+            photo = loss_fn(rgb, gt, ssim_lambda)
+        else:
+            from .loss import photometric_loss
+            photo = photometric_loss(out.rgb, gt, ssim_lambda, clamp_max=None if sky is not None else 1.0)
+        loss = photo + (out.alpha * w_a).sum() / n_pix
     else:
         loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum()) / n_pix
     loss.backward()

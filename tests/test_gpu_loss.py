@@ -86,3 +86,16 @@ def test_photometric_loss_in_train_step():
     assert abs(float(lh) - float(0.8 * l1 + 0.2 * (1 - s))) < 1e-5
     for k in Pd:
         assert rel_l2(Pd[k].grad.cpu(), Pc[k].grad) < 5e-4, k
+
+
+def test_fused_clamp_equals_torch_clamp_then_loss():
+    from sgn_rast import loss
+    pred, gt = _images(64, 96, 12, noise=0.3)          # plenty of values above 1
+    assert float((pred > 1).float().mean()) > 0.02
+    p_ref = pred.clone().requires_grad_(True)
+    l1_ref, s_ref = O.l1_ssim_losses(torch.clamp(p_ref, max=1.0), gt)
+    (0.8 * l1_ref + 0.2 * (1 - s_ref)).backward()
+    p_hip = pred.cuda().requires_grad_(True)
+    loss.photometric_loss(p_hip, gt.cuda(), 0.2, clamp_max=1.0).backward()
+    assert rel_l2(p_hip.grad.cpu(), p_ref.grad) < 2e-5
+    assert float(p_hip.grad[pred.cuda() > 1].abs().max()) == 0.0
