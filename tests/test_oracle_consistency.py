@@ -227,3 +227,34 @@ def test_empty_and_degenerate_inputs(c_oracle, torch_oracle):
     with pytest.raises(AssertionError):
         torch_oracle.rasterize_gaussians(xys, depths, radii, conics, nth, torch.rand(16, 3),
                                          torch.rand(16, 1), 8, 8, 17, bg)
+
+
+def test_torch_oracle_gradients_match_fp64_finite_differences(torch_oracle):
+    """SURVEY.md §8c self-consistency pin (3): fp64 gradcheck of the differentiable restatement on a 14-Gaussian
+    scene — projection -> SH -> compositing (rgb + alpha), all five parameter tensors.  View directions are held
+    constant, as the reference detaches them (sgn_splatfacto.py:934)."""
+    O = torch_oracle
+    g = torch.Generator().manual_seed(3)
+    N, H, W = 14, 32, 32
+    dbl = lambda t: t.double().requires_grad_(True)
+    means = dbl(torch.stack([torch.rand(N, generator=g) * 1.2 - 0.6, torch.rand(N, generator=g) * 1.2 - 0.6,
+                             torch.rand(N, generator=g) * 2 + 2.5], -1))
+    ls = dbl(torch.rand(N, 3, generator=g) * 0.8 - 2.2)
+    q = dbl(torch.randn(N, 4, generator=g))
+    op = dbl(torch.randn(N, 1, generator=g))
+    sh = dbl(torch.randn(N, 4, 3, generator=g) * 0.3)
+    Wt, Wa = torch.rand(H, W, 3, generator=g).double(), torch.rand(H, W, generator=g).double()
+    vm = torch.eye(4).double()[:3]
+    dirs = means.detach().clone()
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+
+    def f(means, ls, q, op, sh):
+        qn = q / q.norm(dim=-1, keepdim=True)
+        xys, depths, radii, conics, _c, nth, _cov = O.project_gaussians(means, torch.exp(ls), 1, qn, vm, 40.0, 40.0,
+                                                                         16.0, 16.0, H, W, 16)
+        rgb = torch.clamp(O.spherical_harmonics(1, dirs, sh) + 0.5, min=0.0)
+        img, a = O.rasterize_gaussians(xys, depths, radii, conics, nth, rgb, torch.sigmoid(op), H, W, 16,
+                                       background=torch.zeros(3).double(), return_alpha=True)
+        return (img * Wt).sum() + (a * Wa).sum()
+
+    assert torch.autograd.gradcheck(f, (means, ls, q, op, sh), eps=1e-6, atol=1e-6, rtol=1e-5)
