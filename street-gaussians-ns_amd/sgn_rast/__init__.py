@@ -1,8 +1,11 @@
 """sgn_rast — MI355X-native differentiable Gaussian rasterizer (host side).
 
-Only what the hot path needs: the ctypes binding of libsgnrast.so (``_lib``), the
-gsplat-compatible operator surface (``ops``), the data-parallel helpers (``dp``)
-and the deterministic synthetic scenes used by bench/smoke/tests (``scenes``).
+Only what the hot path needs: the ctypes binding of libsgnrast.so (``_lib``), the gsplat-compatible operator
+surface (``ops``), the fused front ends (``fused``: activations / rigid transform / Fourier DC / sigmoid folded into
+the kernels), the callers either side of the path that SURVEY.md §8f ranks next (``sky``: nvdiffrast cube-map lookup,
+``loss``: L1 + SSIM, ``optim``: multi-tensor Adam, ``densify``: per-step statistics), the data-parallel helpers
+(``dp``), the call-site replay used by bench/smoke/tests (``step``) and the deterministic synthetic scenes
+(``scenes``).  Sub-modules are imported on demand; none of them has a CPU fallback.
 """
 from .ops import (  # noqa: F401
     bin_and_sort_gaussians,
