@@ -250,7 +250,10 @@ __device__ __forceinline__ void row_interval(const Ellipse &E, int ty, int block
     hi = min(hi, t_hi);
 }
 
-constexpr int ROWS_BIG = 6;   // bboxes taller than this are handled by the whole wave (lane <-> tile row)
+#ifndef SGN_ROWS_BIG
+#define SGN_ROWS_BIG 6
+#endif
+constexpr int ROWS_BIG = SGN_ROWS_BIG;   // bboxes taller than this are handled by the whole wave (lane <-> tile row)
 
 // Tiles of one Gaussian per lane (row-major over the bbox, one kept interval per tile row).  EMIT = false: returns
 // the number of kept tiles; EMIT = true: also writes the (tile, gaussian id) pairs starting at `cur`.
