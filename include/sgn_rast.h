@@ -98,8 +98,14 @@ int sgn_project_fwd(int n, const float *means3d, const float *scales, float glob
                     int32_t *radii /*[n]*/, float *conics /*[n,3]*/, float *compensation /*[n]*/,
                     int32_t *num_tiles_hit /*[n]*/, sgn_stream_t stream);
 
+/* gsplat's `assert (quats.norm(dim=-1) - 1 < 1e-6).all()` (project_gaussians.py) as a device-side check: *flag (device
+ * int32) becomes 1 if any row of quats [n,4] (16-byte aligned) fails `norm - 1 < tol`.  The host reads the flag at its
+ * next sync point (see sgn_rast/ops.py: deferred assertion). */
+int sgn_check_unit_quats(int n, const float *quats, float tol, int32_t *flag, sgn_stream_t stream);
+
 /* _C.project_gaussians_backward (_ProjectGaussians.backward).  v_compensation may be NULL
- * (treated as zeros: the reference discards compensation, sgn_splatfacto.py:860,947).
+ * (treated as zeros: the reference discards compensation, sgn_splatfacto.py:860,947); v_depth may be NULL too
+ * (zeros: depths took no part in the loss).
  * v_cov2d / v_cov3d are optional scratch outputs (may be NULL).  All rows written. */
 int sgn_project_bwd(int n, const float *means3d, const float *scales, float glob_scale,
                     const float *quats, const float *viewmat12, float fx, float fy,

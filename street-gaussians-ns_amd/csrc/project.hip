@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         float vm[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) vm[j] = V[j] * vv0 + V[4 + j] * vv1 + V[8 + j] * vv2;
-        const float vz = v_depth[i];
+        const float vz = v_depth ? v_depth[i] : 0.f;      // NULL: depths took no part in the loss
         vm[0] += V[8] * vz; vm[1] += V[9] * vz; vm[2] += V[10] * vz;
 
         const float X00 = conics[3 * i], X01 = conics[3 * i + 1], X11 = conics[3 * i + 2];
@@ -389,7 +389,7 @@ SGN_EXPORT int sgn_project_bwd(int n, const float *means3d, const float *scales,
     SGN_ARG_CHECK(n >= 0, -1);
     if (n == 0) return 0;
     SGN_ARG_CHECK(means3d && scales && quats && viewmat12 && cov3d && radii && conics && v_xy &&
-                      v_depth && v_conic && v_mean3d && v_scale && v_quat, -4);
+                      v_conic && v_mean3d && v_scale && v_quat, -4);
     SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
     const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
     sgn_timing_begin(SGN_T_PROJECT_BWD, stream);
@@ -434,7 +434,7 @@ SGN_EXPORT int sgn_project_bwd_fused(int n, const float *means_local, const floa
                                      float *v_quats_raw, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     if (n == 0) return 0;
-    SGN_ARG_CHECK(means_local && log_scales && quats_raw && viewmat12 && cov3d && radii && conics && v_xy && v_depth &&
+    SGN_ARG_CHECK(means_local && log_scales && quats_raw && viewmat12 && cov3d && radii && conics && v_xy &&
                       v_conic && v_means_local && v_log_scales && v_quats_raw, -4);
     SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
     SGN_ARG_CHECK((object_ids == nullptr) == (poses == nullptr), -6);
@@ -445,6 +445,31 @@ SGN_EXPORT int sgn_project_bwd_fused(int n, const float *means_local, const floa
                        compensation, v_xy, v_depth, v_conic, v_compensation, nullptr, nullptr, v_means_local,
                        v_log_scales, v_quats_raw);
     sgn_timing_end(SGN_T_PROJECT_BWD, stream);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+// gsplat's `assert (quats.norm(dim=-1) - 1 < 1e-6).all(), "quats must be normalized"` (project_gaussians.py) as ONE
+// pass that raises a device flag, so the host can look at it at its next existing sync point instead of stalling
+// the queue for the assertion alone (4 torch kernels + a host sync per call otherwise).
+namespace {
+__global__ __launch_bounds__(256) void check_unit_quats_kernel(int n, const float *__restrict__ quats, float tol,
+                                                               int32_t *__restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4 q = reinterpret_cast<const float4 *>(quats)[i];
+    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    if (!(nrm - 1.f < tol)) *flag = 1;      // same one-sided test as upstream; NaN fails it too.  Benign race.
+}
+}  // namespace
+
+SGN_EXPORT int sgn_check_unit_quats(int n, const float *quats, float tol, int32_t *flag, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0 && flag != nullptr, -1);
+    hipStream_t s = (hipStream_t)stream;
+    SGN_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int32_t), s));
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(quats != nullptr && (reinterpret_cast<uintptr_t>(quats) & 15) == 0, -2);
+    hipLaunchKernelGGL(check_unit_quats_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, quats, tol, flag);
     SGN_LAUNCH_CHECK();
     return 0;
 }

@@ -52,6 +52,7 @@ SIGNATURES = {
     "sgn_l1_ssim_bwd": (_i, [_i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sgn_adam_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_densify_stats": (_i, [_i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
+    "sgn_check_unit_quats": (_i, [_i, _vp, _f, _vp, _vp]),
     "sgn_sh_bwd_multi": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "sgn_sh_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_sh_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -86,7 +86,7 @@ class _ProjectFused(Function):
         n, dev = means.shape[0], means.device
         f32 = dict(dtype=torch.float32, device=dev)
         v_xys = _f32c(v_xys) if v_xys is not None else torch.zeros(n, 2, **f32)
-        v_depths = _f32c(v_depths) if v_depths is not None else torch.zeros(n, **f32)
+        v_depths = _f32c(v_depths) if v_depths is not None else None      # NULL = zeros inside the kernel
         v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros(n, 3, **f32)
         v_comp = _f32c(v_comp) if v_comp is not None else None
         v_m, v_s, v_q = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32)
@@ -115,6 +115,17 @@ def project_gaussians_fused(means, log_scales, quats_raw, viewmat, fx, fy, cx, c
 _sh_bwd_tap = None
 
 
+_ONES: dict = {}
+
+
+def _ones_row(F: int, dev) -> torch.Tensor:
+    """[1,F] ones (the idft row of a model without Fourier DC), made once per device instead of a fill per call."""
+    key = (F, str(dev))
+    if key not in _ONES:
+        _ONES[key] = torch.ones(1, F, dtype=torch.float32, device=dev)
+    return _ONES[key]
+
+
 class _SHFused(Function):
     @staticmethod
     def forward(ctx, degree, means, cam_pos, features_dc, features_rest, object_ids, idft, poses, post):
@@ -124,7 +135,7 @@ class _SHFused(Function):
         means_c, cam_c, dc_c = _f32c(means), _f32c(cam_pos).reshape(-1)[:3].contiguous(), _f32c(features_dc)
         rest_c = _f32c(features_rest) if features_rest is not None else None
         oid = None if object_ids is None else object_ids.detach().to(torch.int32).contiguous()
-        idft_c = _f32c(idft).reshape(-1, F) if idft is not None else torch.ones(1, F, dtype=torch.float32, device=dev)
+        idft_c = _f32c(idft).reshape(-1, F) if idft is not None else _ones_row(F, dev)
         pos = _f32c(poses) if (poses is not None and oid is not None) else None
         colors = torch.empty(n, 3, dtype=torch.float32, device=dev)
         L.check(L.load().sgn_sh_fwd_fused(n, k, int(degree), L.ptr(means_c), L.ptr(cam_c), L.ptr(dc_c), F,

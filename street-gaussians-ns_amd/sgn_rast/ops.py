@@ -15,6 +15,7 @@ arithmetic happens in the hand-written HIP kernels behind the C ABI.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -140,7 +141,7 @@ class _ProjectGaussians(Function):
         n, dev = means3d.shape[0], means3d.device
         f32 = dict(dtype=torch.float32, device=dev)
         v_xys = _f32c(v_xys) if v_xys is not None else torch.zeros(n, 2, **f32)
-        v_depths = _f32c(v_depths) if v_depths is not None else torch.zeros(n, **f32)
+        v_depths = _f32c(v_depths) if v_depths is not None else None      # NULL = zeros inside the kernel
         v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros(n, 3, **f32)
         v_comp = _f32c(v_compensation) if v_compensation is not None else None
         v_mean = torch.empty(n, 3, **f32)
@@ -157,6 +158,35 @@ class _ProjectGaussians(Function):
         return v_mean, v_scale, None, v_quat, None, None, None, None, None, None, None, None, None
 
 
+# Upstream asserts `(quats.norm(dim=-1) - 1 < 1e-6).all()` on every project_gaussians call: four small kernels and a
+# host sync that drains the queue in the middle of the forward pass.  "deferred" (default) runs the same test as one
+# device pass (sgn_check_unit_quats) and raises the same AssertionError at the NEXT host sync the path has anyway (the
+# intersection-count read-back inside rasterize_gaussians); "eager" is upstream's behaviour verbatim; "off" skips it.
+quat_check = os.environ.get("SGN_QUAT_CHECK", "deferred")
+_pending_checks: list = []
+
+
+def _check_quats(quats: torch.Tensor) -> None:
+    if quat_check == "off":
+        return
+    if quat_check == "eager" or not quats.is_cuda:
+        assert (quats.norm(dim=-1) - 1 < 1e-6).all(), "quats must be normalized"
+        return
+    q = _f32c(quats)
+    flag = torch.empty(1, dtype=torch.int32, device=q.device)
+    L.check(L.load().sgn_check_unit_quats(q.shape[0], L.ptr(q), 1e-6, L.ptr(flag), L.stream_ptr()),
+            "sgn_check_unit_quats")
+    _pending_checks.append(flag)
+
+
+def raise_pending_checks() -> None:
+    """Called right after an existing host sync: the flags are already final, reading them costs no stall."""
+    failed = False
+    while _pending_checks:
+        failed |= bool(int(_pending_checks.pop().item()))
+    assert not failed, "quats must be normalized"
+
+
 def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
                       block_width, clip_thresh: float = 0.01):
     """gsplat/project_gaussians.py project_gaussians (sgn_splatfacto.py:860-873).
@@ -164,7 +194,7 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     Returns ``(xys, depths, radii, conics, compensation, num_tiles_hit, cov3d)``;
     ``viewmat`` is the world->camera matrix ([3,4] or [4,4]; only rows 0-2 are read)."""
     assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
-    assert (quats.norm(dim=-1) - 1 < 1e-6).all(), "quats must be normalized"
+    _check_quats(quats)
     return _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
                                    viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
                                    clip_thresh)
@@ -183,7 +213,9 @@ def compute_cumulative_intersects(num_tiles_hit: torch.Tensor) -> Tuple[int, tor
     lib = L.load()
     ws = L.workspace(lib.sgn_scan_workspace_bytes(n), dev)
     L.check(lib.sgn_scan_i32(n, L.ptr(nth), L.ptr(cum), L.ptr(ws), ws.numel(), L.stream_ptr()), "sgn_scan_i32")
-    return int(cum[-1].item()), cum
+    total = int(cum[-1].item())
+    raise_pending_checks()
+    return total, cum
 
 
 def map_gaussian_to_intersects(num_points, num_intersects, xys, depths, radii, cum_tiles_hit, tile_bounds,
@@ -272,6 +304,7 @@ def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_boun
                                 L.ptr(gid_by_rank), L.ptr(bin_recs), L.ptr(ws), ws.numel(), L.stream_ptr()),
             "sgn_bin_prepare")
     num_intersects = int(cum_r[-1].item())  # host sync: sizes the intersection buffers (as upstream)
+    raise_pending_checks()
     ids_sorted = torch.empty(num_intersects, **i32)
     ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(num_intersects), dev)
     L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(bin_recs), L.ptr(cum_r), L.ptr(gid_by_rank), tx, ty,

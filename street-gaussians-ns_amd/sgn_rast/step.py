@@ -19,6 +19,18 @@ from . import ops as _hip_ops
 from .scenes import Camera
 
 
+_CONST: Dict[tuple, torch.Tensor] = {}
+
+
+def _zeros3(dev, dtype=torch.float32) -> torch.Tensor:
+    """The reference keeps its background colour as a module attribute made once (sgn_splatfacto.py:311); the replay
+    does the same instead of launching a fill kernel per step."""
+    key = (str(dev), dtype)
+    if key not in _CONST:
+        _CONST[key] = torch.zeros(3, device=dev, dtype=dtype)
+    return _CONST[key]
+
+
 def leaf_params(raw: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Raw scene tensors -> autograd leaves (what nn.Parameter would be in SplatfactoModel)."""
     return {k: v.detach().clone().requires_grad_(True) for k, v in raw.items()}
@@ -30,7 +42,7 @@ def render(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, b
     dev = P["means"].device
     H, W = cam.height, cam.width
     if background is None:
-        background = torch.zeros(3, device=dev, dtype=P["means"].dtype)          # :311,931
+        background = _zeros3(dev, P["means"].dtype)                              # :311,931
     scales = torch.exp(P["log_scales"])                                          # :857
     colors = torch.cat((P["features_dc"], P["features_rest"]), dim=1)            # :858
     quats = P["quats"] / P["quats"].norm(dim=-1, keepdim=True)                   # :864
@@ -51,7 +63,7 @@ def render(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, b
     if with_depth:                                                               # :982-996
         depth_im = ops.rasterize_gaussians(
             xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3), opacities, H, W,
-            block_width, torch.zeros(3, device=dev, dtype=P["means"].dtype))[..., 0:1]
+            block_width, _zeros3(dev, P["means"].dtype))[..., 0:1]
         out.depth = torch.where(alpha[..., None] > 1e-3, depth_im / alpha[..., None], 10)
     return out
 
@@ -68,7 +80,7 @@ def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int 
     dev = P["means"].device
     H, W = cam.height, cam.width
     if background is None:
-        background = torch.zeros(3, device=dev, dtype=torch.float32)
+        background = _zeros3(dev)
     xys, depths, radii, conics, _comp, num_tiles_hit, _cov3d = fused.project_gaussians_fused(
         P["means"], P["log_scales"], P["quats"], cam.viewmat[:3, :], cam.fx, cam.fy, cam.cx, cam.cy, H, W,
         block_width, object_ids=object_ids, poses=poses)
@@ -85,7 +97,7 @@ def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int 
     if with_depth:
         depth_im = fused.rasterize_gaussians_fused(
             xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3), P["opacity_logits"], H, W,
-            block_width, torch.zeros(3, device=dev, dtype=torch.float32))[..., 0:1]
+            block_width, _zeros3(dev))[..., 0:1]
         out.depth = torch.where(alpha[..., None] > 1e-3, depth_im / alpha[..., None], 10)
     return out
 
@@ -111,7 +123,7 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
     dev = models[0]["means"].device
     H, W = cam.height, cam.width
     counts = [m["means"].shape[0] for m in models]
-    bg_zero = torch.zeros(3, device=dev, dtype=torch.float32)
+    bg_zero = _zeros3(dev)
     cat = lambda key: torch.cat([m[key] for m in models], dim=0)                        # :355-360
     if fused:
         from . import fused as F_

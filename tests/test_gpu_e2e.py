@@ -201,3 +201,34 @@ def test_binning_cache_reuse_and_invalidation():
         ops.bin_gaussians_fused = orig
         ops.binning_cache_enabled = True
         ops.clear_binning_cache()
+
+
+def test_quat_assertion_deferred_and_eager():
+    """Upstream's "quats must be normalized" assertion: eager mode raises at project_gaussians like gsplat; the default
+    deferred mode raises the same error at the next host sync of the path (inside rasterize_gaussians)."""
+    from sgn_rast import ops, scenes
+    cam, raw = scenes.make_scene("c1", seed=1, device="cuda", n_override=500)
+    scales = torch.exp(raw["log_scales"])
+    good = raw["quats"] / raw["quats"].norm(dim=-1, keepdim=True)
+    bad = good.clone()
+    bad[17] *= 1.5
+    args = lambda q: (raw["means"], scales, 1, q, cam.viewmat[:3, :], cam.fx, cam.fy, cam.cx, cam.cy, cam.height,
+                      cam.width, 16)
+    old = ops.quat_check
+    try:
+        ops.quat_check = "eager"
+        with pytest.raises(AssertionError, match="quats must be normalized"):
+            ops.project_gaussians(*args(bad))
+        ops.quat_check = "deferred"
+        xys, depths, radii, conics, _c, nth, _cov = ops.project_gaussians(*args(bad))      # no sync, no raise yet
+        rgbs = torch.rand(500, 3, device="cuda")
+        with pytest.raises(AssertionError, match="quats must be normalized"):
+            ops.rasterize_gaussians(xys, depths, radii, conics, nth, rgbs, torch.sigmoid(raw["opacity_logits"]),
+                                    cam.height, cam.width, 16)
+        assert not ops._pending_checks
+        xys, depths, radii, conics, _c, nth, _cov = ops.project_gaussians(*args(good))
+        ops.rasterize_gaussians(xys, depths, radii, conics, nth, rgbs, torch.sigmoid(raw["opacity_logits"]),
+                                cam.height, cam.width, 16)
+    finally:
+        ops.quat_check = old
+        ops._pending_checks.clear()
