@@ -133,11 +133,24 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
         P = dict(means=cat("means"), log_scales=cat("log_scales"), quats=cat("quats"),
                  opacity_logits=cat("opacity_logits"), features_rest=cat("features_rest"),
                  features_dc=torch.cat([pad(m["features_dc"]) for m in models], dim=0))
-        object_ids = torch.repeat_interleave(torch.arange(len(models), device=dev, dtype=torch.int32),
-                                             torch.tensor(counts, device=dev))
+        # per-Gaussian object id: depends on the model sizes only (they change at densification, not per step), so it
+        # is built on the host once per layout — repeat_interleave with device counts would sync every step
+        key = ("oid", str(dev), tuple(counts))
+        if key not in _CONST:
+            if len(_CONST) > 64:
+                _CONST.clear()
+            _CONST[key] = torch.repeat_interleave(torch.arange(len(models), dtype=torch.int32),
+                                                  torch.tensor(counts)).to(dev)
+        object_ids = _CONST[key]
+        # Fourier weights padded to the widest model: rows beyond a model's own dimension stay zero
+        Fs = [m["features_dc"].shape[1] for m in models]
+        mask_key = ("fmask", str(dev), tuple(Fs), Fmax)
+        if mask_key not in _CONST:
+            _CONST[mask_key] = (torch.arange(Fmax)[None, :] < torch.tensor(Fs)[:, None]).to(dev, torch.float32)
         idft_p = torch.zeros(len(models), Fmax, device=dev)
-        for i, m in enumerate(models):
-            idft_p[i, : m["features_dc"].shape[1]] = idft[i][: m["features_dc"].shape[1]]
+        fw = min(Fmax, idft.shape[1])
+        idft_p[:, :fw] = idft[:, :fw]
+        idft_p = idft_p * _CONST[mask_key]
         out = render_fused(P, cam, sh_degree_to_use, block_width, with_depth=True, object_ids=object_ids,
                            poses=poses, idft=idft_p)
         opac_arg, raster = P["opacity_logits"], F_.rasterize_gaussians_fused
