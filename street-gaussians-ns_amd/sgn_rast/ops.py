@@ -281,15 +281,26 @@ def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_boun
     (tile, Gaussian) pairs that cannot reach alpha >= 1/255 on any pixel centre of the tile are dropped: the
     list becomes a sub-sequence of upstream's and the rasterizer's outputs are unchanged.
     Returns (num_intersects, gaussian_ids_sorted, tile_bins)."""
+    return _bin_finish(_bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width,
+                                          conics, opacity, opacity_is_logit, cull))
+
+
+_side = {}   # per device: (side stream, pinned int32[1])
+
+
+def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
+                       opacity_is_logit, cull):
+    """First half of the fused binning: depth rank, kept-tile counts, scan — and the read-back of the intersection
+    count started on a side stream, so the caller may queue independent work on the current stream before it calls
+    :func:`_bin_finish` (which is where the host waits)."""
     dev = L.require_device(xys, depths, radii, num_tiles_hit, conics, opacity)
     lib = L.load()
     n = int(num_points)
     tx, ty = int(tile_bounds[0]), int(tile_bounds[1])
     i32 = dict(dtype=torch.int32, device=dev)
-    tile_bins = torch.empty(tx * ty, 2, **i32)
+    st = dict(n=n, tx=tx, ty=ty, block=int(block_width), dev=dev, tile_bins=torch.empty(tx * ty, 2, **i32))
     if n == 0:
-        tile_bins.zero_()
-        return 0, torch.zeros(0, **i32), tile_bins
+        return st
     radii_c = radii.detach().to(torch.int32).contiguous()
     xys_c = _f32c(xys)
     do_cull = int(bool(cull and conics is not None and opacity is not None))
@@ -303,13 +314,37 @@ def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_boun
                                 int(bool(opacity_is_logit)), do_cull, tx, ty, int(block_width), L.ptr(cum_r),
                                 L.ptr(gid_by_rank), L.ptr(bin_recs), L.ptr(ws), ws.numel(), L.stream_ptr()),
             "sgn_bin_prepare")
-    num_intersects = int(cum_r[-1].item())  # host sync: sizes the intersection buffers (as upstream)
+    if dev not in _side:
+        _side[dev] = (torch.cuda.Stream(device=dev), torch.empty(1, dtype=torch.int32).pin_memory())
+    side, pinned = _side[dev]
+    ready = torch.cuda.Event()
+    ready.record(torch.cuda.current_stream(dev))
+    side.wait_event(ready)
+    with torch.cuda.stream(side):
+        pinned.copy_(cum_r[n - 1:n], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(side)
+    st.update(cum_r=cum_r, gid_by_rank=gid_by_rank, bin_recs=bin_recs, ws=ws, done=done, pinned=pinned,
+              keep=(xys_c, radii_c, conics_c, opac_c))
+    return st
+
+
+def _bin_finish(st):
+    """Second half: wait for the count (the path's one host sync, as upstream), emit, tile sort, bins."""
+    i32 = dict(dtype=torch.int32, device=st["dev"])
+    tile_bins, n = st["tile_bins"], st["n"]
+    if n == 0:
+        tile_bins.zero_()
+        return 0, torch.zeros(0, **i32), tile_bins
+    st["done"].synchronize()
+    num_intersects = int(st["pinned"][0])
     raise_pending_checks()
+    lib = L.load()
     ids_sorted = torch.empty(num_intersects, **i32)
-    ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(num_intersects), dev)
-    L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(bin_recs), L.ptr(cum_r), L.ptr(gid_by_rank), tx, ty,
-                                  int(block_width), L.ptr(ids_sorted), L.ptr(tile_bins), L.ptr(ws2), ws2.numel(),
-                                  L.stream_ptr()), "sgn_bin_intersect")
+    ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(num_intersects), st["dev"])
+    L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(st["bin_recs"]), L.ptr(st["cum_r"]),
+                                  L.ptr(st["gid_by_rank"]), st["tx"], st["ty"], st["block"], L.ptr(ids_sorted),
+                                  L.ptr(tile_bins), L.ptr(ws2), ws2.numel(), L.stream_ptr()), "sgn_bin_intersect")
     return num_intersects, ids_sorted, tile_bins
 
 
@@ -333,20 +368,49 @@ def clear_binning_cache() -> None:
     _bin_cache["key"] = _bin_cache["keep"] = _bin_cache["val"] = None
 
 
+_bin_pending = {"key": None, "state": None, "keep": None}
+
+
+def _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity, opacity_is_logit):
+    cull = tile_culling_enabled
+    tensors = (xys, depths, radii, num_tiles_hit) + ((conics, opacity) if cull else ())
+    return _bin_key(tensors, tile_bounds, block_width, (bool(opacity_is_logit), cull)), tensors, cull
+
+
+def prefetch_binning(xys, depths, radii, conics, num_tiles_hit, opacity, img_height, img_width, block_width,
+                     opacity_is_logit=False) -> None:
+    """Optional hint for callers that have other device work to queue between projection and rasterization (the SH
+    evaluation, typically): starts the binning of the coming ``rasterize_gaussians`` call now — depth rank, counts,
+    scan, and the asynchronous read-back of the intersection count — so that by the time ``rasterize_gaussians`` needs
+    the count on the host the GPU is still busy with the work queued in between, instead of idling while the host
+    wakes up and launches the second half.  The rasterize call must receive these very tensors."""
+    tile_bounds = ((img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width, 1)
+    key, tensors, cull = _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
+                                    opacity_is_logit)
+    if binning_cache_enabled and _bin_cache["key"] == key:
+        return
+    _bin_pending["state"] = _bin_prepare_async(xys.size(0), xys, depths, radii, num_tiles_hit, tile_bounds, block_width,
+                                               conics, opacity, opacity_is_logit, cull)
+    _bin_pending["key"] = key
+    _bin_pending["keep"] = tuple(t.detach() for t in tensors)
+
+
 def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics,
                           opacity, opacity_is_logit):
-    cull = tile_culling_enabled
-    args = (num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
-            opacity_is_logit, cull)
-    if not binning_cache_enabled:
-        return bin_gaussians_fused(*args)
-    tensors = (xys, depths, radii, num_tiles_hit) + ((conics, opacity) if cull else ())
-    key = _bin_key(tensors, tile_bounds, block_width, (bool(opacity_is_logit), cull))
-    if _bin_cache["key"] == key:
+    key, tensors, cull = _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
+                                    opacity_is_logit)
+    if binning_cache_enabled and _bin_cache["key"] == key:
         return _bin_cache["val"]
-    val = bin_gaussians_fused(*args)
-    _bin_cache["key"], _bin_cache["val"] = key, val
-    _bin_cache["keep"] = tuple(t.detach() for t in tensors)
+    if _bin_pending["key"] == key:
+        state = _bin_pending["state"]
+    else:
+        state = _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics,
+                                   opacity, opacity_is_logit, cull)
+    _bin_pending["key"] = _bin_pending["state"] = _bin_pending["keep"] = None
+    val = _bin_finish(state)
+    if binning_cache_enabled:
+        _bin_cache["key"], _bin_cache["val"] = key, val
+        _bin_cache["keep"] = tuple(t.detach() for t in tensors)
     return val
 
 

@@ -87,6 +87,9 @@ def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int 
     out = SimpleNamespace(xys=xys, depths=depths, radii=radii, conics=conics, num_tiles_hit=num_tiles_hit)
     if xys.requires_grad:
         xys.retain_grad()
+    # start the binning now: its host read-back then overlaps the SH evaluation queued below
+    _hip_ops.prefetch_binning(xys, depths, radii, conics, num_tiles_hit, P["opacity_logits"], H, W, block_width,
+                              opacity_is_logit=True)
     # SH view directions use WORLD means (scene_graph.py:355): the kernel applies the pose itself
     rgbs = fused.spherical_harmonics_fused(sh_degree_to_use, P["means"], cam.cam_pos, P["features_dc"],
                                            P["features_rest"], object_ids=object_ids, idft=idft, poses=poses)

@@ -170,13 +170,13 @@ def test_binning_cache_reuse_and_invalidation():
     cam, raw = scenes.make_scene("c1", n_override=3000)
     P = _to_dev(cam, raw)
     calls = {"n": 0}
-    orig = ops.bin_gaussians_fused
+    orig = ops._bin_prepare_async
 
     def counting(*a, **k):
         calls["n"] += 1
         return orig(*a, **k)
 
-    ops.bin_gaussians_fused = counting
+    ops._bin_prepare_async = counting
     try:
         ops.clear_binning_cache()
         with torch.no_grad():
@@ -197,8 +197,25 @@ def test_binning_cache_reuse_and_invalidation():
             off = ops.rasterize_gaussians(xys2, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
                                           out.opacities, cam.height, cam.width, 16, torch.zeros(3, device=DEV))
             assert calls["n"] == 4 and torch.equal(off, ref)
+            # prefetch hint: the binning started early is the one the rasterize call finishes (no second prepare)
+            ops.binning_cache_enabled = True
+            ops.clear_binning_cache()
+            xys3 = out.xys.clone()
+            ops.prefetch_binning(xys3, out.depths, out.radii, out.conics, out.num_tiles_hit, out.opacities, cam.height,
+                                 cam.width, 16)
+            assert calls["n"] == 5
+            pre = ops.rasterize_gaussians(xys3, out.depths, out.radii, out.conics, out.num_tiles_hit, out.rgbs,
+                                          out.opacities, cam.height, cam.width, 16, torch.zeros(3, device=DEV))
+            assert calls["n"] == 5 and torch.equal(pre, ref)
+            # a prefetch for other tensors is simply dropped
+            ops.prefetch_binning(xys2, out.depths, out.radii, out.conics, out.num_tiles_hit, out.opacities, cam.height,
+                                 cam.width, 16)
+            other = ops.rasterize_gaussians(out.xys.clone(), out.depths, out.radii, out.conics, out.num_tiles_hit,
+                                            out.rgbs, out.opacities, cam.height, cam.width, 16,
+                                            torch.zeros(3, device=DEV))
+            assert torch.equal(other, ref) and ops._bin_pending["key"] is None
     finally:
-        ops.bin_gaussians_fused = orig
+        ops._bin_prepare_async = orig
         ops.binning_cache_enabled = True
         ops.clear_binning_cache()
 
