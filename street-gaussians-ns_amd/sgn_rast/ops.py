@@ -429,12 +429,18 @@ class _RasterizeGaussians(Function):
                 "only the 3-channel rasterize path is implemented (the reference never uses N-D colours: "
                 "sgn_splatfacto.py:988 repeats depth x3 to stay on it)")
         xys_c, conics_c, colors_c = _f32c(xys), _f32c(conics), _f32c(colors)
-        num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
-            num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
-            opacity_is_logit)
         opac_c, bg_c = _f32c(opacity).reshape(-1), _f32c(background)
         f32 = dict(dtype=torch.float32, device=dev)
         lib = L.load()
+        # everything that does not depend on the intersection count is prepared BEFORE the binning's host sync: the
+        # GPU idles from the moment the count is known until the next launch arrives, so that window is kept short
+        out_img = torch.empty(img_height, img_width, 3, **f32)
+        final_Ts = torch.empty(img_height, img_width, **f32)
+        final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
+        stream_ptr = L.stream_ptr()
+        num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
+            num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
+            opacity_is_logit)
         recs = None
         if num_intersects < 1:
             out_img = torch.ones(img_height, img_width, 3, **f32) * bg_c
@@ -443,15 +449,12 @@ class _RasterizeGaussians(Function):
             final_Ts = torch.ones(img_height, img_width, **f32)
             final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
         else:
-            out_img = torch.empty(img_height, img_width, 3, **f32)
-            final_Ts = torch.empty(img_height, img_width, **f32)
-            final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
             recs = L.workspace(lib.sgn_raster_workspace_bytes(num_points, num_intersects), dev)
             L.check(lib.sgn_raster_fwd(
                 img_height, img_width, block_width, num_points, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), id_lo, id_hi,
                 L.ptr(bg_c), L.ptr(out_img),
-                L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), L.stream_ptr()), "sgn_raster_fwd")
+                L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), stream_ptr), "sgn_raster_fwd")
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
         ctx.num_intersects = num_intersects
         ctx.opacity_is_logit = int(bool(opacity_is_logit))
