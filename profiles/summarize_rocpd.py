@@ -5,6 +5,7 @@
     python profiles/summarize_rocpd.py kernels DIR/NAME_results.db        > profiles/rNN_kernel_stats.md
     rocprofv3 --pmc C1 C2 ... -d DIR -o NAME -- python bench.py ...
     python profiles/summarize_rocpd.py pmc DIR/NAME_results.db [filter]   > profiles/rNN_pmc.md
+    python profiles/summarize_rocpd.py gaps DIR/NAME_results.db           (idle gaps between kernels, steady state)
 
 (The sqlite files are tens of MB; they are summarised on the GPU box and deleted.)
 """
@@ -47,9 +48,58 @@ def pmc(path, flt=""):
         print(f"| `{k}` | {d['_n']} | {d['_dur_us']:.1f} | " + " | ".join(f"{d.get(c, 0):.4g}" for c in names) + " |")
 
 
+
+
+def gaps(path, skip_frac=0.5):
+    """Idle gaps between consecutive kernels in the second half of the trace (steady state): where does the GPU wait
+    for the host?  Prints busy/span and the largest gaps with the kernels on either side."""
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    tables = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    cand = [t for t in tables if "kernel_dispatch" in t or t == "kernels"]
+    rows = None
+    for t in cand:
+        cols = [r[1] for r in cur.execute(f"pragma table_info({t})")]
+        if "start" in cols and "end" in cols:
+            namecol = "name" if "name" in cols else ("kernel_name" if "kernel_name" in cols else None)
+            if namecol is None and "kernel_id" in cols:
+                sym = [x for x in tables if "kernel_symbol" in x]
+                if sym:
+                    rows = list(cur.execute(f"select s.kernel_name, d.start, d.end from {t} d join {sym[0]} s on d.kernel_id = s.id order by d.start"))
+                    break
+            elif namecol:
+                rows = list(cur.execute(f"select {namecol}, start, end from {t} order by start"))
+                break
+    if rows is None:
+        print("no dispatch table with start/end found; tables:", tables)
+        return
+    rows = rows[int(len(rows) * skip_frac):]
+    span = rows[-1][2] - rows[0][1]
+    busy, cur_end, gl = 0, rows[0][1], []
+    for i, (name, st, en) in enumerate(rows):
+        if st > cur_end:
+            gl.append((st - cur_end, short(rows[i - 1][0], 50), short(name, 50)))
+        busy += max(0, en - max(st, cur_end))
+        cur_end = max(cur_end, en)
+    print(f"dispatches {len(rows)}, span {span / 1e3:.1f} us, busy {busy / 1e3:.1f} us ({100 * busy / span:.1f} %), "
+          f"idle {(span - busy) / 1e3:.1f} us in {len(gl)} gaps")
+    agg = {}
+    for g, a, b in gl:
+        k = (a, b)
+        agg.setdefault(k, [0, 0])
+        agg[k][0] += g
+        agg[k][1] += 1
+    print("| idle_us total | count | avg_us | after kernel | before kernel |")
+    print("|---:|---:|---:|---|---|")
+    for (a, b), (tot, cnt) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:14]:
+        print(f"| {tot / 1e3:.1f} | {cnt} | {tot / cnt / 1e3:.1f} | `{a}` | `{b}` |")
+
+
 if __name__ == "__main__":
     mode, path = sys.argv[1], sys.argv[2]
     if mode == "kernels":
         kernels(path)
+    elif mode == "gaps":
+        gaps(path)
     else:
         pmc(path, sys.argv[3] if len(sys.argv) > 3 else "")

@@ -315,17 +315,22 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
                                 L.ptr(gid_by_rank), L.ptr(bin_recs), L.ptr(ws), ws.numel(), L.stream_ptr()),
             "sgn_bin_prepare")
     if dev not in _side:
-        _side[dev] = (torch.cuda.Stream(device=dev), torch.empty(1, dtype=torch.int32).pin_memory())
+        _side[dev] = (torch.cuda.Stream(device=dev), torch.empty(8, dtype=torch.int32).pin_memory())
     side, pinned = _side[dev]
     ready = torch.cuda.Event()
     ready.record(torch.cuda.current_stream(dev))
     side.wait_event(ready)
+    # pending argument checks ride along: their flags reach the host in the same transfer as the count, so the
+    # deferred assertion costs no round trip of its own
+    flags = [_pending_checks.pop() for _ in range(min(len(_pending_checks), 7))]
     with torch.cuda.stream(side):
-        pinned.copy_(cum_r[n - 1:n], non_blocking=True)
+        pinned[0:1].copy_(cum_r[n - 1:n], non_blocking=True)
+        for i, f in enumerate(flags):
+            pinned[1 + i:2 + i].copy_(f, non_blocking=True)
         done = torch.cuda.Event()
         done.record(side)
     st.update(cum_r=cum_r, gid_by_rank=gid_by_rank, bin_recs=bin_recs, ws=ws, done=done, pinned=pinned,
-              keep=(xys_c, radii_c, conics_c, opac_c))
+              n_flags=len(flags), keep=(xys_c, radii_c, conics_c, opac_c, flags))
     return st
 
 
@@ -338,7 +343,10 @@ def _bin_finish(st):
         return 0, torch.zeros(0, **i32), tile_bins
     st["done"].synchronize()
     num_intersects = int(st["pinned"][0])
-    raise_pending_checks()
+    failed = any(int(st["pinned"][1 + i]) for i in range(st["n_flags"]))
+    assert not failed, "quats must be normalized"
+    if _pending_checks:                    # checks queued after the prefetch (rare): one more read-back
+        raise_pending_checks()
     lib = L.load()
     ids_sorted = torch.empty(num_intersects, **i32)
     ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(num_intersects), st["dev"])
