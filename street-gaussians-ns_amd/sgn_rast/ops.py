@@ -285,14 +285,14 @@ def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_boun
                                           conics, opacity, opacity_is_logit, cull))
 
 
-_side = {}   # per device: (side stream, pinned int32[1])
+_side = {}   # per device: pinned int32[8] (intersection count + up to 7 deferred-check flags)
 
 
 def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
                        opacity_is_logit, cull):
-    """First half of the fused binning: depth rank, kept-tile counts, scan — and the read-back of the intersection
-    count started on a side stream, so the caller may queue independent work on the current stream before it calls
-    :func:`_bin_finish` (which is where the host waits)."""
+    """First half of the fused binning: depth rank, kept-tile counts, scan — and the asynchronous read-back of the
+    intersection count into pinned memory, so the caller may queue independent work behind it before it calls
+    :func:`_bin_finish` (which is where the host waits, for the copy only)."""
     dev = L.require_device(xys, depths, radii, num_tiles_hit, conics, opacity)
     lib = L.load()
     n = int(num_points)
@@ -315,20 +315,17 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
                                 L.ptr(gid_by_rank), L.ptr(bin_recs), L.ptr(ws), ws.numel(), L.stream_ptr()),
             "sgn_bin_prepare")
     if dev not in _side:
-        _side[dev] = (torch.cuda.Stream(device=dev), torch.empty(8, dtype=torch.int32).pin_memory())
-    side, pinned = _side[dev]
-    ready = torch.cuda.Event()
-    ready.record(torch.cuda.current_stream(dev))
-    side.wait_event(ready)
+        _side[dev] = torch.empty(8, dtype=torch.int32).pin_memory()
+    pinned = _side[dev]
     # pending argument checks ride along: their flags reach the host in the same transfer as the count, so the
-    # deferred assertion costs no round trip of its own
+    # deferred assertion costs no round trip of its own.  The copies are queued on the current stream (a side stream
+    # would add an event hop of ~15 us before the copy even starts); work queued afterwards simply follows them.
     flags = [_pending_checks.pop() for _ in range(min(len(_pending_checks), 7))]
-    with torch.cuda.stream(side):
-        pinned[0:1].copy_(cum_r[n - 1:n], non_blocking=True)
-        for i, f in enumerate(flags):
-            pinned[1 + i:2 + i].copy_(f, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record(side)
+    pinned[0:1].copy_(cum_r[n - 1:n], non_blocking=True)
+    for i, f in enumerate(flags):
+        pinned[1 + i:2 + i].copy_(f, non_blocking=True)
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(dev))
     st.update(cum_r=cum_r, gid_by_rank=gid_by_rank, bin_recs=bin_recs, ws=ws, done=done, pinned=pinned,
               n_flags=len(flags), keep=(xys_c, radii_c, conics_c, opac_c, flags))
     return st
