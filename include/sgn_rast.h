@@ -231,7 +231,15 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                                           depth list binned once for the whole scene*/,
                    const float *background3, float *out_img /*[H,W,3]*/, float *final_Ts /*[H,W]*/,
                    int32_t *final_idx /*[H,W]*/, void *recs_ws, size_t recs_ws_bytes,
+                   int rows_built /*1: sgn_raster_build_rows already filled recs_ws (gather mode)*/,
                    sgn_stream_t stream);
+/* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built
+ * while the host waits for the intersection count (keeps the GPU busy across that sync).  sgn_raster_gather_mode()
+ * tells whether the current record-fetch mode can use pre-built rows (1) or re-packs them itself (0). */
+int sgn_raster_build_rows(int n, const float *xys, const float *conics, const float *colors, const float *opacities,
+                          int opacity_is_logit, int id_lo, int id_hi, void *recs_ws, size_t recs_ws_bytes,
+                          sgn_stream_t stream);
+int sgn_raster_gather_mode(void);
 
 /* _C.rasterize_backward.  alpha_clamp_bwd: 0.99f reproduces gsplat 0.1.x (which clamps at
  * 0.999 in forward and 0.99 in backward).  Outputs are fully written (zero-filled first).

@@ -651,11 +651,32 @@ static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float 
     return 0;
 }
 
+// The per-Gaussian rows do not depend on the intersection list: a caller may build them while it waits for the
+// intersection count (pass rows_built = 1 to sgn_raster_fwd afterwards; gather mode only — in stream mode the rows are
+// re-packed into depth order and sgn_raster_fwd builds them itself).
+SGN_EXPORT int sgn_raster_build_rows(int n, const float *xys, const float *conics, const float *colors,
+                                     const float *opacities, int opacity_is_logit, int id_lo, int id_hi,
+                                     void *recs_ws, size_t recs_ws_bytes, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(xys && conics && colors && opacities && recs_ws, -2);
+    SGN_ARG_CHECK(recs_ws_bytes >= (size_t)n * sizeof(Rec), -3);
+    hipStream_t s = (hipStream_t)stream;
+    sgn_timing_begin(SGN_T_PACK, s);
+    hipLaunchKernelGGL(build_grec_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, conics, colors, opacities,
+                       opacity_is_logit, id_lo, id_hi, (float4 *)recs_ws);
+    sgn_timing_end(SGN_T_PACK, s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_raster_gather_mode(void) { return g_gather; }
+
 SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
                               int opacity_is_logit, int id_lo, int id_hi, const float *background3, float *out_img,
-                              float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes,
+                              float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes, int rows_built,
                               sgn_stream_t stream) {
     SGN_ARG_CHECK(img_h > 0 && img_w > 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
@@ -664,7 +685,7 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     SGN_ARG_CHECK(n_isect == 0 || (gaussian_ids_sorted && xys && conics && colors && opacities && recs_ws), -5);
     SGN_ARG_CHECK(n >= 0 && recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect), -6);
     hipStream_t s = (hipStream_t)stream;
-    if (n_isect > 0)
+    if (n_isect > 0 && !(rows_built && g_gather))
         pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
                      recs_ws, s);
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;

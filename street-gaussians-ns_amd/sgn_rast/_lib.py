@@ -68,7 +68,9 @@ SIGNATURES = {
     "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sgn_raster_workspace_bytes": (_sz, [_i, _i64]),
     "sgn_raster_fwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
-                            _vp]),
+                            _i, _vp]),
+    "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "sgn_raster_gather_mode": (_i, []),
     "sgn_raster_bwd_workspace_bytes": (_sz, [_i]),
     "sgn_raster_bwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f,
                             _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp]),

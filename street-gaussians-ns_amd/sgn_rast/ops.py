@@ -443,23 +443,39 @@ class _RasterizeGaussians(Function):
         final_Ts = torch.empty(img_height, img_width, **f32)
         final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
         stream_ptr = L.stream_ptr()
+        # ... and the per-Gaussian rows are built between the binning's first half and its host sync, so the GPU has
+        # work queued while the host wakes up (gather mode; the stream mode re-packs rows per intersection later)
+        key, _t, cull = _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
+                                   opacity_is_logit)
+        recs, rows_built = None, 0
+        if num_points > 0 and lib.sgn_raster_gather_mode():
+            if not (binning_cache_enabled and _bin_cache["key"] == key) and _bin_pending["key"] != key:
+                _bin_pending["state"] = _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds,
+                                                           block_width, conics, opacity, opacity_is_logit, cull)
+                _bin_pending["key"], _bin_pending["keep"] = key, tuple(t.detach() for t in _t)
+            recs = L.workspace(lib.sgn_raster_workspace_bytes(num_points, 0), dev)
+            L.check(lib.sgn_raster_build_rows(num_points, L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c),
+                                              int(bool(opacity_is_logit)), id_lo, id_hi, L.ptr(recs), recs.numel(),
+                                              stream_ptr), "sgn_raster_build_rows")
+            rows_built = 1
         num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
             num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
             opacity_is_logit)
-        recs = None
         if num_intersects < 1:
+            recs = None
             out_img = torch.ones(img_height, img_width, 3, **f32) * bg_c
             gaussian_ids_sorted = torch.zeros(0, dtype=torch.int32, device=dev)
             tile_bins = torch.zeros(tile_bounds[0] * tile_bounds[1], 2, dtype=torch.int32, device=dev)
             final_Ts = torch.ones(img_height, img_width, **f32)
             final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
         else:
-            recs = L.workspace(lib.sgn_raster_workspace_bytes(num_points, num_intersects), dev)
+            if not rows_built:
+                recs = L.workspace(lib.sgn_raster_workspace_bytes(num_points, num_intersects), dev)
             L.check(lib.sgn_raster_fwd(
                 img_height, img_width, block_width, num_points, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), id_lo, id_hi,
                 L.ptr(bg_c), L.ptr(out_img),
-                L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), stream_ptr), "sgn_raster_fwd")
+                L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), rows_built, stream_ptr), "sgn_raster_fwd")
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
         ctx.num_intersects = num_intersects
         ctx.opacity_is_logit = int(bool(opacity_is_logit))
