@@ -289,15 +289,15 @@ int sgn_sky_blend_bwd(int h, int w, float fx, float fy, float cx, float cy, cons
 
 /* Fused photometric loss (sgn_splatfacto.py:1084-1087): Ll1 = mean |gt - pred| and
  * ssim = pytorch_msssim.SSIM(data_range, size_average=True, channel=3) of two [h,w,3] images (11-tap Gaussian window,
- * sigma 1.5, no padding, K = (0.01, 0.03)); h, w > 10.  sums2 (device, 2 floats) receives the two SUMS: the caller
- * divides by 3hw and 3(h-10)(w-10).  ws (>= sgn_l1_ssim_workspace_bytes) holds per-workgroup partial sums and, with
+ * sigma 1.5, no padding, K = (0.01, 0.03)); h, w > 10.  out3 (device, 3 floats) receives Ll1, ssim and the reference's
+ * weighted sum (1 - ssim_lambda) Ll1 + ssim_lambda (1 - ssim) (:1086-1087).  ws (>= sgn_l1_ssim_workspace_bytes) holds per-workgroup partial sums and, with
  * with_grad != 0, the SSIM partials sgn_l1_ssim_bwd needs (pass the same ws); the backward writes d loss / d pred
  * given gscale2 = (d loss/d Ll1, d loss/d ssim) as two DEVICE floats (no host sync between backward nodes). */
 size_t sgn_l1_ssim_workspace_bytes(int h, int w, int with_grad);
 int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt, float data_range,
                     float clamp_max /*pred is read as min(pred, clamp_max): the caller's rgb.clamp(max=1),
                                       sgn_splatfacto.py:969, folded in; pass INFINITY for none*/,
-                    float *sums2, int with_grad, void *ws, size_t ws_bytes, sgn_stream_t stream);
+                    float ssim_lambda, float *out3, int with_grad, void *ws, size_t ws_bytes, sgn_stream_t stream);
 int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt, float clamp_max, const void *ws,
                     const float *gscale2, float *v_pred, sgn_stream_t stream);
 

@@ -136,14 +136,22 @@ __global__ __launch_bounds__(256) void l1_ssim_fwd_kernel(int H, int W, Win win,
     }
 }
 
+// out3 = [Ll1 = mean |gt - pred|, ssim mean, (1 - lambda) Ll1 + lambda (1 - ssim)]: the means and the reference's
+// weighted sum (sgn_splatfacto.py:1086-1087) come out of the reduction itself instead of a dozen scalar torch kernels
 __global__ __launch_bounds__(256) void l1_ssim_reduce_kernel(int nblk, const float *__restrict__ partials,
-                                                             float *__restrict__ sums) {
+                                                             float inv_n_l1, float inv_n_ss, float lambda,
+                                                             float *__restrict__ out3) {
     __shared__ float lds4[4];
     float a = 0.f, b = 0.f;
     for (int i = threadIdx.x; i < nblk; i += 256) { a += partials[2 * i]; b += partials[2 * i + 1]; }
     a = block_sum(a, lds4);
     b = block_sum(b, lds4);
-    if (threadIdx.x == 0) { sums[0] = a; sums[1] = b; }
+    if (threadIdx.x == 0) {
+        const float l1 = a * inv_n_l1, ss = b * inv_n_ss;
+        out3[0] = l1;
+        out3[1] = ss;
+        out3[2] = (1.f - lambda) * l1 + lambda * (1.f - ss);
+    }
 }
 
 // v_pred [H,W,3] = gl1 * sign(pred - gt) / (3HW) + gss / (3 Ho Wo) * (G*A + 2 pred G*B + gt G*C)
@@ -254,10 +262,10 @@ SGN_EXPORT size_t sgn_l1_ssim_workspace_bytes(int h, int w, int with_grad) {
 }
 
 SGN_EXPORT int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt, float data_range, float clamp_max,
-                               float *sums2 /*device: [sum |gt-pred|, sum ssim_map]*/, int with_grad, void *ws,
-                               size_t ws_bytes, sgn_stream_t stream) {
+                               float ssim_lambda, float *out3 /*device: [Ll1, ssim, (1-l) Ll1 + l (1-ssim)]*/,
+                               int with_grad, void *ws, size_t ws_bytes, sgn_stream_t stream) {
     SGN_ARG_CHECK(h > HALO && w > HALO, -1);      // pytorch_msssim asserts the image is larger than the window
-    SGN_ARG_CHECK(pred && gt && sums2 && ws, -2);
+    SGN_ARG_CHECK(pred && gt && out3 && ws, -2);
     SGN_ARG_CHECK(ws_bytes >= sgn_l1_ssim_workspace_bytes(h, w, with_grad), -3);
     hipStream_t s = (hipStream_t)stream;
     float *partials = (float *)ws;
@@ -268,7 +276,9 @@ SGN_EXPORT int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt,
     sgn_timing_begin(SGN_T_LOSS_FWD, (void *)s);
     hipLaunchKernelGGL(l1_ssim_fwd_kernel, grid, dim3(256), 0, s, h, w, win, C1, C2, clamp_max, pred, gt, partials,
                        dmaps);
-    hipLaunchKernelGGL(l1_ssim_reduce_kernel, dim3(1), dim3(256), 0, s, (int)(grid.x * grid.y), partials, sums2);
+    hipLaunchKernelGGL(l1_ssim_reduce_kernel, dim3(1), dim3(256), 0, s, (int)(grid.x * grid.y), partials,
+                       1.f / (3.f * (float)h * (float)w), 1.f / (3.f * (float)(h - HALO) * (float)(w - HALO)),
+                       ssim_lambda, out3);
     sgn_timing_end(SGN_T_LOSS_FWD, (void *)s);
     SGN_LAUNCH_CHECK();
     return 0;

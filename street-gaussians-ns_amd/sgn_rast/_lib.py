@@ -48,7 +48,7 @@ SIGNATURES = {
     "sgn_sky_blend_fwd": (_i, [_i, _i, _f, _f, _f, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_sky_blend_bwd": (_i, [_i, _i, _f, _f, _f, _f, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_l1_ssim_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sgn_l1_ssim_fwd": (_i, [_i, _i, _vp, _vp, _f, _f, _vp, _i, _vp, _sz, _vp]),
+    "sgn_l1_ssim_fwd": (_i, [_i, _i, _vp, _vp, _f, _f, _f, _vp, _i, _vp, _sz, _vp]),
     "sgn_l1_ssim_bwd": (_i, [_i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "sgn_adam_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_densify_stats": (_i, [_i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),

@@ -21,38 +21,67 @@ import torch
 from . import _lib as L
 
 
+def _forward(ctx, pred, gt, data_range, clamp_max, ssim_lambda):
+    L.require_device(pred, gt)
+    if pred.dim() != 3 or pred.shape[-1] != 3 or pred.shape != gt.shape:
+        raise ValueError(f"l1_ssim expects two [H,W,3] images, got {tuple(pred.shape)} and {tuple(gt.shape)}")
+    h, w = pred.shape[0], pred.shape[1]
+    if min(h, w) <= 10:
+        raise ValueError("images must be larger than the 11-tap SSIM window")   # pytorch_msssim asserts too
+    p, g = pred.contiguous().float(), gt.contiguous().float()
+    lib = L.load()
+    out3 = torch.empty(3, dtype=torch.float32, device=p.device)
+    need_grad = int(bool(ctx.needs_input_grad[0]))
+    maps = L.workspace(lib.sgn_l1_ssim_workspace_bytes(h, w, need_grad), p.device)
+    cmax = float("inf") if clamp_max is None else float(clamp_max)
+    L.check(lib.sgn_l1_ssim_fwd(h, w, L.ptr(p), L.ptr(g), float(data_range), cmax, float(ssim_lambda), L.ptr(out3),
+                                need_grad, L.ptr(maps), maps.numel(), L.stream_ptr()), "sgn_l1_ssim_fwd")
+    ctx.hw, ctx.cmax, ctx.maps = (h, w), cmax, maps
+    ctx.save_for_backward(p, g)
+    return out3
+
+
+def _backward(ctx, gscale):
+    p, g = ctx.saved_tensors
+    h, w = ctx.hw
+    v = torch.empty_like(p)
+    L.check(L.load().sgn_l1_ssim_bwd(h, w, L.ptr(p), L.ptr(g), ctx.cmax, L.ptr(ctx.maps), L.ptr(gscale), L.ptr(v),
+                                     L.stream_ptr()), "sgn_l1_ssim_bwd")
+    return v
+
+
 class _L1SSIM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, gt, data_range, clamp_max):
-        L.require_device(pred, gt)
-        if pred.dim() != 3 or pred.shape[-1] != 3 or pred.shape != gt.shape:
-            raise ValueError(f"l1_ssim expects two [H,W,3] images, got {tuple(pred.shape)} and {tuple(gt.shape)}")
-        h, w = pred.shape[0], pred.shape[1]
-        if min(h, w) <= 10:
-            raise ValueError("images must be larger than the 11-tap SSIM window")   # pytorch_msssim asserts too
-        p, g = pred.contiguous().float(), gt.contiguous().float()
-        lib = L.load()
-        sums = torch.empty(2, dtype=torch.float32, device=p.device)
-        need_grad = int(bool(ctx.needs_input_grad[0]))
-        maps = L.workspace(lib.sgn_l1_ssim_workspace_bytes(h, w, need_grad), p.device)
-        cmax = float("inf") if clamp_max is None else float(clamp_max)
-        L.check(lib.sgn_l1_ssim_fwd(h, w, L.ptr(p), L.ptr(g), float(data_range), cmax, L.ptr(sums), need_grad,
-                                    L.ptr(maps), maps.numel(), L.stream_ptr()), "sgn_l1_ssim_fwd")
-        ctx.hw = (h, w)
-        ctx.cmax = cmax
-        ctx.maps = maps
-        ctx.save_for_backward(p, g)
-        return sums[0] / (3.0 * h * w), sums[1] / (3.0 * (h - 10) * (w - 10))
+        out3 = _forward(ctx, pred, gt, data_range, clamp_max, 0.0)
+        return out3[0], out3[1]
 
     @staticmethod
     def backward(ctx, g_l1, g_ssim):
-        p, g = ctx.saved_tensors
-        h, w = ctx.hw
         gscale = torch.stack([g_l1.reshape(()), g_ssim.reshape(())]).float().contiguous()
-        v = torch.empty_like(p)
-        L.check(L.load().sgn_l1_ssim_bwd(h, w, L.ptr(p), L.ptr(g), ctx.cmax, L.ptr(ctx.maps), L.ptr(gscale), L.ptr(v),
-                                         L.stream_ptr()), "sgn_l1_ssim_bwd")
-        return v, None, None, None
+        return _backward(ctx, gscale), None, None, None
+
+
+_LAMBDA_VEC: dict = {}
+
+
+class _Photometric(torch.autograd.Function):
+    """(1 - l) Ll1 + l (1 - ssim) as ONE node: the weighted sum is formed in the reduction kernel, the backward
+    turns the upstream scalar into the two weights with a single tiny multiply."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, ssim_lambda, clamp_max):
+        out3 = _forward(ctx, pred, gt, 1.0, clamp_max, ssim_lambda)
+        ctx.lam = float(ssim_lambda)
+        return out3[2]
+
+    @staticmethod
+    def backward(ctx, g):
+        key = (ctx.lam, str(g.device))
+        if key not in _LAMBDA_VEC:
+            _LAMBDA_VEC[key] = torch.tensor([1.0 - ctx.lam, -ctx.lam], dtype=torch.float32, device=g.device)
+        gscale = (_LAMBDA_VEC[key] * g.reshape(())).contiguous()
+        return _backward(ctx, gscale), None, None, None
 
 
 def l1_ssim(pred: torch.Tensor, gt: torch.Tensor, data_range: float = 1.0, clamp_max=None):
@@ -63,9 +92,9 @@ def l1_ssim(pred: torch.Tensor, gt: torch.Tensor, data_range: float = 1.0, clamp
 
 
 def photometric_loss(pred: torch.Tensor, gt: torch.Tensor, ssim_lambda: float = 0.2, clamp_max=None) -> torch.Tensor:
-    """``(1 - l) * Ll1 + l * (1 - ssim)`` — the sum of losses["Ll1"] and losses["simloss"] (``:1086-1087``)."""
-    Ll1, s = l1_ssim(pred, gt, clamp_max=clamp_max)
-    return (1.0 - ssim_lambda) * Ll1 + ssim_lambda * (1.0 - s)
+    """``(1 - l) * Ll1 + l * (1 - ssim)`` — the sum of losses["Ll1"] and losses["simloss"] (``:1086-1087``), one
+    forward and one backward kernel plus a single scalar multiply."""
+    return _Photometric.apply(pred, gt, ssim_lambda, clamp_max)
 
 
 def _as_hwc(t: torch.Tensor) -> torch.Tensor:
