@@ -176,6 +176,8 @@ def _check_quats(quats: torch.Tensor) -> None:
     flag = torch.empty(1, dtype=torch.int32, device=q.device)
     L.check(L.load().sgn_check_unit_quats(q.shape[0], L.ptr(q), 1e-6, L.ptr(flag), L.stream_ptr()),
             "sgn_check_unit_quats")
+    if len(_pending_checks) >= 16:     # projections without a rasterize call in between: settle the backlog now
+        raise_pending_checks()
     _pending_checks.append(flag)
 
 
@@ -285,7 +287,7 @@ def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_boun
                                           conics, opacity, opacity_is_logit, cull))
 
 
-_side = {}   # per device: pinned int32[8] (intersection count + up to 7 deferred-check flags)
+_side = {}   # per device: [pinned int32[4,8] (count + up to 7 deferred-check flags per in-flight prepare), next slot]
 
 
 def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
@@ -315,8 +317,10 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
                                 L.ptr(gid_by_rank), L.ptr(bin_recs), L.ptr(ws), ws.numel(), L.stream_ptr()),
             "sgn_bin_prepare")
     if dev not in _side:
-        _side[dev] = torch.empty(8, dtype=torch.int32).pin_memory()
-    pinned = _side[dev]
+        _side[dev] = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]
+    pool = _side[dev]
+    pinned = pool[0][pool[1] % 4]          # rotate: a prepare that is still pending keeps its own slot
+    pool[1] += 1
     # pending argument checks ride along: their flags reach the host in the same transfer as the count, so the
     # deferred assertion costs no round trip of its own.  The copies are queued on the current stream (a side stream
     # would add an event hop of ~15 us before the copy even starts); work queued afterwards simply follows them.
