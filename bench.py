@@ -240,7 +240,7 @@ def main():
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier()
+            torch.distributed.barrier(device_ids=[local])
 
     for _ in range(args.warmup):
         out = one_step()
