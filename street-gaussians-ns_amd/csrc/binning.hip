@@ -261,20 +261,24 @@ constexpr int ROWS_BIG = SGN_ROWS_BIG;   // bboxes taller than this are handled 
 struct NoOut {
     __device__ __forceinline__ void operator()(int, uint32_t, int32_t) const {}
 };
+// TK = tile-key type: uint16_t whenever the image has at most 65536 tiles (1920x1280/16 = 9600), which takes a
+// quarter of the bytes off the emission and off every pass of the tile sort; uint32_t otherwise.
+template <typename TK>
 struct GlobalOut {
-    uint32_t *__restrict__ tkeys;
+    TK *__restrict__ tkeys;
     int32_t *__restrict__ tvals;
     __device__ __forceinline__ void operator()(int pos, uint32_t key, int32_t val) const {
-        tkeys[pos] = key;
+        tkeys[pos] = (TK)key;
         tvals[pos] = val;
     }
 };
+template <typename TK>
 struct LdsOut {          // wave-local staging: positions relative to the wave's first output slot
-    uint32_t *keys;
+    TK *keys;
     int32_t *vals;
     int base;
     __device__ __forceinline__ void operator()(int pos, uint32_t key, int32_t val) const {
-        keys[pos - base] = key;
+        keys[pos - base] = (TK)key;
         vals[pos - base] = val;
     }
 };
@@ -380,12 +384,13 @@ __global__ __launch_bounds__(256) void gather_counts_kernel(int n, const int32_t
 // entries the pairs are staged in LDS and written out with full-width coalesced stores (per-lane sequential
 // dword stores cost one memory request each: 16.6 M requests per view on the benchmark scene).
 constexpr int EMIT_CAP = 1024;
+template <typename TK>
 __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__restrict__ gid_by_rank,
                                                       const int32_t *__restrict__ cum_r,
                                                       const BinRec *__restrict__ recs, int tiles_x, int tiles_y,
-                                                      int block, uint32_t *__restrict__ tkeys,
+                                                      int block, TK *__restrict__ tkeys,
                                                       int32_t *__restrict__ tvals) {
-    __shared__ uint32_t lk[EMIT_CAP];
+    __shared__ TK lk[EMIT_CAP];
     __shared__ int32_t lv[EMIT_CAP];
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 64, r = r0 + lane;
@@ -409,19 +414,20 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
     }
     const Ellipse E = make_ellipse(gx, gy, a, b, c, s);
     if (total <= EMIT_CAP) {
-        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, LdsOut{lk, lv, base});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, LdsOut<TK>{lk, lv, base});
         __syncthreads();                                      // single-wave workgroup: a fence, no s_barrier
         for (int j = lane; j < total; j += 64) {
             tkeys[base + j] = lk[j];
             tvals[base + j] = lv[j];
         }
     } else {
-        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, GlobalOut{tkeys, tvals});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, GlobalOut<TK>{tkeys, tvals});
     }
 }
 
 // sorted tile ids -> tile_bins
-__global__ __launch_bounds__(256) void tile_bins32_kernel(int64_t n_isect, const uint32_t *__restrict__ tkeys,
+template <typename TK>
+__global__ __launch_bounds__(256) void tile_bins32_kernel(int64_t n_isect, const TK *__restrict__ tkeys,
                                                           int32_t *__restrict__ bins) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_isect) return;
@@ -498,6 +504,8 @@ SGN_EXPORT int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_
 size_t sgn_sort_pairs32_ws_bytes(int64_t n);
 void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const int32_t *vin, uint32_t *kout,
                              int32_t *vout, void *ws, hipStream_t s);
+void sgn_sort_pairs16_launch(uint32_t n, int end_bit, const uint16_t *kin, const int32_t *vin, uint16_t *kout,
+                             int32_t *vout, void *ws, hipStream_t s);
 
 SGN_EXPORT size_t sgn_bin_prepare_workspace_bytes(int n) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
@@ -568,17 +576,34 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
     int32_t *tvals = (int32_t *)p;          p += al256((size_t)n_isect * 4);
     uint32_t *tkeys_sorted = (uint32_t *)p; p += al256((size_t)n_isect * 4);
     void *sort_ws = p;
-    sgn_timing_begin(SGN_T_MAP, s);
-    hipLaunchKernelGGL(bin_emit_kernel, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
-                       reinterpret_cast<const BinRec *>(bin_records), tiles_x, tiles_y, block_width, tkeys, tvals);
-    sgn_timing_end(SGN_T_MAP, s);
-    sgn_timing_begin(SGN_T_SORT, s);
-    sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws, s);
-    sgn_timing_end(SGN_T_SORT, s);
-    sgn_timing_begin(SGN_T_BINS, s);
-    hipLaunchKernelGGL(tile_bins32_kernel, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, tkeys_sorted,
-                       tile_bins);
-    sgn_timing_end(SGN_T_BINS, s);
+    const BinRec *recs = reinterpret_cast<const BinRec *>(bin_records);
+    if (n_tiles <= 65536) {       // 16-bit tile keys (the buffers keep their 4-byte-per-key size)
+        uint16_t *k16 = (uint16_t *)tkeys, *k16s = (uint16_t *)tkeys_sorted;
+        sgn_timing_begin(SGN_T_MAP, s);
+        hipLaunchKernelGGL(bin_emit_kernel<uint16_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
+                           recs, tiles_x, tiles_y, block_width, k16, tvals);
+        sgn_timing_end(SGN_T_MAP, s);
+        sgn_timing_begin(SGN_T_SORT, s);
+        sgn_sort_pairs16_launch((uint32_t)n_isect, tile_bits, k16, tvals, k16s, gaussian_ids_sorted, sort_ws, s);
+        sgn_timing_end(SGN_T_SORT, s);
+        sgn_timing_begin(SGN_T_BINS, s);
+        hipLaunchKernelGGL(tile_bins32_kernel<uint16_t>, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, k16s,
+                           tile_bins);
+        sgn_timing_end(SGN_T_BINS, s);
+    } else {
+        sgn_timing_begin(SGN_T_MAP, s);
+        hipLaunchKernelGGL(bin_emit_kernel<uint32_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
+                           recs, tiles_x, tiles_y, block_width, tkeys, tvals);
+        sgn_timing_end(SGN_T_MAP, s);
+        sgn_timing_begin(SGN_T_SORT, s);
+        sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws,
+                                s);
+        sgn_timing_end(SGN_T_SORT, s);
+        sgn_timing_begin(SGN_T_BINS, s);
+        hipLaunchKernelGGL(tile_bins32_kernel<uint32_t>, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect,
+                           tkeys_sorted, tile_bins);
+        sgn_timing_end(SGN_T_BINS, s);
+    }
     SGN_LAUNCH_CHECK();
     return 0;
 }

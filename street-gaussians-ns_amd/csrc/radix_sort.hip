@@ -281,6 +281,12 @@ void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const
     sort_launch<uint32_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s);
 }
 
+// 16-bit keys (tile ids of images with <= 65536 tiles); same workspace layout and size as the 32-bit entry
+void sgn_sort_pairs16_launch(uint32_t n, int end_bit, const uint16_t *kin, const int32_t *vin, uint16_t *kout,
+                             int32_t *vout, void *ws, hipStream_t s) {
+    sort_launch<uint16_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s);
+}
+
 SGN_EXPORT size_t sgn_sort_workspace_bytes(int64_t n_isect) { return sort_ws_bytes<uint64_t, true, 8>(n_isect); }
 
 SGN_EXPORT int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const int64_t *keys_in,
