@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
                                                         const float *__restrict__ depths,
                                                         const int32_t *__restrict__ radii, Cull cull, int tiles_x,
                                                         int tiles_y, int block, uint32_t *__restrict__ dkeys,
-                                                        int32_t *__restrict__ dvals, BinRec *__restrict__ recs) {
+                                                        int32_t *__restrict__ dvals, BinRec *__restrict__ recs,
+                                                        int32_t *__restrict__ cnt_gid) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     int mnx = 0, mny = 0, mxx = 0, mxy = 0;
     BinRec R;
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
     if (i < n) {
         dkeys[i] = R.rad > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;  // culled splats sort last
         dvals[i] = i;
+        cnt_gid[i] = R.cnt;             // dense copy: the rank-order gather below then works on 4 B/Gaussian
         float4 *o = reinterpret_cast<float4 *>(recs + i);
         o[0] = make_float4(R.gx, R.gy, R.a, R.b);
         o[1] = make_float4(R.c, R.s, __int_as_float(R.rad), __int_as_float(R.cnt));
@@ -373,10 +375,10 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
 }
 
 __global__ __launch_bounds__(256) void gather_counts_kernel(int n, const int32_t *__restrict__ gid_by_rank,
-                                                            const BinRec *__restrict__ recs,
+                                                            const int32_t *__restrict__ cnt_gid,
                                                             int32_t *__restrict__ cnt_r) {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < n) cnt_r[r] = recs[gid_by_rank[r]].cnt;
+    if (r < n) cnt_r[r] = cnt_gid[gid_by_rank[r]];
 }
 
 // lane = depth rank r: writes the (tile, gaussian id) pairs of Gaussian gid_by_rank[r] starting at cum_r[r-1].
@@ -509,7 +511,7 @@ void sgn_sort_pairs16_launch(uint32_t n, int end_bit, const uint16_t *kin, const
 
 SGN_EXPORT size_t sgn_bin_prepare_workspace_bytes(int n) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
-    return al256(sgn_scan_workspace_bytes(n)) + 4 * al256(nn * 4) + sgn_sort_pairs32_ws_bytes(n);
+    return al256(sgn_scan_workspace_bytes(n)) + 5 * al256(nn * 4) + sgn_sort_pairs32_ws_bytes(n);
 }
 
 static Cull make_cull(const float *conics, const float *opac, int opac_is_logit, int cull) {
@@ -536,18 +538,19 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     int32_t *dvals = (int32_t *)p;   p += al256((size_t)n * 4);
     uint32_t *dkeys_sorted = (uint32_t *)p; p += al256((size_t)n * 4);
     int32_t *cnt_r = (int32_t *)p;   p += al256((size_t)n * 4);
+    int32_t *cnt_gid = (int32_t *)p; p += al256((size_t)n * 4);
     void *sort_ws = p;
     const Cull c = make_cull(conics, opacities, opacity_is_logit, cull);
     BinRec *recs = reinterpret_cast<BinRec *>(bin_records);
     sgn_timing_begin(SGN_T_MAP, s);
     hipLaunchKernelGGL(bin_count_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, depths, radii, c, tiles_x,
-                       tiles_y, block_width, dkeys, dvals, recs);
+                       tiles_y, block_width, dkeys, dvals, recs, cnt_gid);
     sgn_timing_end(SGN_T_MAP, s);
     sgn_timing_begin(SGN_T_SORT, s);
     sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
     sgn_timing_end(SGN_T_SORT, s);
     sgn_timing_begin(SGN_T_MAP, s);
-    hipLaunchKernelGGL(gather_counts_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, gid_by_rank, recs, cnt_r);
+    hipLaunchKernelGGL(gather_counts_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, gid_by_rank, cnt_gid, cnt_r);
     sgn_timing_end(SGN_T_MAP, s);
     return sgn_scan_i32(n, cnt_r, cum_by_rank, scan_ws, sgn_scan_workspace_bytes(n), stream);
 }
