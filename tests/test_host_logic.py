@@ -101,3 +101,41 @@ def test_dependency_shims_resolve_to_the_hip_modules():
     assert dr.texture is sky.texture and ms.SSIM is loss.SSIM
     mod = ms.SSIM(data_range=1.0, size_average=True, channel=3)          # the reference's constructor call (:330)
     assert mod.data_range == 1.0
+
+
+def test_next_row_modules_validate_arguments_without_a_gpu():
+    """sky / loss / optim / densify: argument errors are raised on the host, and CPU tensors are refused (no
+    fallback) before anything touches the device."""
+    from sgn_rast import _lib, densify, loss, optim, sky
+    tex, uv = torch.rand(1, 6, 4, 4, 3), torch.rand(1, 2, 2, 3)
+    with pytest.raises(NotImplementedError):
+        sky.texture(tex, uv, filter_mode="nearest")
+    with pytest.raises(NotImplementedError):
+        sky.texture(tex, uv, boundary_mode="wrap")
+    with pytest.raises(ValueError):
+        sky.texture(torch.rand(1, 5, 4, 4, 3), uv)                  # not a cube map
+    with pytest.raises(ValueError):
+        sky.texture(tex, torch.rand(2, 2, 2, 3))                    # batch mismatch
+    with pytest.raises(_lib.SgnRastError):
+        sky.texture(tex, uv)                                        # CPU tensors: refused
+    with pytest.raises(NotImplementedError):
+        loss.SSIM(data_range=1.0, size_average=False)
+    with pytest.raises(NotImplementedError):
+        loss.SSIM(data_range=1.0, channel=1)
+    with pytest.raises(ValueError):
+        loss.SSIM(data_range=1.0)(torch.rand(2, 3, 16, 16), torch.rand(2, 3, 16, 16))   # batch 1 only
+    with pytest.raises(_lib.SgnRastError):
+        loss.l1_ssim(torch.rand(16, 16, 3), torch.rand(16, 16, 3))
+    with pytest.raises(NotImplementedError):
+        optim.FusedAdam([torch.zeros(3, requires_grad=True)], amsgrad=True)
+    with pytest.raises(ValueError):
+        optim.FusedAdam([torch.zeros(3, requires_grad=True)], lr=-1.0)
+    p = torch.zeros(3, requires_grad=True)
+    p.grad = torch.ones(3)
+    with pytest.raises(_lib.SgnRastError):
+        optim.FusedAdam([p]).step()
+    with pytest.raises(_lib.SgnRastError):
+        densify.Stats().update(torch.zeros(4, 2), torch.ones(4, dtype=torch.int32), (8, 8))
+    # the state layout is torch.optim.Adam's (the reference's densification edits these tensors in place)
+    o = optim.FusedAdam([torch.zeros(3, requires_grad=True)], lr=1e-3, eps=1e-15)
+    assert o.param_groups[0]["eps"] == 1e-15 and o.param_groups[0]["betas"] == (0.9, 0.999)
