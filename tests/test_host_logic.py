@@ -139,3 +139,17 @@ def test_next_row_modules_validate_arguments_without_a_gpu():
     # the state layout is torch.optim.Adam's (the reference's densification edits these tensors in place)
     o = optim.FusedAdam([torch.zeros(3, requires_grad=True)], lr=1e-3, eps=1e-15)
     assert o.param_groups[0]["eps"] == 1e-15 and o.param_groups[0]["betas"] == (0.9, 0.999)
+
+
+def test_bench_cpu_baseline_leg_runs_without_a_gpu():
+    """bench.py's bounded CPU-baseline sample (the oracle timed on the host cores) is a separate process that needs no
+    GPU; its JSON carries the fields the bench line embeds."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-baseline-only", "--scene", "c1",
+                          "--cpu-rows", "1", "--cpu-frac", "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-500:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["unit"] == "images/sec" and d["kind"] == "port" and d["value"] > 0 and d["cores"] >= 1
+    assert "2500 of 10000 Gaussians" in d["sample"]
