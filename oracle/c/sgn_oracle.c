@@ -541,3 +541,112 @@ SGO_API void sgo_raster_bwd(int H, int W, int block, int N, const int32_t *ids,
     }
     free(acc);
 }
+
+/* ============================================================================================================
+ * Callers either side of the rasterizer — second, independent restatement next to
+ * oracle/torch_oracle.py (cube_texture, ssim): scalar loops, double accumulation.  PARITY UNPINNED like the rest of
+ * this file: nvdiffrast (empty submodule in the reference) and pytorch_msssim (PyPI dependency) are not available;
+ * these follow their published behaviour as used at street_gaussians_ns/sgn_splatfacto.py:145 and :330,1084-1087.
+ * ============================================================================================================ */
+
+/* direction -> (face, u, v) of the GL cube map (+x,-x,+y,-y,+z,-z); returns -1 for non-finite input */
+static int cube_face_uv(const float d[3], float *u, float *v) {
+    const float x = d[0], y = d[1], z = d[2];
+    const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
+    int idx; float c, sx = x, sy = y;
+    if (az > fmaxf(ax, ay)) { idx = 4; c = z; }
+    else if (ay > ax) { idx = 2; c = y; sy = z; }
+    else { idx = 0; c = x; sx = z; }
+    if (c < 0.f) idx += 1;
+    const float m = 0.5f / fabsf(c);
+    const float m0 = (idx == 0 || idx == 5) ? -m : m;
+    const float m1 = (idx != 2) ? -m : m;
+    *u = sx * m0 + 0.5f;
+    *v = sy * m1 + 0.5f;
+    if (!isfinite(*u) || !isfinite(*v)) return -1;
+    *u = fminf(fmaxf(*u, 0.f), 1.f);
+    *v = fminf(fmaxf(*v, 0.f), 1.f);
+    return idx;
+}
+
+static void cube_dir(int face, float u, float v, float out[3]) {
+    const float s = 2.f * u - 1.f, t = 2.f * v - 1.f;
+    switch (face) {
+        case 0: out[0] = 1.f;  out[1] = -t; out[2] = -s; break;
+        case 1: out[0] = -1.f; out[1] = -t; out[2] = s;  break;
+        case 2: out[0] = s;  out[1] = 1.f;  out[2] = t;  break;
+        case 3: out[0] = s;  out[1] = -1.f; out[2] = -t; break;
+        case 4: out[0] = s;  out[1] = -t; out[2] = 1.f;  break;
+        default: out[0] = -s; out[1] = -t; out[2] = -1.f; break;
+    }
+}
+
+/* tex [6,R,R,C], dirs [n,3] -> out [n,C]; if v_out != NULL also accumulates v_tex (zero-filled by the caller) */
+SGO_API void sgo_cube_texture(int n, int R, int C, const float *tex, const float *dirs, float *out,
+                              const float *v_out, float *v_tex) {
+    for (int i = 0; i < n; ++i) {
+        float u, v;
+        const int face = cube_face_uv(dirs + 3 * i, &u, &v);
+        for (int c = 0; c < C; ++c) out[(size_t)i * C + c] = 0.f;
+        if (face < 0) continue;
+        const float fu = u * (float)R - 0.5f, fv = v * (float)R - 0.5f;
+        const float flu = floorf(fu), flv = floorf(fv);
+        const int iu0 = (int)flu, iv0 = (int)flv;
+        const float au = fu - flu, av = fv - flv;
+        int off[4]; float w[4], wsum = 0.f;
+        for (int k = 0; k < 4; ++k) {
+            const int iu = iu0 + (k & 1), iv = iv0 + (k >> 1);
+            const float wk = ((k & 1) ? au : 1.f - au) * ((k >> 1) ? av : 1.f - av);
+            const int ou = iu < 0 || iu >= R, ov = iv < 0 || iv >= R;
+            off[k] = -1; w[k] = 0.f;
+            if (ou && ov) continue;                       /* corner tap: dropped, renormalised below */
+            int f = face, ix = iu, iy = iv;
+            if (ou || ov) {                               /* edge tap: re-project the texel centre */
+                float p[3], u2, v2;
+                cube_dir(face, ((float)iu + 0.5f) / (float)R, ((float)iv + 0.5f) / (float)R, p);
+                f = cube_face_uv(p, &u2, &v2);
+                ix = (int)floorf(u2 * (float)R); iy = (int)floorf(v2 * (float)R);
+                ix = ix < 0 ? 0 : (ix > R - 1 ? R - 1 : ix);
+                iy = iy < 0 ? 0 : (iy > R - 1 ? R - 1 : iy);
+            }
+            off[k] = (f * R + iy) * R + ix; w[k] = wk; wsum += wk;
+        }
+        const float inv = (wsum > 0.f && wsum < 1.f) ? 1.f / wsum : 1.f;
+        for (int c = 0; c < C; ++c) {
+            double acc = 0.0;
+            for (int k = 0; k < 4; ++k) {
+                if (off[k] < 0) continue;
+                acc += (double)(w[k] * inv) * tex[(size_t)off[k] * C + c];
+                if (v_out) v_tex[(size_t)off[k] * C + c] += (w[k] * inv) * v_out[(size_t)i * C + c];
+            }
+            out[(size_t)i * C + c] = (float)acc;
+        }
+    }
+}
+
+/* SSIM of two [H,W,3] images (HWC), 11-tap Gaussian window sigma 1.5, valid region, K = (0.01, 0.03);
+ * returns mean ssim; *l1 = mean |y - x| */
+SGO_API double sgo_l1_ssim(int H, int W, const float *x, const float *y, double data_range, double *l1) {
+    double g[11], gs = 0.0;
+    for (int k = 0; k < 11; ++k) { g[k] = exp(-((k - 5) * (k - 5)) / (2.0 * 1.5 * 1.5)); gs += g[k]; }
+    for (int k = 0; k < 11; ++k) g[k] /= gs;
+    const double C1 = (0.01 * data_range) * (0.01 * data_range), C2 = (0.03 * data_range) * (0.03 * data_range);
+    double sum_l1 = 0.0, sum_s = 0.0;
+    for (size_t i = 0; i < (size_t)H * W * 3; ++i) sum_l1 += fabs((double)y[i] - (double)x[i]);
+    for (int c = 0; c < 3; ++c)
+        for (int oy = 0; oy + 10 < H; ++oy)
+            for (int ox = 0; ox + 10 < W; ++ox) {
+                double m1 = 0, m2 = 0, e11 = 0, e22 = 0, e12 = 0;
+                for (int a = 0; a < 11; ++a)
+                    for (int b = 0; b < 11; ++b) {
+                        const double wgt = g[a] * g[b];
+                        const double p = x[((size_t)(oy + a) * W + ox + b) * 3 + c];
+                        const double q = y[((size_t)(oy + a) * W + ox + b) * 3 + c];
+                        m1 += wgt * p; m2 += wgt * q; e11 += wgt * p * p; e22 += wgt * q * q; e12 += wgt * p * q;
+                    }
+                const double s1 = e11 - m1 * m1, s2 = e22 - m2 * m2, s12 = e12 - m1 * m2;
+                sum_s += ((2 * m1 * m2 + C1) / (m1 * m1 + m2 * m2 + C1)) * ((2 * s12 + C2) / (s1 + s2 + C2));
+            }
+    *l1 = sum_l1 / ((double)H * W * 3);
+    return sum_s / ((double)(H - 10) * (W - 10) * 3);
+}

@@ -151,3 +151,25 @@ def raster_bwd(H, W, block, ids, bins, xys, conics, colors, opac, bg, final_T, f
                          _p(_f(v_out)), _p(_f(v_out_alpha)), C.c_float(alpha_clamp_bwd), _p(v_xy),
                          _p(v_conic), _p(v_col), _p(v_op))
     return v_xy, v_conic, v_col, v_op
+
+
+def cube_texture(tex, dirs, v_out=None):
+    """tex [6,R,R,C], dirs [n,3] -> out [n,C] (and the texture gradient for ``v_out`` [n,C] when given)."""
+    tex, d = _f(tex), _f(dirs).reshape(-1, 3).contiguous()
+    n, R, Cc = d.shape[0], tex.shape[1], tex.shape[3]
+    out = torch.zeros(n, Cc)
+    v_tex = torch.zeros_like(tex) if v_out is not None else None
+    v = _f(v_out).reshape(n, Cc).contiguous() if v_out is not None else None
+    lib().sgo_cube_texture(n, R, Cc, _p(tex), _p(d), _p(out), _p(v) if v is not None else None,
+                           _p(v_tex) if v_tex is not None else None)
+    return (out, v_tex) if v_out is not None else out
+
+
+def l1_ssim(x, y, data_range: float = 1.0):
+    """(mean |y - x|, mean SSIM) of two [H,W,3] images, double precision inside."""
+    x, y = _f(x), _f(y)
+    fn = lib().sgo_l1_ssim
+    fn.restype = C.c_double
+    l1 = C.c_double(0.0)
+    s = fn(x.shape[0], x.shape[1], _p(x), _p(y), C.c_double(data_range), C.byref(l1))
+    return float(l1.value), float(s)

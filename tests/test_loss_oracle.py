@@ -38,3 +38,14 @@ def test_reference_loss_composition():
     l1, s = O.l1_ssim_losses(rgb, gt)
     assert abs(float(l1) - float((gt - rgb).abs().mean())) < 1e-7
     assert abs(float(s) - float(O.ssim(gt.permute(2, 0, 1)[None], rgb.permute(2, 0, 1)[None]))) < 1e-7
+
+
+def test_c_and_torch_restatements_of_l1_ssim_agree(c_oracle):
+    """Plain C (direct 11x11 double-precision window sums) vs. torch (separable fp32 conv2d)."""
+    g = torch.Generator().manual_seed(8)
+    for H, W in ((11, 11), (17, 23), (40, 33)):
+        x = torch.rand(H, W, 3, generator=g)
+        y = (x + 0.2 * torch.randn(H, W, 3, generator=g)).clamp(0, 1)
+        l1_t, s_t = O.l1_ssim_losses(x, y)
+        l1_c, s_c = c_oracle.l1_ssim(x, y)
+        assert abs(l1_c - float(l1_t)) < 1e-6 and abs(s_c - float(s_t)) < 5e-6

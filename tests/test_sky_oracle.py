@@ -70,3 +70,19 @@ def test_env_light_directions_match_reference_formula():
     cam = cam / cam.norm()
     wdir = c2w[:, :3] @ cam
     assert torch.allclose(d[py, px], torch.stack([wdir[0], wdir[2], -wdir[1]]), atol=1e-6)
+
+
+def test_c_and_torch_restatements_of_the_cube_lookup_agree(c_oracle):
+    """Two independent restatements (plain C scalar loops vs. vectorised torch), same taps and weights."""
+    g = torch.Generator().manual_seed(4)
+    for R, C in ((1, 3), (2, 1), (7, 3), (32, 4)):
+        tex = torch.rand(6, R, R, C, generator=g)
+        q = torch.randn(4000, 3, generator=g)
+        q[:3] = torch.tensor([[1., 1, 0], [0, 1, 1], [1, 1, 1]])
+        w = torch.rand(4000, C, generator=g)
+        t = tex.clone().requires_grad_(True)
+        ref = O.cube_texture(t, q)
+        (ref * w).sum().backward()
+        out, v_tex = c_oracle.cube_texture(tex, q, w)
+        assert (out - ref.detach()).abs().max() < 2e-6
+        assert (v_tex - t.grad).abs().max() < 1e-4 * max(1.0, float(t.grad.abs().max()))
