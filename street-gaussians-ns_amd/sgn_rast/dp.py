@@ -154,6 +154,7 @@ class SHGradExchange:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())  # force: exercise the path at world 1
         self._stash = None
+        self._last = None        # layout of the last exchange (kind, degree, K, means, object ids ...), see finish()
         self._works = []
         self._view = None
 
@@ -213,9 +214,31 @@ class SHGradExchange:
                            means=means, object_ids=object_ids, poses=poses, idft=idft, keep=(v_eff, cam_pos))
         return True
 
+    def _participate_empty(self) -> None:
+        """This rank's SH backward never ran this step (its view saw no Gaussian, so no colour gradient exists):
+        the other ranks are already inside the all-gathers, so join them with a zero colour gradient — every rank
+        must make the same collective calls — using what the last tap told us about the layout."""
+        last = self._last
+        if last is None:
+            raise RuntimeError("SHGradExchange: the SH backward did not run on this rank and no earlier step is "
+                               "known to take the layout from; the other ranks are waiting in all_gather")
+        n = self.dc.shape[0]
+        zeros = torch.zeros(n, 3, dtype=torch.float32, device=self.dc.device)
+        if last["kind"] == "dirs":
+            self._stash = dict(last, v_all=self._gather(zeros), dirs_all=self._gather(zeros + 1.0), keep=(zeros,))
+        else:
+            cam = (self._view[1] if self._view is not None else last["cam_pos"]).detach().reshape(3).to(
+                zeros.device, torch.float32)
+            self._stash = dict(last, v_all=self._gather(zeros), cam_all=self._gather(cam), keep=(zeros, cam))
+
     def finish(self) -> None:
-        if not self.active or self._stash is None:
+        if not self.active:
             return
+        if self._stash is None:
+            self._participate_empty()
+        self._last = {k: v for k, v in self._stash.items() if k not in ("v_all", "dirs_all", "cam_all", "keep")}
+        if self._stash["kind"] == "cam":
+            self._last["cam_pos"] = self._stash["keep"][-1]
         for w in self._works:
             w.wait()
         self._works.clear()

@@ -128,6 +128,17 @@ def _exchange_worker(rank, world, port, outdir):
         red.finish()
         torch.save((local, torch.cat((dc.grad, rest.grad), dim=1).clone()), os.path.join(outdir, f"{mode}{rank}.pt"))
         dc.grad.copy_(local[:, :1]); rest.grad.copy_(local[:, 1:])
+        # next step: rank 1's view sees nothing, its SH backward never runs; it must still join the collectives
+        if rank == 0:
+            if mode == "dirs":
+                ex._tap_dirs(dirs, v_rgb, deg, k)
+            elif mode == "view":
+                ex._tap_dirs(dirs, v_rgb, deg, k)
+            else:
+                ex._tap_fused(means, cam_pos, v_rgb, deg, k, None, None, torch.ones(1, 1))
+        red.finish()
+        torch.save(torch.cat((dc.grad, rest.grad), dim=1).clone(), os.path.join(outdir, f"{mode}{rank}_empty.pt"))
+        dc.grad.copy_(local[:, :1]); rest.grad.copy_(local[:, 1:])
     dist.barrier()
     dist.destroy_process_group()
 
@@ -148,3 +159,6 @@ def test_sh_low_rank_exchange_equals_dense_allreduce(tmp_path):
         for r in range(world):
             assert torch.allclose(res[r][1], dense_mean, rtol=1e-5, atol=1e-6), (mode, r)
         assert torch.equal(res[0][1], res[1][1])                    # replicas agree bit-for-bit
+        # the step in which rank 1 contributed nothing: both replicas hold rank 0's gradient / world
+        e0, e1 = (torch.load(os.path.join(tmp_path, f"{mode}{r}_empty.pt")) for r in range(world))
+        assert torch.equal(e0, e1) and torch.allclose(e0, res[0][0] / world, rtol=1e-5, atol=1e-6), mode
