@@ -94,7 +94,17 @@ class GradAllReducer:
         gradient on the compute stream."""
         small, flat, work = [], None, None
         if self.active:
-            small = [p for p in self.params if id(p) not in self.big_ids and p.grad is not None]
+            # every rank must make the same collective calls in the same order: a parameter that received no gradient
+            # on this rank (its view saw nothing) takes part with zeros, and a "big" one whose hook therefore never
+            # fired is reduced here, before the bucket, where the other ranks' hooks put it
+            pending_ids = {id(p) for _w, p in self._pending}
+            for p in self.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                if id(p) in self.big_ids and id(p) not in pending_ids:
+                    self._pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group,
+                                                          async_op=True), p))
+            small = [p for p in self.params if id(p) not in self.big_ids]
             if small:
                 flat = torch.cat([p.grad.reshape(-1) for p in small])
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

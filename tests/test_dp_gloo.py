@@ -162,3 +162,43 @@ def test_sh_low_rank_exchange_equals_dense_allreduce(tmp_path):
         # the step in which rank 1 contributed nothing: both replicas hold rank 0's gradient / world
         e0, e1 = (torch.load(os.path.join(tmp_path, f"{mode}{r}_empty.pt")) for r in range(world))
         assert torch.equal(e0, e1) and torch.allclose(e0, res[0][0] / world, rtol=1e-5, atol=1e-6), mode
+
+
+def _silent_rank_worker(rank, world, port, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "street-gaussians-ns_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from sgn_rast import dp
+    torch.set_num_threads(2)
+    dp.init_from_env(backend="gloo")
+    g = torch.Generator().manual_seed(5)
+    P = {k: torch.randn(*s, generator=g).requires_grad_(True) for k, s in
+         (("means", (50, 3)), ("opacity", (50, 1)), ("rest", (50, 15, 3)))}
+    red = dp.GradAllReducer(list(P.values()), big=[P["rest"]])
+    if rank == 0:                       # rank 1's view saw nothing: no backward, every .grad stays None
+        loss = sum((p * (i + 1.0)).sum() for i, p in enumerate(P.values()))
+        loss.backward()
+    red.finish()
+    torch.save({k: v.grad.clone() for k, v in P.items()}, os.path.join(outdir, f"silent{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_rank_without_gradients_still_joins_every_collective(tmp_path):
+    """Hook-driven all-reduce of the big tensor + flat bucket: a rank whose backward produced nothing must issue the
+    same collectives (zeros), otherwise the others hang; the averaged result is rank 0's gradient / world."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_silent_rank_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    g0, g1 = (torch.load(os.path.join(tmp_path, f"silent{r}.pt")) for r in range(world))
+    for i, k in enumerate(("means", "opacity", "rest")):
+        assert torch.equal(g0[k], g1[k])
+        assert torch.allclose(g0[k], torch.full_like(g0[k], (i + 1.0) / world))
