@@ -93,6 +93,8 @@ class GradAllReducer:
         all-reduce is launched first and runs on the collective stream while the SH exchange rebuilds the dense SH
         gradient on the compute stream."""
         small, flat, work = [], None, None
+        if self.sh_exchange is not None:
+            self.sh_exchange.start_if_silent()      # its all-gathers come first on every rank (the taps fire in backward)
         if self.active:
             # every rank must make the same collective calls in the same order: a parameter that received no gradient
             # on this rank (its view saw nothing) takes part with zeros, and a "big" one whose hook therefore never
@@ -241,11 +243,15 @@ class SHGradExchange:
                 zeros.device, torch.float32)
             self._stash = dict(last, v_all=self._gather(zeros), cam_all=self._gather(cam), keep=(zeros, cam))
 
+    def start_if_silent(self) -> None:
+        """Issue this step's all-gathers now if the SH backward never tapped in (see _participate_empty)."""
+        if self.active and self._stash is None:
+            self._participate_empty()
+
     def finish(self) -> None:
         if not self.active:
             return
-        if self._stash is None:
-            self._participate_empty()
+        self.start_if_silent()
         self._last = {k: v for k, v in self._stash.items() if k not in ("v_all", "dirs_all", "cam_all", "keep")}
         if self._stash["kind"] == "cam":
             self._last["cam_pos"] = self._stash["keep"][-1]

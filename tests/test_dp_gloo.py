@@ -202,3 +202,59 @@ def test_rank_without_gradients_still_joins_every_collective(tmp_path):
     for i, k in enumerate(("means", "opacity", "rest")):
         assert torch.equal(g0[k], g1[k])
         assert torch.allclose(g0[k], torch.full_like(g0[k], (i + 1.0) / world))
+
+
+def _silent_mixed_worker(rank, world, port, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "street-gaussians-ns_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from sgn_rast import dp
+    torch.set_num_threads(2)
+    dp.init_from_env(backend="gloo")
+    gp = torch.Generator().manual_seed(7)
+    n, k, deg = 120, 16, 3
+    means = (torch.randn(n, 3, generator=gp) * 3).requires_grad_(True)
+    dc = torch.randn(n, 1, 3, generator=gp).requires_grad_(True)
+    rest = torch.randn(n, k - 1, 3, generator=gp).requires_grad_(True)
+    cam_pos = torch.randn(3, generator=torch.Generator().manual_seed(50 + rank))
+    v_rgb = torch.randn(n, 3, generator=torch.Generator().manual_seed(60 + rank))
+    ex = dp.SHGradExchange(dc, rest, average=True, multi_fn=_sh_multi_torch).set_view(means, cam_pos)
+    red = dp.GradAllReducer([means, dc, rest], big=[rest], sh_exchange=ex)
+    dirs = means.detach() - cam_pos
+    for step_i in range(2):
+        for p in (means, dc, rest):
+            p.grad = None
+        silent = (step_i == 1 and rank == 1)              # second step: rank 1 renders nothing at all
+        if not silent:
+            means.grad = torch.full_like(means, 1.0 + rank)
+            ex._tap_dirs(dirs, v_rgb, deg, k)             # what the SH backward does (all-gathers start here)
+        red.finish()
+        torch.save((means.grad.clone(), dc.grad.clone(), rest.grad.clone()),
+                   os.path.join(outdir, f"mixed{step_i}_{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_silent_rank_keeps_collective_order_with_exchange_and_bucket(tmp_path):
+    """Low-rank exchange + flat bucket together: the silent rank must issue all-gathers, then the bucket, in the order
+    the other ranks did (exchange first: its taps fire during backward)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_silent_mixed_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+        assert p.exitcode == 0
+    for step_i in range(2):
+        a, b = (torch.load(os.path.join(tmp_path, f"mixed{step_i}_{r}.pt")) for r in range(world))
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)                       # replicas agree
+    m0 = torch.load(os.path.join(tmp_path, "mixed0_0.pt"))[0]
+    m1 = torch.load(os.path.join(tmp_path, "mixed1_0.pt"))[0]
+    assert torch.allclose(m0, torch.full_like(m0, 1.5)) and torch.allclose(m1, torch.full_like(m1, 0.5))
+    sh0, sh1 = torch.load(os.path.join(tmp_path, "mixed0_0.pt"))[2], torch.load(os.path.join(tmp_path, "mixed1_0.pt"))[2]
+    assert float(sh0.abs().sum()) > 0 and float(sh1.abs().sum()) > 0 and not torch.allclose(sh0, sh1)
