@@ -434,12 +434,16 @@ SGO_API void sgo_tile_bins(int64_t I, const int64_t *keys_sorted, int32_t *bins)
  *   alpha = min(0.999, opac * exp(-sigma));  skip if sigma < 0 or alpha < 1/255
  *   nT = T*(1-alpha); stop (NOT composited) if nT <= 1e-4
  *   vis = alpha*T;  C_ch = fmaf(color_ch, vis, C_ch);  T = nT */
-SGO_API void sgo_raster_fwd(int H, int W, int block, const int32_t *ids, const int32_t *bins,
-                            const float *xys, const float *conics, const float *colors,
-                            const float *opac, const float *bg, float *out_img, float *final_T,
-                            int32_t *final_idx) {
+/* Pixel rows [row_lo, row_hi) only (outputs of other rows untouched): lets the parity tests check a band of a
+ * BASELINE-size image (1920x1280, 0.5-1 M Gaussians) in seconds; pixels are independent, so a band of the
+ * image is exactly the band of the full result. */
+SGO_API void sgo_raster_fwd_rows(int H, int W, int block, const int32_t *ids, const int32_t *bins,
+                                 const float *xys, const float *conics, const float *colors,
+                                 const float *opac, const float *bg, float *out_img, float *final_T,
+                                 int32_t *final_idx, int row_lo, int row_hi) {
     int tiles_x = (W + block - 1) / block;
-    for (int i = 0; i < H; ++i)
+    row_lo = imax(row_lo, 0); row_hi = imin(row_hi, H);
+    for (int i = row_lo; i < row_hi; ++i)
         for (int j = 0; j < W; ++j) {
             int tile = (i / block) * tiles_x + (j / block);
             int start = bins[2 * tile], end = bins[2 * tile + 1];
@@ -470,6 +474,13 @@ SGO_API void sgo_raster_fwd(int H, int W, int block, const int32_t *ids, const i
         }
 }
 
+SGO_API void sgo_raster_fwd(int H, int W, int block, const int32_t *ids, const int32_t *bins,
+                            const float *xys, const float *conics, const float *colors,
+                            const float *opac, const float *bg, float *out_img, float *final_T,
+                            int32_t *final_idx) {
+    sgo_raster_fwd_rows(H, W, block, ids, bins, xys, conics, colors, opac, bg, out_img, final_T, final_idx, 0, H);
+}
+
 /* -------------------------------------------------------- rasterize backward
  * gsplat backward.cu rasterize_backward_kernel, SURVEY.md A.4.
  * alpha_clamp_bwd: upstream 0.1.x clamps alpha at 0.99 here (0.999 in forward);
@@ -477,15 +488,18 @@ SGO_API void sgo_raster_fwd(int H, int W, int block, const int32_t *ids, const i
  * used by the autograd cross-check.  v_conic[1] keeps upstream's 0.5 factor.
  * Accumulates in double so the oracle is order-independent "truth"; outputs
  * (zero-initialised by the caller) are float. */
-SGO_API void sgo_raster_bwd(int H, int W, int block, int N, const int32_t *ids,
-                            const int32_t *bins, const float *xys, const float *conics,
-                            const float *colors, const float *opac, const float *bg,
-                            const float *final_T, const int32_t *final_idx, const float *v_out,
-                            const float *v_out_alpha, float alpha_clamp_bwd, float *v_xy,
-                            float *v_conic, float *v_colors, float *v_opac) {
+SGO_API void sgo_raster_bwd_rows(int H, int W, int block, int N, const int32_t *ids,
+                                 const int32_t *bins, const float *xys, const float *conics,
+                                 const float *colors, const float *opac, const float *bg,
+                                 const float *final_T, const int32_t *final_idx, const float *v_out,
+                                 const float *v_out_alpha, float alpha_clamp_bwd, float *v_xy,
+                                 float *v_conic, float *v_colors, float *v_opac, int row_lo, int row_hi) {
+    /* contributions of pixel rows [row_lo, row_hi) only: equals the full backward whenever v_out / v_out_alpha
+     * are zero outside the band (every term of every sum carries a factor v_out or v_out_alpha of its pixel) */
     int tiles_x = (W + block - 1) / block;
     double *acc = (double *)calloc((size_t)N * 9, sizeof(double));
-    for (int i = 0; i < H; ++i)
+    row_lo = imax(row_lo, 0); row_hi = imin(row_hi, H);
+    for (int i = row_lo; i < row_hi; ++i)
         for (int j = 0; j < W; ++j) {
             int tile = (i / block) * tiles_x + (j / block);
             int start = bins[2 * tile], end = bins[2 * tile + 1];
@@ -540,6 +554,16 @@ SGO_API void sgo_raster_bwd(int H, int W, int block, int N, const int32_t *ids,
         v_opac[g] = (float)A[8];
     }
     free(acc);
+}
+
+SGO_API void sgo_raster_bwd(int H, int W, int block, int N, const int32_t *ids,
+                            const int32_t *bins, const float *xys, const float *conics,
+                            const float *colors, const float *opac, const float *bg,
+                            const float *final_T, const int32_t *final_idx, const float *v_out,
+                            const float *v_out_alpha, float alpha_clamp_bwd, float *v_xy,
+                            float *v_conic, float *v_colors, float *v_opac) {
+    sgo_raster_bwd_rows(H, W, block, N, ids, bins, xys, conics, colors, opac, bg, final_T, final_idx, v_out,
+                        v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors, v_opac, 0, H);
 }
 
 /* ============================================================================================================

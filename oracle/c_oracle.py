@@ -133,23 +133,29 @@ def bin_and_sort(xys, depths, radii, num_tiles_hit, H, W, block):
     return cum, keys, vals, ks, vs, bins
 
 
-def raster_fwd(H, W, block, ids, bins, xys, conics, colors, opac, bg):
+def raster_fwd(H, W, block, ids, bins, xys, conics, colors, opac, bg, rows=None):
+    """``rows=(lo, hi)``: pixel rows [lo, hi) only (the rest of the outputs stays zero) — a band of a
+    BASELINE-size image is a band of the full result, at a fraction of the CPU time."""
     out = torch.zeros(H, W, 3); fT = torch.zeros(H, W); fi = torch.zeros(H, W, dtype=torch.int32)
-    lib().sgo_raster_fwd(C.c_int(H), C.c_int(W), C.c_int(block), _p(ids.contiguous()), _p(bins.contiguous()),
-                         _p(_f(xys)), _p(_f(conics)), _p(_f(colors)), _p(_f(opac).reshape(-1)), _p(_f(bg)),
-                         _p(out), _p(fT), _p(fi))
+    lo, hi = (0, H) if rows is None else rows
+    lib().sgo_raster_fwd_rows(C.c_int(H), C.c_int(W), C.c_int(block), _p(ids.contiguous()), _p(bins.contiguous()),
+                              _p(_f(xys)), _p(_f(conics)), _p(_f(colors)), _p(_f(opac).reshape(-1)), _p(_f(bg)),
+                              _p(out), _p(fT), _p(fi), C.c_int(lo), C.c_int(hi))
     return out, fT, fi
 
 
 def raster_bwd(H, W, block, ids, bins, xys, conics, colors, opac, bg, final_T, final_idx, v_out,
-               v_out_alpha, alpha_clamp_bwd=0.99):
+               v_out_alpha, alpha_clamp_bwd=0.99, rows=None):
+    """``rows=(lo, hi)``: contributions of pixel rows [lo, hi) only (= the full backward when ``v_out`` and
+    ``v_out_alpha`` vanish outside the band)."""
     N = xys.shape[0]
     v_xy = torch.zeros(N, 2); v_conic = torch.zeros(N, 3); v_col = torch.zeros(N, 3); v_op = torch.zeros(N, 1)
-    lib().sgo_raster_bwd(C.c_int(H), C.c_int(W), C.c_int(block), C.c_int(N), _p(ids.contiguous()),
-                         _p(bins.contiguous()), _p(_f(xys)), _p(_f(conics)), _p(_f(colors)),
-                         _p(_f(opac).reshape(-1)), _p(_f(bg)), _p(_f(final_T)), _p(final_idx.contiguous()),
-                         _p(_f(v_out)), _p(_f(v_out_alpha)), C.c_float(alpha_clamp_bwd), _p(v_xy),
-                         _p(v_conic), _p(v_col), _p(v_op))
+    lo, hi = (0, H) if rows is None else rows
+    lib().sgo_raster_bwd_rows(C.c_int(H), C.c_int(W), C.c_int(block), C.c_int(N), _p(ids.contiguous()),
+                              _p(bins.contiguous()), _p(_f(xys)), _p(_f(conics)), _p(_f(colors)),
+                              _p(_f(opac).reshape(-1)), _p(_f(bg)), _p(_f(final_T)), _p(final_idx.contiguous()),
+                              _p(_f(v_out)), _p(_f(v_out_alpha)), C.c_float(alpha_clamp_bwd), _p(v_xy),
+                              _p(v_conic), _p(v_col), _p(v_op), C.c_int(lo), C.c_int(hi))
     return v_xy, v_conic, v_col, v_op
 
 

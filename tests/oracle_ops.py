@@ -7,6 +7,10 @@ from torch.autograd import Function
 from oracle import c_oracle as CO
 
 ALPHA_CLAMP_BWD = 0.99  # gsplat 0.1.x backward clamp
+# (row_lo, row_hi) or None: restrict the compositing (forward and backward) to a band of pixel rows.  Used by the
+# BASELINE-size gradient parity tests together with loss weights that vanish outside the band, so the band's
+# backward IS the full backward; image rows outside the band come back as zeros (not compared).
+PIXEL_ROWS = None
 
 
 class _Project(Function):
@@ -58,8 +62,9 @@ class _Raster(Function):
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, nth, colors, opacity, H, W, block, background, return_alpha):
         cum, keys, vals, ks, vs, bins = CO.bin_and_sort(xys, depths, radii, nth, H, W, block)
-        img, fT, fi = CO.raster_fwd(H, W, block, vs, bins, xys, conics, colors, opacity, background)
+        img, fT, fi = CO.raster_fwd(H, W, block, vs, bins, xys, conics, colors, opacity, background, rows=PIXEL_ROWS)
         ctx.dims = (H, W, block)
+        ctx.rows = PIXEL_ROWS
         ctx.oshape = opacity.shape
         ctx.save_for_backward(vs, bins, xys.detach(), conics.detach(), colors.detach(), opacity.detach(),
                               background, fT, fi)
@@ -75,7 +80,7 @@ class _Raster(Function):
         if v_alpha is None:
             v_alpha = torch.zeros(H, W)
         v_xy, v_conic, v_col, v_op = CO.raster_bwd(H, W, block, vs, bins, xys, conics, colors, opacity, bg, fT, fi,
-                                                    v_img, v_alpha, ALPHA_CLAMP_BWD)
+                                                    v_img, v_alpha, ALPHA_CLAMP_BWD, rows=ctx.rows)
         return (v_xy, None, None, v_conic, None, v_col, v_op.reshape(ctx.oshape)) + (None,) * 5
 
 
