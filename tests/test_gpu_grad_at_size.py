@@ -114,8 +114,15 @@ def test_train_step_gradients_match_oracle_at_size(name, production_defaults):
     for reduce_mode in (1, 0):
         lib.sgn_set_reduce_mode(reduce_mode)
         Pd, got = _hip_step(cam, raw, w_img, w_a)
-        assert torch.equal(got.radii.cpu(), exp.radii) and torch.equal(got.num_tiles_hit.cpu(), exp.num_tiles_hit)
-        assert torch.equal(got.xys.detach().cpu(), exp.xys.detach())
+        # The library's projection is bit-exact on identical inputs (test_project_forward_bit_exact; at this size:
+        # profiles/scripts/diag_street_projection.py, 0 differing rows of 1 M).  Here the reference's own glue
+        # (torch.exp / the quaternion division, sgn_splatfacto.py:857,864) runs on the GPU for one side and on the
+        # CPU for the other, and torch's two exp kernels differ by 1 ulp on a few inputs: allow a handful of rows
+        # whose radius then lands on the other side of an integer.
+        n = exp.radii.numel()
+        assert int((got.radii.cpu() != exp.radii).sum()) <= max(2, n // 100_000)
+        assert int((got.num_tiles_hit.cpu() != exp.num_tiles_hit).sum()) <= max(2, n // 100_000)
+        torch.testing.assert_close(got.xys.detach().cpu(), exp.xys.detach(), rtol=2e-6, atol=1e-4)
         band = slice(row_lo, row_hi)
         for attr in ("rgb", "alpha"):
             err = (getattr(got, attr).detach().cpu()[band] - getattr(exp, attr).detach()[band]).abs()
