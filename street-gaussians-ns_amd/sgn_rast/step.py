@@ -36,9 +36,24 @@ def leaf_params(raw: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return {k: v.detach().clone().requires_grad_(True) for k, v in raw.items()}
 
 
+def _split_recat(t: torch.Tensor, counts, retain_grad: bool = False):
+    """The scene graph's property setters (sgn_splatfacto_scene_graph.py:153-215): every projection output is split
+    per sub-model (views; `retain_grad` on the xys views, which is what each sub-model's `after_train` reads) and
+    concatenated again — so the tensor the rasterizer receives is a COPY of the projection's output."""
+    parts = torch.split(t, counts)                                               # set_split_tensor_variable :153-167
+    if retain_grad:
+        for part in parts:
+            if part.requires_grad:
+                part.retain_grad()
+    return torch.concat(parts, dim=0), parts                                     # get_aggreated_variable :138-146
+
+
 def render(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, block_width: int = 16,
            background: Optional[torch.Tensor] = None, with_depth: bool = False, ops=_hip_ops,
-           retain_xys_grad: bool = True) -> SimpleNamespace:
+           retain_xys_grad: bool = True, split_counts=None, caller_syncs: bool = True) -> SimpleNamespace:
+    """``split_counts``: per-sub-model Gaussian counts when the caller is the scene graph (its property setters split
+    and re-concatenate every projection output).  ``caller_syncs``: also replay the two host syncs the reference's
+    own code performs per pass (`radii.sum() == 0` at :878, `assert (num_tiles_hit > 0).any()` at :944)."""
     dev = P["means"].device
     H, W = cam.height, cam.width
     if background is None:
@@ -48,13 +63,24 @@ def render(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, b
     quats = P["quats"] / P["quats"].norm(dim=-1, keepdim=True)                   # :864
     xys, depths, radii, conics, _comp, num_tiles_hit, _cov3d = ops.project_gaussians(  # :860-873
         P["means"], scales, 1, quats, cam.viewmat[:3, :], cam.fx, cam.fy, cam.cx, cam.cy, H, W, block_width)
-    out = SimpleNamespace(xys=xys, depths=depths, radii=radii, conics=conics, num_tiles_hit=num_tiles_hit)
+    out = SimpleNamespace()
+    if split_counts is not None:                       # tuple-assign through the scene graph's setters, in order
+        xys, out.xys_parts = _split_recat(xys, split_counts, retain_grad=retain_xys_grad)
+        depths, out.depths_parts = _split_recat(depths, split_counts)
+        radii, out.radii_parts = _split_recat(radii, split_counts)
+        conics, out.conics_parts = _split_recat(conics, split_counts)
+        num_tiles_hit, out.num_tiles_hit_parts = _split_recat(num_tiles_hit, split_counts)
+    out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit = xys, depths, radii, conics, num_tiles_hit
+    if caller_syncs and bool(radii.sum() == 0):                                  # :878 (host sync)
+        raise RuntimeError("no Gaussian is visible (the reference returns its empty outputs here)")
     if retain_xys_grad and xys.requires_grad:
         xys.retain_grad()                                                        # :889-890
     viewdirs = P["means"].detach() - cam.cam_pos.to(P["means"].dtype)            # :934
     viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)                    # :935
     rgbs = ops.spherical_harmonics(sh_degree_to_use, viewdirs, colors)           # :939
     rgbs = torch.clamp(rgbs + 0.5, min=0.0)                                      # :940
+    if caller_syncs:
+        assert (num_tiles_hit > 0).any()                                         # :944 (host sync)
     opacities = torch.sigmoid(P["opacity_logits"])                               # :949
     rgb, alpha = ops.rasterize_gaussians(                                        # :954-967
         xys, depths, radii, conics, num_tiles_hit, rgbs, opacities, H, W, block_width,
@@ -115,7 +141,8 @@ def _quaternion_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 
 
 def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Camera, sh_degree_to_use: int = 3,
-                       block_width: int = 16, ops=_hip_ops, fused: bool = False) -> SimpleNamespace:
+                       block_width: int = 16, ops=_hip_ops, fused: bool = False,
+                       caller_syncs: bool = True) -> SimpleNamespace:
     """Replay of ``SplatfactoSceneGraphModel.get_outputs`` in training mode
     (``sgn_splatfacto_scene_graph.py:305-366``): ``models[0]`` is the background, ``models[i>0]`` rigid objects
     whose parameters live in the object's local frame; ``poses[i]`` = [R(9) t(3) q_o2w(4)], ``idft[i]`` = Fourier
@@ -172,11 +199,11 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
         P = dict(means=torch.cat(world_means), quats=torch.cat(world_quats), features_dc=torch.cat(dcs),
                  opacity_logits=cat("opacity_logits"), features_rest=cat("features_rest"),
                  log_scales=cat("log_scales"))
-        out = render(P, cam, sh_degree_to_use, block_width, with_depth=True, ops=ops)  # :363
+        out = render(P, cam, sh_degree_to_use, block_width, with_depth=True, ops=ops,   # :363
+                     split_counts=counts, caller_syncs=caller_syncs)
         opac_arg, raster = out.opacities, ops.rasterize_gaussians
 
-    def submodel_acc(lo: int, hi: int):                                                 # :255-303
-        sl = slice(lo, hi)
+    def submodel_acc(lo: int, hi: int, which):                                          # :255-303
         if hi <= lo:
             return torch.zeros(H, W, device=dev)
         if fused:
@@ -186,17 +213,33 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
             _, acc = raster(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit, rgbs, opac_arg, H, W,
                             block_width, background=bg_zero, return_alpha=True, id_range=(lo, hi))
             return acc
-        colors = torch.cat((P["features_dc"][sl], P["features_rest"][sl]), dim=1)
-        viewdirs = P["means"][sl].detach() - cam.cam_pos
+        # get_submodel_output (:255-303): per-model tensors are aggregated with torch.cat — the geometry from the
+        # per-model SPLITS of the main projection (copies again), the parameters from the sub-models themselves
+        sub = range(*which)
+        agg = lambda parts: torch.cat([parts[i] for i in sub], dim=0)               # aggregate_submodel_var :249-253
+        means_s = torch.cat([world_means[i] for i in sub], dim=0)
+        dc_s = torch.cat([dcs[i] for i in sub], dim=0)
+        opac_s = torch.cat([models[i]["opacity_logits"] for i in sub], dim=0)
+        rest_s = torch.cat([models[i]["features_rest"] for i in sub], dim=0)
+        xys_s, depths_s, radii_s = agg(out.xys_parts), agg(out.depths_parts), agg(out.radii_parts)
+        conics_s, nth_s = agg(out.conics_parts), agg(out.num_tiles_hit_parts)
+        colors = torch.cat((dc_s, rest_s), dim=1)                                       # :280
+        viewdirs = means_s.detach() - cam.cam_pos
         viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
-        rgbs = torch.clamp(ops.spherical_harmonics(sh_degree_to_use, viewdirs, colors) + 0.5, min=0.0)
-        _, acc = raster(out.xys[sl], out.depths[sl], out.radii[sl], out.conics[sl], out.num_tiles_hit[sl], rgbs,
-                        opac_arg[sl], H, W, block_width, background=bg_zero, return_alpha=True)
+        rgbs = torch.clamp(ops.spherical_harmonics(sh_degree_to_use, viewdirs, colors) + 0.5, min=0.0)  # :285 (unused)
+        # render_gaussian_attrs (:916-967) evaluates the SH again from the colours it is handed
+        viewdirs = means_s.detach() - cam.cam_pos
+        viewdirs = viewdirs / viewdirs.norm(dim=-1, keepdim=True)
+        rgbs = torch.clamp(ops.spherical_harmonics(sh_degree_to_use, viewdirs, colors) + 0.5, min=0.0)  # :939
+        if caller_syncs:
+            assert (out.num_tiles_hit > 0).any()                                         # :944 (self.num_tiles_hit)
+        _, acc = raster(xys_s, depths_s, radii_s, conics_s, nth_s, rgbs, torch.sigmoid(opac_s), H, W, block_width,
+                        background=bg_zero, return_alpha=True)
         return acc
 
     n_bg = counts[0]
-    out.object_acc = submodel_acc(n_bg, sum(counts))                                     # :364-365
-    out.background_acc = submodel_acc(0, n_bg)                                           # :366
+    out.object_acc = submodel_acc(n_bg, sum(counts), (1, len(models)))                   # :364-365
+    out.background_acc = submodel_acc(0, n_bg, (0, 1))                                   # :366
     return out
 
 
