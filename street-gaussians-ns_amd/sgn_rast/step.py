@@ -89,7 +89,7 @@ def render(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, b
     if with_depth:                                                               # :982-996
         depth_im = ops.rasterize_gaussians(
             xys, depths, radii, conics, num_tiles_hit, depths[:, None].repeat(1, 3), opacities, H, W,
-            block_width, _zeros3(dev, P["means"].dtype))[..., 0:1]
+            block_width, torch.zeros(3, device=dev, dtype=P["means"].dtype))[..., 0:1]     # :993 (a new tensor)
         out.depth = torch.where(alpha[..., None] > 1e-3, depth_im / alpha[..., None], 10)
     return out
 
