@@ -9,7 +9,8 @@
  * i.e. of gsplat 0.1.x's `gsplat.cuda._C` pybind module (`gsplat/cuda/csrc/
  * bindings.cu`; third-party, not vendored in /root/reference — names below are
  * the upstream binding names).  Plain pointers + sizes, no torch types, no
- * exceptions, no global state besides a thread-local error string.
+ * exceptions, no mutable global state besides a thread-local error string and the opt-in profiling spans
+ * (sgn_timing_*, off by default).
  *
  * Conventions
  *   - all pointers are DEVICE pointers to contiguous arrays unless marked host;
@@ -38,32 +39,29 @@ typedef void *sgn_stream_t; /* hipStream_t */
 int sgn_version(void);
 const char *sgn_last_error(void);
 
-/* Parity-test switch: 1 = raster kernels use the portable polynomial exp (bit-identical to
- * oracle/c/sgn_oracle.c exp_portable), 0 (default) = hardware v_exp_f32. Process-global. */
-void sgn_set_exact_exp(int on);
-int sgn_get_exact_exp(void);
-/* Backward wave reduction: 1 (default) = transposed reduction on v_permlane32_swap / v_permlane16_swap + DPP row
- * adds (8 swaps + 12 DPP adds for the nine per-Gaussian sums); 0 = nine butterfly reductions (54 shuffles), kept for
- * A/B measurements and tests. */
-void sgn_set_reduce_mode(int mode);
-/* Timing ablations for profiles/ ONLY (results become wrong): bit0 = no gradient atomics,
- * bit1 = no wave reduction.  0 = normal operation. */
-void sgn_set_debug_flags(int flags);
-/* 0: raster kernels stream a depth-ordered 48-byte record per intersection (packed first);
- * 1: they chase gaussian_ids_sorted[k] -> per-Gaussian row with dependent scalar loads (no pack pass). */
-void sgn_set_gather_mode(int on);
-/* 1: one wave64 per tile, 4 pixels per lane; 4: four waves per tile, one 8x8 quadrant each; 0 (default):
- * adaptive — tiles whose depth list (forward) / reverse walk (backward) is at least the threshold are split
- * over four waves, the rest are done by one (shorter critical path where the list is long, fewest fetches and
- * reductions where it is short). */
-void sgn_set_waves_per_tile(int w);
-void sgn_set_adaptive_thresholds(int fwd_entries, int bwd_entries); /* <= 0 keeps the current value */
-/* XCD-aware tile -> workgroup order in the raster kernels (contiguous tile band per XCD / L2). */
-void sgn_set_xcd_swizzle(int on);
-/* Depth lists (forward) / reverse walks (backward) with at least this many entries are read through 64-entry
- * batches staged in wave-private LDS (vector gather a batch ahead) instead of the one-entry scalar look-ahead,
- * which is latency-bound for a lone wave on a long list.  <= 0 keeps the current value; a huge value disables. */
-void sgn_set_batch_thresholds(int fwd_entries, int bwd_entries);
+/* Kernel-selection options of the raster entry points, passed WITH EVERY CALL (NULL = the defaults): the library keeps
+ * no mutable configuration of its own, so two threads / streams may rasterize with different settings.  (Round 1 had
+ * process-global sgn_set_* switches here; they are gone.) */
+typedef struct sgn_raster_opts {
+    int exact_exp;      /* parity tests: 1 = portable polynomial exp (bit-identical to oracle/c/sgn_oracle.c
+                           exp_portable), 0 (default) = hardware v_exp_f32 */
+    int reduce_mode;    /* backward wave reduction: 1 (default) = transposed reduction on v_permlane32_swap /
+                           v_permlane16_swap + DPP row adds (8 swaps + 12 DPP adds for the nine per-Gaussian sums);
+                           0 = nine butterfly reductions (54 shuffles), kept for A/B measurements and tests */
+    int gather;         /* 1 (default): kernels chase gaussian_ids_sorted[k] -> per-Gaussian row with dependent scalar
+                           loads (no pack pass); 0: they stream a depth-ordered 48-byte record per intersection */
+    int waves_per_tile; /* 1: one wave64 per tile, 4 pixels per lane; 4: four waves per tile, one 8x8 quadrant each;
+                           0 (default): adaptive - tiles whose depth list (forward) / reverse walk (backward) has at
+                           least adapt_fwd / adapt_bwd entries are split over four waves, the rest done by one */
+    int adapt_fwd, adapt_bwd; /* defaults 3072 / 1536; <= 0 = default */
+    int batch_fwd, batch_bwd; /* lists / reverse walks with at least this many entries are read through 64-entry
+                                 batches staged in wave-private LDS instead of the one-entry scalar look-ahead
+                                 (defaults 256 / 128; <= 0 = default; a huge value disables) */
+    int xcd_swizzle;    /* 1: XCD-aware tile -> workgroup order (contiguous tile band per XCD / L2); default 0 */
+    int debug_flags;    /* timing ablations for profiles/ ONLY (results become wrong): bit0 = no gradient atomics,
+                           bit1 = no wave reduction; 0 = normal operation */
+} sgn_raster_opts;
+void sgn_raster_default_opts(sgn_raster_opts *out);
 
 /* Opt-in per-kernel timing for bench.py / profiles: when enabled, each timed launch is bracketed by
  * hipEventRecord on the stream it is launched on; sgn_timing_get sums the finished spans of a slot. */
@@ -217,11 +215,23 @@ int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const in
                       int32_t *gaussian_ids_sorted /*[n_isect]*/, int32_t *tile_bins /*[tiles,2]*/, void *ws,
                       size_t ws_bytes, sgn_stream_t stream);
 
+/* Window recognition for the drop-in scene-graph path (no upstream counterpart).  The reference renders its sub-model
+ * passes (sgn_splatfacto_scene_graph.py:364-366) from torch.cat COPIES of per-model slices of the main projection
+ * (:270-276).  mismatch[c] (device, int32, c < n_cand <= 4) becomes 0 iff the window tensors equal rows
+ * [cand_lo_host[c], cand_lo_host[c] + n_win) of the full-scene tensors BIT FOR BIT (xys [.,2], depths, radii,
+ * num_tiles_hit; conics [.,3] and opacities too when given - the exact tile culling depends on them); the caller may
+ * then rasterize the window over the depth list binned for the full scene (sgn_raster_fwd with id range + window). */
+int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *cand_lo_host, const float *xys_w,
+                   const float *depths_w, const int32_t *radii_w, const int32_t *num_tiles_hit_w, const float *conics_w,
+                   const float *opacities_w, const float *xys, const float *depths, const int32_t *radii,
+                   const int32_t *num_tiles_hit, const float *conics, const float *opacities, int32_t *mismatch,
+                   sgn_stream_t stream);
+
 /* _C.rasterize_forward (3-channel path; reference call sites sgn_splatfacto.py:954-967,
  * :982-994).  `recs_ws` (>= sgn_raster_workspace_bytes(n, n_isect)) receives the depth-ordered
  * 48-byte record stream the kernels read through the scalar cache; keep it alive and pass
  * recs_packed=1 to sgn_raster_bwd to skip re-packing. */
-size_t sgn_raster_workspace_bytes(int n, int64_t n_isect);
+size_t sgn_raster_workspace_bytes(int n, int64_t n_isect, const sgn_raster_opts *opts);
 int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                    const float *conics, const float *colors /*[n,3]*/, const float *opacities /*[n]*/,
@@ -229,17 +239,20 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    int id_lo, int id_hi /*only Gaussians with id in [id_lo, id_hi) take part (0, n = all): a sub-model
                                           pass of the scene graph (sgn_splatfacto_scene_graph.py:364-366) over the
                                           depth list binned once for the whole scene*/,
+                   int window /*1: xys / conics / colors / opacities hold rows [id_lo, id_hi) ONLY (row g - id_lo): the
+                                sub-model's own tensors, while gaussian_ids_sorted / tile_bins index all n Gaussians of
+                                the scene the list was binned for (the drop-in scene-graph path: the caller hands
+                                torch.cat COPIES of per-model slices, recognised by content)*/,
                    const float *background3, float *out_img /*[H,W,3]*/, float *final_Ts /*[H,W]*/,
                    int32_t *final_idx /*[H,W]*/, void *recs_ws, size_t recs_ws_bytes,
                    int rows_built /*1: sgn_raster_build_rows already filled recs_ws (gather mode)*/,
-                   sgn_stream_t stream);
+                   const sgn_raster_opts *opts, sgn_stream_t stream);
 /* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built
- * while the host waits for the intersection count (keeps the GPU busy across that sync).  sgn_raster_gather_mode()
- * tells whether the current record-fetch mode can use pre-built rows (1) or re-packs them itself (0). */
+ * while the host waits for the intersection count (keeps the GPU busy across that sync).  Pre-built rows are used by
+ * sgn_raster_fwd when opts->gather != 0 (pass rows_built = 1); in stream mode it re-packs them itself. */
 int sgn_raster_build_rows(int n, const float *xys, const float *conics, const float *colors, const float *opacities,
-                          int opacity_is_logit, int id_lo, int id_hi, void *recs_ws, size_t recs_ws_bytes,
+                          int opacity_is_logit, int id_lo, int id_hi, int window, void *recs_ws, size_t recs_ws_bytes,
                           sgn_stream_t stream);
-int sgn_raster_gather_mode(void);
 
 /* _C.rasterize_backward.  alpha_clamp_bwd: 0.99f reproduces gsplat 0.1.x (which clamps at
  * 0.999 in forward and 0.99 in backward).  Outputs are fully written (zero-filled first).
@@ -249,12 +262,13 @@ size_t sgn_raster_bwd_workspace_bytes(int n);
 int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                    const float *conics, const float *colors, const float *opacities, int opacity_is_logit,
-                   int id_lo, int id_hi, const float *background3, const float *final_Ts, const int32_t *final_idx,
+                   int id_lo, int id_hi, int window /*as in sgn_raster_fwd; the four outputs then have id_hi - id_lo rows*/,
+                   const float *background3, const float *final_Ts, const int32_t *final_idx,
                    const float *v_out_img /*[H,W,3]*/, const float *v_out_alpha /*[H,W]*/,
                    float alpha_clamp_bwd, float *v_xy /*[n,2]*/, float *v_conic /*[n,3]*/,
                    float *v_colors /*[n,3]*/, float *v_opacity /*[n]*/, void *recs_ws,
                    size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
-                   sgn_stream_t stream);
+                   const sgn_raster_opts *opts, sgn_stream_t stream);
 
 /* Sky cube-map lookup: replaces nvdiffrast `dr.texture(tex[None], dirs, filter_mode='linear',
  * boundary_mode='cube')` used by EnvLight (sgn_splatfacto.py:109-150).  tex [6,R,R,C] (faces +x,-x,+y,-y,+z,-z),

@@ -610,3 +610,64 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
     SGN_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------ window recognition
+// The scene graph renders its sub-model passes (sgn_splatfacto_scene_graph.py:364-366) from torch.cat COPIES of the
+// per-model slices of the main projection (:270-276): new tensors, same bytes.  To reuse the depth list binned for the
+// whole scene the host must know that a call's geometry EQUALS rows [lo, lo + n_win) of the geometry that list was
+// built from; this kernel compares them bit for bit (integer compare: NaNs match themselves) for up to 4 candidate
+// offsets in one pass and ORs a mismatch flag per candidate.
+namespace {
+struct MatchArgs {
+    const uint32_t *w[6];   // window tensors: xys[2], depths[1], radii[1], num_tiles_hit[1], conics[3], opac[1]
+    const uint32_t *f[6];   // the same six of the full scene
+    int width[6];
+    int lo[4];
+    int n_cand;
+};
+__global__ __launch_bounds__(256) void rows_match_kernel(int n_win, MatchArgs a, int32_t *__restrict__ mismatch) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned bad = 0u;
+    if (i < n_win) {
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            if (a.w[t] == nullptr) continue;
+            const int wd = a.width[t];
+            for (int k = 0; k < wd; ++k) {
+                const uint32_t v = a.w[t][(size_t)i * wd + k];
+                for (int c = 0; c < a.n_cand; ++c)
+                    if (a.f[t][((size_t)a.lo[c] + i) * wd + k] != v) bad |= 1u << c;
+            }
+        }
+    }
+    for (int c = 0; c < a.n_cand; ++c) {
+        const bool any = __ballot((bad >> c) & 1u) != 0ull;
+        if (any && (threadIdx.x & 63) == 0) atomicOr(mismatch + c, 1);
+    }
+}
+}  // namespace
+
+SGN_EXPORT int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *cand_lo_host, const float *xys_w,
+                              const float *depths_w, const int32_t *radii_w, const int32_t *num_tiles_hit_w,
+                              const float *conics_w, const float *opacities_w, const float *xys, const float *depths,
+                              const int32_t *radii, const int32_t *num_tiles_hit, const float *conics,
+                              const float *opacities, int32_t *mismatch, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n_win > 0 && n_full >= n_win && n_cand >= 1 && n_cand <= 4 && cand_lo_host && mismatch, -1);
+    SGN_ARG_CHECK(xys_w && depths_w && radii_w && num_tiles_hit_w && xys && depths && radii && num_tiles_hit, -2);
+    SGN_ARG_CHECK((conics_w == nullptr) == (conics == nullptr) && (opacities_w == nullptr) == (opacities == nullptr), -3);
+    MatchArgs a;
+    const void *w[6] = {xys_w, depths_w, radii_w, num_tiles_hit_w, conics_w, opacities_w};
+    const void *f[6] = {xys, depths, radii, num_tiles_hit, conics, opacities};
+    const int width[6] = {2, 1, 1, 1, 3, 1};
+    for (int t = 0; t < 6; ++t) { a.w[t] = (const uint32_t *)w[t]; a.f[t] = (const uint32_t *)f[t]; a.width[t] = width[t]; }
+    a.n_cand = n_cand;
+    for (int c = 0; c < 4; ++c) {
+        a.lo[c] = c < n_cand ? cand_lo_host[c] : 0;
+        SGN_ARG_CHECK(a.lo[c] >= 0 && a.lo[c] + n_win <= n_full, -4);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SGN_HIP_CHECK(hipMemsetAsync(mismatch, 0, sizeof(int32_t) * n_cand, s));
+    hipLaunchKernelGGL(rows_match_kernel, dim3(sgn_cdiv(n_win, 256)), dim3(256), 0, s, n_win, a, mismatch);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

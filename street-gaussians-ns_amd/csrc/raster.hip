@@ -72,9 +72,13 @@ __global__ __launch_bounds__(256) void build_grec_kernel(int n, const float *__r
                                                          const float *__restrict__ conics,
                                                          const float *__restrict__ colors,
                                                          const float *__restrict__ opac, int opac_is_logit,
-                                                         int id_lo, int id_hi, float4 *__restrict__ grec) {
+                                                         int id_lo, int id_hi, int window,
+                                                         float4 *__restrict__ grec) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= n) return;
+    // window != 0: the four input arrays hold rows [id_lo, id_hi) only (a sub-model's own tensors), row g - id_lo
+    const int off = window ? id_lo : 0;
+    xys -= 2 * (ptrdiff_t)off; conics -= 3 * (ptrdiff_t)off; colors -= 3 * (ptrdiff_t)off; opac -= off;
     if (g < id_lo || g >= id_hi) {
         // sub-model pass over a shared depth list (scene graph): Gaussians outside [id_lo, id_hi) become inert
         // rows — zero opacity (alpha < 1/255 on every pixel) and a bbox no quadrant test can pass
@@ -575,16 +579,17 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
     }
 }
 
-__global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *__restrict__ ws,
+// rows [row0, row0 + n) of the packed gradient workspace -> the n rows of the four output arrays
+__global__ __launch_bounds__(256) void unpack_grads_kernel(int n, int row0, const float *__restrict__ ws,
                                                            const float *__restrict__ opac, int opac_is_logit,
                                                            float *__restrict__ v_xy, float *__restrict__ v_conic,
                                                            float *__restrict__ v_colors,
                                                            float *__restrict__ v_opac) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const float4 a = reinterpret_cast<const float4 *>(ws)[3 * i + 0];
-    const float4 b = reinterpret_cast<const float4 *>(ws)[3 * i + 1];
-    const float4 c = reinterpret_cast<const float4 *>(ws)[3 * i + 2];
+    const float4 a = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 0];
+    const float4 b = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 1];
+    const float4 c = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 2];
     v_xy[2 * i] = a.x; v_xy[2 * i + 1] = a.y;
     v_conic[3 * i] = a.z; v_conic[3 * i + 1] = a.w; v_conic[3 * i + 2] = b.x;
     v_colors[3 * i] = b.y; v_colors[3 * i + 1] = b.z; v_colors[3 * i + 2] = b.w;
@@ -596,38 +601,45 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, const float *_
     v_opac[i] = vo;
 }
 
-int g_exact_exp = 0;
-int g_reduce_mode = 1;   // 0: butterfly shuffles, 1: transposed permlane-swap reduction (default)
-int g_debug = 0;         // timing ablations only (bit0: no atomics, bit1: no wave reduction)
-int g_wpt = 0;           // waves per tile: 1, 4, or 0 = adaptive (split long lists, default)
-int g_adapt_fwd = 3072;  // forward: split tiles with >= this many list entries
-int g_adapt_bwd = 1536;  // backward: split tiles whose reverse walk covers >= this many entries
-int g_batch_fwd = 256;   // forward: lists with >= this many entries go through the LDS-batched path
-int g_batch_bwd = 128;   // backward: reverse walks with >= this many entries go through the LDS-batched path
-int g_xcd_swizzle = 0;   // XCD-aware tile order in the raster kernels
-int g_gather = 1;        // 1 (default): chase ids -> per-Gaussian rows; 0: stream packed records
+// Kernel-selection options arrive with every call (include/sgn_rast.h: sgn_raster_opts); NULL = defaults.
+sgn_raster_opts resolve_opts(const sgn_raster_opts *o) {
+    sgn_raster_opts r;
+    sgn_raster_default_opts(&r);
+    if (o) {
+        r = *o;
+        r.exact_exp = r.exact_exp ? 1 : 0;
+        r.reduce_mode = r.reduce_mode ? 1 : 0;
+        r.gather = r.gather ? 1 : 0;
+        r.waves_per_tile = (r.waves_per_tile == 4 || r.waves_per_tile == 1) ? r.waves_per_tile : 0;
+        sgn_raster_opts d;
+        sgn_raster_default_opts(&d);
+        if (r.adapt_fwd <= 0) r.adapt_fwd = d.adapt_fwd;
+        if (r.adapt_bwd <= 0) r.adapt_bwd = d.adapt_bwd;
+        if (r.batch_fwd <= 0) r.batch_fwd = d.batch_fwd;
+        if (r.batch_bwd <= 0) r.batch_bwd = d.batch_bwd;
+    }
+    return r;
+}
 
 }  // namespace
 
-SGN_EXPORT void sgn_set_exact_exp(int on) { g_exact_exp = on ? 1 : 0; }
-SGN_EXPORT int sgn_get_exact_exp(void) { return g_exact_exp; }
-SGN_EXPORT void sgn_set_reduce_mode(int mode) { g_reduce_mode = mode ? 1 : 0; }
-SGN_EXPORT void sgn_set_debug_flags(int flags) { g_debug = flags; }
-SGN_EXPORT void sgn_set_gather_mode(int on) { g_gather = on ? 1 : 0; }
-SGN_EXPORT void sgn_set_xcd_swizzle(int on) { g_xcd_swizzle = on ? 1 : 0; }
-SGN_EXPORT void sgn_set_batch_thresholds(int fwd_entries, int bwd_entries) {
-    if (fwd_entries > 0) g_batch_fwd = fwd_entries;
-    if (bwd_entries > 0) g_batch_bwd = bwd_entries;
-}
-SGN_EXPORT void sgn_set_waves_per_tile(int w) { g_wpt = (w == 4 || w == 1) ? w : 0; }
-SGN_EXPORT void sgn_set_adaptive_thresholds(int fwd_entries, int bwd_entries) {
-    if (fwd_entries > 0) g_adapt_fwd = fwd_entries;
-    if (bwd_entries > 0) g_adapt_bwd = bwd_entries;
+SGN_EXPORT void sgn_raster_default_opts(sgn_raster_opts *out) {
+    if (!out) return;
+    out->exact_exp = 0;        // hardware v_exp_f32
+    out->reduce_mode = 1;      // transposed permlane-swap reduction
+    out->gather = 1;           // chase ids -> per-Gaussian rows
+    out->waves_per_tile = 0;   // adaptive
+    out->adapt_fwd = 3072;     // forward: split tiles with >= this many list entries
+    out->adapt_bwd = 1536;     // backward: split tiles whose reverse walk covers >= this many entries
+    out->batch_fwd = 256;      // forward: lists with >= this many entries go through the LDS-batched path
+    out->batch_bwd = 128;      // backward: same for reverse walks
+    out->xcd_swizzle = 0;
+    out->debug_flags = 0;
 }
 
-SGN_EXPORT size_t sgn_raster_workspace_bytes(int n, int64_t n_isect) {
+SGN_EXPORT size_t sgn_raster_workspace_bytes(int n, int64_t n_isect, const sgn_raster_opts *opts) {
     // [n per-Gaussian rows][n_isect depth-ordered records (stream mode only)]
-    const size_t stream = g_gather ? 0 : (size_t)(n_isect > 0 ? n_isect : 1);
+    const size_t stream = resolve_opts(opts).gather ? 0 : (size_t)(n_isect > 0 ? n_isect : 1);
     return ((size_t)(n > 0 ? n : 1) + stream) * sizeof(Rec);
 }
 
@@ -637,14 +649,14 @@ SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
 
 // builds the per-Gaussian rows and (stream mode) the depth-ordered record stream
 static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
-                        const float *colors, const float *opac, int opac_is_logit, int id_lo, int id_hi, void *recs,
-                        hipStream_t s) {
+                        const float *colors, const float *opac, int opac_is_logit, int id_lo, int id_hi, int window,
+                        int gather, void *recs, hipStream_t s) {
     float4 *grec = (float4 *)recs;                       // rows first,
     float4 *stream_recs = (float4 *)recs + 3 * (size_t)n; // then the optional depth-ordered stream
     sgn_timing_begin(SGN_T_PACK, s);
     hipLaunchKernelGGL(build_grec_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, conics, colors, opac,
-                       opac_is_logit, id_lo, id_hi, grec);
-    if (!g_gather)
+                       opac_is_logit, id_lo, id_hi, window, grec);
+    if (!gather)
         hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(3 * n_isect, 256)), dim3(256), 0, s, n_isect, ids,
                            grec, stream_recs);
     sgn_timing_end(SGN_T_PACK, s);
@@ -655,8 +667,9 @@ static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float 
 // intersection count (pass rows_built = 1 to sgn_raster_fwd afterwards; gather mode only — in stream mode the rows are
 // re-packed into depth order and sgn_raster_fwd builds them itself).
 SGN_EXPORT int sgn_raster_build_rows(int n, const float *xys, const float *conics, const float *colors,
-                                     const float *opacities, int opacity_is_logit, int id_lo, int id_hi,
+                                     const float *opacities, int opacity_is_logit, int id_lo, int id_hi, int window,
                                      void *recs_ws, size_t recs_ws_bytes, sgn_stream_t stream) {
+    SGN_ARG_CHECK(!window || (0 <= id_lo && id_lo <= id_hi && id_hi <= n), -4);
     SGN_ARG_CHECK(n >= 0, -1);
     if (n == 0) return 0;
     SGN_ARG_CHECK(xys && conics && colors && opacities && recs_ws, -2);
@@ -664,30 +677,30 @@ SGN_EXPORT int sgn_raster_build_rows(int n, const float *xys, const float *conic
     hipStream_t s = (hipStream_t)stream;
     sgn_timing_begin(SGN_T_PACK, s);
     hipLaunchKernelGGL(build_grec_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, conics, colors, opacities,
-                       opacity_is_logit, id_lo, id_hi, (float4 *)recs_ws);
+                       opacity_is_logit, id_lo, id_hi, window, (float4 *)recs_ws);
     sgn_timing_end(SGN_T_PACK, s);
     SGN_LAUNCH_CHECK();
     return 0;
 }
 
-SGN_EXPORT int sgn_raster_gather_mode(void) { return g_gather; }
-
 SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
-                              int opacity_is_logit, int id_lo, int id_hi, const float *background3, float *out_img,
-                              float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes, int rows_built,
-                              sgn_stream_t stream) {
+                              int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
+                              float *out_img, float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes,
+                              int rows_built, const sgn_raster_opts *opts, sgn_stream_t stream) {
+    const sgn_raster_opts o = resolve_opts(opts);
     SGN_ARG_CHECK(img_h > 0 && img_w > 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
     SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -3);
     SGN_ARG_CHECK(tile_bins && background3 && out_img && final_Ts && final_idx, -4);
     SGN_ARG_CHECK(n_isect == 0 || (gaussian_ids_sorted && xys && conics && colors && opacities && recs_ws), -5);
-    SGN_ARG_CHECK(n >= 0 && recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect), -6);
+    SGN_ARG_CHECK(n >= 0 && recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect, &o), -6);
+    SGN_ARG_CHECK(!window || (0 <= id_lo && id_lo <= id_hi && id_hi <= n), -7);
     hipStream_t s = (hipStream_t)stream;
-    if (n_isect > 0 && !(rows_built && g_gather))
+    if (n_isect > 0 && !(rows_built && o.gather))
         pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
-                     recs_ws, s);
+                     window, o.gather, recs_ws, s);
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     const Rec *rows = (const Rec *)recs_ws;
     const Rec *stream_recs = rows + n;
@@ -695,17 +708,17 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
 #define SGN_LAUNCH_FWD(EX, GA, Q, AD)                                                                                \
     hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
                        img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
-                       gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, g_adapt_fwd, g_xcd_swizzle, g_batch_fwd)
+                       gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, o.adapt_fwd, o.xcd_swizzle, o.batch_fwd)
 #define SGN_LAUNCH_FWD2(EX, GA)                                                     \
     do {                                                                            \
-        if (g_wpt == 4) SGN_LAUNCH_FWD(EX, GA, 1, false);                           \
-        else if (g_wpt == 1) SGN_LAUNCH_FWD(EX, GA, 4, false);                      \
+        if (o.waves_per_tile == 4) SGN_LAUNCH_FWD(EX, GA, 1, false);                \
+        else if (o.waves_per_tile == 1) SGN_LAUNCH_FWD(EX, GA, 4, false);           \
         else SGN_LAUNCH_FWD(EX, GA, 4, true);                                       \
     } while (0)
-    if (g_exact_exp) {
-        if (g_gather) SGN_LAUNCH_FWD2(true, true); else SGN_LAUNCH_FWD2(true, false);
+    if (o.exact_exp) {
+        if (o.gather) SGN_LAUNCH_FWD2(true, true); else SGN_LAUNCH_FWD2(true, false);
     } else {
-        if (g_gather) SGN_LAUNCH_FWD2(false, true); else SGN_LAUNCH_FWD2(false, false);
+        if (o.gather) SGN_LAUNCH_FWD2(false, true); else SGN_LAUNCH_FWD2(false, false);
     }
 #undef SGN_LAUNCH_FWD2
 #undef SGN_LAUNCH_FWD
@@ -717,12 +730,14 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
 SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
-                              int opacity_is_logit, int id_lo, int id_hi, const float *background3,
+                              int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
                               const float *final_Ts, const int32_t *final_idx,
                               const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd,
                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
                               size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
-                              sgn_stream_t stream) {
+                              const sgn_raster_opts *opts, sgn_stream_t stream) {
+    const sgn_raster_opts o = resolve_opts(opts);
+    SGN_ARG_CHECK(!window || (0 <= id_lo && id_lo <= id_hi && id_hi <= n), -9);
     SGN_ARG_CHECK(img_h > 0 && img_w > 0 && n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
     SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -3);
@@ -735,30 +750,30 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     if (n_isect > 0) {
         SGN_ARG_CHECK(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background3 &&
                           final_Ts && final_idx && v_out_img && v_out_alpha && recs_ws, -7);
-        SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect), -8);
+        SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect, &o), -8);
         if (!recs_packed)
             pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
-                         recs_ws, s);
+                         window, o.gather, recs_ws, s);
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
         const Rec *rows = (const Rec *)recs_ws;
         const Rec *stream_recs = rows + n;
         sgn_timing_begin(SGN_T_RASTER_BWD, s);
 #define SGN_LAUNCH_BWD(EX, RM, GA)                                                                               \
     do {                                                                                                         \
-        if (g_wpt == 4) SGN_LAUNCH_BWDQ(EX, RM, GA, 1, false);                                                   \
-        else if (g_wpt == 1) SGN_LAUNCH_BWDQ(EX, RM, GA, 4, false);                                              \
+        if (o.waves_per_tile == 4) SGN_LAUNCH_BWDQ(EX, RM, GA, 1, false);                                        \
+        else if (o.waves_per_tile == 1) SGN_LAUNCH_BWDQ(EX, RM, GA, 4, false);                                   \
         else SGN_LAUNCH_BWDQ(EX, RM, GA, 4, true);                                                               \
     } while (0)
 #define SGN_LAUNCH_BWDQ(EX, RM, GA, Q, AD)                                                                       \
     hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, img_w, img_h, \
                        block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, \
                        background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws, \
-                       g_debug, g_adapt_bwd, g_xcd_swizzle, g_batch_bwd)
-#define SGN_LAUNCH_BWD2(EX, RM) do { if (g_gather) SGN_LAUNCH_BWD(EX, RM, true); else SGN_LAUNCH_BWD(EX, RM, false); } while (0)
-        if (g_exact_exp) {
-            if (g_reduce_mode) SGN_LAUNCH_BWD2(true, 1); else SGN_LAUNCH_BWD2(true, 0);
+                       o.debug_flags, o.adapt_bwd, o.xcd_swizzle, o.batch_bwd)
+#define SGN_LAUNCH_BWD2(EX, RM) do { if (o.gather) SGN_LAUNCH_BWD(EX, RM, true); else SGN_LAUNCH_BWD(EX, RM, false); } while (0)
+        if (o.exact_exp) {
+            if (o.reduce_mode) SGN_LAUNCH_BWD2(true, 1); else SGN_LAUNCH_BWD2(true, 0);
         } else {
-            if (g_reduce_mode) SGN_LAUNCH_BWD2(false, 1); else SGN_LAUNCH_BWD2(false, 0);
+            if (o.reduce_mode) SGN_LAUNCH_BWD2(false, 1); else SGN_LAUNCH_BWD2(false, 0);
         }
 #undef SGN_LAUNCH_BWD2
 #undef SGN_LAUNCH_BWD
@@ -766,8 +781,12 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         sgn_timing_end(SGN_T_RASTER_BWD, s);
     }
     sgn_timing_begin(SGN_T_UNPACK, s);
-    hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, (const float *)grad_ws,
-                       opacities, opacity_is_logit, v_xy, v_conic, v_colors, v_opacity);
+    {   // window: the outputs (and `opacities`) hold rows [id_lo, id_hi) only
+        const int n_out = window ? id_hi - id_lo : n, row0 = window ? id_lo : 0;
+        if (n_out > 0)
+            hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n_out, 256)), dim3(256), 0, s, n_out, row0,
+                               (const float *)grad_ws, opacities, opacity_is_logit, v_xy, v_conic, v_colors, v_opacity);
+    }
     sgn_timing_end(SGN_T_UNPACK, s);
     SGN_LAUNCH_CHECK();
     return 0;

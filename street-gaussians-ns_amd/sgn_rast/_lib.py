@@ -6,6 +6,8 @@ infrastructure only; nothing here imports it.)
 """
 from __future__ import annotations
 
+import contextlib
+import contextvars
 import ctypes as C
 import os
 
@@ -20,15 +22,7 @@ _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 SIGNATURES = {
     "sgn_version": (_i, []),
     "sgn_last_error": (C.c_char_p, []),
-    "sgn_set_exact_exp": (None, [_i]),
-    "sgn_get_exact_exp": (_i, []),
-    "sgn_set_reduce_mode": (None, [_i]),
-    "sgn_set_debug_flags": (None, [_i]),
-    "sgn_set_gather_mode": (None, [_i]),
-    "sgn_set_waves_per_tile": (None, [_i]),
-    "sgn_set_adaptive_thresholds": (None, [_i, _i]),
-    "sgn_set_xcd_swizzle": (None, [_i]),
-    "sgn_set_batch_thresholds": (None, [_i, _i]),
+    "sgn_raster_default_opts": (None, [_vp]),
     "sgn_timing_enable": (None, [_i]),
     "sgn_timing_get": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "sgn_project_fwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f,
@@ -66,19 +60,93 @@ SIGNATURES = {
     "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_bin_intersect_workspace_bytes": (_sz, [_i64]),
     "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
-    "sgn_raster_workspace_bytes": (_sz, [_i, _i64]),
-    "sgn_raster_fwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz,
-                            _i, _vp]),
-    "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "sgn_raster_gather_mode": (_i, []),
+    "sgn_rows_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_raster_workspace_bytes": (_sz, [_i, _i64, _vp]),
+    "sgn_raster_fwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                            _sz, _i, _vp, _vp]),
+    "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sgn_raster_bwd_workspace_bytes": (_sz, [_i]),
-    "sgn_raster_bwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _f,
-                            _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp]),
+    "sgn_raster_bwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
+                            _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp, _vp]),
 }
 
 _lib = None
-DEFAULT_REDUCE_MODE = int(os.environ.get("SGN_REDUCE_MODE", "1"))
-DEFAULT_GATHER_MODE = int(os.environ.get("SGN_RASTER_GATHER", "1"))
+
+
+class RasterOpts(C.Structure):
+    """`sgn_raster_opts` of include/sgn_rast.h: kernel-selection options handed to the raster entry points per call."""
+    _fields_ = [(k, C.c_int) for k in ("exact_exp", "reduce_mode", "gather", "waves_per_tile", "adapt_fwd", "adapt_bwd",
+                                       "batch_fwd", "batch_bwd", "xcd_swizzle", "debug_flags")]
+
+    def copy(self) -> "RasterOpts":
+        out = RasterOpts()
+        C.memmove(C.byref(out), C.byref(self), C.sizeof(RasterOpts))
+        return out
+
+
+# The library itself is stateless; the HOST keeps the options: one process-wide default object (library defaults,
+# overridable through SGN_* environment variables for A/B runs) and, inside `with options(...)`, a private copy that
+# only the current thread / context sees (contextvars), so concurrent callers cannot race on a switch.
+_ENV = dict(reduce_mode="SGN_REDUCE_MODE", gather="SGN_RASTER_GATHER", waves_per_tile="SGN_WAVES_PER_TILE",
+            batch_fwd="SGN_BATCH_FWD", batch_bwd="SGN_BATCH_BWD", xcd_swizzle="SGN_XCD_SWIZZLE",
+            adapt_fwd="SGN_ADAPT_FWD", adapt_bwd="SGN_ADAPT_BWD", debug_flags="SGN_DEBUG_FLAGS")
+_process_opts = None
+_ctx_opts: contextvars.ContextVar = contextvars.ContextVar("sgn_raster_opts", default=None)
+
+
+def _library_defaults() -> RasterOpts:
+    o = RasterOpts()
+    load().sgn_raster_default_opts(C.byref(o))
+    for field, env in _ENV.items():
+        if os.environ.get(env, "") != "":
+            setattr(o, field, int(os.environ[env]))
+    return o
+
+
+def opts() -> RasterOpts:
+    """The options the next raster call of this context will carry."""
+    global _process_opts
+    cur = _ctx_opts.get()
+    if cur is not None:
+        return cur
+    if _process_opts is None:
+        _process_opts = _library_defaults()
+    return _process_opts
+
+
+def opts_ptr():
+    return C.byref(opts())
+
+
+def set_options(**kw) -> None:
+    """Change fields of the current options object (the process default, or the private copy inside `options`)."""
+    o = opts()
+    for k, v in kw.items():
+        if k not in dict(RasterOpts._fields_):
+            raise AttributeError(k)
+        setattr(o, k, int(v))
+
+
+def reset_options() -> None:
+    """Back to the library defaults (+ SGN_* environment overrides)."""
+    global _process_opts
+    _process_opts = None
+    _ctx_opts.set(None)
+
+
+@contextlib.contextmanager
+def options(**kw):
+    """`with options(exact_exp=1): ...` — a private copy of the options for this thread / context only."""
+    o = opts().copy()
+    for k, v in kw.items():
+        if k not in dict(RasterOpts._fields_):
+            raise AttributeError(k)
+        setattr(o, k, int(v))
+    token = _ctx_opts.set(o)
+    try:
+        yield o
+    finally:
+        _ctx_opts.reset(token)
 
 
 class SgnRastError(RuntimeError):
@@ -98,13 +166,6 @@ def load() -> C.CDLL:
             fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        lib.sgn_set_reduce_mode(DEFAULT_REDUCE_MODE)
-        lib.sgn_set_gather_mode(DEFAULT_GATHER_MODE)
-        lib.sgn_set_waves_per_tile(int(os.environ.get("SGN_WAVES_PER_TILE", "0")))
-        lib.sgn_set_batch_thresholds(int(os.environ.get("SGN_BATCH_FWD", "0")), int(os.environ.get("SGN_BATCH_BWD", "0")))
-        lib.sgn_set_xcd_swizzle(int(os.environ.get("SGN_XCD_SWIZZLE", "0")))
-        lib.sgn_set_adaptive_thresholds(int(os.environ.get("SGN_ADAPT_FWD", "0")), int(os.environ.get("SGN_ADAPT_BWD", "0")))
-        lib.sgn_set_debug_flags(int(os.environ.get("SGN_DEBUG_FLAGS", "0")))
         _lib = lib
     return _lib
 

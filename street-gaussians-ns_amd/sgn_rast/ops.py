@@ -15,6 +15,7 @@ arithmetic happens in the hand-written HIP kernels behind the C ABI.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Optional, Tuple
 
@@ -423,6 +424,63 @@ def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bo
     return val
 
 
+# ------------------------------------------------------- window recognition
+# The scene graph renders its sub-model passes from torch.cat COPIES of per-model slices of the main projection
+# (sgn_splatfacto_scene_graph.py:270-276, passes at :364-366): new tensors every time, so the identity-keyed cache
+# above cannot hit, and re-binning each slice cost two more rank/emit/sort rounds per step (121 vs 390 images/s in
+# round 1).  Those copies are still BIT-IDENTICAL to a row window of the geometry the cached list was binned for —
+# the background is the head of the concatenation, the objects its tail — so a call whose tensors are smaller than
+# the cached scene is compared against those two windows on the device (sgn_rows_match: one pass over the window,
+# a few MB) and, on a match, rasterized over the CACHED list with an id range: no ranking, no emission, no sort.
+# One host read-back of the verdict replaces the intersection-count read-back of the re-binning it avoids.
+window_matching_enabled = True
+window_stats = {"tried": 0, "hit": 0}
+
+
+def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacity, cull):
+    """(lo, cached value, n_full) when the call's geometry equals rows [lo, lo + n) of the cached scene, else None."""
+    ck, keep, val = _bin_cache["key"], _bin_cache["keep"], _bin_cache["val"]
+    if ck is None or not window_matching_enabled or not binning_cache_enabled or n <= 0:
+        return None
+    if ck[len(keep):] != key_tail or val[0] < 1:       # tile grid, block, flags (logit / cull), stream
+        return None
+    n_full = keep[0].shape[0]
+    if n_full <= n:
+        return None
+    mine = (xys, depths, radii, num_tiles_hit) + ((conics, opacity) if cull else ())
+    for t, c in zip(mine, keep):
+        if t.dtype != c.dtype or t.shape[1:] != c.shape[1:] or t.device != c.device:
+            return None
+    window_stats["tried"] += 1
+    dev = xys.device
+    lib = L.load()
+    cands = sorted({0, n_full - n})
+    lo_host = (C.c_int32 * len(cands))(*cands)
+    flags = torch.empty(4, dtype=torch.int32, device=dev)
+    w = [t.detach().contiguous() for t in mine] + [None] * (6 - len(mine))
+    f = [c.contiguous() for c in keep] + [None] * (6 - len(keep))
+    if cull:
+        w[5], f[5] = w[5].reshape(-1), f[5].reshape(-1)
+    L.check(lib.sgn_rows_match(n, n_full, len(cands), lo_host, *[L.ptr(t) for t in w], *[L.ptr(t) for t in f],
+                               L.ptr(flags), L.stream_ptr()), "sgn_rows_match")
+    if dev not in _side:
+        _side[dev] = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]
+    pool = _side[dev]
+    pinned = pool[0][pool[1] % 4]
+    pool[1] += 1
+    pinned[0:len(cands)].copy_(flags[0:len(cands)], non_blocking=True)
+    done = torch.cuda.Event()
+    done.record(torch.cuda.current_stream(dev))
+    done.synchronize()
+    if _pending_checks:
+        raise_pending_checks()
+    for i, lo in enumerate(cands):
+        if int(pinned[i]) == 0:
+            window_stats["hit"] += 1
+            return lo, val, n_full
+    return None
+
+
 # --------------------------------------------------------------- rasterize
 class _RasterizeGaussians(Function):
     @staticmethod
@@ -430,7 +488,6 @@ class _RasterizeGaussians(Function):
                 block_width, background=None, return_alpha=False, opacity_is_logit=False, id_range=None):
         dev = L.require_device(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
         num_points = xys.size(0)
-        id_lo, id_hi = (0, num_points) if id_range is None else (int(id_range[0]), int(id_range[1]))
         tile_bounds = ((img_width + block_width - 1) // block_width,
                        (img_height + block_width - 1) // block_width, 1)
         if colors.shape[-1] != 3:
@@ -441,30 +498,45 @@ class _RasterizeGaussians(Function):
         opac_c, bg_c = _f32c(opacity).reshape(-1), _f32c(background)
         f32 = dict(dtype=torch.float32, device=dev)
         lib = L.load()
+        ro = L.opts().copy()              # this call's kernel options: the backward runs with the same ones
+        ro_ptr = C.byref(ro)
         # everything that does not depend on the intersection count is prepared BEFORE the binning's host sync: the
         # GPU idles from the moment the count is known until the next launch arrives, so that window is kept short
         out_img = torch.empty(img_height, img_width, 3, **f32)
         final_Ts = torch.empty(img_height, img_width, **f32)
         final_idx = torch.empty(img_height, img_width, dtype=torch.int32, device=dev)
         stream_ptr = L.stream_ptr()
-        # ... and the per-Gaussian rows are built between the binning's first half and its host sync, so the GPU has
-        # work queued while the host wakes up (gather mode; the stream mode re-packs rows per intersection later)
         key, _t, cull = _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
                                    opacity_is_logit)
+        hit = binning_cache_enabled and _bin_cache["key"] == key
+        # a sub-model's copy of a window of the cached scene?  (drop-in scene-graph path; see _match_window)
+        n_full, window, win = num_points, 0, None
+        if id_range is None and not hit and _bin_pending["key"] != key:
+            win = _match_window(key[len(_t):], num_points, xys, depths, radii, num_tiles_hit, conics, opacity, cull)
+        if win is not None:
+            lo, cached, n_full = win
+            id_lo, id_hi, window = lo, lo + num_points, 1
+        else:
+            id_lo, id_hi = (0, num_points) if id_range is None else (int(id_range[0]), int(id_range[1]))
+        # ... and the per-Gaussian rows are built between the binning's first half and its host sync, so the GPU has
+        # work queued while the host wakes up (gather mode; the stream mode re-packs rows per intersection later)
         recs, rows_built = None, 0
-        if num_points > 0 and lib.sgn_raster_gather_mode():
-            if not (binning_cache_enabled and _bin_cache["key"] == key) and _bin_pending["key"] != key:
+        if num_points > 0 and ro.gather:
+            if win is None and not hit and _bin_pending["key"] != key:
                 _bin_pending["state"] = _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds,
                                                            block_width, conics, opacity, opacity_is_logit, cull)
                 _bin_pending["key"], _bin_pending["keep"] = key, tuple(t.detach() for t in _t)
-            recs = L.workspace(lib.sgn_raster_workspace_bytes(num_points, 0), dev)
-            L.check(lib.sgn_raster_build_rows(num_points, L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c),
-                                              int(bool(opacity_is_logit)), id_lo, id_hi, L.ptr(recs), recs.numel(),
-                                              stream_ptr), "sgn_raster_build_rows")
+            recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, 0, ro_ptr), dev)
+            L.check(lib.sgn_raster_build_rows(n_full, L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c),
+                                              int(bool(opacity_is_logit)), id_lo, id_hi, window, L.ptr(recs),
+                                              recs.numel(), stream_ptr), "sgn_raster_build_rows")
             rows_built = 1
-        num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
-            num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
-            opacity_is_logit)
+        if win is not None:
+            num_intersects, gaussian_ids_sorted, tile_bins = cached
+        else:
+            num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
+                num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
+                opacity_is_logit)
         if num_intersects < 1:
             recs = None
             out_img = torch.ones(img_height, img_width, 3, **f32) * bg_c
@@ -474,16 +546,17 @@ class _RasterizeGaussians(Function):
             final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
         else:
             if not rows_built:
-                recs = L.workspace(lib.sgn_raster_workspace_bytes(num_points, num_intersects), dev)
+                recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
             L.check(lib.sgn_raster_fwd(
-                img_height, img_width, block_width, num_points, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
+                img_height, img_width, block_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), id_lo, id_hi,
-                L.ptr(bg_c), L.ptr(out_img),
-                L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), rows_built, stream_ptr), "sgn_raster_fwd")
+                window, L.ptr(bg_c), L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(),
+                rows_built, ro_ptr, stream_ptr), "sgn_raster_fwd")
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
         ctx.num_intersects = num_intersects
         ctx.opacity_is_logit = int(bool(opacity_is_logit))
         ctx.id_range = (id_lo, id_hi)
+        ctx.window, ctx.n_full, ctx.ro = window, n_full, ro
         ctx.opacity_shape = opacity.shape
         ctx.recs = recs
         ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys_c, conics_c, colors_c, opac_c, bg_c,
@@ -498,7 +571,7 @@ class _RasterizeGaussians(Function):
         (gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity, background, final_Ts,
          final_idx) = ctx.saved_tensors
         dev = xys.device
-        n = xys.shape[0]
+        n = xys.shape[0]                     # rows of the caller's tensors (= the window's rows in window mode)
         H, W = ctx.img_height, ctx.img_width
         f32 = dict(dtype=torch.float32, device=dev)
         if v_out_alpha is None:
@@ -512,17 +585,19 @@ class _RasterizeGaussians(Function):
             v_xy.zero_(); v_conic.zero_(); v_colors.zero_(); v_opacity.zero_()
         else:
             lib = L.load()
+            ro_ptr = C.byref(ctx.ro)
             recs, packed = ctx.recs, 1
             if recs is None:
-                recs, packed = L.workspace(lib.sgn_raster_workspace_bytes(n, ctx.num_intersects), dev), 0
-            gws = L.workspace(lib.sgn_raster_bwd_workspace_bytes(n), dev)
+                recs = L.workspace(lib.sgn_raster_workspace_bytes(ctx.n_full, ctx.num_intersects, ro_ptr), dev)
+                packed = 0
+            gws = L.workspace(lib.sgn_raster_bwd_workspace_bytes(ctx.n_full), dev)
             L.check(lib.sgn_raster_bwd(
-                H, W, ctx.block_width, n, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
+                H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity), ctx.opacity_is_logit, ctx.id_range[0],
-                ctx.id_range[1], L.ptr(background), L.ptr(final_Ts),
+                ctx.id_range[1], ctx.window, L.ptr(background), L.ptr(final_Ts),
                 L.ptr(final_idx), L.ptr(v_out_img), L.ptr(v_out_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
                 L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
-                L.ptr(gws), gws.numel(), L.stream_ptr()), "sgn_raster_bwd")
+                L.ptr(gws), gws.numel(), ro_ptr, L.stream_ptr()), "sgn_raster_bwd")
         v_opacity = v_opacity.reshape(ctx.opacity_shape)
         # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha)
         return v_xy, None, None, v_conic, None, v_colors, v_opacity, None, None, None, None, None, None, None

@@ -75,11 +75,18 @@ def test_argument_errors_are_reported_without_a_gpu(built_lib):
     rc = lib.sgn_sh_fwd(4, 7, 3, None, None, None, None)
     assert rc < 0
     assert lib.sgn_sort_workspace_bytes(1 << 20) > (1 << 20) * 12
-    lib.sgn_set_gather_mode(1)
-    assert lib.sgn_raster_workspace_bytes(5, 10) == 5 * 48        # per-Gaussian rows only
-    lib.sgn_set_gather_mode(0)
-    assert lib.sgn_raster_workspace_bytes(5, 10) == 15 * 48       # + depth-ordered record stream
-    lib.sgn_set_gather_mode(built_lib.DEFAULT_GATHER_MODE)
+    import ctypes
+    o = built_lib.RasterOpts()
+    lib.sgn_raster_default_opts(ctypes.byref(o))                  # options travel with each call: no setters
+    assert (o.exact_exp, o.reduce_mode, o.gather, o.waves_per_tile, o.adapt_fwd, o.adapt_bwd, o.batch_fwd,
+            o.batch_bwd, o.xcd_swizzle, o.debug_flags) == (0, 1, 1, 0, 3072, 1536, 256, 128, 0, 0)
+    assert lib.sgn_raster_workspace_bytes(5, 10, None) == 5 * 48  # NULL = defaults: per-Gaussian rows only
+    o.gather = 0
+    assert lib.sgn_raster_workspace_bytes(5, 10, ctypes.byref(o)) == 15 * 48   # + depth-ordered record stream
+    assert not [n for n in built_lib.SIGNATURES if n.startswith("sgn_set_")]   # the library has no global switches
+    with built_lib.options(exact_exp=1) as priv:                  # host-side options are context-local
+        assert built_lib.opts() is priv and priv.exact_exp == 1
+    assert built_lib.opts().exact_exp == 0
     assert lib.sgn_scan_workspace_bytes(5000) >= 12
 
 

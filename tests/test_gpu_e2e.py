@@ -90,14 +90,14 @@ def test_c2_size_binning_properties_and_exact_forward(c_oracle):
         rgbs = torch.clamp(ops.spherical_harmonics(3, dirs, coeffs) + 0.5, min=0.0)
         opac = torch.sigmoid(P["opacity_logits"])
         bg = torch.tensor([0.05, 0.1, 0.15], device=DEV)
-        L.load().sgn_set_exact_exp(1)
+        L.set_options(exact_exp=1)
         c_oracle.set_exp_mode(1)
         try:
             img, alpha = ops.rasterize_gaussians(xys, depths, radii, conics, nth, rgbs, opac, H, W, 16, bg, True)
             e_img, e_T, e_idx = c_oracle.raster_fwd(H, W, 16, vs.cpu(), bins.cpu(), xys.cpu(), conics.cpu(),
                                                     rgbs.cpu(), opac.cpu(), bg.cpu())
         finally:
-            L.load().sgn_set_exact_exp(0)
+            L.set_options(exact_exp=0)
             c_oracle.set_exp_mode(0)
         assert torch.equal(img.cpu(), e_img)
         assert torch.equal(alpha.cpu(), 1 - e_T)
@@ -131,7 +131,7 @@ def test_tile_culling_does_not_change_results():
     cam, raw = scenes.make_scene("c1")
     P = _to_dev(cam, raw)
     w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
-    L.load().sgn_set_exact_exp(1)
+    L.set_options(exact_exp=1)
     try:
         res = {}
         for cull in (False, True):
@@ -142,7 +142,7 @@ def test_tile_culling_does_not_change_results():
                          {k: v.grad.clone() for k, v in P.items()})
     finally:
         ops.tile_culling_enabled = True
-        L.load().sgn_set_exact_exp(0)
+        L.set_options(exact_exp=0)
         ops.clear_binning_cache()
     for a, b in zip(res[False][:3], res[True][:3]):
         assert torch.equal(a, b)

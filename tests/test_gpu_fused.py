@@ -147,7 +147,7 @@ def test_id_range_pass_equals_sliced_pass(batch):
     """A sub-model pass given as (full tensors, id_range) == the reference's way (slice, re-bin, render), forward
     and backward, with the long-list LDS path forced on and off."""
     from sgn_rast import _lib as L, fused, ops, scenes, step
-    L.load().sgn_set_batch_thresholds(*((24, 24) if batch else (1 << 30, 1 << 30)))
+    L.set_options(batch_fwd=24 if batch else 1 << 30, batch_bwd=24 if batch else 1 << 30)
     try:
         cam, raw = scenes.make_scene("c1", seed=5, device=DEV, n_override=4000)
         P = step.leaf_params(raw)
@@ -183,4 +183,76 @@ def test_id_range_pass_equals_sliced_pass(batch):
         for x, y in zip(res[0][2:], res[1][2:]):
             assert rel_l2(x, y) < 1e-5
     finally:
-        L.load().sgn_set_batch_thresholds(256, 128)
+        L.set_options(batch_fwd=256, batch_bwd=128)
+
+
+@pytest.mark.parametrize("gather", [1, 0])
+def test_window_copies_reuse_the_cached_binning(gather):
+    """Drop-in scene-graph path: the sub-model passes receive torch.cat COPIES of per-model slices of the main
+    projection (sgn_splatfacto_scene_graph.py:270-276).  The shim recognises them by content as the head / tail window
+    of the cached scene and rasterizes over the cached depth list: bit-identical image and alpha to the re-binned
+    call, equal gradients (sized like the window), no new binning; anything else falls back to re-binning."""
+    from sgn_rast import _lib as L, ops, scenes, step
+    with L.options(gather=gather):
+        cam, raw = scenes.make_scene("c1", seed=5, device=DEV, n_override=4000)
+        counts = [2500, 700, 800]
+        with torch.no_grad():
+            scales = torch.exp(raw["log_scales"])
+            quats = raw["quats"] / raw["quats"].norm(dim=-1, keepdim=True)
+            xys, depths, radii, conics, _c, nth, _ = ops.project_gaussians(
+                raw["means"], scales, 1, quats, cam.viewmat[:3, :], cam.fx, cam.fy, cam.cx, cam.cy, cam.height,
+                cam.width, 16)
+            opac = torch.sigmoid(raw["opacity_logits"])
+        g = torch.Generator().manual_seed(3)
+        rgbs = torch.rand(4000, 3, generator=g).to(DEV)
+        w_img, w_a = step.loss_weights(cam, seed=9, device=DEV)
+        bg = torch.tensor([0.2, 0.1, 0.3], device=DEV)
+        recat = lambda t: torch.concat(torch.split(t, counts), dim=0)          # the scene graph's setters
+        main = [recat(t) for t in (xys, depths, radii, conics, nth)]
+        calls = {"n": 0}
+        orig = ops._bin_prepare_async
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return orig(*a, **k)
+
+        ops._bin_prepare_async = counting
+        try:
+            for lo, hi in ((0, 2500), (2500, 4000)):                            # background, then all objects
+                res = []
+                for enabled in (True, False):
+                    ops.window_matching_enabled = enabled
+                    ops.clear_binning_cache()
+                    ops.rasterize_gaussians(*main, rgbs, opac, cam.height, cam.width, 16, bg, True)   # main pass
+                    n_before = calls["n"]
+                    sub = [torch.cat([p for p in torch.split(t, counts)][(0 if lo == 0 else 1):(1 if lo == 0 else 3)])
+                           for t in (xys, depths, radii, conics, nth)]
+                    leaves = [sub[0].clone().requires_grad_(True), sub[3].clone().requires_grad_(True),
+                              rgbs[lo:hi].clone().requires_grad_(True), opac[lo:hi].clone().requires_grad_(True)]
+                    # cloned leaves: new tensors with the window's bytes, like the reference's copies
+                    img, a = ops.rasterize_gaussians(leaves[0], sub[1], sub[2], leaves[1], sub[4], leaves[2], leaves[3],
+                                                     cam.height, cam.width, 16, bg, True)
+                    assert calls["n"] == (n_before if enabled else n_before + 1)
+                    ((img * w_img).sum() + (a * w_a).sum()).backward()
+                    res.append((img.detach(), a.detach()) + tuple(l.grad.clone() for l in leaves))
+                assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+                for x, y in zip(res[0][2:], res[1][2:]):
+                    assert x.shape == y.shape and rel_l2(x, y) < 1e-5
+                    assert float(y.abs().sum()) > 0
+            # not a window of the cached scene (one value changed): silently re-binned, same result as without matching
+            ops.window_matching_enabled = True
+            ops.clear_binning_cache()
+            ops.rasterize_gaussians(*main, rgbs, opac, cam.height, cam.width, 16, bg, True)
+            n_before = calls["n"]
+            sub = [t[:2500].clone() for t in (xys, depths, radii, conics, nth)]
+            sub[0][7, 0] += 1.0
+            img_m, _ = ops.rasterize_gaussians(*sub, rgbs[:2500], opac[:2500], cam.height, cam.width, 16, bg, True)
+            assert calls["n"] == n_before + 1
+            ops.window_matching_enabled = False
+            ops.clear_binning_cache()
+            img_r, _ = ops.rasterize_gaussians(*sub, rgbs[:2500], opac[:2500], cam.height, cam.width, 16, bg, True)
+            assert torch.equal(img_m, img_r)
+        finally:
+            ops._bin_prepare_async = orig
+            ops.window_matching_enabled = True
+            ops.clear_binning_cache()

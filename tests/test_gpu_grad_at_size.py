@@ -56,15 +56,13 @@ def _hip_step(cam, raw, w_img, w_a):
 def production_defaults():
     """These tests are about the DEFAULT kernel configuration: assert nothing left a switch flipped."""
     from sgn_rast import _lib as L
-    lib = L.load()
-    lib.sgn_set_exact_exp(0)
-    lib.sgn_set_gather_mode(L.DEFAULT_GATHER_MODE)
-    lib.sgn_set_waves_per_tile(0)
-    lib.sgn_set_adaptive_thresholds(3072, 1536)
-    lib.sgn_set_batch_thresholds(256, 128)
-    lib.sgn_set_reduce_mode(1)
-    yield lib
-    lib.sgn_set_reduce_mode(1)
+    L.load()
+    L.reset_options()
+    o = L.opts()
+    assert (o.exact_exp, o.reduce_mode, o.gather, o.waves_per_tile) == (0, 1, 1, 0)
+    assert (o.adapt_fwd, o.adapt_bwd, o.batch_fwd, o.batch_bwd) == (3072, 1536, 256, 128)
+    yield L
+    L.reset_options()
 
 
 @pytest.mark.parametrize("name", ["c2", "metric", "street"])
@@ -112,7 +110,7 @@ def test_train_step_gradients_match_oracle_at_size(name, production_defaults):
         oracle_ops.PIXEL_ROWS = None
 
     for reduce_mode in (1, 0):
-        lib.sgn_set_reduce_mode(reduce_mode)
+        lib.set_options(reduce_mode=reduce_mode)
         Pd, got = _hip_step(cam, raw, w_img, w_a)
         # The library's projection is bit-exact on identical inputs (test_project_forward_bit_exact; at this size:
         # profiles/scripts/diag_street_projection.py, 0 differing rows of 1 M).  Here the reference's own glue
@@ -133,7 +131,7 @@ def test_train_step_gradients_match_oracle_at_size(name, production_defaults):
             r = rel_l2(Pd[k].grad.cpu(), Pc[k].grad)
             assert r < 1e-4, (name, k, reduce_mode, r)
             assert float(Pc[k].grad.abs().sum()) > 0, k
-    lib.sgn_set_reduce_mode(1)
+    lib.set_options(reduce_mode=1)
 
 
 def test_raster_backward_alone_matches_oracle_at_metric_size(production_defaults):
@@ -170,7 +168,7 @@ def test_raster_backward_alone_matches_oracle_at_metric_size(production_defaults
         ops.set_alpha_clamp_bwd(clamp)
         try:
             for reduce_mode in (1, 0):
-                lib.sgn_set_reduce_mode(reduce_mode)
+                lib.set_options(reduce_mode=reduce_mode)
                 leaves = [t.detach().clone().requires_grad_(True) for t in (xys, conics, rgbs, opac)]
                 img, alpha = ops.rasterize_gaussians(leaves[0], depths, radii, leaves[1], nth, leaves[2], leaves[3],
                                                      H, W, 16, bg.to(DEV), True)
@@ -182,4 +180,4 @@ def test_raster_backward_alone_matches_oracle_at_metric_size(production_defaults
                     assert r < 1e-4, (nm, clamp, reduce_mode, r)
         finally:
             ops.set_alpha_clamp_bwd(0.99)
-            lib.sgn_set_reduce_mode(1)
+            lib.set_options(reduce_mode=1)

@@ -28,16 +28,13 @@ def raster_record_mode(request):
     long-list path forced on or off."""
     from sgn_rast import _lib as L
     gather, wpt, batch = request.param
-    L.load().sgn_set_batch_thresholds(*((24, 24) if batch else (1 << 30, 1 << 30)))  # force / forbid the LDS path
-    L.load().sgn_set_gather_mode(gather)
-    L.load().sgn_set_waves_per_tile(wpt)
+    thr = (24, 24) if batch else (1 << 30, 1 << 30)                  # force / forbid the LDS path
+    kw = dict(batch_fwd=thr[0], batch_bwd=thr[1], gather=gather, waves_per_tile=wpt)
     if wpt == 0:
-        L.load().sgn_set_adaptive_thresholds(96, 48)   # small scenes: make some tiles split, others not
-    yield request.param
-    L.load().sgn_set_gather_mode(L.DEFAULT_GATHER_MODE)
-    L.load().sgn_set_waves_per_tile(0)
-    L.load().sgn_set_adaptive_thresholds(3072, 1536)
-    L.load().sgn_set_batch_thresholds(256, 128)
+        kw.update(adapt_fwd=96, adapt_bwd=48)                        # small scenes: make some tiles split, others not
+    L.load()
+    with L.options(**kw):
+        yield request.param
 
 
 def _project_args(cam, P, block=16, dev="cpu"):
@@ -273,7 +270,7 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
     R = _raster_inputs(c_oracle, cam, P, block)
     bg = torch.tensor([0.1, 0.2, 0.3])
     c_oracle.set_exp_mode(1)
-    L.load().sgn_set_exact_exp(1)
+    L.set_options(exact_exp=1)
     try:
         exp_img, exp_T, exp_idx = c_oracle.raster_fwd(cam.height, cam.width, block, R["ids"], R["bins"], R["xys"],
                                                       R["conics"], R["rgb"], R["opac"], bg)
@@ -296,7 +293,7 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
         assert torch.equal(out_img.cpu(), exp_img)
     finally:
         c_oracle.set_exp_mode(0)
-        L.load().sgn_set_exact_exp(0)
+        L.set_options(exact_exp=0)
 
 
 @pytest.mark.parametrize("block,size", [(16, (128, 128)), (16, (130, 70)), (8, (100, 60))])
@@ -304,7 +301,7 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
 @pytest.mark.parametrize("reduce_mode", [0, 1])
 def test_rasterize_backward(hip, c_oracle, block, size, clamp, reduce_mode):
     from sgn_rast import _lib as L, ops
-    L.load().sgn_set_reduce_mode(reduce_mode)   # 0: butterfly shuffles, 1: transposed permlane-swap reduction
+    L.set_options(reduce_mode=reduce_mode)   # 0: butterfly shuffles, 1: transposed permlane-swap reduction
     cam, P = small_scene(n=3000, w=size[0], h=size[1], focal=float(size[0]))
     P["opacity_logits"][:200] = 9.0   # opacity ~0.9999: exercises the 0.999 (fwd) / 0.99 (bwd) clamps
     R = _raster_inputs(c_oracle, cam, P, block)
@@ -315,7 +312,7 @@ def test_rasterize_backward(hip, c_oracle, block, size, clamp, reduce_mode):
         torch.autograd.backward([img, alpha], [d["v_img"], d["v_alpha"]])
     finally:
         ops.set_alpha_clamp_bwd(ops.UPSTREAM_ALPHA_CLAMP_BWD)
-        L.load().sgn_set_reduce_mode(L.DEFAULT_REDUCE_MODE)
+        L.set_options(reduce_mode=1)
     # oracle backward from the oracle's own forward state
     exp_img, exp_T, exp_idx = c_oracle.raster_fwd(cam.height, cam.width, block, R["ids"], R["bins"], R["xys"],
                                                   R["conics"], R["rgb"], R["opac"], bg)
