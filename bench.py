@@ -50,6 +50,10 @@ def parse():
     ap.add_argument("--path", default="dropin", choices=["dropin", "fused"],
                     help="dropin: gsplat-shaped ops + the reference's torch glue (headline); fused: sgn_rast.fused")
     ap.add_argument("--no-fused-extra", action="store_true", help="skip the extra fused-path measurement")
+    ap.add_argument("--caller-syncs", action="store_true",
+                    help="also replay the two host syncs of the reference's own model code per pass "
+                         "(sgn_splatfacto.py:878 `radii.sum() == 0`, :944 `assert (num_tiles_hit > 0).any()`); the "
+                         "scene-graph step always does")
     ap.add_argument("--street", action="store_true",
                     help="non-uniform 'street' content (empty sky, ground, facades, dense low-opacity clusters) at the "
                          "scene's N and resolution: load-balance profiling, not the headline metric")
@@ -282,10 +286,10 @@ def main():
         if sky is not None:
             adam.append(optim.FusedAdam([sky["base"]], lr=0.01, eps=1e-15))
 
-    def one_step(fused=(args.path == "fused")):
+    def one_step(fused=(args.path == "fused"), caller_syncs=args.caller_syncs):
         if sg is None:
             out = step.train_step(P, cam, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer,
-                                  fused=fused, sky=sky, gt=gt_img)
+                                  fused=fused, sky=sky, gt=gt_img, caller_syncs=caller_syncs)
             if adam is not None:
                 optim.step_many(adam)
             return out
@@ -339,6 +343,20 @@ def main():
         fused_extra = {"value": world * args.steps / dtf, "unit": "images/sec", "ms_per_step": 1e3 * dtf / args.steps,
                        "note": "same inputs/outputs through sgn_rast.fused (activations, view dirs, SH concat, "
                                "sigmoid folded into the kernels); not the drop-in call path"}
+
+    # the same drop-in step with the two host syncs the reference's model code makes around the operators
+    sync_extra = None
+    if args.path == "dropin" and sg is None and not args.caller_syncs and not args.no_fused_extra:
+        for _ in range(max(2, args.warmup // 2)):
+            one_step(caller_syncs=True)
+        barrier(); torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step(caller_syncs=True)
+        torch.cuda.synchronize(); barrier()
+        dts = time.perf_counter() - ts0
+        sync_extra = {"value": world * args.steps / dts, "unit": "images/sec", "ms_per_step": 1e3 * dts / args.steps,
+                      "note": "drop-in path plus the reference model's own host syncs (sgn_splatfacto.py:878, :944)"}
 
     # per-kernel HIP-event spans (library brackets each launch on its own stream), separate short pass
     L.timing_enable(True)
@@ -407,6 +425,8 @@ def main():
             line["config"]["workload"] += "; + multi-tensor Adam step over all parameter groups"
         if fused_extra is not None:
             line["fused_path"] = fused_extra
+        if sync_extra is not None:
+            line["with_caller_syncs"] = sync_extra
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline_bounded(args)

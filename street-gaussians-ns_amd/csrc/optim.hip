@@ -93,11 +93,15 @@ SGN_EXPORT int sgn_adam_step(int count, float *const *params, const float *const
     SGN_ARG_CHECK(params && grads && exp_avgs && exp_avg_sqs && numel && lr && beta1 && beta2 && eps && steps, -2);
     hipStream_t s = (hipStream_t)stream;
     sgn_timing_begin(SGN_T_ADAM, (void *)s);
-    for (int first = 0; first < count; first += ADAM_MAX_TENSORS) {
+    // `i` is consumed ACROSS launches: empty tensors are skipped without taking a table slot, so a launch may
+    // consume more than ADAM_MAX_TENSORS input rows — restarting the next launch at first + ADAM_MAX_TENSORS stepped
+    // some rows twice (advisor finding, round 1).
+    int i = 0;
+    while (i < count) {
         AdamTable T;
         T.count = 0;
         int blocks = 0;
-        for (int i = first; i < count && T.count < ADAM_MAX_TENSORS; ++i) {
+        for (; i < count && T.count < ADAM_MAX_TENSORS; ++i) {
             SGN_ARG_CHECK(numel[i] >= 0 && steps[i] >= 1, -3);
             if (numel[i] == 0) continue;
             SGN_ARG_CHECK(params[i] && grads[i] && exp_avgs[i] && exp_avg_sqs[i], -4);

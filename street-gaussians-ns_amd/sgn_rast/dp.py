@@ -8,9 +8,8 @@ CPU tests).  Parameters are replicated; rank ``r`` renders camera ``perm[world*s
 seed-synchronised permutation (replaces the ``random.randint`` pop at
 ``sgn_datamanager.py:281``); the only exchange step is a SUM all-reduce of the per-Gaussian
 gradients (59 floats = 236 B per Gaussian at SH degree 3).  xGMI is point-to-point, so a ring
-all-reduce is per-link bound: the big SH gradient (192 of the 236 B) is reduced *as soon as its
-autograd node finishes*, overlapping ``project_gaussians`` backward; the four small tensors go
-out as one flat bucket after backward.  Densification statistics are reduced (SUM/SUM/MAX) so
+all-reduce is per-link bound: big tensors get an all-reduce of their own, the small ones go out as
+one flat bucket, all asynchronous and issued after backward in one fixed order on every rank.  Densification statistics are reduced (SUM/SUM/MAX) so
 replicas take bit-identical split/dup/cull decisions.
 
 Optionally (``SHGradExchange``) the SH gradient is not all-reduced at all: its low-rank factors (3-float colour
@@ -59,12 +58,17 @@ def view_for_rank(step: int, rank: int, world: int, n_views: int, seed: int = 0)
 
 
 class GradAllReducer:
-    """Bucketed, overlapped all-reduce of per-Gaussian gradients.
+    """Bucketed all-reduce of per-Gaussian gradients, issued from :meth:`finish` in ONE FIXED ORDER.
 
-    ``big`` parameters (the SH coefficients) get a post-accumulate-grad hook that launches an
-    async all-reduce the moment their gradient is final; everything else is flattened into one
-    bucket in :meth:`finish`.  ``average=True`` divides by world size (the loss is a per-image
-    mean, so DP over views averages)."""
+    Every rank makes the same collective calls in the same sequence by construction — the low-rank exchange's
+    all-gathers, then one all-reduce per ``big`` parameter (in ``params`` order), then the flat bucket of everything
+    else — whatever its own backward did: a parameter that received no gradient on this rank (its view saw nothing)
+    takes part with zeros.  (Round 1 launched the big all-reduces and the exchange's all-gathers from autograd hooks
+    as their gradients became final; the order then depended on each rank's autograd graph — a rank whose sky or SH
+    node ran in a different order, or not at all, issued a different sequence, which hangs or corrupts NCCL.  The
+    overlap that bought was the ~0.05 ms of `project_gaussians` backward.)  All calls are asynchronous: the bucket
+    travels while the exchange rebuilds the dense SH gradient.  ``average=True`` divides by world size (the loss is a
+    per-image mean, so DP over views averages)."""
 
     def __init__(self, params: Sequence[torch.Tensor], big: Iterable[torch.Tensor] = (),
                  average: bool = True, group=None, sh_exchange: "Optional[SHGradExchange]" = None,
@@ -77,41 +81,25 @@ class GradAllReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())   # force: run the collectives at world 1
-        self._pending: List = []
-        self._handles = []
-        if self.active:
-            for p in self.params:
-                if id(p) in self.big_ids:
-                    self._handles.append(p.register_post_accumulate_grad_hook(self._hook))
-
-    def _hook(self, p: torch.Tensor) -> None:
-        work = dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._pending.append((work, p))
 
     def finish(self) -> None:
-        """Call after ``loss.backward()``: reduces the small bucket, waits for the async ones.  The bucket's
-        all-reduce is launched first and runs on the collective stream while the SH exchange rebuilds the dense SH
-        gradient on the compute stream."""
-        small, flat, work = [], None, None
+        """Call after ``loss.backward()``."""
+        pending, small, flat, work = [], [], None, None
         if self.sh_exchange is not None:
-            self.sh_exchange.start_if_silent()      # its all-gathers come first on every rank (the taps fire in backward)
+            self.sh_exchange.start()                     # 1. all-gathers of the low-rank factors
         if self.active:
-            # every rank must make the same collective calls in the same order: a parameter that received no gradient
-            # on this rank (its view saw nothing) takes part with zeros, and a "big" one whose hook therefore never
-            # fired is reduced here, before the bucket, where the other ranks' hooks put it
-            pending_ids = {id(p) for _w, p in self._pending}
             for p in self.params:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
-                if id(p) in self.big_ids and id(p) not in pending_ids:
-                    self._pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group,
-                                                          async_op=True), p))
+            for p in self.params:                        # 2. big tensors, one all-reduce each, in params order
+                if id(p) in self.big_ids:
+                    pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True), p))
             small = [p for p in self.params if id(p) not in self.big_ids]
-            if small:
+            if small:                                    # 3. everything else as one flat bucket
                 flat = torch.cat([p.grad.reshape(-1) for p in small])
                 work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.sh_exchange is not None:
-            self.sh_exchange.finish()
+            self.sh_exchange.finish()                    # 4. rebuild (overlaps 2-3) or dense fallback
         if not self.active:
             return
         if work is not None:
@@ -123,16 +111,13 @@ class GradAllReducer:
                 n = p.grad.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
-        for work, p in self._pending:
-            work.wait()
+        for w, p in pending:
+            w.wait()
             if self.average:
                 p.grad /= self.world
-        self._pending.clear()
 
     def remove(self) -> None:
-        for h in self._handles:
-            h.remove()
-        self._handles.clear()
+        """Kept for callers of the round-1 API (there are no hooks to remove any more)."""
 
 
 def _sh_multi_hip(degree, k, dirs_all, means, cam_all, object_ids, poses, v_all, scale):
@@ -152,12 +137,29 @@ class SHGradExchange:
     """Low-rank exchange of the SH-coefficient gradient (192 of the 236 B/Gaussian).
 
     One view's SH gradient is ``basis(viewdir)[k] * v_rgb[c]``: ranks all-gather the 3-float colour gradient
-    plus either the view directions (drop-in ops: 24 B/Gaussian/rank) or just the camera position (fused ops:
-    12 B/Gaussian/rank) and rebuild the SUMMED dense gradient locally (``sgn_sh_bwd_multi``), instead of
-    all-reducing 192 B/Gaussian.  On the point-to-point xGMI mesh that is 2x / 4x fewer bytes per link.
-    Install once; it taps the SH backward, starts the all-gathers as soon as the colour gradient exists
-    (overlapping the rest of backward) and :meth:`finish` (called by ``GradAllReducer.finish``) overwrites the
-    leaf gradients of ``features_dc`` / ``features_rest`` with the cross-rank result."""
+    plus either the view directions (drop-in ops: 24 B/Gaussian/rank) or just the camera position (fused ops, or
+    drop-in ops after :meth:`set_view`: 12 B/Gaussian/rank) and rebuild the SUMMED dense gradient locally
+    (``sgn_sh_bwd_multi``), instead of all-reducing 192 B/Gaussian.  On the point-to-point xGMI mesh that is 2x / 4x
+    fewer bytes per link.
+
+    What the exchange may take over — and what it must not.  The SH backward "taps" in (``ops._sh_exchange`` /
+    ``fused._sh_exchange``).  A tap is CLAIMED only when the node's coefficients are provably the two registered
+    leaves and nothing rank-specific sits between them and the colours:
+
+    * drop-in ops: ``coeffs`` is literally ``torch.cat((features_dc, features_rest), dim=1)`` of the leaves (checked on
+      the autograd graph), i.e. the static single-model step (``sgn_splatfacto.py:858``);
+    * fused ops: ``features_dc`` / ``features_rest`` ARE the leaves and there is no per-object pose table, object-id
+      table or Fourier weighting (those differ per rank in view-parallel training: each rank renders another camera
+      and time, so one pose table cannot serve all gathered views — advisor finding, round 1).
+
+    A claimed node skips its local dense backward (its result would be replaced by the cross-rank sum).  Every other
+    SH node runs its ordinary dense backward into ``leaf.grad``; if any such node ran, :meth:`finish` all-reduces
+    those dense leaf gradients as well and adds the exchange's result — correct for any graph, just not cheaper.
+    A step in which only unclaimed nodes ran (scene graph, Fourier DC) is therefore a plain dense all-reduce.
+    The taps only RECORD; all collectives are issued from :meth:`start` / :meth:`finish`, which
+    ``GradAllReducer.finish`` calls at a fixed position on every rank.  A rank whose SH backward never ran (its view
+    saw no Gaussian) joins with zeros, taking the step's shape from the previous step (layouts are static across
+    steps; call :meth:`set_view` so it also has current means)."""
 
     def __init__(self, features_dc: torch.Tensor, features_rest: torch.Tensor, average: bool = True, group=None,
                  multi_fn=_sh_multi_hip, force: bool = False):
@@ -165,8 +167,10 @@ class SHGradExchange:
         self.average, self.group, self.multi_fn = average, group, multi_fn
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())  # force: exercise the path at world 1
-        self._stash = None
-        self._last = None        # layout of the last exchange (kind, degree, K, means, object ids ...), see finish()
+        self._claimed = None     # factors recorded by the claimed tap of this step
+        self._unclaimed = False  # an SH node that the exchange did not take over ran this step
+        self._started = None     # state between start() and finish()
+        self._last = None        # shape of the last step: kind, degree, K, mixed
         self._works = []
         self._view = None
 
@@ -183,15 +187,60 @@ class SHGradExchange:
 
     def install(self) -> "SHGradExchange":
         from . import fused, ops
-        ops._sh_bwd_tap = self._tap_dirs
-        fused._sh_bwd_tap = self._tap_fused
+        ops._sh_exchange = self
+        fused._sh_exchange = self
         return self
 
     def remove(self) -> None:
         from . import fused, ops
-        ops._sh_bwd_tap = None
-        fused._sh_bwd_tap = None
+        ops._sh_exchange = None
+        fused._sh_exchange = None
 
+    # ------------------------------------------------------------------ claims (forward time, host only)
+    def claims_coeffs(self, coeffs: torch.Tensor) -> bool:
+        """Is ``coeffs`` exactly ``torch.cat((features_dc, features_rest), dim=1)`` of the registered leaves?"""
+        if not self.active or self.dc.shape[1] != 1:
+            return False
+        fn = coeffs.grad_fn
+        if fn is None or type(fn).__name__ != "CatBackward0" or getattr(fn, "_saved_dim", 1) != 1:
+            return False
+        nxt = fn.next_functions
+        return len(nxt) == 2 and all(getattr(f[0], "variable", None) is leaf
+                                     for f, leaf in zip(nxt, (self.dc, self.rest)))
+
+    def claims_leaves(self, features_dc, features_rest, object_ids, poses, idft) -> bool:
+        if not self.active or features_dc is not self.dc or features_rest is not self.rest:
+            return False
+        return object_ids is None and poses is None and self.dc.shape[1] == 1
+
+    # ------------------------------------------------------------------ taps (backward time; record only)
+    def tap_dirs(self, viewdirs, v_colors, degree, k, claimed: bool) -> bool:
+        """Drop-in SH backward.  True = the exchange takes this node's gradient over (caller skips its dense kernel)."""
+        if not self.active:
+            return False
+        if not claimed or self._claimed is not None:
+            self._unclaimed = True
+            return False
+        if self._view is not None and self._view[0].shape[0] == v_colors.shape[0]:
+            means, cam_pos = self._view
+            cam_pos = cam_pos.detach().reshape(3).to(v_colors.device, torch.float32)
+            self._claimed = dict(kind="cam", degree=degree, k=k, v=v_colors, cam=cam_pos,
+                                 means=means.detach().contiguous())
+        else:
+            self._claimed = dict(kind="dirs", degree=degree, k=k, v=v_colors, dirs=viewdirs)
+        return True
+
+    def tap_fused(self, means, cam_pos, v_eff, degree, k, claimed: bool) -> bool:
+        if not self.active:
+            return False
+        if not claimed or self._claimed is not None:
+            self._unclaimed = True
+            return False
+        self._claimed = dict(kind="cam", degree=degree, k=k, v=v_eff,
+                             cam=cam_pos.detach().reshape(3).to(v_eff.device, torch.float32), means=means)
+        return True
+
+    # ------------------------------------------------------------------ collectives (fixed position on every rank)
     def _gather(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
@@ -203,85 +252,77 @@ class SHGradExchange:
         self._works.append(w)
         return out
 
-    def _tap_dirs(self, viewdirs, v_colors, degree, k):
-        """Returns True when the exchange takes the SH gradient over: the caller then skips its own dense backward
-        (the local [N,K,3] gradient would be overwritten by the cross-rank sum anyway)."""
-        if not self.active:
-            return False
-        if self._view is not None and self._view[0].shape[0] == v_colors.shape[0]:
-            means, cam_pos = self._view
-            cam_pos = cam_pos.detach().reshape(3).to(v_colors.device, torch.float32)
-            self._stash = dict(kind="cam", degree=degree, k=k, v_all=self._gather(v_colors),
-                               cam_all=self._gather(cam_pos), means=means.detach().contiguous(), object_ids=None,
-                               poses=None, idft=None, keep=(v_colors, cam_pos))
-            return True
-        self._stash = dict(kind="dirs", degree=degree, k=k, v_all=self._gather(v_colors),
-                           dirs_all=self._gather(viewdirs), keep=(viewdirs, v_colors))
-        return True
-
-    def _tap_fused(self, means, cam_pos, v_eff, degree, k, object_ids, poses, idft):
-        if not self.active:
-            return False
-        self._stash = dict(kind="cam", degree=degree, k=k, v_all=self._gather(v_eff), cam_all=self._gather(cam_pos),
-                           means=means, object_ids=object_ids, poses=poses, idft=idft, keep=(v_eff, cam_pos))
-        return True
-
-    def _participate_empty(self) -> None:
-        """This rank's SH backward never ran this step (its view saw no Gaussian, so no colour gradient exists):
-        the other ranks are already inside the all-gathers, so join them with a zero colour gradient — every rank
-        must make the same collective calls — using what the last tap told us about the layout."""
-        last = self._last
-        if last is None:
-            raise RuntimeError("SHGradExchange: the SH backward did not run on this rank and no earlier step is "
-                               "known to take the layout from; the other ranks are waiting in all_gather")
-        n = self.dc.shape[0]
-        zeros = torch.zeros(n, 3, dtype=torch.float32, device=self.dc.device)
-        if last["kind"] == "dirs":
-            self._stash = dict(last, v_all=self._gather(zeros), dirs_all=self._gather(zeros + 1.0), keep=(zeros,))
-        else:
-            cam = (self._view[1] if self._view is not None else last["cam_pos"]).detach().reshape(3).to(
-                zeros.device, torch.float32)
-            self._stash = dict(last, v_all=self._gather(zeros), cam_all=self._gather(cam), keep=(zeros, cam))
-
-    def start_if_silent(self) -> None:
-        """Issue this step's all-gathers now if the SH backward never tapped in (see _participate_empty)."""
-        if self.active and self._stash is None:
-            self._participate_empty()
+    def start(self) -> None:
+        """Issue this step's all-gathers (if the step has a claimed node on ANY rank)."""
+        if not self.active or self._started is not None:
+            return
+        c, mixed = self._claimed, self._unclaimed
+        if c is None and not self._unclaimed:
+            # this rank's SH backward never ran (its view saw no Gaussian): the other ranks are making the calls of
+            # an ordinary step, so make the same ones with a zero colour gradient, shaped like the previous step
+            last = self._last
+            if last is None:
+                raise RuntimeError("SHGradExchange: the SH backward did not run on this rank and no earlier step is "
+                                   "known to take the shape of the exchange from; the other ranks are waiting")
+            mixed = last["mixed"]
+            if last["kind"] != "dense":
+                n = self.dc.shape[0]
+                zeros = torch.zeros(n, 3, dtype=torch.float32, device=self.dc.device)
+                c = dict(kind=last["kind"], degree=last["degree"], k=last["k"], v=zeros)
+                if last["kind"] == "dirs":
+                    c["dirs"] = zeros + 1.0
+                else:
+                    if self._view is None:
+                        raise RuntimeError("SHGradExchange: a rank without SH backward needs set_view(means, cam_pos) "
+                                           "to join a camera-position exchange with current means")
+                    c["means"] = self._view[0].detach().contiguous()
+                    c["cam"] = self._view[1].detach().reshape(3).to(zeros.device, torch.float32)
+        st = dict(kind="dense" if c is None else c["kind"], mixed=bool(mixed) or c is None, c=c)
+        if c is not None:
+            st["v_all"] = self._gather(c["v"])
+            st["x_all"] = self._gather(c["dirs"] if c["kind"] == "dirs" else c["cam"])
+        self._started = st
+        self._claimed, self._unclaimed = None, False
 
     def finish(self) -> None:
         if not self.active:
             return
-        self.start_if_silent()
-        self._last = {k: v for k, v in self._stash.items() if k not in ("v_all", "dirs_all", "cam_all", "keep")}
-        if self._stash["kind"] == "cam":
-            self._last["cam_pos"] = self._stash["keep"][-1]
+        self.start()
+        st, self._started = self._started, None
+        c = st["c"]
+        self._last = dict(kind=st["kind"], mixed=st["mixed"], degree=None if c is None else c["degree"],
+                          k=None if c is None else c["k"])
+        scale = 1.0 / self.world if self.average else 1.0
+        dense = []
+        if st["mixed"]:     # SH nodes the exchange did not take over left dense gradients in the leaves: reduce those
+            for leaf in (self.dc, self.rest):
+                if leaf.grad is None:
+                    leaf.grad = torch.zeros_like(leaf)
+                dense.append(dist.all_reduce(leaf.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in self._works:
             w.wait()
         self._works.clear()
-        s, self._stash = self._stash, None
-        scale = 1.0 / self.world if self.average else 1.0
-        if s["kind"] == "dirs":
-            v = self.multi_fn(s["degree"], s["k"], s["dirs_all"], None, None, None, None, s["v_all"], scale)
-        else:
-            v = self.multi_fn(s["degree"], s["k"], None, s["means"], s["cam_all"], s["object_ids"], s["poses"],
-                              s["v_all"], scale)
-        if isinstance(v, tuple):                       # already split into the two leaves (HIP path)
-            v0, v_rest = v
-        else:                                          # dense [N,K,3] (the torch stand-in used by the gloo tests)
-            v0, v_rest = v[:, 0:1, :], v[:, 1:, :]
-        F = self.dc.shape[1]
-        if F == 1:
-            dc_grad = v0
-        else:  # Fourier DC: d dc_eff / d features_dc[:, f] = idft[object, f]
-            idft, oid = s["idft"], s["object_ids"]
-            w = idft[oid.long()] if oid is not None else idft[:1].expand(v0.shape[0], F)
-            dc_grad = w[:, :, None] * v0
-        for leaf, g in ((self.dc, dc_grad), (self.rest, v_rest)):
-            g = g if g.is_contiguous() else g.contiguous()
-            if leaf.grad is None:
-                leaf.grad = g if g.shape == leaf.shape else g.reshape(leaf.shape)
+        low = None
+        if c is not None:
+            if c["kind"] == "dirs":
+                v = self.multi_fn(c["degree"], c["k"], st["x_all"], None, None, None, None, st["v_all"], scale)
             else:
-                leaf.grad.copy_(g)
+                v = self.multi_fn(c["degree"], c["k"], None, c["means"], st["x_all"], None, None, st["v_all"], scale)
+            low = v if isinstance(v, tuple) else (v[:, 0:1, :], v[:, 1:, :])   # HIP path: already split per leaf
+        for w in dense:
+            w.wait()
+        for i, leaf in enumerate((self.dc, self.rest)):
+            if st["mixed"] and self.average:
+                leaf.grad /= self.world
+            if low is not None:
+                g = low[i] if low[i].is_contiguous() else low[i].contiguous()
+                g = g if g.shape == leaf.shape else g.reshape(leaf.shape)
+                if st["mixed"]:
+                    leaf.grad += g
+                elif leaf.grad is None:
+                    leaf.grad = g
+                else:
+                    leaf.grad.copy_(g)
 
 
 def sync_densify_stats(xys_grad_norm: torch.Tensor, vis_counts: torch.Tensor, max_2dsize: torch.Tensor,

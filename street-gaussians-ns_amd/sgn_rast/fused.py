@@ -110,9 +110,9 @@ def project_gaussians_fused(means, log_scales, quats_raw, viewmat, fx, fy, cx, c
                                glob_scale)
 
 
-# tap for sgn_rast.dp.SHGradExchange (see ops._sh_bwd_tap); receives
-# (means, cam_pos, v_colors_effective, degree, K, object_ids, poses, idft)
-_sh_bwd_tap = None
+# hook for sgn_rast.dp.SHGradExchange (see ops._sh_exchange): `claims_leaves` at forward time, `tap_fused` (means,
+# cam_pos, effective colour gradient, degree, K) at backward time
+_sh_exchange = None
 
 
 _ONES: dict = {}
@@ -128,8 +128,9 @@ def _ones_row(F: int, dev) -> torch.Tensor:
 
 class _SHFused(Function):
     @staticmethod
-    def forward(ctx, degree, means, cam_pos, features_dc, features_rest, object_ids, idft, poses, post):
+    def forward(ctx, degree, means, cam_pos, features_dc, features_rest, object_ids, idft, poses, post, claimed=False):
         dev = L.require_device(means, cam_pos, features_dc, features_rest, object_ids, idft, poses)
+        ctx.claimed = bool(claimed)
         n, F = features_dc.shape[0], features_dc.shape[1]
         k = 1 + (features_rest.shape[1] if features_rest is not None else 0)
         means_c, cam_c, dc_c = _f32c(means), _f32c(cam_pos).reshape(-1)[:3].contiguous(), _f32c(features_dc)
@@ -159,18 +160,18 @@ class _SHFused(Function):
         pos = saved[5] if ctx.has_pose else None
         degree, k, F, post, has_rest = ctx.meta
         n, dev = means.shape[0], means.device
-        if _sh_bwd_tap is not None:
+        if _sh_exchange is not None:
             v_eff = _f32c(v_colors)
-            if post:
+            if post and ctx.claimed:
                 v_eff = v_eff * (colors > 0)
-            if _sh_bwd_tap(means, cam, v_eff, degree, k, oid, pos, idft):
-                return (None,) * 9       # the data-parallel exchange rebuilds the (summed) gradient itself
+            if _sh_exchange.tap_fused(means, cam, v_eff, degree, k, ctx.claimed):
+                return (None,) * 10      # the data-parallel exchange rebuilds the (summed) gradient itself
         v_dc = torch.empty(n, F, 3, dtype=torch.float32, device=dev)
         v_rest = torch.empty(n, k - 1, 3, dtype=torch.float32, device=dev) if has_rest else None
         L.check(L.load().sgn_sh_bwd_fused(n, k, degree, L.ptr(means), L.ptr(cam), F, L.ptr(oid), L.ptr(idft), L.ptr(pos), post,
                                           L.ptr(colors), L.ptr(_f32c(v_colors)), L.ptr(v_dc), L.ptr(v_rest),
                                           L.stream_ptr()), "sgn_sh_bwd_fused")
-        return None, None, None, v_dc, v_rest, None, None, None, None
+        return None, None, None, v_dc, v_rest, None, None, None, None, None
 
 
 def spherical_harmonics_fused(degrees_to_use: int, means, cam_pos, features_dc, features_rest,
@@ -183,9 +184,11 @@ def spherical_harmonics_fused(degrees_to_use: int, means, cam_pos, features_dc, 
     at sgn_splatfacto.py:934)."""
     k = 1 + (features_rest.shape[1] if features_rest is not None else 0)
     assert k >= (degrees_to_use + 1) ** 2
+    claimed = _sh_exchange is not None and _sh_exchange.claims_leaves(features_dc, features_rest, object_ids, poses,
+                                                                      idft)
     return _SHFused.apply(degrees_to_use, means.detach(), cam_pos, features_dc.contiguous(),
                           None if features_rest is None else features_rest.contiguous(), object_ids, idft, poses,
-                          post_half_clamp)
+                          post_half_clamp, claimed)
 
 
 def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors, opacity_logits, img_height,

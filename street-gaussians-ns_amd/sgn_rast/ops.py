@@ -60,18 +60,19 @@ def deg_from_sh(num_bases: int) -> int:
     assert False, "Invalid number of SH bases"
 
 
-# Optional tap for data-parallel training (sgn_rast.dp.SHGradExchange): called from the SH backward with
-# (viewdirs, v_colors, degrees_to_use, K) so the low-rank factors of the SH gradient can be exchanged
-# instead of the dense [N,K,3] tensor.  None in normal operation.
-_sh_bwd_tap = None
+# Optional hook for data-parallel training (sgn_rast.dp.SHGradExchange).  At forward time the exchange says whether it
+# may take this node's gradient over (`claims_coeffs`: the coefficients are literally torch.cat of its two registered
+# leaves); at backward time `tap_dirs` records the low-rank factors (view directions, colour gradient) so they can be
+# exchanged instead of the dense [N,K,3] tensor.  None in normal operation.
+_sh_exchange = None
 
 
 class _SphericalHarmonics(Function):
     @staticmethod
-    def forward(ctx, degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor):
+    def forward(ctx, degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor, claimed: bool = False):
         L.require_device(viewdirs, coeffs)
         num_points, k = coeffs.shape[0], coeffs.shape[-2]
-        ctx.degrees_to_use, ctx.k = degrees_to_use, k
+        ctx.degrees_to_use, ctx.k, ctx.claimed = degrees_to_use, k, bool(claimed)
         deg_from_sh(k)
         viewdirs = _f32c(viewdirs)
         coeffs_c = _f32c(coeffs)
@@ -86,12 +87,13 @@ class _SphericalHarmonics(Function):
         (viewdirs,) = ctx.saved_tensors
         n = v_colors.shape[0]
         v_colors = _f32c(v_colors)
-        if _sh_bwd_tap is not None and _sh_bwd_tap(viewdirs, v_colors, ctx.degrees_to_use, ctx.k):
-            return None, None, None      # the data-parallel exchange rebuilds the (summed) gradient itself
+        if _sh_exchange is not None and _sh_exchange.tap_dirs(viewdirs, v_colors, ctx.degrees_to_use, ctx.k,
+                                                              ctx.claimed):
+            return None, None, None, None    # the data-parallel exchange rebuilds the (summed) gradient itself
         v_coeffs = torch.empty(n, ctx.k, 3, dtype=torch.float32, device=v_colors.device)
         L.check(L.load().sgn_sh_bwd(n, ctx.k, ctx.degrees_to_use, L.ptr(viewdirs), L.ptr(v_colors),
                                     L.ptr(v_coeffs), L.stream_ptr()), "sgn_sh_bwd")
-        return None, None, v_coeffs
+        return None, None, v_coeffs, None
 
 
 def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor,
@@ -103,7 +105,8 @@ def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: tor
     polynomial; the kernel evaluates the "fast" recurrences)."""
     assert coeffs.shape[-2] >= num_sh_bases(degrees_to_use)
     assert method in ("poly", "fast"), "Invalid method."
-    return _SphericalHarmonics.apply(degrees_to_use, viewdirs.contiguous(), coeffs.contiguous())
+    claimed = _sh_exchange is not None and _sh_exchange.claims_coeffs(coeffs)
+    return _SphericalHarmonics.apply(degrees_to_use, viewdirs.contiguous(), coeffs.contiguous(), claimed)
 
 
 # ---------------------------------------------------------------- project

@@ -116,29 +116,53 @@ def _exchange_worker(rank, world, port, outdir):
     for mode in ("dirs", "cam", "view"):
         ex = dp.SHGradExchange(dc, rest, average=True, multi_fn=_sh_multi_torch)
         red = dp.GradAllReducer([dc, rest], big=[rest], sh_exchange=ex)
-        assert red.params == [] and not red._handles               # SH leaves are left to the exchange
+        assert red.params == []                                    # SH leaves are left to the exchange
+        assert ex.claims_coeffs(torch.cat((dc, rest), dim=1))      # literally the cat of the two leaves
+        assert not ex.claims_coeffs(torch.cat((dc * 1.0, rest), dim=1)) and not ex.claims_coeffs(
+            torch.cat((dc, rest), dim=1)[:10])
+        assert ex.claims_leaves(dc, rest, None, None, None) and not ex.claims_leaves(dc, rest, None, means, None)
         if mode == "dirs":
-            ex._tap_dirs(dirs, v_rgb, deg, k)
+            assert ex.tap_dirs(dirs, v_rgb, deg, k, True)
         elif mode == "view":                                        # drop-in tap, camera registered by the trainer
             ex.set_view(means, cam_pos)
-            ex._tap_dirs(dirs, v_rgb, deg, k)
-            assert ex._stash["kind"] == "cam"
+            assert ex.tap_dirs(dirs, v_rgb, deg, k, True)
+            assert ex._claimed["kind"] == "cam"
         else:
-            ex._tap_fused(means, cam_pos, v_rgb, deg, k, None, None, torch.ones(1, 1))
+            ex.set_view(means, cam_pos)                             # a rank without SH backward needs current means
+            assert ex.tap_fused(means, cam_pos, v_rgb, deg, k, True)
         red.finish()
         torch.save((local, torch.cat((dc.grad, rest.grad), dim=1).clone()), os.path.join(outdir, f"{mode}{rank}.pt"))
         dc.grad.copy_(local[:, :1]); rest.grad.copy_(local[:, 1:])
         # next step: rank 1's view sees nothing, its SH backward never runs; it must still join the collectives
         if rank == 0:
-            if mode == "dirs":
-                ex._tap_dirs(dirs, v_rgb, deg, k)
-            elif mode == "view":
-                ex._tap_dirs(dirs, v_rgb, deg, k)
+            if mode in ("dirs", "view"):
+                ex.tap_dirs(dirs, v_rgb, deg, k, True)
             else:
-                ex._tap_fused(means, cam_pos, v_rgb, deg, k, None, None, torch.ones(1, 1))
+                ex.tap_fused(means, cam_pos, v_rgb, deg, k, True)
         red.finish()
         torch.save(torch.cat((dc.grad, rest.grad), dim=1).clone(), os.path.join(outdir, f"{mode}{rank}_empty.pt"))
         dc.grad.copy_(local[:, :1]); rest.grad.copy_(local[:, 1:])
+    # ---- SH nodes the exchange may NOT take over (scene graph: per-rank poses / Fourier weights; coefficients that
+    # are not the cat of the leaves): their taps are refused, the local dense backward runs, and finish() all-reduces
+    # the dense leaf gradients (advisor finding r01: rebuilding with the LOCAL pose table made replicas diverge)
+    ex = dp.SHGradExchange(dc, rest, average=True, multi_fn=_sh_multi_torch)
+    red = dp.GradAllReducer([dc, rest], sh_exchange=ex)
+    dc.grad.copy_(local[:, :1]); rest.grad.copy_(local[:, 1:])     # what the dense SH backward left in the leaves
+    assert not ex.tap_fused(means, cam_pos, v_rgb, deg, k, False)
+    red.finish()
+    torch.save(torch.cat((dc.grad, rest.grad), dim=1).clone(), os.path.join(outdir, f"dense{rank}.pt"))
+    # next step: rank 1 silent; it must join the dense all-reduce with zeros (shape taken from the previous step)
+    dc.grad = None; rest.grad = None
+    if rank == 0:
+        dc.grad = local[:, :1].clone(); rest.grad = local[:, 1:].clone()
+        ex.tap_fused(means, cam_pos, v_rgb, deg, k, False)
+    red.finish()
+    torch.save(torch.cat((dc.grad, rest.grad), dim=1).clone(), os.path.join(outdir, f"dense{rank}_empty.pt"))
+    # ---- mixed step: one claimed node plus one unclaimed node feeding the same leaves: low-rank sum + dense sum
+    dc.grad = (0.5 * local[:, :1]).clone(); rest.grad = (0.5 * local[:, 1:]).clone()   # the unclaimed node's share
+    assert ex.tap_dirs(dirs, v_rgb, deg, k, True) and not ex.tap_dirs(dirs, v_rgb, deg, k, True)  # 2nd claim refused
+    red.finish()
+    torch.save(torch.cat((dc.grad, rest.grad), dim=1).clone(), os.path.join(outdir, f"mixed{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -162,6 +186,14 @@ def test_sh_low_rank_exchange_equals_dense_allreduce(tmp_path):
         # the step in which rank 1 contributed nothing: both replicas hold rank 0's gradient / world
         e0, e1 = (torch.load(os.path.join(tmp_path, f"{mode}{r}_empty.pt")) for r in range(world))
         assert torch.equal(e0, e1) and torch.allclose(e0, res[0][0] / world, rtol=1e-5, atol=1e-6), mode
+    local = [torch.load(os.path.join(tmp_path, f"dirs{r}.pt"))[0] for r in range(world)]
+    dense_mean = (local[0] + local[1]) / world
+    d0, d1 = (torch.load(os.path.join(tmp_path, f"dense{r}.pt")) for r in range(world))
+    assert torch.equal(d0, d1) and torch.allclose(d0, dense_mean, rtol=1e-6, atol=1e-7)      # refused taps: dense
+    e0, e1 = (torch.load(os.path.join(tmp_path, f"dense{r}_empty.pt")) for r in range(world))
+    assert torch.equal(e0, e1) and torch.allclose(e0, local[0] / world, rtol=1e-6, atol=1e-7)
+    m0, m1 = (torch.load(os.path.join(tmp_path, f"mixed{r}.pt")) for r in range(world))
+    assert torch.equal(m0, m1) and torch.allclose(m0, 1.5 * dense_mean, rtol=1e-5, atol=1e-6)
 
 
 def _silent_rank_worker(rank, world, port, outdir):
@@ -188,7 +220,7 @@ def _silent_rank_worker(rank, world, port, outdir):
 
 @pytest.mark.timeout(600)
 def test_rank_without_gradients_still_joins_every_collective(tmp_path):
-    """Hook-driven all-reduce of the big tensor + flat bucket: a rank whose backward produced nothing must issue the
+    """Per-tensor all-reduce of the big tensor + flat bucket: a rank whose backward produced nothing must issue the
     same collectives (zeros), otherwise the others hang; the averaged result is rank 0's gradient / world."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -229,7 +261,7 @@ def _silent_mixed_worker(rank, world, port, outdir):
         silent = (step_i == 1 and rank == 1)              # second step: rank 1 renders nothing at all
         if not silent:
             means.grad = torch.full_like(means, 1.0 + rank)
-            ex._tap_dirs(dirs, v_rgb, deg, k)             # what the SH backward does (all-gathers start here)
+            ex.tap_dirs(dirs, v_rgb, deg, k, True)        # what the SH backward does (records the factors)
         red.finish()
         torch.save((means.grad.clone(), dc.grad.clone(), rest.grad.clone()),
                    os.path.join(outdir, f"mixed{step_i}_{rank}.pt"))

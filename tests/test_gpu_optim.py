@@ -102,6 +102,25 @@ def test_more_tensors_than_one_table():
         assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-7)
 
 
+def test_empty_tensors_among_more_than_one_table():
+    """30 rows, two of them empty (an object model that lost all its Gaussians): every row is stepped exactly once
+    (round 1 restarted the second launch at row 24 after the first had consumed 26 rows: rows 24-25 stepped twice)."""
+    from sgn_rast import optim
+    sizes = [5 + i for i in range(30)]
+    sizes[3] = sizes[11] = 0
+    ps = [torch.randn(s, device="cuda").requires_grad_(True) for s in sizes]
+    rs = [p.detach().cpu().clone().requires_grad_(True) for p in ps]
+    oh = [optim.FusedAdam([p], lr=0.01, eps=1e-15) for p in ps]             # one optimizer per tensor: step_many
+    orf = torch.optim.Adam([r for r in rs if r.numel()], lr=0.01, eps=1e-15)
+    for _ in range(3):
+        for p, r in zip(ps, rs):
+            r.grad = torch.randn(r.shape)
+            p.grad = r.grad.cuda()
+        optim.step_many(oh); orf.step()
+    for i, (p, r) in enumerate(zip(ps, rs)):
+        assert torch.allclose(p.detach().cpu(), r.detach(), rtol=1e-5, atol=1e-7), i
+
+
 def _after_train_reference(state, xys_grad, radii, last_size):
     """SplatfactoModel.after_train restated line by line (sgn_splatfacto.py:520-541), plain torch on the CPU."""
     visible_mask = (radii > 0).flatten()
