@@ -270,6 +270,15 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
                    const sgn_raster_opts *opts, sgn_stream_t stream);
 
+/* pytorch3d.transforms.quaternion_multiply as object2world_gs uses it (sgn_splatfacto_scene_graph.py:416): Hamilton
+ * product a (x) b, real part first, result standardised to a non-negative real part.  `a` is EITHER one quaternion
+ * for all rows, passed as a HOST array of 4 floats (a_host4; the reference's quat_o2w is a CPU tensor), OR one per row
+ * (a_rows, device [n,4]); exactly one of the two is non-NULL.  b, out, v_out, v_b: device [n,4], 16-byte aligned.
+ * Backward: v_b (may be NULL) and, for per-row a only, v_a_rows (may be NULL). */
+int sgn_quat_mul_fwd(int n, const float *a_host4, const float *a_rows, const float *b, float *out, sgn_stream_t stream);
+int sgn_quat_mul_bwd(int n, const float *a_host4, const float *a_rows, const float *b, const float *v_out, float *v_b,
+                     float *v_a_rows, sgn_stream_t stream);
+
 /* Sky cube-map lookup: replaces nvdiffrast `dr.texture(tex[None], dirs, filter_mode='linear',
  * boundary_mode='cube')` used by EnvLight (sgn_splatfacto.py:109-150).  tex [6,R,R,C] (faces +x,-x,+y,-y,+z,-z),
  * dirs [h,w,3] (the [H,W] grid of uv; need not be normalised; use h = 1 for a flat list), out [h,w,C];

@@ -47,6 +47,8 @@ SIGNATURES = {
     "sgn_adam_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_densify_stats": (_i, [_i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     "sgn_check_unit_quats": (_i, [_i, _vp, _f, _vp, _vp]),
+    "sgn_quat_mul_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_quat_mul_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_sh_bwd_multi": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp]),
     "sgn_sh_fwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_sh_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -16,6 +16,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops as _hip_ops
+from .quat import quaternion_multiply   # what `from pytorch3d.transforms import quaternion_multiply` resolves to
 from .scenes import Camera
 
 
@@ -131,15 +132,6 @@ def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int 
     return out
 
 
-def _quaternion_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """pytorch3d.transforms.quaternion_multiply (Hamilton product, real part first), used by
-    object2world_gs at sgn_splatfacto_scene_graph.py:416."""
-    aw, ax, ay, az = torch.unbind(a, -1)
-    bw, bx, by, bz = torch.unbind(b, -1)
-    return torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
-                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
-
-
 def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Camera, sh_degree_to_use: int = 3,
                        block_width: int = 16, ops=_hip_ops, fused: bool = False,
                        caller_syncs: bool = True) -> SimpleNamespace:
@@ -186,6 +178,14 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
         opac_arg, raster = P["opacity_logits"], F_.rasterize_gaussians_fused
     else:
         world_means, world_quats, dcs = [], [], []
+        # the reference's quat_o2w is a CPU float64 4-vector per object (`torch.from_numpy(quaternion_from_matrix(rot))`,
+        # :412): one small read-back per step here, where the reference runs numpy on the host
+        pk = ("q_o2w", poses.data_ptr(), poses._version, str(dev))
+        if pk not in _CONST:
+            if len(_CONST) > 64:
+                _CONST.clear()
+            _CONST[pk] = poses[:, 12:16].detach().to("cpu", torch.float64)
+        q_o2w = _CONST[pk]
         for i, m in enumerate(models):
             Fi = m["features_dc"].shape[1]
             dcs.append((m["features_dc"] * idft[i][:Fi, None]).sum(dim=1, keepdim=True) if Fi > 1
@@ -195,7 +195,7 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
             else:
                 R, t, q = poses[i, :9].reshape(3, 3), poses[i, 9:12], poses[i, 12:16]
                 world_means.append(m["means"] @ R.T + t[None, :])                      # :415
-                world_quats.append(_quaternion_multiply(q[None, :], m["quats"]))       # :416
+                world_quats.append(quaternion_multiply(q_o2w[i], m["quats"]))           # :416
         P = dict(means=torch.cat(world_means), quats=torch.cat(world_quats), features_dc=torch.cat(dcs),
                  opacity_logits=cat("opacity_logits"), features_rest=cat("features_rest"),
                  log_scales=cat("log_scales"))

@@ -256,3 +256,30 @@ def test_window_copies_reuse_the_cached_binning(gather):
             ops._bin_prepare_async = orig
             ops.window_matching_enabled = True
             ops.clear_binning_cache()
+
+
+@pytest.mark.parametrize("per_row", [False, True])
+def test_fused_quaternion_multiply_equals_pytorch3d_formula(per_row):
+    """csrc/quat.hip vs pytorch3d's formulation in plain torch (same operation order: bit-equal forward), forward and
+    backward; `a` a CPU float64 4-vector like the reference's quat_o2w, or one quaternion per row."""
+    from sgn_rast import quat
+    g = torch.Generator().manual_seed(4)
+    n = 10_007
+    b = torch.randn(n, 4, generator=g).to(DEV).requires_grad_(True)
+    a = (torch.randn(n, 4, generator=g).to(DEV).requires_grad_(True) if per_row
+         else torch.randn(4, generator=g, dtype=torch.float64))
+    v = torch.randn(n, 4, generator=g).to(DEV)
+    out = quat.quaternion_multiply(a, b)
+    assert out.grad_fn is not None and type(out.grad_fn).__name__ == "_QuatMulBackward"     # the kernel ran
+    out.backward(v)
+    got = (out.detach().clone(), b.grad.clone(), a.grad.clone() if per_row else None)
+    b.grad = None
+    if per_row:
+        a.grad = None
+    a_ref = a if per_row else a.to(DEV)
+    ref = quat.standardize_quaternion(quat.quaternion_raw_multiply(a_ref if per_row else a_ref.float(), b))
+    ref.backward(v)
+    assert torch.equal(got[0], ref.detach())
+    assert rel_l2(got[1], b.grad) < 1e-6
+    if per_row:
+        assert rel_l2(got[2], a.grad) < 1e-6

@@ -153,3 +153,33 @@ def test_bench_cpu_baseline_leg_runs_without_a_gpu():
     d = json.loads(line)
     assert d["unit"] == "images/sec" and d["kind"] == "port" and d["value"] > 0 and d["cores"] >= 1
     assert "2500 of 10000 Gaussians" in d["sample"]
+
+
+def test_quaternion_multiply_shim_on_cpu_is_pytorch3d_formula():
+    """`from pytorch3d.transforms import quaternion_multiply` resolves to the product shim; with CPU operands (the
+    reference's bbox optimiser, data/utils/bbox_optimizers.py:155-161) it is pytorch3d's plain-torch formulation: Hamilton
+    product, real part first, standardised sign, float64 0-dim scalars do not promote a float32 tensor."""
+    import importlib
+    import sys
+    saved = sys.modules.pop("pytorch3d", None), sys.modules.pop("pytorch3d.transforms", None)
+    try:
+        T = importlib.import_module("pytorch3d.transforms")
+        assert T.quaternion_multiply.__module__ == "sgn_rast.quat"
+        g = torch.Generator().manual_seed(0)
+        a = torch.randn(4, generator=g, dtype=torch.float64)
+        b = torch.randn(50, 4, generator=g)
+        out = T.quaternion_multiply(a, b)
+        assert out.dtype == torch.float32 and bool((out[:, 0] >= 0).all())
+        # against rotation matrices: R(a (x) b) == R(a) R(b)
+        from sgn_rast.ops import quat_to_rotmat
+        Ra, Rb, Ro = quat_to_rotmat(a.float()), quat_to_rotmat(b), quat_to_rotmat(out)
+        assert torch.allclose(Ro, Ra[None] @ Rb, atol=1e-5)
+        i, j, k = torch.tensor([0., 1, 0, 0]), torch.tensor([0., 0, 1, 0]), torch.tensor([0., 0, 0, 1])
+        assert torch.equal(T.quaternion_multiply(i, j), k)                # ij = k
+        assert torch.equal(T.quaternion_multiply(j, i), -k)               # ji = -k (real part 0: sign kept)
+        assert torch.equal(T.quaternion_multiply(-i, i), torch.tensor([1., 0, 0, 0]))
+    finally:
+        for name, mod in zip(("pytorch3d", "pytorch3d.transforms"), saved):
+            sys.modules.pop(name, None)
+            if mod is not None:
+                sys.modules[name] = mod
