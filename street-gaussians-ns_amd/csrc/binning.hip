@@ -625,20 +625,19 @@ struct MatchArgs {
     int lo[4];
     int n_cand;
 };
+// flat, coalesced: thread j compares WORD j of every tensor (j < n_win * width) against word lo * width + j of the
+// full tensor, for each candidate offset
 __global__ __launch_bounds__(256) void rows_match_kernel(int n_win, MatchArgs a, int32_t *__restrict__ mismatch) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
     unsigned bad = 0u;
-    if (i < n_win) {
 #pragma unroll
-        for (int t = 0; t < 6; ++t) {
-            if (a.w[t] == nullptr) continue;
-            const int wd = a.width[t];
-            for (int k = 0; k < wd; ++k) {
-                const uint32_t v = a.w[t][(size_t)i * wd + k];
-                for (int c = 0; c < a.n_cand; ++c)
-                    if (a.f[t][((size_t)a.lo[c] + i) * wd + k] != v) bad |= 1u << c;
-            }
-        }
+    for (int t = 0; t < 6; ++t) {
+        if (a.w[t] == nullptr) continue;
+        const int wd = a.width[t];
+        if (j >= (size_t)n_win * wd) continue;
+        const uint32_t v = a.w[t][j];
+        for (int c = 0; c < a.n_cand; ++c)
+            if (a.f[t][(size_t)a.lo[c] * wd + j] != v) bad |= 1u << c;
     }
     for (int c = 0; c < a.n_cand; ++c) {
         const bool any = __ballot((bad >> c) & 1u) != 0ull;
@@ -667,7 +666,7 @@ SGN_EXPORT int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *
     }
     hipStream_t s = (hipStream_t)stream;
     SGN_HIP_CHECK(hipMemsetAsync(mismatch, 0, sizeof(int32_t) * n_cand, s));
-    hipLaunchKernelGGL(rows_match_kernel, dim3(sgn_cdiv(n_win, 256)), dim3(256), 0, s, n_win, a, mismatch);
+    hipLaunchKernelGGL(rows_match_kernel, dim3(sgn_cdiv((int64_t)n_win * 3, 256)), dim3(256), 0, s, n_win, a, mismatch);
     SGN_LAUNCH_CHECK();
     return 0;
 }
