@@ -311,14 +311,28 @@ def main():
     for _ in range(args.warmup):
         out = one_step()
     torch.cuda.synchronize()
+    # A full (generation-2) garbage collection over the ~1e6 objects that importing torch leaves behind takes ~50 ms
+    # on this host and lands somewhere inside a 200-step window (profiles/r02e: one 20-step chunk at 4.07 ms/step,
+    # the rest at 1.60).  Standard remedy for latency-sensitive loops: collect now and move the survivors to the
+    # permanent generation; garbage created by the steps themselves is still collected (young generations).
+    import gc
+    gc.collect()
+    if os.environ.get("SGN_BENCH_GC_FREEZE", "1") == "1":
+        gc.freeze()
     n_isect = int(out.num_tiles_hit.sum().item()) if args.warmup else 0
 
     barrier(); torch.cuda.synchronize()
+    trace = [] if os.environ.get("SGN_BENCH_TRACE") else None     # debugging: host time stamps, no device sync
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         out = one_step()
+        if trace is not None and (i + 1) % 20 == 0:
+            trace.append(time.perf_counter())
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
+    if trace:
+        print("host ms/step per 20:", [round(1e3 * (b - a) / 20, 3) for a, b in zip([t0] + trace[:-1], trace)],
+              file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -330,6 +344,7 @@ def main():
     if args.path == "dropin" and not args.no_fused_extra:
         for _ in range(max(2, args.warmup // 2)):
             one_step(True)
+        gc.collect()
         barrier(); torch.cuda.synchronize()
         tf0 = time.perf_counter()
         for _ in range(args.steps):
@@ -349,6 +364,7 @@ def main():
     if args.path == "dropin" and sg is None and not args.caller_syncs and not args.no_fused_extra:
         for _ in range(max(2, args.warmup // 2)):
             one_step(caller_syncs=True)
+        gc.collect()
         barrier(); torch.cuda.synchronize()
         ts0 = time.perf_counter()
         for _ in range(args.steps):

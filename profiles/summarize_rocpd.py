@@ -95,11 +95,46 @@ def gaps(path, skip_frac=0.5):
         print(f"| {tot / 1e3:.1f} | {cnt} | {tot / cnt / 1e3:.1f} | `{a}` | `{b}` |")
 
 
+def _dispatch_rows(path):
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    tables = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
+    for t in [t for t in tables if "kernel_dispatch" in t or t == "kernels"]:
+        cols = [r[1] for r in cur.execute(f"pragma table_info({t})")]
+        if "start" in cols and "end" in cols:
+            namecol = "name" if "name" in cols else ("kernel_name" if "kernel_name" in cols else None)
+            if namecol is None and "kernel_id" in cols:
+                sym = [x for x in tables if "kernel_symbol" in x]
+                if sym:
+                    return list(cur.execute(f"select s.kernel_name, d.start, d.end from {t} d join {sym[0]} s "
+                                            f"on d.kernel_id = s.id order by d.start"))
+            elif namecol:
+                return list(cur.execute(f"select {namecol}, start, end from {t} order by start"))
+    return None
+
+
+def timeline(path, marker="project_fwd", which=-2):
+    """One steady-state step, kernel by kernel: `marker` (a substring of the kernel that starts a step) delimits steps;
+    prints the `which`-th one with each kernel's duration and the idle gap in front of it."""
+    rows = _dispatch_rows(path)
+    starts = [i for i, r in enumerate(rows) if marker in r[0]]
+    a, b = starts[which], starts[which + 1] if which + 1 < 0 or which + 1 < len(starts) else len(rows)
+    t0, prev_end = rows[a][1], rows[a][1]
+    print(f"step of {b - a} kernels, {(rows[b - 1][2] - t0) / 1e3:.1f} us")
+    print("| t_us | gap_us | dur_us | kernel |")
+    print("|---:|---:|---:|---|")
+    for name, st, en in rows[a:b]:
+        print(f"| {(st - t0) / 1e3:.1f} | {max(0, st - prev_end) / 1e3:.1f} | {(en - st) / 1e3:.1f} | `{short(name, 70)}` |")
+        prev_end = max(prev_end, en)
+
+
 if __name__ == "__main__":
     mode, path = sys.argv[1], sys.argv[2]
     if mode == "kernels":
         kernels(path)
     elif mode == "gaps":
         gaps(path)
+    elif mode == "timeline":
+        timeline(path, *(sys.argv[3:4] or ["project_fwd"]))
     else:
         pmc(path, sys.argv[3] if len(sys.argv) > 3 else "")
