@@ -629,6 +629,12 @@ struct MatchArgs {
 // full tensor, for each candidate offset
 __global__ __launch_bounds__(256) void rows_match_kernel(int n_win, MatchArgs a, int32_t *__restrict__ mismatch) {
     const size_t j = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // candidates already known to mismatch need no further work (and no further atomics: a window that is NOT at a
+    // candidate offset differs almost everywhere, and 40 k waves hammering one address cost more than the compare)
+    unsigned dead = 0u;
+    for (int c = 0; c < a.n_cand; ++c)
+        if (__atomic_load_n(mismatch + c, __ATOMIC_RELAXED) != 0) dead |= 1u << c;
+    if (dead == (1u << a.n_cand) - 1u) return;
     unsigned bad = 0u;
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(256) void rows_match_kernel(int n_win, MatchArgs a,
         if (j >= (size_t)n_win * wd) continue;
         const uint32_t v = a.w[t][j];
         for (int c = 0; c < a.n_cand; ++c)
-            if (a.f[t][(size_t)a.lo[c] * wd + j] != v) bad |= 1u << c;
+            if (!((dead >> c) & 1u) && a.f[t][(size_t)a.lo[c] * wd + j] != v) bad |= 1u << c;
     }
     for (int c = 0; c < a.n_cand; ++c) {
         const bool any = __ballot((bad >> c) & 1u) != 0ull;

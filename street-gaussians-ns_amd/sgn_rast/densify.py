@@ -46,3 +46,177 @@ class Stats:
         from .dp import sync_densify_stats
         if self.xys_grad_norm is not None:
             sync_densify_stats(self.xys_grad_norm, self.vis_counts, self.max_2Dsize, group=group)
+
+
+# ======================================================================================================================
+# Split / duplicate / cull + optimiser-state surgery, replicated under data parallelism
+# ======================================================================================================================
+from dataclasses import dataclass
+from typing import Dict
+
+PARAM_NAMES = ("means", "log_scales", "quats", "features_dc", "features_rest", "opacity_logits")
+
+
+@dataclass
+class DensifyConfig:
+    """The thresholds of ``SplatfactoModelConfig`` that ``refinement_after`` reads (sgn_splatfacto.py:153-226)."""
+    warmup_length: int = 500
+    refine_every: int = 100
+    cull_alpha_thresh: float = 0.1
+    cull_scale_thresh: float = 0.5
+    continue_cull_post_densification: bool = True
+    reset_alpha_every: int = 30
+    densify_grad_thresh: float = 0.0002
+    densify_size_thresh: float = 0.01
+    n_split_samples: int = 2
+    cull_screen_size: float = 0.15
+    split_screen_size: float = 0.05
+    stop_screen_size_at: int = 4000
+    stop_split_at: int = 15000
+    num_train_data: int = 0
+
+
+class Densifier:
+    """``SplatfactoModel.refinement_after`` / ``split_gaussians`` / ``dup_gaussians`` / ``cull_gaussians`` and the
+    optimiser-state surgery ``dup_in_optim`` / ``remove_from_optim`` (``street_gaussians_ns/sgn_splatfacto.py:459-511,
+    550-720``) for a parameter dictionary (the names of :mod:`sgn_rast.step`) and one optimiser per parameter — the
+    reference's layout (``sgn_config.py:71-108``) — whose state uses torch.optim.Adam's keys (``exp_avg``,
+    ``exp_avg_sq``; :class:`sgn_rast.optim.FusedAdam` or ``torch.optim.Adam`` alike).
+
+    View-parallel training keeps N replicas of the Gaussians; they must take BIT-IDENTICAL decisions or they drift apart
+    at the first refinement (step 600) and the gradient all-reduce stops making sense.  Everything the decisions read is
+    made identical first: the statistics are reduced across ranks (``Stats.sync``: SUM of gradient norms and visibility
+    counts — the average over all views rendered since the last refinement — and MAX of the screen-space size); the
+    parameters are identical by construction (same initial values, same all-reduced gradients, same optimiser); and the
+    one random draw (``split_gaussians``' ``torch.randn``, ``:680``) comes from a generator seeded with
+    ``(seed, step)`` on every rank.  Quirks of the reference kept on purpose: ``split_gaussians`` shrinks the scales of
+    the split Gaussians IN PLACE before the duplicate mask is computed (``:699`` then ``:603``), so a Gaussian just
+    above the size threshold can be both split and duplicated; new optimiser rows are zeros.
+    """
+
+    def __init__(self, params: Dict[str, torch.Tensor], optimizers: Dict[str, torch.optim.Optimizer],
+                 config: DensifyConfig = DensifyConfig(), seed: int = 0, group=None, stats: Optional[Stats] = None):
+        assert set(params) == set(PARAM_NAMES) and set(optimizers) >= set(PARAM_NAMES)
+        self.params, self.optimizers, self.cfg, self.seed, self.group = params, optimizers, config, seed, group
+        self.stats = stats if stats is not None else Stats()
+        self.last_size = (1, 1)
+        self.record: Dict[str, float] = {}
+
+    # ------------------------------------------------------------------------------------------------ after_train
+    def after_train(self, step: int, xys_grad: Optional[torch.Tensor], radii: torch.Tensor, last_size) -> None:
+        """:513-541 — accumulate this step's statistics (stops at ``stop_split_at`` like the reference)."""
+        self.last_size = (int(last_size[0]), int(last_size[1]))
+        if step >= self.cfg.stop_split_at:
+            return
+        if xys_grad is None:                      # this rank's view saw nothing: zero gradient, nothing visible
+            xys_grad = torch.zeros(radii.shape[0], 2, dtype=torch.float32, device=radii.device)
+        self.stats.update(xys_grad, radii, self.last_size)
+
+    # ------------------------------------------------------------------------------------------ optimiser surgery
+    @staticmethod
+    def _leaf_like(old: torch.Tensor, data: torch.Tensor) -> torch.Tensor:
+        """A new autograd leaf of the kind ``old`` was (nn.Parameter, as the reference re-creates them, or plain)."""
+        return torch.nn.Parameter(data) if isinstance(old, torch.nn.Parameter) else data.requires_grad_(True)
+
+    def _rebind(self, name: str, new_param: torch.Tensor, state_fn) -> None:
+        """Swap parameter ``name`` for ``new_param`` in its optimiser, transforming exp_avg / exp_avg_sq with
+        ``state_fn`` (:459-475, :483-504)."""
+        opt, old = self.optimizers[name], self.params[name]
+        group = opt.param_groups[0]
+        idx = next(i for i, p in enumerate(group["params"]) if p is old)
+        st = opt.state.pop(old, {})
+        if "exp_avg" in st:
+            st["exp_avg"], st["exp_avg_sq"] = state_fn(st["exp_avg"]), state_fn(st["exp_avg_sq"])
+        group["params"][idx] = new_param
+        opt.state[new_param] = st
+        self.params[name] = new_param
+
+    # ----------------------------------------------------------------------------------------------------- pieces
+    def _split(self, mask: torch.Tensor, samps: int, step: int) -> Dict[str, torch.Tensor]:
+        """:674-710.  The sample offsets are drawn from a generator seeded identically on every rank."""
+        P = self.params
+        n_splits = int(mask.sum().item())
+        dev = P["means"].device
+        gen = torch.Generator(device=dev)
+        gen.manual_seed((self.seed * 1_000_003 + step) & 0x7FFFFFFFFFFFFFFF)
+        centered = torch.randn((samps * n_splits, 3), device=dev, generator=gen)
+        scaled = torch.exp(P["log_scales"][mask].repeat(samps, 1)) * centered
+        q = P["quats"][mask] / P["quats"][mask].norm(dim=-1, keepdim=True)
+        from .ops import quat_to_rotmat
+        rots = quat_to_rotmat(q.repeat(samps, 1))
+        rotated = torch.bmm(rots, scaled[..., None]).squeeze()
+        out = {"means": rotated + P["means"][mask].repeat(samps, 1),
+               "features_dc": P["features_dc"][mask].repeat(samps, 1, 1),
+               "features_rest": P["features_rest"][mask].repeat(samps, 1, 1),
+               "opacity_logits": P["opacity_logits"][mask].repeat(samps, 1),
+               "log_scales": torch.log(torch.exp(P["log_scales"][mask]) / 1.6).repeat(samps, 1),
+               "quats": P["quats"][mask].repeat(samps, 1)}
+        P["log_scales"][mask] = torch.log(torch.exp(P["log_scales"][mask]) / 1.6)      # in place, like :699
+        return out
+
+    def _cull(self, step: int, extra: Optional[torch.Tensor]) -> torch.Tensor:
+        """:648-672 — returns the deleted mask; parameters are replaced by their kept rows."""
+        P, c = self.params, self.cfg
+        culls = (torch.sigmoid(P["opacity_logits"]) < c.cull_alpha_thresh).squeeze(-1)
+        if extra is not None:
+            culls = culls | extra
+        if step > c.refine_every * c.reset_alpha_every:
+            toobig = (torch.exp(P["log_scales"]).max(dim=-1).values > c.cull_scale_thresh)
+            if step < c.stop_screen_size_at:
+                toobig = toobig | (self.stats.max_2Dsize > c.cull_screen_size)
+            culls = culls | toobig
+            self.record["refine_culls_toobigs_count"] = int(toobig.sum().item())
+        keep = ~culls
+        for name in PARAM_NAMES:
+            self._rebind(name, self._leaf_like(P[name], P[name].detach()[keep]), lambda t: t[keep])
+        return culls
+
+    # ------------------------------------------------------------------------------------------- refinement_after
+    @torch.no_grad()
+    def refinement_after(self, step: int) -> bool:
+        """:550-646.  Returns True when the set of Gaussians changed (callers then rebuild whatever is sized by N:
+        gradient reducers, cached object-id tables).  Call on EVERY rank at the same step."""
+        c, S = self.cfg, self.stats
+        if step <= c.warmup_length or S.xys_grad_norm is None:
+            return False
+        S.sync(self.group)                               # replicas decide on the statistics of ALL views
+        self.record.clear()
+        P = self.params
+        n_before = P["means"].shape[0]
+        reset_interval = c.reset_alpha_every * c.refine_every
+        do_densify = step < c.stop_split_at and step % reset_interval > c.num_train_data + c.refine_every
+        deleted = None
+        if do_densify:
+            avg = (S.xys_grad_norm / S.vis_counts) * 0.5 * max(self.last_size[0], self.last_size[1])
+            high = avg > c.densify_grad_thresh
+            splits = torch.exp(P["log_scales"]).max(dim=-1).values > c.densify_size_thresh
+            if step < c.stop_screen_size_at:
+                splits = splits | (S.max_2Dsize > c.split_screen_size)
+            splits = splits & high
+            nsamps = c.n_split_samples
+            new_split = self._split(splits, nsamps, step)
+            dups = (torch.exp(P["log_scales"]).max(dim=-1).values <= c.densify_size_thresh) & high
+            self.record.update(high_grads_count=int(high.sum().item()), refine_splits_count=int(splits.sum().item()),
+                               refine_dups_count=int(dups.sum().item()))
+            n_split_new, n_dup = new_split["means"].shape[0], int(dups.sum().item())
+            for name in PARAM_NAMES:
+                old = P[name]
+                cat = torch.cat([old.detach(), new_split[name], old.detach()[dups]], dim=0)
+                pad = n_split_new + n_dup
+                self._rebind(name, self._leaf_like(old, cat),
+                             lambda t: torch.cat([t, t.new_zeros((pad,) + tuple(t.shape[1:]))], dim=0))
+            S.max_2Dsize = torch.cat([S.max_2Dsize, S.max_2Dsize.new_zeros(n_split_new + n_dup)], dim=0)
+            splits_mask = torch.cat([splits, splits.new_zeros(n_split_new + n_dup)])
+            deleted = self._cull(step, splits_mask)      # the split originals go, plus the usual culls
+        elif step >= c.stop_split_at and c.continue_cull_post_densification:
+            deleted = self._cull(step, None)
+        if step < c.stop_split_at and step % reset_interval == c.refine_every:          # opacity reset (:625-641)
+            reset_value = c.cull_alpha_thresh * 2.0       # fp32 logit read back as a Python float, like :631
+            P["opacity_logits"].data = torch.clamp(
+                P["opacity_logits"].data,
+                max=torch.logit(torch.tensor(reset_value, device=P["opacity_logits"].device)).item())
+            st = self.optimizers["opacity_logits"].state.get(P["opacity_logits"], {})
+            if "exp_avg" in st:
+                st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(st["exp_avg"]), torch.zeros_like(st["exp_avg_sq"])
+        S.reset()
+        return deleted is not None or P["means"].shape[0] != n_before

@@ -290,3 +290,67 @@ def test_silent_rank_keeps_collective_order_with_exchange_and_bucket(tmp_path):
     assert torch.allclose(m0, torch.full_like(m0, 1.5)) and torch.allclose(m1, torch.full_like(m1, 0.5))
     sh0, sh1 = torch.load(os.path.join(tmp_path, "mixed0_0.pt"))[2], torch.load(os.path.join(tmp_path, "mixed1_0.pt"))[2]
     assert float(sh0.abs().sum()) > 0 and float(sh1.abs().sum()) > 0 and not torch.allclose(sh0, sh1)
+
+
+def _densify_worker(rank, world, port, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "street-gaussians-ns_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from helpers import TorchStats
+    from sgn_rast import densify, dp, scenes
+    torch.set_num_threads(2)
+    dp.init_from_env(backend="gloo")
+    cam = scenes.make_camera(96, 64, 80.0)
+    raw = scenes.make_gaussians(1200, cam, seed=0, z_range=(1.0, 5.0))            # replicated start
+    P = {k: torch.nn.Parameter(v.clone()) for k, v in raw.items()}
+    opts = {k: torch.optim.Adam([P[k]], lr=2e-3, eps=1e-15) for k in P}
+    cfg = densify.DensifyConfig(warmup_length=0, refine_every=5, reset_alpha_every=3, cull_alpha_thresh=0.08,
+                                densify_grad_thresh=0.004, densify_size_thresh=0.04, cull_scale_thresh=0.09,
+                                stop_split_at=1000, stop_screen_size_at=400, num_train_data=2)
+    D = densify.Densifier(P, opts, cfg, seed=3, stats=TorchStats())
+    counts = [P["means"].shape[0]]
+    for step in range(1, 41):
+        n = D.params["means"].shape[0]
+        # what the render would deliver: a view-dependent (per-rank!) screen-space gradient and radii ...
+        gv = torch.Generator().manual_seed(1000 * step + rank)
+        xys_grad = torch.randn(n, 2, generator=gv) * 0.0005
+        radii = torch.randint(0, 12, (n,), generator=gv, dtype=torch.int32)
+        # ... and the parameter gradients AFTER the all-reduce: identical on every rank by construction
+        ga = torch.Generator().manual_seed(step)
+        for k in D.params:
+            D.params[k].grad = torch.randn(D.params[k].shape, generator=ga) * 0.1
+            opts[k].step()
+        D.after_train(step, xys_grad, radii, (64, 96))
+        if step % cfg.refine_every == 0:
+            D.refinement_after(step)
+            counts.append(D.params["means"].shape[0])
+    torch.save(({k: v.detach().clone() for k, v in D.params.items()},
+                {k: {kk: vv.clone() for kk, vv in opts[k].state[D.params[k]].items()} for k in D.params}, counts),
+               os.path.join(outdir, f"densify{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_replicas_stay_bit_identical_through_densification(tmp_path):
+    """Two ranks, different views (different screen-space gradients / radii per rank), eight refinement cycles with
+    splits, duplications, culls and two opacity resets (steps 5 and 20 of the 15-step reset interval): parameters AND
+    Adam moments remain bit-identical across ranks — statistics reduced SUM/SUM/MAX, split samples drawn from the
+    (seed, step) generator — and the Gaussian count really changes."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_densify_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=500)
+        assert p.exitcode == 0
+    (p0, s0, c0), (p1, s1, c1) = (torch.load(os.path.join(tmp_path, f"densify{r}.pt")) for r in range(world))
+    assert c0 == c1 and len(set(c0)) >= 4, c0                 # same history of counts, and it moved
+    for k in p0:
+        assert p0[k].shape == p1[k].shape and torch.equal(p0[k], p1[k]), k
+        for kk in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(s0[k][kk], s1[k][kk]), (k, kk)
+            assert s0[k][kk].shape == p0[k].shape
