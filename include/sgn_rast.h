@@ -50,9 +50,10 @@ typedef struct sgn_raster_opts {
                            0 = nine butterfly reductions (54 shuffles), kept for A/B measurements and tests */
     int gather;         /* 1 (default): kernels chase gaussian_ids_sorted[k] -> per-Gaussian row with dependent scalar
                            loads (no pack pass); 0: they stream a depth-ordered 48-byte record per intersection */
-    int waves_per_tile; /* 1: one wave64 per tile, 4 pixels per lane; 4: four waves per tile, one 8x8 quadrant each;
-                           0 (default): adaptive - tiles whose depth list (forward) / reverse walk (backward) has at
-                           least adapt_fwd / adapt_bwd entries are split over four waves, the rest done by one */
+    int waves_fwd;      /* waves per tile in the forward: 4 (default) = four waves, one 8x8 quadrant each; 1 = one wave64
+                           per tile, 4 pixels per lane; 0 = adaptive (split tiles whose list has >= adapt_fwd entries) */
+    int waves_bwd;      /* same for the backward; default 0 = adaptive on the reverse-walk length (>= adapt_bwd): one
+                           wave per tile means ONE gradient reduction per (tile, Gaussian), four waves mean four */
     int adapt_fwd, adapt_bwd; /* defaults 3072 / 1536; <= 0 = default */
     int batch_fwd, batch_bwd; /* lists / reverse walks with at least this many entries are read through 64-entry
                                  batches staged in wave-private LDS instead of the one-entry scalar look-ahead
@@ -227,6 +228,11 @@ int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *cand_lo_hos
                    const int32_t *num_tiles_hit, const float *conics, const float *opacities, int32_t *mismatch,
                    sgn_stream_t stream);
 
+/* Launch order for the raster kernels (no upstream counterpart): order[0..n_tiles) = the tiles sorted by depth-list
+ * length, longest class first (half-octave classes).  Results do not depend on it; on skewed content it removes the
+ * tail of late-starting long tiles. */
+int sgn_tile_order(int n_tiles, const int32_t *tile_bins, int32_t *order, sgn_stream_t stream);
+
 /* _C.rasterize_forward (3-channel path; reference call sites sgn_splatfacto.py:954-967,
  * :982-994).  `recs_ws` (>= sgn_raster_workspace_bytes(n, n_isect)) receives the depth-ordered
  * 48-byte record stream the kernels read through the scalar cache; keep it alive and pass
@@ -246,6 +252,7 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    const float *background3, float *out_img /*[H,W,3]*/, float *final_Ts /*[H,W]*/,
                    int32_t *final_idx /*[H,W]*/, void *recs_ws, size_t recs_ws_bytes,
                    int rows_built /*1: sgn_raster_build_rows already filled recs_ws (gather mode)*/,
+                   const int32_t *tile_order /*NULL, or sgn_tile_order's permutation of the tiles: launch order*/,
                    const sgn_raster_opts *opts, sgn_stream_t stream);
 /* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built
  * while the host waits for the intersection count (keeps the GPU busy across that sync).  Pre-built rows are used by
@@ -268,7 +275,7 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    float alpha_clamp_bwd, float *v_xy /*[n,2]*/, float *v_conic /*[n,3]*/,
                    float *v_colors /*[n,3]*/, float *v_opacity /*[n]*/, void *recs_ws,
                    size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
-                   const sgn_raster_opts *opts, sgn_stream_t stream);
+                   const int32_t *tile_order, const sgn_raster_opts *opts, sgn_stream_t stream);
 
 /* pytorch3d.transforms.quaternion_multiply as object2world_gs uses it (sgn_splatfacto_scene_graph.py:416): Hamilton
  * product a (x) b, real part first, result standardised to a non-negative real part.  `a` is EITHER one quaternion

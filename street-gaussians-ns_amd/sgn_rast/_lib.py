@@ -64,12 +64,13 @@ SIGNATURES = {
     "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sgn_rows_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_raster_workspace_bytes": (_sz, [_i, _i64, _vp]),
+    "sgn_tile_order": (_i, [_i, _vp, _vp, _vp]),
     "sgn_raster_fwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
-                            _sz, _i, _vp, _vp]),
+                            _sz, _i, _vp, _vp, _vp]),
     "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sgn_raster_bwd_workspace_bytes": (_sz, [_i]),
     "sgn_raster_bwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
-                            _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp, _vp]),
+                            _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -77,7 +78,7 @@ _lib = None
 
 class RasterOpts(C.Structure):
     """`sgn_raster_opts` of include/sgn_rast.h: kernel-selection options handed to the raster entry points per call."""
-    _fields_ = [(k, C.c_int) for k in ("exact_exp", "reduce_mode", "gather", "waves_per_tile", "adapt_fwd", "adapt_bwd",
+    _fields_ = [(k, C.c_int) for k in ("exact_exp", "reduce_mode", "gather", "waves_fwd", "waves_bwd", "adapt_fwd", "adapt_bwd",
                                        "batch_fwd", "batch_bwd", "xcd_swizzle", "debug_flags")]
 
     def copy(self) -> "RasterOpts":
@@ -89,7 +90,7 @@ class RasterOpts(C.Structure):
 # The library itself is stateless; the HOST keeps the options: one process-wide default object (library defaults,
 # overridable through SGN_* environment variables for A/B runs) and, inside `with options(...)`, a private copy that
 # only the current thread / context sees (contextvars), so concurrent callers cannot race on a switch.
-_ENV = dict(reduce_mode="SGN_REDUCE_MODE", gather="SGN_RASTER_GATHER", waves_per_tile="SGN_WAVES_PER_TILE",
+_ENV = dict(reduce_mode="SGN_REDUCE_MODE", gather="SGN_RASTER_GATHER", waves_fwd="SGN_WAVES_FWD", waves_bwd="SGN_WAVES_BWD",
             batch_fwd="SGN_BATCH_FWD", batch_bwd="SGN_BATCH_BWD", xcd_swizzle="SGN_XCD_SWIZZLE",
             adapt_fwd="SGN_ADAPT_FWD", adapt_bwd="SGN_ADAPT_BWD", debug_flags="SGN_DEBUG_FLAGS")
 _process_opts = None

@@ -29,7 +29,7 @@ def raster_record_mode(request):
     from sgn_rast import _lib as L
     gather, wpt, batch = request.param
     thr = (24, 24) if batch else (1 << 30, 1 << 30)                  # force / forbid the LDS path
-    kw = dict(batch_fwd=thr[0], batch_bwd=thr[1], gather=gather, waves_per_tile=wpt)
+    kw = dict(batch_fwd=thr[0], batch_bwd=thr[1], gather=gather, waves_fwd=wpt, waves_bwd=wpt)
     if wpt == 0:
         kw.update(adapt_fwd=96, adapt_bwd=48)                        # small scenes: make some tiles split, others not
     L.load()
@@ -287,8 +287,8 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
         L.check(lib.sgn_raster_fwd(cam.height, cam.width, block, n, I, L.ptr(d["ids"]), L.ptr(d["bins"]),
                                    L.ptr(d["xys"]), L.ptr(d["conics"]), L.ptr(d["rgb"]),
                                    L.ptr(d["opac"].reshape(-1).contiguous()), 0, 0, n, 0, L.ptr(bg.to(DEV)),
-                                   L.ptr(out_img), L.ptr(fT), L.ptr(fi), L.ptr(recs), recs.numel(), 0, L.opts_ptr(),
-                                   L.stream_ptr()), "raster_fwd")
+                                   L.ptr(out_img), L.ptr(fT), L.ptr(fi), L.ptr(recs), recs.numel(), 0, None,
+                                   L.opts_ptr(), L.stream_ptr()), "raster_fwd")
         assert torch.equal(fi.cpu(), exp_idx)
         assert torch.equal(fT.cpu(), exp_T)
         assert torch.equal(out_img.cpu(), exp_img)
@@ -356,3 +356,35 @@ def test_uint8_colors_and_single_output(hip, c_oracle):
                                   cam.height, cam.width, 16, bg.to(DEV))
     assert isinstance(img, torch.Tensor) and img.shape == (cam.height, cam.width, 3)
     assert float((img.cpu() - exp_img).abs().mean()) < 1e-6
+
+
+def test_tile_order_is_a_permutation_longest_first_and_changes_nothing(hip):
+    """sgn_tile_order: a permutation of the tiles, non-increasing in half-octave length class; rendering with and
+    without it gives bit-identical images (forward) and equal gradients."""
+    from sgn_rast import _lib as L, ops, scenes, step
+    g = torch.Generator().manual_seed(0)
+    lens = torch.cat([torch.randint(0, 5000, (700,), generator=g), torch.zeros(100, dtype=torch.int64)])
+    lens = lens[torch.randperm(lens.numel(), generator=g)]
+    start = torch.cumsum(lens, 0) - lens
+    bins = torch.stack([start, start + lens], 1).to(torch.int32).to(DEV)
+    order = torch.empty(bins.shape[0], dtype=torch.int32, device=DEV)
+    L.check(L.load().sgn_tile_order(bins.shape[0], L.ptr(bins), L.ptr(order), L.stream_ptr()), "sgn_tile_order")
+    o = order.cpu().long()
+    assert torch.equal(torch.sort(o).values, torch.arange(bins.shape[0]))
+    cls = torch.where(lens[o] > 0, 1 + 2 * torch.floor(torch.log2(lens[o].clamp_min(1).double())).long(), 0)
+    assert bool((cls[1:] <= cls[:-1] + 1).all()) and int(lens[o][0]) >= int(lens.max()) // 2
+    cam, raw = scenes.make_scene("c1", device=DEV)
+    w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+    res = []
+    for enabled in (True, False):
+        ops.tile_order_enabled = enabled
+        ops.clear_binning_cache()
+        try:
+            P = step.leaf_params(raw)
+            out = step.train_step(P, cam, w_img, w_a)
+            res.append((out.rgb.detach().clone(), out.alpha.detach().clone(), {k: v.grad.clone() for k, v in P.items()}))
+        finally:
+            ops.tile_order_enabled = True
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for k in res[0][2]:
+        assert rel_l2(res[0][2][k], res[1][2][k]) < 1e-5, k
