@@ -54,7 +54,7 @@ typedef struct sgn_raster_opts {
                            per tile, 4 pixels per lane; 0 = adaptive (split tiles whose list has >= adapt_fwd entries) */
     int waves_bwd;      /* same for the backward; default 0 = adaptive on the reverse-walk length (>= adapt_bwd): one
                            wave per tile means ONE gradient reduction per (tile, Gaussian), four waves mean four */
-    int adapt_fwd, adapt_bwd; /* defaults 3072 / 1536; <= 0 = default */
+    int adapt_fwd, adapt_bwd; /* defaults 3072 / 512; <= 0 = default */
     int batch_fwd, batch_bwd; /* lists / reverse walks with at least this many entries are read through 64-entry
                                  batches staged in wave-private LDS instead of the one-entry scalar look-ahead
                                  (defaults 256 / 128; <= 0 = default; a huge value disables) */
@@ -228,10 +228,14 @@ int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *cand_lo_hos
                    const int32_t *num_tiles_hit, const float *conics, const float *opacities, int32_t *mismatch,
                    sgn_stream_t stream);
 
-/* Launch order for the raster kernels (no upstream counterpart): order[0..n_tiles) = the tiles sorted by depth-list
- * length, longest class first (half-octave classes).  Results do not depend on it; on skewed content it removes the
- * tail of late-starting long tiles. */
-int sgn_tile_order(int n_tiles, const int32_t *tile_bins, int32_t *order, sgn_stream_t stream);
+/* Launch order for the raster kernels (no upstream counterpart): order[0..n_tiles) = the tiles sorted by length,
+ * longest class first (half-octave classes); order[n_tiles] = n_long, the number of leading entries whose class is at
+ * least that of `long_thresh` (0 when long_thresh <= 0).  "Length" is the depth-list length of tile_bins, or - with
+ * tile_kmax (sgn_raster_fwd's output) - the reverse-walk length the backward will see.  Results do not depend on the
+ * order; on skewed content it removes the tail of late-starting long tiles, and n_long drives the backward's
+ * two-kernel adaptive scheme (sgn_raster_bwd).  `order` has n_tiles + 1 entries. */
+int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_kmax, int long_thresh, int32_t *order,
+                   sgn_stream_t stream);
 
 /* _C.rasterize_forward (3-channel path; reference call sites sgn_splatfacto.py:954-967,
  * :982-994).  `recs_ws` (>= sgn_raster_workspace_bytes(n, n_isect)) receives the depth-ordered
@@ -253,6 +257,7 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    int32_t *final_idx /*[H,W]*/, void *recs_ws, size_t recs_ws_bytes,
                    int rows_built /*1: sgn_raster_build_rows already filled recs_ws (gather mode)*/,
                    const int32_t *tile_order /*NULL, or sgn_tile_order's permutation of the tiles: launch order*/,
+                   int32_t *tile_kmax /*NULL, or [tiles] out: deepest list position composited by any pixel of the tile*/,
                    const sgn_raster_opts *opts, sgn_stream_t stream);
 /* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built
  * while the host waits for the intersection count (keeps the GPU busy across that sync).  Pre-built rows are used by
@@ -275,7 +280,11 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    float alpha_clamp_bwd, float *v_xy /*[n,2]*/, float *v_conic /*[n,3]*/,
                    float *v_colors /*[n,3]*/, float *v_opacity /*[n]*/, void *recs_ws,
                    size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
-                   const int32_t *tile_order, const sgn_raster_opts *opts, sgn_stream_t stream);
+                   const int32_t *tile_order /*NULL, or sgn_tile_order(..., tile_kmax, opts->adapt_bwd, ...): with
+                                               opts->waves_bwd == 0 its first n_long tiles (walks >= adapt_bwd) run four
+                                               lean waves per tile, persistent and longest first, the rest one wave per
+                                               tile; NULL = in-kernel split of long walks*/,
+                   const sgn_raster_opts *opts, sgn_stream_t stream);
 
 /* pytorch3d.transforms.quaternion_multiply as object2world_gs uses it (sgn_splatfacto_scene_graph.py:416): Hamilton
  * product a (x) b, real part first, result standardised to a non-negative real part.  `a` is EITHER one quaternion

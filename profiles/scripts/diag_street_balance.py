@@ -44,18 +44,15 @@ def timed(tag, **opt):
     print(f"  {tag:44s} fwd {f[1] / f[0]:.3f} ms  bwd {b[1] / b[0]:.3f} ms", flush=True)
 
 
-timed("default (adapt 3072/1536, batch 256/128)")
-timed("adapt 1024/512", adapt_fwd=1024, adapt_bwd=512)
-timed("adapt 512/256", adapt_fwd=512, adapt_bwd=256)
-timed("adapt 256/128", adapt_fwd=256, adapt_bwd=128)
-timed("fwd 1 wave, bwd 4 waves", waves_fwd=1, waves_bwd=4)
-timed("fwd adaptive, bwd 1 wave", waves_fwd=0, waves_bwd=1)
+timed("default (fwd 4 waves; bwd two-kernel, long >= 512)")
+timed("bwd long >= 128", adapt_bwd=128)
+timed("bwd long >= 256", adapt_bwd=256)
+timed("bwd long >= 1024", adapt_bwd=1024)
+timed("bwd long >= 2048", adapt_bwd=2048)
+timed("bwd 4 waves everywhere", waves_bwd=4)
+timed("bwd 1 wave everywhere", waves_bwd=1)
 ops.tile_order_enabled = False
-timed("no tile order (index order)")
-timed("no tile order, bwd adapt 512", adapt_bwd=512)
+timed("no tile order: legacy in-kernel split")
 ops.tile_order_enabled = True
-timed("tile order, bwd adapt 512", adapt_bwd=512)
-timed("tile order, bwd adapt 1024", adapt_bwd=1024)
-timed("batch 64/64", batch_fwd=64, batch_bwd=64)
-timed("batch off", batch_fwd=1 << 30, batch_bwd=1 << 30)
-timed("xcd swizzle", xcd_swizzle=1)
+timed("fwd 1 wave", waves_fwd=1)
+timed("fwd legacy adaptive", waves_fwd=0)

@@ -689,32 +689,42 @@ __device__ __forceinline__ int len_bucket(int len) {
     const int half = e > 0 ? (len >> (e - 1)) & 1 : 0;
     return min(63, 1 + 2 * e + half);
 }
+// length of tile t for the ordering: its depth-list length, or (kmax given) its reverse-walk length
+__device__ __forceinline__ int order_len(int t, const int2 *__restrict__ bins, const int32_t *__restrict__ kmax) {
+    const int2 r = bins[t];
+    const int len = r.y - r.x;
+    if (kmax == nullptr || len <= 0) return len;
+    return min(len, max(0, kmax[t] - r.x + 1));
+}
 __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int2 *__restrict__ bins,
+                                                          const int32_t *__restrict__ kmax, int long_thresh,
                                                           int32_t *__restrict__ order) {
     __shared__ int hist[64], start[64];
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += 1024) {
-        const int2 r = bins[t];
-        atomicAdd(&hist[len_bucket(r.y - r.x)], 1);
-    }
+    for (int t = threadIdx.x; t < n_tiles; t += 1024) atomicAdd(&hist[len_bucket(order_len(t, bins, kmax))], 1);
     __syncthreads();
     if (threadIdx.x == 0) {                      // longest class first
-        int run = 0;
-        for (int b = 63; b >= 0; --b) { start[b] = run; run += hist[b]; }
+        int run = 0, n_long = 0;
+        const int b_long = long_thresh > 0 ? len_bucket(long_thresh) : 64;
+        for (int b = 63; b >= 0; --b) {
+            start[b] = run;
+            run += hist[b];
+            if (b >= b_long) n_long = run;       // classes >= the threshold's class form a prefix of the order
+        }
+        order[n_tiles] = n_long;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += 1024) {
-        const int2 r = bins[t];
-        order[atomicAdd(&start[len_bucket(r.y - r.x)], 1)] = t;
-    }
+    for (int t = threadIdx.x; t < n_tiles; t += 1024)
+        order[atomicAdd(&start[len_bucket(order_len(t, bins, kmax))], 1)] = t;
 }
 }  // namespace
 
-SGN_EXPORT int sgn_tile_order(int n_tiles, const int32_t *tile_bins, int32_t *order, sgn_stream_t stream) {
+SGN_EXPORT int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_kmax, int long_thresh,
+                              int32_t *order, sgn_stream_t stream) {
     SGN_ARG_CHECK(n_tiles > 0 && tile_bins && order, -1);
     hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,
-                       (const int2 *)tile_bins, order);
+                       (const int2 *)tile_bins, tile_kmax, long_thresh, order);
     SGN_LAUNCH_CHECK();
     return 0;
 }

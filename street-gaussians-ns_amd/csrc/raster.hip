@@ -118,6 +118,12 @@ __global__ __launch_bounds__(256) void pack_records_kernel(int64_t n_isect, cons
     recs[t] = grec[3 * (int64_t)ids[p] + j];
 }
 
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
 // pixel of (slot q, lane) inside tile (tx,ty).  block 16: four 8x8 quadrants; otherwise linear.
 __device__ __forceinline__ void slot_pixel(int q, int lane, int B, int &ox, int &oy, bool &in_tile) {
     if (B == 16) {
@@ -182,7 +188,8 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
                                                         const float *__restrict__ bg, float *__restrict__ out_img,
                                                         float *__restrict__ final_T,
                                                         int32_t *__restrict__ final_idx, int adapt_thresh, int swz,
-                                                        int batch_thresh, const int32_t *__restrict__ tile_order) {
+                                                        int batch_thresh, const int32_t *__restrict__ tile_order,
+                                                        int32_t *__restrict__ tile_kmax) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
     constexpr int WPT = ADAPT ? 4 : 4 / QPW;   // waves launched per tile
     // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile) so the waves that do the
@@ -320,6 +327,13 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
             }
         }
     }
+    if (tile_kmax) {   // deepest list position any pixel of the tile composited: the backward's walk starts there
+        int lm = 0;
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) lm = max(lm, inside[q] ? last[q] : 0);
+        lm = wave_max_i(lm);
+        if (lane == 0 && lm > 0) atomicMax(tile_kmax + tile, lm);
+    }
 #pragma unroll
     for (int q = 0; q < QPW; ++q) {
         if (inside[q]) {
@@ -364,32 +378,18 @@ __device__ __forceinline__ float fold16(float a, float b) {   // rows: [a.r0+a.r
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
-    return v;
-}
-
 // grad_ws row layout (12 floats / Gaussian): 0,1 v_xy | 2,3,4 v_conic | 5,6,7 v_rgb | 8 v_opacity
 template <bool EXACT, int REDUCE, bool GATHER, int QPW, bool ADAPT>
-__global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int tiles_x,
-                                                        const int2 *__restrict__ bins,
-                                                        const Rec *__restrict__ recs,
-                                                        const int32_t *__restrict__ ids,
-                                                        const float *__restrict__ bg,
-                                                        const float *__restrict__ final_T,
-                                                        const int32_t *__restrict__ final_idx,
-                                                        const float *__restrict__ v_out,
-                                                        const float *__restrict__ v_out_alpha,
-                                                        float alpha_clamp, float *__restrict__ grad_ws, int dbg,
-                                                        int adapt_thresh, int swz, int batch_thresh,
-                                                        const int32_t *__restrict__ tile_order) {
+__device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, int B, int tiles_x,
+                                                const int2 *__restrict__ bins, const Rec *__restrict__ recs,
+                                                const int32_t *__restrict__ ids, const float *__restrict__ bg,
+                                                const float *__restrict__ final_T,
+                                                const int32_t *__restrict__ final_idx,
+                                                const float *__restrict__ v_out,
+                                                const float *__restrict__ v_out_alpha, float alpha_clamp,
+                                                float *__restrict__ grad_ws, int dbg, int adapt_thresh,
+                                                int batch_thresh) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
-    constexpr int WPT = ADAPT ? 4 : 4 / QPW;
-    const int n_tiles_ = gridDim.x / WPT;      // ADAPT: wave-major numbering, see the forward kernel
-    int tile = xcd_tile(ADAPT ? (int)(blockIdx.x % n_tiles_) : (int)(blockIdx.x / WPT), n_tiles_, swz);
-    if (tile_order) tile = tile_order[tile];
-    const int wv = ADAPT ? (int)(blockIdx.x / n_tiles_) : (int)(blockIdx.x % WPT);
     const int q0 = ADAPT ? 0 : wv * QPW;
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
@@ -582,6 +582,56 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
     }
 }
 
+// Launch shapes of the backward.
+//   MODE 0: one workgroup per (tile, wave) in index or `tile_order` order (forced 1 / 4 waves per tile, or the legacy
+//           in-kernel adaptive split when ADAPT).
+//   MODE 1: "short" half of the two-kernel adaptive scheme: one wave per tile (QPW = 4); block b takes tile
+//           order[b] and leaves the first n_long = order[n_tiles] entries (the long walks) to MODE 2.
+//   MODE 2: "long" half: four lean waves per tile (QPW = 1, half the registers of the QPW = 4 body), a fixed grid of
+//           persistent waves striding over the (tile, quadrant) items of the n_long longest walks, longest first.
+// Why two kernels: splitting a long walk over four waves INSIDE the QPW = 4 kernel keeps that kernel's register
+// budget and its per-slot control flow (street scene: 0.93 ms); the QPW = 1 body on the same tiles takes 0.59 ms,
+// but costs 1.6x on tiles whose walks are short (benchmark scene: 0.52 vs 0.33 ms), where one wave per tile means one
+// gradient reduction per (tile, Gaussian) instead of up to four.
+template <bool EXACT, int REDUCE, bool GATHER, int QPW, bool ADAPT, int MODE>
+__global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int tiles_x, int n_tiles,
+                                                        const int2 *__restrict__ bins,
+                                                        const Rec *__restrict__ recs,
+                                                        const int32_t *__restrict__ ids,
+                                                        const float *__restrict__ bg,
+                                                        const float *__restrict__ final_T,
+                                                        const int32_t *__restrict__ final_idx,
+                                                        const float *__restrict__ v_out,
+                                                        const float *__restrict__ v_out_alpha,
+                                                        float alpha_clamp, float *__restrict__ grad_ws, int dbg,
+                                                        int adapt_thresh, int swz, int batch_thresh,
+                                                        const int32_t *__restrict__ tile_order) {
+    if constexpr (MODE == 0) {
+        constexpr int WPT = ADAPT ? 4 : 4 / QPW;
+        // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile), see the forward kernel
+        int tile = xcd_tile(ADAPT ? (int)(blockIdx.x % n_tiles) : (int)(blockIdx.x / WPT), n_tiles, swz);
+        if (tile_order) tile = tile_order[tile];
+        const int wv = ADAPT ? (int)(blockIdx.x / n_tiles) : (int)(blockIdx.x % WPT);
+        raster_bwd_tile<EXACT, REDUCE, GATHER, QPW, ADAPT>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, final_T,
+                                                           final_idx, v_out, v_out_alpha, alpha_clamp, grad_ws, dbg,
+                                                           adapt_thresh, batch_thresh);
+    } else if constexpr (MODE == 1) {
+        static_assert(QPW == 4 && !ADAPT, "short tiles: one wave per tile");
+        const int n_long = tile_order[n_tiles];
+        if ((int)blockIdx.x < n_long) return;
+        raster_bwd_tile<EXACT, REDUCE, GATHER, 4, false>(tile_order[blockIdx.x], 0, W, H, B, tiles_x, bins, recs, ids,
+                                                         bg, final_T, final_idx, v_out, v_out_alpha, alpha_clamp,
+                                                         grad_ws, dbg, adapt_thresh, batch_thresh);
+    } else {
+        static_assert(QPW == 1 && !ADAPT, "long tiles: four lean waves per tile");
+        const int n_items = 4 * tile_order[n_tiles];
+        for (int i = blockIdx.x; i < n_items; i += gridDim.x)
+            raster_bwd_tile<EXACT, REDUCE, GATHER, 1, false>(tile_order[i >> 2], i & 3, W, H, B, tiles_x, bins, recs,
+                                                             ids, bg, final_T, final_idx, v_out, v_out_alpha,
+                                                             alpha_clamp, grad_ws, dbg, adapt_thresh, batch_thresh);
+    }
+}
+
 // rows [row0, row0 + n) of the packed gradient workspace -> the n rows of the four output arrays
 __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, int row0, const float *__restrict__ ws,
                                                            const float *__restrict__ opac, int opac_is_logit,
@@ -637,7 +687,7 @@ SGN_EXPORT void sgn_raster_default_opts(sgn_raster_opts *out) {
                                //          for a lone wave)
     out->waves_bwd = 0;        // backward: adaptive (one reduction per (tile, Gaussian) unless the walk is long)
     out->adapt_fwd = 3072;     // forward: split tiles with >= this many list entries
-    out->adapt_bwd = 1536;     // backward: split tiles whose reverse walk covers >= this many entries
+    out->adapt_bwd = 512;      // backward: reverse walks of >= this many entries go to the four-waves-per-tile kernel
     out->batch_fwd = 256;      // forward: lists with >= this many entries go through the LDS-batched path
     out->batch_bwd = 128;      // backward: same for reverse walks
     out->xcd_swizzle = 0;
@@ -695,8 +745,8 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
                               const float *conics, const float *colors, const float *opacities,
                               int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
                               float *out_img, float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes,
-                              int rows_built, const int32_t *tile_order, const sgn_raster_opts *opts,
-                              sgn_stream_t stream) {
+                              int rows_built, const int32_t *tile_order, int32_t *tile_kmax,
+                              const sgn_raster_opts *opts, sgn_stream_t stream) {
     const sgn_raster_opts o = resolve_opts(opts);
     SGN_ARG_CHECK(img_h > 0 && img_w > 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
@@ -712,12 +762,13 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     const Rec *rows = (const Rec *)recs_ws;
     const Rec *stream_recs = rows + n;
+    if (tile_kmax) SGN_HIP_CHECK(hipMemsetAsync(tile_kmax, 0, sizeof(int32_t) * tiles_x * tiles_y, s));
     sgn_timing_begin(SGN_T_RASTER_FWD, s);
 #define SGN_LAUNCH_FWD(EX, GA, Q, AD)                                                                                \
     hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
                        img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
                        gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, o.adapt_fwd, o.xcd_swizzle, o.batch_fwd,   \
-                       tile_order)
+                       tile_order, tile_kmax)
 #define SGN_LAUNCH_FWD2(EX, GA)                                                     \
     do {                                                                            \
         if (o.waves_fwd == 4) SGN_LAUNCH_FWD(EX, GA, 1, false);                     \
@@ -766,18 +817,28 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
         const Rec *rows = (const Rec *)recs_ws;
         const Rec *stream_recs = rows + n;
+        const int n_tiles = tiles_x * tiles_y;
+        const int long_grid = n_tiles * 4 < 8192 ? n_tiles * 4 : 8192;   // persistent waves of the long-walk kernel
         sgn_timing_begin(SGN_T_RASTER_BWD, s);
+#define SGN_BWD_ARGS(GA)                                                                                         \
+    img_w, img_h, block_width, tiles_x, n_tiles, (const int2 *)tile_bins, GA ? rows : stream_recs,               \
+        gaussian_ids_sorted, background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd,          \
+        (float *)grad_ws, o.debug_flags, o.adapt_bwd, o.xcd_swizzle, o.batch_bwd, tile_order
+#define SGN_LAUNCH_BWDQ(EX, RM, GA, Q, AD)                                                                       \
+    hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q, AD, 0>), dim3(n_tiles * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
+                       SGN_BWD_ARGS(GA))
 #define SGN_LAUNCH_BWD(EX, RM, GA)                                                                               \
     do {                                                                                                         \
         if (o.waves_bwd == 4) SGN_LAUNCH_BWDQ(EX, RM, GA, 1, false);                                             \
         else if (o.waves_bwd == 1) SGN_LAUNCH_BWDQ(EX, RM, GA, 4, false);                                        \
-        else SGN_LAUNCH_BWDQ(EX, RM, GA, 4, true);                                                               \
+        else if (tile_order == nullptr || block_width != 16) SGN_LAUNCH_BWDQ(EX, RM, GA, 4, true);               \
+        else {   /* two-kernel adaptive scheme: order[0..n_long) = long walks, the rest short */                 \
+            hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, 1, false, 2>), dim3(long_grid), dim3(64), 0, s,    \
+                               SGN_BWD_ARGS(GA));                                                                \
+            hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, 4, false, 1>), dim3(n_tiles), dim3(64), 0, s,      \
+                               SGN_BWD_ARGS(GA));                                                                \
+        }                                                                                                        \
     } while (0)
-#define SGN_LAUNCH_BWDQ(EX, RM, GA, Q, AD)                                                                       \
-    hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, img_w, img_h, \
-                       block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, \
-                       background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws, \
-                       o.debug_flags, o.adapt_bwd, o.xcd_swizzle, o.batch_bwd, tile_order)
 #define SGN_LAUNCH_BWD2(EX, RM) do { if (o.gather) SGN_LAUNCH_BWD(EX, RM, true); else SGN_LAUNCH_BWD(EX, RM, false); } while (0)
         if (o.exact_exp) {
             if (o.reduce_mode) SGN_LAUNCH_BWD2(true, 1); else SGN_LAUNCH_BWD2(true, 0);
@@ -787,6 +848,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
 #undef SGN_LAUNCH_BWD2
 #undef SGN_LAUNCH_BWD
 #undef SGN_LAUNCH_BWDQ
+#undef SGN_BWD_ARGS
         sgn_timing_end(SGN_T_RASTER_BWD, s);
     }
     sgn_timing_begin(SGN_T_UNPACK, s);

@@ -365,17 +365,20 @@ tile_order_enabled = True
 _order_cache = {"bins": None, "order": None}
 
 
-def _tile_order(tile_bins: torch.Tensor):
-    """Launch order of the raster workgroups for this binning (longest lists first); one tiny kernel per binning,
-    shared by every pass that reuses it (depth pass, sub-model passes, backward)."""
+def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = None, long_thresh: int = 0):
+    """Launch order of the raster workgroups (longest first).  Forward: by depth-list length, one tiny kernel per
+    binning, shared by every pass that reuses it.  Backward (``tile_kmax`` from its forward): by reverse-walk length,
+    with the count of walks >= ``long_thresh`` behind the permutation (the two-kernel adaptive scheme)."""
     if not tile_order_enabled:
         return None
-    if _order_cache["bins"] is tile_bins:
+    if tile_kmax is None and _order_cache["bins"] is tile_bins:
         return _order_cache["order"]
-    order = torch.empty(tile_bins.shape[0], dtype=torch.int32, device=tile_bins.device)
-    L.check(L.load().sgn_tile_order(tile_bins.shape[0], L.ptr(tile_bins), L.ptr(order), L.stream_ptr()),
-            "sgn_tile_order")
-    _order_cache["bins"], _order_cache["order"] = tile_bins, order
+    n_tiles = tile_bins.shape[0]
+    order = torch.empty(n_tiles + 1, dtype=torch.int32, device=tile_bins.device)
+    L.check(L.load().sgn_tile_order(n_tiles, L.ptr(tile_bins), L.ptr(tile_kmax), int(long_thresh), L.ptr(order),
+                                    L.stream_ptr()), "sgn_tile_order")
+    if tile_kmax is None:
+        _order_cache["bins"], _order_cache["order"] = tile_bins, order
     return order
 
 
@@ -569,17 +572,18 @@ class _RasterizeGaussians(Function):
             if not rows_built:
                 recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
             order = _tile_order(tile_bins)
+            tile_kmax = torch.empty(tile_bins.shape[0], dtype=torch.int32, device=dev)
             L.check(lib.sgn_raster_fwd(
                 img_height, img_width, block_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), id_lo, id_hi,
                 window, L.ptr(bg_c), L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(),
-                rows_built, L.ptr(order), ro_ptr, stream_ptr), "sgn_raster_fwd")
+                rows_built, L.ptr(order), L.ptr(tile_kmax), ro_ptr, stream_ptr), "sgn_raster_fwd")
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
         ctx.num_intersects = num_intersects
         ctx.opacity_is_logit = int(bool(opacity_is_logit))
         ctx.id_range = (id_lo, id_hi)
         ctx.window, ctx.n_full, ctx.ro = window, n_full, ro
-        ctx.order = order if num_intersects >= 1 else None
+        ctx.tile_kmax = tile_kmax if num_intersects >= 1 else None
         ctx.opacity_shape = opacity.shape
         ctx.recs = recs
         ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys_c, conics_c, colors_c, opac_c, bg_c,
@@ -614,13 +618,14 @@ class _RasterizeGaussians(Function):
                 recs = L.workspace(lib.sgn_raster_workspace_bytes(ctx.n_full, ctx.num_intersects, ro_ptr), dev)
                 packed = 0
             gws = L.workspace(lib.sgn_raster_bwd_workspace_bytes(ctx.n_full), dev)
+            order = _tile_order(tile_bins, ctx.tile_kmax, ctx.ro.adapt_bwd)
             L.check(lib.sgn_raster_bwd(
                 H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity), ctx.opacity_is_logit, ctx.id_range[0],
                 ctx.id_range[1], ctx.window, L.ptr(background), L.ptr(final_Ts),
                 L.ptr(final_idx), L.ptr(v_out_img), L.ptr(v_out_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
                 L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
-                L.ptr(gws), gws.numel(), L.ptr(ctx.order), ro_ptr, L.stream_ptr()), "sgn_raster_bwd")
+                L.ptr(gws), gws.numel(), L.ptr(order), ro_ptr, L.stream_ptr()), "sgn_raster_bwd")
         v_opacity = v_opacity.reshape(ctx.opacity_shape)
         # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha)
         return v_xy, None, None, v_conic, None, v_colors, v_opacity, None, None, None, None, None, None, None

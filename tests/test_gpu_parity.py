@@ -287,7 +287,7 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
         L.check(lib.sgn_raster_fwd(cam.height, cam.width, block, n, I, L.ptr(d["ids"]), L.ptr(d["bins"]),
                                    L.ptr(d["xys"]), L.ptr(d["conics"]), L.ptr(d["rgb"]),
                                    L.ptr(d["opac"].reshape(-1).contiguous()), 0, 0, n, 0, L.ptr(bg.to(DEV)),
-                                   L.ptr(out_img), L.ptr(fT), L.ptr(fi), L.ptr(recs), recs.numel(), 0, None,
+                                   L.ptr(out_img), L.ptr(fT), L.ptr(fi), L.ptr(recs), recs.numel(), 0, None, None,
                                    L.opts_ptr(), L.stream_ptr()), "raster_fwd")
         assert torch.equal(fi.cpu(), exp_idx)
         assert torch.equal(fT.cpu(), exp_T)
@@ -367,9 +367,11 @@ def test_tile_order_is_a_permutation_longest_first_and_changes_nothing(hip):
     lens = lens[torch.randperm(lens.numel(), generator=g)]
     start = torch.cumsum(lens, 0) - lens
     bins = torch.stack([start, start + lens], 1).to(torch.int32).to(DEV)
-    order = torch.empty(bins.shape[0], dtype=torch.int32, device=DEV)
-    L.check(L.load().sgn_tile_order(bins.shape[0], L.ptr(bins), L.ptr(order), L.stream_ptr()), "sgn_tile_order")
-    o = order.cpu().long()
+    order = torch.empty(bins.shape[0] + 1, dtype=torch.int32, device=DEV)
+    L.check(L.load().sgn_tile_order(bins.shape[0], L.ptr(bins), None, 512, L.ptr(order), L.stream_ptr()),
+            "sgn_tile_order")
+    assert int(order[-1]) == int((lens >= 512).sum())                # n_long: 512 is a class boundary
+    o = order[:-1].cpu().long()
     assert torch.equal(torch.sort(o).values, torch.arange(bins.shape[0]))
     cls = torch.where(lens[o] > 0, 1 + 2 * torch.floor(torch.log2(lens[o].clamp_min(1).double())).long(), 0)
     assert bool((cls[1:] <= cls[:-1] + 1).all()) and int(lens[o][0]) >= int(lens.max()) // 2
