@@ -54,7 +54,7 @@ typedef struct sgn_raster_opts {
                            per tile, 4 pixels per lane; 0 = adaptive (split tiles whose list has >= adapt_fwd entries) */
     int waves_bwd;      /* same for the backward; default 0 = adaptive on the reverse-walk length (>= adapt_bwd): one
                            wave per tile means ONE gradient reduction per (tile, Gaussian), four waves mean four */
-    int adapt_fwd, adapt_bwd; /* defaults 3072 / 512; <= 0 = default */
+    int adapt_fwd, adapt_bwd; /* defaults 3072 / 256; <= 0 = default */
     int batch_fwd, batch_bwd; /* lists / reverse walks with at least this many entries are read through 64-entry
                                  batches staged in wave-private LDS instead of the one-entry scalar look-ahead
                                  (defaults 256 / 128; <= 0 = default; a huge value disables) */

@@ -687,7 +687,7 @@ SGN_EXPORT void sgn_raster_default_opts(sgn_raster_opts *out) {
                                //          for a lone wave)
     out->waves_bwd = 0;        // backward: adaptive (one reduction per (tile, Gaussian) unless the walk is long)
     out->adapt_fwd = 3072;     // forward: split tiles with >= this many list entries
-    out->adapt_bwd = 512;      // backward: reverse walks of >= this many entries go to the four-waves-per-tile kernel
+    out->adapt_bwd = 256;      // backward: reverse walks of >= this many entries go to the four-waves-per-tile kernel
     out->batch_fwd = 256;      // forward: lists with >= this many entries go through the LDS-batched path
     out->batch_bwd = 128;      // backward: same for reverse walks
     out->xcd_swizzle = 0;
