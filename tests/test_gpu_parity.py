@@ -305,7 +305,7 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
         fi = torch.empty(cam.height, cam.width, dtype=torch.int32, device=DEV)
         n = R["xys"].shape[0]
         recs = L.workspace(lib.sgn_raster_workspace_bytes(n, I, L.opts_ptr()), out_img.device)
-        L.check(lib.sgn_raster_fwd(cam.height, cam.width, block, n, I, L.ptr(d["ids"]), 0, L.ptr(d["bins"]),
+        L.check(lib.sgn_raster_fwd(cam.height, cam.width, block, n, I, L.ptr(d["ids"]), L.ptr(d["bins"]),
                                    L.ptr(d["xys"]), L.ptr(d["conics"]), L.ptr(d["rgb"]),
                                    L.ptr(d["opac"].reshape(-1).contiguous()), 0, 0, n, 0, L.ptr(bg.to(DEV)),
                                    L.ptr(out_img), L.ptr(fT), L.ptr(fi), L.ptr(recs), recs.numel(), 0, None, None,
