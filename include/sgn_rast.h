@@ -206,20 +206,15 @@ size_t sgn_bin_prepare_workspace_bytes(int n);
  * gathers one sector per Gaussian instead of five arrays. */
 #define SGN_BIN_RECORD_FLOATS 8
 int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii, const float *conics,
-                    const float *opacities, int opacity_is_logit,
-                    int cull /*0: upstream's list; 1: exact per tile; 2: exact per 8x8 QUADRANT of a 16x16 tile (block_width
-                               16, n < 2^28): tighter still, and sgn_bin_intersect(quadrant_masks = 1) then packs the 4-bit
-                               mask of the quadrants the Gaussian can colour into bits 28..31 of every list entry*/,
-                    int tiles_x, int tiles_y,
+                    const float *opacities, int opacity_is_logit, int cull, int tiles_x, int tiles_y,
                     int block_width, int32_t *cum_by_rank /*[n] inclusive scan of kept-tile counts, rank order*/,
                     int32_t *gid_by_rank /*[n]*/, float *bin_records /*[n,8] out*/, void *ws, size_t ws_bytes,
                     sgn_stream_t stream);
 size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect);
 int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                       const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
-                      int quadrant_masks /*must be 1 iff sgn_bin_prepare ran with cull == 2*/,
-                      int32_t *gaussian_ids_sorted /*[n_isect]; with quadrant_masks: id | mask << 28*/,
-                      int32_t *tile_bins /*[tiles,2]*/, void *ws, size_t ws_bytes, sgn_stream_t stream);
+                      int32_t *gaussian_ids_sorted /*[n_isect]*/, int32_t *tile_bins /*[tiles,2]*/, void *ws,
+                      size_t ws_bytes, sgn_stream_t stream);
 
 /* Window recognition for the drop-in scene-graph path (no upstream counterpart).  The reference renders its sub-model
  * passes (sgn_splatfacto_scene_graph.py:364-366) from torch.cat COPIES of per-model slices of the main projection
@@ -248,9 +243,7 @@ int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_km
  * recs_packed=1 to sgn_raster_bwd to skip re-packing. */
 size_t sgn_raster_workspace_bytes(int n, int64_t n_isect, const sgn_raster_opts *opts);
 int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
-                   const int32_t *gaussian_ids_sorted,
-                   int ids_have_masks /*1: list from sgn_bin_intersect(quadrant_masks = 1)*/,
-                   const int32_t *tile_bins, const float *xys,
+                   const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                    const float *conics, const float *colors /*[n,3]*/, const float *opacities /*[n]*/,
                    int opacity_is_logit /*0 = gsplat semantics; 1 = fuse torch.sigmoid (sgn_splatfacto.py:949)*/,
                    int id_lo, int id_hi /*only Gaussians with id in [id_lo, id_hi) take part (0, n = all): a sub-model
@@ -279,7 +272,7 @@ int sgn_raster_build_rows(int n, const float *xys, const float *conics, const fl
  * consumed consistently by sgn_project_bwd). */
 size_t sgn_raster_bwd_workspace_bytes(int n);
 int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
-                   const int32_t *gaussian_ids_sorted, int ids_have_masks, const int32_t *tile_bins, const float *xys,
+                   const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                    const float *conics, const float *colors, const float *opacities, int opacity_is_logit,
                    int id_lo, int id_hi, int window /*as in sgn_raster_fwd; the four outputs then have id_hi - id_lo rows*/,
                    const float *background3, const float *final_Ts, const int32_t *final_idx,

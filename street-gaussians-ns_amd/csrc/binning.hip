@@ -229,71 +229,25 @@ __device__ __forceinline__ Ellipse make_ellipse(float gx, float gy, float a, flo
     return E;
 }
 
-// Columns [lo, hi] (inclusive, UNCLAMPED, may be empty: hi < lo) of width `col_w` pixels whose pixel-centre span
-// [k col_w + 0.5, k col_w + col_w - 0.5] meets the ellipse on the band of `n_px` pixel-centre rows starting at
-// absolute y `y_first`.  E.valid must be 1.
-__device__ __forceinline__ void band_interval(const Ellipse &E, float y_first, int n_px, int col_w, int &lo,
-                                              int &hi) {
-    const float y0 = y_first - E.gy, y1 = y0 + (float)(n_px - 1);
-    const float ya = fmaxf(y0, -E.y_ext), yb = fminf(y1, E.y_ext);   // band clipped to the ellipse's Y extent
-    if (ya > yb) { lo = 0; hi = -1; return; }
-    const float yr = fminf(fmaxf(E.y_at_xmax, ya), yb);               // maximiser of X_right on the band
-    const float yl = fminf(fmaxf(-E.y_at_xmax, ya), yb);              // minimiser of X_left on the band
-    const float x_max = (-E.b * yr + fast_sqrt(fmaxf(E.two_as - E.D * yr * yr, 0.f))) * E.inv_a + 1e-3f;
-    const float x_min = (-E.b * yl - fast_sqrt(fmaxf(E.two_as - E.D * yl * yl, 0.f))) * E.inv_a - 1e-3f;
-    const float fw = (float)col_w, inv_fw = fast_rcp(fw);
-    hi = sgn_f2i(floorf((x_max + E.gx - 0.5f) * inv_fw));
-    lo = sgn_f2i(ceilf((x_min + E.gx + 0.5f - fw) * inv_fw));
-}
-
 // kept tile interval [lo, hi] (inclusive, may be empty: hi < lo) of tile row `ty`, clamped to [mnx, mxx)
 __device__ __forceinline__ void row_interval(const Ellipse &E, int ty, int block, int mnx, int mxx, int &lo,
                                              int &hi) {
     lo = mnx; hi = mxx - 1;
     if (E.valid == 2) return;
     if (E.valid == 0) { hi = lo - 1; return; }
-    int t_lo, t_hi;
-    band_interval(E, (float)(ty * block) + 0.5f, block, block, t_lo, t_hi);
+    const float y0 = (float)(ty * block) + 0.5f - E.gy, y1 = y0 + (float)(block - 1);
+    const float ya = fmaxf(y0, -E.y_ext), yb = fminf(y1, E.y_ext);   // band clipped to the ellipse's Y extent
+    if (ya > yb) { hi = lo - 1; return; }
+    const float yr = fminf(fmaxf(E.y_at_xmax, ya), yb);               // maximiser of X_right on the band
+    const float yl = fminf(fmaxf(-E.y_at_xmax, ya), yb);              // minimiser of X_left on the band
+    const float x_max = (-E.b * yr + fast_sqrt(fmaxf(E.two_as - E.D * yr * yr, 0.f))) * E.inv_a + 1e-3f;
+    const float x_min = (-E.b * yl - fast_sqrt(fmaxf(E.two_as - E.D * yl * yl, 0.f))) * E.inv_a - 1e-3f;
+    // tile tx spans pixel centres [tx*B + 0.5, tx*B + B - 0.5]; keep it iff that span meets [x_min, x_max] + gx
+    const float fb = (float)block, inv_fb = fast_rcp(fb);
+    const int t_hi = sgn_f2i(floorf((x_max + E.gx - 0.5f) * inv_fb));
+    const int t_lo = sgn_f2i(ceilf((x_min + E.gx + 0.5f - fb) * inv_fb));
     lo = max(lo, t_lo);
     hi = min(hi, t_hi);
-}
-
-// Quadrant-exact variant for 16x16 tiles (QUAD): the raster kernels work on the four 8x8 quadrants of a tile, so the
-// test is made per 8-pixel HALF row against 8-pixel quadrant columns.  A tile row then yields two column intervals
-// (top / bottom half); tile tx is kept iff one of its four quadrants is hit, and the 4-bit mask (bit q: quadrant
-// (q & 1, q >> 1) as in raster.hip:slot_pixel) travels with the intersection, so the rasterizer neither tests nor
-// visits quadrants the Gaussian cannot colour.  (The two half-row tile intervals need not overlap: a thin, nearly
-// horizontal ellipse crosses the one-pixel gap between the halves' pixel centres inside a tile it does not touch.)
-struct QuadRow {
-    int lo0, hi0, lo1, hi1;   // quadrant-column intervals of the top / bottom half row, clamped to the bbox
-    int t_lo, t_hi;           // tiles that may be kept: [t_lo, t_hi] (some in between may have an empty mask)
-    int count;                // kept tiles
-};
-__device__ __forceinline__ QuadRow quad_row(const Ellipse &E, int ty, int mnx, int mxx) {
-    QuadRow R;
-    if (E.valid == 2) {       // culling off / degenerate conic: every bbox tile, every quadrant
-        R.lo0 = R.lo1 = 2 * mnx; R.hi0 = R.hi1 = 2 * mxx - 1;
-    } else if (E.valid == 0) {
-        R.lo0 = R.lo1 = 0; R.hi0 = R.hi1 = -1;
-    } else {
-        band_interval(E, (float)(ty * 16) + 0.5f, 8, 8, R.lo0, R.hi0);
-        band_interval(E, (float)(ty * 16) + 8.5f, 8, 8, R.lo1, R.hi1);
-        R.lo0 = max(R.lo0, 2 * mnx); R.hi0 = min(R.hi0, 2 * mxx - 1);
-        R.lo1 = max(R.lo1, 2 * mnx); R.hi1 = min(R.hi1, 2 * mxx - 1);
-    }
-    const bool e0 = R.hi0 >= R.lo0, e1 = R.hi1 >= R.lo1;
-    const int a0 = R.lo0 >> 1, b0 = R.hi0 >> 1, a1 = R.lo1 >> 1, b1 = R.hi1 >> 1;   // tile intervals of the halves
-    R.t_lo = e0 ? (e1 ? min(a0, a1) : a0) : (e1 ? a1 : 0);
-    R.t_hi = e0 ? (e1 ? max(b0, b1) : b0) : (e1 ? b1 : -1);
-    const int n0 = e0 ? b0 - a0 + 1 : 0, n1 = e1 ? b1 - a1 + 1 : 0;
-    const int both = (e0 && e1) ? max(0, min(b0, b1) - max(a0, a1) + 1) : 0;
-    R.count = n0 + n1 - both;
-    return R;
-}
-__device__ __forceinline__ unsigned quad_mask(const QuadRow &R, int tx) {
-    const int c0 = 2 * tx, c1 = 2 * tx + 1;
-    return (unsigned)(R.lo0 <= c0 && c0 <= R.hi0) | ((unsigned)(R.lo0 <= c1 && c1 <= R.hi0) << 1) |
-           ((unsigned)(R.lo1 <= c0 && c0 <= R.hi1) << 2) | ((unsigned)(R.lo1 <= c1 && c1 <= R.hi1) << 3);
 }
 
 #ifndef SGN_ROWS_BIG
@@ -329,7 +283,7 @@ struct LdsOut {          // wave-local staging: positions relative to the wave's
     }
 };
 
-template <bool EMIT, bool QUAD, class Out>
+template <bool EMIT, class Out>
 __device__ __forceinline__ int tiles_of(bool live, const Ellipse &E, int mnx, int mny, int mxx, int mxy, int gid,
                                         int cur, int tiles_x, int block, const Out &out) {
     const int lane = threadIdx.x & 63;
@@ -337,25 +291,14 @@ __device__ __forceinline__ int tiles_of(bool live, const Ellipse &E, int mnx, in
     int cnt = 0;
     if (h > 0 && h <= ROWS_BIG) {
         for (int ty = mny; ty < mxy; ++ty) {
-            if constexpr (QUAD) {
-                const QuadRow R = quad_row(E, ty, mnx, mxx);
+            int lo, hi;
+            row_interval(E, ty, block, mnx, mxx, lo, hi);
+            for (int tx = lo; tx <= hi; ++tx) {
                 if (EMIT) {
-                    for (int tx = R.t_lo; tx <= R.t_hi; ++tx) {
-                        const unsigned m = quad_mask(R, tx);
-                        if (m) { out(cur, (uint32_t)(ty * tiles_x + tx), (int32_t)((unsigned)gid | (m << 28))); ++cur; }
-                    }
+                    out(cur, (uint32_t)(ty * tiles_x + tx), gid);
+                    ++cur;
                 }
-                cnt += R.count;
-            } else {
-                int lo, hi;
-                row_interval(E, ty, block, mnx, mxx, lo, hi);
-                for (int tx = lo; tx <= hi; ++tx) {
-                    if (EMIT) {
-                        out(cur, (uint32_t)(ty * tiles_x + tx), gid);
-                        ++cur;
-                    }
-                    ++cnt;
-                }
+                ++cnt;
             }
         }
     }
@@ -375,12 +318,9 @@ __device__ __forceinline__ int tiles_of(bool live, const Ellipse &E, int mnx, in
         int total = 0;
         for (int r0 = 0; r0 < bh; r0 += 64) {
             const int ty = bmny + r0 + lane;
-            int lo = 0, hi = -1, c = 0;
-            QuadRow R;
-            if (r0 + lane < bh) {
-                if constexpr (QUAD) { R = quad_row(B, ty, bmnx, bmxx); lo = R.t_lo; hi = R.t_hi; c = R.count; }
-                else { row_interval(B, ty, block, bmnx, bmxx, lo, hi); c = max(hi - lo + 1, 0); }
-            }
+            int lo = 0, hi = -1;
+            if (r0 + lane < bh) row_interval(B, ty, block, bmnx, bmxx, lo, hi);
+            const int c = max(hi - lo + 1, 0);
             int incl = c;                                   // inclusive prefix over the 64 rows of this chunk
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
@@ -389,15 +329,7 @@ __device__ __forceinline__ int tiles_of(bool live, const Ellipse &E, int mnx, in
             }
             if (EMIT) {
                 int pos = base + incl - c;
-                if constexpr (QUAD) {
-                    if (c > 0)
-                        for (int tx = lo; tx <= hi; ++tx) {
-                            const unsigned m = quad_mask(R, tx);
-                            if (m) { out(pos, (uint32_t)(ty * tiles_x + tx), (int32_t)((unsigned)bgid | (m << 28))); ++pos; }
-                        }
-                } else {
-                    for (int tx = lo; tx <= hi; ++tx, ++pos) out(pos, (uint32_t)(ty * tiles_x + tx), bgid);
-                }
+                for (int tx = lo; tx <= hi; ++tx, ++pos) out(pos, (uint32_t)(ty * tiles_x + tx), bgid);
             }
             const int chunk_total = __shfl(incl, 63, 64);
             base += chunk_total;
@@ -409,7 +341,6 @@ __device__ __forceinline__ int tiles_of(bool live, const Ellipse &E, int mnx, in
 }
 
 // lane = Gaussian id (coalesced reads): depth sort key, bin record and its kept-tile count in one pass
-template <bool QUAD>
 __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__restrict__ xys,
                                                         const float *__restrict__ depths,
                                                         const int32_t *__restrict__ radii, Cull cull, int tiles_x,
@@ -432,7 +363,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
         }
     }
     const Ellipse E = make_ellipse(R.gx, R.gy, R.a, R.b, R.c, R.s);
-    R.cnt = tiles_of<false, QUAD>(live, E, mnx, mny, mxx, mxy, i, 0, tiles_x, block, NoOut{});
+    R.cnt = tiles_of<false>(live, E, mnx, mny, mxx, mxy, i, 0, tiles_x, block, NoOut{});
     if (i < n) {
         dkeys[i] = R.rad > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;  // culled splats sort last
         dvals[i] = i;
@@ -455,7 +386,7 @@ __global__ __launch_bounds__(256) void gather_counts_kernel(int n, const int32_t
 // entries the pairs are staged in LDS and written out with full-width coalesced stores (per-lane sequential
 // dword stores cost one memory request each: 16.6 M requests per view on the benchmark scene).
 constexpr int EMIT_CAP = 1024;
-template <typename TK, bool QUAD>
+template <typename TK>
 __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__restrict__ gid_by_rank,
                                                       const int32_t *__restrict__ cum_r,
                                                       const BinRec *__restrict__ recs, int tiles_x, int tiles_y,
@@ -485,14 +416,14 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
     }
     const Ellipse E = make_ellipse(gx, gy, a, b, c, s);
     if (total <= EMIT_CAP) {
-        tiles_of<true, QUAD>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, LdsOut<TK>{lk, lv, base});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, LdsOut<TK>{lk, lv, base});
         __syncthreads();                                      // single-wave workgroup: a fence, no s_barrier
         for (int j = lane; j < total; j += 64) {
             tkeys[base + j] = lk[j];
             tvals[base + j] = lv[j];
         }
     } else {
-        tiles_of<true, QUAD>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, GlobalOut<TK>{tkeys, tvals});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, GlobalOut<TK>{tkeys, tvals});
     }
 }
 
@@ -600,7 +531,6 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     if (n == 0) return 0;
     SGN_ARG_CHECK(xys && depths && radii && cum_by_rank && gid_by_rank && bin_records && ws, -3);
     SGN_ARG_CHECK(ws_bytes >= sgn_bin_prepare_workspace_bytes(n), -4);
-    SGN_ARG_CHECK(cull != 2 || (block_width == 16 && n < (1 << 28) && conics && opacities), -5);
     hipStream_t s = (hipStream_t)stream;
     char *p = (char *)ws;
     void *scan_ws = p; p += al256(sgn_scan_workspace_bytes(n));
@@ -613,12 +543,8 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     const Cull c = make_cull(conics, opacities, opacity_is_logit, cull);
     BinRec *recs = reinterpret_cast<BinRec *>(bin_records);
     sgn_timing_begin(SGN_T_MAP, s);
-    if (cull == 2)
-        hipLaunchKernelGGL(bin_count_kernel<true>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, depths, radii, c,
-                           tiles_x, tiles_y, block_width, dkeys, dvals, recs, cnt_gid);
-    else
-        hipLaunchKernelGGL(bin_count_kernel<false>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, depths, radii, c,
-                           tiles_x, tiles_y, block_width, dkeys, dvals, recs, cnt_gid);
+    hipLaunchKernelGGL(bin_count_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, depths, radii, c, tiles_x,
+                       tiles_y, block_width, dkeys, dvals, recs, cnt_gid);
     sgn_timing_end(SGN_T_MAP, s);
     sgn_timing_begin(SGN_T_SORT, s);
     sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
@@ -636,10 +562,9 @@ SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
 
 SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                                  const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
-                                 int quadrant_masks, int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *ws,
-                                 size_t ws_bytes, sgn_stream_t stream) {
+                                 int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *ws, size_t ws_bytes,
+                                 sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0 && n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
-    SGN_ARG_CHECK(!quadrant_masks || (block_width == 16 && n < (1 << 28)), -6);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     SGN_ARG_CHECK(tile_bins != nullptr, -3);
     hipStream_t s = (hipStream_t)stream;
@@ -658,12 +583,8 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
     if (n_tiles <= 65536) {       // 16-bit tile keys (the buffers keep their 4-byte-per-key size)
         uint16_t *k16 = (uint16_t *)tkeys, *k16s = (uint16_t *)tkeys_sorted;
         sgn_timing_begin(SGN_T_MAP, s);
-        if (quadrant_masks)
-            hipLaunchKernelGGL((bin_emit_kernel<uint16_t, true>), dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank,
-                               cum_by_rank, recs, tiles_x, tiles_y, block_width, k16, tvals);
-        else
-            hipLaunchKernelGGL((bin_emit_kernel<uint16_t, false>), dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank,
-                               cum_by_rank, recs, tiles_x, tiles_y, block_width, k16, tvals);
+        hipLaunchKernelGGL(bin_emit_kernel<uint16_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
+                           recs, tiles_x, tiles_y, block_width, k16, tvals);
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
         sgn_sort_pairs16_launch((uint32_t)n_isect, tile_bits, k16, tvals, k16s, gaussian_ids_sorted, sort_ws, s);
@@ -674,12 +595,8 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
         sgn_timing_end(SGN_T_BINS, s);
     } else {
         sgn_timing_begin(SGN_T_MAP, s);
-        if (quadrant_masks)
-            hipLaunchKernelGGL((bin_emit_kernel<uint32_t, true>), dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank,
-                               cum_by_rank, recs, tiles_x, tiles_y, block_width, tkeys, tvals);
-        else
-            hipLaunchKernelGGL((bin_emit_kernel<uint32_t, false>), dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank,
-                               cum_by_rank, recs, tiles_x, tiles_y, block_width, tkeys, tvals);
+        hipLaunchKernelGGL(bin_emit_kernel<uint32_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
+                           recs, tiles_x, tiles_y, block_width, tkeys, tvals);
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
         sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws,

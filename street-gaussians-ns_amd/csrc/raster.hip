@@ -110,12 +110,12 @@ __global__ __launch_bounds__(256) void build_grec_kernel(int n, const float *__r
 
 __global__ __launch_bounds__(256) void pack_records_kernel(int64_t n_isect, const int32_t *__restrict__ ids,
                                                            const float4 *__restrict__ grec,
-                                                           float4 *__restrict__ recs, int idm) {
+                                                           float4 *__restrict__ recs) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of one record
     if (t >= 3 * n_isect) return;
     const int64_t p = t / 3;
     const int j = (int)(t - 3 * p);
-    recs[t] = grec[3 * (int64_t)(ids[p] & idm) + j];
+    recs[t] = grec[3 * (int64_t)ids[p] + j];
 }
 
 __device__ __forceinline__ int wave_max_i(int v) {
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
                                                         float *__restrict__ final_T,
                                                         int32_t *__restrict__ final_idx, int adapt_thresh, int swz,
                                                         int batch_thresh, const int32_t *__restrict__ tile_order,
-                                                        int32_t *__restrict__ tile_kmax, int masks) {
+                                                        int32_t *__restrict__ tile_kmax) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
     constexpr int WPT = ADAPT ? 4 : 4 / QPW;   // waves launched per tile
     // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile) so the waves that do the
@@ -267,24 +267,17 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
         return true;
     };
 
-    // `masks`: the list carries, in the top 4 bits of every id, the quadrants the Gaussian can colour in THIS tile
-    // (exact, computed once by the binning: binning.hip quad_row); otherwise the kernel tests the alpha-cutoff bbox of
-    // the row against the quadrants itself.  A row with a negative extent is inert (outside an id range / invisible).
-    const int idm = masks ? 0x0FFFFFFF : -1;
     const int L = range.y - range.x;
     if (L > 0 && L < batch_thresh) {
         // short list: chase ids -> rows with scalar loads, one entry ahead (operands arrive in SGPRs)
-        int idc = GATHER ? ids[range.x] : 0;
-        Rec cur = recs[GATHER ? (idc & idm) : range.x];
+        Rec cur = recs[GATHER ? ids[range.x] : range.x];
         int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
         for (int k = range.x; k < range.y; ++k) {
             const int kn = (k + 1 < range.y) ? k + 1 : k;
-            const Rec nxt = recs[GATHER ? (idn & idm) : kn];  // scalar prefetch of the next record
-            const int idnn = GATHER ? ids[min(k + 2, range.y - 1)] : 0;
-            const unsigned qm = masks ? ((cur.ex < 0.f) ? 0u : ((unsigned)idc >> 28))
-                                      : quadrant_mask(cur, qcx, qcy, qtest);
-            if (!entry(cur, k, qm)) break;
-            cur = nxt; idc = idn; idn = idnn;
+            const Rec nxt = recs[GATHER ? idn : kn];  // scalar prefetch of the next record
+            if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
+            if (!entry(cur, k, quadrant_mask(cur, qcx, qcy, qtest))) break;
+            cur = nxt;
         }
     } else if (L > 0) {
         // long list: the one-entry scalar look-ahead leaves a lone wave latency-bound (a dependent id -> row
@@ -293,18 +286,12 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
         // ds_read_b128 (no barrier: the workgroup is this one wave and its LDS ops retire in order).
         __shared__ float4 stage[2][64 * 3];
         const int nb = (L + 63) >> 6;
-        int idp = 0;                                       // this lane's (packed) list entry of the batch in flight
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = range.x + (bidx << 6) + lane;
             if (k < range.y) {
-                idp = GATHER ? ids[k] : 0;
-                const float4 *p = reinterpret_cast<const float4 *>(recs + (GATHER ? (idp & idm) : k));
+                const float4 *p = reinterpret_cast<const float4 *>(recs + (GATHER ? ids[k] : k));
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
             }
-        };
-        auto lane_quadrants = [&](const float4 &r0, const float4 &r2) __attribute__((always_inline)) -> unsigned {
-            if (masks) return (r2.z < 0.f) ? 0u : ((unsigned)idp >> 28);
-            return row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest);
         };
         // this wave's quadrants as a bit mask (all four, or the single one of a split tile)
         unsigned mine_q = 0u;
@@ -314,7 +301,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
-        unsigned qrow = lane_quadrants(r0, r2) & mine_q;
+        unsigned qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
         bool go = true;
         for (int bi = 0; bi < nb && go; ++bi) {
             const int cnt = min(64, L - (bi << 6));
@@ -336,7 +323,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
             if (go && bi + 1 < nb) {                      // first use of the prefetched registers
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
-                qrow = lane_quadrants(r0, r2) & mine_q;
+                qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
             }
         }
     }
@@ -401,7 +388,7 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
                                                 const float *__restrict__ v_out,
                                                 const float *__restrict__ v_out_alpha, float alpha_clamp,
                                                 float *__restrict__ grad_ws, int dbg, int adapt_thresh,
-                                                int batch_thresh, int masks) {
+                                                int batch_thresh) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
     const int q0 = ADAPT ? 0 : wv * QPW;
     const int lane = threadIdx.x;
@@ -540,37 +527,27 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
         }
     };
 
-    const int idm = masks ? 0x0FFFFFFF : -1;   // see the forward kernel
     const int L = kmax - range.x + 1;   // entries of the reverse walk
     if (L < batch_thresh) {
-        int idc = GATHER ? ids[kmax] : 0;
-        Rec cur = recs[GATHER ? (idc & idm) : kmax];
+        Rec cur = recs[GATHER ? ids[kmax] : kmax];
         int idn = GATHER ? ids[max(kmax - 1, range.x)] : 0;
         for (int k = kmax; k >= range.x; --k) {
             const int kn = (k - 1 >= range.x) ? k - 1 : k;
-            const Rec nxt = recs[GATHER ? (idn & idm) : kn];
-            const int idnn = GATHER ? ids[max(k - 2, range.x)] : 0;
-            const unsigned qm = masks ? ((cur.ex < 0.f) ? 0u : ((unsigned)idc >> 28))
-                                      : quadrant_mask(cur, qcx, qcy, qtest);
-            entry(cur, k, qm);
-            cur = nxt; idc = idn; idn = idnn;
+            const Rec nxt = recs[GATHER ? idn : kn];
+            if constexpr (GATHER) idn = ids[max(k - 2, range.x)];
+            entry(cur, k, quadrant_mask(cur, qcx, qcy, qtest));
+            cur = nxt;
         }
     } else {
         // long walk: 64-entry batches staged through wave-private LDS (see the forward kernel)
         __shared__ float4 stage[2][64 * 3];
         const int nb = (L + 63) >> 6;
-        int idp = 0;
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = kmax - (bidx << 6) - lane;
             if (k >= range.x) {
-                idp = GATHER ? ids[k] : 0;
-                const float4 *p = reinterpret_cast<const float4 *>(recs + (GATHER ? (idp & idm) : k));
+                const float4 *p = reinterpret_cast<const float4 *>(recs + (GATHER ? ids[k] : k));
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
             }
-        };
-        auto lane_quadrants = [&](const float4 &r0, const float4 &r2) __attribute__((always_inline)) -> unsigned {
-            if (masks) return (r2.z < 0.f) ? 0u : ((unsigned)idp >> 28);
-            return row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest);
         };
         unsigned mine_q = 0u;
 #pragma unroll
@@ -579,7 +556,7 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
-        unsigned qrow = lane_quadrants(r0, r2) & mine_q;
+        unsigned qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
         for (int bi = 0; bi < nb; ++bi) {
             const int cnt = min(64, L - (bi << 6));
             unsigned long long todo = __ballot(lane < cnt && qrow != 0u);
@@ -599,7 +576,7 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
             if (bi + 1 < nb) {
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
-                qrow = lane_quadrants(r0, r2) & mine_q;
+                qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
             }
         }
     }
@@ -628,7 +605,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                                                         const float *__restrict__ v_out_alpha,
                                                         float alpha_clamp, float *__restrict__ grad_ws, int dbg,
                                                         int adapt_thresh, int swz, int batch_thresh,
-                                                        const int32_t *__restrict__ tile_order, int masks) {
+                                                        const int32_t *__restrict__ tile_order) {
     if constexpr (MODE == 0) {
         constexpr int WPT = ADAPT ? 4 : 4 / QPW;
         // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile), see the forward kernel
@@ -637,21 +614,21 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         const int wv = ADAPT ? (int)(blockIdx.x / n_tiles) : (int)(blockIdx.x % WPT);
         raster_bwd_tile<EXACT, REDUCE, GATHER, QPW, ADAPT>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, final_T,
                                                            final_idx, v_out, v_out_alpha, alpha_clamp, grad_ws, dbg,
-                                                           adapt_thresh, batch_thresh, masks);
+                                                           adapt_thresh, batch_thresh);
     } else if constexpr (MODE == 1) {
         static_assert(QPW == 4 && !ADAPT, "short tiles: one wave per tile");
         const int n_long = tile_order[n_tiles];
         if ((int)blockIdx.x < n_long) return;
         raster_bwd_tile<EXACT, REDUCE, GATHER, 4, false>(tile_order[blockIdx.x], 0, W, H, B, tiles_x, bins, recs, ids,
                                                          bg, final_T, final_idx, v_out, v_out_alpha, alpha_clamp,
-                                                         grad_ws, dbg, adapt_thresh, batch_thresh, masks);
+                                                         grad_ws, dbg, adapt_thresh, batch_thresh);
     } else {
         static_assert(QPW == 1 && !ADAPT, "long tiles: four lean waves per tile");
         const int n_items = 4 * tile_order[n_tiles];
         for (int i = blockIdx.x; i < n_items; i += gridDim.x)
             raster_bwd_tile<EXACT, REDUCE, GATHER, 1, false>(tile_order[i >> 2], i & 3, W, H, B, tiles_x, bins, recs,
                                                              ids, bg, final_T, final_idx, v_out, v_out_alpha,
-                                                             alpha_clamp, grad_ws, dbg, adapt_thresh, batch_thresh, masks);
+                                                             alpha_clamp, grad_ws, dbg, adapt_thresh, batch_thresh);
     }
 }
 
@@ -730,7 +707,7 @@ SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
 // builds the per-Gaussian rows and (stream mode) the depth-ordered record stream
 static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
                         const float *colors, const float *opac, int opac_is_logit, int id_lo, int id_hi, int window,
-                        int gather, int ids_have_masks, void *recs, hipStream_t s) {
+                        int gather, void *recs, hipStream_t s) {
     float4 *grec = (float4 *)recs;                       // rows first,
     float4 *stream_recs = (float4 *)recs + 3 * (size_t)n; // then the optional depth-ordered stream
     sgn_timing_begin(SGN_T_PACK, s);
@@ -738,7 +715,7 @@ static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float 
                        opac_is_logit, id_lo, id_hi, window, grec);
     if (!gather)
         hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(3 * n_isect, 256)), dim3(256), 0, s, n_isect, ids,
-                           grec, stream_recs, ids_have_masks ? 0x0FFFFFFF : -1);
+                           grec, stream_recs);
     sgn_timing_end(SGN_T_PACK, s);
     return 0;
 }
@@ -764,8 +741,7 @@ SGN_EXPORT int sgn_raster_build_rows(int n, const float *xys, const float *conic
 }
 
 SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
-                              const int32_t *gaussian_ids_sorted, int ids_have_masks, const int32_t *tile_bins,
-                              const float *xys,
+                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
                               int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
                               float *out_img, float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes,
@@ -780,11 +756,9 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     SGN_ARG_CHECK(n >= 0 && recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect, &o), -6);
     SGN_ARG_CHECK(!window || (0 <= id_lo && id_lo <= id_hi && id_hi <= n), -7);
     hipStream_t s = (hipStream_t)stream;
-    SGN_ARG_CHECK(!ids_have_masks || block_width == 16, -8);
-    const int masks = (ids_have_masks && o.gather) ? 1 : 0;   // stream mode re-packs rows per entry and tests bboxes
     if (n_isect > 0 && !(rows_built && o.gather))
         pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
-                     window, o.gather, ids_have_masks, recs_ws, s);
+                     window, o.gather, recs_ws, s);
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     const Rec *rows = (const Rec *)recs_ws;
     const Rec *stream_recs = rows + n;
@@ -794,7 +768,7 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
                        img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
                        gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, o.adapt_fwd, o.xcd_swizzle, o.batch_fwd,   \
-                       tile_order, tile_kmax, masks)
+                       tile_order, tile_kmax)
 #define SGN_LAUNCH_FWD2(EX, GA)                                                     \
     do {                                                                            \
         if (o.waves_fwd == 4) SGN_LAUNCH_FWD(EX, GA, 1, false);                     \
@@ -814,8 +788,7 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
 }
 
 SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
-                              const int32_t *gaussian_ids_sorted, int ids_have_masks, const int32_t *tile_bins,
-                              const float *xys,
+                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
                               int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
                               const float *final_Ts, const int32_t *final_idx,
@@ -838,11 +811,9 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         SGN_ARG_CHECK(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background3 &&
                           final_Ts && final_idx && v_out_img && v_out_alpha && recs_ws, -7);
         SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect, &o), -8);
-        SGN_ARG_CHECK(!ids_have_masks || block_width == 16, -10);
-        const int masks = (ids_have_masks && o.gather) ? 1 : 0;
         if (!recs_packed)
             pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
-                         window, o.gather, ids_have_masks, recs_ws, s);
+                         window, o.gather, recs_ws, s);
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
         const Rec *rows = (const Rec *)recs_ws;
         const Rec *stream_recs = rows + n;
@@ -852,7 +823,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
 #define SGN_BWD_ARGS(GA)                                                                                         \
     img_w, img_h, block_width, tiles_x, n_tiles, (const int2 *)tile_bins, GA ? rows : stream_recs,               \
         gaussian_ids_sorted, background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd,          \
-        (float *)grad_ws, o.debug_flags, o.adapt_bwd, o.xcd_swizzle, o.batch_bwd, tile_order, masks
+        (float *)grad_ws, o.debug_flags, o.adapt_bwd, o.xcd_swizzle, o.batch_bwd, tile_order
 #define SGN_LAUNCH_BWDQ(EX, RM, GA, Q, AD)                                                                       \
     hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q, AD, 0>), dim3(n_tiles * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
                        SGN_BWD_ARGS(GA))

@@ -310,8 +310,6 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     radii_c = radii.detach().to(torch.int32).contiguous()
     xys_c = _f32c(xys)
     do_cull = int(bool(cull and conics is not None and opacity is not None))
-    # 16x16 tiles: cull per 8x8 quadrant and carry the quadrant mask in the top 4 bits of every list entry
-    quad = bool(do_cull and quadrant_masks_enabled and int(block_width) == 16 and n < (1 << 28))
     conics_c = _f32c(conics) if do_cull else None
     opac_c = _f32c(opacity).reshape(-1) if do_cull else None
     cum_r = torch.empty(n, **i32)
@@ -319,7 +317,7 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     bin_recs = torch.empty(n, 8, dtype=torch.float32, device=dev)
     ws = L.workspace(lib.sgn_bin_prepare_workspace_bytes(n), dev)
     L.check(lib.sgn_bin_prepare(n, L.ptr(xys_c), L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(conics_c), L.ptr(opac_c),
-                                int(bool(opacity_is_logit)), 2 if quad else do_cull, tx, ty, int(block_width), L.ptr(cum_r),
+                                int(bool(opacity_is_logit)), do_cull, tx, ty, int(block_width), L.ptr(cum_r),
                                 L.ptr(gid_by_rank), L.ptr(bin_recs), L.ptr(ws), ws.numel(), L.stream_ptr()),
             "sgn_bin_prepare")
     if dev not in _side:
@@ -336,7 +334,7 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
         pinned[1 + i:2 + i].copy_(f, non_blocking=True)
     done = torch.cuda.Event()
     done.record(torch.cuda.current_stream(dev))
-    st.update(cum_r=cum_r, gid_by_rank=gid_by_rank, bin_recs=bin_recs, ws=ws, done=done, pinned=pinned, quad=quad,
+    st.update(cum_r=cum_r, gid_by_rank=gid_by_rank, bin_recs=bin_recs, ws=ws, done=done, pinned=pinned,
               n_flags=len(flags), keep=(xys_c, radii_c, conics_c, opac_c, flags))
     return st
 
@@ -358,25 +356,9 @@ def _bin_finish(st):
     ids_sorted = torch.empty(num_intersects, **i32)
     ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(num_intersects), st["dev"])
     L.check(lib.sgn_bin_intersect(n, num_intersects, L.ptr(st["bin_recs"]), L.ptr(st["cum_r"]),
-                                  L.ptr(st["gid_by_rank"]), st["tx"], st["ty"], st["block"], int(st["quad"]),
-                                  L.ptr(ids_sorted), L.ptr(tile_bins), L.ptr(ws2), ws2.numel(), L.stream_ptr()),
-            "sgn_bin_intersect")
-    if st["quad"]:
-        ids_sorted._sgn_quadrant_masks = True      # travels with the tensor object (binning cache, autograd ctx)
+                                  L.ptr(st["gid_by_rank"]), st["tx"], st["ty"], st["block"], L.ptr(ids_sorted),
+                                  L.ptr(tile_bins), L.ptr(ws2), ws2.numel(), L.stream_ptr()), "sgn_bin_intersect")
     return num_intersects, ids_sorted, tile_bins
-
-
-quadrant_masks_enabled = True    # exact per-quadrant culling + masks in the list (16x16 tiles, culling on)
-
-
-def list_has_masks(ids_sorted: torch.Tensor) -> bool:
-    """Do the entries of this sorted list carry a quadrant mask in bits 28..31?"""
-    return bool(getattr(ids_sorted, "_sgn_quadrant_masks", False))
-
-
-def strip_masks(ids_sorted: torch.Tensor) -> torch.Tensor:
-    """Plain Gaussian ids of a list made with quadrant masks (tests / inspection)."""
-    return ids_sorted & 0x0FFFFFFF if list_has_masks(ids_sorted) else ids_sorted
 
 
 tile_order_enabled = True
@@ -592,8 +574,7 @@ class _RasterizeGaussians(Function):
             order = _tile_order(tile_bins)
             tile_kmax = torch.empty(tile_bins.shape[0], dtype=torch.int32, device=dev)
             L.check(lib.sgn_raster_fwd(
-                img_height, img_width, block_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted),
-                int(list_has_masks(gaussian_ids_sorted)), L.ptr(tile_bins),
+                img_height, img_width, block_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), id_lo, id_hi,
                 window, L.ptr(bg_c), L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(),
                 rows_built, L.ptr(order), L.ptr(tile_kmax), ro_ptr, stream_ptr), "sgn_raster_fwd")
@@ -603,7 +584,6 @@ class _RasterizeGaussians(Function):
         ctx.id_range = (id_lo, id_hi)
         ctx.window, ctx.n_full, ctx.ro = window, n_full, ro
         ctx.tile_kmax = tile_kmax if num_intersects >= 1 else None
-        ctx.masks = int(num_intersects >= 1 and list_has_masks(gaussian_ids_sorted))
         ctx.opacity_shape = opacity.shape
         ctx.recs = recs
         ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys_c, conics_c, colors_c, opac_c, bg_c,
@@ -640,8 +620,7 @@ class _RasterizeGaussians(Function):
             gws = L.workspace(lib.sgn_raster_bwd_workspace_bytes(ctx.n_full), dev)
             order = _tile_order(tile_bins, ctx.tile_kmax, ctx.ro.adapt_bwd)
             L.check(lib.sgn_raster_bwd(
-                H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(gaussian_ids_sorted), ctx.masks,
-                L.ptr(tile_bins),
+                H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity), ctx.opacity_is_logit, ctx.id_range[0],
                 ctx.id_range[1], ctx.window, L.ptr(background), L.ptr(final_Ts),
                 L.ptr(final_idx), L.ptr(v_out_img), L.ptr(v_out_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
