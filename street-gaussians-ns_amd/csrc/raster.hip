@@ -158,40 +158,14 @@ __device__ __forceinline__ unsigned quadrant_mask(const Rec &g, float qcx, float
 
 // Batched path: every lane holds ONE row of the batch and tests all four quadrants for it (lane-parallel over
 // 64 entries instead of once per entry), so entries that cannot touch this wave's pixels are never visited.
-// The test is EXACT here (it costs ~3 VALU instructions per entry when 64 lanes share it): a quadrant is kept iff the
-// convex set {sigma <= s}, s = ln(255 o) + margin, meets the rectangle of its pixel centres, i.e. iff the minimum of
-// the quadratic form over the rectangle is <= s.  The minimiser is the centre if it lies inside, otherwise it lies on
-// an edge, where the form is a 1-D quadratic with a clamped closed-form minimum.  On the benchmark scene 28 % of the
-// pairs that pass the axis-aligned bbox test of the scalar path have no pixel with alpha >= 1/255
-// (profiles/experiments/r02_quadrant_masks_notes.md).
-__device__ __forceinline__ float edge_min(float k_fixed, float k_free, float b, float d_fixed, float lo, float hi,
-                                          float inv_free) {
-    // sigma(d_free) = k_fixed d_fixed^2 + b d_fixed d_free + k_free d_free^2   (k = conic / 2)
-    const float t = fminf(fmaxf(-0.5f * b * d_fixed * inv_free, lo), hi);
-    return fmaf(k_free * t, t, fmaf(b * d_fixed, t, k_fixed * d_fixed * d_fixed));
-}
-__device__ __forceinline__ unsigned row_quadrants(float gx, float gy, float opac, float ha, float b, float hc,
-                                                  float ex, int tile_x0, int tile_y0, bool enable) {
+__device__ __forceinline__ unsigned row_quadrants(float gx, float gy, float ex, float ey, int tile_x0, int tile_y0,
+                                                  bool enable) {
     if (!enable) return 0xFu;
-    if (ex < 0.f) return 0u;                                   // inert row (outside an id range / never visible)
-    const float s = __logf(255.f * opac) + 0.01f;              // same 1 % margin as build_grec's bbox
-    if (!(ha > 0.f && hc > 0.f && ha * hc * 4.f > b * b)) return 0xFu;   // degenerate conic: keep everything
-    const float inv_ha = __builtin_amdgcn_rcpf(ha), inv_hc = __builtin_amdgcn_rcpf(hc);
     unsigned m = 0u;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        // pixel centres of the quadrant relative to the Gaussian's centre: dx in [x0, x0 + 7], dy in [y0, y0 + 7]
-        const float x0 = (float)(tile_x0 + (q & 1) * 8) + 0.5f - gx, x1 = x0 + 7.f;
-        const float y0 = (float)(tile_y0 + (q >> 1) * 8) + 0.5f - gy, y1 = y0 + 7.f;
-        float mn;
-        if (x0 <= 0.f && 0.f <= x1 && y0 <= 0.f && 0.f <= y1) mn = 0.f;
-        else {
-            mn = edge_min(ha, hc, b, x0, y0, y1, inv_hc);                       // left edge:  dx = x0, dy free
-            mn = fminf(mn, edge_min(ha, hc, b, x1, y0, y1, inv_hc));            // right edge
-            mn = fminf(mn, edge_min(hc, ha, b, y0, x0, x1, inv_ha));            // top edge:   dy = y0, dx free
-            mn = fminf(mn, edge_min(hc, ha, b, y1, x0, x1, inv_ha));            // bottom edge
-        }
-        if (mn <= s) m |= 1u << q;
+        const float cx = (float)(tile_x0 + (q & 1) * 8) + 4.0f, cy = (float)(tile_y0 + (q >> 1) * 8) + 4.0f;
+        if (fabsf(gx - cx) <= ex + 3.5f && fabsf(gy - cy) <= ey + 3.5f) m |= 1u << q;
     }
     return m;
 }
@@ -327,7 +301,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
-        unsigned qrow = row_quadrants(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, tx * 16, ty * 16, qtest) & mine_q;
+        unsigned qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
         bool go = true;
         for (int bi = 0; bi < nb && go; ++bi) {
             const int cnt = min(64, L - (bi << 6));
@@ -349,7 +323,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
             if (go && bi + 1 < nb) {                      // first use of the prefetched registers
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
-                qrow = row_quadrants(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, tx * 16, ty * 16, qtest) & mine_q;
+                qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
             }
         }
     }
@@ -582,7 +556,7 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
-        unsigned qrow = row_quadrants(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, tx * 16, ty * 16, qtest) & mine_q;
+        unsigned qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
         for (int bi = 0; bi < nb; ++bi) {
             const int cnt = min(64, L - (bi << 6));
             unsigned long long todo = __ballot(lane < cnt && qrow != 0u);
@@ -602,7 +576,7 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
             if (bi + 1 < nb) {
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
-                qrow = row_quadrants(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r2.z, tx * 16, ty * 16, qtest) & mine_q;
+                qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
             }
         }
     }
