@@ -696,13 +696,35 @@ __device__ __forceinline__ int order_len(int t, const int2 *__restrict__ bins, c
     if (kmax == nullptr || len <= 0) return len;
     return min(len, max(0, kmax[t] - r.x + 1));
 }
+// wave-aggregated LDS counter: lanes with the same bucket are served by ONE atomic (all tiles of a uniform scene fall
+// in one length class: 64 lanes hammering one LDS address serialise, measured 65 us per pass before this)
+__device__ __forceinline__ int bucket_slot(int *counters, int bucket, bool active) {
+    int slot = 0;
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const int b = __shfl(bucket, src, 64);
+        const unsigned long long same = __ballot(active && bucket == b);
+        int base = 0;
+        if (lane == src) base = atomicAdd(&counters[b], __popcll(same));
+        base = __shfl(base, src, 64);
+        if (active && bucket == b) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
 __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int2 *__restrict__ bins,
                                                           const int32_t *__restrict__ kmax, int long_thresh,
                                                           int32_t *__restrict__ order) {
     __shared__ int hist[64], start[64];
     if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += 1024) atomicAdd(&hist[len_bucket(order_len(t, bins, kmax))], 1);
+    for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
+        const int t = t0 + threadIdx.x;
+        const bool act = t < n_tiles;
+        bucket_slot(hist, act ? len_bucket(order_len(t, bins, kmax)) : 0, act);
+    }
     __syncthreads();
     if (threadIdx.x == 0) {                      // longest class first
         int run = 0, n_long = 0;
@@ -715,8 +737,12 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int
         order[n_tiles] = n_long;
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < n_tiles; t += 1024)
-        order[atomicAdd(&start[len_bucket(order_len(t, bins, kmax))], 1)] = t;
+    for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
+        const int t = t0 + threadIdx.x;
+        const bool act = t < n_tiles;
+        const int slot = bucket_slot(start, act ? len_bucket(order_len(t, bins, kmax)) : 0, act);
+        if (act) order[slot] = t;
+    }
 }
 }  // namespace
 

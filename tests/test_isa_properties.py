@@ -41,7 +41,9 @@ def test_raster_kernels_have_no_scratch_and_scalar_operands(raster_asm):
     ks = _kernels(raster_asm)
     fwd = [t for k, t in ks.items() if "raster_fwd_kernel" in k]
     bwd = [t for k, t in ks.items() if "raster_bwd_kernel" in k]
-    assert len(fwd) == 12 and len(bwd) == 24          # exact x gather x {4 waves, 1 wave, adaptive} (x reduce mode)
+    # forward: exact x gather x {4 waves, 1 wave, adaptive}; backward: exact x reduce x gather x {4 waves, 1 wave,
+    # legacy in-kernel adaptive, short-walk half, persistent long-walk half of the two-kernel scheme}
+    assert len(fwd) == 12 and len(bwd) == 40
     for t in fwd + bwd:
         assert re.search(r"ScratchSize: 0\b", t), "a raster kernel spills to scratch"
         assert "s_load_dwordx8" in t and "s_load_dwordx4" in t     # 48-byte row / record in SGPRs
