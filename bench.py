@@ -226,7 +226,11 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    from sgn_rast import _lib as L, dp, scenes, step
+    from sgn_rast import _lib as L, dp, ops, scenes, step
+    # upstream's quats assertion: the library's default is upstream's eager behaviour (host sync inside every
+    # project_gaussians call); the benchmark opts in to the deferred form, like a trainer that cares would, and times
+    # the eager form in the `with_caller_syncs` line
+    ops.quat_check = os.environ.get("SGN_QUAT_CHECK", "deferred")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); run it under gpurun")
     rank, world, local = dp.init_from_env()
@@ -362,6 +366,7 @@ def main():
     # the same drop-in step with the two host syncs the reference's model code makes around the operators
     sync_extra = None
     if args.path == "dropin" and sg is None and not args.caller_syncs and not args.no_fused_extra:
+        deferred_mode, ops.quat_check = ops.quat_check, "eager"
         for _ in range(max(2, args.warmup // 2)):
             one_step(caller_syncs=True)
         gc.collect()
@@ -371,8 +376,10 @@ def main():
             one_step(caller_syncs=True)
         torch.cuda.synchronize(); barrier()
         dts = time.perf_counter() - ts0
+        ops.quat_check = deferred_mode
         sync_extra = {"value": world * args.steps / dts, "unit": "images/sec", "ms_per_step": 1e3 * dts / args.steps,
-                      "note": "drop-in path plus the reference model's own host syncs (sgn_splatfacto.py:878, :944)"}
+                      "note": "drop-in path with upstream's eager quats assertion (library default) plus the reference "
+                              "model's own host syncs (sgn_splatfacto.py:878, :944)"}
 
     # per-kernel HIP-event spans (library brackets each launch on its own stream), separate short pass
     L.timing_enable(True)
@@ -422,6 +429,7 @@ def main():
             "kernels_avg_ms": {k: round(v[1], 4) for k, v in kernels.items()},
         }
         line["config"]["path"] = args.path
+        line["config"]["quat_check"] = ops.quat_check
         if args.street:
             line["metric"] = "train-step images/sec (fwd+bwd), non-uniform street-like content (profiling workload)"
             line["config"]["workload"] = "street: " + line["config"]["workload"]

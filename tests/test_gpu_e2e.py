@@ -243,6 +243,15 @@ def test_quat_assertion_deferred_and_eager():
             ops.rasterize_gaussians(xys, depths, radii, conics, nth, rgbs, torch.sigmoid(raw["opacity_logits"]),
                                     cam.height, cam.width, 16)
         assert not ops._pending_checks
+        # a prefetched binning that is never finished must not swallow the flag (advisor finding r01): project(bad),
+        # prefetch (the flag rides in that prepare's read-back slot), then rasterize OTHER tensors
+        xys, depths, radii, conics, _c, nth, _cov = ops.project_gaussians(*args(bad))
+        opac = torch.sigmoid(raw["opacity_logits"])
+        ops.prefetch_binning(xys, depths, radii, conics, nth, opac, cam.height, cam.width, 16)
+        assert not ops._pending_checks and ops._bin_pending["state"] is not None
+        with pytest.raises(AssertionError, match="quats must be normalized"):
+            ops.rasterize_gaussians(xys.clone(), depths, radii, conics, nth, rgbs, opac, cam.height, cam.width, 16)
+        assert not ops._pending_checks
         xys, depths, radii, conics, _c, nth, _cov = ops.project_gaussians(*args(good))
         ops.rasterize_gaussians(xys, depths, radii, conics, nth, rgbs, torch.sigmoid(raw["opacity_logits"]),
                                 cam.height, cam.width, 16)
