@@ -231,11 +231,12 @@ int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *cand_lo_hos
 /* Launch order for the raster kernels (no upstream counterpart): order[0..n_tiles) = the tiles sorted by length,
  * longest class first (half-octave classes); order[n_tiles] = n_long, the number of leading entries whose class is at
  * least that of `long_thresh` (0 when long_thresh <= 0).  "Length" is the depth-list length of tile_bins, or - with
- * tile_kmax (sgn_raster_fwd's output) - the reverse-walk length the backward will see.  Results do not depend on the
- * order; on skewed content it removes the tail of late-starting long tiles, and n_long drives the backward's
- * two-kernel adaptive scheme (sgn_raster_bwd).  `order` has n_tiles + 1 entries. */
-int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_kmax, int long_thresh, int32_t *order,
-                   sgn_stream_t stream);
+ * tile_stats (sgn_raster_fwd's output) - the reverse-walk length the backward will see; with small_q16 > 0 a tile whose
+ * forward evaluated fewer than small_q16 / 16 (entry, quadrant) pairs per walked entry (small splats) counts as long.
+ * Results do not depend on the order; on skewed content it removes the tail of late-starting long tiles, and n_long
+ * drives the backward's two-kernel adaptive scheme (sgn_raster_bwd).  `order` has n_tiles + 1 entries. */
+int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_stats, int long_thresh, int small_q16,
+                   int32_t *order, sgn_stream_t stream);
 
 /* _C.rasterize_forward (3-channel path; reference call sites sgn_splatfacto.py:954-967,
  * :982-994).  `recs_ws` (>= sgn_raster_workspace_bytes(n, n_isect)) receives the depth-ordered
@@ -257,7 +258,8 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    int32_t *final_idx /*[H,W]*/, void *recs_ws, size_t recs_ws_bytes,
                    int rows_built /*1: sgn_raster_build_rows already filled recs_ws (gather mode)*/,
                    const int32_t *tile_order /*NULL, or sgn_tile_order's permutation of the tiles: launch order*/,
-                   int32_t *tile_kmax /*NULL, or [tiles] out: deepest list position composited by any pixel of the tile*/,
+                   int32_t *tile_stats /*NULL, or [tiles,2] out: deepest list position composited by any pixel of the tile;
+                                         number of (entry, quadrant) pairs evaluated*/,
                    const sgn_raster_opts *opts, sgn_stream_t stream);
 /* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built
  * while the host waits for the intersection count (keeps the GPU busy across that sync).  Pre-built rows are used by
@@ -280,7 +282,7 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    float alpha_clamp_bwd, float *v_xy /*[n,2]*/, float *v_conic /*[n,3]*/,
                    float *v_colors /*[n,3]*/, float *v_opacity /*[n]*/, void *recs_ws,
                    size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
-                   const int32_t *tile_order /*NULL, or sgn_tile_order(..., tile_kmax, opts->adapt_bwd, ...): with
+                   const int32_t *tile_order /*NULL, or sgn_tile_order(..., tile_stats, opts->adapt_bwd, ...): with
                                                opts->waves_bwd == 0 its first n_long tiles (walks >= adapt_bwd) run four
                                                lean waves per tile, persistent and longest first, the rest one wave per
                                                tile; NULL = in-kernel split of long walks*/,

@@ -44,13 +44,10 @@ def timed(tag, **opt):
     print(f"  {tag:44s} fwd {f[1] / f[0]:.3f} ms  bwd {b[1] / b[0]:.3f} ms", flush=True)
 
 
-timed("default (fwd 4 waves; bwd two-kernel, long >= 256; batch 256/128)")
-timed("batch 128/64", batch_fwd=128, batch_bwd=64)
-timed("batch 64/32", batch_fwd=64, batch_bwd=32)
-timed("batch 32/16", batch_fwd=32, batch_bwd=16)
-timed("batch 16/8", batch_fwd=16, batch_bwd=8)
-timed("batch off", batch_fwd=1 << 30, batch_bwd=1 << 30)
-timed("bwd 4 waves everywhere, batch 64/32", waves_bwd=4, batch_fwd=64, batch_bwd=32)
-timed("bwd 1 wave everywhere, batch 64/32", waves_bwd=1, batch_fwd=64, batch_bwd=32)
-timed("bwd long >= 128, batch 64/32", adapt_bwd=128, batch_fwd=64, batch_bwd=32)
-timed("fwd 1 wave, batch 64/32", waves_fwd=1, batch_fwd=64, batch_bwd=32)
+timed("default (small-splat rule 26/16)")
+for q in (0, 20, 24, 32, 40, 64):
+    ops.small_splat_q16 = q
+    timed(f"small-splat rule {q}/16")
+ops.small_splat_q16 = 26
+timed("bwd 4 waves everywhere", waves_bwd=4)
+timed("bwd 1 wave everywhere", waves_bwd=1)

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
     const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
 
     // one depth-list entry for this wave's pixels; returns false once every pixel of the wave is finished
+    int n_eval = 0;   // (entry, quadrant) pairs this wave evaluated (wave-uniform): the backward's size-of-splat hint
     auto entry = [&](const Rec &cur, int k, unsigned qm) __attribute__((always_inline)) -> bool {
         unsigned long long live[QPW], any_live = 0ull;
 #pragma unroll
@@ -246,6 +247,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
 #pragma unroll
         for (int q = 0; q < QPW; ++q) {
             if (live[q] == 0ull || !((qm >> (q0 + q)) & 1u)) continue;  // wave-uniform
+            ++n_eval;
             const float dx = cur.x - px[q], dy = cur.y - py[q];
             float s = (cur.ha * dx) * dx;
             s = fmaf(cur.hc * dy, dy, s);
@@ -327,12 +329,14 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
             }
         }
     }
-    if (tile_kmax) {   // deepest list position any pixel of the tile composited: the backward's walk starts there
+    if (tile_kmax) {   // [2t]: deepest list position any pixel of the tile composited (the backward's walk starts
+                       // there); [2t + 1]: (entry, quadrant) pairs evaluated: pairs / walk ~ 1 means small splats
         int lm = 0;
 #pragma unroll
         for (int q = 0; q < QPW; ++q) lm = max(lm, inside[q] ? last[q] : 0);
         lm = wave_max_i(lm);
-        if (lane == 0 && lm > 0) atomicMax(tile_kmax + tile, lm);
+        if (lane == 0 && lm > 0) atomicMax(tile_kmax + 2 * tile, lm);
+        if (lane == 0 && n_eval > 0) atomicAdd(tile_kmax + 2 * tile + 1, n_eval);
     }
 #pragma unroll
     for (int q = 0; q < QPW; ++q) {
@@ -762,7 +766,7 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     const Rec *rows = (const Rec *)recs_ws;
     const Rec *stream_recs = rows + n;
-    if (tile_kmax) SGN_HIP_CHECK(hipMemsetAsync(tile_kmax, 0, sizeof(int32_t) * tiles_x * tiles_y, s));
+    if (tile_kmax) SGN_HIP_CHECK(hipMemsetAsync(tile_kmax, 0, sizeof(int32_t) * 2 * tiles_x * tiles_y, s));
     sgn_timing_begin(SGN_T_RASTER_FWD, s);
 #define SGN_LAUNCH_FWD(EX, GA, Q, AD)                                                                                \
     hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \

@@ -364,6 +364,7 @@ def _bin_finish(st):
 
 
 tile_order_enabled = True
+small_splat_q16 = 26      # backward: tiles with < 26/16 evaluated (entry, quadrant) pairs per walked entry -> 4 waves
 _order_cache = {"bins": None, "order": None}
 
 
@@ -377,7 +378,8 @@ def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = Non
         return _order_cache["order"]
     n_tiles = tile_bins.shape[0]
     order = torch.empty(n_tiles + 1, dtype=torch.int32, device=tile_bins.device)
-    L.check(L.load().sgn_tile_order(n_tiles, L.ptr(tile_bins), L.ptr(tile_kmax), int(long_thresh), L.ptr(order),
+    L.check(L.load().sgn_tile_order(n_tiles, L.ptr(tile_bins), L.ptr(tile_kmax), int(long_thresh),
+                                    int(small_splat_q16) if tile_kmax is not None else 0, L.ptr(order),
                                     L.stream_ptr()), "sgn_tile_order")
     if tile_kmax is None:
         _order_cache["bins"], _order_cache["order"] = tile_bins, order
@@ -587,7 +589,7 @@ class _RasterizeGaussians(Function):
             if not rows_built:
                 recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
             order = _tile_order(tile_bins)
-            tile_kmax = torch.empty(tile_bins.shape[0], dtype=torch.int32, device=dev)
+            tile_kmax = torch.empty(tile_bins.shape[0], 2, dtype=torch.int32, device=dev)   # walk depth, pairs
             L.check(lib.sgn_raster_fwd(
                 img_height, img_width, block_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), id_lo, id_hi,

@@ -368,7 +368,7 @@ def test_tile_order_is_a_permutation_longest_first_and_changes_nothing(hip):
     start = torch.cumsum(lens, 0) - lens
     bins = torch.stack([start, start + lens], 1).to(torch.int32).to(DEV)
     order = torch.empty(bins.shape[0] + 1, dtype=torch.int32, device=DEV)
-    L.check(L.load().sgn_tile_order(bins.shape[0], L.ptr(bins), None, 512, L.ptr(order), L.stream_ptr()),
+    L.check(L.load().sgn_tile_order(bins.shape[0], L.ptr(bins), None, 512, 0, L.ptr(order), L.stream_ptr()),
             "sgn_tile_order")
     assert int(order[-1]) == int((lens >= 512).sum())                # n_long: 512 is a class boundary
     o = order[:-1].cpu().long()
