@@ -234,7 +234,8 @@ int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *cand_lo_hos
  * tile_stats (sgn_raster_fwd's output) - the reverse-walk length the backward will see; with small_q16 > 0 a tile whose
  * forward evaluated fewer than small_q16 / 16 (entry, quadrant) pairs per walked entry (small splats) counts as long.
  * Results do not depend on the order; on skewed content it removes the tail of late-starting long tiles, and n_long
- * drives the backward's two-kernel adaptive scheme (sgn_raster_bwd).  `order` has n_tiles + 1 entries. */
+ * drives the backward's two-kernel adaptive scheme (sgn_raster_bwd).  `order` has n_tiles + 2 entries (the last one is
+ * a work cursor sgn_raster_bwd's persistent kernel advances: one order buffer serves ONE backward launch). */
 int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_stats, int long_thresh, int small_q16,
                    int32_t *order, sgn_stream_t stream);
 

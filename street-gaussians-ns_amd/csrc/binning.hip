@@ -753,6 +753,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int
             if (b >= b_long) n_long = run;       // classes >= the threshold's class form a prefix of the order
         }
         order[n_tiles] = n_long;
+        order[n_tiles + 1] = 0;              // work cursor of the backward's persistent long-walk kernel
     }
     __syncthreads();
 #pragma unroll

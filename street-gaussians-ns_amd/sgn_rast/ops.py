@@ -377,7 +377,7 @@ def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = Non
     if tile_kmax is None and _order_cache["bins"] is tile_bins:
         return _order_cache["order"]
     n_tiles = tile_bins.shape[0]
-    order = torch.empty(n_tiles + 1, dtype=torch.int32, device=tile_bins.device)
+    order = torch.empty(n_tiles + 2, dtype=torch.int32, device=tile_bins.device)   # permutation, n_long, cursor
     L.check(L.load().sgn_tile_order(n_tiles, L.ptr(tile_bins), L.ptr(tile_kmax), int(long_thresh),
                                     int(small_splat_q16) if tile_kmax is not None else 0, L.ptr(order),
                                     L.stream_ptr()), "sgn_tile_order")

@@ -367,11 +367,11 @@ def test_tile_order_is_a_permutation_longest_first_and_changes_nothing(hip):
     lens = lens[torch.randperm(lens.numel(), generator=g)]
     start = torch.cumsum(lens, 0) - lens
     bins = torch.stack([start, start + lens], 1).to(torch.int32).to(DEV)
-    order = torch.empty(bins.shape[0] + 1, dtype=torch.int32, device=DEV)
+    order = torch.empty(bins.shape[0] + 2, dtype=torch.int32, device=DEV)
     L.check(L.load().sgn_tile_order(bins.shape[0], L.ptr(bins), None, 512, 0, L.ptr(order), L.stream_ptr()),
             "sgn_tile_order")
-    assert int(order[-1]) == int((lens >= 512).sum())                # n_long: 512 is a class boundary
-    o = order[:-1].cpu().long()
+    assert int(order[-2]) == int((lens >= 512).sum()) and int(order[-1]) == 0   # n_long (512: class boundary), cursor
+    o = order[:-2].cpu().long()
     assert torch.equal(torch.sort(o).values, torch.arange(bins.shape[0]))
     cls = torch.where(lens[o] > 0, 1 + 2 * torch.floor(torch.log2(lens[o].clamp_min(1).double())).long(), 0)
     assert bool((cls[1:] <= cls[:-1] + 1).all()) and int(lens[o][0]) >= int(lens.max()) // 2
