@@ -591,8 +591,8 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
 //           in-kernel adaptive split when ADAPT).
 //   MODE 1: "short" half of the two-kernel adaptive scheme: one wave per tile (QPW = 4); block b takes tile
 //           order[b] and leaves the first n_long = order[n_tiles] entries (the long walks) to MODE 2.
-//   MODE 2: "long" half: four lean waves per tile (QPW = 1, half the registers of the QPW = 4 body), a fixed grid of
-//           persistent waves striding over the (tile, quadrant) items of the n_long longest walks, longest first.
+//   MODE 2: "long" half: four lean waves per tile (QPW = 1, half the registers of the QPW = 4 body) over the n_long
+//           longest walks, longest first.
 // Why two kernels: splitting a long walk over four waves INSIDE the QPW = 4 kernel keeps that kernel's register
 // budget and its per-slot control flow (street scene: 0.93 ms); the QPW = 1 body on the same tiles takes 0.59 ms,
 // but costs 1.6x on tiles whose walks are short (benchmark scene: 0.52 vs 0.33 ms), where one wave per tile means one
@@ -628,20 +628,14 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                                                          grad_ws, dbg, adapt_thresh, batch_thresh);
     } else {
         static_assert(QPW == 1 && !ADAPT, "long tiles: four lean waves per tile");
-        // persistent waves pull (tile, quadrant) items, longest walks first, from a shared cursor: with a static
-        // stride the wave that drew the longest item of every round finished last (0.75 vs 0.57 ms on the street
-        // scene); the cursor lives behind the order (order[n_tiles + 1], zeroed by sgn_tile_order)
-        const int n_items = 4 * tile_order[n_tiles];
-        int *cursor = const_cast<int *>(tile_order) + n_tiles + 1;
-        for (;;) {
-            int i = 0;
-            if (threadIdx.x == 0) i = atomicAdd(cursor, 1);
-            i = __builtin_amdgcn_readfirstlane(i);
-            if (i >= n_items) break;
-            raster_bwd_tile<EXACT, REDUCE, GATHER, 1, false>(tile_order[i >> 2], i & 3, W, H, B, tiles_x, bins, recs,
-                                                             ids, bg, final_T, final_idx, v_out, v_out_alpha,
-                                                             alpha_clamp, grad_ws, dbg, adapt_thresh, batch_thresh);
-        }
+        // one workgroup per (tile, quadrant) of the n_long longest walks, longest first; the hardware's own dispatch
+        // balances them.  (Persistent waves were tried: a static stride left the wave with the longest item of every
+        // round last, 0.75 vs 0.57 ms on the street scene; a shared atomic cursor serialised on its one address,
+        // +90 us even when there was nothing to do.)  Workgroups beyond the long prefix exit at once.
+        if ((int)blockIdx.x >= 4 * tile_order[n_tiles]) return;
+        raster_bwd_tile<EXACT, REDUCE, GATHER, 1, false>(tile_order[blockIdx.x >> 2], blockIdx.x & 3, W, H, B, tiles_x,
+                                                         bins, recs, ids, bg, final_T, final_idx, v_out, v_out_alpha,
+                                                         alpha_clamp, grad_ws, dbg, adapt_thresh, batch_thresh);
     }
 }
 
@@ -831,7 +825,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         const Rec *rows = (const Rec *)recs_ws;
         const Rec *stream_recs = rows + n;
         const int n_tiles = tiles_x * tiles_y;
-        const int long_grid = n_tiles * 4 < 8192 ? n_tiles * 4 : 8192;   // persistent waves of the long-walk kernel
+        const int long_grid = n_tiles * 4;   // the long-walk kernel: workgroups beyond 4 * n_long exit at once
         sgn_timing_begin(SGN_T_RASTER_BWD, s);
 #define SGN_BWD_ARGS(GA)                                                                                         \
     img_w, img_h, block_width, tiles_x, n_tiles, (const int2 *)tile_bins, GA ? rows : stream_recs,               \
