@@ -287,7 +287,10 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                                                opts->waves_bwd == 0 its first n_long tiles (walks >= adapt_bwd) run four
                                                lean waves per tile, persistent and longest first, the rest one wave per
                                                tile; NULL = in-kernel split of long walks*/,
-                   const sgn_raster_opts *opts, sgn_stream_t stream);
+                   const sgn_raster_opts *opts, sgn_stream_t stream,
+                   sgn_stream_t aux_stream /*NULL, or a second stream of the same device: the two halves of the
+                                             adaptive scheme touch disjoint tiles and then run concurrently (forked
+                                             behind `stream`'s queue, joined before the gradients are unpacked)*/);
 
 /* pytorch3d.transforms.quaternion_multiply as object2world_gs uses it (sgn_splatfacto_scene_graph.py:416): Hamilton
  * product a (x) b, real part first, result standardised to a non-negative real part.  `a` is EITHER one quaternion

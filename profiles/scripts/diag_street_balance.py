@@ -44,10 +44,15 @@ def timed(tag, **opt):
     print(f"  {tag:44s} fwd {f[1] / f[0]:.3f} ms  bwd {b[1] / b[0]:.3f} ms", flush=True)
 
 
-timed("default (small-splat rule 26/16)")
-for q in (0, 20, 24, 32, 40, 64):
+timed("default (two kernels on two streams, small-splat rule 26/16)")
+ops.concurrent_backward = False
+timed("one stream")
+ops.concurrent_backward = True
+for q in (0, 40, 64):
     ops.small_splat_q16 = q
     timed(f"small-splat rule {q}/16")
 ops.small_splat_q16 = 26
+timed("long >= 128", adapt_bwd=128)
+timed("long >= 512", adapt_bwd=512)
 timed("bwd 4 waves everywhere", waves_bwd=4)
 timed("bwd 1 wave everywhere", waves_bwd=1)

@@ -21,6 +21,25 @@ void sgn_set_error(const char *fmt, ...) {
 extern "C" __attribute__((visibility("default"))) const char *sgn_last_error(void) { return g_err; }
 extern "C" __attribute__((visibility("default"))) int sgn_version(void) { return 100; }
 
+// ---------------------------------------------------------------- fork / join events
+// Two untimed events per (thread, device) for entry points that fan work out to a caller-provided auxiliary stream
+// (sgn_raster_bwd).  Created on first use and kept: a resource cache like the error string above, not configuration.
+int sgn_fork_events(hipEvent_t *fork, hipEvent_t *join) {
+    struct Pair { int dev; hipEvent_t a, b; };
+    static thread_local std::vector<Pair> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    for (auto &p : cache)
+        if (p.dev == dev) { *fork = p.a; *join = p.b; return 0; }
+    Pair p;
+    p.dev = dev;
+    if (hipEventCreateWithFlags(&p.a, hipEventDisableTiming) != hipSuccess) return 2;
+    if (hipEventCreateWithFlags(&p.b, hipEventDisableTiming) != hipSuccess) { (void)hipEventDestroy(p.a); return 3; }
+    cache.push_back(p);
+    *fork = p.a; *join = p.b;
+    return 0;
+}
+
 // ---------------------------------------------------------------- kernel timing (bench/profiles)
 // Opt-in: when enabled every timed launch is bracketed by hipEventRecord on the SAME stream the
 // kernel is launched on; sgn_timing_get() synchronises the recorded events and sums them.

@@ -802,7 +802,8 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
                               const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd,
                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
                               size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
-                              const int32_t *tile_order, const sgn_raster_opts *opts, sgn_stream_t stream) {
+                              const int32_t *tile_order, const sgn_raster_opts *opts, sgn_stream_t stream,
+                              sgn_stream_t aux_stream) {
     const sgn_raster_opts o = resolve_opts(opts);
     SGN_ARG_CHECK(!window || (0 <= id_lo && id_lo <= id_hi && id_hi <= n), -9);
     SGN_ARG_CHECK(img_h > 0 && img_w > 0 && n >= 0, -1);
@@ -826,6 +827,15 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         const Rec *stream_recs = rows + n;
         const int n_tiles = tiles_x * tiles_y;
         const int long_grid = n_tiles * 4;   // the long-walk kernel: workgroups beyond 4 * n_long exit at once
+        // fork: the long-walk kernel goes to the auxiliary stream (if any) behind everything queued so far
+        const bool two_kernel = o.waves_bwd == 0 && tile_order != nullptr && block_width == 16;
+        hipStream_t s2 = s;
+        hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+        if (two_kernel && aux_stream != nullptr && (hipStream_t)aux_stream != s && sgn_fork_events(&ev_fork, &ev_join) == 0) {
+            s2 = (hipStream_t)aux_stream;
+            SGN_HIP_CHECK(hipEventRecord(ev_fork, s));
+            SGN_HIP_CHECK(hipStreamWaitEvent(s2, ev_fork, 0));
+        }
         sgn_timing_begin(SGN_T_RASTER_BWD, s);
 #define SGN_BWD_ARGS(GA)                                                                                         \
     img_w, img_h, block_width, tiles_x, n_tiles, (const int2 *)tile_bins, GA ? rows : stream_recs,               \
@@ -839,8 +849,9 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         if (o.waves_bwd == 4) SGN_LAUNCH_BWDQ(EX, RM, GA, 1, false);                                             \
         else if (o.waves_bwd == 1) SGN_LAUNCH_BWDQ(EX, RM, GA, 4, false);                                        \
         else if (tile_order == nullptr || block_width != 16) SGN_LAUNCH_BWDQ(EX, RM, GA, 4, true);               \
-        else {   /* two-kernel adaptive scheme: order[0..n_long) = long walks, the rest short */                 \
-            hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, 1, false, 2>), dim3(long_grid), dim3(64), 0, s,    \
+        else {   /* two-kernel adaptive scheme: order[0..n_long) = long walks, the rest short; the two halves */ \
+                 /* touch disjoint tiles and run CONCURRENTLY when the caller lends a second stream           */ \
+            hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, 1, false, 2>), dim3(long_grid), dim3(64), 0, s2,   \
                                SGN_BWD_ARGS(GA));                                                                \
             hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, 4, false, 1>), dim3(n_tiles), dim3(64), 0, s,      \
                                SGN_BWD_ARGS(GA));                                                                \
@@ -856,6 +867,10 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
 #undef SGN_LAUNCH_BWD
 #undef SGN_LAUNCH_BWDQ
 #undef SGN_BWD_ARGS
+        if (s2 != s) {   // join: the unpack (and everything after) waits for the long-walk kernel
+            SGN_HIP_CHECK(hipEventRecord(ev_join, s2));
+            SGN_HIP_CHECK(hipStreamWaitEvent(s, ev_join, 0));
+        }
         sgn_timing_end(SGN_T_RASTER_BWD, s);
     }
     sgn_timing_begin(SGN_T_UNPACK, s);

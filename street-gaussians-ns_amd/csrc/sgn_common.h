@@ -12,6 +12,7 @@ void sgn_set_error(const char *fmt, ...);
 int sgn_timing_enabled();
 void sgn_timing_begin(int slot, void *stream);
 void sgn_timing_end(int slot, void *stream);
+int sgn_fork_events(hipEvent_t *fork, hipEvent_t *join);   // api.cpp: cached per (thread, device)
 
 #define SGN_ARG_CHECK(cond, code)                                              \
     do {                                                                       \

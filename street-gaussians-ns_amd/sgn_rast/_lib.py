@@ -70,7 +70,7 @@ SIGNATURES = {
     "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "sgn_raster_bwd_workspace_bytes": (_sz, [_i]),
     "sgn_raster_bwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
-                            _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp, _vp, _vp]),
+                            _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None
@@ -199,6 +199,18 @@ def ptr(t):
 
 def stream_ptr() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_aux_streams: dict = {}
+
+
+def aux_stream_ptr(device) -> C.c_void_p:
+    """A second stream of ``device`` the library may fan independent kernels out to (sgn_raster_bwd runs the two halves
+    of its adaptive scheme concurrently); made once per device."""
+    dev = torch.device(device)
+    if dev not in _aux_streams:
+        _aux_streams[dev] = torch.cuda.Stream(device=dev)
+    return C.c_void_p(_aux_streams[dev].cuda_stream)
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:

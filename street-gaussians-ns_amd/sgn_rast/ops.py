@@ -364,6 +364,7 @@ def _bin_finish(st):
 
 
 tile_order_enabled = True
+concurrent_backward = True   # lend sgn_raster_bwd a second stream: its short-walk and long-walk kernels overlap
 small_splat_q16 = 26      # backward: tiles with < 26/16 evaluated (entry, quadrant) pairs per walked entry -> 4 waves
 _order_cache = {"bins": None, "order": None}
 
@@ -642,7 +643,8 @@ class _RasterizeGaussians(Function):
                 ctx.id_range[1], ctx.window, L.ptr(background), L.ptr(final_Ts),
                 L.ptr(final_idx), L.ptr(v_out_img), L.ptr(v_out_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
                 L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
-                L.ptr(gws), gws.numel(), L.ptr(order), ro_ptr, L.stream_ptr()), "sgn_raster_bwd")
+                L.ptr(gws), gws.numel(), L.ptr(order), ro_ptr, L.stream_ptr(),
+                L.aux_stream_ptr(dev) if concurrent_backward else None), "sgn_raster_bwd")
         v_opacity = v_opacity.reshape(ctx.opacity_shape)
         # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha)
         return v_xy, None, None, v_conic, None, v_colors, v_opacity, None, None, None, None, None, None, None
