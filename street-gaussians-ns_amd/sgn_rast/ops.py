@@ -365,7 +365,7 @@ def _bin_finish(st):
 
 tile_order_enabled = True
 concurrent_backward = True   # lend sgn_raster_bwd a second stream: its short-walk and long-walk kernels overlap
-small_splat_q16 = 26      # backward: tiles with < 26/16 evaluated (entry, quadrant) pairs per walked entry -> 4 waves
+small_splat_q16 = 0       # experimental: > 0 sends tiles with < q/16 evaluated (entry, quadrant) pairs per walked entry to the 4-waves kernel (no gain measured: profiles/r02_street_balance.md)
 _order_cache = {"bins": None, "order": None}
 
 
