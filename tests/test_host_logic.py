@@ -183,3 +183,44 @@ def test_quaternion_multiply_shim_on_cpu_is_pytorch3d_formula():
             sys.modules.pop(name, None)
             if mod is not None:
                 sys.modules[name] = mod
+
+
+def test_ply_round_trip_and_inria_field_order(tmp_path):
+    from sgn_rast import io, scenes
+    cam = scenes.make_camera(64, 48, 64.0)
+    P = scenes.make_gaussians(500, cam, seed=3)
+    P["means"][7, 1] = float("nan")                                  # dropped on export, like the reference does
+    path = str(tmp_path / "point_cloud.ply")
+    assert io.write_ply(path, P) == 499
+    head = open(path, "rb").read(2000).split(b"end_header")[0].decode()
+    props = [ln.split()[-1] for ln in head.splitlines() if ln.startswith("property")]
+    assert props[:9] == ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"]
+    assert props[9] == "f_rest_0" and props[9 + 45 - 1] == "f_rest_44"                # 15 coefficients x 3 channels
+    assert props[-8:] == ["opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"]
+    assert "format binary_little_endian 1.0" in head and "element vertex 499" in head
+    Q = io.read_ply(path)
+    keep = torch.arange(500) != 7
+    for k in P:
+        assert torch.equal(Q[k], P[k][keep]), k
+    # channel-major f_rest (the INRIA order): f_rest_1 is coefficient 1 of channel 0, f_rest_15 coefficient 0 of channel 1
+    import numpy as np
+    raw = np.frombuffer(open(path, "rb").read().split(b"end_header\n")[1], dtype="<f4").reshape(499, -1)
+    assert raw[0, 9 + 1] == float(P["features_rest"][0, 1, 0]) and raw[0, 9 + 15] == float(P["features_rest"][0, 0, 1])
+
+
+def test_checkpoint_state_names_and_size_changing_load():
+    from sgn_rast import io, scenes
+    cam = scenes.make_camera(64, 48, 64.0)
+    bg, obj = scenes.make_gaussians(300, cam, seed=1), scenes.make_gaussians(120, cam, seed=2)
+    st = io.model_state({"background": bg, "object_7": obj})
+    assert "all_models.background.gauss_params.scales" in st and "all_models.object_7.gauss_params.opacities" in st
+    st["all_models.background.env_map.base"] = torch.zeros(6, 2, 2, 3)        # foreign keys are ignored
+    back = io.load_model_state(st)
+    assert set(back) == {"background", "object_7"} and back["object_7"]["means"].shape[0] == 120
+    for k in bg:
+        assert torch.equal(back["background"][k], bg[k]) and back["background"][k].requires_grad
+    single = io.load_model_state({k: v for k, v in zip(["means", "scales", "quats", "features_dc", "features_rest",
+                                                        "opacities"], [bg["means"], bg["log_scales"], bg["quats"],
+                                                                       bg["features_dc"], bg["features_rest"],
+                                                                       bg["opacity_logits"]])})   # old flat names
+    assert torch.equal(single[""]["log_scales"], bg["log_scales"])

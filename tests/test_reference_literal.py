@@ -246,3 +246,30 @@ def test_call_traces_literal_equals_replay_equals_golden(ns):
     for name, calls in (("single", lit), ("scene_graph", tr.calls)):
         with open(os.path.join(GOLDEN, f"calltrace_{name}.json")) as f:
             assert canonical(json.load(f)) == canonical(calls), f"golden trace {name} is stale: run make_calltrace.py"
+
+
+def test_reference_model_loads_a_state_written_by_sgn_rast_io(ns):
+    """`sgn_rast.io.model_state` uses the reference's key names: its own `load_state_dict` (size-changing,
+    sgn_splatfacto.py:425-437; per-sub-model routing, sgn_splatfacto_scene_graph.py:393-400) accepts it."""
+    from sgn_rast import io, scenes
+    cam = scenes.make_camera(W, H, FOCAL)
+    big = scenes.make_gaussians(777, cam, seed=9, z_range=(1.0, 5.0))
+    _, raw = _single_scene()
+    model = refhost.build_single(ns, raw, sky_res=0)                         # 3000 Gaussians
+    with refhost.cpu_as_cuda():
+        model.load_state_dict(io.model_state({"": big}), strict=False)
+    assert model.num_points == 777
+    for ours, ref in io.REF_NAMES.items():
+        assert torch.equal(model.gauss_params[ref].detach(), big[ours]), ref
+    cam2, models, poses = _graph_scene()
+    graph, _ = refhost.build_scene_graph(ns, models, poses)
+    new = {"background": scenes.make_gaussians(500, cam2, seed=4)}
+    for k, n_k in (("object_t1", 40), ("object_t2", 90), ("object_t3", 10)):   # a checkpoint holds every sub-model
+        new[k] = scenes.make_gaussians(n_k, cam2, seed=5)
+        new[k]["features_dc"] = torch.randn(n_k, 5, 3)
+    state = io.model_state(new)
+    state = {("_model." + k): v for k, v in state.items()}                   # nerfstudio's pipeline prefix
+    with refhost.cpu_as_cuda():
+        graph.load_state_dict({k[len("_model."):]: v for k, v in state.items()}, strict=False)
+    assert graph.all_models["background"].num_points == 500 and graph.all_models["object_t2"].num_points == 90
+    assert torch.equal(graph.all_models["object_t2"].gauss_params["features_dc"].detach(), new["object_t2"]["features_dc"])
