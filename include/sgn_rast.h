@@ -205,17 +205,11 @@ size_t sgn_bin_prepare_workspace_bytes(int n);
  * count) is written by sgn_bin_prepare in id order and read back by sgn_bin_intersect: the rank-order emission
  * gathers one sector per Gaussian instead of five arrays. */
 #define SGN_BIN_RECORD_FLOATS 8
-/* The depth ranking alone (stable sort of the Gaussians by depth bits, culled ones last): it needs depths and radii
- * only, so a caller may run it as soon as the projection is queued - e.g. on a second stream beside the SH evaluation -
- * and pass the result to sgn_bin_prepare with rank_given = 1. */
-size_t sgn_depth_rank_workspace_bytes(int n);
-int sgn_depth_rank(int n, const float *depths, const int32_t *radii, int32_t *gid_by_rank /*[n] out*/, void *ws,
-                   size_t ws_bytes, sgn_stream_t stream);
 int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii, const float *conics,
                     const float *opacities, int opacity_is_logit, int cull, int tiles_x, int tiles_y,
                     int block_width, int32_t *cum_by_rank /*[n] inclusive scan of kept-tile counts, rank order*/,
-                    int32_t *gid_by_rank /*[n]: out, or in when rank_given*/, int rank_given,
-                    float *bin_records /*[n,8] out*/, void *ws, size_t ws_bytes, sgn_stream_t stream);
+                    int32_t *gid_by_rank /*[n]*/, float *bin_records /*[n,8] out*/, void *ws, size_t ws_bytes,
+                    sgn_stream_t stream);
 size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect);
 int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                       const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,

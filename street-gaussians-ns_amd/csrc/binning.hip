@@ -365,25 +365,13 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
     const Ellipse E = make_ellipse(R.gx, R.gy, R.a, R.b, R.c, R.s);
     R.cnt = tiles_of<false>(live, E, mnx, mny, mxx, mxy, i, 0, tiles_x, block, NoOut{});
     if (i < n) {
-        if (dkeys) {                    // nullptr: the depth rank was computed ahead of time (sgn_depth_rank)
-            dkeys[i] = R.rad > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;  // culled splats sort last
-            dvals[i] = i;
-        }
+        dkeys[i] = R.rad > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;  // culled splats sort last
+        dvals[i] = i;
         cnt_gid[i] = R.cnt;             // dense copy: the rank-order gather below then works on 4 B/Gaussian
         float4 *o = reinterpret_cast<float4 *>(recs + i);
         o[0] = make_float4(R.gx, R.gy, R.a, R.b);
         o[1] = make_float4(R.c, R.s, __int_as_float(R.rad), __int_as_float(R.cnt));
     }
-}
-
-// depth sort keys alone (sgn_depth_rank): the same keys bin_count_kernel writes
-__global__ __launch_bounds__(256) void depth_keys_kernel(int n, const float *__restrict__ depths,
-                                                         const int32_t *__restrict__ radii,
-                                                         uint32_t *__restrict__ dkeys, int32_t *__restrict__ dvals) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    dkeys[i] = radii[i] > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
-    dvals[i] = i;
 }
 
 __global__ __launch_bounds__(256) void gather_counts_kernel(int n, const int32_t *__restrict__ gid_by_rank,
@@ -533,37 +521,10 @@ static Cull make_cull(const float *conics, const float *opac, int opac_is_logit,
     return c;
 }
 
-SGN_EXPORT size_t sgn_depth_rank_workspace_bytes(int n) {
-    const size_t nn = (size_t)(n > 0 ? n : 1);
-    return 3 * al256(nn * 4) + sgn_sort_pairs32_ws_bytes(n);
-}
-
-// The depth ranking of the N Gaussians needs depths and radii only - both known the moment the projection is queued,
-// long before the opacities the culling wants.  A caller may run it ahead of time, e.g. on a second stream beside the
-// SH evaluation, and hand the result to sgn_bin_prepare (rank_given = 1).
-SGN_EXPORT int sgn_depth_rank(int n, const float *depths, const int32_t *radii, int32_t *gid_by_rank, void *ws,
-                              size_t ws_bytes, sgn_stream_t stream) {
-    SGN_ARG_CHECK(n >= 0, -1);
-    if (n == 0) return 0;
-    SGN_ARG_CHECK(depths && radii && gid_by_rank && ws, -2);
-    SGN_ARG_CHECK(ws_bytes >= sgn_depth_rank_workspace_bytes(n), -3);
-    hipStream_t s = (hipStream_t)stream;
-    char *p = (char *)ws;
-    uint32_t *dkeys = (uint32_t *)p; p += al256((size_t)n * 4);
-    int32_t *dvals = (int32_t *)p;   p += al256((size_t)n * 4);
-    uint32_t *dkeys_sorted = (uint32_t *)p; p += al256((size_t)n * 4);
-    sgn_timing_begin(SGN_T_SORT, s);
-    hipLaunchKernelGGL(depth_keys_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, depths, radii, dkeys, dvals);
-    sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, p, s);
-    sgn_timing_end(SGN_T_SORT, s);
-    SGN_LAUNCH_CHECK();
-    return 0;
-}
-
 SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii,
                                const float *conics, const float *opacities, int opacity_is_logit, int cull,
                                int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
-                               int32_t *gid_by_rank, int rank_given, float *bin_records, void *ws, size_t ws_bytes,
+                               int32_t *gid_by_rank, float *bin_records, void *ws, size_t ws_bytes,
                                sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
@@ -583,13 +544,11 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     BinRec *recs = reinterpret_cast<BinRec *>(bin_records);
     sgn_timing_begin(SGN_T_MAP, s);
     hipLaunchKernelGGL(bin_count_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, depths, radii, c, tiles_x,
-                       tiles_y, block_width, rank_given ? (uint32_t *)nullptr : dkeys, dvals, recs, cnt_gid);
+                       tiles_y, block_width, dkeys, dvals, recs, cnt_gid);
     sgn_timing_end(SGN_T_MAP, s);
-    if (!rank_given) {
-        sgn_timing_begin(SGN_T_SORT, s);
-        sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
-        sgn_timing_end(SGN_T_SORT, s);
-    }
+    sgn_timing_begin(SGN_T_SORT, s);
+    sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
+    sgn_timing_end(SGN_T_SORT, s);
     sgn_timing_begin(SGN_T_MAP, s);
     hipLaunchKernelGGL(gather_counts_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, gid_by_rank, cnt_gid, cnt_r);
     sgn_timing_end(SGN_T_MAP, s);

@@ -195,59 +195,6 @@ def raise_pending_checks() -> None:
     assert not failed, "quats must be normalized"
 
 
-# ------------------------------------------------------------ early depth rank
-# The depth ranking of the Gaussians (a 4-pass radix sort over N keys, ~0.1 ms) needs depths and radii only, i.e. it can
-# start the moment the projection is queued — the culling that the rest of the binning does wants the opacities, which
-# the reference computes two steps later (SH evaluation, then sigmoid, sgn_splatfacto.py:939-949).  `project_gaussians`
-# therefore starts the ranking on the auxiliary stream, beside the caller's SH evaluation and torch glue, and the next
-# `rasterize_gaussians` on those very tensors picks it up.  Speculative on the drop-in path: if the rasterize call
-# receives other tensors (the scene graph hands in re-concatenated copies), the result is ignored and, after a few
-# misses in a row, the speculation pauses.
-early_rank_enabled = True
-prefetch_on_aux = True      # prefetch_binning (fused path) queues its kernels on the auxiliary stream, beside the SH pass
-_early = {"entry": None, "misses": 0, "pause": 0}
-
-
-def _start_early_rank(depths: torch.Tensor, radii: torch.Tensor) -> None:
-    n = depths.shape[0]
-    if not early_rank_enabled or n == 0 or not depths.is_cuda:
-        return
-    if _early["pause"] > 0:
-        _early["pause"] -= 1
-        return
-    if _early["entry"] is not None:                 # the previous speculation was never used
-        _early["misses"] += 1
-        if _early["misses"] >= 3:
-            _early["misses"], _early["pause"], _early["entry"] = 0, 200, None
-            return
-    dev = depths.device
-    lib = L.load()
-    main, aux = torch.cuda.current_stream(dev), L.aux_stream(dev)
-    aux.wait_stream(main)
-    d, r = depths.detach(), radii.detach()
-    with torch.cuda.stream(aux):
-        gid = torch.empty(n, dtype=torch.int32, device=dev)
-        ws = L.workspace(lib.sgn_depth_rank_workspace_bytes(n), dev)
-        L.check(lib.sgn_depth_rank(n, L.ptr(d), L.ptr(r), L.ptr(gid), L.ptr(ws), ws.numel(),
-                                   C.c_void_p(aux.cuda_stream)), "sgn_depth_rank")
-        done = torch.cuda.Event()
-        done.record(aux)
-    d.record_stream(aux); r.record_stream(aux)
-    _early["entry"] = dict(key=(d.data_ptr(), d._version, r.data_ptr(), n), keep=(d, r, ws), gid=gid, done=done)
-
-
-def _take_early_rank(depths: torch.Tensor, radii: torch.Tensor):
-    """The ranking started by project_gaussians for exactly these tensors, made visible to the current stream."""
-    e = _early["entry"]
-    if e is None or e["key"] != (depths.data_ptr(), depths._version, radii.data_ptr(), depths.shape[0]):
-        return None
-    _early["entry"], _early["misses"] = None, 0
-    main = torch.cuda.current_stream(depths.device)
-    main.wait_event(e["done"])
-    e["gid"].record_stream(main)
-    return e["gid"]
-
-
 def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
                       block_width, clip_thresh: float = 0.01):
     """gsplat/project_gaussians.py project_gaussians (sgn_splatfacto.py:860-873).
@@ -256,11 +203,9 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     ``viewmat`` is the world->camera matrix ([3,4] or [4,4]; only rows 0-2 are read)."""
     assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
     _check_quats(quats)
-    out = _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
-                                  viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
-                                  clip_thresh)
-    _start_early_rank(out[1], out[2])
-    return out
+    return _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
+                                   viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
+                                   clip_thresh)
 
 
 # ----------------------------------------------------------------- binning
@@ -352,29 +297,11 @@ _side = {}   # per device: [pinned int32[4,8] (count + up to 7 deferred-check fl
 
 
 def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
-                       opacity_is_logit, cull, on_aux: bool = False):
+                       opacity_is_logit, cull):
     """First half of the fused binning: depth rank, kept-tile counts, scan — and the asynchronous read-back of the
     intersection count into pinned memory, so the caller may queue independent work behind it before it calls
-    :func:`_bin_finish` (which is where the host waits, for the copy only).  ``on_aux``: queue it on the auxiliary
-    stream (behind everything the current stream holds now), so that it runs BESIDE what the caller queues next."""
+    :func:`_bin_finish` (which is where the host waits, for the copy only)."""
     dev = L.require_device(xys, depths, radii, num_tiles_hit, conics, opacity)
-    args = (num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity, opacity_is_logit,
-            cull)
-    if not (on_aux and int(num_points) > 0):
-        return _bin_prepare_impl(dev, *args)
-    main, aux = torch.cuda.current_stream(dev), L.aux_stream(dev)
-    aux.wait_stream(main)
-    with torch.cuda.stream(aux):
-        st = _bin_prepare_impl(dev, *args)
-    for t in st["keep"][:4] + (depths.detach(),):
-        if t is not None:
-            t.record_stream(aux)
-    st["aux"] = True
-    return st
-
-
-def _bin_prepare_impl(dev, num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
-                      opacity_is_logit, cull):
     lib = L.load()
     n = int(num_points)
     tx, ty = int(tile_bounds[0]), int(tile_bounds[1])
@@ -388,14 +315,13 @@ def _bin_prepare_impl(dev, num_points, xys, depths, radii, num_tiles_hit, tile_b
     conics_c = _f32c(conics) if do_cull else None
     opac_c = _f32c(opacity).reshape(-1) if do_cull else None
     cum_r = torch.empty(n, **i32)
-    early = _take_early_rank(depths, radii)              # depth rank already computed beside the SH evaluation?
-    gid_by_rank = early if early is not None else torch.empty(n, **i32)
+    gid_by_rank = torch.empty(n, **i32)
     bin_recs = torch.empty(n, 8, dtype=torch.float32, device=dev)
     ws = L.workspace(lib.sgn_bin_prepare_workspace_bytes(n), dev)
     L.check(lib.sgn_bin_prepare(n, L.ptr(xys_c), L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(conics_c), L.ptr(opac_c),
                                 int(bool(opacity_is_logit)), do_cull, tx, ty, int(block_width), L.ptr(cum_r),
-                                L.ptr(gid_by_rank), int(early is not None), L.ptr(bin_recs), L.ptr(ws), ws.numel(),
-                                L.stream_ptr()), "sgn_bin_prepare")
+                                L.ptr(gid_by_rank), L.ptr(bin_recs), L.ptr(ws), ws.numel(), L.stream_ptr()),
+            "sgn_bin_prepare")
     if dev not in _side:
         _side[dev] = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]
     pool = _side[dev]
@@ -423,11 +349,6 @@ def _bin_finish(st):
         tile_bins.zero_()
         return 0, torch.zeros(0, **i32), tile_bins
     st["done"].synchronize()
-    if st.get("aux"):                      # prepared on the auxiliary stream: its results become visible here
-        main = torch.cuda.current_stream(st["dev"])
-        main.wait_event(st["done"])
-        for t in (st["cum_r"], st["gid_by_rank"], st["bin_recs"], st["ws"]):
-            t.record_stream(main)
     num_intersects = int(st["pinned"][0])
     failed = any(int(st["pinned"][1 + i]) for i in range(st["n_flags"]))
     assert not failed, "quats must be normalized"
@@ -519,7 +440,7 @@ def prefetch_binning(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
         return
     _drop_pending()
     _bin_pending["state"] = _bin_prepare_async(xys.size(0), xys, depths, radii, num_tiles_hit, tile_bounds, block_width,
-                                               conics, opacity, opacity_is_logit, cull, on_aux=prefetch_on_aux)
+                                               conics, opacity, opacity_is_logit, cull)
     _bin_pending["key"] = key
     _bin_pending["keep"] = tuple(t.detach() for t in tensors)
 
