@@ -250,14 +250,7 @@ __device__ __forceinline__ void row_interval(const Ellipse &E, int ty, int block
     hi = min(hi, t_hi);
 }
 
-#ifndef SGN_ROWS_BIG
-#define SGN_ROWS_BIG 6
-#endif
-constexpr int ROWS_BIG = SGN_ROWS_BIG;   // bboxes taller than this are handled by the whole wave (lane <-> tile row)
-
-// Tiles of one Gaussian per lane (row-major over the bbox, one kept interval per tile row).  EMIT = false: returns
-// the number of kept tiles; EMIT = true: also writes the (tile, gaussian id) pairs starting at `cur`.
-// Must be called by all 64 lanes of the wave (tall bboxes are shared out over the lanes).
+// Output sinks of the tile expansion below.
 struct NoOut {
     __device__ __forceinline__ void operator()(int, uint32_t, int32_t) const {}
 };
@@ -283,61 +276,92 @@ struct LdsOut {          // wave-local staging: positions relative to the wave's
     }
 };
 
+// wave64 inclusive scan on the DPP network (no LDS crossbar): Hillis-Steele inside each 16-lane row, then lane 15
+// of rows 0 / 2 into rows 1 / 3 and lane 31 into rows 2 and 3.  All 64 lanes must be active.
+__device__ __forceinline__ int wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// LDS traffic between lanes of ONE wave: the hardware retires a wave's LDS operations in order, the fence only
+// keeps the compiler from moving them across
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Per-wave scratch of the flattened row list: the Gaussians' row_interval constants, looked up by the lanes that
+// own their tile rows.
+struct FlatScratch {
+    float4 pa[64];    // gx, gy, b, 1/a
+    float4 pb[64];    // 2as, D, y_ext, y_at_xmax
+    int4 pc[64];      // mnx, mxx, mny, valid
+    int gid[64];      // gaussian id (emission)
+    int rowend[64];   // inclusive prefix of the row counts (a Gaussian without rows repeats its predecessor)
+    int acc[64];      // kept tiles per Gaussian (count)
+};
+
+// Kept tiles of the 64 Gaussians of a wave, one Gaussian per lane on entry: row-major over each bbox, one kept
+// interval per tile row.  EMIT = false: returns the lane's number of kept tiles; EMIT = true: writes the wave's
+// (tile, gaussian id) pairs from output slot `base` on (the Gaussians' runs follow each other in lane order, so
+// slots come from a running scan and agree with the counts by construction: same code).
+// Heights vary widely inside a wave (1-3 rows typically, 7-20 for one Gaussian in ten, the whole image for a few),
+// so the wave does not loop per lane: all tile rows are laid end to end into one list and handed out 64 at a time,
+// lane <-> (Gaussian, row) by binary search in the prefix of the row counts; every lane evaluates one row_interval
+// per round whatever the mix.  (Round 1 looped over rows per lane and took the tall boxes one at a time with the
+// whole wave: 80.7 / 39.4 us emission / count on the benchmark scene against 41.0 / 25.4 us for this form,
+// profiles/experiments/r01_tall_quad_notes.md, profiles/r02k_*.)
+// Must be called by all 64 lanes of the wave.
 template <bool EMIT, class Out>
 __device__ __forceinline__ int tiles_of(bool live, const Ellipse &E, int mnx, int mny, int mxx, int mxy, int gid,
-                                        int cur, int tiles_x, int block, const Out &out) {
+                                        int base, int tiles_x, int block, FlatScratch &fs, const Out &out) {
     const int lane = threadIdx.x & 63;
-    const int w = mxx - mnx, h = (live && w > 0) ? mxy - mny : 0;
-    int cnt = 0;
-    if (h > 0 && h <= ROWS_BIG) {
-        for (int ty = mny; ty < mxy; ++ty) {
-            int lo, hi;
-            row_interval(E, ty, block, mnx, mxx, lo, hi);
-            for (int tx = lo; tx <= hi; ++tx) {
-                if (EMIT) {
-                    out(cur, (uint32_t)(ty * tiles_x + tx), gid);
-                    ++cur;
-                }
-                ++cnt;
-            }
-        }
-    }
-    // tall bboxes: one Gaussian at a time, lane <-> tile row, wave prefix sum of the row counts
-    unsigned long long big = __ballot(h > ROWS_BIG);
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        Ellipse B;
-        B.gx = __shfl(E.gx, src, 64); B.gy = __shfl(E.gy, src, 64); B.a = __shfl(E.a, src, 64);
-        B.b = __shfl(E.b, src, 64); B.inv_a = __shfl(E.inv_a, src, 64); B.two_as = __shfl(E.two_as, src, 64);
-        B.D = __shfl(E.D, src, 64); B.y_ext = __shfl(E.y_ext, src, 64); B.y_at_xmax = __shfl(E.y_at_xmax, src, 64);
-        B.valid = __shfl(E.valid, src, 64);
-        const int bmnx = __shfl(mnx, src, 64), bmxx = __shfl(mxx, src, 64), bmny = __shfl(mny, src, 64);
-        const int bh = __shfl(h, src, 64), bgid = __shfl(gid, src, 64);
-        int base = __shfl(cur, src, 64);
-        int total = 0;
-        for (int r0 = 0; r0 < bh; r0 += 64) {
-            const int ty = bmny + r0 + lane;
-            int lo = 0, hi = -1;
-            if (r0 + lane < bh) row_interval(B, ty, block, bmnx, bmxx, lo, hi);
-            const int c = max(hi - lo + 1, 0);
-            int incl = c;                                   // inclusive prefix over the 64 rows of this chunk
+    const int h = (live && mxx > mnx) ? mxy - mny : 0;
+    const int rend = wave_incl_scan_dpp(h);
+    const int n_rows = __builtin_amdgcn_readlane(rend, 63);
+    if (n_rows == 0) return 0;
+    fs.pa[lane] = make_float4(E.gx, E.gy, E.b, E.inv_a);
+    fs.pb[lane] = make_float4(E.two_as, E.D, E.y_ext, E.y_at_xmax);
+    fs.pc[lane] = make_int4(mnx, mxx, mny, E.valid);
+    fs.rowend[lane] = rend;
+    if (EMIT) fs.gid[lane] = gid; else fs.acc[lane] = 0;
+    wave_lds_fence();
+    int pos0 = base;                                         // output slot of this round's first tile
+    for (int r0 = 0; r0 < n_rows; r0 += 64) {                // wave-uniform trip count (n_rows is an SGPR)
+        const int item = r0 + lane;
+        const bool valid = item < n_rows;
+        int g = 0;                                           // first Gaussian whose rowend exceeds item
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const int u = __shfl_up(incl, d, 64);
-                if (lane >= d) incl += u;
-            }
-            if (EMIT) {
-                int pos = base + incl - c;
-                for (int tx = lo; tx <= hi; ++tx, ++pos) out(pos, (uint32_t)(ty * tiles_x + tx), bgid);
-            }
-            const int chunk_total = __shfl(incl, 63, 64);
-            base += chunk_total;
-            total += chunk_total;
+        for (int step = 32; step; step >>= 1)
+            if (fs.rowend[g + step - 1] <= item) g += step;
+        const int first = g ? fs.rowend[g - 1] : 0;          // list index of that Gaussian's first row
+        const float4 pa = fs.pa[g], pb = fs.pb[g];
+        const int4 pc = fs.pc[g];
+        Ellipse B;
+        B.gx = pa.x; B.gy = pa.y; B.a = 0.f; B.b = pa.z; B.inv_a = pa.w;
+        B.two_as = pb.x; B.D = pb.y; B.y_ext = pb.z; B.y_at_xmax = pb.w; B.valid = pc.w;
+        const int ty = pc.z + item - first;
+        int lo = 0, hi = -1;
+        if (valid) row_interval(B, ty, block, pc.x, pc.y, lo, hi);
+        const int c = max(hi - lo + 1, 0);
+        if (EMIT) {
+            const int incl = wave_incl_scan_dpp(c);
+            const int val = fs.gid[g];
+            int pos = pos0 + incl - c;
+            for (int tx = lo; tx <= hi; ++tx, ++pos) out(pos, (uint32_t)(ty * tiles_x + tx), val);
+            pos0 += __builtin_amdgcn_readlane(incl, 63);
+        } else if (c > 0) {
+            atomicAdd(&fs.acc[g], c);
         }
-        if (lane == src) cnt = total;
     }
-    return cnt;
+    if (EMIT) return 0;
+    wave_lds_fence();
+    return h > 0 ? fs.acc[lane] : 0;
 }
 
 // lane = Gaussian id (coalesced reads): depth sort key, bin record and its kept-tile count in one pass
@@ -347,6 +371,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
                                                         int tiles_y, int block, uint32_t *__restrict__ dkeys,
                                                         int32_t *__restrict__ dvals, BinRec *__restrict__ recs,
                                                         int32_t *__restrict__ cnt_gid) {
+    __shared__ FlatScratch scratch[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     int mnx = 0, mny = 0, mxx = 0, mxy = 0;
     BinRec R;
@@ -363,7 +388,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
         }
     }
     const Ellipse E = make_ellipse(R.gx, R.gy, R.a, R.b, R.c, R.s);
-    R.cnt = tiles_of<false>(live, E, mnx, mny, mxx, mxy, i, 0, tiles_x, block, NoOut{});
+    R.cnt = tiles_of<false>(live, E, mnx, mny, mxx, mxy, i, 0, tiles_x, block, scratch[threadIdx.x >> 6], NoOut{});
     if (i < n) {
         dkeys[i] = R.rad > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;  // culled splats sort last
         dvals[i] = i;
@@ -394,9 +419,10 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
                                                       int32_t *__restrict__ tvals) {
     __shared__ TK lk[EMIT_CAP];
     __shared__ int32_t lv[EMIT_CAP];
+    __shared__ FlatScratch scratch;
     const int lane = threadIdx.x;
     const int r0 = blockIdx.x * 64, r = r0 + lane;
-    int mnx = 0, mny = 0, mxx = 0, mxy = 0, cur = 0, gid = 0;
+    int mnx = 0, mny = 0, mxx = 0, mxy = 0, gid = 0;
     float gx = 0.f, gy = 0.f, a = 1.f, b = 0.f, c = 1.f, s = -1.f;
     bool live = false;
     const int base = (r0 == 0) ? 0 : cum_r[r0 - 1];
@@ -411,19 +437,18 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
             live = true;
             gx = q0.x; gy = q0.y; a = q0.z; b = q0.w; c = q1.x; s = q1.y;
             sgn_tile_bbox(gx, gy, (float)rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
-            cur = (r == 0) ? 0 : cum_r[r - 1];
         }
     }
     const Ellipse E = make_ellipse(gx, gy, a, b, c, s);
     if (total <= EMIT_CAP) {
-        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, LdsOut<TK>{lk, lv, base});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, LdsOut<TK>{lk, lv, base});
         __syncthreads();                                      // single-wave workgroup: a fence, no s_barrier
         for (int j = lane; j < total; j += 64) {
             tkeys[base + j] = lk[j];
             tvals[base + j] = lv[j];
         }
     } else {
-        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, cur, tiles_x, block, GlobalOut<TK>{tkeys, tvals});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, GlobalOut<TK>{tkeys, tvals});
     }
 }
 
