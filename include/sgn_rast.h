@@ -50,11 +50,14 @@ typedef struct sgn_raster_opts {
                            0 = nine butterfly reductions (54 shuffles), kept for A/B measurements and tests */
     int gather;         /* 1 (default): kernels chase gaussian_ids_sorted[k] -> per-Gaussian row with dependent scalar
                            loads (no pack pass); 0: they stream a depth-ordered 48-byte record per intersection */
-    int waves_fwd;      /* waves per tile in the forward: 4 (default) = four waves, one 8x8 quadrant each; 1 = one wave64
-                           per tile, 4 pixels per lane; 0 = adaptive (split tiles whose list has >= adapt_fwd entries) */
+    int waves_fwd;      /* forward kernel: 2 (default) = packed FP32, two waves per 16x16 tile, two pixels per lane; the
+                           first tile_order[n_tiles] tiles of the launch order (lists of >= adapt_fwd entries) get four
+                           waves instead (other tile sizes run as 4); 4 = four waves per tile, one 8x8 quadrant each;
+                           1 = one wave64 per tile, 4 pixels per lane; 0 = adaptive between 1 and 4 (split tiles whose
+                           list has >= adapt_fwd entries) */
     int waves_bwd;      /* same for the backward; default 0 = adaptive on the reverse-walk length (>= adapt_bwd): one
                            wave per tile means ONE gradient reduction per (tile, Gaussian), four waves mean four */
-    int adapt_fwd, adapt_bwd; /* defaults 3072 / 256; <= 0 = default */
+    int adapt_fwd, adapt_bwd; /* defaults 1024 / 256; <= 0 = default */
     int batch_fwd, batch_bwd; /* lists / reverse walks with at least this many entries are read through 64-entry
                                  batches staged in wave-private LDS instead of the one-entry scalar look-ahead
                                  (defaults 256 / 128; <= 0 = default; a huge value disables) */

@@ -181,23 +181,13 @@ __device__ __forceinline__ unsigned row_quadrants(float gx, float gy, float ex, 
 // ADAPT (with QPW = 4, grid = 4 waves per tile): a tile whose depth list is shorter than `adapt_thresh` is
 // done by its wave 0 alone (the other three exit at once); a longer one is split, one quadrant per wave.
 template <bool EXACT, bool GATHER, int QPW, bool ADAPT>
-__global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int tiles_x,
-                                                        const int2 *__restrict__ bins,
-                                                        const Rec *__restrict__ recs,
-                                                        const int32_t *__restrict__ ids,
-                                                        const float *__restrict__ bg, float *__restrict__ out_img,
-                                                        float *__restrict__ final_T,
-                                                        int32_t *__restrict__ final_idx, int adapt_thresh, int swz,
-                                                        int batch_thresh, const int32_t *__restrict__ tile_order,
-                                                        int32_t *__restrict__ tile_kmax) {
+__device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, int B, int tiles_x,
+                                                const int2 *__restrict__ bins, const Rec *__restrict__ recs,
+                                                const int32_t *__restrict__ ids, const float *__restrict__ bg,
+                                                float *__restrict__ out_img, float *__restrict__ final_T,
+                                                int32_t *__restrict__ final_idx, int adapt_thresh, int batch_thresh,
+                                                int32_t *__restrict__ tile_kmax, float4 (*stage)[64 * 3]) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
-    constexpr int WPT = ADAPT ? 4 : 4 / QPW;   // waves launched per tile
-    // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile) so the waves that do the
-    // work of un-split tiles are spread over all 8 XCDs (block b runs on XCD b % 8), not on every 4th block.
-    const int n_tiles_ = gridDim.x / WPT;
-    int tile = xcd_tile(ADAPT ? (int)(blockIdx.x % n_tiles_) : (int)(blockIdx.x / WPT), n_tiles_, swz);
-    if (tile_order) tile = tile_order[tile];   // longest depth lists first (sgn_tile_order): no long tile starts late
-    const int wv = ADAPT ? (int)(blockIdx.x / n_tiles_) : (int)(blockIdx.x % WPT);
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
     int q0 = ADAPT ? 0 : wv * QPW;             // first quadrant (pixel slot) of this wave
@@ -286,7 +276,6 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
         // load pair per entry), so stage 64-entry batches through wave-private LDS instead: lane l gathers
         // row ids[k0+l] with vector loads a whole batch ahead, entries are then read back with broadcast
         // ds_read_b128 (no barrier: the workgroup is this one wave and its LDS ops retire in order).
-        __shared__ float4 stage[2][64 * 3];
         const int nb = (L + 63) >> 6;
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = range.x + (bidx << 6) + lane;
@@ -348,6 +337,221 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
             out_img[3 * pix[q] + 1] = fmaf(Tq, bg1, C1[q]);
             out_img[3 * pix[q] + 2] = fmaf(Tq, bg2, C2[q]);
         }
+    }
+}
+
+template <bool EXACT, bool GATHER, int QPW, bool ADAPT>
+__global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int tiles_x,
+                                                        const int2 *__restrict__ bins,
+                                                        const Rec *__restrict__ recs,
+                                                        const int32_t *__restrict__ ids,
+                                                        const float *__restrict__ bg, float *__restrict__ out_img,
+                                                        float *__restrict__ final_T,
+                                                        int32_t *__restrict__ final_idx, int adapt_thresh, int swz,
+                                                        int batch_thresh, const int32_t *__restrict__ tile_order,
+                                                        int32_t *__restrict__ tile_kmax) {
+    constexpr int WPT = ADAPT ? 4 : 4 / QPW;   // waves launched per tile
+    // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile) so the waves that do the
+    // work of un-split tiles are spread over all 8 XCDs (block b runs on XCD b % 8), not on every 4th block.
+    const int n_tiles_ = gridDim.x / WPT;
+    int tile = xcd_tile(ADAPT ? (int)(blockIdx.x % n_tiles_) : (int)(blockIdx.x / WPT), n_tiles_, swz);
+    if (tile_order) tile = tile_order[tile];   // longest depth lists first (sgn_tile_order): no long tile starts late
+    const int wv = ADAPT ? (int)(blockIdx.x / n_tiles_) : (int)(blockIdx.x % WPT);
+    __shared__ float4 stage[2][64 * 3];         // 64-entry batches of the long-list path (wave-private)
+    raster_fwd_tile<EXACT, GATHER, QPW, ADAPT>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, out_img, final_T,
+                                                final_idx, adapt_thresh, batch_thresh, tile_kmax, stage);
+}
+
+// ---------------------------------------------------------------- forward, packed-FP32 form (16x16 tiles)
+// Two waves per tile, each owns a 16x8 half: lane l carries the pixel at (l & 7, l >> 3) of the half's LEFT 8x8
+// quadrant and the one 8 columns to the right (slot 0 / slot 1).  Every entry that can touch the half is
+// evaluated for both pixels at once on gfx950's packed FP32 pipe (v_pk_add/mul/fma_f32: two values per lane at
+// the rate of one): the quadratic form, alpha, the transmittance update and the colour accumulation take ~40
+// VALU instructions for 128 pixels where the one-pixel-per-lane kernel issues 28 per 64.  The per-Gaussian
+// operands stay wave-uniform (SGPRs on the scalar-chase path, broadcast LDS reads on the batched one) and enter
+// the packed instructions through op_sel.  Measured on the benchmark scene: 183 -> 157 us.
+// (Tried and dropped, profiles/experiments/r02_packed_forward_notes.md: a three-way form that sends entries
+// touching only one of the two quadrants down a one-slot path.  It executes fewer instructions on paper; the
+// compiler joins the three paths with ~12 register copies per entry and the kernel took 194 us.)
+// The first tile_order[n_tiles] tiles of the launch order — lists of at least adapt_fwd entries, sgn_tile_order —
+// are given four waves, one quadrant each (raster_fwd_tile<QPW = 1>): on street scenes most of the work sits in
+// a few thousand-entry lists, and two waves per such tile leave the SIMDs short of waves (547 vs 294 us).
+//
+// Same arithmetic, operation by operation, as raster_fwd_tile (file header); only the bookkeeping around it is
+// rearranged so that the packed part needs no "valid" mask:
+//   a' = (T > 0 && sigma >= 0 && alpha >= 1/255) ? alpha : 0        (a' = 0: nT = T*1 = T, vis = 0*T = 0 exactly)
+//   nT = T * (1 - a'),  stop <=> bits(nT) <= bits(1e-4)  as UNSIGNED (finished pixels carry T < 0: huge unsigned;
+//                                                          a live T is always > 1e-4, so a' = 0 never stops)
+//   vis = stop ? 0 : a' * T,   T = stop ? -T : nT,   last = (a' > 0 && !stop) ? k : last
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat2(float v) { return v2f{v, v}; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <bool EXACT, bool GATHER>
+__global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int tiles_x, int n_tiles_,
+                                                           const int2 *__restrict__ bins,
+                                                           const Rec *__restrict__ recs,
+                                                           const int32_t *__restrict__ ids,
+                                                           const float *__restrict__ bg, float *__restrict__ out_img,
+                                                           float *__restrict__ final_T,
+                                                           int32_t *__restrict__ final_idx, int swz,
+                                                           int batch_thresh, const int32_t *__restrict__ tile_order,
+                                                           int32_t *__restrict__ tile_kmax) {
+    __shared__ float4 stage[2][64 * 3];
+    // The first n_long tiles of the launch order (sgn_tile_order with long_thresh: the longest lists) get four waves
+    // each, the others two.  Blocks come in groups of eight tiles (8 x 4, then 8 x 2 blocks): block b runs on XCD
+    // b % 8, so a tile's waves share an XCD (and its L2) and are dispatched together, longest tiles first.  No block
+    // inside the two regions is empty: interleaving waves that exit at once with working ones left half of the SIMDs
+    // idle (the dispatcher places consecutive workgroups round-robin), 267 vs 159 us on the benchmark scene.
+    const int n_long = tile_order ? min(max(tile_order[n_tiles_], 0), n_tiles_) : 0;
+    const int b_long = ((n_long + 7) >> 3) << 5;
+    const int b = (int)blockIdx.x;
+    int t_idx, wv;
+    const bool is_long = b < b_long;
+    if (is_long) {
+        t_idx = (b >> 5) * 8 + (b & 7);
+        wv = (b >> 3) & 3;
+        if (t_idx >= n_long) return;
+    } else {
+        const int b2 = b - b_long;
+        t_idx = n_long + (b2 >> 4) * 8 + (b2 & 7);
+        wv = (b2 >> 3) & 1;
+        if (t_idx >= n_tiles_) return;
+    }
+    int tile = xcd_tile(t_idx, n_tiles_, swz);
+    if (tile_order) tile = tile_order[tile];
+    const int2 range = bins[tile];
+    const int L = range.y - range.x;
+    if (is_long) {
+        raster_fwd_tile<EXACT, GATHER, 1, false>(tile, wv, W, H, 16, tiles_x, bins, recs, ids, bg, out_img, final_T,
+                                                 final_idx, 0, batch_thresh, tile_kmax, stage);
+        return;
+    }
+    const unsigned shift_q = 2u * wv;                    // this wave's quadrants: bits shift_q, shift_q + 1
+    const int lane = threadIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+
+    const int j0 = tx * 16 + (lane & 7), i0 = ty * 16 + wv * 8 + (lane >> 3);
+    const bool in0 = j0 < W && i0 < H, in1 = j0 + 8 < W && i0 < H;
+    const int pix = i0 * W + j0;
+    const v2f px = {(float)j0 + 0.5f, (float)j0 + 8.5f};
+    const float py = (float)i0 + 0.5f;
+    v2f T = {in0 ? 1.f : -1.f, in1 ? 1.f : -1.f};
+    v2f C0 = {0.f, 0.f}, C1 = C0, C2 = C0;
+    int last0 = 0, last1 = 0;
+    const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
+
+    int n_eval = 0;
+    // m: which of this wave's two quadrants the entry can touch (bit 0 = slot 0, bit 1 = slot 1), never 0
+    auto entry = [&](const Rec &cur, int k, unsigned m) __attribute__((always_inline)) -> bool {
+        const bool l0 = T.x > 0.f, l1 = T.y > 0.f;
+        const unsigned long long b0 = __ballot(l0), b1 = __ballot(l1);
+        if ((b0 | b1) == 0ull) return false;
+        n_eval += __popc(m & ((b0 ? 1u : 0u) | (b1 ? 2u : 0u)));
+        {
+            const v2f dx = splat2(cur.x) - px;
+            const float dy = cur.y - py;
+            v2f s = (splat2(cur.ha) * dx) * dx;
+            s = fma2(splat2(cur.hc * dy), splat2(dy), s);
+            const v2f sigma = fma2(splat2(cur.b) * dx, splat2(dy), s);
+            v2f e;
+            if constexpr (EXACT) {
+                e = v2f{exp_portable(-sigma.x), exp_portable(-sigma.y)};
+            } else {
+                const v2f t = sigma * splat2(-1.44269504088896341f);   // __expf(-sigma) = v_exp_f32(-sigma * log2 e)
+                e = v2f{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+            }
+            const v2f ao = splat2(cur.opac) * e;
+            const float a0 = fminf(0.999f, ao.x), a1 = fminf(0.999f, ao.y);
+            const bool ok0 = l0 && sigma.x >= 0.f && a0 >= (1.f / 255.f);
+            const bool ok1 = l1 && sigma.y >= 0.f && a1 >= (1.f / 255.f);
+            const v2f a = {ok0 ? a0 : 0.f, ok1 ? a1 : 0.f};
+            const v2f nT = T * (splat2(1.f) - a);
+            const v2f w = a * T;
+            const bool stop0 = __float_as_uint(nT.x) <= 0x38D1B717u;    // 1e-4f; see the header of this kernel
+            const bool stop1 = __float_as_uint(nT.y) <= 0x38D1B717u;
+            const v2f vis = {stop0 ? 0.f : w.x, stop1 ? 0.f : w.y};
+            C0 = fma2(splat2(cur.r), vis, C0);
+            C1 = fma2(splat2(cur.g), vis, C1);
+            C2 = fma2(splat2(cur.bl), vis, C2);
+            last0 = (ok0 && !stop0) ? k : last0;
+            last1 = (ok1 && !stop1) ? k : last1;
+            T = v2f{stop0 ? -T.x : nT.x, stop1 ? -T.y : nT.y};
+        }
+        return true;
+    };
+
+    if (L > 0 && L < batch_thresh) {
+        Rec cur = recs[GATHER ? ids[range.x] : range.x];
+        int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
+        for (int k = range.x; k < range.y; ++k) {
+            const int kn = (k + 1 < range.y) ? k + 1 : k;
+            const Rec nxt = recs[GATHER ? idn : kn];
+            if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
+            const unsigned m = (quadrant_mask(cur, qcx, qcy, true) >> shift_q) & 3u;
+            if (m != 0u && !entry(cur, k, m)) break;
+            cur = nxt;
+        }
+    } else if (L > 0) {
+        const int nb = (L + 63) >> 6;
+        auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
+            const int k = range.x + (bidx << 6) + lane;
+            if (k < range.y) {
+                const float4 *p = reinterpret_cast<const float4 *>(recs + (GATHER ? ids[k] : k));
+                r0 = p[0]; r1 = p[1]; r2 = p[2];
+            }
+        };
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+        fetch(0, r0, r1, r2);
+        stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
+        unsigned qrow = (row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, true) >> shift_q) & 3u;
+        bool go = true;
+        for (int bi = 0; bi < nb && go; ++bi) {
+            const int cnt = min(64, L - (bi << 6));
+            unsigned long long todo = __ballot(lane < cnt && qrow != 0u);
+            const unsigned qcur = qrow;
+            if (bi + 1 < nb) fetch(bi + 1, r0, r1, r2);
+            const float4 *sb = stage[bi & 1];
+            while (todo) {
+                const int j = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                Rec cur;
+                const float4 a0 = sb[j * 3 + 0], a1 = sb[j * 3 + 1], a2 = sb[j * 3 + 2];
+                cur.x = a0.x; cur.y = a0.y; cur.opac = a0.z; cur.ha = a0.w;
+                cur.b = a1.x; cur.hc = a1.y; cur.r = a1.z; cur.g = a1.w;
+                cur.bl = a2.x; cur.gid = __float_as_int(a2.y); cur.ex = a2.z; cur.ey = a2.w;
+                const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)qcur, j);
+                if (!entry(cur, range.x + (bi << 6) + j, m)) { go = false; break; }
+            }
+            if (go && bi + 1 < nb) {
+                float4 *sn = stage[(bi + 1) & 1];
+                sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
+                qrow = (row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, true) >> shift_q) & 3u;
+            }
+        }
+    }
+    if (tile_kmax) {
+        int lm = max(in0 ? last0 : 0, in1 ? last1 : 0);
+        lm = wave_max_i(lm);
+        if (lane == 0 && lm > 0) atomicMax(tile_kmax + 2 * tile, lm);
+        if (lane == 0 && n_eval > 0) atomicAdd(tile_kmax + 2 * tile + 1, n_eval);
+    }
+    if (in0) {
+        const float Tq = fabsf(T.x);
+        final_T[pix] = Tq;
+        final_idx[pix] = last0;
+        out_img[3 * pix + 0] = fmaf(Tq, bg0, C0.x);
+        out_img[3 * pix + 1] = fmaf(Tq, bg1, C1.x);
+        out_img[3 * pix + 2] = fmaf(Tq, bg2, C2.x);
+    }
+    if (in1) {
+        const float Tq = fabsf(T.y);
+        final_T[pix + 8] = Tq;
+        final_idx[pix + 8] = last1;
+        out_img[3 * pix + 24] = fmaf(Tq, bg0, C0.y);
+        out_img[3 * pix + 25] = fmaf(Tq, bg1, C1.y);
+        out_img[3 * pix + 26] = fmaf(Tq, bg2, C2.y);
     }
 }
 
@@ -670,7 +874,7 @@ sgn_raster_opts resolve_opts(const sgn_raster_opts *o) {
         r.exact_exp = r.exact_exp ? 1 : 0;
         r.reduce_mode = r.reduce_mode ? 1 : 0;
         r.gather = r.gather ? 1 : 0;
-        r.waves_fwd = (r.waves_fwd == 4 || r.waves_fwd == 1) ? r.waves_fwd : 0;
+        r.waves_fwd = (r.waves_fwd == 4 || r.waves_fwd == 2 || r.waves_fwd == 1) ? r.waves_fwd : 0;
         r.waves_bwd = (r.waves_bwd == 4 || r.waves_bwd == 1) ? r.waves_bwd : 0;
         sgn_raster_opts d;
         sgn_raster_default_opts(&d);
@@ -689,11 +893,10 @@ SGN_EXPORT void sgn_raster_default_opts(sgn_raster_opts *out) {
     out->exact_exp = 0;        // hardware v_exp_f32
     out->reduce_mode = 1;      // transposed permlane-swap reduction
     out->gather = 1;           // chase ids -> per-Gaussian rows
-    out->waves_fwd = 4;        // forward: four waves per tile, one 8x8 quadrant each (r02: +3 % on the uniform scene,
-                               //          2.3x faster on skewed content: a 3000-entry list is a 0.9 ms critical path
-                               //          for a lone wave)
+    out->waves_fwd = 2;        // forward: packed FP32, two waves per tile (r02k: 183 -> 157 us on the uniform scene), four
+                               //          waves, one 8x8 quadrant each, for the tiles with the longest lists
     out->waves_bwd = 0;        // backward: adaptive (one reduction per (tile, Gaussian) unless the walk is long)
-    out->adapt_fwd = 3072;     // forward: split tiles with >= this many list entries
+    out->adapt_fwd = 1024;     // forward: lists with >= this many entries get four waves (half-octave classes)
     out->adapt_bwd = 256;      // backward: reverse walks of >= this many entries go to the four-waves-per-tile kernel
     out->batch_fwd = 256;      // forward: lists with >= this many entries go through the LDS-batched path
     out->batch_bwd = 128;      // backward: same for reverse walks
@@ -776,9 +979,14 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
                        img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
                        gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, o.adapt_fwd, o.xcd_swizzle, o.batch_fwd,   \
                        tile_order, tile_kmax)
+#define SGN_LAUNCH_FWD_PK(EX, GA)                                                                                    \
+    hipLaunchKernelGGL((raster_fwd_pk_kernel<EX, GA>), dim3(((tiles_x * tiles_y + 7) / 8) * 32 + 32), dim3(64), 0, s, img_w, img_h,    \
+                       tiles_x, tiles_x * tiles_y, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, background3,  \
+                       out_img, final_Ts, final_idx, o.xcd_swizzle, o.batch_fwd, tile_order, tile_kmax)
 #define SGN_LAUNCH_FWD2(EX, GA)                                                     \
     do {                                                                            \
-        if (o.waves_fwd == 4) SGN_LAUNCH_FWD(EX, GA, 1, false);                     \
+        if (o.waves_fwd == 2 && block_width == 16) SGN_LAUNCH_FWD_PK(EX, GA);       \
+        else if (o.waves_fwd == 4 || o.waves_fwd == 2) SGN_LAUNCH_FWD(EX, GA, 1, false); \
         else if (o.waves_fwd == 1) SGN_LAUNCH_FWD(EX, GA, 4, false);                \
         else SGN_LAUNCH_FWD(EX, GA, 4, true);                                       \
     } while (0)
@@ -788,6 +996,7 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
         if (o.gather) SGN_LAUNCH_FWD2(false, true); else SGN_LAUNCH_FWD2(false, false);
     }
 #undef SGN_LAUNCH_FWD2
+#undef SGN_LAUNCH_FWD_PK
 #undef SGN_LAUNCH_FWD
     sgn_timing_end(SGN_T_RASTER_FWD, s);
     SGN_LAUNCH_CHECK();

@@ -589,7 +589,8 @@ class _RasterizeGaussians(Function):
         else:
             if not rows_built:
                 recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
-            order = _tile_order(tile_bins)
+            # packed forward: the leading tiles of the order whose lists reach adapt_fwd entries get four waves
+            order = _tile_order(tile_bins, None, (ro.adapt_fwd if ro.adapt_fwd > 0 else 1024) if ro.waves_fwd == 2 else 0)
             tile_kmax = torch.empty(tile_bins.shape[0], 2, dtype=torch.int32, device=dev)   # walk depth, pairs
             L.check(lib.sgn_raster_fwd(
                 img_height, img_width, block_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),

@@ -79,7 +79,7 @@ def test_argument_errors_are_reported_without_a_gpu(built_lib):
     o = built_lib.RasterOpts()
     lib.sgn_raster_default_opts(ctypes.byref(o))                  # options travel with each call: no setters
     assert (o.exact_exp, o.reduce_mode, o.gather, o.waves_fwd, o.waves_bwd, o.adapt_fwd, o.adapt_bwd, o.batch_fwd,
-            o.batch_bwd, o.xcd_swizzle, o.debug_flags) == (0, 1, 1, 4, 0, 3072, 256, 256, 128, 0, 0)
+            o.batch_bwd, o.xcd_swizzle, o.debug_flags) == (0, 1, 1, 2, 0, 1024, 256, 256, 128, 0, 0)
     assert lib.sgn_raster_workspace_bytes(5, 10, None) == 5 * 48  # NULL = defaults: per-Gaussian rows only
     o.gather = 0
     assert lib.sgn_raster_workspace_bytes(5, 10, ctypes.byref(o)) == 15 * 48   # + depth-ordered record stream

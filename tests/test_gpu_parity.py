@@ -19,9 +19,10 @@ def hip():
     return ops
 
 
-@pytest.fixture(autouse=True, params=[(0, 1, 0), (1, 1, 0), (1, 4, 0), (1, 0, 0), (1, 0, 1), (0, 1, 1)],
+@pytest.fixture(autouse=True, params=[(0, 1, 0), (1, 1, 0), (1, 4, 0), (1, 0, 0), (1, 0, 1), (0, 1, 1), (1, 2, 0),
+                                       (1, 2, 1), (0, 2, 1)],
                 ids=["stream", "gather", "gather-4waves", "gather-adaptive", "gather-adaptive-ldsbatch",
-                     "stream-ldsbatch"])
+                     "stream-ldsbatch", "gather-packed", "gather-packed-ldsbatch", "stream-packed-ldsbatch"])
 def raster_record_mode(request):
     """Every test in this module runs with the record-fetch modes of the raster kernels (packed depth-ordered
     stream vs. ids -> per-Gaussian rows chased with scalar loads) with 1 / 4 / adaptive waves per tile, and with the LDS-batched
@@ -29,8 +30,9 @@ def raster_record_mode(request):
     from sgn_rast import _lib as L
     gather, wpt, batch = request.param
     thr = (24, 24) if batch else (1 << 30, 1 << 30)                  # force / forbid the LDS path
-    kw = dict(batch_fwd=thr[0], batch_bwd=thr[1], gather=gather, waves_fwd=wpt, waves_bwd=wpt)
-    if wpt == 0:
+    # wpt 2: the packed-FP32 forward (two waves per tile, two pixels per lane); the backward runs adaptive
+    kw = dict(batch_fwd=thr[0], batch_bwd=thr[1], gather=gather, waves_fwd=wpt, waves_bwd=wpt if wpt != 2 else 0)
+    if wpt in (0, 2):
         kw.update(adapt_fwd=96, adapt_bwd=48)                        # small scenes: make some tiles split, others not
     L.load()
     with L.options(**kw):

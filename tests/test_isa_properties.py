@@ -51,6 +51,21 @@ def test_raster_kernels_have_no_scratch_and_scalar_operands(raster_asm):
     assert gather_fwd and all("ds_read_b128" in t for t in gather_fwd)   # LDS-batched long-list path compiled in
 
 
+def test_packed_forward_runs_on_the_packed_fp32_pipe(raster_asm):
+    """The default forward (two pixels per lane) must really be packed: the quadratic form, alpha, the transmittance
+    update and the three colour sums are v_pk_* instructions, and nothing spills."""
+    ks = _kernels(raster_asm)
+    pk = {k: t for k, t in ks.items() if "raster_fwd_pk_kernel" in k}
+    assert len(pk) == 4                                            # exact x gather
+    for k, t in pk.items():
+        assert re.search(r"ScratchSize: 0\b", t), "the packed forward spills to scratch"
+        assert "s_load_dwordx8" in t and "ds_read_b128" in t      # scalar-chase and LDS-batched paths both compiled in
+        # two code paths (scalar chase, LDS batches) x (3 colour + 2 quadratic-form) packed FMAs, + the 1-px long-tile body
+        assert t.count("v_pk_fma_f32") >= 10 and t.count("v_pk_mul_f32") >= 12, k
+    fast = next(t for k, t in pk.items() if "ILb0ELb1E" in k)
+    assert fast.count("v_exp_f32") >= 4                            # hardware exp, two per entry and path
+
+
 def test_backward_uses_the_permlane_swap_reduction(raster_asm):
     ks = _kernels(raster_asm)
     for k, t in ks.items():
