@@ -364,15 +364,18 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
 
 // ---------------------------------------------------------------- forward, packed-FP32 form (16x16 tiles)
 // Two waves per tile, each owns a 16x8 half: lane l carries the pixel at (l & 7, l >> 3) of the half's LEFT 8x8
-// quadrant and the one 8 columns to the right (slot 0 / slot 1).  Every entry that can touch the half is
-// evaluated for both pixels at once on gfx950's packed FP32 pipe (v_pk_add/mul/fma_f32: two values per lane at
-// the rate of one): the quadratic form, alpha, the transmittance update and the colour accumulation take ~40
-// VALU instructions for 128 pixels where the one-pixel-per-lane kernel issues 28 per 64.  The per-Gaussian
-// operands stay wave-uniform (SGPRs on the scalar-chase path, broadcast LDS reads on the batched one) and enter
-// the packed instructions through op_sel.  Measured on the benchmark scene: 183 -> 157 us.
+// quadrant and the one 8 columns to the right (slot 0 / slot 1) as a register pair, and every entry that can
+// touch the half is evaluated for both with v_pk_add/mul/fma_f32 (operands of the Gaussian stay wave-uniform:
+// SGPRs on the scalar-chase path, broadcast LDS reads on the batched one, selected through op_sel).
+// What this buys on gfx950 is NOT cheaper arithmetic: a packed FP32 instruction costs the cycles of two single
+// ones here (profiles/microbench/valu_rates.hip: v_pk_fma_f32 5.0 cycles per wave-instruction, v_fma_f32 2.5-2.9).
+// It halves what is paid per ENTRY and per WAVE rather than per pixel — liveness ballots, list / loop control in
+// the scalar unit, the broadcast LDS reads (or the scalar row fetch), the index bookkeeping — because one wave
+// now serves 128 pixels: SQ_INSTS_VALU 1.00e8 -> 0.80e8, SQ_INSTS_SALU 7.7e7 -> 4.4e7, LDS instructions
+// 1.01e7 -> 0.52e7 per launch, 183 -> 157 us on the benchmark scene (profiles/r02k_pmc_sq*.md).
 // (Tried and dropped, profiles/experiments/r02_packed_forward_notes.md: a three-way form that sends entries
-// touching only one of the two quadrants down a one-slot path.  It executes fewer instructions on paper; the
-// compiler joins the three paths with ~12 register copies per entry and the kernel took 194 us.)
+// touching only one of the two quadrants down a one-slot path — the compiler joins the three paths with ~12
+// register copies per entry, 194 us; and the same pairing in the backward, whose cost is the arithmetic itself.)
 // The first tile_order[n_tiles] tiles of the launch order — lists of at least adapt_fwd entries, sgn_tile_order —
 // are given four waves, one quadrant each (raster_fwd_tile<QPW = 1>): on street scenes most of the work sits in
 // a few thousand-entry lists, and two waves per such tile leave the SIMDs short of waves (547 vs 294 us).
