@@ -797,7 +797,8 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
 //   MODE 0: one workgroup per (tile, wave) in index or `tile_order` order (forced 1 / 4 waves per tile, or the legacy
 //           in-kernel adaptive split when ADAPT).
 //   MODE 1: "short" half of the two-kernel adaptive scheme: one wave per tile (QPW = 4); block b takes tile
-//           order[b] and leaves the first n_long = order[n_tiles] entries (the long walks) to MODE 2.
+//           order[b] and leaves the first n_long = order[n_tiles] entries (the long walks) to MODE 2.  (Its own
+//           kernel, raster_bwd_short_kernel below: it carries an occupancy attribute the other shapes must not.)
 //   MODE 2: "long" half: four lean waves per tile (QPW = 1, half the registers of the QPW = 4 body) over the n_long
 //           longest walks, longest first.
 // Why two kernels: splitting a long walk over four waves INSIDE the QPW = 4 kernel keeps that kernel's register
@@ -826,14 +827,8 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         raster_bwd_tile<EXACT, REDUCE, GATHER, QPW, ADAPT>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, final_T,
                                                            final_idx, v_out, v_out_alpha, alpha_clamp, grad_ws, dbg,
                                                            adapt_thresh, batch_thresh);
-    } else if constexpr (MODE == 1) {
-        static_assert(QPW == 4 && !ADAPT, "short tiles: one wave per tile");
-        const int n_long = tile_order[n_tiles];
-        if ((int)blockIdx.x < n_long) return;
-        raster_bwd_tile<EXACT, REDUCE, GATHER, 4, false>(tile_order[blockIdx.x], 0, W, H, B, tiles_x, bins, recs, ids,
-                                                         bg, final_T, final_idx, v_out, v_out_alpha, alpha_clamp,
-                                                         grad_ws, dbg, adapt_thresh, batch_thresh);
     } else {
+        static_assert(MODE == 2, "MODE 1 lives in raster_bwd_short_kernel");
         static_assert(QPW == 1 && !ADAPT, "long tiles: four lean waves per tile");
         // one workgroup per (tile, quadrant) of the n_long longest walks, longest first; the hardware's own dispatch
         // balances them.  (Persistent waves were tried: a static stride left the wave with the longest item of every
@@ -844,6 +839,24 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                                                          bins, recs, ids, bg, final_T, final_idx, v_out, v_out_alpha,
                                                          alpha_clamp, grad_ws, dbg, adapt_thresh, batch_thresh);
     }
+}
+
+// The "short" half of the two-kernel scheme (MODE 1 above) as its own kernel, held at FOUR waves per SIMD.  Built
+// without the SLP vectoriser (see the Makefile) its body needs 94 VGPRs and would run five; on the street scene the
+// extra waves take issue slots from the concurrently running long-walk kernel, which is the critical path there
+// (long-walk kernel 613 -> 768 us, step 1.97 -> 2.24 ms, profiles/experiments/r02_packed_forward_notes.md).
+template <bool EXACT, int REDUCE, bool GATHER>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void raster_bwd_short_kernel(
+    int W, int H, int B, int tiles_x, int n_tiles, const int2 *__restrict__ bins, const Rec *__restrict__ recs,
+    const int32_t *__restrict__ ids, const float *__restrict__ bg, const float *__restrict__ final_T,
+    const int32_t *__restrict__ final_idx, const float *__restrict__ v_out, const float *__restrict__ v_out_alpha,
+    float alpha_clamp, float *__restrict__ grad_ws, int dbg, int adapt_thresh, int swz, int batch_thresh,
+    const int32_t *__restrict__ tile_order) {
+    const int n_long = tile_order[n_tiles];
+    if ((int)blockIdx.x < n_long) return;
+    raster_bwd_tile<EXACT, REDUCE, GATHER, 4, false>(tile_order[blockIdx.x], 0, W, H, B, tiles_x, bins, recs, ids, bg,
+                                                     final_T, final_idx, v_out, v_out_alpha, alpha_clamp, grad_ws, dbg,
+                                                     adapt_thresh, batch_thresh);
 }
 
 // rows [row0, row0 + n) of the packed gradient workspace -> the n rows of the four output arrays
@@ -1065,7 +1078,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
                  /* touch disjoint tiles and run CONCURRENTLY when the caller lends a second stream           */ \
             hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, 1, false, 2>), dim3(long_grid), dim3(64), 0, s2,   \
                                SGN_BWD_ARGS(GA));                                                                \
-            hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, 4, false, 1>), dim3(n_tiles), dim3(64), 0, s,      \
+            hipLaunchKernelGGL((raster_bwd_short_kernel<EX, RM, GA>), dim3(n_tiles), dim3(64), 0, s,      \
                                SGN_BWD_ARGS(GA));                                                                \
         }                                                                                                        \
     } while (0)

@@ -15,7 +15,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
 def _asm(tmp_path_factory, name):
     out = tmp_path_factory.mktemp("isa") / (name + ".s")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
+    extra = ["-fno-slp-vectorize"] if name == "raster" else []      # as csrc/Makefile builds it
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics", *extra,
            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only", "-o", str(out),
            os.path.join(CSRC, name + ".hip")]
     subprocess.run(cmd, check=True, capture_output=True, timeout=600)
@@ -40,9 +41,9 @@ def raster_asm(tmp_path_factory):
 def test_raster_kernels_have_no_scratch_and_scalar_operands(raster_asm):
     ks = _kernels(raster_asm)
     fwd = [t for k, t in ks.items() if "raster_fwd_kernel" in k]
-    bwd = [t for k, t in ks.items() if "raster_bwd_kernel" in k]
+    bwd = [t for k, t in ks.items() if "raster_bwd_kernel" in k or "raster_bwd_short_kernel" in k]
     # forward: exact x gather x {4 waves, 1 wave, adaptive}; backward: exact x reduce x gather x {4 waves, 1 wave,
-    # legacy in-kernel adaptive, short-walk half, persistent long-walk half of the two-kernel scheme}
+    # legacy in-kernel adaptive, long-walk half of the two-kernel scheme} + its short-walk half (own kernel)
     assert len(fwd) == 12 and len(bwd) == 40
     for t in fwd + bwd:
         assert re.search(r"ScratchSize: 0\b", t), "a raster kernel spills to scratch"
@@ -66,12 +67,25 @@ def test_packed_forward_runs_on_the_packed_fp32_pipe(raster_asm):
     assert fast.count("v_exp_f32") >= 4                            # hardware exp, two per entry and path
 
 
+def test_short_walk_backward_is_held_at_four_waves_and_not_slp_packed(raster_asm):
+    """raster.hip is built without the SLP vectoriser (a packed FP32 instruction costs two single ones on gfx950, the
+    vectoriser's v_mov shuffles come on top), and the short-walk kernel must not grow past four waves per SIMD
+    (it would starve the concurrently running long-walk kernel): the occupancy attribute must have taken."""
+    ks = _kernels(raster_asm)
+    short = {k: t for k, t in ks.items() if "raster_bwd_short_kernel" in k}
+    assert len(short) == 8
+    for k, t in short.items():
+        assert "v_pk_fma_f32" not in t and "v_pk_mul_f32" not in t, k
+        m = re.search(r"; Occupancy: (\d+)", t)
+        assert m and int(m.group(1)) == 4, (k, m and m.group(1))
+
+
 def test_backward_uses_the_permlane_swap_reduction(raster_asm):
     ks = _kernels(raster_asm)
     for k, t in ks.items():
-        if "raster_bwd_kernel" not in k:
+        if "raster_bwd_kernel" not in k and "raster_bwd_short_kernel" not in k:
             continue
-        reduce_mode = int(re.search(r"raster_bwd_kernelILb[01]ELi([01])E", k).group(1))
+        reduce_mode = int(re.search(r"raster_bwd_(?:short_)?kernelILb[01]ELi([01])E", k).group(1))
         swaps = t.count("v_permlane32_swap") + t.count("v_permlane16_swap")
         if reduce_mode == 1:
             assert swaps == 16 and t.count("row_half_mirror") >= 6        # 8 swaps + 12 DPP adds per code path, 2 paths
