@@ -214,10 +214,18 @@ int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t 
                     int32_t *gid_by_rank /*[n]*/, float *bin_records /*[n,8] out*/, void *ws, size_t ws_bytes,
                     sgn_stream_t stream);
 size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect);
+/* n_isect_dev == NULL: n_isect is the intersection count the host has read back (cum_by_rank[n-1]).
+ * n_isect_dev != NULL (speculative form, no upstream counterpart): the call is queued BEFORE the host knows the count;
+ * n_isect is then the CAPACITY the caller sized gaussian_ids_sorted and the workspace for (e.g. from its previous
+ * call) and the kernels read the true count from *n_isect_dev (= cum_by_rank + n - 1) on the device.  If the true
+ * count turns out to be <= the capacity the outputs are exactly those of the plain form (rows [0, count) of
+ * gaussian_ids_sorted); if it is larger nothing is written out of bounds, the outputs are meaningless and the caller
+ * must call again with the real count.  The GPU then works through the emission and the tile sort while the host
+ * waits for the count instead of idling through the host's wake-up. */
 int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                       const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
                       int32_t *gaussian_ids_sorted /*[n_isect]*/, int32_t *tile_bins /*[tiles,2]*/, void *ws,
-                      size_t ws_bytes, sgn_stream_t stream);
+                      size_t ws_bytes, const int32_t *n_isect_dev, sgn_stream_t stream);
 
 /* Window recognition for the drop-in scene-graph path (no upstream counterpart).  The reference renders its sub-model
  * passes (sgn_splatfacto_scene_graph.py:364-366) from torch.cat COPIES of per-model slices of the main projection

@@ -260,9 +260,12 @@ template <typename TK>
 struct GlobalOut {
     TK *__restrict__ tkeys;
     int32_t *__restrict__ tvals;
+    int cap;              // slots of the output buffers (speculative launches may be sized too small: never write past)
     __device__ __forceinline__ void operator()(int pos, uint32_t key, int32_t val) const {
-        tkeys[pos] = (TK)key;
-        tvals[pos] = val;
+        if (pos < cap) {
+            tkeys[pos] = (TK)key;
+            tvals[pos] = val;
+        }
     }
 };
 template <typename TK>
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
                                                       const int32_t *__restrict__ cum_r,
                                                       const BinRec *__restrict__ recs, int tiles_x, int tiles_y,
                                                       int block, TK *__restrict__ tkeys,
-                                                      int32_t *__restrict__ tvals) {
+                                                      int32_t *__restrict__ tvals, int cap) {
     __shared__ TK lk[EMIT_CAP];
     __shared__ int32_t lv[EMIT_CAP];
     __shared__ FlatScratch scratch;
@@ -443,19 +446,21 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
     if (total <= EMIT_CAP) {
         tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, LdsOut<TK>{lk, lv, base});
         __syncthreads();                                      // single-wave workgroup: a fence, no s_barrier
-        for (int j = lane; j < total; j += 64) {
+        for (int j = lane; j < min(total, cap - base); j += 64) {
             tkeys[base + j] = lk[j];
             tvals[base + j] = lv[j];
         }
     } else {
-        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, GlobalOut<TK>{tkeys, tvals});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, GlobalOut<TK>{tkeys, tvals, cap});
     }
 }
 
 // sorted tile ids -> tile_bins
 template <typename TK>
 __global__ __launch_bounds__(256) void tile_bins32_kernel(int64_t n_isect, const TK *__restrict__ tkeys,
-                                                          int32_t *__restrict__ bins) {
+                                                          int32_t *__restrict__ bins,
+                                                          const int32_t *__restrict__ n_dev) {
+    if (n_dev) n_isect = min(n_isect, (int64_t)max(*n_dev, 0));   // speculative launch: n_isect is the capacity
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_isect) return;
     const int32_t cur = (int32_t)tkeys[idx];
@@ -530,9 +535,9 @@ SGN_EXPORT int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_
 // ---- fused path entry points (declared in sgn_rast.h) ------------------------------------------
 size_t sgn_sort_pairs32_ws_bytes(int64_t n);
 void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const int32_t *vin, uint32_t *kout,
-                             int32_t *vout, void *ws, hipStream_t s);
+                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev = nullptr);
 void sgn_sort_pairs16_launch(uint32_t n, int end_bit, const uint16_t *kin, const int32_t *vin, uint16_t *kout,
-                             int32_t *vout, void *ws, hipStream_t s);
+                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev = nullptr);
 
 SGN_EXPORT size_t sgn_bin_prepare_workspace_bytes(int n) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
@@ -588,7 +593,7 @@ SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
 SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                                  const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
                                  int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *ws, size_t ws_bytes,
-                                 sgn_stream_t stream) {
+                                 const int32_t *n_isect_dev, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0 && n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     SGN_ARG_CHECK(tile_bins != nullptr, -3);
@@ -609,27 +614,28 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
         uint16_t *k16 = (uint16_t *)tkeys, *k16s = (uint16_t *)tkeys_sorted;
         sgn_timing_begin(SGN_T_MAP, s);
         hipLaunchKernelGGL(bin_emit_kernel<uint16_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
-                           recs, tiles_x, tiles_y, block_width, k16, tvals);
+                           recs, tiles_x, tiles_y, block_width, k16, tvals, (int)n_isect);
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
-        sgn_sort_pairs16_launch((uint32_t)n_isect, tile_bits, k16, tvals, k16s, gaussian_ids_sorted, sort_ws, s);
+        sgn_sort_pairs16_launch((uint32_t)n_isect, tile_bits, k16, tvals, k16s, gaussian_ids_sorted, sort_ws, s,
+                                n_isect_dev);
         sgn_timing_end(SGN_T_SORT, s);
         sgn_timing_begin(SGN_T_BINS, s);
         hipLaunchKernelGGL(tile_bins32_kernel<uint16_t>, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, k16s,
-                           tile_bins);
+                           tile_bins, n_isect_dev);
         sgn_timing_end(SGN_T_BINS, s);
     } else {
         sgn_timing_begin(SGN_T_MAP, s);
         hipLaunchKernelGGL(bin_emit_kernel<uint32_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
-                           recs, tiles_x, tiles_y, block_width, tkeys, tvals);
+                           recs, tiles_x, tiles_y, block_width, tkeys, tvals, (int)n_isect);
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
         sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws,
-                                s);
+                                s, n_isect_dev);
         sgn_timing_end(SGN_T_SORT, s);
         sgn_timing_begin(SGN_T_BINS, s);
         hipLaunchKernelGGL(tile_bins32_kernel<uint32_t>, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect,
-                           tkeys_sorted, tile_bins);
+                           tkeys_sorted, tile_bins, n_isect_dev);
         sgn_timing_end(SGN_T_BINS, s);
     }
     SGN_LAUNCH_CHECK();

@@ -36,8 +36,10 @@ __device__ __forceinline__ unsigned digit_of(K key, int shift, unsigned mask) {
 template <typename K, int BITS, int RS_IPT>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(uint32_t n, const K *__restrict__ keys, int shift,
                                                              unsigned dmask, uint32_t nblk,
-                                                             uint32_t *__restrict__ table) {
+                                                             uint32_t *__restrict__ table,
+                                                             const int32_t *__restrict__ n_dev) {
     constexpr int NB = 1 << BITS;
+    if (n_dev) n = min(n, (uint32_t)max(*n_dev, 0));   // speculative launch: n is the capacity, *n_dev the count
     constexpr int RS_TILE = RS_THREADS * RS_IPT;
     __shared__ uint32_t hist[NB];
     for (int d = threadIdx.x; d < NB; d += RS_THREADS) hist[d] = 0;
@@ -107,8 +109,10 @@ template <typename K, bool HAS_VAL, int BITS, int RS_IPT>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     uint32_t n, const K *__restrict__ keys_in, const int32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     int32_t *__restrict__ vals_out, int shift, unsigned dmask, uint32_t nblk, const uint32_t *__restrict__ table,
-    const uint32_t *__restrict__ totals) {
+    const uint32_t *__restrict__ totals, const int32_t *__restrict__ n_dev) {
     constexpr int NB = 1 << BITS;
+    if (n_dev) n = min(n, (uint32_t)max(*n_dev, 0));
+    if (blockIdx.x * (RS_THREADS * RS_IPT) >= n) return;   // workgroup-uniform
     constexpr int DPT = NB / RS_THREADS;  // digits owned per thread in the prefix phase (1 or 2)
     constexpr int RS_TILE = RS_THREADS * RS_IPT;   // keys per workgroup
     constexpr int RS_WAVE_ITEMS = 64 * RS_IPT;     // keys per wave
@@ -122,7 +126,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tile_base = blockIdx.x * RS_TILE;
-    const uint32_t tile_cnt = min((uint32_t)RS_TILE, n - tile_base);
+    const uint32_t tile_cnt = min((uint32_t)RS_TILE, n - tile_base);   // > 0: checked above
 #pragma unroll
     for (int w = 0; w < RS_WAVES; ++w)
 #pragma unroll
@@ -232,7 +236,7 @@ size_t sort_ws_bytes(int64_t n) {
 // ping-pong LSD passes; the last pass lands in keys_out / vals_out
 template <typename K, bool HAS_VAL, int BITS, int RS_IPT>
 void sort_launch_ipt(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const int32_t *vals_in, K *keys_out,
-                     int32_t *vals_out, void *ws, hipStream_t s) {
+                     int32_t *vals_out, void *ws, hipStream_t s, const int32_t *n_dev) {
     constexpr int NB = 1 << BITS;
     const uint32_t nblk = (uint32_t)sgn_cdiv(n, RS_THREADS * RS_IPT);
     char *p = (char *)ws;
@@ -254,10 +258,10 @@ void sort_launch_ipt(uint32_t n, int begin_bit, int end_bit, const K *keys_in, c
         K *dst_k = to_out ? keys_out : alt_keys;
         int32_t *dst_v = to_out ? vals_out : alt_vals;
         hipLaunchKernelGGL((rs_hist_kernel<K, BITS, RS_IPT>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, shift, dmask,
-                           nblk, table);
+                           nblk, table, n_dev);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(NB), dim3(RS_THREADS), 0, s, nblk, table, totals);
         hipLaunchKernelGGL((rs_scatter_kernel<K, HAS_VAL, BITS, RS_IPT>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, src_v,
-                           dst_k, dst_v, shift, dmask, nblk, table, totals);
+                           dst_k, dst_v, shift, dmask, nblk, table, totals, n_dev);
         src_k = dst_k;
         src_v = dst_v;
     }
@@ -265,11 +269,12 @@ void sort_launch_ipt(uint32_t n, int begin_bit, int end_bit, const K *keys_in, c
 
 template <typename K, bool HAS_VAL, int BITS>
 void sort_launch(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const int32_t *vals_in, K *keys_out,
-                 int32_t *vals_out, void *ws, hipStream_t s) {
+                 int32_t *vals_out, void *ws, hipStream_t s, const int32_t *n_dev = nullptr) {
+    // n_dev != nullptr: n is the CAPACITY the launch is sized for, the element count is read on the device
     if (rs_pick_ipt(n) == RS_IPT_SMALL)
-        sort_launch_ipt<K, HAS_VAL, BITS, RS_IPT_SMALL>(n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out, ws, s);
+        sort_launch_ipt<K, HAS_VAL, BITS, RS_IPT_SMALL>(n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out, ws, s, n_dev);
     else
-        sort_launch_ipt<K, HAS_VAL, BITS, RS_IPT_LARGE>(n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out, ws, s);
+        sort_launch_ipt<K, HAS_VAL, BITS, RS_IPT_LARGE>(n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out, ws, s, n_dev);
 }
 
 }  // namespace
@@ -277,14 +282,14 @@ void sort_launch(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const
 // internal (fused binning path, binning.hip)
 size_t sgn_sort_pairs32_ws_bytes(int64_t n) { return sort_ws_bytes<uint32_t, true, 8>(n); }
 void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const int32_t *vin, uint32_t *kout,
-                             int32_t *vout, void *ws, hipStream_t s) {
-    sort_launch<uint32_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s);
+                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev) {
+    sort_launch<uint32_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s, n_dev);
 }
 
 // 16-bit keys (tile ids of images with <= 65536 tiles); same workspace layout and size as the 32-bit entry
 void sgn_sort_pairs16_launch(uint32_t n, int end_bit, const uint16_t *kin, const int32_t *vin, uint16_t *kout,
-                             int32_t *vout, void *ws, hipStream_t s) {
-    sort_launch<uint16_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s);
+                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev) {
+    sort_launch<uint16_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s, n_dev);
 }
 
 SGN_EXPORT size_t sgn_sort_workspace_bytes(int64_t n_isect) { return sort_ws_bytes<uint64_t, true, 8>(n_isect); }

@@ -220,6 +220,49 @@ def test_binning_cache_reuse_and_invalidation():
         ops.clear_binning_cache()
 
 
+def test_speculative_binning_hits_misses_and_equals_the_plain_form():
+    """Emission and tile sort are queued before the host knows the intersection count, into buffers sized from the
+    previous call (ops._bin_finish).  The result must be the plain form's bit for bit whether the guess fits (hit,
+    also with a much smaller count) or not (miss: the scene grew 3x between two calls with the same N and grid)."""
+    from sgn_rast import ops, scenes, step
+    cam, raw = scenes.make_scene("c1", n_override=20000)
+    P = _to_dev(cam, raw)
+    big = dict(P)
+    big["log_scales"] = P["log_scales"] + 1.2            # ~3.3x larger splats: many more (tile, Gaussian) pairs
+    small = dict(P)
+    small["log_scales"] = P["log_scales"] - 1.0
+
+    def render(params, spec):
+        ops.speculative_binning = spec
+        ops.clear_binning_cache()
+        with torch.no_grad():
+            out = step.render(params, cam)
+        val = ops._bin_cache["val"]                        # (count, gaussian_ids_sorted, tile_bins) of this render
+        return out.rgb.clone(), out.alpha.clone(), val[1].clone(), val[2].clone()
+
+    try:
+        ops._last_count.clear()
+        stats = ops.binning_stats
+        h0, m0 = stats["speculative_hits"], stats["speculative_misses"]
+        ref = {k: render(p, False) for k, p in (("base", P), ("big", big), ("small", small))}
+        assert (stats["speculative_hits"], stats["speculative_misses"]) == (h0, m0)
+        ops._last_count.clear()
+        a = render(P, True)                                # nothing to guess from: plain form
+        assert (stats["speculative_hits"], stats["speculative_misses"]) == (h0, m0)
+        b = render(P, True)                                # same scene again: hit
+        assert stats["speculative_hits"] == h0 + 1
+        c = render(big, True)                              # 3x the pairs: the guess is too small -> miss, re-run
+        assert stats["speculative_misses"] == m0 + 1
+        d = render(small, True)                            # far fewer pairs than guessed: hit
+        assert stats["speculative_hits"] == h0 + 2
+        for got, want in ((a, ref["base"]), (b, ref["base"]), (c, ref["big"]), (d, ref["small"])):
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+            assert torch.equal(got[2], want[2]) and torch.equal(got[3], want[3])   # gaussian_ids_sorted, tile_bins
+    finally:
+        ops.speculative_binning = True
+        ops.clear_binning_cache()
+
+
 def test_quat_assertion_deferred_and_eager():
     """Upstream's "quats must be normalized" assertion: eager mode raises at project_gaussians like gsplat; the default
     deferred mode raises the same error at the next host sync of the path (inside rasterize_gaussians)."""
