@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--street", action="store_true",
                     help="non-uniform 'street' content (empty sky, ground, facades, dense low-opacity clusters) at the "
                          "scene's N and resolution: load-balance profiling, not the headline metric")
+    ap.add_argument("--translucent", action="store_true",
+                    help="opacity logits shifted by -2 (mean opacity ~0.15, as in a freshly initialised or opacity-reset "
+                         "scene): no tile saturates, every pixel walks its whole depth list (profiling workload)")
     ap.add_argument("--scene-graph", action="store_true",
                     help="reference-faithful scene-graph step (SURVEY.md §8d): background + 8 rigid objects, four "
                          "raster passes (rgb+alpha, depth, object acc, background acc); not the headline metric")
@@ -246,6 +249,8 @@ def main():
     cam, raw = scenes.make_scene(args.scene, seed=0, yaw=0.01 * rank, device=dev, n_override=args.n)
     if args.street:
         raw = scenes.make_street_gaussians(raw["means"].shape[0], cam, seed=0, device=dev)
+    if args.translucent:
+        raw["opacity_logits"] = raw["opacity_logits"] - 2.0
     P = step.leaf_params(raw)
     w_img, w_a = step.loss_weights(cam, seed=1000 + rank, device=dev)
     reducer = None
@@ -430,9 +435,13 @@ def main():
         }
         line["config"]["path"] = args.path
         line["config"]["quat_check"] = ops.quat_check
+        line["config"]["speculative_binning"] = dict(enabled=bool(ops.speculative_binning), **ops.binning_stats)
         if args.street:
             line["metric"] = "train-step images/sec (fwd+bwd), non-uniform street-like content (profiling workload)"
             line["config"]["workload"] = "street: " + line["config"]["workload"]
+        if args.translucent:
+            line["metric"] = "train-step images/sec (fwd+bwd), translucent content: no tile saturates (profiling workload)"
+            line["config"]["workload"] = "translucent (opacity logits - 2): " + line["config"]["workload"]
         if args.scene_graph:
             line["metric"] = "scene-graph train-step images/sec (4 raster passes, fwd+bwd) @1M Gaussians 1920x1280"
             line["config"]["workload"] = ("scene graph: " + line["config"]["workload"] +
