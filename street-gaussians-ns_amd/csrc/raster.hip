@@ -835,6 +835,10 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         // round last, 0.75 vs 0.57 ms on the street scene; a shared atomic cursor serialised on its one address,
         // +90 us even when there was nothing to do.)  Workgroups beyond the long prefix exit at once.
         if ((int)blockIdx.x >= 4 * tile_order[n_tiles]) return;
+        // These waves are the critical path of the backward on skewed content (one 3000-entry walk = 0.5 ms) and share
+        // their SIMDs with the short-walk kernel's waves: give them the issue priority (street scene: 516 -> 537
+        // images/s; two quadrants per wave here, i.e. half the reductions, made it 435: it IS the critical path).
+        __builtin_amdgcn_s_setprio(3);
         raster_bwd_tile<EXACT, REDUCE, GATHER, 1, false>(tile_order[blockIdx.x >> 2], blockIdx.x & 3, W, H, B, tiles_x,
                                                          bins, recs, ids, bg, final_T, final_idx, v_out, v_out_alpha,
                                                          alpha_clamp, grad_ws, dbg, adapt_thresh, batch_thresh);
