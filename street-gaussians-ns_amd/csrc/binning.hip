@@ -260,7 +260,16 @@ template <typename TK>
 struct GlobalOut {
     TK *__restrict__ tkeys;
     int32_t *__restrict__ tvals;
-    int cap;              // slots of the output buffers (speculative launches may be sized too small: never write past)
+    __device__ __forceinline__ void operator()(int pos, uint32_t key, int32_t val) const {
+        tkeys[pos] = (TK)key;
+        tvals[pos] = val;
+    }
+};
+template <typename TK>
+struct BoundedOut {       // a speculative launch whose buffers turn out too small: never write past `cap` slots
+    TK *__restrict__ tkeys;
+    int32_t *__restrict__ tvals;
+    int cap;
     __device__ __forceinline__ void operator()(int pos, uint32_t key, int32_t val) const {
         if (pos < cap) {
             tkeys[pos] = (TK)key;
@@ -443,15 +452,17 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
         }
     }
     const Ellipse E = make_ellipse(gx, gy, a, b, c, s);
-    if (total <= EMIT_CAP) {
+    if (base + total > cap) {                                 // wave-uniform; only a mis-sized speculative launch
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, BoundedOut<TK>{tkeys, tvals, cap});
+    } else if (total <= EMIT_CAP) {
         tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, LdsOut<TK>{lk, lv, base});
         __syncthreads();                                      // single-wave workgroup: a fence, no s_barrier
-        for (int j = lane; j < min(total, cap - base); j += 64) {
+        for (int j = lane; j < total; j += 64) {
             tkeys[base + j] = lk[j];
             tvals[base + j] = lv[j];
         }
     } else {
-        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, GlobalOut<TK>{tkeys, tvals, cap});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, GlobalOut<TK>{tkeys, tvals});
     }
 }
 
