@@ -6,4 +6,4 @@ ab() {  # label, bench args
     timeout 300 python bench.py $2 --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null | python profiles/scripts/benchline.py $1 $v
   done
 }
-ab street "--street"
+ab metric ""; ab street "--street"; ab translucent "--translucent"
