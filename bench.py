@@ -371,7 +371,7 @@ def main():
     # the same drop-in step with the two host syncs the reference's model code makes around the operators
     sync_extra = None
     if args.path == "dropin" and sg is None and not args.caller_syncs and not args.no_fused_extra:
-        deferred_mode, ops.quat_check = ops.quat_check, "eager"
+        deferred_mode, ops.quat_check = ops.quat_check, os.environ.get("SGN_BENCH_EAGER_MODE", "eager")
         for _ in range(max(2, args.warmup // 2)):
             one_step(caller_syncs=True)
         gc.collect()

@@ -164,27 +164,48 @@ class _ProjectGaussians(Function):
 
 # Upstream asserts `(quats.norm(dim=-1) - 1 < 1e-6).all()` on every project_gaussians call: four small kernels and a
 # host sync that drains the queue in the middle of the forward pass.  "eager" (DEFAULT: a drop-in replacement raises
-# where upstream raises) is that behaviour verbatim.  "deferred" is an opt-in (SGN_QUAT_CHECK=deferred, or
-# `ops.quat_check = "deferred"` as bench.py does): the same test as one device pass (sgn_check_unit_quats), raising the
-# same AssertionError at the NEXT host sync the path has anyway (the intersection-count read-back inside
-# rasterize_gaussians) - worth 0.1 ms per step; "off" skips the test.
+# where upstream raises — from the same project_gaussians call) runs the same one-sided test as ONE device pass
+# (sgn_check_unit_quats), queues the projection behind it and only then waits for the flag, so the GPU projects while
+# the host wakes up.  "deferred" is an opt-in (SGN_QUAT_CHECK=deferred, or `ops.quat_check = "deferred"` as bench.py
+# does): the flag is read at the NEXT host sync the path has anyway (the intersection-count read-back inside
+# rasterize_gaussians), raising the same AssertionError there — no sync of its own; "off" skips the test.
 quat_check = os.environ.get("SGN_QUAT_CHECK", "eager")
 _pending_checks: list = []
+_eager_side = {}   # per device: pinned int32[8] ring for the eager flag read-back
 
 
-def _check_quats(quats: torch.Tensor) -> None:
+def _check_quats(quats: torch.Tensor):
+    """Starts the argument check; returns None or a token for :func:`_finish_quat_check` (eager mode)."""
     if quat_check == "off":
-        return
-    if quat_check == "eager" or not quats.is_cuda:
+        return None
+    if quat_check == "eager-upstream" or not quats.is_cuda:      # upstream's literal expression (A/B, CPU tensors)
         assert (quats.norm(dim=-1) - 1 < 1e-6).all(), "quats must be normalized"
-        return
+        return None
     q = _f32c(quats)
     flag = torch.empty(1, dtype=torch.int32, device=q.device)
     L.check(L.load().sgn_check_unit_quats(q.shape[0], L.ptr(q), 1e-6, L.ptr(flag), L.stream_ptr()),
             "sgn_check_unit_quats")
+    if quat_check == "eager":
+        if q.device not in _eager_side:
+            _eager_side[q.device] = [torch.empty(8, dtype=torch.int32).pin_memory(), 0]
+        ring = _eager_side[q.device]
+        slot = ring[0][ring[1] % 8:ring[1] % 8 + 1]
+        ring[1] += 1
+        slot.copy_(flag, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(q.device))
+        return slot, done, flag
     if len(_pending_checks) >= 16:     # projections without a rasterize call in between: settle the backlog now
         raise_pending_checks()
     _pending_checks.append(flag)
+    return None
+
+
+def _finish_quat_check(token) -> None:
+    if token is not None:
+        slot, done, _keep = token
+        done.synchronize()
+        assert int(slot[0]) == 0, "quats must be normalized"
 
 
 def raise_pending_checks() -> None:
@@ -202,10 +223,12 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     Returns ``(xys, depths, radii, conics, compensation, num_tiles_hit, cov3d)``;
     ``viewmat`` is the world->camera matrix ([3,4] or [4,4]; only rows 0-2 are read)."""
     assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
-    _check_quats(quats)
-    return _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
-                                   viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
-                                   clip_thresh)
+    token = _check_quats(quats)
+    out = _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
+                                  viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
+                                  clip_thresh)
+    _finish_quat_check(token)          # eager mode: the projection is already queued while the host waits here
+    return out
 
 
 # ----------------------------------------------------------------- binning
