@@ -193,7 +193,7 @@ def _check_quats(quats: torch.Tensor):
         ring[1] += 1
         slot.copy_(flag, non_blocking=True)
         done = torch.cuda.Event()
-        done.record(torch.cuda.current_stream(q.device))
+        done.record()
         return slot, done, flag
     if len(_pending_checks) >= 16:     # projections without a rasterize call in between: settle the backlog now
         raise_pending_checks()
@@ -358,7 +358,7 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     for i, f in enumerate(flags):
         pinned[1 + i:2 + i].copy_(f, non_blocking=True)
     done = torch.cuda.Event()
-    done.record(torch.cuda.current_stream(dev))
+    done.record()
     st.update(cum_r=cum_r, gid_by_rank=gid_by_rank, bin_recs=bin_recs, ws=ws, done=done, pinned=pinned,
               n_flags=len(flags), keep=(xys_c, radii_c, conics_c, opac_c, flags))
     return st
@@ -460,7 +460,7 @@ binning_cache_enabled = True
 
 def _bin_key(tensors, tile_bounds, block_width, flags):
     return tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors) + (
-        tuple(int(b) for b in tile_bounds), int(block_width), flags, torch.cuda.current_stream().cuda_stream)
+        tuple(int(b) for b in tile_bounds), int(block_width), flags, L.stream_handle())
 
 
 def clear_binning_cache() -> None:
@@ -571,7 +571,7 @@ def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacit
     pool[1] += 1
     pinned[0:len(cands)].copy_(flags[0:len(cands)], non_blocking=True)
     done = torch.cuda.Event()
-    done.record(torch.cuda.current_stream(dev))
+    done.record()
     done.synchronize()
     if _pending_checks:
         raise_pending_checks()
