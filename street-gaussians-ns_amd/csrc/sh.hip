@@ -94,35 +94,102 @@ __device__ __forceinline__ void stage_rows(float *__restrict__ my, const float *
     }
 }
 
-// One wave (64 lanes) per 64 Gaussians; a block is WAVES waves with private LDS slabs.
+// LDS traffic between lanes of ONE wave (private slab): the hardware retires a wave's LDS operations in order, the
+// fence only keeps the compiler from moving them across
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// stage_rows split in two, so that the loads of the NEXT span can be in flight while this one is evaluated
+template <int KC>
+__device__ __forceinline__ void load_span(float4 (&v)[(16 * KC + 63) / 64], const float *__restrict__ src, int cnt,
+                                          int lane) {
+    constexpr int NIT = (16 * KC + 63) / 64;
+    const int n4 = (cnt * KC) >> 2;
+    const float4 *src4 = reinterpret_cast<const float4 *>(src);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int t = lane + 64 * it;
+        v[it] = (t < n4) ? src4[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+template <int KC, int LS>
+__device__ __forceinline__ void store_span(float *__restrict__ my, const float4 (&v)[(16 * KC + 63) / 64],
+                                           const float *__restrict__ src, int cnt, int lane) {
+    constexpr int NIT = (16 * KC + 63) / 64;
+    const int total = cnt * KC, n4 = total >> 2;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int t = lane + 64 * it;
+        if (t < n4) {
+            const float f[4] = {v[it].x, v[it].y, v[it].z, v[it].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int e = 4 * t + j, r = e / KC, c = e - r * KC;
+                my[r * LS + c] = f[j];
+            }
+        }
+    }
+    const int e = (n4 << 2) + lane;                   // up to three trailing floats of a partial wave
+    if (lane < (total & 3)) {
+        const int r = e / KC, c = e - r * KC;
+        my[r * LS + c] = src[e];
+    }
+}
+
+// One wave (64 lanes) per span of 64 Gaussians; a block is WAVES waves with private LDS slabs and each wave walks
+// spans in a grid-stride loop with the NEXT span's twelve float4 loads already in flight while it evaluates the
+// current one (one span per wave and no prefetch reached 4.1 TB/s where a plain streaming read on this GPU reaches
+// 6.5, profiles/microbench/hbm_rates.hip: with 12.5 KB of LDS per wave only 12 waves fit a CU, and each spent most
+// of its life NOT waiting for memory).
 // KC = K*3 dwords per row; LDS row stride KC+1 (odd) => conflict-free per-lane row walks.
 template <int K, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void sh_fwd_kernel(int n, int deg, const float *__restrict__ dirs,
                                                             const float *__restrict__ coeffs,
                                                             float *__restrict__ colors) {
-    constexpr int KC = K * 3, LS = KC + 1;
+    constexpr int KC = K * 3, LS = KC + 1, NIT = (16 * KC + 63) / 64;
     __shared__ float lds[WAVES][64 * LS];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g0 = (blockIdx.x * WAVES + wave) * 64;
-    const int cnt = max(0, min(64, n - g0));
+    const int n_spans = (n + 63) >> 6, stride = gridDim.x * WAVES;
     float *my = lds[wave];
-    stage_rows<KC, LS>(my, coeffs + (size_t)g0 * KC, cnt, lane);
-    __syncthreads();
-    if (lane >= cnt) return;
-    const int i = g0 + lane;
-    float b[25];
-    const int nb = sh_bases(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2], deg, b);
-    const float *row = my + lane * LS;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const bool aligned = (reinterpret_cast<uintptr_t>(coeffs) & 15) == 0;   // 64 rows * KC floats keep the alignment
+    int span = blockIdx.x * WAVES + wave;
+    float4 v[NIT];
+    float d0 = 0.f, d1 = 0.f, d2 = 1.f;               // this lane's view direction of the span in flight
+    auto fetch = [&](int sp) __attribute__((always_inline)) {
+        const int g = sp * 64, c = min(64, n - g);
+        if (aligned) load_span<KC>(v, coeffs + (size_t)g * KC, c, lane);
+        if (lane < c) { d0 = dirs[3 * (g + lane)]; d1 = dirs[3 * (g + lane) + 1]; d2 = dirs[3 * (g + lane) + 2]; }
+    };
+    if (span < n_spans) fetch(span);
+    for (; span < n_spans; span += stride) {
+        const int g0 = span * 64, cnt = min(64, n - g0);
+        const float *src = coeffs + (size_t)g0 * KC;
+        if (aligned) store_span<KC, LS>(my, v, src, cnt, lane);
+        else stage_rows<KC, LS>(my, src, cnt, lane);                        // a view with an odd storage offset
+        const float x = d0, y = d1, z = d2;
+        const int next = span + stride;
+        if (next < n_spans) fetch(next);
+        wave_lds_fence();
+        if (lane < cnt) {
+            const int i = g0 + lane;
+            float b[25];
+            const int nb = sh_bases(x, y, z, deg, b);
+            const float *row = my + lane * LS;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        if (k < nb) {
-            a0 += b[k] * row[3 * k];
-            a1 += b[k] * row[3 * k + 1];
-            a2 += b[k] * row[3 * k + 2];
+            for (int k = 0; k < K; ++k) {
+                if (k < nb) {
+                    a0 += b[k] * row[3 * k];
+                    a1 += b[k] * row[3 * k + 1];
+                    a2 += b[k] * row[3 * k + 2];
+                }
+            }
+            colors[3 * i] = a0; colors[3 * i + 1] = a1; colors[3 * i + 2] = a2;
         }
+        wave_lds_fence();                              // this span's row reads stay ahead of the next span's writes
     }
-    colors[3 * i] = a0; colors[3 * i + 1] = a1; colors[3 * i + 2] = a2;
 }
 
 template <int K, int WAVES>
@@ -352,8 +419,10 @@ template <int K>
 int launch_fwd(int n, int deg, const float *dirs, const float *coeffs, float *colors, hipStream_t s) {
     constexpr int WAVES = (K > 16) ? 2 : 4;  // keep static LDS under 64 KiB
     sgn_timing_begin(SGN_T_SH_FWD, s);
-    hipLaunchKernelGGL((sh_fwd_kernel<K, WAVES>), dim3(sgn_cdiv(n, WAVES * 64)), dim3(WAVES * 64), 0, s, n,
-                       deg, dirs, coeffs, colors);
+    // grid-stride over spans: enough workgroups to fill the LDS-limited residency (160 KB / slab bytes per CU) twice
+    const int full = sgn_cdiv(n, WAVES * 64);
+    const int grid = full < 256 * 6 ? full : 256 * 6;
+    hipLaunchKernelGGL((sh_fwd_kernel<K, WAVES>), dim3(grid), dim3(WAVES * 64), 0, s, n, deg, dirs, coeffs, colors);
     sgn_timing_end(SGN_T_SH_FWD, s);
     return 0;
 }

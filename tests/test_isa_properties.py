@@ -111,6 +111,8 @@ def test_streaming_kernels_issue_their_loads_before_the_first_lds_write(tmp_path
     fast = fwd[fwd.index("global_load_dwordx4"):]                 # the aligned fast path: 12 float4 per lane
     first_store = min(i for i in (fast.find("ds_write"), fast.find("ds_store")) if i >= 0)
     assert fast[:first_store].count("global_load_dwordx4") >= 10     # (the scheduler may sink one or two)
+    # the grid-stride loop prefetches the NEXT span: a second batch of twelve float4 loads after the LDS writes
+    assert fwd.count("global_load_dwordx4") >= 24 and "s_cbranch" in fwd
     rs = _kernels(_asm(tmp_path_factory, "radix_sort"))
     scat = next(t for k, t in rs.items() if "rs_scatter_kernelIjLb1ELi8ELi16E" in k)
     first_wait = scat.index("s_waitcnt vmcnt(0)")
