@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=100,
+                    help="untimed steps run BEFORE the W warm-up steps (same count on every rank: the steps contain "
+                         "collectives) so that clocks, the caching allocator, RCCL channels and the speculative binning's "
+                         "capacity estimate are steady when the driver asks for a short warm-up (W=5, K=20 is a 30 ms window)")
     ap.add_argument("--scene", default="metric", choices=["c1", "c2", "metric", "c4"])
     ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -317,6 +321,9 @@ def main():
         if world > 1:
             torch.distributed.barrier(device_ids=[local])
 
+    for _ in range(max(0, args.settle)):
+        one_step()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = one_step()
     torch.cuda.synchronize()
@@ -434,6 +441,7 @@ def main():
             "kernels_avg_ms": {k: round(v[1], 4) for k, v in kernels.items()},
         }
         line["config"]["path"] = args.path
+        line["config"]["settle_steps"] = max(0, args.settle)   # untimed, before the W warm-up steps
         line["config"]["quat_check"] = ops.quat_check
         line["config"]["speculative_binning"] = dict(enabled=bool(ops.speculative_binning), **ops.binning_stats)
         if args.street:

@@ -357,6 +357,24 @@ int sgn_l1_ssim_fwd(int h, int w, const float *pred, const float *gt, float data
 int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt, float clamp_max, const void *ws,
                     const float *gscale2, float *v_pred, sgn_stream_t stream);
 
+/* Accumulation regularisers of the reference's loss dictionary, means over the n_pixels = H*W
+ * entries of [H,W,1] accumulation images, one pass each way for both terms (either may be absent):
+ *   out2[0] = mean([semantic == sky_value] * accumulation)      sgn_splatfacto.py:1090-1093 (losses["sky_accumulation"]
+ *                                                               before its config multiplier; gt_semantic is int64)
+ *   out2[1] = mean(-(o log o + (1 - o) log(1 - o))), o = clamp(object_acc, 1e-5, 1 - 1e-5)
+ *                                                               sgn_splatfacto_scene_graph.py:386-389
+ * accumulation == NULL skips the first term (out2[0] = 0), object_acc == NULL the second.  semantic holds n_pixels
+ * integers of sem_bytes in {1, 4, 8} bytes (uint8 / bool mask with sky_value 1, int32, int64).  The backward takes
+ * gscale2 = (d loss/d out2[0], d loss/d out2[1]) as two DEVICE floats and writes d loss/d accumulation and/or
+ * d loss/d object_acc (NULL = not wanted); torch.clamp's rule: zero gradient outside [1e-5, 1 - 1e-5]. */
+size_t sgn_acc_losses_workspace_bytes(int64_t n_pixels);
+int sgn_acc_losses_fwd(int64_t n_pixels, const float *accumulation, const void *semantic, int sem_bytes,
+                       int64_t sky_value, const float *object_acc, float *out2, void *ws, size_t ws_bytes,
+                       sgn_stream_t stream);
+int sgn_acc_losses_bwd(int64_t n_pixels, const void *semantic, int sem_bytes, int64_t sky_value,
+                       const float *object_acc, const float *gscale2, float *v_accumulation, float *v_object_acc,
+                       sgn_stream_t stream);
+
 /* One torch.optim.Adam step (amsgrad = False, weight_decay = 0, maximize = False) over `count` tensors in a single
  * launch (optimiser set-up at sgn_config.py:71-108, eps = 1e-15).  Every array argument is a HOST
  * array of length `count`; params / grads / exp_avgs / exp_avg_sqs hold DEVICE pointers to contiguous fp32 tensors of

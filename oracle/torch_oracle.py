@@ -521,3 +521,18 @@ def l1_ssim_losses(rgb: torch.Tensor, gt: torch.Tensor):
     Ll1 = torch.abs(gt - rgb).mean()
     s = ssim(gt.permute(2, 0, 1)[None, ...], rgb.permute(2, 0, 1)[None, ...])
     return Ll1, s
+
+
+def sky_accumulation_loss(accumulation: torch.Tensor, gt_semantic: torch.Tensor, sky_value: int = 2) -> torch.Tensor:
+    """``(sky_mask * accumulation).mean()`` with ``sky_mask = (gt_semantic == SemanticType.SKY.value)`` exactly as
+    sgn_splatfacto.py:1092-1093 writes it (before ``sky_acc_loss_mult``); accumulation / gt_semantic [H,W,1].
+    Pinned against the reference's own ``get_loss_dict`` in tests/test_reference_literal.py."""
+    sky_mask = gt_semantic == sky_value
+    return (sky_mask * accumulation).mean()
+
+
+def object_acc_entropy_loss(object_acc: torch.Tensor) -> torch.Tensor:
+    """Binary entropy of the clamped object accumulation exactly as sgn_splatfacto_scene_graph.py:387-389 writes it
+    (before ``object_acc_entropy_loss_mult``).  Pinned against the reference's own ``get_loss_dict``."""
+    object_acc = torch.clamp(object_acc, min=1e-5, max=1 - 1e-5)
+    return -(object_acc * torch.log(object_acc) + (1. - object_acc) * torch.log(1. - object_acc)).mean()

@@ -299,3 +299,139 @@ SGN_EXPORT int sgn_l1_ssim_bwd(int h, int w, const float *pred, const float *gt,
     SGN_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Accumulation regularisers of the reference's loss dictionary, both means over the H*W pixels
+// of an [H,W,1] accumulation image the rasterizer produced:
+//   losses["sky_accumulation"]        = mult * (sky_mask * accumulation).mean(),  sky_mask = (gt_semantic == SKY)
+//                                       street_gaussians_ns/sgn_splatfacto.py:1090-1093 (gt_semantic int64 [H,W,1])
+//   losses["object_acc_entropy_loss"] = mult * -(o log o + (1 - o) log(1 - o)).mean(),  o = clamp(object_acc, 1e-5, 1 - 1e-5)
+//                                       street_gaussians_ns/sgn_splatfacto_scene_graph.py:386-389
+// In torch these are ~10 elementwise launches forward and as many backward over 2.46 M pixels; here one streaming pass
+// each way computes both (either may be absent), per-workgroup partial sums, means formed in the reduction.
+namespace {
+
+constexpr int ACC_THREADS = 256, ACC_MAX_BLOCKS = 2048;
+
+__device__ __forceinline__ bool sem_is(const void *sem, int sem_bytes, size_t i, long long value) {
+    if (sem_bytes == 8) return ((const long long *)sem)[i] == value;
+    if (sem_bytes == 4) return (long long)((const int *)sem)[i] == value;
+    return (long long)((const unsigned char *)sem)[i] == value;
+}
+
+__device__ __forceinline__ float acc_clamp_lo() { return 1e-5f; }
+__device__ __forceinline__ float acc_clamp_hi() { return (float)(1.0 - 1e-5); }   // torch rounds the Python scalar to fp32
+
+__global__ __launch_bounds__(ACC_THREADS) void acc_losses_fwd_kernel(long long n, const float *__restrict__ acc,
+                                                                     const void *__restrict__ sem, int sem_bytes,
+                                                                     long long sky_value,
+                                                                     const float *__restrict__ obj,
+                                                                     float *__restrict__ partials) {
+    __shared__ float lds4[4];
+    float sky = 0.f, ent = 0.f;
+    const long long stride = (long long)gridDim.x * ACC_THREADS;
+    for (long long i = (long long)blockIdx.x * ACC_THREADS + threadIdx.x; i < n; i += stride) {
+        if (acc) {
+            const float a = acc[i];
+            sky += sem_is(sem, sem_bytes, (size_t)i, sky_value) ? a : 0.f;
+        }
+        if (obj) {
+            const float o = fminf(fmaxf(obj[i], acc_clamp_lo()), acc_clamp_hi());
+            const float q = 1.f - o;
+            ent -= o * logf(o) + q * logf(q);
+        }
+    }
+    const float bs = block_sum(sky, lds4);
+    const float be = block_sum(ent, lds4);
+    if (threadIdx.x == 0) {
+        partials[2 * blockIdx.x] = bs;
+        partials[2 * blockIdx.x + 1] = be;
+    }
+}
+
+__global__ __launch_bounds__(ACC_THREADS) void acc_losses_reduce_kernel(int nblk, const float *__restrict__ partials,
+                                                                        double inv_n, float *__restrict__ out2) {
+    __shared__ double lds[ACC_THREADS];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += ACC_THREADS) { a += (double)partials[2 * i]; b += (double)partials[2 * i + 1]; }
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        lds[threadIdx.x] = pass ? b : a;
+        __syncthreads();
+        for (int d = ACC_THREADS / 2; d >= 1; d >>= 1) {
+            if ((int)threadIdx.x < d) lds[threadIdx.x] += lds[threadIdx.x + d];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out2[pass] = (float)(lds[0] * inv_n);
+    }
+}
+
+// v_acc[i] = g0 / n * [sem == sky];  v_obj[i] = g1 / n * (log(1 - o) - log(o)) inside the clamp, 0 outside
+// (torch.clamp passes the gradient where min <= x <= max)
+__global__ __launch_bounds__(ACC_THREADS) void acc_losses_bwd_kernel(long long n, const void *__restrict__ sem,
+                                                                     int sem_bytes, long long sky_value,
+                                                                     const float *__restrict__ obj,
+                                                                     const float *__restrict__ gscale, float n_f,
+                                                                     float *__restrict__ v_acc,
+                                                                     float *__restrict__ v_obj) {
+    const float g0 = gscale[0] / n_f, g1 = gscale[1] / n_f;      // mean's backward: grad / numel, a true division
+    const long long stride = (long long)gridDim.x * ACC_THREADS;
+    for (long long i = (long long)blockIdx.x * ACC_THREADS + threadIdx.x; i < n; i += stride) {
+        if (v_acc) v_acc[i] = sem_is(sem, sem_bytes, (size_t)i, sky_value) ? g0 : 0.f;
+        if (v_obj) {
+            const float raw = obj[i];
+            const bool inside = raw >= acc_clamp_lo() && raw <= acc_clamp_hi();
+            const float o = fminf(fmaxf(raw, acc_clamp_lo()), acc_clamp_hi());
+            v_obj[i] = inside ? g1 * (logf(1.f - o) - logf(o)) : 0.f;
+        }
+    }
+}
+
+inline int acc_blocks(int64_t n) {
+    const int b = sgn_cdiv(n, ACC_THREADS);
+    return b < 1 ? 1 : (b > ACC_MAX_BLOCKS ? ACC_MAX_BLOCKS : b);
+}
+
+}  // namespace
+
+SGN_EXPORT size_t sgn_acc_losses_workspace_bytes(int64_t n_pixels) {
+    return (((size_t)acc_blocks(n_pixels) * 2 * sizeof(float)) + 255) & ~(size_t)255;
+}
+
+SGN_EXPORT int sgn_acc_losses_fwd(int64_t n_pixels, const float *accumulation, const void *semantic, int sem_bytes,
+                                  int64_t sky_value, const float *object_acc,
+                                  float *out2 /*device: [mean(sky_mask * acc), mean entropy]*/, void *ws, size_t ws_bytes,
+                                  sgn_stream_t stream) {
+    SGN_ARG_CHECK(n_pixels > 0, -1);
+    SGN_ARG_CHECK(out2 && ws && (accumulation || object_acc), -2);
+    SGN_ARG_CHECK(!accumulation || (semantic && (sem_bytes == 1 || sem_bytes == 4 || sem_bytes == 8)), -3);
+    SGN_ARG_CHECK(ws_bytes >= sgn_acc_losses_workspace_bytes(n_pixels), -4);
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = acc_blocks(n_pixels);
+    sgn_timing_begin(SGN_T_LOSS_FWD, (void *)s);
+    hipLaunchKernelGGL(acc_losses_fwd_kernel, dim3(nblk), dim3(ACC_THREADS), 0, s, (long long)n_pixels, accumulation,
+                       semantic, sem_bytes, (long long)sky_value, object_acc, (float *)ws);
+    hipLaunchKernelGGL(acc_losses_reduce_kernel, dim3(1), dim3(ACC_THREADS), 0, s, nblk, (const float *)ws,
+                       1.0 / (double)n_pixels, out2);
+    sgn_timing_end(SGN_T_LOSS_FWD, (void *)s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_acc_losses_bwd(int64_t n_pixels, const void *semantic, int sem_bytes, int64_t sky_value,
+                                  const float *object_acc,
+                                  const float *gscale2 /*device: [d loss/d sky mean, d loss/d entropy mean]*/,
+                                  float *v_accumulation, float *v_object_acc, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n_pixels > 0, -1);
+    SGN_ARG_CHECK(gscale2 && (v_accumulation || v_object_acc), -2);
+    SGN_ARG_CHECK(!v_accumulation || (semantic && (sem_bytes == 1 || sem_bytes == 4 || sem_bytes == 8)), -3);
+    SGN_ARG_CHECK(!v_object_acc || object_acc, -4);
+    hipStream_t s = (hipStream_t)stream;
+    sgn_timing_begin(SGN_T_LOSS_BWD, (void *)s);
+    hipLaunchKernelGGL(acc_losses_bwd_kernel, dim3(acc_blocks(n_pixels)), dim3(ACC_THREADS), 0, s, (long long)n_pixels,
+                       semantic, sem_bytes, (long long)sky_value, object_acc, gscale2, (float)n_pixels,
+                       v_accumulation, v_object_acc);
+    sgn_timing_end(SGN_T_LOSS_BWD, (void *)s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

@@ -44,6 +44,9 @@ SIGNATURES = {
     "sgn_l1_ssim_workspace_bytes": (_sz, [_i, _i, _i]),
     "sgn_l1_ssim_fwd": (_i, [_i, _i, _vp, _vp, _f, _f, _f, _vp, _i, _vp, _sz, _vp]),
     "sgn_l1_ssim_bwd": (_i, [_i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
+    "sgn_acc_losses_workspace_bytes": (_sz, [_i64]),
+    "sgn_acc_losses_fwd": (_i, [_i64, _vp, _vp, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_acc_losses_bwd": (_i, [_i64, _vp, _i, _i64, _vp, _vp, _vp, _vp, _vp]),
     "sgn_adam_step": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_densify_stats": (_i, [_i, _vp, _vp, _f, _i, _vp, _vp, _vp, _vp]),
     "sgn_check_unit_quats": (_i, [_i, _vp, _f, _vp, _vp]),

@@ -13,6 +13,11 @@ ABI (``sgn_l1_ssim_fwd/bwd``) directly on the rasterizer's HWC image; fails loud
 * :func:`l1_ssim` — ``(Ll1, ssim)`` of two [H,W,3] images, gradient to ``pred``.
 * :class:`SSIM` — ``pytorch_msssim.SSIM`` call shape (``forward(X, Y)`` on [1,3,H,W]) for the import shim; the
   permuted views the reference passes are recognised and used in place (no NCHW copy).
+* :func:`sky_accumulation`, :func:`object_acc_entropy`, :func:`accumulation_losses` — the two accumulation
+  regularisers of the reference's loss dictionary (``sgn_splatfacto.py:1090-1093``,
+  ``sgn_splatfacto_scene_graph.py:386-389``): ``(sky_mask * accumulation).mean()`` and the binary entropy of the clamped
+  object accumulation, one streaming pass each way for both (``sgn_acc_losses_fwd/bwd``) instead of ~10 elementwise
+  torch launches forward and as many backward.
 """
 from __future__ import annotations
 
@@ -128,3 +133,84 @@ class SSIM(torch.nn.Module):
         if x.requires_grad:
             return l1_ssim(x, y, self.data_range)[1]
         return l1_ssim(y, x, self.data_range)[1]
+
+
+# ------------------------------------------------------------------------------------------- accumulation regularisers
+SKY = 2   # street_gaussians_ns/data/utils/data_utils.py:26-29  SemanticType.SKY
+
+
+def _sem_arg(semantic: torch.Tensor, n: int):
+    """(contiguous integer tensor, bytes per element) the C ABI accepts: 1 (uint8 / bool), 4 (int32), 8 (int64)."""
+    if semantic.numel() != n:
+        raise ValueError(f"semantic has {semantic.numel()} elements, the accumulation image {n}")
+    t = semantic.detach()
+    if t.dtype == torch.bool:
+        t = t.contiguous().view(torch.uint8)
+    elif t.dtype not in (torch.uint8, torch.int32, torch.int64):
+        t = t.to(torch.int64)
+    t = t.contiguous()
+    return t, t.element_size()
+
+
+class _AccLosses(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, accumulation, semantic, sky_value, object_acc):
+        dev = L.require_device(accumulation, semantic, object_acc)
+        if accumulation is None and object_acc is None:
+            raise ValueError("accumulation_losses needs an accumulation image, an object accumulation image or both")
+        if accumulation is not None and semantic is None:
+            raise ValueError("the sky-accumulation term needs the semantic image")
+        n = (accumulation if accumulation is not None else object_acc).numel()
+        if n < 1 or (accumulation is not None and object_acc is not None and object_acc.numel() != n):
+            raise ValueError("accumulation images must be non-empty and of one size")
+        acc = None if accumulation is None else accumulation.detach().float().contiguous()
+        obj = None if object_acc is None else object_acc.detach().float().contiguous()
+        sem, sem_bytes = (None, 0) if accumulation is None else _sem_arg(semantic, n)
+        if sem is not None and sem.dtype == torch.uint8 and semantic.dtype == torch.bool:
+            sky_value = 1 if sky_value else 0      # a boolean mask: "is sky" is True
+        lib = L.load()
+        out2 = torch.empty(2, dtype=torch.float32, device=dev)
+        ws = L.workspace(lib.sgn_acc_losses_workspace_bytes(n), dev)
+        L.check(lib.sgn_acc_losses_fwd(n, L.ptr(acc), L.ptr(sem), sem_bytes, int(sky_value), L.ptr(obj), L.ptr(out2),
+                                       L.ptr(ws), ws.numel(), L.stream_ptr()), "sgn_acc_losses_fwd")
+        ctx.n, ctx.sem_bytes, ctx.sky_value = n, sem_bytes, int(sky_value)
+        ctx.acc_shape = None if accumulation is None else accumulation.shape
+        ctx.obj_shape = None if object_acc is None else object_acc.shape
+        ctx.sem, ctx.obj = sem, obj
+        return out2[0], out2[1]
+
+    @staticmethod
+    def backward(ctx, g_sky, g_ent):
+        want_acc = ctx.acc_shape is not None and ctx.needs_input_grad[0]
+        want_obj = ctx.obj_shape is not None and ctx.needs_input_grad[3]
+        if not (want_acc or want_obj):
+            return None, None, None, None
+        gscale = torch.stack([g_sky.reshape(()), g_ent.reshape(())]).float().contiguous()
+        f32 = dict(dtype=torch.float32, device=gscale.device)
+        v_acc = torch.empty(ctx.n, **f32) if want_acc else None
+        v_obj = torch.empty(ctx.n, **f32) if want_obj else None
+        L.check(L.load().sgn_acc_losses_bwd(ctx.n, L.ptr(ctx.sem) if want_acc else None, ctx.sem_bytes, ctx.sky_value,
+                                            L.ptr(ctx.obj) if want_obj else None, L.ptr(gscale), L.ptr(v_acc),
+                                            L.ptr(v_obj), L.stream_ptr()), "sgn_acc_losses_bwd")
+        return (v_acc.reshape(ctx.acc_shape) if want_acc else None, None, None,
+                v_obj.reshape(ctx.obj_shape) if want_obj else None)
+
+
+def accumulation_losses(accumulation, semantic, object_acc, sky_value: int = SKY):
+    """``((sky_mask * accumulation).mean(), -(o log o + (1 - o) log(1 - o)).mean())`` with ``sky_mask = (semantic ==
+    sky_value)`` and ``o = clamp(object_acc, 1e-5, 1 - 1e-5)`` — the reference's two accumulation regularisers BEFORE
+    their config multipliers (``sky_acc_loss_mult`` 0.5, ``object_acc_entropy_loss_mult`` 0.001), in one forward and
+    one backward pass.  ``accumulation`` / ``object_acc``: [H,W,1] (or [H,W]) float images; ``semantic``: integer (the
+    reference's int64 [H,W,1]) or boolean "is sky" image.  Either image may be ``None`` (its term is then 0)."""
+    return _AccLosses.apply(accumulation, semantic, sky_value, object_acc)
+
+
+def sky_accumulation(accumulation, semantic, sky_value: int = SKY) -> torch.Tensor:
+    """``(sky_mask * accumulation).mean()`` (``sgn_splatfacto.py:1092-1093``)."""
+    return _AccLosses.apply(accumulation, semantic, sky_value, None)[0]
+
+
+def object_acc_entropy(object_acc) -> torch.Tensor:
+    """``-(o log o + (1 - o) log(1 - o)).mean()``, ``o = clamp(object_acc, 1e-5, 1 - 1e-5)``
+    (``sgn_splatfacto_scene_graph.py:387-389``)."""
+    return _AccLosses.apply(None, None, 0, object_acc)[1]

@@ -99,3 +99,66 @@ def test_fused_clamp_equals_torch_clamp_then_loss():
     loss.photometric_loss(p_hip, gt.cuda(), 0.2, clamp_max=1.0).backward()
     assert rel_l2(p_hip.grad.cpu(), p_ref.grad) < 2e-5
     assert float(p_hip.grad[pred.cuda() > 1].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ accumulation regularisers (sgn_acc_losses_*)
+def _acc_images(h, w, seed):
+    g = torch.Generator().manual_seed(seed)
+    acc = torch.rand(h, w, 1, generator=g)
+    obj = torch.rand(h, w, 1, generator=g)
+    obj[0, : min(w, 7)] = 0.0                       # below the 1e-5 clamp: value clamped, no gradient
+    obj[-1, : min(w, 7)] = 1.0                      # above the 1 - 1e-5 clamp
+    obj[h // 2, : min(w, 7)] = 0.5
+    sem = torch.randint(0, 3, (h, w, 1), generator=g)           # int64, as the reference's dataset builds it
+    return acc, obj, sem
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (7, 13), (128, 96), (333, 257), (1280, 1920)])
+def test_accumulation_losses_forward_backward(h, w):
+    """Both terms in one pass each way vs the reference's literal expressions (oracle.sky_accumulation_loss /
+    object_acc_entropy_loss; sgn_splatfacto.py:1092-1093, sgn_splatfacto_scene_graph.py:387-389)."""
+    from sgn_rast import loss
+    acc, obj, sem = _acc_images(h, w, 7 * h + w)
+    a_ref, o_ref = acc.clone().requires_grad_(True), obj.clone().requires_grad_(True)
+    s_ref, e_ref = O.sky_accumulation_loss(a_ref, sem), O.object_acc_entropy_loss(o_ref)
+    (0.5 * s_ref + 0.001 * e_ref).backward()
+    a, o = acc.cuda().requires_grad_(True), obj.cuda().requires_grad_(True)
+    s, e = loss.accumulation_losses(a, sem.cuda(), o)
+    (0.5 * s + 0.001 * e).backward()
+    assert abs(float(s) - float(s_ref)) <= 2e-6 * max(1e-3, abs(float(s_ref)))
+    assert abs(float(e) - float(e_ref)) <= 2e-6 * max(1e-3, abs(float(e_ref)))
+    assert torch.allclose(a.grad.cpu(), a_ref.grad, rtol=3e-7, atol=0.0)      # upstream / n on the mask, 0 elsewhere
+    assert a.grad.shape == acc.shape and o.grad.shape == obj.shape
+    assert (o.grad.cpu() - o_ref.grad).abs().max() <= 2e-6 * o_ref.grad.abs().max() + 1e-12
+    clamped = (obj < 1e-5) | (obj > 1 - 1e-5)
+    assert float(o.grad.cpu()[clamped].abs().sum()) == 0.0
+
+
+def test_accumulation_losses_single_terms_and_semantic_dtypes():
+    from sgn_rast import loss
+    acc, obj, sem = _acc_images(61, 47, 3)
+    want_s, want_e = float(O.sky_accumulation_loss(acc, sem)), float(O.object_acc_entropy_loss(obj))
+    for semantic in (sem, sem.int(), sem.to(torch.uint8), sem == 2, sem[..., 0]):
+        a = acc.cuda().requires_grad_(True)
+        s = loss.sky_accumulation(a, semantic.cuda())
+        s.backward()
+        assert abs(float(s) - want_s) < 1e-6, semantic.dtype
+        assert torch.allclose(a.grad.cpu(), (sem == 2).float().reshape(acc.shape) / acc.numel(), rtol=3e-7, atol=0.0)
+    o = obj.cuda().requires_grad_(True)
+    e = loss.object_acc_entropy(o)
+    e.backward()
+    o_ref = obj.clone().requires_grad_(True)
+    O.object_acc_entropy_loss(o_ref).backward()
+    assert abs(float(e) - want_e) < 1e-6
+    assert (o.grad.cpu() - o_ref.grad).abs().max() <= 2e-6 * o_ref.grad.abs().max()
+    # a term whose image needs no gradient is skipped in the backward; nothing to do at all returns None
+    a = acc.cuda().requires_grad_(True)
+    s, e = loss.accumulation_losses(a, sem.cuda(), obj.cuda())
+    (s + e).backward()
+    assert a.grad is not None
+    with pytest.raises(ValueError):
+        loss.accumulation_losses(None, None, None)
+    with pytest.raises(ValueError):
+        loss.sky_accumulation(acc.cuda(), sem[:10].cuda())
+    with pytest.raises(Exception):
+        loss.sky_accumulation(acc, sem)             # CPU tensors: no fallback

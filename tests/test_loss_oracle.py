@@ -49,3 +49,29 @@ def test_c_and_torch_restatements_of_l1_ssim_agree(c_oracle):
         l1_t, s_t = O.l1_ssim_losses(x, y)
         l1_c, s_c = c_oracle.l1_ssim(x, y)
         assert abs(l1_c - float(l1_t)) < 1e-6 and abs(s_c - float(s_t)) < 5e-6
+
+
+def test_accumulation_regularisers_closed_forms():
+    """oracle/torch_oracle.py:sky_accumulation_loss / object_acc_entropy_loss (the reference's literal expressions,
+    pinned against its own get_loss_dict in test_reference_literal.py): values and gradients in closed form."""
+    g = torch.Generator().manual_seed(3)
+    H, W = 24, 40
+    acc = torch.rand(H, W, 1, generator=g, dtype=torch.float64).requires_grad_(True)
+    sem = torch.randint(0, 3, (H, W, 1), generator=g)
+    O.sky_accumulation_loss(acc, sem).backward()
+    assert torch.equal(acc.grad, (sem == 2).double() / (H * W))
+    assert float(O.sky_accumulation_loss(torch.ones(H, W, 1), torch.full((H, W, 1), 2))) == 1.0
+    assert float(O.sky_accumulation_loss(torch.ones(H, W, 1), torch.zeros(H, W, 1, dtype=torch.int64))) == 0.0
+    o = torch.rand(H, W, 1, generator=g, dtype=torch.float64)
+    o[0, :5] = 0.0
+    o[1, :5] = 1.0
+    o[2, :5] = 0.5
+    o.requires_grad_(True)
+    e = O.object_acc_entropy_loss(o)
+    e.backward()
+    oc = o.detach().clamp(1e-5, 1 - 1e-5)
+    want = torch.log(1 - oc) - torch.log(oc)
+    want[(o.detach() < 1e-5) | (o.detach() > 1 - 1e-5)] = 0.0            # clamp: no gradient outside
+    assert torch.allclose(o.grad * (H * W), want, rtol=1e-10, atol=1e-12)
+    assert abs(float(O.object_acc_entropy_loss(torch.full((4, 4, 1), 0.5, dtype=torch.float64))) - 0.6931471805599453) < 1e-12
+    assert float(O.object_acc_entropy_loss(torch.zeros(4, 4, 1, dtype=torch.float64))) < 2e-4   # 1e-5 clamp, not 0 log 0

@@ -62,8 +62,7 @@ def _replay_losses(out, sky, batch, ssim_lambda=0.2, sky_mult=0.5):
     a = out.alpha[..., None]
     rgb = torch.clamp(out.rgb, max=1.0) * a + sky * (1 - a)                    # :969-972
     l1, ssim = O.l1_ssim_losses(rgb, batch["image"])
-    sky_mask = batch["semantic"] == 2
-    return (1 - ssim_lambda) * l1 + ssim_lambda * (1 - ssim) + sky_mult * (sky_mask * a).mean(), rgb
+    return (1 - ssim_lambda) * l1 + ssim_lambda * (1 - ssim) + sky_mult * O.sky_accumulation_loss(a, batch["semantic"]), rgb
 
 
 REF2OURS = dict(means="means", scales="log_scales", quats="quats", features_dc="features_dc",
@@ -168,8 +167,8 @@ def test_scene_graph_runs_literally_and_equals_the_replay(ns):
     Ms = [step.leaf_params(m) for m in models]
     exp = step.render_scene_graph(Ms, p_t, idft, cam, ops=oracle_ops)
     loss, rgb = _replay_losses(exp, out["sky"].detach(), batch)
-    oa = torch.clamp(exp.object_acc[..., None], min=1e-5, max=1 - 1e-5)        # scene_graph.py:386-389
-    loss = loss + 0.001 * -(oa * torch.log(oa) + (1.0 - oa) * torch.log(1.0 - oa)).mean()
+    from oracle import torch_oracle as O
+    loss = loss + 0.001 * O.object_acc_entropy_loss(exp.object_acc[..., None])    # scene_graph.py:386-389
     loss.backward()
     for key, got, want in (("accumulation", out["accumulation"][..., 0], exp.alpha), ("depth", out["depth"], exp.depth),
                            ("object_acc", out["object_acc"][..., 0], exp.object_acc),
