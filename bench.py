@@ -146,15 +146,16 @@ def cpu_baseline(scene: str, n_override: int, rows: int, frac: int = 8):
                    + ("" if n_s == n_full else f", then x{n_full / n_s:.1f} for the Gaussian subsample")
                    + f" -> {t_full:.1f}s/step"),
     }
-    res["c_port"] = cpu_baseline_c(scene, n_override)
+    res["c_port"] = cpu_baseline_c(scene, n_override, every=int(os.environ.get("SGN_BENCH_C_EVERY", "1")))
     return res
 
 
-def cpu_baseline_c(scene: str, n_override: int, every: int = 8):
-    """Second CPU number, MEASURED rather than modelled: the scalar plain-C restatement (oracle/c/sgn_oracle.c, one
-    core) runs the whole train-step image — projection, SH, binning of ALL Gaussians, backward — with the compositing
-    done on every `every`-th tile row (pixels are independent and the rows are spread over the image, so the
-    compositing time scales by exactly that factor; nothing is extrapolated over the Gaussian count)."""
+def cpu_baseline_c(scene: str, n_override: int, every: int = 1):
+    """Second CPU number, MEASURED: the scalar plain-C restatement (oracle/c/sgn_oracle.c, one core) runs ONE WHOLE
+    train-step image — projection, SH, binning, compositing of every pixel, the full backward — on all the Gaussians
+    (every = 1: nothing is sampled or extrapolated; ~14 s on the GPU box's host).  every > 1 composites only every
+    `every`-th tile row (pixels are independent, the rows are spread over the image, so the compositing time scales by
+    exactly that factor) for quick runs."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_ops
     from oracle import c_oracle as CO
@@ -162,21 +163,29 @@ def cpu_baseline_c(scene: str, n_override: int, every: int = 8):
     cam, raw = scenes.make_scene(scene, n_override=n_override)
     P = step.leaf_params(raw)
     tiles_y = (cam.height + 15) // 16
+    w_img, w_a = step.loss_weights(cam, seed=7)
+    n_all = raw['means'].shape[0]
+    if every <= 1:
+        t0 = time.perf_counter()
+        step.train_step(P, cam, w_img, w_a, ops=oracle_ops)
+        t_full = time.perf_counter() - t0
+        return {"value": 1.0 / t_full, "unit": "images/sec", "cores": 1, "kind": "port",
+                "sample": (f"plain-C scalar oracle, scene '{scene}' {cam.width}x{cam.height}, ALL {n_all} Gaussians, every "
+                           f"pixel, fwd+bwd: one whole train-step image measured, {t_full:.1f}s/step (nothing extrapolated)")}
     rows = list(range(every // 2, tiles_y, every))
     mask = torch.zeros(cam.height, 1)
     for r in rows:
         mask[r * 16:(r + 1) * 16] = 1.0
-    w_img, w_a = step.loss_weights(cam, seed=7)
     w_img, w_a = w_img * mask[..., None], w_a * mask
     t_comp = [0.0]
     fwd0, bwd0 = CO.raster_fwd, CO.raster_bwd
 
     def fwd(H, W, block, ids, bins, xys, conics, colors, opac, bg, rows=None):
         t = time.perf_counter()
-        out = img, fT, fi = None, None, None
+        out = None
         for r in rows_:
             o = fwd0(H, W, block, ids, bins, xys, conics, colors, opac, bg, rows=(r * 16, min(H, (r + 1) * 16)))
-            out = o if out[0] is None else tuple(a + b for a, b in zip(out, o))
+            out = o if out is None else tuple(a + b for a, b in zip(out, o))
         t_comp[0] += time.perf_counter() - t
         return out
 
@@ -200,7 +209,7 @@ def cpu_baseline_c(scene: str, n_override: int, every: int = 8):
         CO.raster_fwd, CO.raster_bwd = fwd0, bwd0
     t_full = (t_all - t_comp[0]) + t_comp[0] * tiles_y / len(rows)
     return {"value": 1.0 / t_full, "unit": "images/sec", "cores": 1, "kind": "port",
-            "sample": (f"plain-C scalar oracle, scene '{scene}', ALL {raw['means'].shape[0]} Gaussians, fwd+bwd: measured "
+            "sample": (f"plain-C scalar oracle, scene '{scene}', ALL {n_all} Gaussians, fwd+bwd: measured "
                        f"{t_all:.1f}s with compositing on {len(rows)}/{tiles_y} tile rows spread over the image "
                        f"({t_comp[0]:.1f}s of it); compositing x{tiles_y / len(rows):.1f} -> {t_full:.1f}s/step")}
 
