@@ -41,29 +41,53 @@ __device__ __forceinline__ int block_incl_scan(int v, int *lds4, int &total) {
     return w + off;
 }
 
+// `idx` (optional, with `gathered`): the first pass reads in[idx[i]] and leaves the gathered values in `gathered`,
+// which the final pass then reads linearly — the fused binning scans the kept-tile counts in depth-rank order without
+// a gather launch of its own (gathering in BOTH passes was measured: 10.3 us each against 4.6 / 5.6 linear)
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(int n, const int32_t *__restrict__ in,
+                                                                   const int32_t *__restrict__ idx,
+                                                                   int32_t *__restrict__ gathered,
                                                                    int32_t *__restrict__ partial) {
     __shared__ int lds4[4];
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
+    int j[SCAN_ITEMS], v[SCAN_ITEMS];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) j[k] = (base + k < n) ? (idx ? idx[base + k] : base + k) : -1;
     int s = 0;
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; ++k)
-        if (base + k < n) s += in[base + k];
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (j[k] >= 0) ? in[j[k]] : 0;
+        s += v[k];
+    }
+    if (gathered) {
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k)
+            if (j[k] >= 0) gathered[base + k] = v[k];
+    }
     int total;
     block_incl_scan(s, lds4, total);
     if (threadIdx.x == 0) partial[blockIdx.x] = total;
 }
 
-// single workgroup: in-place exclusive scan of the per-chunk totals
+// single workgroup: in-place exclusive scan of the per-chunk totals; SCAN_ITEMS consecutive totals per thread, all
+// requested before the first use (up to 2048 chunks = 4 M items in one round trip and one block scan)
 __global__ __launch_bounds__(SCAN_THREADS) void scan_partials_kernel(int nb, int32_t *__restrict__ partial) {
     __shared__ int lds4[4];
     int carry = 0;
-    for (int b0 = 0; b0 < nb; b0 += SCAN_THREADS) {
-        const int i = b0 + threadIdx.x;
-        const int v = (i < nb) ? partial[i] : 0;
+    for (int b0 = 0; b0 < nb; b0 += SCAN_CHUNK) {
+        const int i0 = b0 + threadIdx.x * SCAN_ITEMS;
+        int v[SCAN_ITEMS], sum = 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) v[k] = (i0 + k < nb) ? partial[i0 + k] : 0;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) sum += v[k];
         int total;
-        const int inc = block_incl_scan(v, lds4, total);
-        if (i < nb) partial[i] = carry + inc - v;
+        int run = carry + block_incl_scan(sum, lds4, total) - sum;
+#pragma unroll
+        for (int k = 0; k < SCAN_ITEMS; ++k) {
+            if (i0 + k < nb) partial[i0 + k] = run;
+            run += v[k];
+        }
         carry += total;
     }
 }
@@ -411,13 +435,6 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
     }
 }
 
-__global__ __launch_bounds__(256) void gather_counts_kernel(int n, const int32_t *__restrict__ gid_by_rank,
-                                                            const int32_t *__restrict__ cnt_gid,
-                                                            int32_t *__restrict__ cnt_r) {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r < n) cnt_r[r] = cnt_gid[gid_by_rank[r]];
-}
-
 // lane = depth rank r: writes the (tile, gaussian id) pairs of Gaussian gid_by_rank[r] starting at cum_r[r-1].
 // One wave per workgroup.  The 64 Gaussians of a wave own one contiguous output range; when it fits EMIT_CAP
 // entries the pairs are staged in LDS and written out with full-width coalesced stores (per-lane sequential
@@ -428,11 +445,15 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
                                                       const int32_t *__restrict__ cum_r,
                                                       const BinRec *__restrict__ recs, int tiles_x, int tiles_y,
                                                       int block, TK *__restrict__ tkeys,
-                                                      int32_t *__restrict__ tvals, int cap) {
+                                                      int32_t *__restrict__ tvals, int cap,
+                                                      int32_t *__restrict__ zero_buf, int zero_n) {
     __shared__ TK lk[EMIT_CAP];
     __shared__ int32_t lv[EMIT_CAP];
     __shared__ FlatScratch scratch;
     const int lane = threadIdx.x;
+    // tile_bins must read 0 for tiles without entries and tile_bins32_kernel (two launches later on this stream)
+    // only writes the tiles that have some: cleared here instead of by a memset launch of its own (~5 us each)
+    for (int j = blockIdx.x * 64 + lane; j < zero_n; j += gridDim.x * 64) zero_buf[j] = 0;
     const int r0 = blockIdx.x * 64, r = r0 + lane;
     int mnx = 0, mny = 0, mxx = 0, mxy = 0, gid = 0;
     float gx = 0.f, gy = 0.f, a = 1.f, b = 0.f, c = 1.f, s = -1.f;
@@ -466,22 +487,39 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
     }
 }
 
-// sorted tile ids -> tile_bins
+// sorted tile ids -> tile_bins.  A thread takes the 16 bytes of keys at 16 * idx (8 sixteen-bit or 4 thirty-two-bit
+// ids: one vector load) plus the key before them and writes the boundaries it sees (one key per thread with two
+// scalar loads each took 12.9 us for the 8.3 M pairs of the benchmark scene).  `tkeys` is 16-byte aligned
+// (workspace carve-outs are 256-byte aligned).
 template <typename TK>
 __global__ __launch_bounds__(256) void tile_bins32_kernel(int64_t n_isect, const TK *__restrict__ tkeys,
                                                           int32_t *__restrict__ bins,
                                                           const int32_t *__restrict__ n_dev) {
+    constexpr int KPT = 16 / (int)sizeof(TK);
     if (n_dev) n_isect = min(n_isect, (int64_t)max(*n_dev, 0));   // speculative launch: n_isect is the capacity
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= n_isect) return;
-    const int32_t cur = (int32_t)tkeys[idx];
-    if (idx == 0) bins[2 * cur] = 0;
-    if (idx == n_isect - 1) bins[2 * cur + 1] = (int32_t)n_isect;
-    if (idx == 0) return;
-    const int32_t prev = (int32_t)tkeys[idx - 1];
-    if (prev != cur) {
-        bins[2 * prev + 1] = (int32_t)idx;
-        bins[2 * cur] = (int32_t)idx;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * KPT;
+    if (i0 >= n_isect) return;
+    TK k[KPT];
+    if (i0 + KPT <= n_isect) {
+        const uint4 raw = *reinterpret_cast<const uint4 *>(tkeys + i0);
+        __builtin_memcpy(k, &raw, 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) k[j] = (i0 + j < n_isect) ? tkeys[i0 + j] : (TK)0;
+    }
+    int32_t prev = (i0 > 0) ? (int32_t)tkeys[i0 - 1] : -1;
+#pragma unroll
+    for (int j = 0; j < KPT; ++j) {
+        const int64_t idx = i0 + j;
+        if (idx >= n_isect) break;
+        const int32_t cur = (int32_t)k[j];
+        if (idx == 0) bins[2 * cur] = 0;
+        else if (prev != cur) {
+            bins[2 * prev + 1] = (int32_t)idx;
+            bins[2 * cur] = (int32_t)idx;
+        }
+        if (idx == n_isect - 1) bins[2 * cur + 1] = (int32_t)n_isect;
+        prev = cur;
     }
 }
 
@@ -494,22 +532,28 @@ SGN_EXPORT size_t sgn_scan_workspace_bytes(int n) {
     return (size_t)(sgn_cdiv(n > 0 ? n : 1, SCAN_CHUNK) + 1) * sizeof(int32_t);
 }
 
+// out[i] = sum_{r <= i} in[idx ? idx[r] : r];  with idx, `gathered` (n ints) receives in[idx[r]]
+static int scan_launch(int n, const int32_t *in, const int32_t *idx, int32_t *gathered, int32_t *out, void *ws,
+                       hipStream_t s) {
+    const int nb = sgn_cdiv(n, SCAN_CHUNK);
+    int32_t *partial = (int32_t *)ws;
+    sgn_timing_begin(SGN_T_SCAN, s);
+    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, n, in, idx, idx ? gathered : nullptr,
+                       partial);
+    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, partial);
+    hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, n, idx ? gathered : in, partial, out);
+    sgn_timing_end(SGN_T_SCAN, s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
 SGN_EXPORT int sgn_scan_i32(int n, const int32_t *in, int32_t *out, void *ws, size_t ws_bytes,
                             sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     if (n == 0) return 0;
     SGN_ARG_CHECK(in && out && ws, -2);
     SGN_ARG_CHECK(ws_bytes >= sgn_scan_workspace_bytes(n), -3);
-    hipStream_t s = (hipStream_t)stream;
-    const int nb = sgn_cdiv(n, SCAN_CHUNK);
-    int32_t *partial = (int32_t *)ws;
-    sgn_timing_begin(SGN_T_SCAN, s);
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, n, in, partial);
-    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, partial);
-    hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, n, in, partial, out);
-    sgn_timing_end(SGN_T_SCAN, s);
-    SGN_LAUNCH_CHECK();
-    return 0;
+    return scan_launch(n, in, nullptr, nullptr, out, ws, (hipStream_t)stream);
 }
 
 SGN_EXPORT int sgn_map_isect(int n, const float *xys, const float *depths, const int32_t *radii,
@@ -578,8 +622,8 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     uint32_t *dkeys = (uint32_t *)p; p += al256((size_t)n * 4);
     int32_t *dvals = (int32_t *)p;   p += al256((size_t)n * 4);
     uint32_t *dkeys_sorted = (uint32_t *)p; p += al256((size_t)n * 4);
-    int32_t *cnt_r = (int32_t *)p;   p += al256((size_t)n * 4);
     int32_t *cnt_gid = (int32_t *)p; p += al256((size_t)n * 4);
+    int32_t *cnt_r = (int32_t *)p;   p += al256((size_t)n * 4);
     void *sort_ws = p;
     const Cull c = make_cull(conics, opacities, opacity_is_logit, cull);
     BinRec *recs = reinterpret_cast<BinRec *>(bin_records);
@@ -590,10 +634,8 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     sgn_timing_begin(SGN_T_SORT, s);
     sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
     sgn_timing_end(SGN_T_SORT, s);
-    sgn_timing_begin(SGN_T_MAP, s);
-    hipLaunchKernelGGL(gather_counts_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, gid_by_rank, cnt_gid, cnt_r);
-    sgn_timing_end(SGN_T_MAP, s);
-    return sgn_scan_i32(n, cnt_r, cum_by_rank, scan_ws, sgn_scan_workspace_bytes(n), stream);
+    // cum_by_rank[r] = sum of the kept-tile counts of ranks <= r: the scan's first pass gathers cnt_gid[gid_by_rank[r]]
+    return scan_launch(n, cnt_gid, gid_by_rank, cnt_r, cum_by_rank, scan_ws, s);
 }
 
 SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
@@ -610,8 +652,10 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
     SGN_ARG_CHECK(tile_bins != nullptr, -3);
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = tiles_x * tiles_y;
-    SGN_HIP_CHECK(hipMemsetAsync(tile_bins, 0, (size_t)n_tiles * 2 * sizeof(int32_t), s));
-    if (n_isect == 0 || n == 0) return 0;
+    if (n_isect == 0 || n == 0) {
+        SGN_HIP_CHECK(hipMemsetAsync(tile_bins, 0, (size_t)n_tiles * 2 * sizeof(int32_t), s));
+        return 0;
+    }
     SGN_ARG_CHECK(bin_records && cum_by_rank && gid_by_rank && gaussian_ids_sorted && ws, -4);
     SGN_ARG_CHECK(ws_bytes >= sgn_bin_intersect_workspace_bytes(n_isect), -5);
     const int tile_bits = bit_length((uint32_t)(n_tiles - 1)) > 0 ? bit_length((uint32_t)(n_tiles - 1)) : 1;
@@ -625,27 +669,27 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
         uint16_t *k16 = (uint16_t *)tkeys, *k16s = (uint16_t *)tkeys_sorted;
         sgn_timing_begin(SGN_T_MAP, s);
         hipLaunchKernelGGL(bin_emit_kernel<uint16_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
-                           recs, tiles_x, tiles_y, block_width, k16, tvals, (int)n_isect);
+                           recs, tiles_x, tiles_y, block_width, k16, tvals, (int)n_isect, tile_bins, 2 * n_tiles);
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
         sgn_sort_pairs16_launch((uint32_t)n_isect, tile_bits, k16, tvals, k16s, gaussian_ids_sorted, sort_ws, s,
                                 n_isect_dev);
         sgn_timing_end(SGN_T_SORT, s);
         sgn_timing_begin(SGN_T_BINS, s);
-        hipLaunchKernelGGL(tile_bins32_kernel<uint16_t>, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, k16s,
+        hipLaunchKernelGGL(tile_bins32_kernel<uint16_t>, dim3(sgn_cdiv(n_isect, 256 * 8)), dim3(256), 0, s, n_isect, k16s,
                            tile_bins, n_isect_dev);
         sgn_timing_end(SGN_T_BINS, s);
     } else {
         sgn_timing_begin(SGN_T_MAP, s);
         hipLaunchKernelGGL(bin_emit_kernel<uint32_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
-                           recs, tiles_x, tiles_y, block_width, tkeys, tvals, (int)n_isect);
+                           recs, tiles_x, tiles_y, block_width, tkeys, tvals, (int)n_isect, tile_bins, 2 * n_tiles);
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
         sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws,
                                 s, n_isect_dev);
         sgn_timing_end(SGN_T_SORT, s);
         sgn_timing_begin(SGN_T_BINS, s);
-        hipLaunchKernelGGL(tile_bins32_kernel<uint32_t>, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect,
+        hipLaunchKernelGGL(tile_bins32_kernel<uint32_t>, dim3(sgn_cdiv(n_isect, 256 * 4)), dim3(256), 0, s, n_isect,
                            tkeys_sorted, tile_bins, n_isect_dev);
         sgn_timing_end(SGN_T_BINS, s);
     }

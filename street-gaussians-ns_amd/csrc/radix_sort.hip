@@ -24,7 +24,10 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = 4;
 // keys per thread: 16 (4096-key tiles) for large inputs; 4 (1024-key tiles) below RS_SMALL_N keys, where 4096-key
 // tiles would leave most of the 256 CUs idle (1 M keys = 245 tiles) and every pass latency-bound
-constexpr int RS_IPT_LARGE = 16, RS_IPT_SMALL = 4;
+#ifndef SGN_RS_IPT_LARGE
+#define SGN_RS_IPT_LARGE 16
+#endif
+constexpr int RS_IPT_LARGE = SGN_RS_IPT_LARGE, RS_IPT_SMALL = 4;
 constexpr uint32_t RS_SMALL_N = 3u << 20;
 inline int rs_pick_ipt(int64_t n) { return n < (int64_t)RS_SMALL_N ? RS_IPT_SMALL : RS_IPT_LARGE; }
 
@@ -45,7 +48,38 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(uint32_t n, const K
     for (int d = threadIdx.x; d < NB; d += RS_THREADS) hist[d] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE;
-    K kk[RS_IPT];                       // all loads first: a load -> LDS-atomic loop waits out HBM once per key
+    // Which key a thread counts does not matter for a histogram, so a thread takes 16-byte vectors of consecutive keys
+    // (8 sixteen-bit tile ids per load instead of eight 2-byte loads: the 16-bit histogram of the 8.3 M-pair tile sort
+    // took 11.2 us for 16.6 MB).  All loads are issued before the first LDS atomic.
+    constexpr int VEC = 16 / (int)sizeof(K);
+    if constexpr (RS_IPT % VEC == 0) {
+        if ((reinterpret_cast<uintptr_t>(keys) & 15u) == 0) {       // workgroup-uniform
+            constexpr int NV = RS_IPT / VEC;
+            K kv[NV][VEC];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const uint32_t i = base + (v * RS_THREADS + threadIdx.x) * VEC;
+                if (i + VEC <= n) {
+                    const uint4 raw = *reinterpret_cast<const uint4 *>(keys + i);
+                    __builtin_memcpy(kv[v], &raw, 16);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) kv[v][j] = (i + j < n) ? keys[i + j] : (K)0;
+                }
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const uint32_t i = base + (v * RS_THREADS + threadIdx.x) * VEC;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    if (i + j < n) atomicAdd(&hist[digit_of<K>(kv[v][j], shift, dmask)], 1u);
+            }
+            __syncthreads();
+            for (int d = threadIdx.x; d < NB; d += RS_THREADS) table[(size_t)d * nblk + blockIdx.x] = hist[d];
+            return;
+        }
+    }
+    K kk[RS_IPT];                       // unaligned input / short tiles: one key per load, all loads first
 #pragma unroll
     for (int k = 0; k < RS_IPT; ++k) {
         const uint32_t i = base + k * RS_THREADS + threadIdx.x;
@@ -88,18 +122,30 @@ __device__ __forceinline__ uint32_t block_excl_scan_u32(uint32_t v, uint32_t *ld
 }
 
 // grid = number of digits (one workgroup per digit): table[d][0..nblk) -> exclusive prefix,
-// totals[d] = row sum
+// totals[d] = row sum.  Each thread owns RS_SCAN_ITEMS consecutive entries and requests all of them before the
+// first use, so a row of up to 256 * RS_SCAN_ITEMS tiles (8 M keys in 4096-key tiles) is ONE global round trip and
+// ONE block scan; the kernel is pure latency (a few KB per workgroup), and as a 256-entry-per-iteration loop it paid
+// four to eight dependent round trips and twice as many barriers per launch, six launches per binning.
+constexpr int RS_SCAN_ITEMS = 8;
 __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t nblk, uint32_t *__restrict__ table,
                                                              uint32_t *__restrict__ totals) {
     __shared__ uint32_t lds4[4];
     uint32_t *row = table + (size_t)blockIdx.x * nblk;
     uint32_t carry = 0;
-    for (uint32_t b0 = 0; b0 < nblk; b0 += RS_THREADS) {
-        const uint32_t i = b0 + threadIdx.x;
-        const uint32_t v = (i < nblk) ? row[i] : 0u;
+    for (uint32_t b0 = 0; b0 < nblk; b0 += RS_THREADS * RS_SCAN_ITEMS) {
+        const uint32_t i0 = b0 + threadIdx.x * RS_SCAN_ITEMS;
+        uint32_t v[RS_SCAN_ITEMS], sum = 0;
+#pragma unroll
+        for (int k = 0; k < RS_SCAN_ITEMS; ++k) v[k] = (i0 + k < nblk) ? row[i0 + k] : 0u;
+#pragma unroll
+        for (int k = 0; k < RS_SCAN_ITEMS; ++k) sum += v[k];
         uint32_t total;
-        const uint32_t ex = block_excl_scan_u32(v, lds4, total);
-        if (i < nblk) row[i] = carry + ex;
+        uint32_t run = carry + block_excl_scan_u32(sum, lds4, total);
+#pragma unroll
+        for (int k = 0; k < RS_SCAN_ITEMS; ++k) {
+            if (i0 + k < nblk) row[i0 + k] = run;
+            run += v[k];
+        }
         carry += total;
     }
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
@@ -127,17 +173,13 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t tile_base = blockIdx.x * RS_TILE;
     const uint32_t tile_cnt = min((uint32_t)RS_TILE, n - tile_base);   // > 0: checked above
-#pragma unroll
-    for (int w = 0; w < RS_WAVES; ++w)
-#pragma unroll
-        for (int j = 0; j < DPT; ++j) wcnt[w][tid * DPT + j] = 0;
-    __syncthreads();
-
     K key[RS_IPT];
     int32_t val[RS_IPT];
     uint32_t rank[RS_IPT];
-    volatile uint32_t *mycnt = wcnt[wave];
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    // the wave's counters through an explicit LDS pointer: as a generic `volatile uint32_t *` every access was compiled
+    // to flat_load / flat_store with sc0 sc1 and a full s_waitcnt vmcnt(0) behind it (two per key)
+    typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+    volatile lds_u32_t *mycnt = (volatile lds_u32_t *)(&wcnt[wave][0]);
     // every key / value of the tile is requested before the first ranking step: the volatile LDS counters below
     // pin program order, so loads left inside the ranking loop are waited for one HBM round trip at a time
 #pragma unroll
@@ -147,31 +189,56 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         key[r] = valid ? keys_in[tile_base + li] : (K)~(K)0;
         if constexpr (HAS_VAL) val[r] = valid ? vals_in[tile_base + li] : 0;
     }
+    // the digit totals and this tile's column of the scanned table do not depend on the ranking: requested here, with
+    // the keys, instead of after the ranking barrier (a strided global read per thread: ~2 us on the critical path of
+    // every workgroup, and the 1 M-key depth passes are ONE round of workgroups, i.e. pure workgroup latency)
+    uint32_t gtot[DPT], tcol[DPT];
+#pragma unroll
+    for (int j = 0; j < DPT; ++j) {
+        const int d = tid * DPT + j;
+        gtot[j] = totals[d];
+        tcol[j] = table[(size_t)d * nblk + blockIdx.x];
+    }
+    // counters cleared while the loads are in flight
+#pragma unroll
+    for (int w = 0; w < RS_WAVES; ++w)
+#pragma unroll
+        for (int j = 0; j < DPT; ++j) wcnt[w][tid * DPT + j] = 0;
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_IPT; ++r) {
         const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;
         const bool valid = li < tile_cnt;
         const unsigned d = digit_of<K>(key[r], shift, dmask);
-        unsigned long long m = __ballot(valid);
+        // match mask m = lanes of this wave holding the same digit: per bit, keep the lanes that voted like me.  Spelled
+        // on 32-bit halves with nb = all-ones where my bit is set, m &= ~(vote ^ nb) is one v_bitop3 per half (the
+        // `bit ? vote : ~vote` form on a 64-bit value took 13 instructions per bit); invalid lanes are masked once, by
+        // the initial value, and passes narrower than BITS stop early (wave-uniform).
+        const unsigned long long vmask = __ballot(valid);
+        uint32_t m_lo = (uint32_t)vmask, m_hi = (uint32_t)(vmask >> 32);
 #pragma unroll
         for (int b = 0; b < BITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long vote = __ballot(valid && bit);
-            m &= bit ? vote : ~vote;
+            if (!((dmask >> b) & 1u)) break;
+            const uint32_t nb = (uint32_t)(((int32_t)(d << (31 - b))) >> 31);   // v_bfe_i32: all ones where bit b is set
+            const unsigned long long vote = __builtin_amdgcn_ballot_w64(nb != 0u);
+            m_lo &= ~((uint32_t)vote ^ nb);
+            m_hi &= ~((uint32_t)(vote >> 32) ^ nb);
         }
-        // lanes of one match group (same digit) read the wave's running counter, the first lane of
-        // the group bumps it.  LDS ops of one wave retire in order, `volatile` keeps program order.
+        // lanes of my group below me (v_mbcnt): my rank inside the group; the group's first lane has none
+        const uint32_t below = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+        // lanes of one match group read the wave's running counter, the first lane of the group bumps it.
+        // LDS ops of one wave retire in order, `volatile` keeps program order.
         uint32_t prev = 0;
         if (valid) {
             prev = mycnt[d];
-            if ((m & lt_mask) == 0ull) mycnt[d] = prev + (uint32_t)__popcll(m);
+            if (below == 0u) mycnt[d] = prev + (uint32_t)(__popc(m_lo) + __popc(m_hi));
         }
-        rank[r] = prev + (uint32_t)__popcll(m & lt_mask);
+        rank[r] = prev + below;
     }
     __syncthreads();
 
     // thread t owns digits [t*DPT, t*DPT+DPT): per-wave counts -> exclusive per-wave offsets + totals
-    uint32_t tot[DPT], gtot[DPT], tsum = 0, gsum = 0;
+    uint32_t tot[DPT], tsum = 0, gsum = 0;
 #pragma unroll
     for (int j = 0; j < DPT; ++j) {
         const int d = tid * DPT + j;
@@ -183,7 +250,6 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
             t += c;
         }
         tot[j] = t;
-        gtot[j] = totals[d];
         tsum += t;
         gsum += gtot[j];
     }
@@ -194,7 +260,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     for (int j = 0; j < DPT; ++j) {
         const int d = tid * DPT + j;
         dstart[d] = dst;
-        gbase[d] = gst + table[(size_t)d * nblk + blockIdx.x] - dst;  // global pos = gbase[d] + local pos
+        gbase[d] = gst + tcol[j] - dst;  // global pos = gbase[d] + local pos
         dst += tot[j];
         gst += gtot[j];
     }
