@@ -116,4 +116,11 @@ def test_streaming_kernels_issue_their_loads_before_the_first_lds_write(tmp_path
     rs = _kernels(_asm(tmp_path_factory, "radix_sort"))
     scat = next(t for k, t in rs.items() if "rs_scatter_kernelIjLb1ELi8ELi16E" in k)
     first_wait = scat.index("s_waitcnt vmcnt(0)")
-    assert scat[:first_wait].count("global_load_dword") == 32     # 16 keys + 16 values in flight before ranking starts
+    # 16 keys + 16 values + the digit total and the scanned-table column of the thread's digit: all in flight before the
+    # ranking starts (the last two used to be requested after the ranking barrier)
+    assert scat[:first_wait].count("global_load_dword") == 34
+    # the per-wave counters are reached through an LDS pointer: as a generic volatile pointer they compiled to
+    # flat_load / flat_store sc0 sc1 + s_waitcnt vmcnt(0), twice per key
+    for k, t in rs.items():
+        assert "flat_load" not in t and "flat_store" not in t, k
+    assert "ds_read_b32" in scat and "ds_write_b32" in scat and "v_mbcnt_hi_u32_b32" in scat and "v_bitop3_b32" in scat
