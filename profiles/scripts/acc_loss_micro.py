@@ -43,7 +43,20 @@ def run(fn):
 
 t_torch, a1, o1 = run(torch_losses)
 t_hip, a2, o2 = run(hip_losses)
+# both loops above are bound by the host (a dozen launches of ~10 us kernels): the kernels' own time, from the
+# library's HIP-event spans
+from sgn_rast import _lib as L
+L.timing_enable(True)
+a, o = acc0.clone().requires_grad_(True), obj0.clone().requires_grad_(True)
+for _ in range(20):
+    a.grad = o.grad = None
+    hip_losses(a, o).backward()
+torch.cuda.synchronize()
+rep = L.timing_report()
+L.timing_enable(False)
+k_fwd, k_bwd = (rep[k][1] / max(rep[k][0], 1) for k in ("loss_fwd", "loss_bwd"))
 rel = float((o1.grad - o2.grad).norm() / o1.grad.norm())
 print(f"sky-accumulation + object-entropy fwd+bwd 1920x1280: torch ops {t_torch:.3f} ms, fused HIP {t_hip:.3f} ms, "
       f"speed-up {t_torch / t_hip:.1f}x, loss {float(torch_losses(acc0, obj0)):.8f} vs {float(hip_losses(acc0, obj0)):.8f}, "
-      f"entropy grad rel-L2 {rel:.2e}, sky grad max|diff| {float((a1.grad - a2.grad).abs().max()):.1e}")
+      f"entropy grad rel-L2 {rel:.2e}, sky grad max|diff| {float((a1.grad - a2.grad).abs().max()):.1e}; "
+      f"HIP kernels alone: forward {1e3 * k_fwd:.1f} us (pass + reduction), backward {1e3 * k_bwd:.1f} us")
