@@ -178,7 +178,8 @@ def test_bin_and_sort_pipeline_bit_exact(hip, c_oracle):
     assert torch.equal(gbins.cpu(), bins)
 
 
-@pytest.mark.parametrize("n,size,focal", [(30000, (640, 360), 500.0), (5000, (130, 70), 100.0), (1, (64, 64), 64.0)])
+@pytest.mark.parametrize("n,size,focal", [(30000, (640, 360), 500.0), (5000, (130, 70), 100.0), (1, (64, 64), 64.0),
+                                          (20000, (4208, 4208), 3000.0)])   # 263 x 263 tiles > 65536: 32-bit tile keys
 def test_fused_rank_binning_equals_upstream_shaped_path(hip, c_oracle, n, size, focal):
     """The rank-order emission + tile-only stable sort that rasterize_gaussians runs must give
     the same gaussian_ids_sorted / tile_bins, bit for bit, as the upstream-shaped 64-bit pair sort
@@ -245,7 +246,8 @@ def _hip_raster(hip, cam, R, block, bg, need_grad=True):
     return img, alpha, leaves, d
 
 
-@pytest.mark.parametrize("block,size", [(16, (128, 128)), (16, (130, 70)), (8, (100, 60)), (5, (64, 37)), (2, (20, 12))])
+@pytest.mark.parametrize("block,size", [(16, (128, 128)), (16, (130, 70)), (8, (100, 60)), (5, (64, 37)), (2, (20, 12)),
+                                        (2, (600, 500))])                   # 300 x 250 tiles > 65536: 32-bit tile keys
 def test_rasterize_forward_fast_exp(hip, c_oracle, block, size):
     cam, P = small_scene(n=3000, w=size[0], h=size[1], focal=float(size[0]))
     R = _raster_inputs(c_oracle, cam, P, block)
