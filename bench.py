@@ -251,6 +251,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); run it under gpurun")
     rank, world, local = dp.init_from_env()
+    if os.environ.get("SGN_BENCH_SHARE_GPU") == "1":
+        # functional check of the N-rank code path on a box with fewer GPUs than ranks (with SGN_DP_BACKEND=gloo:
+        # RCCL refuses two ranks on one device).  Not a scaling number; the line says so.
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     L.load()
@@ -329,7 +333,10 @@ def main():
 
     def barrier():
         if world > 1:
-            torch.distributed.barrier(device_ids=[local])
+            if torch.distributed.get_backend() == "nccl":
+                torch.distributed.barrier(device_ids=[local])
+            else:
+                torch.distributed.barrier()
 
     for _ in range(max(0, args.settle)):
         one_step()
@@ -451,6 +458,10 @@ def main():
             "kernels_avg_ms": {k: round(v[1], 4) for k, v in kernels.items()},
         }
         line["config"]["path"] = args.path
+        if world > 1:
+            line["config"]["backend"] = torch.distributed.get_backend()
+            if os.environ.get("SGN_BENCH_SHARE_GPU") == "1":
+                line["config"]["note"] = "ranks SHARE GPUs (functional check of the N-rank path, not a scaling number)"
         line["config"]["settle_steps"] = max(0, args.settle)   # untimed, before the W warm-up steps
         line["config"]["quat_check"] = ops.quat_check
         line["config"]["speculative_binning"] = dict(enabled=bool(ops.speculative_binning), **ops.binning_stats)

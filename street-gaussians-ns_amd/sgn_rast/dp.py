@@ -36,7 +36,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # SGN_DP_BACKEND=gloo: functional runs of the N-rank path on a box with fewer GPUs than ranks (RCCL refuses
+            # two ranks on one device); production is RCCL
+            backend = os.environ.get("SGN_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -244,6 +246,13 @@ class SHGradExchange:
     def _gather(self, t: torch.Tensor) -> torch.Tensor:
         t = t.contiguous()
         out = torch.empty((self.world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            # gloo has no all_gather for device tensors: stage through the host (functional runs only, see
+            # init_from_env; RCCL takes the direct branch below)
+            host = torch.empty(out.shape, dtype=t.dtype)
+            dist.all_gather(list(host.unbind(0)), t.cpu(), group=self.group)
+            out.copy_(host)
+            return out
         try:
             w = dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
         except Exception:  # backend without the fused form

@@ -176,7 +176,8 @@ class _AccLosses(torch.autograd.Function):
         ctx.n, ctx.sem_bytes, ctx.sky_value = n, sem_bytes, int(sky_value)
         ctx.acc_shape = None if accumulation is None else accumulation.shape
         ctx.obj_shape = None if object_acc is None else object_acc.shape
-        ctx.sem, ctx.obj = sem, obj
+        ctx.has_sem, ctx.has_obj = sem is not None, obj is not None
+        ctx.save_for_backward(*[t for t in (sem, obj) if t is not None])   # in-place edits before backward are detected
         return out2[0], out2[1]
 
     @staticmethod
@@ -185,12 +186,15 @@ class _AccLosses(torch.autograd.Function):
         want_obj = ctx.obj_shape is not None and ctx.needs_input_grad[3]
         if not (want_acc or want_obj):
             return None, None, None, None
+        saved = list(ctx.saved_tensors)
+        sem = saved.pop(0) if ctx.has_sem else None
+        obj = saved.pop(0) if ctx.has_obj else None
         gscale = torch.stack([g_sky.reshape(()), g_ent.reshape(())]).float().contiguous()
         f32 = dict(dtype=torch.float32, device=gscale.device)
         v_acc = torch.empty(ctx.n, **f32) if want_acc else None
         v_obj = torch.empty(ctx.n, **f32) if want_obj else None
-        L.check(L.load().sgn_acc_losses_bwd(ctx.n, L.ptr(ctx.sem) if want_acc else None, ctx.sem_bytes, ctx.sky_value,
-                                            L.ptr(ctx.obj) if want_obj else None, L.ptr(gscale), L.ptr(v_acc),
+        L.check(L.load().sgn_acc_losses_bwd(ctx.n, L.ptr(sem) if want_acc else None, ctx.sem_bytes, ctx.sky_value,
+                                            L.ptr(obj) if want_obj else None, L.ptr(gscale), L.ptr(v_acc),
                                             L.ptr(v_obj), L.stream_ptr()), "sgn_acc_losses_bwd")
         return (v_acc.reshape(ctx.acc_shape) if want_acc else None, None, None,
                 v_obj.reshape(ctx.obj_shape) if want_obj else None)
