@@ -24,6 +24,15 @@ constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = 4;
 // keys per thread: 16 (4096-key tiles) for large inputs; 4 (1024-key tiles) below RS_SMALL_N keys, where 4096-key
 // tiles would leave most of the 256 CUs idle (1 M keys = 245 tiles) and every pass latency-bound
+// Ranking inside a wave (the sort must be stable).  1 (default): ONE returning LDS atomic per key on the digit's
+// per-wave counter.  That is stable iff lanes of one ds_add_rtn_u32 that hit the same address are served in ascending
+// lane order — how the gfx950 LDS resolves same-address lanes, observed rather than documented, and therefore pinned by
+// tests/test_gpu_parity.py::test_sort_stability_under_heavy_same_digit_contention (few distinct keys, runs, interleaved
+// lanes, millions of pairs) on top of the bit-exact sort / binning tests.  0: the ballot-match ranking (one ballot per
+// digit bit, documented semantics only): 8x the instructions in the ranking section, +7 us per binning.
+#ifndef SGN_RS_RANK_ATOMIC
+#define SGN_RS_RANK_ATOMIC 1
+#endif
 #ifndef SGN_RS_IPT_LARGE
 #define SGN_RS_IPT_LARGE 16
 #endif
@@ -179,7 +188,9 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     // the wave's counters through an explicit LDS pointer: as a generic `volatile uint32_t *` every access was compiled
     // to flat_load / flat_store with sc0 sc1 and a full s_waitcnt vmcnt(0) behind it (two per key)
     typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+#if !SGN_RS_RANK_ATOMIC
     volatile lds_u32_t *mycnt = (volatile lds_u32_t *)(&wcnt[wave][0]);
+#endif
     // every key / value of the tile is requested before the first ranking step: the volatile LDS counters below
     // pin program order, so loads left inside the ranking loop are waited for one HBM round trip at a time
 #pragma unroll
@@ -210,6 +221,15 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;
         const bool valid = li < tile_cnt;
         const unsigned d = digit_of<K>(key[r], shift, dmask);
+#if SGN_RS_RANK_ATOMIC
+        // one returning LDS atomic per key (see SGN_RS_RANK_ATOMIC above): the value it returns is the key's rank among
+        // the wave's keys of the same digit seen so far — earlier keys (r) by program order, same-r keys by lane order
+        uint32_t rk = 0;
+        if (valid) rk = __hip_atomic_fetch_add((lds_u32_t *)&wcnt[wave][d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");     // keep the atomics of successive keys in program order
+        rank[r] = rk;
+    }
+#else
         // match mask m = lanes of this wave holding the same digit: per bit, keep the lanes that voted like me.  Spelled
         // on 32-bit halves with nb = all-ones where my bit is set, m &= ~(vote ^ nb) is one v_bitop3 per half (the
         // `bit ? vote : ~vote` form on a 64-bit value took 13 instructions per bit); invalid lanes are masked once, by
@@ -235,6 +255,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
         }
         rank[r] = prev + below;
     }
+#endif
     __syncthreads();
 
     // thread t owns digits [t*DPT, t*DPT+DPT): per-wave counts -> exclusive per-wave offsets + totals

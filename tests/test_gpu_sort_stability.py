@@ -1,0 +1,41 @@
+"""GPU (-m gpu): stability of the radix sort where its ranking leans on observed hardware behaviour.
+
+Own module: tests/test_gpu_parity.py repeats every test for nine raster-kernel modes, which the sort does not depend on.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("n", [1_200_003, 3_300_003])          # 1024-key and 4096-key sort tiles
+@pytest.mark.parametrize("distinct", [1, 2, 3, 7, 64, 9600])
+@pytest.mark.parametrize("layout", ["random", "runs", "interleaved"])
+def test_sort_stability_under_heavy_same_digit_contention(distinct, layout, n):
+    """The scatter ranks a key with ONE returning LDS atomic on its digit's per-wave counter (ds_add_rtn_u32): the
+    sort is stable only if lanes of one instruction that hit the same counter are served in ascending lane order.
+    That is how the gfx950 LDS behaves, but it is observed rather than documented, so it is pinned here where it hurts
+    most: few distinct keys (up to all 64 lanes of every wave on one counter), runs, and lane-interleaved patterns,
+    over millions of pairs — every payload must come out in input order within its key."""
+    from sgn_rast import _lib as L
+    g = torch.Generator().manual_seed(1000 * distinct + len(layout))
+    if layout == "random":
+        tile = torch.randint(0, distinct, (n,), generator=g, dtype=torch.int64)
+    elif layout == "runs":                       # runs of random length 1..199 of one key
+        lens = torch.randint(1, 200, (n // 50,), generator=g)
+        ids = torch.randint(0, distinct, (lens.numel(),), generator=g, dtype=torch.int64)
+        tile = torch.repeat_interleave(ids, lens)[:n]
+        tile = torch.cat([tile, torch.zeros(n - tile.numel(), dtype=torch.int64)])
+    else:                                        # lane l of every wave holds key l % distinct
+        tile = torch.arange(n, dtype=torch.int64) % distinct
+    vals = torch.arange(n, dtype=torch.int32)
+    rk, order = torch.sort(tile, stable=True)
+    lib = L.load()
+    kd, vd = tile.to(DEV), vals.to(DEV)
+    ko, vo = torch.empty_like(kd), torch.empty_like(vd)
+    ws = L.workspace(lib.sgn_sort_workspace_bytes(n), kd.device)
+    L.check(lib.sgn_sort_pairs(n, 0, 14, L.ptr(kd), L.ptr(vd), L.ptr(ko), L.ptr(vo), L.ptr(ws), ws.numel(),
+                               L.stream_ptr()), "sort")            # the tile sort's bit range: two 7-bit passes
+    assert torch.equal(ko.cpu(), rk) and torch.equal(vo.cpu(), vals[order])

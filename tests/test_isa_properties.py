@@ -123,4 +123,5 @@ def test_streaming_kernels_issue_their_loads_before_the_first_lds_write(tmp_path
     # flat_load / flat_store sc0 sc1 + s_waitcnt vmcnt(0), twice per key
     for k, t in rs.items():
         assert "flat_load" not in t and "flat_store" not in t, k
-    assert "ds_read_b32" in scat and "ds_write_b32" in scat and "v_mbcnt_hi_u32_b32" in scat and "v_bitop3_b32" in scat
+    # ranking: one returning LDS atomic per key (16 keys per thread in this instantiation), no ballot-match code
+    assert scat.count("ds_add_rtn_u32") == 16 and "v_bitop3_b32" not in scat
