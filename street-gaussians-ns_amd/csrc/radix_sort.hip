@@ -12,9 +12,10 @@
 // Three kernels per pass —
 //   rs_hist    per-tile (4096 keys) digit histogram in LDS            -> table[digit][tile]
 //   rs_scan    one workgroup per digit: exclusive scan of its row     -> table (in place), total[digit]
-//   rs_scatter per tile: wave64 ballot "match" ranking (one ballot per digit bit, stable inside a
-//              wave), per-wave LDS counters, cross-wave prefix, then the tile is reordered in LDS so the
-//              global stores of one digit are consecutive lanes -> consecutive addresses.
+//   rs_scatter per tile: stable ranking inside a wave on per-wave LDS counters (one returning LDS atomic per key;
+//              the wave64 ballot "match" ranking stays behind SGN_RS_RANK_ATOMIC=0, see below), cross-wave prefix,
+//              then the tile is reordered in LDS so the global stores of one digit are consecutive lanes ->
+//              consecutive addresses.
 // HBM traffic per key per pass: sizeof(key) (hist) + 2 * (sizeof(key) + payload).
 #include "sgn_common.h"
 
@@ -22,17 +23,17 @@ namespace {
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = 4;
-// keys per thread: 16 (4096-key tiles) for large inputs; 4 (1024-key tiles) below RS_SMALL_N keys, where 4096-key
-// tiles would leave most of the 256 CUs idle (1 M keys = 245 tiles) and every pass latency-bound
 // Ranking inside a wave (the sort must be stable).  1 (default): ONE returning LDS atomic per key on the digit's
 // per-wave counter.  That is stable iff lanes of one ds_add_rtn_u32 that hit the same address are served in ascending
 // lane order — how the gfx950 LDS resolves same-address lanes, observed rather than documented, and therefore pinned by
-// tests/test_gpu_parity.py::test_sort_stability_under_heavy_same_digit_contention (few distinct keys, runs, interleaved
+// tests/test_gpu_sort_stability.py::test_sort_stability_under_heavy_same_digit_contention (few distinct keys, runs, interleaved
 // lanes, millions of pairs) on top of the bit-exact sort / binning tests.  0: the ballot-match ranking (one ballot per
 // digit bit, documented semantics only): 8x the instructions in the ranking section, +7 us per binning.
 #ifndef SGN_RS_RANK_ATOMIC
 #define SGN_RS_RANK_ATOMIC 1
 #endif
+// keys per thread: 16 (4096-key tiles) for large inputs; 4 (1024-key tiles) below RS_SMALL_N keys, where 4096-key
+// tiles would leave most of the 256 CUs idle (1 M keys = 245 tiles) and every pass latency-bound
 #ifndef SGN_RS_IPT_LARGE
 #define SGN_RS_IPT_LARGE 16
 #endif
