@@ -282,8 +282,9 @@ int sgn_raster_build_rows(int n, const float *xys, const float *conics, const fl
 
 /* _C.rasterize_backward.  alpha_clamp_bwd: 0.99f reproduces gsplat 0.1.x (which clamps at
  * 0.999 in forward and 0.99 in backward).  Outputs are fully written (zero-filled first).
- * v_conic[:,1] follows upstream's convention (half the true off-diagonal derivative; it is
- * consumed consistently by sgn_project_bwd). */
+ * v_conic[:,1] is the TRUE derivative dL/d(conic.y) (sum of v_sigma dx dy: what autograd through gsplat's
+ * _torch_impl gives); sgn_project_bwd spreads v_conic.y / 2 over the two off-diagonal slots of the symmetric
+ * matrix gradient.  (Rounds 1-2 carried half of it here with the un-halved matrix: same end-to-end gradients.) */
 size_t sgn_raster_bwd_workspace_bytes(int n);
 int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,

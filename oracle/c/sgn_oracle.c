@@ -177,8 +177,9 @@ SGO_API void sgo_project_fwd(int N, const float *means, const float *scales, flo
 /* ------------------------------------------------ project_gaussians backward
  * gsplat backward.cu project_gaussians_backward_kernel + helpers.cuh vjps
  * (SURVEY.md A.5).  Conventions kept from upstream: the EWA vjp uses the
- * UN-clamped view-space point; v_conic[1] is upstream's "half" off-diagonal
- * gradient (paired with the 0.5 factor in rasterize backward); quats are treated
+ * UN-clamped view-space point; v_conic[1] is the true derivative w.r.t. the
+ * off-diagonal conic entry b (conic.y appears once in sigma), so the symmetric
+ * matrix gradient takes g1/2 in both off-diagonal slots; quats are treated
  * as unit.  Outputs zero-initialised by the caller; rows with radii<=0 stay 0. */
 SGO_API void sgo_project_bwd(int N, const float *means, const float *scales, float glob_scale,
                              const float *quats, const float *V, float fx, float fy,
@@ -201,9 +202,9 @@ SGO_API void sgo_project_bwd(int N, const float *means, const float *scales, flo
         float vz = v_depth[i];
         vm[0] += V[8] * vz; vm[1] += V[9] * vz; vm[2] += V[10] * vz;
 
-        /* cov2d_to_conic_vjp: v_Sigma = -X G X with G = [[g0,g1],[g1,g2]] (upstream convention) */
+        /* cov2d_to_conic_vjp: v_Sigma = -X G X with G = [[g0,g1/2],[g1/2,g2]] (v_conic.y / 2: exact scaling) */
         float X00 = conics[3 * i], X01 = conics[3 * i + 1], X11 = conics[3 * i + 2];
-        float g0 = v_conic[3 * i], g1 = v_conic[3 * i + 1], g2 = v_conic[3 * i + 2];
+        float g0 = v_conic[3 * i], g1 = 0.5f * v_conic[3 * i + 1], g2 = v_conic[3 * i + 2];
         /* A = X G */
         float A00 = X00 * g0 + X01 * g1, A01 = X00 * g1 + X01 * g2;
         float A10 = X01 * g0 + X11 * g1, A11 = X01 * g1 + X11 * g2;
@@ -485,7 +486,9 @@ SGO_API void sgo_raster_fwd(int H, int W, int block, const int32_t *ids, const i
  * gsplat backward.cu rasterize_backward_kernel, SURVEY.md A.4.
  * alpha_clamp_bwd: upstream 0.1.x clamps alpha at 0.99 here (0.999 in forward);
  * pass 0.99f for upstream behaviour, 0.999f for the self-consistent variant
- * used by the autograd cross-check.  v_conic[1] keeps upstream's 0.5 factor.
+ * used by the autograd cross-check.  v_conic[1] is the true derivative dL/db (what
+ * autograd through gsplat's _torch_impl gives and gsplat's own tests compare against);
+ * sgo_project_bwd pairs it with G = [[g0, g1/2], [g1/2, g2]].
  * Accumulates in double so the oracle is order-independent "truth"; outputs
  * (zero-initialised by the caller) are float. */
 SGO_API void sgo_raster_bwd_rows(int H, int W, int block, int N, const int32_t *ids,
@@ -538,7 +541,7 @@ SGO_API void sgo_raster_bwd_rows(int H, int W, int block, int N, const int32_t *
                 A[0] += v_sigma * (a * dx + b * dy);
                 A[1] += v_sigma * (b * dx + c * dy);
                 A[2] += 0.5f * v_sigma * dx * dx;
-                A[3] += 0.5f * v_sigma * dx * dy;
+                A[3] += v_sigma * dx * dy;           /* d sigma / d b = dx*dy: the TRUE derivative */
                 A[4] += 0.5f * v_sigma * dy * dy;
                 A[5] += fac * vo[0];
                 A[6] += fac * vo[1];

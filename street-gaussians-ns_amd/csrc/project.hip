@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         vm[0] += V[8] * vz; vm[1] += V[9] * vz; vm[2] += V[10] * vz;
 
         const float X00 = conics[3 * i], X01 = conics[3 * i + 1], X11 = conics[3 * i + 2];
-        const float g0 = v_conic[3 * i], g1 = v_conic[3 * i + 1], g2 = v_conic[3 * i + 2];
+        // v_conic[:,1] is the true dL/d(conic.y); the symmetric matrix gradient carries half of it per slot (exact)
+        const float g0 = v_conic[3 * i], g1 = 0.5f * v_conic[3 * i + 1], g2 = v_conic[3 * i + 2];
         const float A00 = X00 * g0 + X01 * g1, A01 = X00 * g1 + X01 * g2;
         const float A10 = X01 * g0 + X11 * g1, A11 = X01 * g1 + X11 * g2;
         const float S00 = -(A00 * X00 + A01 * X01), S01 = -(A00 * X01 + A01 * X11);

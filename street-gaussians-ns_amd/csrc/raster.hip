@@ -875,7 +875,9 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, int row0, cons
     const float4 b = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 1];
     const float4 c = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 2];
     v_xy[2 * i] = a.x; v_xy[2 * i + 1] = a.y;
-    v_conic[3 * i] = a.z; v_conic[3 * i + 1] = a.w; v_conic[3 * i + 2] = b.x;
+    // the walk accumulates 0.5 * v_sigma * (dx^2, dx dy, dy^2) (one shared half-scale); the public v_conic[:,1] is the
+    // TRUE derivative dL/d(conic.y) = sum v_sigma dx dy, so the off-diagonal slot is doubled here (exact scaling)
+    v_conic[3 * i] = a.z; v_conic[3 * i + 1] = 2.f * a.w; v_conic[3 * i + 2] = b.x;
     v_colors[3 * i] = b.y; v_colors[3 * i + 1] = b.z; v_colors[3 * i + 2] = b.w;
     float vo = c.x;
     if (opac_is_logit) {  // chain through the fused sigmoid

@@ -333,6 +333,32 @@ def test_rasterize_backward(hip, c_oracle, block, size, clamp, reduce_mode):
     assert leaves["opac"].grad.shape == R["opac"].shape   # [N,1] like the input
 
 
+def test_rasterize_v_conic_is_the_true_derivative(hip, c_oracle, torch_oracle):
+    """the rasterizer's public `v_conics` output, on its own, against the only externally
+    checkable definition — fp64 autograd through the torch restatement of `_torch_impl.rasterize_forward` — column
+    by column (so a factor on the off-diagonal entry cannot hide in the norm).  Opacities stay <= 0.98 so the
+    0.999 / 0.99 clamp quirk is inactive (self-consistent clamp)."""
+    from sgn_rast import ops
+    cam, P = small_scene(n=2000, w=96, h=64, focal=96.0)
+    R = _raster_inputs(c_oracle, cam, P, 16)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    ops.set_alpha_clamp_bwd(0.999)
+    try:
+        img, alpha, leaves, d = _hip_raster(hip, cam, R, 16, bg)
+        torch.autograd.backward([img, alpha], [d["v_img"], d["v_alpha"]])
+    finally:
+        ops.set_alpha_clamp_bwd(ops.UPSTREAM_ALPHA_CLAMP_BWD)
+    D = torch.float64
+    t = {k: R[k].to(D).requires_grad_(True) for k in ("xys", "conics", "rgb", "opac")}
+    img64, alpha64 = torch_oracle.rasterize_gaussians(t["xys"], R["depths"].to(D), R["radii"], t["conics"], R["nth"],
+                                                      t["rgb"], t["opac"], cam.height, cam.width, 16, bg.to(D), True)
+    torch.autograd.backward([img64, alpha64], [R["v_img"].to(D), R["v_alpha"].to(D)])
+    got, exp = leaves["conics"].grad.cpu().double(), t["conics"].grad
+    for col in range(3):
+        assert rel_l2(got[:, col], exp[:, col]) < 1e-4, (col, rel_l2(got[:, col], exp[:, col]))
+    assert rel_l2(leaves["xys"].grad.cpu().double(), t["xys"].grad) < 1e-4
+
+
 def test_rasterize_no_intersections(hip):
     n = 16
     bg = torch.tensor([0.3, 0.6, 0.9], device=DEV)

@@ -165,10 +165,11 @@ def test_analytic_backward_matches_fp64_autograd(c_oracle, torch_oracle):
     for clamp in (0.99, 0.999):
         v_xy, v_conic, v_col, v_op = c_oracle.raster_bwd(
             H, W, 16, vs, bins, cx, cc, crgb, f(opac), f(bg), cfT, cfi, f(w_img), f(w_a), clamp)
-        true_conic = v_conic.clone()
-        true_conic[:, 1] *= 2  # upstream keeps half the off-diagonal derivative in v_conic[:,1]
         assert rel_l2(v_xy, f(xys.grad)) < 1e-4
-        assert rel_l2(true_conic, f(conics.grad)) < 1e-4
+        # the rasterizer's v_conic ALONE against fp64 autograd, column by column: [:,1] is the true dL/d(conic.y)
+        # (the externally checkable definition, not the recalled "half" convention)
+        for col in range(3):
+            assert rel_l2(v_conic[:, col], f(conics.grad)[:, col]) < 1e-4, col
         assert rel_l2(v_col, f(rgb.grad)) < 1e-4
         assert rel_l2(v_op, f(opac.grad)) < 1e-4
     vm, vsc, vq, _, _ = c_oracle.project_bwd(
