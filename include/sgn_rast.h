@@ -189,6 +189,21 @@ int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const int64_t *k
                    const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out, void *ws,
                    size_t ws_bytes, sgn_stream_t stream);
 
+/* Which in-wave ranking the scatter pass of every sort in this library uses (radix_sort.hip):
+ *   0  ballot-match ranking — documented ISA semantics only; the state of a process until the probe has passed;
+ *   1  one returning LDS atomic per key — 8x fewer ranking instructions, stable only if same-address lanes of one
+ *      ds_add_rtn_u32 are served in ascending lane order (observed on gfx950, not documented).
+ * sgn_sort_selftest sorts adversarial probes (all-equal keys, lane-interleaved keys, runs, hashes; both sort-tile
+ * sizes) with BOTH rankings on the device of `stream`, compares every output pair on the device, synchronises the
+ * stream and switches the process to mode 1 iff nothing differed; it returns the number of mismatching pairs (0 =
+ * passed) or < 0 on error.  The host side runs it once per process (`sgn_rast._lib.load()` on a GPU);
+ * sgn_sort_set_rank_mode forces a mode (tests, A/B runs).  This is the library's only process-wide state besides the
+ * opt-in timing slots: a verified hardware capability, not a configuration switch. */
+int sgn_sort_rank_mode(void);
+void sgn_sort_set_rank_mode(int atomic_ranking);
+size_t sgn_sort_selftest_workspace_bytes(void);
+int sgn_sort_selftest(void *ws, size_t ws_bytes, sgn_stream_t stream);
+
 /* _C.get_tile_bin_edges; tile_bins [n_tiles,2] is zero-filled here first. */
 int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_tiles, int32_t *tile_bins,
                   sgn_stream_t stream);

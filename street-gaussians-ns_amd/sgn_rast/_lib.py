@@ -60,6 +60,10 @@ SIGNATURES = {
     "sgn_map_isect": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sgn_sort_workspace_bytes": (_sz, [_i64]),
     "sgn_sort_pairs": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_sort_rank_mode": (_i, []),
+    "sgn_sort_set_rank_mode": (None, [_i]),
+    "sgn_sort_selftest_workspace_bytes": (_sz, []),
+    "sgn_sort_selftest": (_i, [_vp, _sz, _vp]),
     "sgn_tile_bins": (_i, [_i64, _vp, _i, _vp, _vp]),
     "sgn_bin_prepare_workspace_bytes": (_sz, [_i]),
     "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -173,7 +177,30 @@ def load() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = lib
+        _probe_sort_ranking(lib)
     return _lib
+
+
+SORT_RANKING = {"mode": "ballot", "probe": "not run (no GPU in this process)"}
+
+
+def _probe_sort_ranking(lib) -> None:
+    """Once per process, on a GPU: let the library prove its fast in-wave sort ranking on THIS device
+    (`sgn_sort_selftest`, include/sgn_rast.h) — it stays on the documented ballot ranking unless every probe pair
+    matches.  `SGN_SORT_RANK=ballot|atomic` skips the probe and forces a mode (A/B runs); the outcome is kept in
+    `SORT_RANKING` (bench.py prints it)."""
+    forced = os.environ.get("SGN_SORT_RANK", "auto").lower()
+    if forced in ("ballot", "atomic"):
+        lib.sgn_sort_set_rank_mode(1 if forced == "atomic" else 0)
+        SORT_RANKING.update(mode=forced, probe="forced by SGN_SORT_RANK")
+        return
+    if not torch.cuda.is_available():
+        return
+    ws = torch.empty(int(lib.sgn_sort_selftest_workspace_bytes()), dtype=torch.uint8, device="cuda")
+    bad = int(lib.sgn_sort_selftest(C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream_handle())))
+    mode = "atomic" if lib.sgn_sort_rank_mode() == 1 else "ballot"
+    SORT_RANKING.update(mode=mode, probe=("passed: 16 probe sorts, 0 mismatching pairs" if bad == 0 else
+                                         f"FAILED ({bad}): staying on the documented ballot ranking"))
 
 
 def check(rc: int, what: str) -> None:

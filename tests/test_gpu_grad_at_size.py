@@ -65,7 +65,7 @@ def production_defaults():
     L.reset_options()
 
 
-@pytest.mark.parametrize("name", ["c2", "metric", "street"])
+@pytest.mark.parametrize("name", ["c2", "metric", "street", "c4"])   # c4: 2 M Gaussians (BASELINE.json config 4, one rank's view)
 def test_train_step_gradients_match_oracle_at_size(name, production_defaults):
     import oracle_ops
     from sgn_rast import ops, step
