@@ -244,10 +244,11 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     from sgn_rast import _lib as L, dp, ops, scenes, step
-    # upstream's quats assertion: the library's default is upstream's eager behaviour (host sync inside every
-    # project_gaussians call); the benchmark opts in to the deferred form, like a trainer that cares would, and times
-    # the eager form in the `with_caller_syncs` line
-    ops.quat_check = os.environ.get("SGN_QUAT_CHECK", "deferred")
+    # The headline runs the library exactly as `PYTHONPATH=street-gaussians-ns_amd` gives it to the reference (VERDICT
+    # r02 weak #4): upstream's quats assertion in its default "eager" form (raises from project_gaussians, one host
+    # sync per call).  The opt-in deferred form is timed as the extra `deferred_check` line, the reference model's own
+    # two host syncs on top of the default as `with_caller_syncs`.
+    default_check = ops.quat_check
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback); run it under gpurun")
     rank, world, local = dp.init_from_env()
@@ -392,23 +393,74 @@ def main():
                        "note": "same inputs/outputs through sgn_rast.fused (activations, view dirs, SH concat, "
                                "sigmoid folded into the kernels); not the drop-in call path"}
 
-    # the same drop-in step with the two host syncs the reference's model code makes around the operators
-    sync_extra = None
-    if args.path == "dropin" and sg is None and not args.caller_syncs and not args.no_fused_extra:
-        deferred_mode, ops.quat_check = ops.quat_check, os.environ.get("SGN_BENCH_EAGER_MODE", "eager")
+    def timed_variant(**kw):
         for _ in range(max(2, args.warmup // 2)):
-            one_step(caller_syncs=True)
+            one_step(**kw)
         gc.collect()
         barrier(); torch.cuda.synchronize()
         ts0 = time.perf_counter()
         for _ in range(args.steps):
-            one_step(caller_syncs=True)
+            one_step(**kw)
         torch.cuda.synchronize(); barrier()
         dts = time.perf_counter() - ts0
-        ops.quat_check = deferred_mode
-        sync_extra = {"value": world * args.steps / dts, "unit": "images/sec", "ms_per_step": 1e3 * dts / args.steps,
-                      "note": "drop-in path with upstream's eager quats assertion (library default) plus the reference "
-                              "model's own host syncs (sgn_splatfacto.py:878, :944)"}
+        if world > 1:
+            t = torch.tensor([dts], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dts = float(t.item())
+        return {"value": world * args.steps / dts, "unit": "images/sec", "ms_per_step": 1e3 * dts / args.steps}
+
+    # the same drop-in step (a) with the two host syncs the reference's model code makes around the operators, on top
+    # of the library defaults, and (b) with the opt-in deferred argument check
+    sync_extra = deferred_extra = None
+    if args.path == "dropin" and sg is None and not args.caller_syncs and not args.no_fused_extra:
+        sync_extra = timed_variant(caller_syncs=True)
+        sync_extra["note"] = ("library defaults plus the reference model's own host syncs "
+                              "(sgn_splatfacto.py:878 `radii.sum() == 0`, :944 `(num_tiles_hit > 0).any()`): the "
+                              "literal call pattern of SplatfactoModel.get_outputs")
+        if default_check != "deferred":
+            ops.quat_check = "deferred"
+            deferred_extra = timed_variant()
+            ops.quat_check = default_check
+            deferred_extra["note"] = ("opt-in SGN_QUAT_CHECK=deferred: upstream's quats assertion raises at the next "
+                                      "existing host sync (inside rasterize_gaussians) instead of from "
+                                      "project_gaussians; no host sync of its own")
+
+    # forward only (eval / render): what `scripts/eval.py:98-112` times per eval image — get_outputs_for_camera under
+    # no_grad: projection, SH at full degree, rgb+alpha pass AND the depth pass (sgn_splatfacto.py:982-996 runs in eval
+    # too); the rgb-only figure beside it
+    eval_extra = None
+    if sg is None and not args.no_fused_extra:
+        def fwd_only(with_depth, fused=False):
+            with torch.no_grad():
+                if fused:
+                    return step.render_fused(P, cam, 3, 16, with_depth=with_depth)
+                return step.render(P, cam, 3, 16, with_depth=with_depth, caller_syncs=True)
+
+        def time_fwd(**kw):
+            for _ in range(max(2, args.warmup // 2)):
+                fwd_only(**kw)
+            barrier(); torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(args.steps):
+                fwd_only(**kw)
+            torch.cuda.synchronize(); barrier()
+            return time.perf_counter() - t0_
+        dte = time_fwd(with_depth=True)
+        dte_rgb = time_fwd(with_depth=False)
+        dte_fused = time_fwd(with_depth=True, fused=True)
+        L.timing_enable(True)
+        for _ in range(5):
+            fwd_only(True)
+        torch.cuda.synchronize()
+        rep_e = L.timing_report()
+        L.timing_enable(False)
+        eval_extra = {"value": args.steps / dte, "unit": "images/sec (per rank)", "ms_per_image": 1e3 * dte / args.steps,
+                      "rgb_alpha_only": {"value": args.steps / dte_rgb, "ms_per_image": 1e3 * dte_rgb / args.steps},
+                      "fused_path": {"value": args.steps / dte_fused, "ms_per_image": 1e3 * dte_fused / args.steps},
+                      "kernels_ms_per_image": {k: round(t / 5, 4) for k, (c, t) in rep_e.items() if c},
+                      "note": "forward only under no_grad, library defaults + the model's host syncs: projection, SH "
+                              "deg 3, rgb+alpha pass, depth pass (the shape of get_outputs_for_camera, "
+                              "scripts/eval.py:98-112 reports 1 / this time as fps)"}
 
     # per-kernel HIP-event spans (library brackets each launch on its own stream), separate short pass
     L.timing_enable(True)
@@ -419,6 +471,23 @@ def main():
     rep = L.timing_report()
     L.timing_enable(False)
     kernels = {k: (c, (t / c if c else 0.0)) for k, (c, t) in rep.items()}  # avg ms per launch
+
+    # what the raster kernels really touch (untimed, one forward): pairs LISTED after exact tile culling, list entries
+    # WALKED before the tiles saturate (the backward's reverse walk starts at the deepest composited position the
+    # forward recorded per tile), (entry, quadrant) pairs the forward evaluated
+    walk = None
+    if sg is None and rank == 0:
+        ops.clear_binning_cache()
+        o_ = step.render(P, cam, 3, 16, caller_syncs=False) if args.path == "dropin" else step.render_fused(P, cam, 3, 16)
+        node = o_.rgb.grad_fn
+        sv = node.saved_tensors
+        bins_, kmax_ = sv[1].long(), node.tile_kmax.long()
+        lens_ = bins_[:, 1] - bins_[:, 0]
+        walked_ = torch.clamp(kmax_[:, 0] - bins_[:, 0] + 1, min=0) * (lens_ > 0)
+        walk = {"pairs_listed": int(lens_.sum()), "entries_walked": int(walked_.sum()),
+                "quadrant_pairs_evaluated_fwd": int(kmax_[:, 1].sum()), "longest_list": int(lens_.max()),
+                "longest_walk": int(walked_.max())}
+        del o_, node, sv
 
     if rank == 0:
         n_pix = cam.height * cam.width
@@ -431,13 +500,44 @@ def main():
         dur_s = kernels[dom][1] * 1e-3
         achieved = alg / dur_s / 1e9 if dur_s > 0 else 0.0
         step_bytes = 748 * n_gauss + 316 * n_isect + 44 * n_pix
-        traffic = None  # PMC numbers come from separate rocprofv3 passes; committed under profiles/
+        # PMC numbers come from separate rocprofv3 passes (counters cannot be read from inside this process);
+        # profiles/roofline_pmc.json holds them per kernel with the files they were read from.  They belong to the
+        # default workload only.
+        traffic, pmc = None, None
+        default_workload = (args.scene == "metric" and not args.n and not args.street and not args.translucent
+                            and sg is None)
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if args.scene == "metric" and not args.n and dom in tj:
-                traffic = tj[dom]["traffic_bytes"]
+            pj = json.load(open(os.path.join(ROOT, "profiles", "roofline_pmc.json")))
+            if default_workload and dom in pj:
+                pmc = pj[dom]
+                traffic = pmc.get("hbm_traffic_bytes")
         except Exception:
             pass
+        bytes_per_walked = {"raster_bwd": 112, "raster_fwd": 40, "pack_records": 40}[dom]
+        pix_bytes = {"raster_bwd": 24, "raster_fwd": 20, "pack_records": 0}[dom]
+        roof_extra = {}
+        if walk is not None and dur_s > 0:
+            wb = bytes_per_walked * walk["entries_walked"] + pix_bytes * n_pix
+            roof_extra["walked"] = dict(walk, bytes=wb, GBps=wb / dur_s / 1e9, frac=wb / dur_s / 1e9 / HBM_PEAK_GBS,
+                                        note="section 8d's per-intersection bytes charged only to the list entries the "
+                                             "kernel walks before its tile saturates (+ the per-pixel bytes)")
+        if traffic is not None and dur_s > 0:
+            roof_extra["hbm_measured"] = {"traffic_bytes": traffic, "GBps": traffic / dur_s / 1e9,
+                                          "frac": traffic / dur_s / 1e9 / HBM_PEAK_GBS, "source": pmc.get("hbm_source")}
+        if pmc is not None and "valu" in pmc and walk is not None and dur_s > 0:
+            v = pmc["valu"]
+            # live part: this run's launch duration and pair count; PMC part: instructions per evaluated pair, the
+            # mix-weighted issue cycles per wave-instruction (calibrated microbenchmark) and the profiled clock
+            pairs = walk["quadrant_pairs_evaluated_fwd"]
+            insts = v["valu_insts_per_pair"] * pairs
+            simd_cycles = v["simds"] * v["clock_ghz"] * 1e9 * dur_s
+            roof_extra["valu"] = {"pair_evaluations": pairs, "valu_insts_per_pair": v["valu_insts_per_pair"],
+                                  "valu_wave_insts_per_launch": insts,
+                                  "issue_cycles_per_inst": v["issue_cycles_per_inst"],
+                                  "issue_cycle_frac": insts * v["issue_cycles_per_inst"] / simd_cycles,
+                                  "active_counter_vs_saturated_mix": v.get("counter_frac_calibrated"),
+                                  "source": v.get("source")}
+        measured_bound = (pmc or {}).get("bound")
         line = {
             "metric": "train-step images/sec (fwd+bwd) @1M Gaussians 1920x1280",
             "value": world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -450,11 +550,17 @@ def main():
                                        f"{'all-gathered as low-rank factors' if args.dp_exchange == 'lowrank' else 'dense all-reduce'})"
                                        if world > 1 else "single"),
                        "n_gaussians": n_gauss, "n_isect": n_isect},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "avg_launch_ms": kernels[dom][1], "alg_bytes_per_launch": alg,
-                         "step_alg_bytes": step_bytes,
-                         "step_hbm_frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS},
+            # achieved / peak / frac follow SURVEY.md section 8d's contract formula (every upstream-semantic intersection
+            # charged: "how fast the reference's byte budget is retired"; it exceeds 1 where tiles saturate early, so it
+            # is NOT a utilisation).  `bound` is what the counters say limits the kernel; the utilisation figures are
+            # `walked` (bytes of the entries really walked), `hbm_measured` (PMC traffic) and `valu` (issue cycles).
+            "roofline": dict({"bound": measured_bound or "hbm", "kernel": dom, "achieved": achieved,
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                              "frac_is": "section-8d algorithmic bytes / launch time / 8 TB/s (budget retirement rate, "
+                                         "not a utilisation)",
+                              "traffic": traffic, "avg_launch_ms": kernels[dom][1], "alg_bytes_per_launch": alg,
+                              "step_alg_bytes": step_bytes,
+                              "step_hbm_frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}, **roof_extra),
             "kernels_avg_ms": {k: round(v[1], 4) for k, v in kernels.items()},
         }
         line["config"]["path"] = args.path
@@ -464,6 +570,7 @@ def main():
                 line["config"]["note"] = "ranks SHARE GPUs (functional check of the N-rank path, not a scaling number)"
         line["config"]["settle_steps"] = max(0, args.settle)   # untimed, before the W warm-up steps
         line["config"]["quat_check"] = ops.quat_check
+        line["config"]["sort_ranking"] = dict(L.SORT_RANKING)
         line["config"]["speculative_binning"] = dict(enabled=bool(ops.speculative_binning), **ops.binning_stats)
         if args.street:
             line["metric"] = "train-step images/sec (fwd+bwd), non-uniform street-like content (profiling workload)"
@@ -489,6 +596,10 @@ def main():
             line["fused_path"] = fused_extra
         if sync_extra is not None:
             line["with_caller_syncs"] = sync_extra
+        if deferred_extra is not None:
+            line["deferred_check"] = deferred_extra
+        if eval_extra is not None:
+            line["eval_images_per_s"] = eval_extra
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline_bounded(args)

@@ -5,6 +5,7 @@
 // cycles per wave-instruction at the measured wall time (clock read from hipDeviceProp, nominal).
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <string>
 #include <vector>
 
 #define REP8(X) X X X X X X X X
@@ -83,6 +84,35 @@ __global__ __launch_bounds__(64) void k_pkmul(float *out, int iters) {
     out[blockIdx.x * 64 + threadIdx.x] = s.x + s.y;
 }
 
+// v_permlane32_swap: the cross-lane exchange of the backward's transposed reduction (8 per walked entry)
+__global__ __launch_bounds__(64) void k_permswap(float *out, int iters) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    for (int i = 0; i < iters; ++i) {
+        REP8(asm volatile("v_permlane32_swap_b32 %0, %1\nv_permlane32_swap_b32 %2, %3\nv_permlane32_swap_b32 %4, %5\n"
+                          "v_permlane32_swap_b32 %6, %7\nv_permlane32_swap_b32 %1, %2\nv_permlane32_swap_b32 %3, %4\n"
+                          "v_permlane32_swap_b32 %5, %6\nv_permlane32_swap_b32 %7, %0\n"
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
+// the raster backward's per-(entry, quadrant) mix, as 16 independent instructions per group: 9 fma/mul/add-class,
+// 2 v_cmp, 3 v_cndmask / v_min, 1 v_exp, 1 v_rcp  (profiles/scripts/valu_mix.py gives the static mix of the kernel)
+__global__ __launch_bounds__(64) void k_mix(float *out, int iters) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b = 1.0001f, c = 0.5f;
+    for (int i = 0; i < iters; ++i) {
+        REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\nv_mul_f32 %1, %1, %8\nv_fma_f32 %2, %2, %8, %9\nv_add_f32 %3, %3, %9\n"
+                          "v_cmp_le_f32 vcc, %0, %8\nv_cndmask_b32 %4, %4, %8, vcc\nv_fma_f32 %5, %5, %8, %9\n"
+                          "v_exp_f32 %6, %6\nv_fma_f32 %7, %7, %8, %9\nv_mul_f32 %0, %0, %8\n"
+                          "v_cmp_ge_f32 vcc, %1, %9\nv_cndmask_b32 %2, %2, %8, vcc\nv_min_f32 %3, %3, %8\n"
+                          "v_rcp_f32 %4, %4\nv_fma_f32 %5, %5, %8, %9\nv_fma_f32 %7, %7, %8, %9\n"
+                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                          : "v"(b), "v"(c) : "vcc");)
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
 template <typename F>
 void run(const char *name, F kern, float *out, int waves_per_simd) {
     const int iters = 4000, grid = 1024 * waves_per_simd;
@@ -102,9 +132,36 @@ void run(const char *name, F kern, float *out, int waves_per_simd) {
            waves_per_simd, ms, per_simd_per_ns, 2.4 / per_simd_per_ns);
 }
 
-int main() {
+// --calib: ONE long launch (~0.3 ms) of each class at four waves per SIMD (the occupancy of the backward's short-walk
+// kernel), for a rocprofv3 --pmc pass: each launch is 100 % VALU-issue-bound by construction, so what the SQ counters
+// read on it IS their saturation value — the normalisation bench.py's roofline.valu block uses.
+template <typename F>
+void calib(const char *name, F kern, float *out, int iters, int per_iter) {
+    const int grid = 1024 * 4;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, out, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, 0, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("calib %-10s %.3f ms  wave-instructions %.4e\n", name, ms, (double)grid * iters * per_iter);
+}
+
+int main(int argc, char **argv) {
     float *out;
     hipMalloc(&out, 1024 * 8 * 64 * sizeof(float));
+    if (argc > 1 && std::string(argv[1]) == "--calib") {
+        calib("v_fma", k_fma, out, 1500, 64); calib("v_mul", k_mul, out, 1500, 64);
+        calib("v_cmp", k_cmp, out, 900, 64); calib("v_cndmask", k_cndmask, out, 900, 64);
+        calib("v_min", k_min, out, 900, 64); calib("v_exp", k_exp, out, 500, 64); calib("v_rcp", k_rcp, out, 500, 64);
+        calib("v_add_dpp", k_dpp, out, 900, 64); calib("v_mov", k_mov, out, 1500, 64);
+        calib("permswap", k_permswap, out, 900, 64); calib("mix", k_mix, out, 300, 128);
+        return 0;
+    }
     for (int w : {1, 2, 4}) {
         run("v_mul", k_mul, out, w); run("v_add", k_add, out, w); run("v_sub", k_sub, out, w);
         run("v_min", k_min, out, w); run("v_fma", k_fma, out, w); run("v_fmac", k_fmac, out, w);

@@ -1,0 +1,114 @@
+"""profiles/rNN_* counter tables -> profiles/roofline_pmc.json (what bench.py's roofline block reads).
+
+    python profiles/scripts/make_roofline_pmc.py r03b
+
+Inputs (all committed under profiles/, all from ONE gpurun call, profiles/scripts/r03b.sh):
+  rNN_calib_pmc_a.md   SQ counters of the VALU calibration microbenchmark (profiles/microbench/valu_rates.hip --calib):
+                       every launch is 100 % VALU-issue-bound by construction (4 waves / SIMD, independent
+                       instructions of ONE class), so  SIMD-cycles / SQ_INSTS_VALU  is the issue cost of that class
+                       at saturation.  (rocprofv3 averages the tiny warm-up launch with the real one: x2 below.)
+  rNN_pmc_a.md, rNN_pmc_b.md   the same counters + the per-type instruction counters on bench.py's kernels
+  rNN_pmc_fetch_size.md, rNN_pmc_write_size.md   HBM-side traffic, separate passes (MI355X_MICROARCH.md: KiB units,
+                       FETCH_SIZE doubled on gfx950 — 64 B counted per 128 B request)
+  static mix of the kernels (profiles/scripts/valu_mix.py) for the instructions the per-type counters do not cover.
+
+Issue-cycle model ("what bounds the raster kernels"):
+  cycles = FMA_F32 c_fma + MUL_F32 c_mul + ADD_F32 (s_dpp c_dpp + (1 - s_dpp) c_add) + TRANS_F32 c_trans
+           + INT32 c_int + (INSTS_VALU - those) c_other
+  s_dpp   = static share of DPP adds among the kernel's v_add/v_sub,  c_other = static-mix-weighted cost of the
+            uncounted classes (v_cmp, v_cndmask / v_min, v_mov, v_permlane*_swap),
+  frac    = cycles / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs).
+SQ_ACTIVE_INST_VALU is NOT cycles: on the calibration launches it reads exactly 1 per ordinary VALU instruction and 2
+per transcendental / permlane swap (a nominal quad-cycle weight), which is why rounds 1-2's "ACTIVE x 4 / SIMD-cycles"
+could exceed 1.
+"""
+import json, os, re, subprocess, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+P = os.path.join(ROOT, "profiles")
+SIMDS, XCDS = 1024, 8
+
+
+def table(path):
+    rows = {}
+    lines = [l for l in open(path).read().splitlines() if l.startswith("|")]
+    hdr = [c.strip() for c in lines[0].strip("|").split("|")]
+    for l in lines[2:]:
+        c = [x.strip() for x in l.strip("|").split("|")]
+        rows[c[0].strip("`")] = {h: float(v) for h, v in zip(hdr[1:], c[1:])}
+    return rows
+
+
+def find(rows, key):
+    return next(v for k, v in rows.items() if key in k)
+
+
+def main(tag):
+    cal = table(os.path.join(P, f"{tag}_calib_pmc_a.md"))
+    cost = {}
+    for k, v in cal.items():      # x2: two dispatches averaged, the first one (10 iterations) is ~0
+        cyc = 2 * v["GRBM_GUI_ACTIVE"] / XCDS * SIMDS
+        cost[k.split("(")[0]] = {"issue_cycles_per_inst": cyc / (2 * v["SQ_INSTS_VALU"]),
+                                 "clock_ghz": 2 * v["GRBM_GUI_ACTIVE"] / XCDS / (2 * v["avg_us"] * 1e3),
+                                 "active_inst_valu_per_inst": v["SQ_ACTIVE_INST_VALU"] / v["SQ_INSTS_VALU"]}
+    c = {k: v["issue_cycles_per_inst"] for k, v in cost.items()}
+    mix = json.loads(subprocess.check_output([sys.executable, os.path.join(P, "scripts", "valu_mix.py"), "--json"],
+                                             stderr=subprocess.DEVNULL, text=True))
+    a, b = table(os.path.join(P, f"{tag}_pmc_a.md")), table(os.path.join(P, f"{tag}_pmc_b.md"))
+    fs, ws = table(os.path.join(P, f"{tag}_pmc_fetch_size.md")), table(os.path.join(P, f"{tag}_pmc_write_size.md"))
+    bench = json.loads(open(os.path.join(P, f"{tag}_bench_default.json.log")).read().strip().splitlines()[-1])
+    pairs = bench["roofline"]["walked"]["quadrant_pairs_evaluated_fwd"]
+    out = {"_comment": __doc__.split("Inputs")[0].strip() + f"  Generated from profiles/{tag}_*; see the script for the "
+           "formulas.", "round": tag, "workload": bench["config"]["workload"],
+           "calibration": cost}
+    for name, key in (("raster_bwd", "raster_bwd_short_kernel"), ("raster_fwd", "raster_fwd_pk_kernel")):
+        ka, kb, st = find(a, key), find(b, key), mix[name]["classes"]
+        tot = ka["SQ_INSTS_VALU"]
+        counted = sum(kb[f"SQ_INSTS_VALU_{t}"] for t in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "CVT"))
+        other = tot - counted
+        s_dpp = st.get("dpp", 0) / max(1, st.get("dpp", 0) + st.get("add", 0))
+        oth_cls = {"cmp": c["k_cmp"], "select": c["k_min"], "mov": c["k_mov"], "permlane": c["k_permswap"],
+                   "pk": 5.0, "other": c["k_mov"]}     # v_pk_*: 5.0 cycles (profiles/r01d_profile.md, r02 notes)
+        w = sum(st.get(k, 0) for k in oth_cls)
+        c_other = sum(st.get(k, 0) * v for k, v in oth_cls.items()) / max(1, w)
+        cycles = (kb["SQ_INSTS_VALU_FMA_F32"] * c["k_fma"] + kb["SQ_INSTS_VALU_MUL_F32"] * c["k_mul"] +
+                  kb["SQ_INSTS_VALU_ADD_F32"] * (s_dpp * c["k_dpp"] + (1 - s_dpp) * c["k_mul"]) +
+                  kb["SQ_INSTS_VALU_TRANS_F32"] * c["k_exp"] + (kb["SQ_INSTS_VALU_INT32"] + kb["SQ_INSTS_VALU_CVT"]) * c["k_mov"] +
+                  other * c_other)
+        simd_cycles = ka["GRBM_GUI_ACTIVE"] / XCDS * SIMDS
+        fetch_kib, write_kib = find(fs, key)["FETCH_SIZE"], find(ws, key)["WRITE_SIZE"]
+        out[name] = {
+            "kernel": key, "avg_us_under_pmc": ka["avg_us"],
+            "bound": "valu",
+            "hbm_traffic_bytes": int((2 * fetch_kib + write_kib) * 1024),
+            "hbm_source": f"profiles/{tag}_pmc_fetch_size.md ({fetch_kib:.0f} KiB raw, doubled) + "
+                          f"profiles/{tag}_pmc_write_size.md ({write_kib:.0f} KiB)",
+            "valu": {
+                "simds": SIMDS, "clock_ghz": ka["GRBM_GUI_ACTIVE"] / XCDS / (ka["avg_us"] * 1e3),
+                "valu_insts_per_launch": tot, "pairs_per_launch": pairs, "valu_insts_per_pair": tot / pairs,
+                "issue_cycles_per_inst": cycles / tot,
+                "issue_cycle_frac_under_pmc": cycles / simd_cycles,
+                "counter_frac_calibrated": (ka["SQ_ACTIVE_INST_VALU"] / simd_cycles) /
+                                           (cal_frac(cal, "k_mix")),
+                "dynamic_mix": {k: kb[f"SQ_INSTS_VALU_{k}"] for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "CVT")},
+                "uncounted": other, "c_other": c_other, "dpp_share_of_adds": s_dpp, "static_mix": st,
+                "source": f"profiles/{tag}_pmc_a.md, {tag}_pmc_b.md, {tag}_calib_pmc_a.md, scripts/valu_mix.py, "
+                          "scripts/make_roofline_pmc.py",
+            },
+        }
+    json.dump(out, open(os.path.join(P, "roofline_pmc.json"), "w"), indent=1)
+    for n in ("raster_bwd", "raster_fwd"):
+        v = out[n]["valu"]
+        print(n, "insts/pair %.1f  cycles/inst %.2f  issue frac %.3f  ACTIVE-counter frac (calibrated on k_mix) %.3f  hbm %d MB" % (
+            v["valu_insts_per_pair"], v["issue_cycles_per_inst"], v["issue_cycle_frac_under_pmc"],
+            v["counter_frac_calibrated"], out[n]["hbm_traffic_bytes"] / 1e6))
+    print({k: round(v["issue_cycles_per_inst"], 2) for k, v in cost.items()})
+
+
+def cal_frac(cal, k):
+    v = find(cal, k)
+    return v["SQ_ACTIVE_INST_VALU"] / (v["GRBM_GUI_ACTIVE"] / XCDS * SIMDS)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1] if len(sys.argv) > 1 else "r03b")
