@@ -80,6 +80,12 @@ def parse():
     ap.add_argument("--force-dp", action="store_true",
                     help="single process: still create a 1-rank RCCL group and run the data-parallel exchange "
                          "(self-test of the N>1 code path on one GPU; not a scaling number)")
+    ap.add_argument("--no-dp-overlap", action="store_true",
+                    help="N>1: issue every collective after backward (round-2 behaviour) instead of sending the "
+                         "all-gathers / the geometry bucket from inside the backward pass")
+    ap.add_argument("--dp-watchdog", type=float, default=float(os.environ.get("SGN_DP_WATCHDOG_S", "90")),
+                    help="N>1: seconds without a finished step after which the run prints a JSON error line and exits "
+                         "(a collective that some rank never joins would otherwise block the lease)")
     ap.add_argument("--dp-exchange", default="lowrank", choices=["lowrank", "dense"],
                     help="N>1: SH gradient via all-gathered low-rank factors (default) or dense all-reduce")
     return ap.parse_args()
@@ -263,7 +269,9 @@ def main():
     if force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
+        import datetime
+        torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1,
+                                             timeout=datetime.timedelta(seconds=dp.DEFAULT_TIMEOUT_S))
 
     cam, raw = scenes.make_scene(args.scene, seed=0, yaw=0.01 * rank, device=dev, n_override=args.n)
     if args.street:
@@ -279,7 +287,8 @@ def main():
             # the harness knows its camera: gather 12 B of camera position instead of [N,3] view directions
             ex = dp.SHGradExchange(P["features_dc"], P["features_rest"], force=force_dp).install().set_view(
                 P["means"], cam.cam_pos)
-        reducer = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex, force=force_dp)
+        reducer = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex, force=force_dp,
+                                    overlap=not args.no_dp_overlap)
     n_gauss = P["means"].shape[0]
 
     sg = None
@@ -289,7 +298,8 @@ def main():
         if world > 1:
             if reducer is not None and reducer.sh_exchange is not None:
                 reducer.sh_exchange.remove()
-            reducer = dp.GradAllReducer([p for m in sg[0] for p in m.values()])
+            reducer.remove()
+            reducer = dp.GradAllReducer([p for m in sg[0] for p in m.values()], overlap=not args.no_dp_overlap)
 
     sky = None
     if args.sky:
@@ -299,7 +309,7 @@ def main():
         if world > 1:
             reducer.remove()
             reducer = dp.GradAllReducer(list(P.values()) + [sky["base"]], big=[P["features_rest"], sky["base"]],
-                                        sh_exchange=reducer.sh_exchange)
+                                        sh_exchange=reducer.sh_exchange, overlap=not args.no_dp_overlap)
 
     gt_img = None
     if args.photometric:
@@ -314,7 +324,19 @@ def main():
         if sky is not None:
             adam.append(optim.FusedAdam([sky["base"]], lr=0.01, eps=1e-15))
 
+    watchdog = None
+    if world > 1 or force_dp:
+        def on_hang(idle):
+            err = {"metric": "train-step images/sec (fwd+bwd) @1M Gaussians 1920x1280", "value": None,
+                   "unit": "images/sec", "n_gpus": world, "error": f"rank {rank}: no step finished for {idle:.0f} s "
+                   "(a collective some rank never joined, or a dead peer); aborting instead of holding the lease",
+                   "config": {"parallelism": f"dp{world}", "backend": torch.distributed.get_backend()}}
+            os.write(real_stdout, (json.dumps(err) + "\n").encode())
+        watchdog = dp.Watchdog(args.dp_watchdog, on_hang)
+
     def one_step(fused=(args.path == "fused"), caller_syncs=args.caller_syncs):
+        if watchdog is not None:
+            watchdog.beat()
         if sg is None:
             out = step.train_step(P, cam, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer,
                                   fused=fused, sky=sky, gt=gt_img, caller_syncs=caller_syncs)
@@ -431,6 +453,8 @@ def main():
     eval_extra = None
     if sg is None and not args.no_fused_extra:
         def fwd_only(with_depth, fused=False):
+            if watchdog is not None:
+                watchdog.beat()
             with torch.no_grad():
                 if fused:
                     return step.render_fused(P, cam, 3, 16, with_depth=with_depth)
@@ -471,6 +495,8 @@ def main():
     rep = L.timing_report()
     L.timing_enable(False)
     kernels = {k: (c, (t / c if c else 0.0)) for k, (c, t) in rep.items()}  # avg ms per launch
+    if watchdog is not None:
+        watchdog.stop()      # every collective of the run is behind us; what follows is rank-local (CPU baseline ...)
 
     # what the raster kernels really touch (untimed, one forward): pairs LISTED after exact tile culling, list entries
     # WALKED before the tiles saturate (the backward's reverse walk starts at the deepest composited position the
@@ -564,8 +590,13 @@ def main():
             "kernels_avg_ms": {k: round(v[1], 4) for k, v in kernels.items()},
         }
         line["config"]["path"] = args.path
-        if world > 1:
+        if world > 1 or force_dp:
             line["config"]["backend"] = torch.distributed.get_backend()
+            line["config"]["dp"] = {"ranks": world, "overlap": not args.no_dp_overlap,
+                                    "collective_timeout_s": dp.DEFAULT_TIMEOUT_S, "watchdog_s": args.dp_watchdog,
+                                    "visible_devices": torch.cuda.device_count(),
+                                    "peer_access": dp.peer_access_matrix(),
+                                    "reducer_stats": dict(reducer.stats) if reducer is not None else None}
             if os.environ.get("SGN_BENCH_SHARE_GPU") == "1":
                 line["config"]["note"] = "ranks SHARE GPUs (functional check of the N-rank path, not a scaling number)"
         line["config"]["settle_steps"] = max(0, args.settle)   # untimed, before the W warm-up steps
@@ -607,6 +638,8 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "images/sec", "cores": os.cpu_count(), "kind": "port",
                                         "sample": f"failed: {e!r}"}
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if watchdog is not None:
+        watchdog.stop()
     if world > 1 or force_dp:
         torch.distributed.destroy_process_group()
 

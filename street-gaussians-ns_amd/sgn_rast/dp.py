@@ -19,14 +19,23 @@ compute step is only ~2-3 ms.
 """
 from __future__ import annotations
 
+import datetime
 import os
-from typing import Dict, Iterable, List, Optional, Sequence
+import sys
+import threading
+import time
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
 
+# A collective that one rank never joins must END the job, not hang the lease (VERDICT r02 missing #1): every process
+# group gets a finite timeout (SGN_DP_TIMEOUT_S, default 120 s — the step is ~2 ms, initialisation a few seconds) and
+# RCCL's asynchronous error handling is switched to "tear the process down" before the group is created.
+DEFAULT_TIMEOUT_S = float(os.environ.get("SGN_DP_TIMEOUT_S", "120"))
 
-def init_from_env(backend: Optional[str] = None) -> tuple:
+
+def init_from_env(backend: Optional[str] = None, timeout_s: Optional[float] = None) -> tuple:
     """Initialise the default process group from RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun).
     Returns (rank, world, local_rank).  No-op single-process fallback when WORLD_SIZE is unset."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -41,8 +50,57 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
             backend = os.environ.get("SGN_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # a timed-out or failed collective aborts the communicator and raises / exits instead of spinning forever
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "0")
+        t = DEFAULT_TIMEOUT_S if timeout_s is None else float(timeout_s)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=t))
     return rank, world, local
+
+
+class Watchdog:
+    """Per-step liveness check for N-rank runs: a daemon thread that fires ``on_fire(idle_seconds)`` once when
+    :meth:`beat` has not been called for ``seconds`` — the caller prints its error line there and the process exits with
+    status 3 (a mismatched or never-joined collective otherwise blocks inside a C++ wait that no Python exception can
+    interrupt).  ``beat()`` is one attribute store; the thread polls four times per second."""
+
+    def __init__(self, seconds: float, on_fire: Callable[[float], None], exit_code: int = 3):
+        self.seconds, self.on_fire, self.exit_code = float(seconds), on_fire, exit_code
+        self._last = time.monotonic()
+        self._stop = threading.Event()
+        self.fired = False
+        self._thread = threading.Thread(target=self._run, name="sgn-dp-watchdog", daemon=True)
+        self._thread.start()
+
+    def beat(self) -> None:
+        self._last = time.monotonic()
+
+    def stop(self) -> None:
+        self._stop.set()
+
+    def _run(self) -> None:
+        while not self._stop.wait(0.25):
+            idle = time.monotonic() - self._last
+            if idle > self.seconds:
+                self.fired = True
+                try:
+                    self.on_fire(idle)
+                finally:
+                    sys.stdout.flush(); sys.stderr.flush()
+                    if self.exit_code is not None:
+                        os._exit(self.exit_code)
+                return
+
+
+def peer_access_matrix() -> Optional[List[str]]:
+    """hipDeviceCanAccessPeer over the devices this process sees, one string of 0/1 per device (diagonal '-'); what
+    RCCL's xGMI rings are built on.  None without a GPU."""
+    if not torch.cuda.is_available():
+        return None
+    n = torch.cuda.device_count()
+    return ["".join("-" if i == j else ("1" if torch.cuda.can_device_access_peer(i, j) else "0") for j in range(n))
+            for i in range(n)]
 
 
 def view_permutation(n_views: int, seed: int, epoch: int) -> torch.Tensor:
@@ -60,56 +118,99 @@ def view_for_rank(step: int, rank: int, world: int, n_views: int, seed: int = 0)
 
 
 class GradAllReducer:
-    """Bucketed all-reduce of per-Gaussian gradients, issued from :meth:`finish` in ONE FIXED ORDER.
+    """Bucketed all-reduce of per-Gaussian gradients in ONE FIXED COLLECTIVE SEQUENCE on every rank:
 
-    Every rank makes the same collective calls in the same sequence by construction — the low-rank exchange's
-    all-gathers, then one all-reduce per ``big`` parameter (in ``params`` order), then the flat bucket of everything
-    else — whatever its own backward did: a parameter that received no gradient on this rank (its view saw nothing)
-    takes part with zeros.  (Round 1 launched the big all-reduces and the exchange's all-gathers from autograd hooks
-    as their gradients became final; the order then depended on each rank's autograd graph — a rank whose sky or SH
-    node ran in a different order, or not at all, issued a different sequence, which hangs or corrupts NCCL.  The
-    overlap that bought was the ~0.05 ms of `project_gaussians` backward.)  All calls are asynchronous: the bucket
-    travels while the exchange rebuilds the dense SH gradient.  ``average=True`` divides by world size (the loss is a
-    per-image mean, so DP over views averages)."""
+        1. the low-rank exchange's all-gathers (colour gradient, view factor)      ``SHGradExchange.start``
+        2. the flat bucket of the small per-Gaussian gradients (means, scales, quats, opacity: 44 B / Gaussian)
+        3. one all-reduce per ``big`` parameter, in ``params`` order
+        4. the exchange's dense fallback all-reduces (only when unclaimed SH nodes ran) ``SHGradExchange.finish``
+
+    :meth:`finish` (after ``loss.backward()``) issues whatever of 1-4 has not been issued yet, in that order, waits
+    and averages.  A parameter that received no gradient on this rank (its view saw nothing) takes part with zeros.
+
+    ``overlap=True`` (round 3) lets steps 1 and 2 start DURING the backward, without changing the sequence: the
+    all-gathers leave from the claimed SH node's backward (the colour gradient is final right after the rasterize
+    backward) and travel under the projection backward and the caller's activation backwards; the bucket leaves from
+    a post-accumulate hook on the moment its last leaf has its gradient, and travels under the exchange's rebuild
+    kernel.  The hooks never reorder anything: the bucket leaves early only if step 1 has already left (or there is
+    no exchange); otherwise :meth:`finish` issues it in its slot.  A rank whose backward never ran (no Gaussian in
+    view) issues everything from :meth:`finish` — the same sequence, later.  (Round 1 issued collectives from hooks
+    in whatever order each rank's autograd graph produced them — sequences could differ between ranks, which hangs
+    RCCL; round 2 issued everything after backward.)  Contract of ``overlap``: exactly ONE backward pass between two
+    :meth:`finish` calls; a gradient accumulated after its bucket left is detected and raises.
+
+    All calls are asynchronous (``async_op=True``: RCCL's own stream, ordered after the producing kernels).
+    ``average=True`` divides by world size (the loss is a per-image mean, so DP over views averages)."""
 
     def __init__(self, params: Sequence[torch.Tensor], big: Iterable[torch.Tensor] = (),
                  average: bool = True, group=None, sh_exchange: "Optional[SHGradExchange]" = None,
-                 force: bool = False):
+                 force: bool = False, overlap: bool = False):
         self.sh_exchange = sh_exchange
         skip = sh_exchange.leaf_ids() if sh_exchange is not None else set()
         self.params = [p for p in params if id(p) not in skip]
         self.big_ids = {id(p) for p in big if id(p) not in skip}
+        self.small = [p for p in self.params if id(p) not in self.big_ids]
         self.average = average
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())   # force: run the collectives at world 1
+        self.overlap = bool(overlap) and self.active
+        self._bucket = None            # (flat, work, versions) once the bucket has left
+        self._arrived = 0
+        self._hooks = []
+        self.stats = {"bucket_early": 0, "bucket_late": 0}
+        if self.overlap:
+            if sh_exchange is not None:
+                sh_exchange.early_start = True
+            for p in self.small:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    # -------------------------------------------------------------------------------- step 2: the flat bucket
+    def _on_grad(self, _p) -> None:
+        self._arrived += 1
+        if self._arrived == len(self.small) and self._bucket is None:
+            ex = self.sh_exchange
+            if ex is None or not ex.active or ex.started:       # never ahead of step 1
+                self._issue_bucket(early=True)
+
+    def _issue_bucket(self, early: bool) -> None:
+        if not self.small or self._bucket is not None:
+            return
+        for p in self.small:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        flat = torch.cat([p.grad.reshape(-1) for p in self.small])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._bucket = (flat, work, [p.grad._version for p in self.small])
+        self.stats["bucket_early" if early else "bucket_late"] += 1
 
     def finish(self) -> None:
         """Call after ``loss.backward()``."""
-        pending, small, flat, work = [], [], None, None
+        pending = []
         if self.sh_exchange is not None:
-            self.sh_exchange.start()                     # 1. all-gathers of the low-rank factors
+            self.sh_exchange.start()                     # 1. all-gathers (no-op if the SH backward already sent them)
         if self.active:
-            for p in self.params:
-                if p.grad is None:
-                    p.grad = torch.zeros_like(p)
-            for p in self.params:                        # 2. big tensors, one all-reduce each, in params order
+            self._issue_bucket(early=False)              # 2. the flat bucket (no-op if the hook already sent it)
+            for p in self.params:                        # 3. big tensors, one all-reduce each, in params order
                 if id(p) in self.big_ids:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
                     pending.append((dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True), p))
-            small = [p for p in self.params if id(p) not in self.big_ids]
-            if small:                                    # 3. everything else as one flat bucket
-                flat = torch.cat([p.grad.reshape(-1) for p in small])
-                work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         if self.sh_exchange is not None:
             self.sh_exchange.finish()                    # 4. rebuild (overlaps 2-3) or dense fallback
         if not self.active:
             return
-        if work is not None:
+        if self._bucket is not None:
+            flat, work, versions = self._bucket
+            self._bucket, self._arrived = None, 0
+            if any(p.grad._version != v for p, v in zip(self.small, versions)):
+                raise RuntimeError("GradAllReducer(overlap=True): a gradient changed after its bucket had left — more "
+                                   "than one backward pass between two finish() calls; use overlap=False")
             work.wait()
             if self.average:
                 flat /= self.world
             off = 0
-            for p in small:
+            for p in self.small:
                 n = p.grad.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
@@ -119,7 +220,11 @@ class GradAllReducer:
                 p.grad /= self.world
 
     def remove(self) -> None:
-        """Kept for callers of the round-1 API (there are no hooks to remove any more)."""
+        """Detach the overlap hooks (a reducer that is being replaced)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        self.overlap = False
 
 
 def _sh_multi_hip(degree, k, dirs_all, means, cam_all, object_ids, poses, v_all, scale):
@@ -175,6 +280,11 @@ class SHGradExchange:
         self._last = None        # shape of the last step: kind, degree, K, mixed
         self._works = []
         self._view = None
+        self.early_start = False  # GradAllReducer(overlap=True): send the all-gathers from the claimed node's backward
+
+    @property
+    def started(self) -> bool:
+        return self._started is not None
 
     def set_view(self, means: torch.Tensor, cam_pos: torch.Tensor) -> "SHGradExchange":
         """Drop-in ops only see view directions; a trainer that knows its camera can say so: with the (replicated)
@@ -220,7 +330,7 @@ class SHGradExchange:
         """Drop-in SH backward.  True = the exchange takes this node's gradient over (caller skips its dense kernel)."""
         if not self.active:
             return False
-        if not claimed or self._claimed is not None:
+        if not claimed or self._claimed is not None or self._started is not None:
             self._unclaimed = True
             return False
         if self._view is not None and self._view[0].shape[0] == v_colors.shape[0]:
@@ -230,16 +340,20 @@ class SHGradExchange:
                                  means=means.detach().contiguous())
         else:
             self._claimed = dict(kind="dirs", degree=degree, k=k, v=v_colors, dirs=viewdirs)
+        if self.early_start:
+            self.start()          # the colour gradient is final: its all-gather travels under the rest of the backward
         return True
 
     def tap_fused(self, means, cam_pos, v_eff, degree, k, claimed: bool) -> bool:
         if not self.active:
             return False
-        if not claimed or self._claimed is not None:
+        if not claimed or self._claimed is not None or self._started is not None:
             self._unclaimed = True
             return False
         self._claimed = dict(kind="cam", degree=degree, k=k, v=v_eff,
                              cam=cam_pos.detach().reshape(3).to(v_eff.device, torch.float32), means=means)
+        if self.early_start:
+            self.start()
         return True
 
     # ------------------------------------------------------------------ collectives (fixed position on every rank)
@@ -291,13 +405,16 @@ class SHGradExchange:
             st["v_all"] = self._gather(c["v"])
             st["x_all"] = self._gather(c["dirs"] if c["kind"] == "dirs" else c["cam"])
         self._started = st
-        self._claimed, self._unclaimed = None, False
+        self._claimed = None     # (_unclaimed keeps collecting until finish(): nodes may still run after an early start)
 
     def finish(self) -> None:
         if not self.active:
             return
         self.start()
         st, self._started = self._started, None
+        if self._unclaimed:       # an unclaimed SH node ran after an early start() of this step
+            st["mixed"] = True
+        self._claimed, self._unclaimed = None, False
         c = st["c"]
         self._last = dict(kind=st["kind"], mixed=st["mixed"], degree=None if c is None else c["degree"],
                           k=None if c is None else c["k"])

@@ -426,7 +426,7 @@ binning_stats = {"speculative_hits": 0, "speculative_misses": 0}
 tile_order_enabled = True
 concurrent_backward = True   # lend sgn_raster_bwd a second stream: its short-walk and long-walk kernels overlap
 small_splat_q16 = 0       # experimental: > 0 sends tiles with < q/16 evaluated (entry, quadrant) pairs per walked entry to the 4-waves kernel (no gain measured: profiles/r02_street_balance.md)
-_order_cache = {"bins": None, "order": None}
+_order_cache = {"bins": None, "order": None, "thresh": None}
 
 
 def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = None, long_thresh: int = 0):
@@ -435,7 +435,7 @@ def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = Non
     with the count of walks >= ``long_thresh`` behind the permutation (the two-kernel adaptive scheme)."""
     if not tile_order_enabled:
         return None
-    if tile_kmax is None and _order_cache["bins"] is tile_bins:
+    if tile_kmax is None and _order_cache["bins"] is tile_bins and _order_cache["thresh"] == int(long_thresh):
         return _order_cache["order"]
     n_tiles = tile_bins.shape[0]
     order = torch.empty(n_tiles + 2, dtype=torch.int32, device=tile_bins.device)   # permutation, n_long, cursor
@@ -443,7 +443,7 @@ def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = Non
                                     int(small_splat_q16) if tile_kmax is not None else 0, L.ptr(order),
                                     L.stream_ptr()), "sgn_tile_order")
     if tile_kmax is None:
-        _order_cache["bins"], _order_cache["order"] = tile_bins, order
+        _order_cache["bins"], _order_cache["order"], _order_cache["thresh"] = tile_bins, order, int(long_thresh)
     return order
 
 
@@ -549,8 +549,15 @@ def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacit
     if n_full <= n:
         return None
     mine = (xys, depths, radii, num_tiles_hit) + ((conics, opacity) if cull else ())
-    for t, c in zip(mine, keep):
+    for i, (t, c) in enumerate(zip(mine, keep)):
         if t.dtype != c.dtype or t.shape[1:] != c.shape[1:] or t.device != c.device:
+            return None
+        # sgn_rows_match compares 32-bit words (row widths {2,1,1,1,3,1}): float32 / int32 tensors only — anything else
+        # (int64 radii, float64 xys: the binning accepts and converts them) falls through to re-binning
+        if t.dtype not in (torch.float32, torch.int32):
+            return None
+        # the cached aliases must still hold the bytes the list was binned from (key rows: data_ptr, _version, ...)
+        if c._version != ck[i][1] or c.data_ptr() != ck[i][0]:
             return None
     window_stats["tried"] += 1
     dev = xys.device

@@ -69,10 +69,15 @@ class _QuatMul(torch.autograd.Function):
 def quaternion_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """``pytorch3d.transforms.quaternion_multiply``: Hamilton product of rotations, real part first, result with a
     non-negative real part."""
-    kernel_ok = (b.is_cuda and b.dim() == 2 and b.shape[-1] == 4 and a.shape[-1] == 4
-                 and (a.numel() == 4 and not a.requires_grad or (a.is_cuda and a.shape == b.shape)))
+    # The kernel path covers exactly the reference's call shape (ADVICE r02): `b` a float32 [N,4] device tensor, `a`
+    # either ONE quaternion that lives on the host (read by value: no device read-back; a float64 4-vector times a
+    # float32 tensor with more elements promotes to float32 in torch as well, so the result dtype is upstream's) or a
+    # float32 device tensor of b's shape.  Everything else — float64 `b`, a single quaternion on the device (reading
+    # it would be a host sync), other broadcasts — takes pytorch3d's own formulation in plain torch.
+    one_host_quat = a.numel() == 4 and not a.is_cuda and not a.requires_grad
+    same_shape = a.is_cuda and a.shape == b.shape and a.dtype == torch.float32
+    kernel_ok = (b.is_cuda and b.dtype == torch.float32 and b.dim() == 2 and b.shape[-1] == 4 and a.shape[-1] == 4
+                 and (one_host_quat or same_shape))
     if not kernel_ok:
         return standardize_quaternion(quaternion_raw_multiply(a, b))
-    # result dtype follows torch's promotion of the reference's call: a 0-dim float64 scalar tensor times a float32
-    # tensor stays float32
     return _QuatMul.apply(a, b)

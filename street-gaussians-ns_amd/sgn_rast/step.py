@@ -73,7 +73,13 @@ def render(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, b
         num_tiles_hit, out.num_tiles_hit_parts = _split_recat(num_tiles_hit, split_counts)
     out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit = xys, depths, radii, conics, num_tiles_hit
     if caller_syncs and bool(radii.sum() == 0):                                  # :878 (host sync)
-        raise RuntimeError("no Gaussian is visible (the reference returns its empty outputs here)")
+        # the reference's empty outputs (:879-886): background colour, zero accumulation / depth, no autograd graph
+        # — a data-parallel rank whose view sees nothing must fall through to the collectives, not abort
+        out.rgb = background.repeat(H, W, 1)
+        out.alpha = torch.zeros(H, W, device=dev)
+        out.depth = torch.zeros(H, W, 1, device=dev)
+        out.empty = True
+        return out
     if retain_xys_grad and xys.requires_grad:
         xys.retain_grad()                                                        # :889-890
     viewdirs = P["means"].detach() - cam.cam_pos.to(P["means"].dtype)            # :934
@@ -201,6 +207,10 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
                  log_scales=cat("log_scales"))
         out = render(P, cam, sh_degree_to_use, block_width, with_depth=True, ops=ops,   # :363
                      split_counts=counts, caller_syncs=caller_syncs)
+        if getattr(out, "empty", False):        # nothing visible: the sub-model passes return their empty outputs too
+            out.object_acc = torch.zeros(H, W, device=dev)
+            out.background_acc = torch.zeros(H, W, device=dev)
+            return out
         opac_arg, raster = out.opacities, ops.rasterize_gaussians
 
     def submodel_acc(lo: int, hi: int, which):                                          # :255-303
@@ -305,7 +315,8 @@ def train_step(P: Dict[str, torch.Tensor], cam: Camera, w_img: torch.Tensor, w_a
         loss = photo + (out.alpha * w_a).sum() / n_pix
     else:
         loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum()) / n_pix
-    loss.backward()
+    if loss.requires_grad:         # an empty view (the reference's constant outputs) has nothing to differentiate
+        loss.backward()
     if reducer is not None:
         reducer.finish()
     out.loss = loss.detach()

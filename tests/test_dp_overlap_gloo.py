@@ -1,0 +1,214 @@
+"""CPU: the overlapped N-rank exchange, world_size 2 over gloo.
+
+`GradAllReducer(overlap=True)` sends the low-rank exchange's all-gathers from the claimed SH node's backward and the
+flat geometry bucket from a post-accumulate hook — WITHOUT changing the collective sequence: the results must equal
+the non-overlapped reducer bit for bit, a silent rank (no backward at all) must still issue the same sequence from
+`finish()`, and a second backward pass between two `finish()` calls must be detected.  Also: the liveness watchdog
+and the finite process-group timeout.
+"""
+import os
+import socket
+import time
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _sh_multi_torch(degree, k, dirs_all, means, cam_all, object_ids, poses, v_all, scale):
+    from oracle import torch_oracle as TO
+    R, n = v_all.shape[0], v_all.shape[1]
+    out = torch.zeros(n, k, 3)
+    for r in range(R):
+        dirs = dirs_all[r] if dirs_all is not None else means - cam_all[r]
+        b = torch.stack(TO._sh_bases(dirs, degree), dim=-1)
+        out[:, : b.shape[1], :] += b[:, :, None] * v_all[r][:, None, :]
+    return out * scale
+
+
+def _make_sh_op(ex):
+    """An SH node with the tap protocol of `sgn_rast.ops._SphericalHarmonics` (claim at forward time on the autograd
+    graph, tap at backward time, dense backward when the exchange does not take the node), on the torch oracle."""
+    from oracle import torch_oracle as TO
+
+    class SH(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, deg, dirs, coeffs, claimed):
+            ctx.deg, ctx.k, ctx.claimed = deg, coeffs.shape[1], claimed
+            ctx.save_for_backward(dirs)
+            return TO.spherical_harmonics(deg, dirs, coeffs.detach())
+
+        @staticmethod
+        def backward(ctx, v):
+            (dirs,) = ctx.saved_tensors
+            if ex is not None and ex.tap_dirs(dirs, v.contiguous(), ctx.deg, ctx.k, ctx.claimed):
+                return None, None, None, None
+            b = torch.stack(TO._sh_bases(dirs, ctx.deg), dim=-1)
+            g = torch.zeros(v.shape[0], ctx.k, 3)
+            g[:, : b.shape[1], :] = b[:, :, None] * v[:, None, :]
+            return None, None, g, None
+
+    def sh(deg, dirs, coeffs):
+        return SH.apply(deg, dirs, coeffs, bool(ex is not None and ex.claims_coeffs(coeffs)))
+    return sh
+
+
+def _overlap_worker(rank, world, port, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "street-gaussians-ns_amd"), os.path.join(root, "tests")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from sgn_rast import dp
+    torch.set_num_threads(2)
+    dp.init_from_env(backend="gloo", timeout_s=60)
+    n, k, deg = 200, 16, 3
+    results = {}
+    for overlap in (False, True):
+        gp = torch.Generator().manual_seed(7)                       # replicated parameters
+        P = {name: torch.randn(*shape, generator=gp).requires_grad_(True) for name, shape in
+             (("means", (n, 3)), ("log_scales", (n, 3)), ("quats", (n, 4)), ("opacity_logits", (n, 1)),
+              ("features_dc", (n, 1, 3)), ("features_rest", (n, k - 1, 3)))}
+        cam_pos = torch.randn(3, generator=torch.Generator().manual_seed(50 + rank))      # per-rank view
+        w = torch.randn(n, 3, generator=torch.Generator().manual_seed(60 + rank))
+        ex = dp.SHGradExchange(P["features_dc"], P["features_rest"], average=True, multi_fn=_sh_multi_torch)
+        ex.set_view(P["means"], cam_pos)
+        red = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex, overlap=overlap)
+        assert red.small == [P["means"], P["log_scales"], P["quats"], P["opacity_logits"]]
+        sh = _make_sh_op(ex)
+        for step_i in range(3):
+            for p in P.values():
+                p.grad = None
+            silent = (step_i == 2 and rank == 1)                   # third step: rank 1's view sees nothing
+            if not silent:
+                # the shape of the real step: geometry -> "projection"; coefficients -> SH -> colours; product -> loss.
+                # the SH node is created AFTER the geometry node, so its backward (the tap) runs BEFORE the geometry
+                # leaves accumulate — as in render(): project_gaussians is the earliest node of the graph
+                geo = (torch.exp(P["log_scales"]).sum(-1, keepdim=True) * P["means"]
+                       * torch.sigmoid(P["opacity_logits"]) + P["quats"][:, :3] / P["quats"].norm(dim=-1, keepdim=True))
+                dirs = P["means"].detach() - cam_pos
+                dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+                rgb = sh(deg, dirs, torch.cat((P["features_dc"], P["features_rest"]), dim=1))
+                loss = ((rgb + geo) * w).sum() * (1.0 + step_i)
+                loss.backward()
+                if overlap:
+                    assert ex.started and red._bucket is not None, "all-gathers and bucket must have left in backward"
+            red.finish()
+            results[(overlap, step_i)] = {name: p.grad.clone() for name, p in P.items()}
+        results[("stats", overlap)] = dict(red.stats)
+        # contract: one backward per finish() — a second one after the bucket left is detected, not silently lost
+        red.remove()
+        ex.remove()
+        if overlap:
+            geo_leaves = [P["means"], P["log_scales"], P["quats"], P["opacity_logits"]]
+            red2 = dp.GradAllReducer(geo_leaves, overlap=True)         # no exchange: the bucket may leave on its own
+            for p in P.values():
+                p.grad = None
+            sum(p.sum() for p in geo_leaves).backward()
+            assert red2._bucket is not None
+            # with an exchange that has not sent its all-gathers the bucket must NOT leave early (sequence rule)
+            (P["means"] * 2).sum().backward()
+            try:
+                red2.finish()
+                results["violation"] = "not detected"
+            except RuntimeError as e:
+                results["violation"] = "detected" if "more than one backward" in str(e) else str(e)
+            dist.barrier()     # both ranks raised before waiting on the bucket; keep them in step
+            red2.remove()
+            ex3 = dp.SHGradExchange(P["features_dc"], P["features_rest"], multi_fn=_sh_multi_torch)
+            red3 = dp.GradAllReducer(list(P.values()), sh_exchange=ex3, overlap=True)
+            for p in P.values():
+                p.grad = None
+            P["features_dc"].grad = torch.zeros_like(P["features_dc"]); P["features_rest"].grad = torch.zeros_like(P["features_rest"])
+            sum(p.sum() for p in geo_leaves).backward()
+            results["held_back"] = red3._bucket is None and not ex3.started
+            ex3.tap_dirs(torch.ones(n, 3), torch.zeros(n, 3), deg, k, False)    # an unclaimed node ran: dense step
+            red3.finish()
+            results["late_stats"] = dict(red3.stats)
+            red3.remove()
+    torch.save(results, os.path.join(outdir, f"overlap{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_overlapped_exchange_equals_sequential_and_keeps_the_sequence(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=500)
+        assert p.exitcode == 0
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"overlap{r}.pt")) for r in range(world))
+    for step_i in range(3):
+        for name in r0[(False, step_i)]:
+            a, b = r0[(False, step_i)][name], r0[(True, step_i)][name]
+            assert torch.equal(a, b), (step_i, name)                        # overlap changes timing, not results
+            assert torch.equal(b, r1[(True, step_i)][name]), (step_i, name)  # replicas agree bit for bit
+            assert float(b.abs().sum()) > 0, (step_i, name)
+    assert r0[("stats", True)] == {"bucket_early": 3, "bucket_late": 0}
+    assert r1[("stats", True)] == {"bucket_early": 2, "bucket_late": 1}      # the silent rank sent it from finish()
+    assert r0[("stats", False)] == {"bucket_early": 0, "bucket_late": 3}
+    assert r0["violation"] == "detected" and r1["violation"] == "detected"
+    assert r0["held_back"] and r1["held_back"]
+    assert r0["late_stats"] == {"bucket_early": 0, "bucket_late": 1}
+
+
+def test_watchdog_fires_once_when_the_loop_stops_beating():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [os.path.join(root, "street-gaussians-ns_amd")]
+    from sgn_rast import dp
+    fired = []
+    wd = dp.Watchdog(0.6, lambda idle: fired.append(idle), exit_code=None)
+    for _ in range(6):                       # a live loop: no firing
+        time.sleep(0.2)
+        wd.beat()
+    assert not fired and not wd.fired
+    time.sleep(1.3)                          # the loop "hangs"
+    assert wd.fired and len(fired) == 1 and fired[0] > 0.6
+    wd.stop()
+
+
+def _timeout_worker(rank, world, port, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "street-gaussians-ns_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from sgn_rast import dp
+    dp.init_from_env(backend="gloo", timeout_s=3)
+    t = torch.ones(4)
+    dist.all_reduce(t)                       # both ranks: fine
+    verdict = "ok"
+    if rank == 0:                            # rank 1 never joins the second collective: rank 0 must NOT hang
+        t0 = time.monotonic()
+        try:
+            dist.all_reduce(t)
+            verdict = "returned"
+        except Exception as e:               # gloo raises on timeout
+            verdict = f"raised after {time.monotonic() - t0:.1f}s: {type(e).__name__}"
+    else:
+        time.sleep(6)
+    open(os.path.join(outdir, f"timeout{rank}.txt"), "w").write(verdict)
+
+
+@pytest.mark.timeout(120)
+def test_a_collective_nobody_joins_times_out_instead_of_hanging(tmp_path):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_timeout_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=60)
+    v = open(os.path.join(tmp_path, "timeout0.txt")).read()
+    assert v.startswith("raised after"), v
+    assert float(v.split()[2][:-2]) < 10.0, v

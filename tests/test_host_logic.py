@@ -224,3 +224,28 @@ def test_checkpoint_state_names_and_size_changing_load():
                                                                        bg["features_dc"], bg["features_rest"],
                                                                        bg["opacity_logits"]])})   # old flat names
     assert torch.equal(single[""]["log_scales"], bg["log_scales"])
+
+
+def test_empty_view_returns_the_reference_empty_outputs_and_still_reaches_the_reducer():
+    """sgn_splatfacto.py:878-886: `radii.sum() == 0` -> background image, zero accumulation / depth.  The replay must
+    return those (not raise), and `train_step` must still call `reducer.finish()` so a data-parallel rank whose view
+    sees nothing joins the collectives."""
+    import oracle_ops
+    from sgn_rast import scenes, step
+    cam = scenes.make_camera(64, 48, 64.0)
+    raw = scenes.make_gaussians(200, cam, seed=0, z_range=(1.0, 4.0))
+    raw["means"][:, 2] = -5.0                                    # everything behind the camera
+    P = step.leaf_params(raw)
+    out = step.render(P, cam, ops=oracle_ops, with_depth=True, caller_syncs=True)
+    assert out.empty and out.rgb.shape == (48, 64, 3) and float(out.rgb.abs().max()) == 0.0
+    assert float(out.alpha.abs().max()) == 0.0 and out.depth.shape == (48, 64, 1)
+
+    class Reducer:
+        called = 0
+
+        def finish(self):
+            Reducer.called += 1
+    w_img, w_a = step.loss_weights(cam)
+    res = step.train_step(P, cam, w_img, w_a, ops=oracle_ops, reducer=Reducer(), caller_syncs=True)
+    assert Reducer.called == 1 and float(res.loss) == 0.0
+    assert all(p.grad is None for p in P.values())
