@@ -70,8 +70,8 @@ def quaternion_multiply(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """``pytorch3d.transforms.quaternion_multiply``: Hamilton product of rotations, real part first, result with a
     non-negative real part."""
     # The kernel path covers exactly the reference's call shape (ADVICE r02): `b` a float32 [N,4] device tensor, `a`
-    # either ONE quaternion that lives on the host (read by value: no device read-back; a float64 4-vector times a
-    # float32 tensor with more elements promotes to float32 in torch as well, so the result dtype is upstream's) or a
+    # either ONE quaternion that lives on the host (read by value: no device read-back; pytorch3d unbinds it into
+    # 0-dim components, which do not promote the float32 rows of `b`, so float32 is upstream's result dtype too) or a
     # float32 device tensor of b's shape.  Everything else — float64 `b`, a single quaternion on the device (reading
     # it would be a host sync), other broadcasts — takes pytorch3d's own formulation in plain torch.
     one_host_quat = a.numel() == 4 and not a.is_cuda and not a.requires_grad
