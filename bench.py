@@ -331,7 +331,10 @@ def main():
                    "unit": "images/sec", "n_gpus": world, "error": f"rank {rank}: no step finished for {idle:.0f} s "
                    "(a collective some rank never joined, or a dead peer); aborting instead of holding the lease",
                    "config": {"parallelism": f"dp{world}", "backend": torch.distributed.get_backend()}}
-            os.write(real_stdout, (json.dumps(err) + "\n").encode())
+            if rank == 0:        # ONE line on stdout, as for a good run; the other ranks report on stderr
+                os.write(real_stdout, (json.dumps(err) + "\n").encode())
+            else:
+                print(json.dumps(err), file=sys.stderr, flush=True)
         watchdog = dp.Watchdog(args.dp_watchdog, on_hang)
 
     def one_step(fused=(args.path == "fused"), caller_syncs=args.caller_syncs):
@@ -361,6 +364,8 @@ def main():
             else:
                 torch.distributed.barrier()
 
+    if os.environ.get("SGN_BENCH_HANG_RANK") == str(rank) and world > 1:
+        time.sleep(3600)     # failure-containment test: this rank never joins the collectives (profiles/scripts/r03c.sh)
     for _ in range(max(0, args.settle)):
         one_step()
     torch.cuda.synchronize()

@@ -33,6 +33,7 @@ def single_view_grads(r, fused):
 
 
 ok = True
+OVERLAP = os.environ.get("DP2_OVERLAP", "1") == "1"
 for exchange in ("lowrank", "dense"):
     for fused in (False, True):
         cam, raw, w_img, w_a = view(rank)
@@ -40,12 +41,15 @@ for exchange in ("lowrank", "dense"):
         ex = None
         if exchange == "lowrank":
             ex = dp.SHGradExchange(P["features_dc"], P["features_rest"]).install().set_view(P["means"], cam.cam_pos)
-        red = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex)
+        red = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex, overlap=OVERLAP)
         for _ in range(2):                                   # twice: the second step runs the speculative binning
             step.train_step(P, cam, w_img, w_a, 3, 16, reducer=red, fused=fused)
         torch.cuda.synchronize()
+        red.remove()
         if ex is not None:
             ex.remove()
+        if rank == 0:
+            print("dp2 reducer stats", exchange, "fused" if fused else "dropin", red.stats, flush=True)
         g0, g1 = single_view_grads(0, fused), single_view_grads(1, fused)
         worst = 0.0
         for k in P:
