@@ -133,14 +133,40 @@ def bin_and_sort(xys, depths, radii, num_tiles_hit, H, W, block):
     return cum, keys, vals, ks, vs, bins
 
 
+# Host threads for the two compositing calls (default 1: the plain scalar oracle).  Pixel rows are independent, so
+# THREADS > 1 hands disjoint row chunks of [lo, hi) to a thread pool (ctypes releases the GIL inside the C call): the
+# forward writes disjoint rows of the same buffers (bit-identical to one call), the backward sums the per-chunk
+# per-Gaussian results in chunk order (deterministic; differs from the one-call result by float rounding of the
+# partial sums only).  Used by the long convergence test to keep its CPU side short; nothing else sets it.
+THREADS = 1
+
+
+def _row_chunks(lo, hi):
+    n = max(1, min(int(THREADS), hi - lo))
+    edges = [lo + (hi - lo) * i // n for i in range(n + 1)]
+    return [(a, b) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+
+
+def _run_chunks(fn, chunks):
+    if len(chunks) == 1:
+        return [fn(*chunks[0])]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=len(chunks)) as ex:
+        return list(ex.map(lambda c: fn(*c), chunks))
+
+
 def raster_fwd(H, W, block, ids, bins, xys, conics, colors, opac, bg, rows=None):
     """``rows=(lo, hi)``: pixel rows [lo, hi) only (the rest of the outputs stays zero) — a band of a
     BASELINE-size image is a band of the full result, at a fraction of the CPU time."""
     out = torch.zeros(H, W, 3); fT = torch.zeros(H, W); fi = torch.zeros(H, W, dtype=torch.int32)
     lo, hi = (0, H) if rows is None else rows
-    lib().sgo_raster_fwd_rows(C.c_int(H), C.c_int(W), C.c_int(block), _p(ids.contiguous()), _p(bins.contiguous()),
-                              _p(_f(xys)), _p(_f(conics)), _p(_f(colors)), _p(_f(opac).reshape(-1)), _p(_f(bg)),
-                              _p(out), _p(fT), _p(fi), C.c_int(lo), C.c_int(hi))
+    a = (ids.contiguous(), bins.contiguous(), _f(xys), _f(conics), _f(colors), _f(opac).reshape(-1), _f(bg))
+    L = lib()
+
+    def go(r0, r1):
+        L.sgo_raster_fwd_rows(C.c_int(H), C.c_int(W), C.c_int(block), *[_p(t) for t in a], _p(out), _p(fT), _p(fi),
+                              C.c_int(r0), C.c_int(r1))
+    _run_chunks(go, _row_chunks(lo, hi))
     return out, fT, fi
 
 
@@ -149,13 +175,20 @@ def raster_bwd(H, W, block, ids, bins, xys, conics, colors, opac, bg, final_T, f
     """``rows=(lo, hi)``: contributions of pixel rows [lo, hi) only (= the full backward when ``v_out`` and
     ``v_out_alpha`` vanish outside the band)."""
     N = xys.shape[0]
-    v_xy = torch.zeros(N, 2); v_conic = torch.zeros(N, 3); v_col = torch.zeros(N, 3); v_op = torch.zeros(N, 1)
     lo, hi = (0, H) if rows is None else rows
-    lib().sgo_raster_bwd_rows(C.c_int(H), C.c_int(W), C.c_int(block), C.c_int(N), _p(ids.contiguous()),
-                              _p(bins.contiguous()), _p(_f(xys)), _p(_f(conics)), _p(_f(colors)),
-                              _p(_f(opac).reshape(-1)), _p(_f(bg)), _p(_f(final_T)), _p(final_idx.contiguous()),
-                              _p(_f(v_out)), _p(_f(v_out_alpha)), C.c_float(alpha_clamp_bwd), _p(v_xy),
-                              _p(v_conic), _p(v_col), _p(v_op), C.c_int(lo), C.c_int(hi))
+    a = (ids.contiguous(), bins.contiguous(), _f(xys), _f(conics), _f(colors), _f(opac).reshape(-1), _f(bg),
+         _f(final_T), final_idx.contiguous(), _f(v_out), _f(v_out_alpha))
+    L = lib()
+
+    def go(r0, r1):
+        o = (torch.zeros(N, 2), torch.zeros(N, 3), torch.zeros(N, 3), torch.zeros(N, 1))
+        L.sgo_raster_bwd_rows(C.c_int(H), C.c_int(W), C.c_int(block), C.c_int(N), *[_p(t) for t in a],
+                              C.c_float(alpha_clamp_bwd), *[_p(t) for t in o], C.c_int(r0), C.c_int(r1))
+        return o
+    parts = _run_chunks(go, _row_chunks(lo, hi))
+    v_xy, v_conic, v_col, v_op = parts[0]
+    for o in parts[1:]:
+        v_xy += o[0]; v_conic += o[1]; v_col += o[2]; v_op += o[3]
     return v_xy, v_conic, v_col, v_op
 
 

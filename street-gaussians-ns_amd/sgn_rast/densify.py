@@ -36,11 +36,25 @@ class Stats:
         first = self.xys_grad_norm is None
         if first:
             f32 = dict(dtype=torch.float32, device=g.device)
-            self.xys_grad_norm, self.vis_counts = torch.empty(n, **f32), torch.empty(n, **f32)
-            self.max_2Dsize = torch.empty(n, **f32)
+            if self._is_follower_rank():
+                # The reference's first update after a refinement counts EVERY Gaussian once, visible or not (:524-527:
+                # `vis_counts = torch.ones_like(...)`).  Under view-parallel training the statistics of the ranks are
+                # SUMMED (`sync`), so only ONE rank's first view may do that — otherwise a Gaussian no rank saw would
+                # count `world` times and N ranks would not equal one rank accumulating N views per step.  Ranks > 0
+                # therefore start from zeros and take the "later view" branch (visible Gaussians only).
+                self.xys_grad_norm, self.vis_counts = torch.zeros(n, **f32), torch.zeros(n, **f32)
+                self.max_2Dsize = torch.zeros(n, **f32)
+                first = False
+            else:
+                self.xys_grad_norm, self.vis_counts = torch.empty(n, **f32), torch.empty(n, **f32)
+                self.max_2Dsize = torch.empty(n, **f32)
         L.check(L.load().sgn_densify_stats(n, L.ptr(g), L.ptr(r), float(max(last_size[0], last_size[1])), int(first),
                                            L.ptr(self.xys_grad_norm), L.ptr(self.vis_counts), L.ptr(self.max_2Dsize),
                                            L.stream_ptr()), "sgn_densify_stats")
+
+    def _is_follower_rank(self) -> bool:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_rank() > 0
 
     def sync(self, group=None) -> None:
         from .dp import sync_densify_stats
@@ -76,6 +90,23 @@ class DensifyConfig:
     num_train_data: int = 0
 
 
+def _mix64(x: torch.Tensor) -> torch.Tensor:
+    """splitmix64 finaliser on int64 tensors (two's-complement wrap-around = arithmetic modulo 2^64; the logical right
+    shifts are arithmetic shifts with the sign-extension masked off)."""
+    x = x * -7046029254386353131                                             # 0x9E3779B97F4A7C15
+    x = (x ^ ((x >> 30) & 0x3FFFFFFFF)) * -4658895280553007687                # 0xBF58476D1CE4E5B9
+    x = (x ^ ((x >> 27) & 0x1FFFFFFFFF)) * -7723592293110705685               # 0x94D049BB133111EB
+    return x ^ ((x >> 31) & 0x1FFFFFFFF)
+
+
+def _hash_normal(base: torch.Tensor, component: int) -> torch.Tensor:
+    """Standard normal deviates from a counter-based hash (Box-Muller on two 53-bit uniforms), float32."""
+    import math
+    u1 = ((_mix64(base + (2 * component + 1)) >> 11) & 0x1FFFFFFFFFFFFF).to(torch.float64) / float(1 << 53)
+    u2 = ((_mix64(base + (2 * component + 2)) >> 11) & 0x1FFFFFFFFFFFFF).to(torch.float64) / float(1 << 53)
+    return (torch.sqrt(-2.0 * torch.log(u1 + 2.0 ** -54)) * torch.cos(2.0 * math.pi * u2)).to(torch.float32)
+
+
 class Densifier:
     """``SplatfactoModel.refinement_after`` / ``split_gaussians`` / ``dup_gaussians`` / ``cull_gaussians`` and the
     optimiser-state surgery ``dup_in_optim`` / ``remove_from_optim`` (``street_gaussians_ns/sgn_splatfacto.py:459-511,
@@ -95,9 +126,24 @@ class Densifier:
     """
 
     def __init__(self, params: Dict[str, torch.Tensor], optimizers: Dict[str, torch.optim.Optimizer],
-                 config: DensifyConfig = DensifyConfig(), seed: int = 0, group=None, stats: Optional[Stats] = None):
+                 config: DensifyConfig = DensifyConfig(), seed: int = 0, group=None, stats: Optional[Stats] = None,
+                 rng_device=None, split_noise: str = "stream"):
         assert set(params) == set(PARAM_NAMES) and set(optimizers) >= set(PARAM_NAMES)
+        assert split_noise in ("stream", "hashed")
+        # "stream" (default) draws the split offsets as the reference does: ONE torch.randn((n_splits * samps, 3)) —
+        # which Gaussian gets which sample then depends on every other Gaussian's split decision.  "hashed" gives
+        # every Gaussian a persistent 62-bit id (children derive theirs from the parent's) and draws its offsets from
+        # a counter-based hash of (seed, step, id, sample): a Gaussian's samples no longer depend on the rest of the
+        # set, so two runs whose threshold decisions differ for a handful of Gaussians stay comparable sample by sample
+        # (trajectory comparisons across devices / world sizes).
+        self.split_noise = split_noise
+        self.ids = torch.arange(next(iter(params.values())).shape[0], dtype=torch.int64,
+                                device=next(iter(params.values())).device)
         self.params, self.optimizers, self.cfg, self.seed, self.group = params, optimizers, config, seed, group
+        # where the split samples are drawn: None = on the parameters' device (the reference's `torch.randn(...,
+        # device=self.device)`); "cpu" = on the host and copied over — the same numbers on any device, for
+        # trajectory comparisons between a GPU run and a CPU run
+        self.rng_device = rng_device
         self.stats = stats if stats is not None else Stats()
         self.last_size = (1, 1)
         self.record: Dict[str, float] = {}
@@ -137,9 +183,19 @@ class Densifier:
         P = self.params
         n_splits = int(mask.sum().item())
         dev = P["means"].device
-        gen = torch.Generator(device=dev)
-        gen.manual_seed((self.seed * 1_000_003 + step) & 0x7FFFFFFFFFFFFFFF)
-        centered = torch.randn((samps * n_splits, 3), device=dev, generator=gen)
+        rdev = dev if self.rng_device is None else torch.device(self.rng_device)
+        if self.split_noise == "hashed":
+            pid = self.ids[mask].to(rdev)                                             # [n_splits]
+            k = torch.arange(samps, dtype=torch.int64, device=rdev)[:, None]           # sample-major, like .repeat(samps, 1)
+            base = _mix64(_mix64(pid[None, :] * 8 + k) ^ (self.seed * 1_000_003 + step))
+            centered = torch.stack([_hash_normal(base, c) for c in range(3)], dim=-1).reshape(samps * n_splits, 3)
+            centered = centered.to(dev)
+            self._child_ids = (base.reshape(-1) & 0x3FFFFFFFFFFFFFFF).to(dev)
+        else:
+            gen = torch.Generator(device=rdev)
+            gen.manual_seed((self.seed * 1_000_003 + step) & 0x7FFFFFFFFFFFFFFF)
+            centered = torch.randn((samps * n_splits, 3), device=rdev, generator=gen).to(dev)
+            self._child_ids = torch.zeros(samps * n_splits, dtype=torch.int64, device=dev)
         scaled = torch.exp(P["log_scales"][mask].repeat(samps, 1)) * centered
         q = P["quats"][mask] / P["quats"][mask].norm(dim=-1, keepdim=True)
         from .ops import quat_to_rotmat
@@ -169,6 +225,7 @@ class Densifier:
         keep = ~culls
         for name in PARAM_NAMES:
             self._rebind(name, self._leaf_like(P[name], P[name].detach()[keep]), lambda t: t[keep])
+        self.ids = self.ids[keep]
         return culls
 
     # ------------------------------------------------------------------------------------------- refinement_after
@@ -205,6 +262,8 @@ class Densifier:
                 pad = n_split_new + n_dup
                 self._rebind(name, self._leaf_like(old, cat),
                              lambda t: torch.cat([t, t.new_zeros((pad,) + tuple(t.shape[1:]))], dim=0))
+            dup_ids = _mix64(self.ids[dups] * 8 + 7 + step) & 0x3FFFFFFFFFFFFFFF
+            self.ids = torch.cat([self.ids, self._child_ids, dup_ids])
             S.max_2Dsize = torch.cat([S.max_2Dsize, S.max_2Dsize.new_zeros(n_split_new + n_dup)], dim=0)
             splits_mask = torch.cat([splits, splits.new_zeros(n_split_new + n_dup)])
             deleted = self._cull(step, splits_mask)      # the split originals go, plus the usual culls
