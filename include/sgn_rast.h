@@ -287,13 +287,39 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    const int32_t *tile_order /*NULL, or sgn_tile_order's permutation of the tiles: launch order*/,
                    int32_t *tile_stats /*NULL, or [tiles,2] out: deepest list position composited by any pixel of the tile;
                                          number of (entry, quadrant) pairs evaluated*/,
+                   const float *depths /*NULL, or [n] (the projection's depths): also accumulate the DEPTH CHANNEL
+                                         out_depth[p] = sum_g depths[g] * alpha_g * T_g — what the reference obtains from a
+                                         second rasterization of depths.repeat(1, 3) with a zero background
+                                         (sgn_splatfacto.py:982-994), for one fma per evaluated pair; not with window = 1*/,
+                   float *out_depth /*[H,W]; with depths*/,
+                   const int32_t *skip_flag /*NULL, or a device int: when it reads 0 every kernel of this call returns at
+                                              once (the caller answers the pass with sgn_depth_reuse); needs
+                                              rows_built = 1 in gather mode*/,
                    const sgn_raster_opts *opts, sgn_stream_t stream);
 /* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built
  * while the host waits for the intersection count (keeps the GPU busy across that sync).  Pre-built rows are used by
  * sgn_raster_fwd when opts->gather != 0 (pass rows_built = 1); in stream mode it re-packs them itself. */
 int sgn_raster_build_rows(int n, const float *xys, const float *conics, const float *colors, const float *opacities,
                           int opacity_is_logit, int id_lo, int id_hi, int window, void *recs_ws, size_t recs_ws_bytes,
-                          sgn_stream_t stream);
+                          const int32_t *skip_flag /*as in sgn_raster_fwd*/, sgn_stream_t stream);
+
+/* Answering the reference's depth pass from the first pass's depth channel, without a host sync (no upstream
+ * counterpart).  The second rasterize_gaussians call of a step (sgn_splatfacto.py:982-994) has the first call's
+ * geometry and `depths[:, None].repeat(1, 3)` as colours.  sgn_colors_match_depths sets *flag = 0 iff colors[i, c] ==
+ * depths[i] bit for bit for all i, c (1 otherwise); the caller queues the ordinary forward with skip_flag = flag and
+ * then sgn_depth_reuse, which — iff *flag == 0 — writes out_img[p, c] = fma(final_T[p], background[c], depth[p])
+ * (the very expression the rasterization ends with) and copies the first pass's final_Ts / final_idx into the second
+ * pass's own buffers (its backward reads them).  flag == NULL: unconditional (a caller that can PROVE the colours are
+ * the depths on the host — e.g. on the autograd graph — skips the comparison and the conditional forward altogether);
+ * final_Ts == final_idx == NULL: no copies (the caller lets the second pass share the first pass's buffers).
+ * Bit-equal to the two-pass result in exact-exp mode. */
+int sgn_colors_match_depths(int n, const float *colors /*[n,3]*/, const float *depths /*[n]*/, int32_t *flag,
+                            sgn_stream_t stream);
+int sgn_depth_reuse(int img_h, int img_w, const int32_t *flag, const float *depth_channel /*[H,W]*/,
+                    const float *final_Ts_first, const int32_t *final_idx_first, const float *background3,
+                    float *out_img /*[H,W,3]*/, float *final_Ts, int32_t *final_idx,
+                    int n_stats /*0, or 2 * tiles: also copy the first pass's tile statistics*/,
+                    const int32_t *tile_stats_first, int32_t *tile_stats, sgn_stream_t stream);
 
 /* _C.rasterize_backward.  alpha_clamp_bwd: 0.99f reproduces gsplat 0.1.x (which clamps at
  * 0.999 in forward and 0.99 in backward).  Outputs are fully written (zero-filled first).

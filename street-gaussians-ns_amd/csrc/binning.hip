@@ -7,6 +7,8 @@
 // Integer work: results are bit-exact with the oracle by construction.
 #include "sgn_common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int SCAN_THREADS = 256;
@@ -92,6 +94,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_partials_kernel(int nb, int
     }
 }
 
+// SCANNED = true: `partial` holds the exclusive scan of the chunk totals (scan_partials_kernel ran).  SCANNED = false
+// (r03: one launch less per binning): `partial` holds the raw chunk totals and every workgroup sums the ones before
+// its own itself — at most a few hundred 4-byte values per workgroup (489 chunks at 1 M items), all requested with
+// the workgroup's own items, against a launch of its own (~5 us + the dependency bubble) for one workgroup's scan.
+template <bool SCANNED>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(int n, const int32_t *__restrict__ in,
                                                                   const int32_t *__restrict__ partial,
                                                                   int32_t *__restrict__ out) {
@@ -99,14 +106,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(int n, const i
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
     int s = 0;
+    int before = 0;
+    if constexpr (!SCANNED) {
+        for (int j = threadIdx.x; j < (int)blockIdx.x; j += SCAN_THREADS) before += partial[j];
+    }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         v[k] = (base + k < n) ? in[base + k] : 0;
         s += v[k];
     }
     int total;
+    int chunk_base;
+    if constexpr (SCANNED) {
+        chunk_base = partial[blockIdx.x];
+    } else {
+        block_incl_scan(before, lds4, chunk_base);          // total over the block = sum of the earlier chunks
+    }
     const int inc = block_incl_scan(s, lds4, total);
-    int run = partial[blockIdx.x] + inc - s;
+    int run = chunk_base + inc - s;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         run += v[k];
@@ -487,17 +504,114 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
     }
 }
 
-// sorted tile ids -> tile_bins.  A thread takes the 16 bytes of keys at 16 * idx (8 sixteen-bit or 4 thirty-two-bit
-// ids: one vector load) plus the key before them and writes the boundaries it sees (one key per thread with two
-// scalar loads each took 12.9 us for the 8.3 M pairs of the benchmark scene).  `tkeys` is 16-byte aligned
-// (workspace carve-outs are 256-byte aligned).
+// ---- launch-order helpers (tile_order_kernel further down)
+__device__ __forceinline__ int len_bucket(int len) {
+    if (len <= 0) return 0;
+    const int e = 31 - __clz(len);
+    const int half = e > 0 ? (len >> (e - 1)) & 1 : 0;
+    return min(63, 1 + 2 * e + half);
+}
+// length of tile t for the ordering: its depth-list length, or (forward statistics given) its reverse-walk length.
+// A tile of SMALL splats - fewer than small_q16 / 16 evaluated (entry, quadrant) pairs per walked entry, i.e. most
+// Gaussians touch a single 8x8 quadrant - is promoted to the long class whatever its length: four waves per tile then
+// cost no extra gradient reductions and quadruple the parallelism (street scene: 0.56 vs 0.68 ms).
+__device__ __forceinline__ int order_len(int t, const int2 *__restrict__ bins, const int32_t *__restrict__ stats,
+                                         int long_thresh, int small_q16) {
+    const int2 r = bins[t];
+    const int len = r.y - r.x;
+    if (stats == nullptr || len <= 0) return len;
+    const int walk = min(len, max(0, stats[2 * t] - r.x + 1));
+    if (small_q16 > 0 && long_thresh > 0 && walk >= 32 && walk < long_thresh && stats[2 * t + 1] * 16 < walk * small_q16)
+        return long_thresh;
+    return walk;
+}
+// wave-aggregated LDS counter: lanes with the same bucket are served by ONE atomic (all tiles of a uniform scene fall
+// in one length class: 64 lanes hammering one LDS address serialise, measured 65 us per pass before this)
+__device__ __forceinline__ int bucket_slot(int *counters, int bucket, bool active) {
+    int slot = 0;
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        const int b = __shfl(bucket, src, 64);
+        const unsigned long long same = __ballot(active && bucket == b);
+        int base = 0;
+        if (lane == src) base = atomicAdd(&counters[b], __popcll(same));
+        base = __shfl(base, src, 64);
+        if (active && bucket == b) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return slot;
+}
+
+// Counting sort of the tiles into half-octave length classes, longest class first, WITHOUT LDS atomics: every thread
+// holds the classes of its ROUNDS tiles (tile = round * blockDim + thread) in registers; per class present in the wave
+// one ballot per round counts / ranks its tiles (popcount, v_mbcnt), the waves' counts meet in LDS once.  (The r02 form
+// did one wave-aggregated LDS atomic per round and class: ~80 dependent LDS round trips per wave in a 256-thread
+// workgroup; this form is ALU-only inside the rounds: 15 -> ~5 us per launch for 9600 tiles, two launches per step.)  order[0..n_tiles) = the permutation,
+// order[n_tiles] = number of tiles whose class reaches long_thresh's, order[n_tiles + 1] = 0.  Tiles beyond
+// ROUNDS * blockDim are not covered: callers fall back for larger grids.
+template <int ROUNDS>
+__device__ __forceinline__ void order_by_class(const signed char (&bucket)[ROUNDS], int n_tiles, int long_thresh,
+                                               int32_t *__restrict__ order, int (*wave_cnt)[64], int *start) {
+    const int nthr = blockDim.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = nthr >> 6;
+    unsigned long long present = 0ull;
+#pragma unroll
+    for (int i = 0; i < ROUNDS; ++i)
+        if (bucket[i] >= 0) present |= 1ull << bucket[i];
+    uint32_t plo = (uint32_t)present, phi = (uint32_t)(present >> 32);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        plo |= (uint32_t)__shfl_xor((int)plo, d, 64);
+        phi |= (uint32_t)__shfl_xor((int)phi, d, 64);
+    }
+    present = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)phi) << 32) |
+              (uint32_t)__builtin_amdgcn_readfirstlane((int)plo);
+    wave_cnt[wave][lane] = 0;
+    for (unsigned long long todo = present; todo; todo &= todo - 1) {        // wave-uniform
+        const int b = __ffsll((long long)todo) - 1;
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i)
+            if (i * nthr < n_tiles) c += __popcll(__ballot(bucket[i] == b));
+        if (lane == 0) wave_cnt[wave][b] = c;
+    }
+    __syncthreads();
+    if (wave == 0) {           // start[b] = tiles in classes above b (longest class first)
+        int tot = 0;
+        for (int w = 0; w < nw; ++w) tot += wave_cnt[w][lane];
+        int above = tot;       // inclusive suffix sum over lanes >= mine, then exclusive
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_down(above, d, 64);
+            if (lane + d < 64) above += u;
+        }
+        start[lane] = above - tot;
+        const int b_long = long_thresh > 0 ? len_bucket(long_thresh) : 64;
+        if (lane == min(b_long, 63)) order[n_tiles] = b_long < 64 ? above : 0;
+        if (lane == 0) order[n_tiles + 1] = 0;
+    }
+    __syncthreads();
+    for (unsigned long long todo = present; todo; todo &= todo - 1) {
+        const int b = __ffsll((long long)todo) - 1;
+        int base = start[b];
+        for (int w = 0; w < wave; ++w) base += wave_cnt[w][b];
+#pragma unroll
+        for (int i = 0; i < ROUNDS; ++i) {
+            if (i * nthr >= n_tiles) continue;
+            const bool mine = bucket[i] == b;
+            const unsigned long long m = __ballot(mine);
+            if (mine) order[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] =
+                          i * nthr + threadIdx.x;
+            base += __popcll(m);
+        }
+    }
+}
+
 template <typename TK>
-__global__ __launch_bounds__(256) void tile_bins32_kernel(int64_t n_isect, const TK *__restrict__ tkeys,
-                                                          int32_t *__restrict__ bins,
-                                                          const int32_t *__restrict__ n_dev) {
+__device__ __forceinline__ void tile_bins32_body(int64_t n_isect, const TK *__restrict__ tkeys,
+                                                 int32_t *__restrict__ bins, int64_t i0) {
     constexpr int KPT = 16 / (int)sizeof(TK);
-    if (n_dev) n_isect = min(n_isect, (int64_t)max(*n_dev, 0));   // speculative launch: n_isect is the capacity
-    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * KPT;
     if (i0 >= n_isect) return;
     TK k[KPT];
     if (i0 + KPT <= n_isect) {
@@ -523,6 +637,19 @@ __global__ __launch_bounds__(256) void tile_bins32_kernel(int64_t n_isect, const
     }
 }
 
+// sorted tile ids -> tile_bins.  A thread takes the 16 bytes of keys at 16 * idx (8 sixteen-bit or 4 thirty-two-bit
+// ids: one vector load) plus the key before them and writes the boundaries it sees (one key per thread with two
+// scalar loads each took 12.9 us for the 8.3 M pairs of the benchmark scene).  `tkeys` is 16-byte aligned
+// (workspace carve-outs are 256-byte aligned).
+template <typename TK>
+__global__ __launch_bounds__(256) void tile_bins32_kernel(int64_t n_isect, const TK *__restrict__ tkeys,
+                                                          int32_t *__restrict__ bins,
+                                                          const int32_t *__restrict__ n_dev) {
+    constexpr int KPT = 16 / (int)sizeof(TK);
+    if (n_dev) n_isect = min(n_isect, (int64_t)max(*n_dev, 0));   // speculative launch: n_isect is the capacity
+    tile_bins32_body<TK>(n_isect, tkeys, bins, ((int64_t)blockIdx.x * 256 + threadIdx.x) * KPT);
+}
+
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 inline int bit_length(uint32_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; }
 
@@ -540,8 +667,14 @@ static int scan_launch(int n, const int32_t *in, const int32_t *idx, int32_t *ga
     sgn_timing_begin(SGN_T_SCAN, s);
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, n, in, idx, idx ? gathered : nullptr,
                        partial);
-    hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, partial);
-    hipLaunchKernelGGL(scan_final_kernel, dim3(nb), dim3(SCAN_THREADS), 0, s, n, idx ? gathered : in, partial, out);
+    if (nb <= 4096) {       // every workgroup adds up the chunk totals before its own (<= 16 KB of reads each)
+        hipLaunchKernelGGL(scan_final_kernel<false>, dim3(nb), dim3(SCAN_THREADS), 0, s, n, idx ? gathered : in, partial,
+                           out);
+    } else {
+        hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, partial);
+        hipLaunchKernelGGL(scan_final_kernel<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, n, idx ? gathered : in, partial,
+                           out);
+    }
     sgn_timing_end(SGN_T_SCAN, s);
     SGN_LAUNCH_CHECK();
     return 0;
@@ -769,63 +902,30 @@ SGN_EXPORT int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *
 // their tile index comes up and the kernel ends with a tail of lone waves.  A counting sort into half-octave length
 // classes (64 buckets) is all the ordering this needs; one workgroup, ~5 us for 9600 tiles.
 namespace {
-__device__ __forceinline__ int len_bucket(int len) {
-    if (len <= 0) return 0;
-    const int e = 31 - __clz(len);
-    const int half = e > 0 ? (len >> (e - 1)) & 1 : 0;
-    return min(63, 1 + 2 * e + half);
-}
-// length of tile t for the ordering: its depth-list length, or (forward statistics given) its reverse-walk length.
-// A tile of SMALL splats - fewer than small_q16 / 16 evaluated (entry, quadrant) pairs per walked entry, i.e. most
-// Gaussians touch a single 8x8 quadrant - is promoted to the long class whatever its length: four waves per tile then
-// cost no extra gradient reductions and quadruple the parallelism (street scene: 0.56 vs 0.68 ms).
-__device__ __forceinline__ int order_len(int t, const int2 *__restrict__ bins, const int32_t *__restrict__ stats,
-                                         int long_thresh, int small_q16) {
-    const int2 r = bins[t];
-    const int len = r.y - r.x;
-    if (stats == nullptr || len <= 0) return len;
-    const int walk = min(len, max(0, stats[2 * t] - r.x + 1));
-    if (small_q16 > 0 && long_thresh > 0 && walk >= 32 && walk < long_thresh && stats[2 * t + 1] * 16 < walk * small_q16)
-        return long_thresh;
-    return walk;
-}
-// wave-aggregated LDS counter: lanes with the same bucket are served by ONE atomic (all tiles of a uniform scene fall
-// in one length class: 64 lanes hammering one LDS address serialise, measured 65 us per pass before this)
-__device__ __forceinline__ int bucket_slot(int *counters, int bucket, bool active) {
-    int slot = 0;
-    unsigned long long todo = __ballot(active);
-    const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        const int b = __shfl(bucket, src, 64);
-        const unsigned long long same = __ballot(active && bucket == b);
-        int base = 0;
-        if (lane == src) base = atomicAdd(&counters[b], __popcll(same));
-        base = __shfl(base, src, 64);
-        if (active && bucket == b) slot = base + __popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
-    }
-    return slot;
-}
 constexpr int ORDER_PER_THREAD = 16;   // tiles per thread kept in registers (one workgroup covers 16384 tiles)
 __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int2 *__restrict__ bins,
                                                           const int32_t *__restrict__ kmax, int long_thresh,
                                                           int small_q16, int32_t *__restrict__ order) {
-    __shared__ int hist[64], start[64];
-    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+    __shared__ int wave_cnt[16][64], start[64];
     // every load of the thread is issued before the first use: as a plain loop this kernel was a chain of ~20 dependent
     // global round trips (16 us for 9600 tiles)
-    int bucket[ORDER_PER_THREAD];
+    signed char bucket[ORDER_PER_THREAD];
 #pragma unroll
     for (int i = 0; i < ORDER_PER_THREAD; ++i) {
         const int t = i * 1024 + threadIdx.x;
-        bucket[i] = t < n_tiles ? len_bucket(order_len(t, bins, kmax, long_thresh, small_q16)) : -1;
+        bucket[i] = (signed char)(t < n_tiles ? len_bucket(order_len(t, bins, kmax, long_thresh, small_q16)) : -1);
     }
+    order_by_class<ORDER_PER_THREAD>(bucket, min(n_tiles, ORDER_PER_THREAD * 1024), long_thresh, order, wave_cnt, start);
+}
+
+// images with more than 16384 tiles: the r02 form (wave-aggregated LDS counters, any tile count)
+__global__ __launch_bounds__(1024) void tile_order_big_kernel(int n_tiles, const int2 *__restrict__ bins,
+                                                              const int32_t *__restrict__ kmax, int long_thresh,
+                                                              int small_q16, int32_t *__restrict__ order) {
+    __shared__ int hist[64], start[64];
+    if (threadIdx.x < 64) hist[threadIdx.x] = 0;
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < ORDER_PER_THREAD; ++i)
-        if (i * 1024 < n_tiles) bucket_slot(hist, max(bucket[i], 0), bucket[i] >= 0);
-    for (int t0 = ORDER_PER_THREAD * 1024; t0 < n_tiles; t0 += 1024) {      // images with more than 16384 tiles
+    for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
         const int t = t0 + threadIdx.x;
         bucket_slot(hist, t < n_tiles ? len_bucket(order_len(t, bins, kmax, long_thresh, small_q16)) : 0, t < n_tiles);
     }
@@ -839,16 +939,10 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int
             if (b >= b_long) n_long = run;       // classes >= the threshold's class form a prefix of the order
         }
         order[n_tiles] = n_long;
-        order[n_tiles + 1] = 0;              // work cursor of the backward's persistent long-walk kernel
+        order[n_tiles + 1] = 0;
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < ORDER_PER_THREAD; ++i) {
-        if (i * 1024 >= n_tiles) continue;
-        const int slot = bucket_slot(start, max(bucket[i], 0), bucket[i] >= 0);
-        if (bucket[i] >= 0) order[slot] = i * 1024 + threadIdx.x;
-    }
-    for (int t0 = ORDER_PER_THREAD * 1024; t0 < n_tiles; t0 += 1024) {
+    for (int t0 = 0; t0 < n_tiles; t0 += 1024) {
         const int t = t0 + threadIdx.x;
         const bool act = t < n_tiles;
         const int slot = bucket_slot(start, act ? len_bucket(order_len(t, bins, kmax, long_thresh, small_q16)) : 0, act);
@@ -860,8 +954,12 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int
 SGN_EXPORT int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_stats, int long_thresh,
                               int small_q16, int32_t *order, sgn_stream_t stream) {
     SGN_ARG_CHECK(n_tiles > 0 && tile_bins && order, -1);
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,
-                       (const int2 *)tile_bins, tile_stats, long_thresh, small_q16, order);
+    if (n_tiles <= ORDER_PER_THREAD * 1024)
+        hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,
+                           (const int2 *)tile_bins, tile_stats, long_thresh, small_q16, order);
+    else
+        hipLaunchKernelGGL(tile_order_big_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,
+                           (const int2 *)tile_bins, tile_stats, long_thresh, small_q16, order);
     SGN_LAUNCH_CHECK();
     return 0;
 }

@@ -73,7 +73,9 @@ __global__ __launch_bounds__(256) void build_grec_kernel(int n, const float *__r
                                                          const float *__restrict__ colors,
                                                          const float *__restrict__ opac, int opac_is_logit,
                                                          int id_lo, int id_hi, int window,
-                                                         float4 *__restrict__ grec) {
+                                                         float4 *__restrict__ grec,
+                                                         const int32_t *__restrict__ skip_flag) {
+    if (skip_flag != nullptr && *skip_flag == 0) return;   // this pass's result is reused (sgn_depth_reuse): no rows
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= n) return;
     // window != 0: the four input arrays hold rows [id_lo, id_hi) only (a sub-model's own tensors), row g - id_lo
@@ -180,13 +182,21 @@ __device__ __forceinline__ unsigned row_quadrants(float gx, float gy, float ex, 
 // shorter critical path per tile: for scenes whose longest depth lists dominate the kernel's tail).
 // ADAPT (with QPW = 4, grid = 4 waves per tile): a tile whose depth list is shorter than `adapt_thresh` is
 // done by its wave 0 alone (the other three exit at once); a longer one is split, one quadrant per wave.
-template <bool EXACT, bool GATHER, int QPW, bool ADAPT>
+// DEPTH (r03): a FOURTH accumulated channel, D = sum depth_g * vis — the image the reference gets from a whole second
+// rasterization of `depths.repeat(1, 3)` (sgn_splatfacto.py:982-994) — for one more fma per evaluated pair.  The
+// per-Gaussian depth is not part of the 48-byte row: it comes from `depths[id]` with one more scalar load next to the
+// row's (scalar-chase path) or rides in a 64-float side array of the LDS stage (batched path); same operation order
+// as the colour channels, so in exact-exp mode D is bit-equal to channel 0 of the two-pass result.
+template <bool EXACT, bool GATHER, int QPW, bool ADAPT, bool DEPTH>
 __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, int B, int tiles_x,
                                                 const int2 *__restrict__ bins, const Rec *__restrict__ recs,
                                                 const int32_t *__restrict__ ids, const float *__restrict__ bg,
                                                 float *__restrict__ out_img, float *__restrict__ final_T,
                                                 int32_t *__restrict__ final_idx, int adapt_thresh, int batch_thresh,
-                                                int32_t *__restrict__ tile_kmax, float4 (*stage)[64 * 3]) {
+                                                int32_t *__restrict__ tile_kmax, float4 (*stage)[64 * 3],
+                                                const float *__restrict__ depths = nullptr,
+                                                float *__restrict__ out_depth = nullptr,
+                                                float (*stage_d)[64] = nullptr) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
@@ -202,7 +212,7 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
 
     // Per-pixel state; "this pixel is finished (or outside the image)" is carried in the SIGN of T
     // (T > 0 <=> still compositing), so liveness costs one v_cmp and no mask bookkeeping in VGPRs.
-    float px[QPW], py[QPW], T[QPW], C0[QPW], C1[QPW], C2[QPW];
+    float px[QPW], py[QPW], T[QPW], C0[QPW], C1[QPW], C2[QPW], Dq[DEPTH ? QPW : 1];
     int last[QPW], pix[QPW];
     bool inside[QPW];
 #pragma unroll
@@ -217,6 +227,7 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
         py[q] = (float)i + 0.5f;
         T[q] = inside[q] ? 1.f : -1.f;
         C0[q] = 0.f; C1[q] = 0.f; C2[q] = 0.f;
+        if constexpr (DEPTH) Dq[q] = 0.f;
         last[q] = 0;
     }
 
@@ -226,7 +237,7 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
 
     // one depth-list entry for this wave's pixels; returns false once every pixel of the wave is finished
     int n_eval = 0;   // (entry, quadrant) pairs this wave evaluated (wave-uniform): the backward's size-of-splat hint
-    auto entry = [&](const Rec &cur, int k, unsigned qm) __attribute__((always_inline)) -> bool {
+    auto entry = [&](const Rec &cur, int k, unsigned qm, float dep) __attribute__((always_inline)) -> bool {
         unsigned long long live[QPW], any_live = 0ull;
 #pragma unroll
         for (int q = 0; q < QPW; ++q) {
@@ -252,6 +263,7 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
             C0[q] = fmaf(cur.r, vis, C0[q]);
             C1[q] = fmaf(cur.g, vis, C1[q]);
             C2[q] = fmaf(cur.bl, vis, C2[q]);
+            if constexpr (DEPTH) Dq[q] = fmaf(dep, vis, Dq[q]);
             last[q] = acc ? k : last[q];
             const float Tk = acc ? nT : T[q];
             T[q] = stop ? -Tk : Tk;  // terminating Gaussian is NOT composited; T keeps its last value
@@ -262,14 +274,20 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
     const int L = range.y - range.x;
     if (L > 0 && L < batch_thresh) {
         // short list: chase ids -> rows with scalar loads, one entry ahead (operands arrive in SGPRs)
-        Rec cur = recs[GATHER ? ids[range.x] : range.x];
+        const int id0 = GATHER ? ids[range.x] : range.x;
+        Rec cur = recs[id0];
+        float dcur = 0.f;
+        if constexpr (DEPTH) dcur = depths[GATHER ? id0 : cur.gid];
         int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
         for (int k = range.x; k < range.y; ++k) {
             const int kn = (k + 1 < range.y) ? k + 1 : k;
             const Rec nxt = recs[GATHER ? idn : kn];  // scalar prefetch of the next record
+            float dnxt = 0.f;
+            if constexpr (DEPTH) dnxt = depths[GATHER ? idn : nxt.gid];
             if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
-            if (!entry(cur, k, quadrant_mask(cur, qcx, qcy, qtest))) break;
+            if (!entry(cur, k, quadrant_mask(cur, qcx, qcy, qtest), dcur)) break;
             cur = nxt;
+            dcur = dnxt;
         }
     } else if (L > 0) {
         // long list: the one-entry scalar look-ahead leaves a lone wave latency-bound (a dependent id -> row
@@ -277,11 +295,14 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
         // row ids[k0+l] with vector loads a whole batch ahead, entries are then read back with broadcast
         // ds_read_b128 (no barrier: the workgroup is this one wave and its LDS ops retire in order).
         const int nb = (L + 63) >> 6;
+        float rd = 0.f;      // DEPTH: the depth of this lane's row of the batch in flight
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = range.x + (bidx << 6) + lane;
             if (k < range.y) {
-                const float4 *p = reinterpret_cast<const float4 *>(recs + (GATHER ? ids[k] : k));
+                const int id = GATHER ? ids[k] : k;
+                const float4 *p = reinterpret_cast<const float4 *>(recs + id);
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
+                if constexpr (DEPTH) rd = depths[GATHER ? id : __float_as_int(r2.y)];
             }
         };
         // this wave's quadrants as a bit mask (all four, or the single one of a split tile)
@@ -292,6 +313,7 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
+        if constexpr (DEPTH) stage_d[0][lane] = rd;
         unsigned qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
         bool go = true;
         for (int bi = 0; bi < nb && go; ++bi) {
@@ -309,11 +331,14 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
                 cur.b = a1.x; cur.hc = a1.y; cur.r = a1.z; cur.g = a1.w;
                 cur.bl = a2.x; cur.gid = __float_as_int(a2.y); cur.ex = a2.z; cur.ey = a2.w;
                 const unsigned qm = (unsigned)__builtin_amdgcn_readlane((int)qcur, j);
-                if (!entry(cur, range.x + (bi << 6) + j, qm)) { go = false; break; }
+                float dep = 0.f;
+                if constexpr (DEPTH) dep = stage_d[bi & 1][j];
+                if (!entry(cur, range.x + (bi << 6) + j, qm, dep)) { go = false; break; }
             }
             if (go && bi + 1 < nb) {                      // first use of the prefetched registers
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
+                if constexpr (DEPTH) stage_d[(bi + 1) & 1][lane] = rd;
                 qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
             }
         }
@@ -336,11 +361,12 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
             out_img[3 * pix[q] + 0] = fmaf(Tq, bg0, C0[q]);
             out_img[3 * pix[q] + 1] = fmaf(Tq, bg1, C1[q]);
             out_img[3 * pix[q] + 2] = fmaf(Tq, bg2, C2[q]);
+            if constexpr (DEPTH) out_depth[pix[q]] = Dq[q];
         }
     }
 }
 
-template <bool EXACT, bool GATHER, int QPW, bool ADAPT>
+template <bool EXACT, bool GATHER, int QPW, bool ADAPT, bool DEPTH>
 __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int tiles_x,
                                                         const int2 *__restrict__ bins,
                                                         const Rec *__restrict__ recs,
@@ -349,7 +375,11 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
                                                         float *__restrict__ final_T,
                                                         int32_t *__restrict__ final_idx, int adapt_thresh, int swz,
                                                         int batch_thresh, const int32_t *__restrict__ tile_order,
-                                                        int32_t *__restrict__ tile_kmax) {
+                                                        int32_t *__restrict__ tile_kmax,
+                                                        const float *__restrict__ depths,
+                                                        float *__restrict__ out_depth,
+                                                        const int32_t *__restrict__ skip_flag) {
+    if (skip_flag != nullptr && *skip_flag == 0) return;   // the caller already holds this pass's result (sgn_depth_reuse)
     constexpr int WPT = ADAPT ? 4 : 4 / QPW;   // waves launched per tile
     // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile) so the waves that do the
     // work of un-split tiles are spread over all 8 XCDs (block b runs on XCD b % 8), not on every 4th block.
@@ -358,8 +388,10 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
     if (tile_order) tile = tile_order[tile];   // longest depth lists first (sgn_tile_order): no long tile starts late
     const int wv = ADAPT ? (int)(blockIdx.x / n_tiles_) : (int)(blockIdx.x % WPT);
     __shared__ float4 stage[2][64 * 3];         // 64-entry batches of the long-list path (wave-private)
-    raster_fwd_tile<EXACT, GATHER, QPW, ADAPT>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, out_img, final_T,
-                                                final_idx, adapt_thresh, batch_thresh, tile_kmax, stage);
+    __shared__ float stage_d[DEPTH ? 2 : 1][64];
+    raster_fwd_tile<EXACT, GATHER, QPW, ADAPT, DEPTH>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, out_img, final_T,
+                                                       final_idx, adapt_thresh, batch_thresh, tile_kmax, stage, depths,
+                                                       out_depth, stage_d);
 }
 
 // ---------------------------------------------------------------- forward, packed-FP32 form (16x16 tiles)
@@ -390,7 +422,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat2(float v) { return v2f{v, v}; }
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <bool EXACT, bool GATHER>
+template <bool EXACT, bool GATHER, bool DEPTH>
 __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int tiles_x, int n_tiles_,
                                                            const int2 *__restrict__ bins,
                                                            const Rec *__restrict__ recs,
@@ -399,8 +431,13 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
                                                            float *__restrict__ final_T,
                                                            int32_t *__restrict__ final_idx, int swz,
                                                            int batch_thresh, const int32_t *__restrict__ tile_order,
-                                                           int32_t *__restrict__ tile_kmax) {
+                                                           int32_t *__restrict__ tile_kmax,
+                                                           const float *__restrict__ depths,
+                                                           float *__restrict__ out_depth,
+                                                           const int32_t *__restrict__ skip_flag) {
+    if (skip_flag != nullptr && *skip_flag == 0) return;   // the caller already holds this pass's result (sgn_depth_reuse)
     __shared__ float4 stage[2][64 * 3];
+    __shared__ float stage_d[DEPTH ? 2 : 1][64];
     // The first n_long tiles of the launch order (sgn_tile_order with long_thresh: the longest lists) get four waves
     // each, the others two.  Blocks come in groups of eight tiles (8 x 4, then 8 x 2 blocks): block b runs on XCD
     // b % 8, so a tile's waves share an XCD (and its L2) and are dispatched together, longest tiles first.  No block
@@ -426,8 +463,9 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
     const int2 range = bins[tile];
     const int L = range.y - range.x;
     if (is_long) {
-        raster_fwd_tile<EXACT, GATHER, 1, false>(tile, wv, W, H, 16, tiles_x, bins, recs, ids, bg, out_img, final_T,
-                                                 final_idx, 0, batch_thresh, tile_kmax, stage);
+        raster_fwd_tile<EXACT, GATHER, 1, false, DEPTH>(tile, wv, W, H, 16, tiles_x, bins, recs, ids, bg, out_img, final_T,
+                                                        final_idx, 0, batch_thresh, tile_kmax, stage, depths, out_depth,
+                                                        stage_d);
         return;
     }
     const unsigned shift_q = 2u * wv;                    // this wave's quadrants: bits shift_q, shift_q + 1
@@ -441,13 +479,13 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
     const v2f px = {(float)j0 + 0.5f, (float)j0 + 8.5f};
     const float py = (float)i0 + 0.5f;
     v2f T = {in0 ? 1.f : -1.f, in1 ? 1.f : -1.f};
-    v2f C0 = {0.f, 0.f}, C1 = C0, C2 = C0;
+    v2f C0 = {0.f, 0.f}, C1 = C0, C2 = C0, Dp = C0;
     int last0 = 0, last1 = 0;
     const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
 
     int n_eval = 0;
     // m: which of this wave's two quadrants the entry can touch (bit 0 = slot 0, bit 1 = slot 1), never 0
-    auto entry = [&](const Rec &cur, int k, unsigned m) __attribute__((always_inline)) -> bool {
+    auto entry = [&](const Rec &cur, int k, unsigned m, float dep) __attribute__((always_inline)) -> bool {
         const bool l0 = T.x > 0.f, l1 = T.y > 0.f;
         const unsigned long long b0 = __ballot(l0), b1 = __ballot(l1);
         if ((b0 | b1) == 0ull) return false;
@@ -478,6 +516,7 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
             C0 = fma2(splat2(cur.r), vis, C0);
             C1 = fma2(splat2(cur.g), vis, C1);
             C2 = fma2(splat2(cur.bl), vis, C2);
+            if constexpr (DEPTH) Dp = fma2(splat2(dep), vis, Dp);
             last0 = (ok0 && !stop0) ? k : last0;
             last1 = (ok1 && !stop1) ? k : last1;
             T = v2f{stop0 ? -T.x : nT.x, stop1 ? -T.y : nT.y};
@@ -486,28 +525,38 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
     };
 
     if (L > 0 && L < batch_thresh) {
-        Rec cur = recs[GATHER ? ids[range.x] : range.x];
+        const int id0 = GATHER ? ids[range.x] : range.x;
+        Rec cur = recs[id0];
+        float dcur = 0.f;
+        if constexpr (DEPTH) dcur = depths[GATHER ? id0 : cur.gid];
         int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
         for (int k = range.x; k < range.y; ++k) {
             const int kn = (k + 1 < range.y) ? k + 1 : k;
             const Rec nxt = recs[GATHER ? idn : kn];
+            float dnxt = 0.f;
+            if constexpr (DEPTH) dnxt = depths[GATHER ? idn : nxt.gid];
             if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
             const unsigned m = (quadrant_mask(cur, qcx, qcy, true) >> shift_q) & 3u;
-            if (m != 0u && !entry(cur, k, m)) break;
+            if (m != 0u && !entry(cur, k, m, dcur)) break;
             cur = nxt;
+            dcur = dnxt;
         }
     } else if (L > 0) {
         const int nb = (L + 63) >> 6;
+        float rd = 0.f;
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = range.x + (bidx << 6) + lane;
             if (k < range.y) {
-                const float4 *p = reinterpret_cast<const float4 *>(recs + (GATHER ? ids[k] : k));
+                const int id = GATHER ? ids[k] : k;
+                const float4 *p = reinterpret_cast<const float4 *>(recs + id);
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
+                if constexpr (DEPTH) rd = depths[GATHER ? id : __float_as_int(r2.y)];
             }
         };
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
+        if constexpr (DEPTH) stage_d[0][lane] = rd;
         unsigned qrow = (row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, true) >> shift_q) & 3u;
         bool go = true;
         for (int bi = 0; bi < nb && go; ++bi) {
@@ -525,11 +574,14 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
                 cur.b = a1.x; cur.hc = a1.y; cur.r = a1.z; cur.g = a1.w;
                 cur.bl = a2.x; cur.gid = __float_as_int(a2.y); cur.ex = a2.z; cur.ey = a2.w;
                 const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)qcur, j);
-                if (!entry(cur, range.x + (bi << 6) + j, m)) { go = false; break; }
+                float dep = 0.f;
+                if constexpr (DEPTH) dep = stage_d[bi & 1][j];
+                if (!entry(cur, range.x + (bi << 6) + j, m, dep)) { go = false; break; }
             }
             if (go && bi + 1 < nb) {
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
+                if constexpr (DEPTH) stage_d[(bi + 1) & 1][lane] = rd;
                 qrow = (row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, true) >> shift_q) & 3u;
             }
         }
@@ -547,6 +599,7 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
         out_img[3 * pix + 0] = fmaf(Tq, bg0, C0.x);
         out_img[3 * pix + 1] = fmaf(Tq, bg1, C1.x);
         out_img[3 * pix + 2] = fmaf(Tq, bg2, C2.x);
+        if constexpr (DEPTH) out_depth[pix] = Dp.x;
     }
     if (in1) {
         const float Tq = fabsf(T.y);
@@ -555,6 +608,7 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
         out_img[3 * pix + 24] = fmaf(Tq, bg0, C0.y);
         out_img[3 * pix + 25] = fmaf(Tq, bg1, C1.y);
         out_img[3 * pix + 26] = fmaf(Tq, bg2, C2.y);
+        if constexpr (DEPTH) out_depth[pix + 8] = Dp.y;
     }
 }
 
@@ -944,7 +998,7 @@ static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float 
     float4 *stream_recs = (float4 *)recs + 3 * (size_t)n; // then the optional depth-ordered stream
     sgn_timing_begin(SGN_T_PACK, s);
     hipLaunchKernelGGL(build_grec_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, conics, colors, opac,
-                       opac_is_logit, id_lo, id_hi, window, grec);
+                       opac_is_logit, id_lo, id_hi, window, grec, (const int32_t *)nullptr);
     if (!gather)
         hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(3 * n_isect, 256)), dim3(256), 0, s, n_isect, ids,
                            grec, stream_recs);
@@ -957,7 +1011,8 @@ static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float 
 // re-packed into depth order and sgn_raster_fwd builds them itself).
 SGN_EXPORT int sgn_raster_build_rows(int n, const float *xys, const float *conics, const float *colors,
                                      const float *opacities, int opacity_is_logit, int id_lo, int id_hi, int window,
-                                     void *recs_ws, size_t recs_ws_bytes, sgn_stream_t stream) {
+                                     void *recs_ws, size_t recs_ws_bytes, const int32_t *skip_flag,
+                                     sgn_stream_t stream) {
     SGN_ARG_CHECK(!window || (0 <= id_lo && id_lo <= id_hi && id_hi <= n), -4);
     SGN_ARG_CHECK(n >= 0, -1);
     if (n == 0) return 0;
@@ -966,7 +1021,7 @@ SGN_EXPORT int sgn_raster_build_rows(int n, const float *xys, const float *conic
     hipStream_t s = (hipStream_t)stream;
     sgn_timing_begin(SGN_T_PACK, s);
     hipLaunchKernelGGL(build_grec_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, conics, colors, opacities,
-                       opacity_is_logit, id_lo, id_hi, window, (float4 *)recs_ws);
+                       opacity_is_logit, id_lo, id_hi, window, (float4 *)recs_ws, skip_flag);
     sgn_timing_end(SGN_T_PACK, s);
     SGN_LAUNCH_CHECK();
     return 0;
@@ -978,8 +1033,12 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
                               int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
                               float *out_img, float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes,
                               int rows_built, const int32_t *tile_order, int32_t *tile_kmax,
+                              const float *depths, float *out_depth, const int32_t *skip_flag,
                               const sgn_raster_opts *opts, sgn_stream_t stream) {
     const sgn_raster_opts o = resolve_opts(opts);
+    SGN_ARG_CHECK((depths == nullptr) == (out_depth == nullptr), -8);
+    SGN_ARG_CHECK(skip_flag == nullptr || (rows_built && o.gather), -9);   // a skipped pass builds no rows of its own
+    SGN_ARG_CHECK(!(window && depths), -10);                               // the depth channel is a whole-scene pass
     SGN_ARG_CHECK(img_h > 0 && img_w > 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
     SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -3);
@@ -996,31 +1055,108 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     const Rec *stream_recs = rows + n;
     if (tile_kmax) SGN_HIP_CHECK(hipMemsetAsync(tile_kmax, 0, sizeof(int32_t) * 2 * tiles_x * tiles_y, s));
     sgn_timing_begin(SGN_T_RASTER_FWD, s);
-#define SGN_LAUNCH_FWD(EX, GA, Q, AD)                                                                                \
-    hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
+#define SGN_LAUNCH_FWD(EX, GA, Q, AD, DE)                                                                            \
+    hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD, DE>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
                        img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
                        gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, o.adapt_fwd, o.xcd_swizzle, o.batch_fwd,   \
-                       tile_order, tile_kmax)
-#define SGN_LAUNCH_FWD_PK(EX, GA)                                                                                    \
-    hipLaunchKernelGGL((raster_fwd_pk_kernel<EX, GA>), dim3(((tiles_x * tiles_y + 7) / 8) * 32 + 32), dim3(64), 0, s, img_w, img_h,    \
+                       tile_order, tile_kmax, depths, out_depth, skip_flag)
+#define SGN_LAUNCH_FWD_PK(EX, GA, DE)                                                                                \
+    hipLaunchKernelGGL((raster_fwd_pk_kernel<EX, GA, DE>), dim3(((tiles_x * tiles_y + 7) / 8) * 32 + 32), dim3(64), 0, s, img_w, img_h,    \
                        tiles_x, tiles_x * tiles_y, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, background3,  \
-                       out_img, final_Ts, final_idx, o.xcd_swizzle, o.batch_fwd, tile_order, tile_kmax)
-#define SGN_LAUNCH_FWD2(EX, GA)                                                     \
-    do {                                                                            \
-        if (o.waves_fwd == 2 && block_width == 16) SGN_LAUNCH_FWD_PK(EX, GA);       \
-        else if (o.waves_fwd == 4 || o.waves_fwd == 2) SGN_LAUNCH_FWD(EX, GA, 1, false); \
-        else if (o.waves_fwd == 1) SGN_LAUNCH_FWD(EX, GA, 4, false);                \
-        else SGN_LAUNCH_FWD(EX, GA, 4, true);                                       \
+                       out_img, final_Ts, final_idx, o.xcd_swizzle, o.batch_fwd, tile_order, tile_kmax, depths, out_depth, skip_flag)
+#define SGN_LAUNCH_FWD3(EX, GA, DE)                                                     \
+    do {                                                                                \
+        if (o.waves_fwd == 2 && block_width == 16) SGN_LAUNCH_FWD_PK(EX, GA, DE);       \
+        else if (o.waves_fwd == 4 || o.waves_fwd == 2) SGN_LAUNCH_FWD(EX, GA, 1, false, DE); \
+        else if (o.waves_fwd == 1) SGN_LAUNCH_FWD(EX, GA, 4, false, DE);                \
+        else SGN_LAUNCH_FWD(EX, GA, 4, true, DE);                                       \
     } while (0)
+#define SGN_LAUNCH_FWD2(EX, GA) do { if (depths) SGN_LAUNCH_FWD3(EX, GA, true); else SGN_LAUNCH_FWD3(EX, GA, false); } while (0)
     if (o.exact_exp) {
         if (o.gather) SGN_LAUNCH_FWD2(true, true); else SGN_LAUNCH_FWD2(true, false);
     } else {
         if (o.gather) SGN_LAUNCH_FWD2(false, true); else SGN_LAUNCH_FWD2(false, false);
     }
 #undef SGN_LAUNCH_FWD2
+#undef SGN_LAUNCH_FWD3
 #undef SGN_LAUNCH_FWD_PK
 #undef SGN_LAUNCH_FWD
     sgn_timing_end(SGN_T_RASTER_FWD, s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------ reuse of the depth channel (r03)
+// The reference renders depth with a SECOND full rasterization of the same geometry whose colours are the depths
+// themselves (sgn_splatfacto.py:982-994: `depths[:, None].repeat(1, 3)`).  When the first pass accumulated the depth
+// channel, that second call is answered from it — if, and only if, its colours really are its depths, which only the
+// device can tell without a host sync:
+//   sgn_colors_match_depths  flag = 0 iff colors[i, c] == depths[i] bit for bit for every row and channel (else 1)
+//   (the caller then queues the ordinary forward with skip_flag = flag: its kernels return at once when flag == 0)
+//   sgn_depth_reuse          iff flag == 0: out_img[p, c] = fma(T[p], background[c], D[p]) — exactly what the
+//                            rasterization would have produced (same fma) — and final_Ts / final_idx are copied
+//                            from the first pass (the backward of the second node needs its own)
+// Everything is queued unconditionally; nothing waits for the flag on the host.
+__global__ __launch_bounds__(256) void colors_match_depths_kernel(int n, const uint32_t *__restrict__ colors,
+                                                                  const uint32_t *__restrict__ depths,
+                                                                  int32_t *__restrict__ flag) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    bool bad = false;
+    if (i < n) {
+        const uint32_t d = depths[i];
+        bad = colors[3 * i] != d || colors[3 * i + 1] != d || colors[3 * i + 2] != d;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+__global__ __launch_bounds__(256) void depth_reuse_kernel(int n_pix, const int32_t *__restrict__ flag,
+                                                          const float *__restrict__ D, const float *__restrict__ T1,
+                                                          const int32_t *__restrict__ idx1,
+                                                          const float *__restrict__ bg, float *__restrict__ out_img,
+                                                          float *__restrict__ final_T, int32_t *__restrict__ final_idx,
+                                                          int n_stats, const int32_t *__restrict__ stats_first,
+                                                          int32_t *__restrict__ stats_out) {
+    if (flag != nullptr && *flag != 0) return;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < n_stats) stats_out[p] = stats_first[p];      // the tile statistics of the pass (same geometry: same walks)
+    if (p >= n_pix) return;
+    const float t = T1[p], d = D[p];
+    out_img[3 * p + 0] = fmaf(t, bg[0], d);
+    out_img[3 * p + 1] = fmaf(t, bg[1], d);
+    out_img[3 * p + 2] = fmaf(t, bg[2], d);
+    if (final_T != nullptr) {          // NULL: the caller's node shares the first pass's buffers (host-proven reuse)
+        final_T[p] = t;
+        final_idx[p] = idx1[p];
+    }
+}
+
+SGN_EXPORT int sgn_colors_match_depths(int n, const float *colors, const float *depths, int32_t *flag,
+                                       sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0 && flag != nullptr, -1);
+    hipStream_t s = (hipStream_t)stream;
+    SGN_HIP_CHECK(hipMemsetAsync(flag, 0, sizeof(int32_t), s));
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(colors && depths, -2);
+    hipLaunchKernelGGL(colors_match_depths_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, (const uint32_t *)colors,
+                       (const uint32_t *)depths, flag);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_depth_reuse(int img_h, int img_w, const int32_t *flag, const float *depth_channel,
+                               const float *final_Ts_first, const int32_t *final_idx_first, const float *background3,
+                               float *out_img, float *final_Ts, int32_t *final_idx, int n_stats,
+                               const int32_t *tile_stats_first, int32_t *tile_stats, sgn_stream_t stream) {
+    SGN_ARG_CHECK(img_h > 0 && img_w > 0, -1);
+    SGN_ARG_CHECK(n_stats == 0 || (n_stats <= img_h * img_w && tile_stats_first && tile_stats), -3);
+    SGN_ARG_CHECK(depth_channel && final_Ts_first && final_idx_first && background3 && out_img, -2);
+    SGN_ARG_CHECK((final_Ts == nullptr) == (final_idx == nullptr), -4);
+    const int n_pix = img_h * img_w;
+    sgn_timing_begin(SGN_T_RASTER_FWD, stream);
+    hipLaunchKernelGGL(depth_reuse_kernel, dim3(sgn_cdiv(n_pix, 256)), dim3(256), 0, (hipStream_t)stream, n_pix, flag,
+                       depth_channel, final_Ts_first, final_idx_first, background3, out_img, final_Ts, final_idx, n_stats,
+                       tile_stats_first, tile_stats);
+    sgn_timing_end(SGN_T_RASTER_FWD, stream);
     SGN_LAUNCH_CHECK();
     return 0;
 }

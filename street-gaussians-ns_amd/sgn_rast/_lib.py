@@ -73,8 +73,10 @@ SIGNATURES = {
     "sgn_raster_workspace_bytes": (_sz, [_i, _i64, _vp]),
     "sgn_tile_order": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp]),
     "sgn_raster_fwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
-                            _sz, _i, _vp, _vp, _vp, _vp]),
-    "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+                            _sz, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
+    "sgn_colors_match_depths": (_i, [_i, _vp, _vp, _vp, _vp]),
+    "sgn_depth_reuse": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sgn_raster_bwd_workspace_bytes": (_sz, [_i]),
     "sgn_raster_bwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                             _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp, _vp, _vp, _vp]),

@@ -192,7 +192,8 @@ def spherical_harmonics_fused(degrees_to_use: int, means, cam_pos, features_dc, 
 
 
 def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors, opacity_logits, img_height,
-                              img_width, block_width, background=None, return_alpha=False, id_range=None):
+                              img_width, block_width, background=None, return_alpha=False, id_range=None,
+                              depth_channel=False):
     """``rasterize_gaussians(..., torch.sigmoid(opacity_logits), ...)`` with the sigmoid (and its backward)
     folded into the record build / gradient unpack kernels.
 
@@ -200,11 +201,16 @@ def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors,
     objects-only / background-only accumulation passes (``sgn_splatfacto_scene_graph.py:364-366``), which the
     reference renders from re-concatenated slices with a fresh sort each.  Passing the full geometry tensors
     keeps the one-entry binning cache hot, so the pass costs a row build and a walk of the shared depth list;
-    result and gradients equal the sliced call's (the sub-list keeps its relative order)."""
+    result and gradients equal the sliced call's (the sub-list keeps its relative order).
+
+    ``depth_channel=True`` returns ``(img, alpha, depth)`` with ``depth[H,W] = sum_g depths_g alpha_g T_g`` accumulated
+    by the SAME pass (one fma per evaluated pair) — the image the reference pays a second rasterization of
+    ``depths.repeat(1, 3)`` for (``sgn_splatfacto.py:982-994``); it carries no gradient (the reference's depth output
+    enters no loss)."""
     assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
     if background is None:
         background = torch.ones(3, dtype=torch.float32, device=colors.device)
     return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(), conics.contiguous(),
                                      num_tiles_hit.contiguous(), colors.contiguous(), opacity_logits.contiguous(),
                                      img_height, img_width, block_width, background.contiguous(), return_alpha, True,
-                                     id_range)
+                                     id_range, bool(depth_channel))

@@ -387,7 +387,6 @@ def _bin_finish(st):
         tile_bins.zero_()
         return 0, torch.zeros(0, **i32), tile_bins
     lib = L.load()
-
     def run(count_or_cap, count_dev):
         ids = torch.empty(count_or_cap, **i32)
         ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(count_or_cap), st["dev"])
@@ -427,6 +426,11 @@ tile_order_enabled = True
 concurrent_backward = True   # lend sgn_raster_bwd a second stream: its short-walk and long-walk kernels overlap
 small_splat_q16 = 0       # experimental: > 0 sends tiles with < q/16 evaluated (entry, quadrant) pairs per walked entry to the 4-waves kernel (no gain measured: profiles/r02_street_balance.md)
 _order_cache = {"bins": None, "order": None, "thresh": None}
+
+
+def _fwd_long_thresh(ro) -> int:
+    """Forward lists with at least this many entries get four waves in the packed forward (0: no such prefix)."""
+    return int(ro.adapt_fwd if ro.adapt_fwd > 0 else 1024) if ro.waves_fwd == 2 else 0
 
 
 def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = None, long_thresh: int = 0):
@@ -589,11 +593,47 @@ def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacit
     return None
 
 
+# ------------------------------------------------------------ depth channel
+# The reference renders depth with a SECOND full rasterization of the same geometry, the colours being the depths
+# themselves (sgn_splatfacto.py:982-994).  The forward kernels can accumulate that image as a fourth channel of the
+# FIRST pass (one fma per evaluated pair), and the second call is then answered from it: a device-side comparison proves
+# that its colours are `depths.repeat(1, 3)`, the ordinary forward is queued behind a flag that turns its kernels into
+# no-ops, and one small kernel writes the image and the per-pixel state the second node's backward needs
+# (sgn_depth_reuse) — no host sync, bit-equal to the two-pass result in exact-exp mode.
+# "auto" (default): the first pass starts accumulating once a step has been seen to make that second call (a rasterize
+# call on the very tensors of the previous one with other colours), and stops again when the calls stop coming;
+# "on" / "off" force it.  The fused API asks for the channel explicitly (rasterize_gaussians_fused(depth_channel=True)).
+depth_channel = os.environ.get("SGN_DEPTH_CHANNEL", "auto")
+_depth_state = {"want": False, "unused": 0, "cache": None}
+depth_stats = {"accumulated": 0, "reused": 0}
+
+
+def _depth_wanted() -> bool:
+    return depth_channel == "on" or (depth_channel == "auto" and _depth_state["want"])
+
+
+def _provably_depths(colors: torch.Tensor, depths: torch.Tensor) -> bool:
+    """Host-side proof, on the autograd graph, that ``colors`` is literally ``depths[:, None].repeat(1, 3)`` of this
+    very ``depths`` tensor (sgn_splatfacto.py:988) — available whenever the projection carries a graph (training).
+    With it the depth pass needs no device-side comparison and none of the conditional launches behind it."""
+    fn, src = colors.grad_fn, depths.grad_fn
+    if fn is None or src is None or type(fn).__name__ != "RepeatBackward0":
+        return False
+    if tuple(getattr(fn, "_saved_repeats", ())) != (1, 3):
+        return False
+    inner = fn.next_functions[0][0]
+    if inner is None or type(inner).__name__ != "UnsqueezeBackward0" or getattr(inner, "_saved_dim", None) not in (1, -1):
+        return False
+    node, nr = inner.next_functions[0]
+    return node is src and nr == depths.output_nr
+
+
 # --------------------------------------------------------------- rasterize
 class _RasterizeGaussians(Function):
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
-                block_width, background=None, return_alpha=False, opacity_is_logit=False, id_range=None):
+                block_width, background=None, return_alpha=False, opacity_is_logit=False, id_range=None,
+                want_depth=False, colors_are_depths=False):
         dev = L.require_device(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
         num_points = xys.size(0)
         tile_bounds = ((img_width + block_width - 1) // block_width,
@@ -626,10 +666,27 @@ class _RasterizeGaussians(Function):
             id_lo, id_hi, window = lo, lo + num_points, 1
         else:
             id_lo, id_hi = (0, num_points) if id_range is None else (int(id_range[0]), int(id_range[1]))
+        # depth channel: is this the reference's depth pass over the geometry of the pass before it (answer it from that
+        # pass's fourth channel), or a first pass that should accumulate the channel?
+        plain = win is None and id_range is None and num_points > 0 and bool(ro.gather) and cull
+        dcache = _depth_state["cache"]
+        reuse = (plain and hit and not want_depth and depth_channel != "off" and dcache is not None
+                 and dcache["key"] == key and colors_c.shape == (num_points, 3))
+        if plain and hit and not reuse and depth_channel == "auto" and not want_depth:
+            _depth_state["want"] = True        # a second pass over the same geometry: accumulate from the next step on
+        accumulate = plain and not reuse and not hit and (want_depth or _depth_wanted())
+        depths_c = _f32c(depths) if (reuse or accumulate) else None
+        skip_flag = None
+        proved = bool(reuse and colors_are_depths)      # the host knows: no flag, no conditional launches, no copies
+        if reuse and not proved:
+            skip_flag = torch.empty(1, dtype=torch.int32, device=dev)
+            L.check(lib.sgn_colors_match_depths(num_points, L.ptr(colors_c), L.ptr(depths_c), L.ptr(skip_flag),
+                                                stream_ptr), "sgn_colors_match_depths")
+        out_depth = torch.empty(img_height, img_width, **f32) if accumulate else None
         # ... and the per-Gaussian rows are built between the binning's first half and its host sync, so the GPU has
         # work queued while the host wakes up (gather mode; the stream mode re-packs rows per intersection later)
         recs, rows_built = None, 0
-        if num_points > 0 and ro.gather:
+        if num_points > 0 and ro.gather and not proved:
             if win is None and not hit and _bin_pending["key"] != key:
                 _drop_pending()
                 _bin_pending["state"] = _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds,
@@ -638,7 +695,7 @@ class _RasterizeGaussians(Function):
             recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, 0, ro_ptr), dev)
             L.check(lib.sgn_raster_build_rows(n_full, L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c),
                                               int(bool(opacity_is_logit)), id_lo, id_hi, window, L.ptr(recs),
-                                              recs.numel(), stream_ptr), "sgn_raster_build_rows")
+                                              recs.numel(), L.ptr(skip_flag), stream_ptr), "sgn_raster_build_rows")
             rows_built = 1
         if win is not None:
             num_intersects, gaussian_ids_sorted, tile_bins = cached
@@ -646,7 +703,17 @@ class _RasterizeGaussians(Function):
             num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
                 num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
                 opacity_is_logit)
-        if num_intersects < 1:
+        if proved and num_intersects >= 1:
+            # the depth pass, proven on the host: its image comes from the first pass's fourth channel, and its node
+            # SHARES that pass's per-pixel state and tile statistics (same geometry and opacities: same values)
+            final_Ts, final_idx, tile_kmax = dcache["T"], dcache["idx"], dcache["kmax"]
+            order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
+            L.check(lib.sgn_depth_reuse(img_height, img_width, None, L.ptr(dcache["D"]), L.ptr(final_Ts),
+                                        L.ptr(final_idx), L.ptr(bg_c), L.ptr(out_img), None, None, 0, None, None,
+                                        stream_ptr), "sgn_depth_reuse")
+            depth_stats["reused"] += 1
+            _depth_state["unused"] = 0
+        elif num_intersects < 1:
             recs = None
             out_img = torch.ones(img_height, img_width, 3, **f32) * bg_c
             gaussian_ids_sorted = torch.zeros(0, dtype=torch.int32, device=dev)
@@ -657,13 +724,30 @@ class _RasterizeGaussians(Function):
             if not rows_built:
                 recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
             # packed forward: the leading tiles of the order whose lists reach adapt_fwd entries get four waves
-            order = _tile_order(tile_bins, None, (ro.adapt_fwd if ro.adapt_fwd > 0 else 1024) if ro.waves_fwd == 2 else 0)
+            order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
             tile_kmax = torch.empty(tile_bins.shape[0], 2, dtype=torch.int32, device=dev)   # walk depth, pairs
             L.check(lib.sgn_raster_fwd(
                 img_height, img_width, block_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), id_lo, id_hi,
                 window, L.ptr(bg_c), L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(),
-                rows_built, L.ptr(order), L.ptr(tile_kmax), ro_ptr, stream_ptr), "sgn_raster_fwd")
+                rows_built, L.ptr(order), L.ptr(tile_kmax), L.ptr(depths_c) if accumulate else None,
+                L.ptr(out_depth), L.ptr(skip_flag), ro_ptr, stream_ptr), "sgn_raster_fwd")
+            if reuse:
+                L.check(lib.sgn_depth_reuse(img_height, img_width, L.ptr(skip_flag), L.ptr(dcache["D"]),
+                                            L.ptr(dcache["T"]), L.ptr(dcache["idx"]), L.ptr(bg_c), L.ptr(out_img),
+                                            L.ptr(final_Ts), L.ptr(final_idx), tile_kmax.numel(),
+                                            L.ptr(dcache["kmax"]), L.ptr(tile_kmax), stream_ptr), "sgn_depth_reuse")
+                recs = None                    # the rows were not built if the flag said "reuse": the backward packs them
+                depth_stats["reused"] += 1
+                _depth_state["unused"] = 0
+            elif accumulate:
+                depth_stats["accumulated"] += 1
+                _depth_state["cache"] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
+                _depth_state["unused"] += 1
+                if _depth_state["unused"] > 8 and depth_channel == "auto":   # the depth passes stopped coming
+                    _depth_state["want"], _depth_state["unused"] = False, 0
+            elif not hit:
+                _depth_state["cache"] = None   # another scene was binned: the cached channel is not its image
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
         ctx.num_intersects = num_intersects
         ctx.opacity_is_logit = int(bool(opacity_is_logit))
@@ -674,13 +758,19 @@ class _RasterizeGaussians(Function):
         ctx.recs = recs
         ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys_c, conics_c, colors_c, opac_c, bg_c,
                               final_Ts, final_idx)
+        if want_depth:
+            if out_depth is None:                 # nothing visible / a path without the channel: the two-pass image
+                out_depth = torch.zeros(img_height, img_width, **f32)
+            ctx.mark_non_differentiable(out_depth)
+            out_alpha = 1 - final_Ts
+            return out_img, out_alpha, out_depth
         if return_alpha:
             out_alpha = 1 - final_Ts
             return out_img, out_alpha
         return out_img
 
     @staticmethod
-    def backward(ctx, v_out_img, v_out_alpha=None):
+    def backward(ctx, v_out_img, v_out_alpha=None, _v_depth=None):
         (gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity, background, final_Ts,
          final_idx) = ctx.saved_tensors
         dev = xys.device
@@ -704,6 +794,9 @@ class _RasterizeGaussians(Function):
                 recs = L.workspace(lib.sgn_raster_workspace_bytes(ctx.n_full, ctx.num_intersects, ro_ptr), dev)
                 packed = 0
             gws = L.workspace(lib.sgn_raster_bwd_workspace_bytes(ctx.n_full), dev)
+            # the backward's own launch order, by REVERSE-WALK length (tried in r03: the forward's order by list length
+            # plus per-tile classification, no launch — the one-wave kernel then ran 323 instead of 288 us on the
+            # benchmark scene: a late long walk is a lone-wave tail; profiles/r03f_*)
             order = _tile_order(tile_bins, ctx.tile_kmax, ctx.ro.adapt_bwd)
             L.check(lib.sgn_raster_bwd(
                 H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
@@ -715,7 +808,7 @@ class _RasterizeGaussians(Function):
                 L.aux_stream_ptr(dev) if concurrent_backward else None), "sgn_raster_bwd")
         v_opacity = v_opacity.reshape(ctx.opacity_shape)
         # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha)
-        return v_xy, None, None, v_conic, None, v_colors, v_opacity, None, None, None, None, None, None, None
+        return (v_xy, None, None, v_conic, None, v_colors, v_opacity) + (None,) * 9
 
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height: int,
@@ -739,7 +832,8 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
     return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(),
                                      conics.contiguous(), num_tiles_hit.contiguous(), colors.contiguous(),
                                      opacity.contiguous(), img_height, img_width, block_width,
-                                     background.contiguous(), return_alpha)
+                                     background.contiguous(), return_alpha, False, None, False,
+                                     depth_channel != "off" and _provably_depths(colors, depths))
 
 
 # -------------------------------------------------------------- _torch_impl

@@ -104,7 +104,7 @@ def render(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, b
 def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, block_width: int = 16,
                  background: Optional[torch.Tensor] = None, with_depth: bool = False,
                  object_ids: Optional[torch.Tensor] = None, poses: Optional[torch.Tensor] = None,
-                 idft: Optional[torch.Tensor] = None) -> SimpleNamespace:
+                 idft: Optional[torch.Tensor] = None, depth_channel: bool = True) -> SimpleNamespace:
     """Same result as :func:`render` on the scene-graph-aggregated parameters, through the fused front
     ends (:mod:`sgn_rast.fused`): raw parameters in, no activation / concat / transform kernels.
     ``P["means"]`` / ``P["quats"]`` are in each object's LOCAL frame when ``object_ids``/``poses`` are given;
@@ -126,6 +126,14 @@ def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int 
     # SH view directions use WORLD means (scene_graph.py:355): the kernel applies the pose itself
     rgbs = fused.spherical_harmonics_fused(sh_degree_to_use, P["means"], cam.cam_pos, P["features_dc"],
                                            P["features_rest"], object_ids=object_ids, idft=idft, poses=poses)
+    if with_depth and depth_channel:
+        # the depth image rides in the colour pass as a fourth channel (no second rasterization)
+        rgb, alpha, depth_im = fused.rasterize_gaussians_fused(
+            xys, depths, radii, conics, num_tiles_hit, rgbs, P["opacity_logits"], H, W, block_width,
+            background=background, return_alpha=True, depth_channel=True)
+        out.rgb, out.alpha, out.rgbs = rgb, alpha, rgbs
+        out.depth = torch.where(alpha[..., None] > 1e-3, depth_im[..., None] / alpha[..., None], 10)   # :995
+        return out
     rgb, alpha = fused.rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, rgbs,
                                                  P["opacity_logits"], H, W, block_width, background=background,
                                                  return_alpha=True)

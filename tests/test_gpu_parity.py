@@ -292,7 +292,7 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
                                    L.ptr(d["xys"]), L.ptr(d["conics"]), L.ptr(d["rgb"]),
                                    L.ptr(d["opac"].reshape(-1).contiguous()), 0, 0, n, 0, L.ptr(bg.to(DEV)),
                                    L.ptr(out_img), L.ptr(fT), L.ptr(fi), L.ptr(recs), recs.numel(), 0, None, None,
-                                   L.opts_ptr(), L.stream_ptr()), "raster_fwd")
+                                   None, None, None, L.opts_ptr(), L.stream_ptr()), "raster_fwd")
         assert torch.equal(fi.cpu(), exp_idx)
         assert torch.equal(fT.cpu(), exp_T)
         assert torch.equal(out_img.cpu(), exp_img)

@@ -42,9 +42,10 @@ def test_raster_kernels_have_no_scratch_and_scalar_operands(raster_asm):
     ks = _kernels(raster_asm)
     fwd = [t for k, t in ks.items() if "raster_fwd_kernel" in k]
     bwd = [t for k, t in ks.items() if "raster_bwd_kernel" in k or "raster_bwd_short_kernel" in k]
-    # forward: exact x gather x {4 waves, 1 wave, adaptive}; backward: exact x reduce x gather x {4 waves, 1 wave,
-    # legacy in-kernel adaptive, long-walk half of the two-kernel scheme} + its short-walk half (own kernel)
-    assert len(fwd) == 12 and len(bwd) == 40
+    # forward: exact x gather x {4 waves, 1 wave, adaptive} x {3 channels, + depth channel}; backward: exact x reduce x
+    # gather x {4 waves, 1 wave, legacy in-kernel adaptive, long-walk half of the two-kernel scheme} + its short-walk
+    # half (own kernel)
+    assert len(fwd) == 24 and len(bwd) == 40
     for t in fwd + bwd:
         assert re.search(r"ScratchSize: 0\b", t), "a raster kernel spills to scratch"
         assert "s_load_dwordx8" in t and "s_load_dwordx4" in t     # 48-byte row / record in SGPRs
@@ -57,14 +58,18 @@ def test_packed_forward_runs_on_the_packed_fp32_pipe(raster_asm):
     update and the three colour sums are v_pk_* instructions, and nothing spills."""
     ks = _kernels(raster_asm)
     pk = {k: t for k, t in ks.items() if "raster_fwd_pk_kernel" in k}
-    assert len(pk) == 4                                            # exact x gather
+    assert len(pk) == 8                                            # exact x gather x depth channel
     for k, t in pk.items():
         assert re.search(r"ScratchSize: 0\b", t), "the packed forward spills to scratch"
         assert "s_load_dwordx8" in t and "ds_read_b128" in t      # scalar-chase and LDS-batched paths both compiled in
         # two code paths (scalar chase, LDS batches) x (3 colour + 2 quadratic-form) packed FMAs, + the 1-px long-tile body
         assert t.count("v_pk_fma_f32") >= 10 and t.count("v_pk_mul_f32") >= 12, k
-    fast = next(t for k, t in pk.items() if "ILb0ELb1E" in k)
+    fast = next(t for k, t in pk.items() if "ILb0ELb1ELb0E" in k)
     assert fast.count("v_exp_f32") >= 4                            # hardware exp, two per entry and path
+    # the depth channel (r03) is ONE more packed fma per entry and path in the two-pixel body, nothing else
+    deep = next(t for k, t in pk.items() if "ILb0ELb1ELb1E" in k)
+    assert 0 < deep.count("v_pk_fma_f32") - fast.count("v_pk_fma_f32") <= 3
+    assert re.search(r"ScratchSize: 0\b", deep)
 
 
 def test_short_walk_backward_is_held_at_four_waves_and_not_slp_packed(raster_asm):
