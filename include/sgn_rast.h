@@ -226,8 +226,15 @@ size_t sgn_bin_prepare_workspace_bytes(int n);
 int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii, const float *conics,
                     const float *opacities, int opacity_is_logit, int cull, int tiles_x, int tiles_y,
                     int block_width, int32_t *cum_by_rank /*[n] inclusive scan of kept-tile counts, rank order*/,
-                    int32_t *gid_by_rank /*[n]*/, float *bin_records /*[n,8] out*/, void *ws, size_t ws_bytes,
-                    sgn_stream_t stream);
+                    int32_t *gid_by_rank /*[n] out; in when rank_ready*/,
+                    int rank_ready /*1: gid_by_rank already holds sgn_depth_rank(n, depths, radii, ...)*/,
+                    float *bin_records /*[n,8] out*/, void *ws, size_t ws_bytes, sgn_stream_t stream);
+/* The first stage of sgn_bin_prepare on its own: gid_by_rank[r] = id of the Gaussian of depth rank r (stable: ties by
+ * id; radii <= 0 last).  It reads depths and radii only, so a caller can queue it right behind the projection — before
+ * opacities and colours exist — and hand the result to sgn_bin_prepare(rank_ready = 1). */
+size_t sgn_depth_rank_workspace_bytes(int n);
+int sgn_depth_rank(int n, const float *depths, const int32_t *radii, int32_t *gid_by_rank /*[n]*/, void *ws,
+                   size_t ws_bytes, sgn_stream_t stream);
 size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect);
 /* n_isect_dev == NULL: n_isect is the intersection count the host has read back (cum_by_rank[n-1]).
  * n_isect_dev != NULL (speculative form, no upstream counterpart): the call is queued BEFORE the host knows the count;

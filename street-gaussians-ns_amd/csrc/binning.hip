@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
                                                         const int32_t *__restrict__ radii, Cull cull, int tiles_x,
                                                         int tiles_y, int block, uint32_t *__restrict__ dkeys,
                                                         int32_t *__restrict__ dvals, BinRec *__restrict__ recs,
-                                                        int32_t *__restrict__ cnt_gid) {
+                                                        int32_t *__restrict__ cnt_gid, int write_keys) {
     __shared__ FlatScratch scratch[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     int mnx = 0, mny = 0, mxx = 0, mxy = 0;
@@ -443,8 +443,10 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
     const Ellipse E = make_ellipse(R.gx, R.gy, R.a, R.b, R.c, R.s);
     R.cnt = tiles_of<false>(live, E, mnx, mny, mxx, mxy, i, 0, tiles_x, block, scratch[threadIdx.x >> 6], NoOut{});
     if (i < n) {
-        dkeys[i] = R.rad > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;  // culled splats sort last
-        dvals[i] = i;
+        if (write_keys) {           // 0: the depth ranking was started earlier (sgn_depth_rank)
+            dkeys[i] = R.rad > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;  // culled splats sort last
+            dvals[i] = i;
+        }
         cnt_gid[i] = R.cnt;             // dense copy: the rank-order gather below then works on 4 B/Gaussian
         float4 *o = reinterpret_cast<float4 *>(recs + i);
         o[0] = make_float4(R.gx, R.gy, R.a, R.b);
@@ -727,6 +729,42 @@ void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const
 void sgn_sort_pairs16_launch(uint32_t n, int end_bit, const uint16_t *kin, const int32_t *vin, uint16_t *kout,
                              int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev = nullptr);
 
+// The depth ranking needs depths and radii only, i.e. it can be queued the moment the projection is: the caller's
+// colour evaluation and activations then run BEHIND ~80 us of device work instead of in front of an idle GPU (the
+// drop-in path loses its lead over the device at upstream's eager argument check / the reference's `radii.sum() == 0`).
+__global__ __launch_bounds__(256) void depth_keys_kernel(int n, const float *__restrict__ depths,
+                                                         const int32_t *__restrict__ radii,
+                                                         uint32_t *__restrict__ dkeys, int32_t *__restrict__ dvals) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    dkeys[i] = radii[i] > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;   // as bin_count_kernel writes them
+    dvals[i] = i;
+}
+
+SGN_EXPORT size_t sgn_depth_rank_workspace_bytes(int n) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    return 3 * al256(nn * 4) + sgn_sort_pairs32_ws_bytes(n);
+}
+
+SGN_EXPORT int sgn_depth_rank(int n, const float *depths, const int32_t *radii, int32_t *gid_by_rank, void *ws,
+                              size_t ws_bytes, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(depths && radii && gid_by_rank && ws, -2);
+    SGN_ARG_CHECK(ws_bytes >= sgn_depth_rank_workspace_bytes(n), -3);
+    hipStream_t s = (hipStream_t)stream;
+    char *p = (char *)ws;
+    uint32_t *dkeys = (uint32_t *)p; p += al256((size_t)n * 4);
+    int32_t *dvals = (int32_t *)p;   p += al256((size_t)n * 4);
+    uint32_t *dkeys_sorted = (uint32_t *)p; p += al256((size_t)n * 4);
+    sgn_timing_begin(SGN_T_SORT, s);
+    hipLaunchKernelGGL(depth_keys_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, depths, radii, dkeys, dvals);
+    sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, p, s);
+    sgn_timing_end(SGN_T_SORT, s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
 SGN_EXPORT size_t sgn_bin_prepare_workspace_bytes(int n) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     return al256(sgn_scan_workspace_bytes(n)) + 5 * al256(nn * 4) + sgn_sort_pairs32_ws_bytes(n);
@@ -742,7 +780,7 @@ static Cull make_cull(const float *conics, const float *opac, int opac_is_logit,
 SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii,
                                const float *conics, const float *opacities, int opacity_is_logit, int cull,
                                int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
-                               int32_t *gid_by_rank, float *bin_records, void *ws, size_t ws_bytes,
+                               int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
                                sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
@@ -762,11 +800,13 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     BinRec *recs = reinterpret_cast<BinRec *>(bin_records);
     sgn_timing_begin(SGN_T_MAP, s);
     hipLaunchKernelGGL(bin_count_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, depths, radii, c, tiles_x,
-                       tiles_y, block_width, dkeys, dvals, recs, cnt_gid);
+                       tiles_y, block_width, dkeys, dvals, recs, cnt_gid, rank_ready ? 0 : 1);
     sgn_timing_end(SGN_T_MAP, s);
-    sgn_timing_begin(SGN_T_SORT, s);
-    sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
-    sgn_timing_end(SGN_T_SORT, s);
+    if (!rank_ready) {       // rank_ready: gid_by_rank already holds sgn_depth_rank's result for these depths / radii
+        sgn_timing_begin(SGN_T_SORT, s);
+        sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
+        sgn_timing_end(SGN_T_SORT, s);
+    }
     // cum_by_rank[r] = sum of the kept-tile counts of ranks <= r: the scan's first pass gathers cnt_gid[gid_by_rank[r]]
     return scan_launch(n, cnt_gid, gid_by_rank, cnt_r, cum_by_rank, scan_ws, s);
 }

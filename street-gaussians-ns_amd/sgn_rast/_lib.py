@@ -66,7 +66,9 @@ SIGNATURES = {
     "sgn_sort_selftest": (_i, [_vp, _sz, _vp]),
     "sgn_tile_bins": (_i, [_i64, _vp, _i, _vp, _vp]),
     "sgn_bin_prepare_workspace_bytes": (_sz, [_i]),
-    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "sgn_depth_rank_workspace_bytes": (_sz, [_i]),
+    "sgn_depth_rank": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_bin_intersect_workspace_bytes": (_sz, [_i64]),
     "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
     "sgn_rows_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -251,13 +253,17 @@ def stream_ptr() -> C.c_void_p:
 _aux_streams: dict = {}
 
 
-def aux_stream_ptr(device) -> C.c_void_p:
+def aux_stream(device) -> "torch.cuda.Stream":
     """A second stream of ``device`` the library may fan independent kernels out to (sgn_raster_bwd runs the two halves
     of its adaptive scheme concurrently); made once per device."""
     dev = torch.device(device)
     if dev not in _aux_streams:
         _aux_streams[dev] = torch.cuda.Stream(device=dev)
-    return C.c_void_p(_aux_streams[dev].cuda_stream)
+    return _aux_streams[dev]
+
+
+def aux_stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(aux_stream(device).cuda_stream)
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:

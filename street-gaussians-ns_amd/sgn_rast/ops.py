@@ -216,6 +216,80 @@ def raise_pending_checks() -> None:
     assert not failed, "quats must be normalized"
 
 
+# ------------------------------------------------------------ early depth rank
+# The depth ranking of the Gaussians (a 4-pass radix sort over N keys, ~80 us) needs depths and radii only.  On the
+# drop-in path with its default EAGER argument check (and with the reference's own `radii.sum() == 0` right after the
+# projection) the host loses its lead over the device at that sync: the caller's view directions, SH, clamp and
+# sigmoid are then launched one by one in front of an idle GPU, and `rasterize_gaussians` starts its binning late.
+# `project_gaussians` therefore queues the ranking right behind the projection (same stream, BEFORE it waits for the
+# check), and the coming `rasterize_gaussians` on these very depths / radii picks it up (sgn_bin_prepare(rank_ready)).
+# Same kernels, same results, started earlier.  Speculative: a projection that no rasterize call follows wastes the
+# ranking; after three such misses in a row the speculation pauses for 200 calls.
+early_rank = os.environ.get("SGN_EARLY_RANK", "auto")      # "auto": with the eager check; "on"; "off"
+# "main": behind the projection on the caller's stream.  "aux": on the library's second stream, forked behind the
+# projection and joined by the rasterize call — a host sync of the CALLER's stream right after the projection (the
+# reference's `radii.sum() == 0`, sgn_splatfacto.py:878) then returns while the ranking still runs
+early_rank_stream = os.environ.get("SGN_EARLY_RANK_STREAM", "main")
+_early = {"entry": None, "misses": 0, "pause": 0}
+early_rank_stats = {"started": 0, "used": 0}
+
+
+def _start_early_rank(depths: torch.Tensor, radii: torch.Tensor) -> None:
+    n = depths.shape[0]
+    if early_rank == "off" or (early_rank == "auto" and quat_check not in ("eager", "eager-upstream")):
+        return
+    if n == 0 or not depths.is_cuda or not tile_culling_enabled:
+        return
+    if _early["pause"] > 0:
+        _early["pause"] -= 1
+        return
+    if _early["entry"] is not None:                 # the previous ranking was never used
+        _early["misses"] += 1
+        if _early["misses"] >= 3:
+            _early["misses"], _early["pause"], _early["entry"] = 0, 200, None
+            return
+    lib = L.load()
+    d, r = depths.detach(), radii.detach()
+    key = (d.data_ptr(), d._version, r.data_ptr(), r._version, n, L.stream_handle())
+    done = None
+    if early_rank_stream == "aux":
+        main = torch.cuda.current_stream(d.device)
+        aux = L.aux_stream(d.device)
+        aux.wait_stream(main)
+        with torch.cuda.stream(aux):
+            gid = torch.empty(n, dtype=torch.int32, device=d.device)
+            ws = L.workspace(lib.sgn_depth_rank_workspace_bytes(n), d.device)
+            L.check(lib.sgn_depth_rank(n, L.ptr(d), L.ptr(r), L.ptr(gid), L.ptr(ws), ws.numel(),
+                                       C.c_void_p(aux.cuda_stream)), "sgn_depth_rank")
+            done = torch.cuda.Event()
+            done.record(aux)
+        d.record_stream(aux); r.record_stream(aux)
+    else:
+        gid = torch.empty(n, dtype=torch.int32, device=d.device)
+        ws = L.workspace(lib.sgn_depth_rank_workspace_bytes(n), d.device)
+        L.check(lib.sgn_depth_rank(n, L.ptr(d), L.ptr(r), L.ptr(gid), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                "sgn_depth_rank")
+    _early["entry"] = dict(key=key, keep=(d, r), gid=gid, done=done)
+    early_rank_stats["started"] += 1
+
+
+def _take_early_rank(depths: torch.Tensor, radii: torch.Tensor):
+    """The ranking `project_gaussians` started for exactly these tensors (float32 depths / int32 radii), or None."""
+    e = _early["entry"]
+    if e is None or depths.dtype != torch.float32 or radii.dtype != torch.int32:
+        return None
+    if e["key"] != (depths.data_ptr(), depths._version, radii.data_ptr(), radii._version, depths.shape[0],
+                    L.stream_handle()):
+        return None
+    _early["entry"], _early["misses"] = None, 0
+    early_rank_stats["used"] += 1
+    if e["done"] is not None:              # ranked on the auxiliary stream: join it here
+        main = torch.cuda.current_stream(depths.device)
+        main.wait_event(e["done"])
+        e["gid"].record_stream(main)
+    return e["gid"]
+
+
 def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
                       block_width, clip_thresh: float = 0.01):
     """gsplat/project_gaussians.py project_gaussians (sgn_splatfacto.py:860-873).
@@ -227,6 +301,7 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     out = _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
                                   viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
                                   clip_thresh)
+    _start_early_rank(out[1], out[2])  # depth ranking queued behind the projection, before the host waits
     _finish_quat_check(token)          # eager mode: the projection is already queued while the host waits here
     return out
 
@@ -338,12 +413,14 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     conics_c = _f32c(conics) if do_cull else None
     opac_c = _f32c(opacity).reshape(-1) if do_cull else None
     cum_r = torch.empty(n, **i32)
-    gid_by_rank = torch.empty(n, **i32)
+    early = _take_early_rank(depths, radii)          # started by project_gaussians behind the projection?
+    gid_by_rank = early if early is not None else torch.empty(n, **i32)
     bin_recs = torch.empty(n, 8, dtype=torch.float32, device=dev)
     ws = L.workspace(lib.sgn_bin_prepare_workspace_bytes(n), dev)
     L.check(lib.sgn_bin_prepare(n, L.ptr(xys_c), L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(conics_c), L.ptr(opac_c),
                                 int(bool(opacity_is_logit)), do_cull, tx, ty, int(block_width), L.ptr(cum_r),
-                                L.ptr(gid_by_rank), L.ptr(bin_recs), L.ptr(ws), ws.numel(), L.stream_ptr()),
+                                L.ptr(gid_by_rank), int(early is not None), L.ptr(bin_recs), L.ptr(ws), ws.numel(),
+                                L.stream_ptr()),
             "sgn_bin_prepare")
     if dev not in _side:
         _side[dev] = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]

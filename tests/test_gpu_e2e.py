@@ -301,3 +301,48 @@ def test_quat_assertion_deferred_and_eager():
     finally:
         ops.quat_check = old
         ops._pending_checks.clear()
+
+
+def test_early_depth_rank_is_picked_up_and_changes_nothing():
+    """`project_gaussians` queues the depth ranking behind the projection (default with the eager argument check); the
+    `rasterize_gaussians` call on the same depths / radii must pick it up (`sgn_bin_prepare(rank_ready=1)`) and
+    produce exactly the list, bins, image and gradients of the ordinary order; a projection that is never rasterized
+    pauses the speculation after three misses."""
+    from sgn_rast import ops, scenes, step
+    cam, raw = scenes.make_scene("c1", n_override=30_000)
+    cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+    w_img, w_a = step.loss_weights(cam, seed=3, device=DEV)
+    res = {}
+    old = ops.early_rank
+    try:
+        for mode in ("off", "on"):
+            ops.early_rank = mode
+            ops._early.update(entry=None, misses=0, pause=0)
+            before = dict(ops.early_rank_stats)
+            ops.clear_binning_cache()
+            P = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+            out = step.train_step(P, cam, w_img, w_a, caller_syncs=True)
+            torch.cuda.synchronize()
+            used = ops.early_rank_stats["used"] - before["used"]
+            assert used == (1 if mode == "on" else 0), (mode, used)
+            ids, bins = ops._bin_cache["val"][1].clone(), ops._bin_cache["val"][2].clone()
+            res[mode] = (out.rgb.detach().clone(), out.alpha.detach().clone(), ids, bins,
+                         {k: v.grad.clone() for k, v in P.items()})
+        assert torch.equal(res["on"][2], res["off"][2]) and torch.equal(res["on"][3], res["off"][3])   # list, bins
+        assert torch.equal(res["on"][0], res["off"][0]) and torch.equal(res["on"][1], res["off"][1])   # image, alpha
+        for k in res["on"][4]:
+            assert rel_l2(res["on"][4][k].cpu(), res["off"][4][k].cpu()) < 1e-5, k
+        # projections nobody rasterizes: the speculation backs off
+        ops.early_rank = "on"
+        ops._early.update(entry=None, misses=0, pause=0)
+        started = ops.early_rank_stats["started"]
+        P = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+        with torch.no_grad():
+            for _ in range(8):
+                ops.project_gaussians(P["means"], torch.exp(P["log_scales"]), 1,
+                                      P["quats"] / P["quats"].norm(dim=-1, keepdim=True), cam.viewmat[:3, :], cam.fx,
+                                      cam.fy, cam.cx, cam.cy, cam.height, cam.width, 16)
+        assert ops.early_rank_stats["started"] - started == 3 and ops._early["pause"] > 0
+    finally:
+        ops.early_rank = old
+        ops._early.update(entry=None, misses=0, pause=0)
