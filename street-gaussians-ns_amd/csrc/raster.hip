@@ -643,7 +643,8 @@ __device__ __forceinline__ float fold16(float a, float b) {   // rows: [a.r0+a.r
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// grad_ws row layout (12 floats / Gaussian): 0,1 v_xy | 2,3,4 v_conic | 5,6,7 v_rgb | 8 v_opacity
+// grad_ws row layout (12 floats / Gaussian): 0,1 m_x, m_y | 2,3,4 s_xx, s_xy, s_yy (raw moments; the conic is applied by
+// unpack_grads_kernel) | 5,6,7 v_rgb | 8 v_opacity
 template <bool EXACT, int REDUCE, bool GATHER, int QPW, bool ADAPT>
 __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, int B, int tiles_x,
                                                 const int2 *__restrict__ bins, const Rec *__restrict__ recs,
@@ -721,7 +722,11 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
 
     // one depth-list entry (reverse walk) for this wave's pixels
     auto entry = [&](const Rec &cur, int k, unsigned qm) __attribute__((always_inline)) {
-        float g_x = 0.f, g_y = 0.f, g_ca = 0.f, g_cb = 0.f, g_cc = 0.f;
+        // Spatial terms as raw MOMENTS (r03): m = sum vs (dx, dy), s = sum vs (dx^2, dx dy, dy^2).  The conic that turns
+        // them into v_xy = (a m_x + b m_y, b m_x + c m_y) and v_conic = (s_xx / 2, s_xy, s_yy / 2) is a per-GAUSSIAN
+        // constant, so it is applied once per Gaussian in unpack_grads_kernel instead of once per (pixel, entry) here:
+        // 2 mul + 2 add + 3 fma in place of 4 mul + 7 fma.
+        float m_x = 0.f, m_y = 0.f, s_xx = 0.f, s_xy = 0.f, s_yy = 0.f;
         float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_o = 0.f;
         bool any = false;
 #pragma unroll
@@ -734,7 +739,9 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
             const float av = cur.opac * vis;
             const float alpha = fminf(alpha_clamp, av);
             const bool valid = (k <= kfin[q]) && sigma >= 0.f && alpha >= (1.f / 255.f);
-            // branch-free: everything is evaluated, invalid lanes are masked out by the selects
+            // branch-free: everything is evaluated, invalid lanes are masked out by three selects.  (ONE select — an
+            // invalid lane continuing with vis = 0, so that alpha = 0, ra = 1, fac = 0, vs = 0 — was measured in r03:
+            // 3 % SLOWER on all three workloads; the select then sits in front of the rcp on the dependency chain.)
             const float ra = __builtin_amdgcn_rcpf(1.f - alpha);   // v_rcp_f32 (1 ulp); oracle divides exactly
             const float Tn = T[q] * ra;
             const float fac = alpha * Tn;
@@ -745,14 +752,12 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
             bv[q] = fmaf(facm, dotc, bv[q]);
             T[q] = valid ? Tn : T[q];
             const float vs = -av * vm;                              // v_sigma (upstream: not zeroed by the clamp)
-            // a*dx = 2*(ha*dx), c*dy = 2*(hc*dy): exact power-of-two scaling
-            g_x = fmaf(vs, fmaf(2.f, t1, cur.b * dy), g_x);
-            g_y = fmaf(vs, fmaf(2.f, t2, t3), g_y);
-            const float hs = 0.5f * vs;
-            const float hd = hs * dx, he = hs * dy;
-            g_ca = fmaf(hd, dx, g_ca);
-            g_cb = fmaf(hd, dy, g_cb);
-            g_cc = fmaf(he, dy, g_cc);
+            const float p = vs * dx, qq = vs * dy;
+            m_x += p;
+            m_y += qq;
+            s_xx = fmaf(p, dx, s_xx);
+            s_xy = fmaf(p, dy, s_xy);
+            s_yy = fmaf(qq, dy, s_yy);
             g_r = fmaf(facm, vo0[q], g_r);
             g_g = fmaf(facm, vo1[q], g_g);
             g_b = fmaf(facm, vo2[q], g_b);
@@ -761,8 +766,8 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
         }
         if (__ballot(any) != 0ull) {  // wave-uniform
             if constexpr (REDUCE == 1) {
-                float t0 = fold16(fold32(g_x, g_y), fold32(g_ca, g_cb));     // rows: x, ca, y, cb
-                float t1 = fold16(fold32(g_cc, g_r), fold32(g_g, g_b));      // rows: cc, g, r, b
+                float t0 = fold16(fold32(m_x, m_y), fold32(s_xx, s_xy));     // rows: m_x, s_xx, m_y, s_xy
+                float t1 = fold16(fold32(s_yy, g_r), fold32(g_g, g_b));      // rows: s_yy, g, r, b
                 float t2 = fold16(fold32(g_o, 0.f), 0.f);                    // rows: o, 0, 0, 0
                 t0 = row_sum_dpp(t0); t1 = row_sum_dpp(t1); t2 = row_sum_dpp(t2);
                 const int c = lane & 15, row = lane >> 4;
@@ -772,16 +777,16 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
                     unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + (c * 4 + rowmap), mine);
             } else {
                 if (!(dbg & 2)) {          // dbg bit1: ablation only, skip the wave reduction (results are wrong)
-                    g_x = wave_sum(g_x); g_y = wave_sum(g_y);
-                    g_ca = wave_sum(g_ca); g_cb = wave_sum(g_cb); g_cc = wave_sum(g_cc);
+                    m_x = wave_sum(m_x); m_y = wave_sum(m_y);
+                    s_xx = wave_sum(s_xx); s_xy = wave_sum(s_xy); s_yy = wave_sum(s_yy);
                     g_r = wave_sum(g_r); g_g = wave_sum(g_g); g_b = wave_sum(g_b);
                     g_o = wave_sum(g_o);
                 }
-                float mine = g_x;
-                mine = (lane == 1) ? g_y : mine;
-                mine = (lane == 2) ? g_ca : mine;
-                mine = (lane == 3) ? g_cb : mine;
-                mine = (lane == 4) ? g_cc : mine;
+                float mine = m_x;
+                mine = (lane == 1) ? m_y : mine;
+                mine = (lane == 2) ? s_xx : mine;
+                mine = (lane == 3) ? s_xy : mine;
+                mine = (lane == 4) ? s_yy : mine;
                 mine = (lane == 5) ? g_r : mine;
                 mine = (lane == 6) ? g_g : mine;
                 mine = (lane == 7) ? g_b : mine;
@@ -919,6 +924,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 
 // rows [row0, row0 + n) of the packed gradient workspace -> the n rows of the four output arrays
 __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, int row0, const float *__restrict__ ws,
+                                                           const float *__restrict__ conics,
                                                            const float *__restrict__ opac, int opac_is_logit,
                                                            float *__restrict__ v_xy, float *__restrict__ v_conic,
                                                            float *__restrict__ v_colors,
@@ -928,10 +934,12 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, int row0, cons
     const float4 a = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 0];
     const float4 b = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 1];
     const float4 c = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 2];
-    v_xy[2 * i] = a.x; v_xy[2 * i + 1] = a.y;
-    // the walk accumulates 0.5 * v_sigma * (dx^2, dx dy, dy^2) (one shared half-scale); the public v_conic[:,1] is the
-    // TRUE derivative dL/d(conic.y) = sum v_sigma dx dy, so the off-diagonal slot is doubled here (exact scaling)
-    v_conic[3 * i] = a.z; v_conic[3 * i + 1] = 2.f * a.w; v_conic[3 * i + 2] = b.x;
+    // moments -> gradients with this Gaussian's conic: sigma = (A dx^2 + C dy^2) / 2 + B dx dy, so
+    //   v_xy = (A m_x + B m_y, B m_x + C m_y),  v_conic = (s_xx / 2, s_xy, s_yy / 2)  ([:,1] is the TRUE dL/dB)
+    const float A = conics[3 * i], B = conics[3 * i + 1], C = conics[3 * i + 2];
+    v_xy[2 * i] = fmaf(A, a.x, B * a.y);
+    v_xy[2 * i + 1] = fmaf(B, a.x, C * a.y);
+    v_conic[3 * i] = 0.5f * a.z; v_conic[3 * i + 1] = a.w; v_conic[3 * i + 2] = 0.5f * b.x;
     v_colors[3 * i] = b.y; v_colors[3 * i + 1] = b.z; v_colors[3 * i + 2] = b.w;
     float vo = c.x;
     if (opac_is_logit) {  // chain through the fused sigmoid
@@ -1177,7 +1185,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
     SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -3);
     if (n == 0) return 0;
-    SGN_ARG_CHECK(v_xy && v_conic && v_colors && v_opacity && grad_ws && opacities, -4);
+    SGN_ARG_CHECK(v_xy && v_conic && v_colors && v_opacity && grad_ws && opacities && conics, -4);
     SGN_ARG_CHECK(grad_ws_bytes >= sgn_raster_bwd_workspace_bytes(n), -5);
     SGN_ARG_CHECK(alpha_clamp_bwd > 0.f && alpha_clamp_bwd < 1.f, -6);
     hipStream_t s = (hipStream_t)stream;
@@ -1245,7 +1253,8 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         const int n_out = window ? id_hi - id_lo : n, row0 = window ? id_lo : 0;
         if (n_out > 0)
             hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n_out, 256)), dim3(256), 0, s, n_out, row0,
-                               (const float *)grad_ws, opacities, opacity_is_logit, v_xy, v_conic, v_colors, v_opacity);
+                               (const float *)grad_ws, conics, opacities, opacity_is_logit, v_xy, v_conic, v_colors,
+                               v_opacity);
     }
     sgn_timing_end(SGN_T_UNPACK, s);
     SGN_LAUNCH_CHECK();
