@@ -1,0 +1,65 @@
+"""Child process of tests/test_gpu_reference_literal.py::test_patched_call_sites_run_on_the_fused_ops (test
+infrastructure).  argv[1] = a directory holding a copy of the reference's model files WITH
+integration/fused_callsites.patch applied.  Runs the patched `SplatfactoModel.get_outputs` + loss + backward literally
+on the HIP ops (fused front ends) and compares with the un-patched call pattern's replay (`sgn_rast.step.render`, which
+test_gpu_reference_literal.py pins to the un-patched literal run bit for bit).  Prints one line per check."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "street-gaussians-ns_amd"), os.path.join(ROOT, "tests")]
+os.environ["SGN_REFERENCE_ROOT"] = sys.argv[1]
+import torch
+
+import refhost
+from helpers import rel_l2
+from sgn_rast import ops, scenes, step
+
+DEV = "cuda"
+W, H, FOCAL = 96, 64, 80.0
+REF2OURS = dict(means="means", scales="log_scales", quats="quats", features_dc="features_dc",
+                features_rest="features_rest", opacities="opacity_logits")
+ns = refhost.load("hip")
+src = open(ns.splat.__file__).read()
+assert "sgn_fused.project_gaussians_fused" in src and "depth_channel=True" in src, "the patch is not applied"
+to_dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
+
+cam = scenes.make_camera(W, H, FOCAL)
+raw = scenes.make_gaussians(3000, cam, seed=0, z_range=(1.0, 5.0))
+model = refhost.build_single(ns, to_dev(raw), sky_res=0).to(DEV)
+camera = refhost.nerfstudio_camera(ns, cam, time=0.0).to(DEV)
+g = torch.Generator().manual_seed(5)
+batch = {"image": torch.rand(H, W, 3, generator=g).to(DEV)}
+ops.clear_binning_cache()
+out = model.get_outputs(camera)                       # the reference's code with the fused call sites, literally
+sum(model.get_loss_dict(out, batch).values()).backward()
+
+cam_d = scenes.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.viewmat.to(DEV), cam.cam_pos.to(DEV))
+P = step.leaf_params(to_dev(raw))
+ops.clear_binning_cache()
+exp = step.render(P, cam_d, with_depth=True)           # un-patched call pattern on the drop-in ops
+rgb = torch.clamp(exp.rgb, max=1.0)
+from sgn_rast import loss as LS
+gt = batch["image"]
+l = 0.8 * torch.abs(gt - rgb).mean() + 0.2 * (1 - LS.SSIM(data_range=1.0, size_average=True, channel=3)(
+    gt.permute(2, 0, 1)[None], rgb.permute(2, 0, 1)[None]))
+l.backward()
+torch.cuda.synchronize()
+ok = True
+for name, a, b in (("rgb", out["rgb"], rgb), ("accumulation", out["accumulation"][..., 0], exp.alpha),
+                   ("depth", out["depth"], exp.depth)):
+    err = (a.detach() - b.detach()).abs()
+    good = float(err.mean()) < 1e-6 and float((err > 1e-4).float().mean()) < 2e-3
+    ok &= good
+    print(f"fused-patch {name}: mean|err| {float(err.mean()):.2e} max {float(err.max()):.2e} -> {'PASS' if good else 'FAIL'}")
+worst = 0.0
+for ref_name, ours in REF2OURS.items():
+    r = rel_l2(model.gauss_params[ref_name].grad.cpu(), P[ours].grad.cpu())
+    worst = max(worst, r)
+good = worst < 1e-4
+ok &= good
+print(f"fused-patch leaf gradients: worst rel-L2 {worst:.2e} -> {'PASS' if good else 'FAIL'}")
+r = rel_l2(model.xys.grad.cpu(), exp.xys.grad.cpu())
+ok &= r < 1e-4
+print(f"fused-patch retained xys.grad: rel-L2 {r:.2e} -> {'PASS' if r < 1e-4 else 'FAIL'}")
+sys.exit(0 if ok else 1)
