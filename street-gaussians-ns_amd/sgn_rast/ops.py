@@ -39,6 +39,90 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
 
+
+# ------------------------------------------------------------------ host state
+# Everything the host side remembers between calls — the binning cache and its pending prefetch, the speculative
+# capacities, deferred argument checks, pinned read-back slots, the depth-channel and early-rank speculation — lives in
+# ONE object per (device, stream) (these were module globals with one entry each).  Two models,
+# cameras or threads that work on different streams never see each other's state; callers that interleave on ONE
+# stream are served by small LRUs (four binnings, four depth channels, four launch orders) instead of one slot each.
+# A single (device, stream) must not be driven from two threads at once (as with any stream-ordered library).
+import collections
+
+
+class _State:
+    BIN_ENTRIES = 4
+
+    def __init__(self):
+        self.bin_cache = {"key": None, "keep": None, "val": None}      # the most recent binning (window matching)
+        self.bin_older = collections.OrderedDict()                     # key -> (keep, val) of the three before it
+        self.bin_pending = {"key": None, "state": None, "keep": None}
+        self.order_cache = collections.OrderedDict()                   # (id(tile_bins), thresh) -> (tile_bins, order)
+        self.last_count: dict = {}     # key -> slowly decaying maximum of the counts seen (views of one scene differ)
+        self.pending_checks: list = []
+        self.side = None               # [pinned int32[4,8] (count + up to 7 deferred-check flags per prepare), next slot]
+        self.eager_side = None         # [pinned int32[8] ring for the eager flag read-back, next slot]
+        self.depth_state = {"want": False, "unused": 0, "cache": None}
+        self.depth_caches = collections.OrderedDict()                  # binning key -> first pass's channel + state
+        self.early = {"entry": None, "misses": 0, "pause": 0}
+
+    # -- binning cache: most recent entry + a short LRU behind it
+    def find_binning(self, key):
+        if self.bin_cache["key"] == key:
+            return self.bin_cache["val"]
+        hit = self.bin_older.pop(key, None)
+        if hit is None:
+            return None
+        self._retire_current()
+        self.bin_cache["key"], (self.bin_cache["keep"], self.bin_cache["val"]) = key, hit
+        return hit[1]
+
+    def has_binning(self, key) -> bool:
+        return self.bin_cache["key"] == key or key in self.bin_older
+
+    def store_binning(self, key, keep, val) -> None:
+        self._retire_current()
+        self.bin_cache["key"], self.bin_cache["keep"], self.bin_cache["val"] = key, keep, val
+
+    def _retire_current(self) -> None:
+        k = self.bin_cache["key"]
+        if k is not None:
+            self.bin_older[k] = (self.bin_cache["keep"], self.bin_cache["val"])
+            while len(self.bin_older) > self.BIN_ENTRIES - 1:
+                old, _ = self.bin_older.popitem(last=False)
+                self.depth_caches.pop(old, None)
+
+    def clear_binning(self) -> None:
+        self.bin_cache["key"] = self.bin_cache["keep"] = self.bin_cache["val"] = None
+        self.bin_older.clear()
+        self.order_cache.clear()
+        self.depth_caches.clear()
+        self.depth_state["cache"] = None
+
+
+_states: dict = {}
+
+
+def _S() -> _State:
+    """The state object of the current device's current stream."""
+    k = (torch.cuda.current_device(), L.stream_handle()) if torch.cuda.is_available() else (-1, 0)
+    st = _states.get(k)
+    if st is None:
+        st = _states[k] = _State()
+    return st
+
+
+_STATE_ALIASES = {"_bin_cache": "bin_cache", "_bin_pending": "bin_pending", "_last_count": "last_count",
+                  "_pending_checks": "pending_checks", "_depth_state": "depth_state", "_early": "early",
+                  "_order_cache": "order_cache"}
+
+
+def __getattr__(name):          # ops._bin_cache etc.: the CURRENT (device, stream)'s objects (tests, diagnostics)
+    if name in _STATE_ALIASES:
+        return getattr(_S(), _STATE_ALIASES[name])
+    raise AttributeError(name)
+
+
 # --------------------------------------------------------------------- sh
 def num_sh_bases(degree: int) -> int:
     """gsplat/sh.py num_sh_bases (reference: sgn_splatfacto.py:268)."""
@@ -170,8 +254,6 @@ class _ProjectGaussians(Function):
 # does): the flag is read at the NEXT host sync the path has anyway (the intersection-count read-back inside
 # rasterize_gaussians), raising the same AssertionError there — no sync of its own; "off" skips the test.
 quat_check = os.environ.get("SGN_QUAT_CHECK", "eager")
-_pending_checks: list = []
-_eager_side = {}   # per device: pinned int32[8] ring for the eager flag read-back
 
 
 def _check_quats(quats: torch.Tensor):
@@ -185,19 +267,20 @@ def _check_quats(quats: torch.Tensor):
     flag = torch.empty(1, dtype=torch.int32, device=q.device)
     L.check(L.load().sgn_check_unit_quats(q.shape[0], L.ptr(q), 1e-6, L.ptr(flag), L.stream_ptr()),
             "sgn_check_unit_quats")
+    S = _S()
     if quat_check == "eager":
-        if q.device not in _eager_side:
-            _eager_side[q.device] = [torch.empty(8, dtype=torch.int32).pin_memory(), 0]
-        ring = _eager_side[q.device]
+        if S.eager_side is None:
+            S.eager_side = [torch.empty(8, dtype=torch.int32).pin_memory(), 0]
+        ring = S.eager_side
         slot = ring[0][ring[1] % 8:ring[1] % 8 + 1]
         ring[1] += 1
         slot.copy_(flag, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
         return slot, done, flag
-    if len(_pending_checks) >= 16:     # projections without a rasterize call in between: settle the backlog now
+    if len(S.pending_checks) >= 16:    # projections without a rasterize call in between: settle the backlog now
         raise_pending_checks()
-    _pending_checks.append(flag)
+    S.pending_checks.append(flag)
     return None
 
 
@@ -210,9 +293,9 @@ def _finish_quat_check(token) -> None:
 
 def raise_pending_checks() -> None:
     """Called right after an existing host sync: the flags are already final, reading them costs no stall."""
-    failed = False
-    while _pending_checks:
-        failed |= bool(int(_pending_checks.pop().item()))
+    failed, pending = False, _S().pending_checks
+    while pending:
+        failed |= bool(int(pending.pop().item()))
     assert not failed, "quats must be normalized"
 
 
@@ -230,7 +313,6 @@ early_rank = os.environ.get("SGN_EARLY_RANK", "auto")      # "auto": with the ea
 # projection and joined by the rasterize call — a host sync of the CALLER's stream right after the projection (the
 # reference's `radii.sum() == 0`, sgn_splatfacto.py:878) then returns while the ranking still runs
 early_rank_stream = os.environ.get("SGN_EARLY_RANK_STREAM", "main")
-_early = {"entry": None, "misses": 0, "pause": 0}
 early_rank_stats = {"started": 0, "used": 0}
 
 
@@ -240,6 +322,7 @@ def _start_early_rank(depths: torch.Tensor, radii: torch.Tensor) -> None:
         return
     if n == 0 or not depths.is_cuda or not tile_culling_enabled:
         return
+    _early = _S().early
     if _early["pause"] > 0:
         _early["pause"] -= 1
         return
@@ -275,6 +358,7 @@ def _start_early_rank(depths: torch.Tensor, radii: torch.Tensor) -> None:
 
 def _take_early_rank(depths: torch.Tensor, radii: torch.Tensor):
     """The ranking `project_gaussians` started for exactly these tensors (float32 depths / int32 radii), or None."""
+    _early = _S().early
     e = _early["entry"]
     if e is None or depths.dtype != torch.float32 or radii.dtype != torch.int32:
         return None
@@ -391,7 +475,6 @@ def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_boun
                                           conics, opacity, opacity_is_logit, cull))
 
 
-_side = {}   # per device: [pinned int32[4,8] (count + up to 7 deferred-check flags per in-flight prepare), next slot]
 
 
 def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
@@ -422,15 +505,16 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
                                 L.ptr(gid_by_rank), int(early is not None), L.ptr(bin_recs), L.ptr(ws), ws.numel(),
                                 L.stream_ptr()),
             "sgn_bin_prepare")
-    if dev not in _side:
-        _side[dev] = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]
-    pool = _side[dev]
+    S = _S()
+    if S.side is None:
+        S.side = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]
+    pool = S.side
     pinned = pool[0][pool[1] % 4]          # rotate: a prepare that is still pending keeps its own slot
     pool[1] += 1
     # pending argument checks ride along: their flags reach the host in the same transfer as the count, so the
     # deferred assertion costs no round trip of its own.  The copies are queued on the current stream (a side stream
     # would add an event hop of ~15 us before the copy even starts); work queued afterwards simply follows them.
-    flags = [_pending_checks.pop() for _ in range(min(len(_pending_checks), 7))]
+    flags = [S.pending_checks.pop() for _ in range(min(len(S.pending_checks), 7))]
     pinned[0:1].copy_(cum_r[n - 1:n], non_blocking=True)
     for i, f in enumerate(flags):
         pinned[1 + i:2 + i].copy_(f, non_blocking=True)
@@ -444,7 +528,6 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
 speculative_binning = os.environ.get("SGN_SPECULATIVE_BINNING", "1") != "0"   # queue emission + tile sort behind
                                # the count copy, sized from the previous call
 _SPEC_MARGIN = 1.3             # capacity = recent peak count of the same (n, tile grid) x this
-_last_count: dict = {}         # key -> slowly decaying maximum of the counts seen (views of one scene differ)
 
 
 def _bin_finish(st):
@@ -460,6 +543,7 @@ def _bin_finish(st):
     view changed abruptly) the plain form runs with the real count, exactly as without speculation."""
     i32 = dict(dtype=torch.int32, device=st["dev"])
     tile_bins, n = st["tile_bins"], st["n"]
+    binning_stats["binnings"] += 1
     if n == 0:
         tile_bins.zero_()
         return 0, torch.zeros(0, **i32), tile_bins
@@ -475,6 +559,8 @@ def _bin_finish(st):
 
     key = (st["dev"], n, st["tx"], st["ty"], st["block"])
     cap, spec_ids = 0, None
+    S = _S()
+    _last_count = S.last_count
     if speculative_binning and _last_count.get(key, 0) > 0:
         cap = min(int(_last_count[key] * _SPEC_MARGIN) + 1024, (1 << 31) - 1)
         spec_ids = run(cap, C.c_void_p(st["cum_r"].data_ptr() + 4 * (n - 1)))
@@ -482,7 +568,7 @@ def _bin_finish(st):
     num_intersects = int(st["pinned"][0])
     failed = any(int(st["pinned"][1 + i]) for i in range(st["n_flags"]))
     assert not failed, "quats must be normalized"
-    if _pending_checks:                    # checks queued after the prefetch (rare): one more read-back
+    if S.pending_checks:                   # checks queued after the prefetch (rare): one more read-back
         raise_pending_checks()
     _last_count[key] = max(num_intersects, int(0.9 * _last_count.get(key, 0)))
     if spec_ids is not None and 0 < num_intersects <= cap:
@@ -496,13 +582,12 @@ def _bin_finish(st):
     return num_intersects, run(num_intersects, None), tile_bins
 
 
-binning_stats = {"speculative_hits": 0, "speculative_misses": 0}
+binning_stats = {"speculative_hits": 0, "speculative_misses": 0, "binnings": 0}
 
 
 tile_order_enabled = True
 concurrent_backward = True   # lend sgn_raster_bwd a second stream: its short-walk and long-walk kernels overlap
 small_splat_q16 = 0       # experimental: > 0 sends tiles with < q/16 evaluated (entry, quadrant) pairs per walked entry to the 4-waves kernel (no gain measured: profiles/r02_street_balance.md)
-_order_cache = {"bins": None, "order": None, "thresh": None}
 
 
 def _fwd_long_thresh(ro) -> int:
@@ -516,15 +601,20 @@ def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = Non
     with the count of walks >= ``long_thresh`` behind the permutation (the two-kernel adaptive scheme)."""
     if not tile_order_enabled:
         return None
-    if tile_kmax is None and _order_cache["bins"] is tile_bins and _order_cache["thresh"] == int(long_thresh):
-        return _order_cache["order"]
+    oc = _S().order_cache
+    ok = (id(tile_bins), int(long_thresh))
+    if tile_kmax is None and ok in oc and oc[ok][0] is tile_bins:
+        oc.move_to_end(ok)
+        return oc[ok][1]
     n_tiles = tile_bins.shape[0]
     order = torch.empty(n_tiles + 2, dtype=torch.int32, device=tile_bins.device)   # permutation, n_long, cursor
     L.check(L.load().sgn_tile_order(n_tiles, L.ptr(tile_bins), L.ptr(tile_kmax), int(long_thresh),
                                     int(small_splat_q16) if tile_kmax is not None else 0, L.ptr(order),
                                     L.stream_ptr()), "sgn_tile_order")
     if tile_kmax is None:
-        _order_cache["bins"], _order_cache["order"], _order_cache["thresh"] = tile_bins, order, int(long_thresh)
+        oc[ok] = (tile_bins, order)          # (keeps tile_bins alive: its id cannot be recycled while the entry lives)
+        while len(oc) > 4:
+            oc.popitem(last=False)
     return order
 
 
@@ -535,7 +625,6 @@ def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = Non
 # The cache keeps detached aliases of the four geometry tensors, so their storage cannot be freed
 # and re-used by the allocator while the entry is alive: equal data_ptr + equal version counter then
 # really means "same bytes".
-_bin_cache = {"key": None, "keep": None, "val": None}
 binning_cache_enabled = True
 
 
@@ -545,10 +634,11 @@ def _bin_key(tensors, tile_bounds, block_width, flags):
 
 
 def clear_binning_cache() -> None:
-    _bin_cache["key"] = _bin_cache["keep"] = _bin_cache["val"] = None
+    """Forget every cached binning (all devices / streams)."""
+    for st in _states.values():
+        st.clear_binning()
 
 
-_bin_pending = {"key": None, "state": None, "keep": None}
 
 
 def _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity, opacity_is_logit):
@@ -561,9 +651,11 @@ def _drop_pending() -> None:
     """A prepared binning that will never be finished (its rasterize call did not come, or a later prefetch replaces
     it) still carries deferred argument-check flags in its read-back slot: hand them back to the backlog so the
     "quats must be normalized" assertion is not lost (advisor finding, round 1)."""
+    S = _S()
+    _bin_pending = S.bin_pending
     st = _bin_pending["state"]
     if st is not None and st.get("keep") is not None:
-        _pending_checks.extend(st["keep"][-1])
+        S.pending_checks.extend(st["keep"][-1])
     _bin_pending["key"] = _bin_pending["state"] = _bin_pending["keep"] = None
 
 
@@ -577,9 +669,11 @@ def prefetch_binning(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
     tile_bounds = ((img_width + block_width - 1) // block_width, (img_height + block_width - 1) // block_width, 1)
     key, tensors, cull = _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
                                     opacity_is_logit)
-    if binning_cache_enabled and _bin_cache["key"] == key:
+    S = _S()
+    if binning_cache_enabled and S.has_binning(key):
         return
     _drop_pending()
+    _bin_pending = S.bin_pending
     _bin_pending["state"] = _bin_prepare_async(xys.size(0), xys, depths, radii, num_tiles_hit, tile_bounds, block_width,
                                                conics, opacity, opacity_is_logit, cull)
     _bin_pending["key"] = key
@@ -590,8 +684,12 @@ def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bo
                           opacity, opacity_is_logit):
     key, tensors, cull = _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
                                     opacity_is_logit)
-    if binning_cache_enabled and _bin_cache["key"] == key:
-        return _bin_cache["val"]
+    S = _S()
+    if binning_cache_enabled:
+        val = S.find_binning(key)
+        if val is not None:
+            return val
+    _bin_pending = S.bin_pending
     if _bin_pending["key"] == key:
         state = _bin_pending["state"]
     else:
@@ -601,8 +699,7 @@ def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bo
     _bin_pending["key"] = _bin_pending["state"] = _bin_pending["keep"] = None
     val = _bin_finish(state)
     if binning_cache_enabled:
-        _bin_cache["key"], _bin_cache["val"] = key, val
-        _bin_cache["keep"] = tuple(t.detach() for t in tensors)
+        S.store_binning(key, tuple(t.detach() for t in tensors), val)
     return val
 
 
@@ -621,7 +718,8 @@ window_stats = {"tried": 0, "hit": 0}
 
 def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacity, cull):
     """(lo, cached value, n_full) when the call's geometry equals rows [lo, lo + n) of the cached scene, else None."""
-    ck, keep, val = _bin_cache["key"], _bin_cache["keep"], _bin_cache["val"]
+    S = _S()
+    ck, keep, val = S.bin_cache["key"], S.bin_cache["keep"], S.bin_cache["val"]
     if ck is None or not window_matching_enabled or not binning_cache_enabled or n <= 0:
         return None
     if ck[len(keep):] != key_tail or val[0] < 1:       # tile grid, block, flags (logit / cull), stream
@@ -652,16 +750,16 @@ def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacit
         w[5], f[5] = w[5].reshape(-1), f[5].reshape(-1)
     L.check(lib.sgn_rows_match(n, n_full, len(cands), lo_host, *[L.ptr(t) for t in w], *[L.ptr(t) for t in f],
                                L.ptr(flags), L.stream_ptr()), "sgn_rows_match")
-    if dev not in _side:
-        _side[dev] = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]
-    pool = _side[dev]
+    if S.side is None:
+        S.side = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]
+    pool = S.side
     pinned = pool[0][pool[1] % 4]
     pool[1] += 1
     pinned[0:len(cands)].copy_(flags[0:len(cands)], non_blocking=True)
     done = torch.cuda.Event()
     done.record()
     done.synchronize()
-    if _pending_checks:
+    if S.pending_checks:
         raise_pending_checks()
     for i, lo in enumerate(cands):
         if int(pinned[i]) == 0:
@@ -681,12 +779,11 @@ def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacit
 # call on the very tensors of the previous one with other colours), and stops again when the calls stop coming;
 # "on" / "off" force it.  The fused API asks for the channel explicitly (rasterize_gaussians_fused(depth_channel=True)).
 depth_channel = os.environ.get("SGN_DEPTH_CHANNEL", "auto")
-_depth_state = {"want": False, "unused": 0, "cache": None}
 depth_stats = {"accumulated": 0, "reused": 0}
 
 
 def _depth_wanted() -> bool:
-    return depth_channel == "on" or (depth_channel == "auto" and _depth_state["want"])
+    return depth_channel == "on" or (depth_channel == "auto" and _S().depth_state["want"])
 
 
 def _provably_depths(colors: torch.Tensor, depths: torch.Tensor) -> bool:
@@ -733,7 +830,9 @@ class _RasterizeGaussians(Function):
         stream_ptr = L.stream_ptr()
         key, _t, cull = _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
                                    opacity_is_logit)
-        hit = binning_cache_enabled and _bin_cache["key"] == key
+        S = _S()
+        _bin_pending, _depth_state = S.bin_pending, S.depth_state
+        hit = binning_cache_enabled and S.has_binning(key)
         # a sub-model's copy of a window of the cached scene?  (drop-in scene-graph path; see _match_window)
         n_full, window, win = num_points, 0, None
         if id_range is None and not hit and _bin_pending["key"] != key:
@@ -746,9 +845,9 @@ class _RasterizeGaussians(Function):
         # depth channel: is this the reference's depth pass over the geometry of the pass before it (answer it from that
         # pass's fourth channel), or a first pass that should accumulate the channel?
         plain = win is None and id_range is None and num_points > 0 and bool(ro.gather) and cull
-        dcache = _depth_state["cache"]
+        dcache = S.depth_caches.get(key)
         reuse = (plain and hit and not want_depth and depth_channel != "off" and dcache is not None
-                 and dcache["key"] == key and colors_c.shape == (num_points, 3))
+                 and colors_c.shape == (num_points, 3))
         if plain and hit and not reuse and depth_channel == "auto" and not want_depth:
             _depth_state["want"] = True        # a second pass over the same geometry: accumulate from the next step on
         accumulate = plain and not reuse and not hit and (want_depth or _depth_wanted())
@@ -819,12 +918,14 @@ class _RasterizeGaussians(Function):
                 _depth_state["unused"] = 0
             elif accumulate:
                 depth_stats["accumulated"] += 1
-                _depth_state["cache"] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
+                S.depth_caches[key] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
+                while len(S.depth_caches) > _State.BIN_ENTRIES:
+                    S.depth_caches.popitem(last=False)
                 _depth_state["unused"] += 1
                 if _depth_state["unused"] > 8 and depth_channel == "auto":   # the depth passes stopped coming
                     _depth_state["want"], _depth_state["unused"] = False, 0
             elif not hit:
-                _depth_state["cache"] = None   # another scene was binned: the cached channel is not its image
+                S.depth_caches.pop(key, None)  # re-binned without the channel: a stale image must not answer later
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
         ctx.num_intersects = num_intersects
         ctx.opacity_is_logit = int(bool(opacity_is_logit))

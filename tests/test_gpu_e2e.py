@@ -346,3 +346,52 @@ def test_early_depth_rank_is_picked_up_and_changes_nothing():
     finally:
         ops.early_rank = old
         ops._early.update(entry=None, misses=0, pause=0)
+
+
+def test_two_models_interleaved_on_one_stream_keep_their_binnings():
+    """the host-side caches were one-entry module globals — two models taking turns on one stream
+    re-binned on every call.  The state is now per (device, stream) with a short LRU: A, B, A-depth, B-depth must bin
+    twice, not four times, and give the images of the un-interleaved order."""
+    from helpers import activated, small_scene
+    from sgn_rast import ops
+
+    def geometry(seed):
+        cam, P = small_scene(n=3000, w=160, h=96, focal=160.0, seed=seed)
+        scales, quats, opac, _ = activated(P)
+        out = ops.project_gaussians(P["means"].to(DEV), scales.to(DEV), 1, quats.to(DEV), cam.viewmat[:3, :].to(DEV),
+                                    cam.fx, cam.fy, cam.cx, cam.cy, cam.height, cam.width, 16)
+        rgbs = torch.rand(3000, 3, generator=torch.Generator().manual_seed(seed)).to(DEV)
+        return cam, out, rgbs, opac.to(DEV)
+
+    def raster(g, depth_pass):
+        cam, (xys, depths, radii, conics, _c, nth, _v), rgbs, opac = g
+        col = depths[:, None].repeat(1, 3) if depth_pass else rgbs
+        return ops.rasterize_gaussians(xys, depths, radii, conics, nth, col, opac, cam.height, cam.width, 16,
+                                       torch.zeros(3, device=DEV))
+
+    old = ops.depth_channel
+    ops.depth_channel = "off"                       # plain binning reuse is what is under test
+    try:
+        with torch.no_grad():
+            ops.clear_binning_cache()
+            A, B = geometry(1), geometry(2)
+            seq = [raster(A, False), raster(A, True), raster(B, False), raster(B, True)]      # un-interleaved
+            ops.clear_binning_cache()
+            n0 = ops.binning_stats["binnings"]
+            got = [raster(A, False), raster(B, False), raster(A, True), raster(B, True)]       # taking turns
+            torch.cuda.synchronize()
+            assert ops.binning_stats["binnings"] - n0 == 2
+            assert torch.equal(got[0], seq[0]) and torch.equal(got[2], seq[1])
+            assert torch.equal(got[1], seq[2]) and torch.equal(got[3], seq[3])
+            # another stream has a state of its own
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                assert ops._bin_cache["key"] is None
+                again = raster(A, False)
+                assert ops._bin_cache["key"] is not None
+            side.synchronize()
+            assert torch.equal(again, seq[0]) and ops.binning_stats["binnings"] - n0 == 3
+    finally:
+        ops.depth_channel = old
+        ops.clear_binning_cache()
