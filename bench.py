@@ -491,7 +491,11 @@ def main():
                               "deg 3, rgb+alpha pass, depth pass (the shape of get_outputs_for_camera, "
                               "scripts/eval.py:98-112 reports 1 / this time as fps)"}
 
-    # per-kernel HIP-event spans (library brackets each launch on its own stream), separate short pass
+    # per-kernel HIP-event spans (library brackets each launch on its own stream), separate short pass.  The forward-only
+    # lines above rendered depth, which taught the "auto" depth-channel policy to accumulate the fourth channel; the
+    # headline step renders none, so the policy is put back to where the timed loop had it.
+    if not args.with_depth and sg is None:
+        ops._depth_state.update(want=False, unused=0)
     L.timing_enable(True)
     k_steps = max(3, min(args.steps, 10))
     for _ in range(k_steps):
