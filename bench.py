@@ -538,14 +538,16 @@ def main():
         # PMC numbers come from separate rocprofv3 passes (counters cannot be read from inside this process);
         # profiles/roofline_pmc.json holds them per kernel with the files they were read from.  They belong to the
         # default workload only.
-        traffic, pmc = None, None
+        traffic, pmc, kernel_bound = None, None, None
         default_workload = (args.scene == "metric" and not args.n and not args.street and not args.translucent
                             and sg is None)
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "roofline_pmc.json")))
-            if default_workload and dom in pj:
-                pmc = pj[dom]
-                traffic = pmc.get("hbm_traffic_bytes")
+            if dom in pj:
+                kernel_bound = pj[dom].get("bound")      # what limits the KERNEL (its counters): any workload
+                if default_workload:                     # the counter VALUES belong to the default workload only
+                    pmc = pj[dom]
+                    traffic = pmc.get("hbm_traffic_bytes")
         except Exception:
             pass
         bytes_per_walked = {"raster_bwd": 112, "raster_fwd": 40, "pack_records": 40}[dom]
@@ -572,7 +574,7 @@ def main():
                                   "issue_cycle_frac": insts * v["issue_cycles_per_inst"] / simd_cycles,
                                   "active_counter_vs_saturated_mix": v.get("counter_frac_calibrated"),
                                   "source": v.get("source")}
-        measured_bound = (pmc or {}).get("bound")
+        measured_bound = kernel_bound
         line = {
             "metric": "train-step images/sec (fwd+bwd) @1M Gaussians 1920x1280",
             "value": world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
