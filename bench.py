@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--scene", default="metric", choices=["c1", "c2", "metric", "c4"])
     ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=2, help="tile rows rendered by the CPU baseline sample")
+    ap.add_argument("--cpu-rows", type=int, default=8,
+                    help="tile rows composited by the pure-PyTorch CPU baseline sample (of 80 at 1920x1280; projection, SH "
+                         "and binning always run on ALL Gaussians): 8 rows = ~15-20 s on the GPU box's 32 host cores")
     ap.add_argument("--cpu-frac", type=int, default=1,
                     help="CPU baseline uses the first N/frac Gaussians of the scene (1 = all: nothing is extrapolated over "
                          "the Gaussian count, whose cost is not linear because of early termination)")
@@ -614,6 +616,8 @@ def main():
         line["config"]["quat_check"] = ops.quat_check
         line["config"]["sort_ranking"] = dict(L.SORT_RANKING)
         line["config"]["speculative_binning"] = dict(enabled=bool(ops.speculative_binning), **ops.binning_stats)
+        line["config"]["early_rank"] = dict(mode=ops.early_rank, **ops.early_rank_stats)
+        line["config"]["depth_channel"] = dict(mode=ops.depth_channel, **ops.depth_stats)
         if args.street:
             line["metric"] = "train-step images/sec (fwd+bwd), non-uniform street-like content (profiling workload)"
             line["config"]["workload"] = "street: " + line["config"]["workload"]

@@ -779,7 +779,7 @@ def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacit
 # call on the very tensors of the previous one with other colours), and stops again when the calls stop coming;
 # "on" / "off" force it.  The fused API asks for the channel explicitly (rasterize_gaussians_fused(depth_channel=True)).
 depth_channel = os.environ.get("SGN_DEPTH_CHANNEL", "auto")
-depth_stats = {"accumulated": 0, "reused": 0}
+depth_stats = {"accumulated": 0, "reused": 0, "proved_on_host": 0}
 
 
 def _depth_wanted() -> bool:
@@ -888,6 +888,7 @@ class _RasterizeGaussians(Function):
                                         L.ptr(final_idx), L.ptr(bg_c), L.ptr(out_img), None, None, 0, None, None,
                                         stream_ptr), "sgn_depth_reuse")
             depth_stats["reused"] += 1
+            depth_stats["proved_on_host"] += 1
             _depth_state["unused"] = 0
         elif num_intersects < 1:
             recs = None

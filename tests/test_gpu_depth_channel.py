@@ -73,6 +73,7 @@ def test_second_call_is_answered_from_the_depth_channel_bit_equal(mode):
     rgb1, a1, d1, _ = _two_calls("on")
     assert ops.depth_stats["accumulated"] == before["accumulated"] + 1
     assert ops.depth_stats["reused"] == before["reused"] + 1
+    assert ops.depth_stats["proved_on_host"] == before["proved_on_host"]       # no graph: the device-side comparison
     rgb0, a0, d0, _ = _two_calls("off")
     assert ops.depth_stats["reused"] == before["reused"] + 1          # "off": two real passes
     assert torch.equal(rgb1, rgb0) and torch.equal(a1, a0)            # the colour pass is untouched by the 4th channel
@@ -81,7 +82,11 @@ def test_second_call_is_answered_from_the_depth_channel_bit_equal(mode):
 
 
 def test_backward_of_the_answered_pass_equals_the_two_pass_backward(mode):
+    from sgn_rast import ops
+    proved = ops.depth_stats["proved_on_host"]
     _, _, d1, g1 = _two_calls("on", with_grad=True)
+    # with a graph behind the projection the library proves `colors is depths[:, None].repeat(1, 3)` on the host
+    assert ops.depth_stats["proved_on_host"] == proved + 1
     _, _, d0, g0 = _two_calls("off", with_grad=True)
     assert torch.equal(d1, d0)
     for k in g0:
