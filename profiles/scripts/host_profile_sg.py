@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path[:0] = [ROOT, os.path.join(ROOT, "street-gaussians-ns_amd")]
 import torch
 from sgn_rast import ops, scenes, step
-ops.quat_check = "deferred"
+ops.quat_check = os.environ.get("SGN_QUAT_CHECK", "eager")
 dev = torch.device("cuda", 0)
 cam, raw = scenes.make_scene("metric", device=dev)
 n = raw["means"].shape[0]

@@ -909,7 +909,12 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
 // extra waves take issue slots from the concurrently running long-walk kernel, which is the critical path there
 // (long-walk kernel 613 -> 768 us, step 1.97 -> 2.24 ms, profiles/experiments/r02_packed_forward_notes.md).
 template <bool EXACT, int REDUCE, bool GATHER>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void raster_bwd_short_kernel(
+// (re-measured in r03 with the moment-form body, profiles/scripts/r03o.sh: 5 or 6 waves change nothing on the benchmark
+// scene — 0.276-0.279 ms — and cost the street scene 8 %: 490 vs 535-540 images/s)
+#ifndef SGN_BWD_SHORT_WAVES_MAX
+#define SGN_BWD_SHORT_WAVES_MAX 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, SGN_BWD_SHORT_WAVES_MAX))) void raster_bwd_short_kernel(
     int W, int H, int B, int tiles_x, int n_tiles, const int2 *__restrict__ bins, const Rec *__restrict__ recs,
     const int32_t *__restrict__ ids, const float *__restrict__ bg, const float *__restrict__ final_T,
     const int32_t *__restrict__ final_idx, const float *__restrict__ v_out, const float *__restrict__ v_out_alpha,
