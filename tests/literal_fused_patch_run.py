@@ -62,4 +62,39 @@ print(f"fused-patch leaf gradients: worst rel-L2 {worst:.2e} -> {'PASS' if good 
 r = rel_l2(model.xys.grad.cpu(), exp.xys.grad.cpu())
 ok &= r < 1e-4
 print(f"fused-patch retained xys.grad: rel-L2 {r:.2e} -> {'PASS' if r < 1e-4 else 'FAIL'}")
+
+# ---- the scene graph on the patched file: its main pass goes through the patched SplatfactoModel.get_outputs (fused
+# projection / SH / rasterization + depth channel), its sub-model passes through the patched render_gaussian_attrs with
+# concatenated colours (original SH branch, fused rasterization)
+models, poses, _ = scenes.make_scene_graph(4000, cam, n_objects=3, object_frac=0.3, fourier_dim=5, seed=0,
+                                           z_range=(1.0, 5.0))
+graph, stamps = refhost.build_scene_graph(ns, [to_dev(m) for m in models], poses, sky_res=0)
+graph = graph.to(DEV)
+frame = 1
+camera = refhost.nerfstudio_camera(ns, cam, time=float(stamps[frame])).to(DEV)
+ops.clear_binning_cache()
+out = graph.get_outputs(camera)
+(out["rgb"].sum() + out["accumulation"].sum() + out["object_acc"].sum()).backward()
+p_t, idft = refhost.scene_graph_tables(ns, models, poses, frame)
+Ms = [step.leaf_params(to_dev(m)) for m in models]
+ops.clear_binning_cache()
+exp = step.render_scene_graph(Ms, p_t.to(DEV), idft.to(DEV), cam_d)
+(torch.clamp(exp.rgb, max=1.0).sum() + exp.alpha.sum() + exp.object_acc.sum()).backward()
+torch.cuda.synchronize()
+for name, a, b in (("rgb", out["rgb"], torch.clamp(exp.rgb, max=1.0)), ("accumulation", out["accumulation"][..., 0], exp.alpha),
+                   ("depth", out["depth"], exp.depth), ("object_acc", out["object_acc"][..., 0], exp.object_acc),
+                   ("background_acc", out["background_acc"][..., 0], exp.background_acc)):
+    err = (a.detach() - b.detach()).abs()
+    good = float(err.mean()) < 2e-6 and float((err > 1e-4).float().mean()) < 2e-3
+    ok &= good
+    print(f"fused-patch scene graph {name}: mean|err| {float(err.mean()):.2e} max {float(err.max()):.2e} -> {'PASS' if good else 'FAIL'}")
+names = ["background"] + [f"object_t{k}" for k in range(1, len(models))]
+worst = 0.0
+for i, name in enumerate(names):
+    for ref_name, ours in REF2OURS.items():
+        g_ref = graph.all_models[name].gauss_params[ref_name].grad
+        worst = max(worst, rel_l2(g_ref.cpu(), Ms[i][ours].grad.cpu()))
+good = worst < 1e-4
+ok &= good
+print(f"fused-patch scene graph leaf gradients: worst rel-L2 {worst:.2e} -> {'PASS' if good else 'FAIL'}")
 sys.exit(0 if ok else 1)
