@@ -100,7 +100,8 @@ class _State:
         self.depth_state["cache"] = None
 
 
-_states: dict = {}
+_states: "collections.OrderedDict" = collections.OrderedDict()
+_MAX_STATES = 16        # programs that keep creating streams must not pin a cache (device memory) per stream for ever
 
 
 def _S() -> _State:
@@ -109,6 +110,10 @@ def _S() -> _State:
     st = _states.get(k)
     if st is None:
         st = _states[k] = _State()
+        while len(_states) > _MAX_STATES:          # least recently CREATED goes (its caches are only speed)
+            _, old = _states.popitem(last=False)
+            old.clear_binning()
+            old.pending_checks.clear()              # (eager mode keeps nothing pending; deferred flags of a dead stream)
     return st
 
 
