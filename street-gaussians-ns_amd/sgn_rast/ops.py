@@ -113,7 +113,10 @@ def _S() -> _State:
         while len(_states) > _MAX_STATES:          # least recently CREATED goes (its caches are only speed)
             _, old = _states.popitem(last=False)
             old.clear_binning()
-            old.pending_checks.clear()              # (eager mode keeps nothing pending; deferred flags of a dead stream)
+            failed = False                          # deferred argument checks of that stream are settled, not dropped
+            while old.pending_checks:
+                failed |= bool(int(old.pending_checks.pop().item()))
+            assert not failed, "quats must be normalized"
     return st
 
 
