@@ -57,7 +57,9 @@ def test_exchange_and_reducer_over_single_rank_rccl_group(fused):
         Pb = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
         ex = dp.SHGradExchange(Pb["features_dc"], Pb["features_rest"], force=True).install()
         red = dp.GradAllReducer(list(Pb.values()), big=[Pb["features_rest"]], sh_exchange=ex, force=True)
-        red.world = 2  # pretend: SUM over 1 rank, then the averaging divides the flat bucket by 2
+        # pretend world = 2 with the host-side averaging (what gloo uses; on RCCL the average is ReduceOp.AVG inside the
+        # collective, which a 1-rank group cannot show): SUM over 1 rank, then the flat bucket is divided by 2
+        red.world, red._avg_in_collective, red._op = 2, False, dist.ReduceOp.SUM
         try:
             step.train_step(Pb, cam, w_img, w_a, fused=fused, reducer=red)
         finally:
@@ -67,5 +69,15 @@ def test_exchange_and_reducer_over_single_rank_rccl_group(fused):
         for k in Pa:
             scale = 1.0 if k in ("features_dc", "features_rest") else 0.5   # exchange averages over world=1
             assert rel_l2(Pb[k].grad, scale * Pa[k].grad) < 1e-5, k
+        # ... and the production form on RCCL: the average taken by the collective itself (1 rank: identity)
+        Pc = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+        red = dp.GradAllReducer(list(Pc.values()), big=[Pc["features_rest"]], force=True, overlap=True)
+        assert red._avg_in_collective
+        step.train_step(Pc, cam, w_img, w_a, fused=fused, reducer=red)
+        red.remove()
+        torch.cuda.synchronize()
+        assert red.stats["bucket_early"] == 1
+        for k in Pa:
+            assert rel_l2(Pc[k].grad, Pa[k].grad) < 1e-5, k
     finally:
         dist.destroy_process_group()
