@@ -122,8 +122,10 @@ def test_two_ranks_follow_one_rank_accumulating_two_views(problem, tmp_path):
     acc = C.fit_schedule(start, gts, device=DEV, views_per_step=2, steps=steps)
     out = str(tmp_path / "dp.pt")
     env = dict(os.environ, SGN_DP_BACKEND="gloo", SGN_BENCH_SHARE_GPU="1")
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29571", os.path.join(os.path.dirname(__file__), "dp_convergence_worker.py"),
+           "127.0.0.1", "--master-port", str(port), os.path.join(os.path.dirname(__file__), "dp_convergence_worker.py"),
            out, str(steps)]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=800)
     assert r.returncode == 0, r.stderr[-3000:]
