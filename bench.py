@@ -339,11 +339,22 @@ def main():
                 print(json.dumps(err), file=sys.stderr, flush=True)
         watchdog = dp.Watchdog(args.dp_watchdog, on_hang)
 
-    def one_step(fused=(args.path == "fused"), caller_syncs=args.caller_syncs):
+    # eight views on a ring of yaw offsets around this rank's own (the `varying_camera` line: a trainer renders another
+    # camera every step, so the intersection count moves and the speculative buffers are sized from other views)
+    ring = [scenes.make_camera(cam.width, cam.height, cam.fx, yaw=0.01 * rank + 0.02 * (v - 4), device=dev) for v in range(8)]
+    step_no = [0]
+
+    def one_step(fused=(args.path == "fused"), caller_syncs=args.caller_syncs, vary_camera=False):
         if watchdog is not None:
             watchdog.beat()
         if sg is None:
-            out = step.train_step(P, cam, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer,
+            view = cam
+            if vary_camera:
+                view = ring[step_no[0] % len(ring)]
+                step_no[0] += 1
+                if reducer is not None and reducer.sh_exchange is not None:
+                    reducer.sh_exchange.set_view(P["means"], view.cam_pos)
+            out = step.train_step(P, view, w_img, w_a, 3, 16, with_depth=args.with_depth, reducer=reducer,
                                   fused=fused, sky=sky, gt=gt_img, caller_syncs=caller_syncs)
             if adam is not None:
                 optim.step_many(adam)
@@ -440,8 +451,17 @@ def main():
 
     # the same drop-in step (a) with the two host syncs the reference's model code makes around the operators, on top
     # of the library defaults, and (b) with the opt-in deferred argument check
-    sync_extra = deferred_extra = None
+    sync_extra = deferred_extra = vary_extra = None
     if args.path == "dropin" and sg is None and not args.caller_syncs and not args.no_fused_extra:
+        h0 = dict(ops.binning_stats)
+        vary_extra = timed_variant(vary_camera=True)
+        vary_extra["speculative_hits"] = ops.binning_stats["speculative_hits"] - h0["speculative_hits"]
+        vary_extra["speculative_misses"] = ops.binning_stats["speculative_misses"] - h0["speculative_misses"]
+        vary_extra["note"] = ("library defaults, a different camera every step (eight views on a ring of 0.02 rad yaw "
+                              "offsets): the intersection count changes from step to step, the speculative emission is "
+                              "sized from other views' counts")
+        if reducer is not None and reducer.sh_exchange is not None:
+            reducer.sh_exchange.set_view(P["means"], cam.cam_pos)
         sync_extra = timed_variant(caller_syncs=True)
         sync_extra["note"] = ("library defaults plus the reference model's own host syncs "
                               "(sgn_splatfacto.py:878 `radii.sum() == 0`, :944 `(num_tiles_hit > 0).any()`): the "
@@ -644,6 +664,8 @@ def main():
             line["with_caller_syncs"] = sync_extra
         if deferred_extra is not None:
             line["deferred_check"] = deferred_extra
+        if vary_extra is not None:
+            line["varying_camera"] = vary_extra
         if eval_extra is not None:
             line["eval_images_per_s"] = eval_extra
         if world == 1 and not args.no_cpu_baseline:
