@@ -88,6 +88,9 @@ def parse():
     ap.add_argument("--dp-watchdog", type=float, default=float(os.environ.get("SGN_DP_WATCHDOG_S", "90")),
                     help="N>1: seconds without a finished step after which the run prints a JSON error line and exits "
                          "(a collective that some rank never joins would otherwise block the lease)")
+    ap.add_argument("--no-dp-safe-first", action="store_true",
+                    help="N > 1: skip the plain dense / no-overlap measurement that is otherwise taken FIRST and kept as "
+                         "the fallback line should the optimised exchange fail or hang")
     ap.add_argument("--dp-exchange", default="lowrank", choices=["lowrank", "dense"],
                     help="N>1: SH gradient via all-gathered low-rank factors (default) or dense all-reduce")
     return ap.parse_args()
@@ -240,6 +243,9 @@ def cpu_baseline_bounded(args):
                 "sample": f"pure-PyTorch oracle did not finish its bounded sample within {args.cpu_timeout:.0f}s"}
 
 
+_on_failure = [None]      # set by main() for N-rank runs: prints the kept headline line (or the error line) and exits
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -282,15 +288,29 @@ def main():
         raw["opacity_logits"] = raw["opacity_logits"] - 2.0
     P = step.leaf_params(raw)
     w_img, w_a = step.loss_weights(cam, seed=1000 + rank, device=dev)
-    reducer = None
-    if world > 1 or force_dp:
+    def make_reducer(safe=False):
+        """The gradient exchange of the N-rank step.  `safe`: one dense all-reduce per tensor after the backward, SUM +
+        a division on the device — nothing but `all_reduce`; the default adds the low-rank SH exchange (all-gathers),
+        averaging inside the collective and the overlap hooks."""
+        if safe:
+            return dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], force=force_dp, overlap=False,
+                                     collective_average=False)
         ex = None
         if args.dp_exchange == "lowrank":
             # the harness knows its camera: gather 12 B of camera position instead of [N,3] view directions
             ex = dp.SHGradExchange(P["features_dc"], P["features_rest"], force=force_dp).install().set_view(
                 P["means"], cam.cam_pos)
-        reducer = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex, force=force_dp,
-                                    overlap=not args.no_dp_overlap)
+        return dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex, force=force_dp,
+                                 overlap=not args.no_dp_overlap)
+
+    # N > 1: the plain exchange is measured first and its line kept; the optimised exchange must then run, agree with it
+    # and finish, or the kept line is what rank 0 prints (no RCCL run of either has ever been possible before the
+    # driver's own: `safe_first` makes the first one yield a number whatever the optimised path does)
+    safe_first = (world > 1 and not args.no_dp_safe_first and not args.scene_graph and not args.sky
+                  and (args.dp_exchange == "lowrank" or not args.no_dp_overlap))
+    reducer = None
+    if world > 1 or force_dp:
+        reducer = make_reducer(safe=safe_first)
     n_gauss = P["means"].shape[0]
 
     sg = None
@@ -326,18 +346,39 @@ def main():
         if sky is not None:
             adam.append(optim.FusedAdam([sky["base"]], lr=0.01, eps=1e-15))
 
+    # Failure containment for N-rank runs.  `kept["line"]` is the last COMPLETE headline measurement; once it exists, a
+    # later phase that raises or hangs (the optimised exchange, an extra line) makes rank 0 print it — marked — and every
+    # rank leave with status 0, instead of the job ending without a number.  Before it exists the error line is printed.
     watchdog = None
+    kept = {"line": None}
+
+    def give_up(reason):
+        if watchdog is not None:
+            watchdog.stop()
+        print(f"[bench rank {rank}] giving up: {reason}", file=sys.stderr, flush=True)
+        if kept["line"] is not None:
+            if rank == 0:
+                line = kept["line"]
+                line["config"].setdefault("dp", {})["abandoned_phase"] = reason
+                os.write(real_stdout, (json.dumps(line) + "\n").encode())
+            sys.stderr.flush()
+            os._exit(0)
+        err = {"metric": "train-step images/sec (fwd+bwd) @1M Gaussians 1920x1280", "value": None,
+               "unit": "images/sec", "n_gpus": world, "error": reason,
+               "config": {"parallelism": f"dp{world}", "backend": torch.distributed.get_backend()
+                          if torch.distributed.is_initialized() else None}}
+        if rank == 0:        # ONE line on stdout, as for a good run; the other ranks report on stderr
+            os.write(real_stdout, (json.dumps(err) + "\n").encode())
+        else:
+            print(json.dumps(err), file=sys.stderr, flush=True)
+        os._exit(3)
+
     if world > 1 or force_dp:
         def on_hang(idle):
-            err = {"metric": "train-step images/sec (fwd+bwd) @1M Gaussians 1920x1280", "value": None,
-                   "unit": "images/sec", "n_gpus": world, "error": f"rank {rank}: no step finished for {idle:.0f} s "
-                   "(a collective some rank never joined, or a dead peer); aborting instead of holding the lease",
-                   "config": {"parallelism": f"dp{world}", "backend": torch.distributed.get_backend()}}
-            if rank == 0:        # ONE line on stdout, as for a good run; the other ranks report on stderr
-                os.write(real_stdout, (json.dumps(err) + "\n").encode())
-            else:
-                print(json.dumps(err), file=sys.stderr, flush=True)
+            give_up(f"rank {rank}: no step finished for {idle:.0f} s (a collective some rank never joined, or a dead "
+                    "peer); aborting instead of holding the lease")
         watchdog = dp.Watchdog(args.dp_watchdog, on_hang)
+        _on_failure[0] = give_up
 
     # eight views on a ring of yaw offsets around this rank's own (the `varying_camera` line: a trainer renders another
     # camera every step, so the intersection count moves and the speculative buffers are sized from other views)
@@ -379,38 +420,96 @@ def main():
 
     if os.environ.get("SGN_BENCH_HANG_RANK") == str(rank) and world > 1:
         time.sleep(3600)     # failure-containment test: this rank never joins the collectives (profiles/scripts/r03c.sh)
-    for _ in range(max(0, args.settle)):
-        one_step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        out = one_step()
-    torch.cuda.synchronize()
-    # A full (generation-2) garbage collection over the ~1e6 objects that importing torch leaves behind takes ~50 ms
-    # on this host and lands somewhere inside a 200-step window (profiles/r02e: one 20-step chunk at 4.07 ms/step,
-    # the rest at 1.60).  Standard remedy for latency-sensitive loops: collect now and move the survivors to the
-    # permanent generation; garbage created by the steps themselves is still collected (young generations).
     import gc
-    gc.collect()
-    if os.environ.get("SGN_BENCH_GC_FREEZE", "1") == "1":
-        gc.freeze()
-    n_isect = int(out.num_tiles_hit.sum().item()) if args.warmup else 0
-
-    barrier(); torch.cuda.synchronize()
     trace = [] if os.environ.get("SGN_BENCH_TRACE") else None     # debugging: host time stamps, no device sync
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = one_step()
-        if trace is not None and (i + 1) % 20 == 0:
-            trace.append(time.perf_counter())
-    torch.cuda.synchronize(); barrier()
-    dt = time.perf_counter() - t0
-    if trace:
-        print("host ms/step per 20:", [round(1e3 * (b - a) / 20, 3) for a, b in zip([t0] + trace[:-1], trace)],
-              file=sys.stderr, flush=True)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+
+    def measure_headline(settle):
+        """W untimed steps, then EXACTLY K timed steps between barrier + synchronize pairs; max over ranks."""
+        for _ in range(max(0, settle)):
+            one_step()
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            out_ = one_step()
+        torch.cuda.synchronize()
+        # A full (generation-2) garbage collection over the ~1e6 objects that importing torch leaves behind takes ~50 ms
+        # on this host and lands somewhere inside a 200-step window (profiles/r02e: one 20-step chunk at 4.07 ms/step,
+        # the rest at 1.60).  Standard remedy for latency-sensitive loops: collect now and move the survivors to the
+        # permanent generation; garbage created by the steps themselves is still collected (young generations).
+        gc.collect()
+        if os.environ.get("SGN_BENCH_GC_FREEZE", "1") == "1":
+            gc.freeze()
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out_ = one_step()
+            if trace is not None and (i + 1) % 20 == 0:
+                trace.append(time.perf_counter())
+        torch.cuda.synchronize(); barrier()
+        dt_ = time.perf_counter() - t0
+        if trace:
+            print("host ms/step per 20:", [round(1e3 * (b - a) / 20, 3) for a, b in zip([t0] + trace[:-1], trace)],
+                  file=sys.stderr, flush=True)
+            del trace[:]
+        if world > 1:
+            t = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, out_
+
+    def exchange_name(safe):
+        if safe:
+            return "dense all-reduce of every gradient after the backward (SUM, divided on the device)"
+        return ("SH grads " + ("all-gathered as low-rank factors" if args.dp_exchange == "lowrank" else "dense all-reduce")
+                + ", geometry grads in one bucket" + ("" if args.no_dp_overlap else ", overlapped with the backward"))
+
+    def headline_line(dt_, parallelism):
+        """The contract's keys for a finished headline measurement (kept as the fallback line; the full line adds the
+        roofline block, per-kernel times and the extra lines)."""
+        return {"metric": "train-step images/sec (fwd+bwd) @1M Gaussians 1920x1280",
+                "value": world * args.steps / dt_, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": 1e3 * dt_ / args.steps, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{args.scene}: {n_gauss} Gaussians, {cam.width}x{cam.height}, SH deg 3 (K=16), "
+                                       "block 16, fwd+bwd", "parallelism": parallelism, "path": args.path,
+                           "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None},
+                "roofline": None, "note": "fallback line: a later phase of the run failed (config.dp.abandoned_phase)"}
+
+    dp_paths, safe_reducer = None, None
+    dt, out = measure_headline(args.settle)
+    if safe_first:
+        dt_safe, safe_reducer = dt, reducer
+        kept["line"] = headline_line(dt_safe, f"dp{world} (view-parallel; {exchange_name(True)})")
+        watchdog.seconds = min(watchdog.seconds, 30.0)     # a step is milliseconds; the fallback line is in hand
+        ref = {k: p.grad.detach().clone() for k, p in P.items()}      # averaged gradients of the last plain step
+        reducer = make_reducer(safe=False)
+        fail = os.environ.get("SGN_BENCH_FAIL_OPT", "")             # failure-injection for the containment test
+        if fail == f"raise:{rank}":
+            raise RuntimeError("injected failure in the optimised exchange (SGN_BENCH_FAIL_OPT)")
+        if fail == f"hang:{rank}":
+            time.sleep(3600)
+        one_step()                                                  # same inputs, the optimised exchange
+        worst = torch.stack([(P[k].grad - ref[k]).norm() / ref[k].norm().clamp_min(1e-30) for k in P]).max()
+        torch.distributed.all_reduce(worst, op=torch.distributed.ReduceOp.MAX)
+        worst = float(worst.item())
+        if not worst < 1e-4:
+            raise RuntimeError(f"optimised exchange disagrees with the dense all-reduce: rel-L2 {worst:.3e}")
+        del ref
+        dt_opt, out = measure_headline(0)
+        dp_paths = {"dense_after_backward": {"value": world * args.steps / dt_safe, "ms_per_step": 1e3 * dt_safe / args.steps},
+                    "optimised": {"value": world * args.steps / dt_opt, "ms_per_step": 1e3 * dt_opt / args.steps,
+                                  "exchange": exchange_name(False), "grad_rel_l2_vs_dense": worst},
+                    "headline": "optimised" if dt_opt <= dt_safe else "dense_after_backward"}
+        if dt_opt <= dt_safe:
+            dt = dt_opt
+        else:                      # the plain exchange is faster on this machine: it is the headline and runs the extras
+            if reducer.sh_exchange is not None:
+                reducer.sh_exchange.remove()
+            reducer.remove()
+            reducer, dt = safe_reducer, dt_safe
+        kept["line"] = headline_line(dt, f"dp{world} (view-parallel; {exchange_name(reducer is safe_reducer)})")
+        kept["line"]["config"]["dp"] = {"paths": dp_paths}
+    elif world > 1:
+        kept["line"] = headline_line(dt, f"dp{world} (view-parallel; {exchange_name(False)})")
     n_isect = int(out.num_tiles_hit.sum().item())
 
     # the same function through the fused front ends (extension API), reported beside the headline
@@ -605,8 +704,7 @@ def main():
             "config": {"workload": (f"{args.scene}: {n_gauss} Gaussians, {cam.width}x{cam.height}, SH deg 3 (K=16), "
                                     f"block 16, fwd+bwd{' + depth pass' if args.with_depth else ''}; "
                                     f"measured I={n_isect} tile intersections/view"),
-                       "parallelism": (f"dp{world} (view-parallel; RCCL all-reduce of geometry grads, SH grads "
-                                       f"{'all-gathered as low-rank factors' if args.dp_exchange == 'lowrank' else 'dense all-reduce'})"
+                       "parallelism": (f"dp{world} (view-parallel; {exchange_name(safe_reducer is not None and reducer is safe_reducer)})"
                                        if world > 1 else "single"),
                        "n_gaussians": n_gauss, "n_isect": n_isect},
             # achieved / peak / frac follow SURVEY.md section 8d's contract formula (every upstream-semantic intersection
@@ -630,6 +728,9 @@ def main():
                                     "visible_devices": torch.cuda.device_count(),
                                     "peer_access": dp.peer_access_matrix(),
                                     "reducer_stats": dict(reducer.stats) if reducer is not None else None}
+            if dp_paths is not None:
+                # both exchanges were measured, the plain one first (kept as the fallback line while the other ran)
+                line["config"]["dp"]["paths"] = dp_paths
             if os.environ.get("SGN_BENCH_SHARE_GPU") == "1":
                 line["config"]["note"] = "ranks SHARE GPUs (functional check of the N-rank path, not a scaling number)"
         line["config"]["settle_steps"] = max(0, args.settle)   # untimed, before the W warm-up steps
@@ -682,4 +783,11 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except Exception as e:
+        if _on_failure[0] is None:
+            raise
+        import traceback
+        traceback.print_exc()
+        _on_failure[0](f"{type(e).__name__}: {e}")

@@ -144,7 +144,7 @@ class GradAllReducer:
 
     def __init__(self, params: Sequence[torch.Tensor], big: Iterable[torch.Tensor] = (),
                  average: bool = True, group=None, sh_exchange: "Optional[SHGradExchange]" = None,
-                 force: bool = False, overlap: bool = False):
+                 force: bool = False, overlap: bool = False, collective_average: Optional[bool] = None):
         self.sh_exchange = sh_exchange
         skip = sh_exchange.leaf_ids() if sh_exchange is not None else set()
         self.params = [p for p in params if id(p) not in skip]
@@ -157,7 +157,11 @@ class GradAllReducer:
         self.overlap = bool(overlap) and self.active
         # RCCL averages inside the collective (ReduceOp.AVG): no division pass over the bucket / the big tensors
         # afterwards (44 MB + 180 MB of read-modify-write per step at 1 M Gaussians); gloo has no AVG
+        # (``collective_average=False`` keeps the plain SUM + division: the most conservative form, what bench.py's
+        # fallback measurement uses)
         self._avg_in_collective = bool(average and dist.is_initialized() and dist.get_backend(group) == "nccl")
+        if collective_average is not None:
+            self._avg_in_collective = self._avg_in_collective and bool(collective_average)
         self._op = dist.ReduceOp.AVG if self._avg_in_collective else dist.ReduceOp.SUM
         self._bucket = None            # (flat, work, versions) once the bucket has left
         self._arrived = 0
