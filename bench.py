@@ -739,6 +739,7 @@ def main():
         line["config"]["speculative_binning"] = dict(enabled=bool(ops.speculative_binning), **ops.binning_stats)
         line["config"]["early_rank"] = dict(mode=ops.early_rank, **ops.early_rank_stats)
         line["config"]["depth_channel"] = dict(mode=ops.depth_channel, **ops.depth_stats)
+        line["config"]["quadrant_masks"] = dict(mode=ops.quadrant_masks, **ops.quadrant_mask_stats)
         if args.street:
             line["metric"] = "train-step images/sec (fwd+bwd), non-uniform street-like content (profiling workload)"
             line["config"]["workload"] = "street: " + line["config"]["workload"]

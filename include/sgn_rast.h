@@ -64,6 +64,8 @@ typedef struct sgn_raster_opts {
     int xcd_swizzle;    /* 1: XCD-aware tile -> workgroup order (contiguous tile band per XCD / L2); default 0 */
     int debug_flags;    /* timing ablations for profiles/ ONLY (results become wrong): bit0 = no gradient atomics,
                            bit1 = no wave reduction; 0 = normal operation */
+    int ids_qmask;      /* 1: gaussian_ids_sorted carries quadrant masks in bits 28-31 (sgn_bin_intersect with
+                           quadrant_masks) — a property of the list handed in, not a tuning knob; default 0 */
 } sgn_raster_opts;
 void sgn_raster_default_opts(sgn_raster_opts *out);
 
@@ -243,11 +245,20 @@ size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect);
  * count turns out to be <= the capacity the outputs are exactly those of the plain form (rows [0, count) of
  * gaussian_ids_sorted); if it is larger nothing is written out of bounds, the outputs are meaningless and the caller
  * must call again with the real count.  The GPU then works through the emission and the tile sort while the host
- * waits for the count instead of idling through the host's wake-up. */
+ * waits for the count instead of idling through the host's wake-up.
+ *
+ * quadrant_masks != 0 (16x16 tiles, n < SGN_QMASK_MAX_IDS; no upstream counterpart): every entry of
+ * gaussian_ids_sorted carries, in bits 28-31, which of its tile's four 8x8 quadrants the Gaussian can reach with
+ * alpha >= 1/255 (bit q: x half = q & 1, y half = q >> 1) — the exact convex test of the culling, evaluated per half
+ * band — and the Gaussian id in bits 0-27 (SGN_QMASK_ID_BITS).  The raster kernels then skip quadrants from these bits
+ * (sgn_raster_opts.ids_qmask = 1) instead of testing the ellipse's bounding box per entry.  With culling off every
+ * entry gets 0xF. */
+#define SGN_QMASK_ID_BITS 28
+#define SGN_QMASK_MAX_IDS (1 << SGN_QMASK_ID_BITS)
 int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                       const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
-                      int32_t *gaussian_ids_sorted /*[n_isect]*/, int32_t *tile_bins /*[tiles,2]*/, void *ws,
-                      size_t ws_bytes, const int32_t *n_isect_dev, sgn_stream_t stream);
+                      int32_t *gaussian_ids_sorted /*[n_isect]*/, int32_t *tile_bins /*[tiles,2]*/,
+                      int quadrant_masks, void *ws, size_t ws_bytes, const int32_t *n_isect_dev, sgn_stream_t stream);
 
 /* Window recognition for the drop-in scene-graph path (no upstream counterpart).  The reference renders its sub-model
  * passes (sgn_splatfacto_scene_graph.py:364-366) from torch.cat COPIES of per-model slices of the main projection
@@ -267,8 +278,9 @@ int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *cand_lo_hos
  * tile_stats (sgn_raster_fwd's output) - the reverse-walk length the backward will see; with small_q16 > 0 a tile whose
  * forward evaluated fewer than small_q16 / 16 (entry, quadrant) pairs per walked entry (small splats) counts as long.
  * Results do not depend on the order; on skewed content it removes the tail of late-starting long tiles, and n_long
- * drives the backward's two-kernel adaptive scheme (sgn_raster_bwd).  `order` has n_tiles + 2 entries (the last one is
- * a work cursor sgn_raster_bwd's persistent kernel advances: one order buffer serves ONE backward launch). */
+ * drives the backward's two-kernel adaptive scheme (sgn_raster_bwd).  `order` has n_tiles + 2 entries; the last one is
+ * 0, or - with tile_stats, images of up to 16384 tiles - 1000 * (list entries the forward WALKED before its tiles
+ * saturated) / (entries listed): the statistic the host's quadrant-mask policy reads back (sgn_bin_intersect). */
 int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_stats, int long_thresh, int small_q16,
                    int32_t *order, sgn_stream_t stream);
 

@@ -291,6 +291,24 @@ __device__ __forceinline__ void row_interval(const Ellipse &E, int ty, int block
     hi = min(hi, t_hi);
 }
 
+// Quadrant masks (r03).  The raster kernels skip the 8x8 quadrants of a tile an entry cannot touch; they used to decide
+// that per entry from the axis-aligned box of the ellipse (two subtractions, two compares, a ballot — and 10 % of the
+// quadrants it lets through have no valid pixel, because the ellipse is not its box).  The emission already holds the
+// exact convex test, so it evaluates it once more per tile row for the two 8-pixel half bands and hands each
+// (tile, Gaussian) pair its four bits in the top of the id word (ids < 2^28): bit q = quadrant (x half = q & 1,
+// y half = q >> 1), the numbering of raster.hip's slot_pixel.  Same margins as the tile test; a pair whose ellipse
+// slips between the pixel centres of every quadrant gets 0 and is skipped by the kernels.
+// x-extent [x_min, x_max] (absolute pixels) of the ellipse over the band Y in [y0, y1] (relative to its centre)
+__device__ __forceinline__ bool band_extent(const Ellipse &E, float y0, float y1, float &x_min, float &x_max) {
+    const float ya = fmaxf(y0, -E.y_ext), yb = fminf(y1, E.y_ext);
+    if (ya > yb) return false;
+    const float yr = fminf(fmaxf(E.y_at_xmax, ya), yb);
+    const float yl = fminf(fmaxf(-E.y_at_xmax, ya), yb);
+    x_max = (-E.b * yr + fast_sqrt(fmaxf(E.two_as - E.D * yr * yr, 0.f))) * E.inv_a + 1e-3f + E.gx;
+    x_min = (-E.b * yl - fast_sqrt(fmaxf(E.two_as - E.D * yl * yl, 0.f))) * E.inv_a - 1e-3f + E.gx;
+    return true;
+}
+
 // Output sinks of the tile expansion below.
 struct NoOut {
     __device__ __forceinline__ void operator()(int, uint32_t, int32_t) const {}
@@ -372,7 +390,8 @@ struct FlatScratch {
 // Must be called by all 64 lanes of the wave.
 template <bool EMIT, class Out>
 __device__ __forceinline__ int tiles_of(bool live, const Ellipse &E, int mnx, int mny, int mxx, int mxy, int gid,
-                                        int base, int tiles_x, int block, FlatScratch &fs, const Out &out) {
+                                        int base, int tiles_x, int block, FlatScratch &fs, const Out &out,
+                                        int qmask = 0) {
     const int lane = threadIdx.x & 63;
     const int h = (live && mxx > mnx) ? mxy - mny : 0;
     const int rend = wave_incl_scan_dpp(h);
@@ -406,7 +425,41 @@ __device__ __forceinline__ int tiles_of(bool live, const Ellipse &E, int mnx, in
             const int incl = wave_incl_scan_dpp(c);
             const int val = fs.gid[g];
             int pos = pos0 + incl - c;
-            for (int tx = lo; tx <= hi; ++tx, ++pos) out(pos, (uint32_t)(ty * tiles_x + tx), val);
+            if (qmask) {                                     // wave-uniform; 16x16 tiles only (the host checks)
+                // the two half bands' x-extents as inclusive ranges of HALF COLUMNS (h = 2 tx + x half; pixel centres
+                // 8h + 0.5 .. 8h + 7.5): h is touched iff x_max >= 8h + 0.5 and x_min <= 8h + 7.5
+                int ht_lo = 1, ht_hi = 0, hb_lo = 1, hb_hi = 0;     // empty
+                if (c > 0 && B.valid == 1) {
+                    const float yt = (float)(ty * 16) + 0.5f - B.gy;
+                    float x0, x1;
+                    if (band_extent(B, yt, yt + 7.f, x0, x1)) {
+                        ht_lo = sgn_f2i(ceilf(fmaxf(x0 - 7.5f, -1.0e6f) * 0.125f));
+                        ht_hi = sgn_f2i(floorf(fminf(x1 - 0.5f, 1.0e6f) * 0.125f));
+                    }
+                    if (band_extent(B, yt + 8.f, yt + 15.f, x0, x1)) {
+                        hb_lo = sgn_f2i(ceilf(fmaxf(x0 - 7.5f, -1.0e6f) * 0.125f));
+                        hb_hi = sgn_f2i(floorf(fminf(x1 - 0.5f, 1.0e6f) * 0.125f));
+                    }
+                }
+                if (B.valid == 2) { ht_lo = hb_lo = -(1 << 29); ht_hi = hb_hi = 1 << 29; }   // degenerate conic: all
+                // bit i of a run word: half column `base + i`; 32 half columns = 16 tiles per word
+                auto run = [](int h_lo, int h_hi, int base) __attribute__((always_inline)) -> unsigned {
+                    const int a = max(h_lo - base, 0), b = min(h_hi - base, 31);
+                    return a > b ? 0u : (((2u << (b - a)) - 1u) << a);
+                };
+                unsigned run_t = run(ht_lo, ht_hi, 2 * lo), run_b = run(hb_lo, hb_hi, 2 * lo);
+                int i = 0;
+                for (int tx = lo; tx <= hi; ++tx, ++pos, i += 2) {
+                    if (i == 32) {                           // a row wider than 16 tiles: next word
+                        run_t = run(ht_lo, ht_hi, 2 * tx); run_b = run(hb_lo, hb_hi, 2 * tx);
+                        i = 0;
+                    }
+                    const unsigned m = ((run_t >> i) & 3u) | (((run_b >> i) & 3u) << 2);
+                    out(pos, (uint32_t)(ty * tiles_x + tx), (int32_t)((uint32_t)val | (m << 28)));
+                }
+            } else {
+                for (int tx = lo; tx <= hi; ++tx, ++pos) out(pos, (uint32_t)(ty * tiles_x + tx), val);
+            }
             pos0 += __builtin_amdgcn_readlane(incl, 63);
         } else if (c > 0) {
             atomicAdd(&fs.acc[g], c);
@@ -465,7 +518,7 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
                                                       const BinRec *__restrict__ recs, int tiles_x, int tiles_y,
                                                       int block, TK *__restrict__ tkeys,
                                                       int32_t *__restrict__ tvals, int cap,
-                                                      int32_t *__restrict__ zero_buf, int zero_n) {
+                                                      int32_t *__restrict__ zero_buf, int zero_n, int qmask) {
     __shared__ TK lk[EMIT_CAP];
     __shared__ int32_t lv[EMIT_CAP];
     __shared__ FlatScratch scratch;
@@ -493,16 +546,16 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
     }
     const Ellipse E = make_ellipse(gx, gy, a, b, c, s);
     if (base + total > cap) {                                 // wave-uniform; only a mis-sized speculative launch
-        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, BoundedOut<TK>{tkeys, tvals, cap});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, BoundedOut<TK>{tkeys, tvals, cap}, qmask);
     } else if (total <= EMIT_CAP) {
-        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, LdsOut<TK>{lk, lv, base});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, LdsOut<TK>{lk, lv, base}, qmask);
         __syncthreads();                                      // single-wave workgroup: a fence, no s_barrier
         for (int j = lane; j < total; j += 64) {
             tkeys[base + j] = lk[j];
             tvals[base + j] = lv[j];
         }
     } else {
-        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, GlobalOut<TK>{tkeys, tvals});
+        tiles_of<true>(live, E, mnx, mny, mxx, mxy, gid, base, tiles_x, block, scratch, GlobalOut<TK>{tkeys, tvals}, qmask);
     }
 }
 
@@ -551,7 +604,8 @@ __device__ __forceinline__ int bucket_slot(int *counters, int bucket, bool activ
 // one ballot per round counts / ranks its tiles (popcount, v_mbcnt), the waves' counts meet in LDS once.  (The r02 form
 // did one wave-aggregated LDS atomic per round and class: ~80 dependent LDS round trips per wave in a 256-thread
 // workgroup; this form is ALU-only inside the rounds: 15 -> ~5 us per launch for 9600 tiles, two launches per step.)  order[0..n_tiles) = the permutation,
-// order[n_tiles] = number of tiles whose class reaches long_thresh's, order[n_tiles + 1] = 0.  Tiles beyond
+// order[n_tiles] = number of tiles whose class reaches long_thresh's, order[n_tiles + 1] = 0 (the backward's order
+// puts its walk statistic there afterwards, tile_order_kernel).  Tiles beyond
 // ROUNDS * blockDim are not covered: callers fall back for larger grids.
 template <int ROUNDS>
 __device__ __forceinline__ void order_by_class(const signed char (&bucket)[ROUNDS], int n_tiles, int long_thresh,
@@ -818,11 +872,12 @@ SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
 
 SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                                  const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
-                                 int32_t *gaussian_ids_sorted, int32_t *tile_bins, void *ws, size_t ws_bytes,
-                                 const int32_t *n_isect_dev, sgn_stream_t stream) {
+                                 int32_t *gaussian_ids_sorted, int32_t *tile_bins, int quadrant_masks, void *ws,
+                                 size_t ws_bytes, const int32_t *n_isect_dev, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0 && n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     SGN_ARG_CHECK(tile_bins != nullptr, -3);
+    SGN_ARG_CHECK(!quadrant_masks || (block_width == 16 && n < SGN_QMASK_MAX_IDS), -6);
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = tiles_x * tiles_y;
     if (n_isect == 0 || n == 0) {
@@ -842,7 +897,8 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
         uint16_t *k16 = (uint16_t *)tkeys, *k16s = (uint16_t *)tkeys_sorted;
         sgn_timing_begin(SGN_T_MAP, s);
         hipLaunchKernelGGL(bin_emit_kernel<uint16_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
-                           recs, tiles_x, tiles_y, block_width, k16, tvals, (int)n_isect, tile_bins, 2 * n_tiles);
+                           recs, tiles_x, tiles_y, block_width, k16, tvals, (int)n_isect, tile_bins, 2 * n_tiles,
+                           quadrant_masks);
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
         sgn_sort_pairs16_launch((uint32_t)n_isect, tile_bits, k16, tvals, k16s, gaussian_ids_sorted, sort_ws, s,
@@ -855,7 +911,8 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
     } else {
         sgn_timing_begin(SGN_T_MAP, s);
         hipLaunchKernelGGL(bin_emit_kernel<uint32_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
-                           recs, tiles_x, tiles_y, block_width, tkeys, tvals, (int)n_isect, tile_bins, 2 * n_tiles);
+                           recs, tiles_x, tiles_y, block_width, tkeys, tvals, (int)n_isect, tile_bins, 2 * n_tiles,
+                           quadrant_masks);
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
         sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws,
@@ -950,12 +1007,37 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(int n_tiles, const int
     // every load of the thread is issued before the first use: as a plain loop this kernel was a chain of ~20 dependent
     // global round trips (16 us for 9600 tiles)
     signed char bucket[ORDER_PER_THREAD];
+    __shared__ unsigned long long sums[2];      // backward order only: list entries WALKED by the forward / LISTED
+    if (threadIdx.x < 2) sums[threadIdx.x] = 0ull;
+    long long walked = 0, listed = 0;
 #pragma unroll
     for (int i = 0; i < ORDER_PER_THREAD; ++i) {
         const int t = i * 1024 + threadIdx.x;
         bucket[i] = (signed char)(t < n_tiles ? len_bucket(order_len(t, bins, kmax, long_thresh, small_q16)) : -1);
+        if (kmax != nullptr && t < n_tiles) {
+            const int2 r = bins[t];
+            const int len = max(r.y - r.x, 0);
+            listed += len;
+            walked += len > 0 ? min(len, max(0, kmax[2 * t] - r.x + 1)) : 0;
+        }
     }
     order_by_class<ORDER_PER_THREAD>(bucket, min(n_tiles, ORDER_PER_THREAD * 1024), long_thresh, order, wave_cnt, start);
+    if (kmax != nullptr) {
+        // order[n_tiles + 1] = 1000 * walked / listed: how much of the lists the forward got through before its tiles
+        // saturated.  The host reads it with its next read-back and decides from it whether quadrant masks (paid per
+        // LISTED entry by the emission, earned per WALKED entry by the raster kernels) are worth computing.
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            walked += __shfl_xor(walked, d, 64);
+            listed += __shfl_xor(listed, d, 64);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicAdd(&sums[0], (unsigned long long)walked);
+            atomicAdd(&sums[1], (unsigned long long)listed);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) order[n_tiles + 1] = sums[1] ? (int)((1000ull * sums[0]) / sums[1]) : 0;
+    }
 }
 
 // images with more than 16384 tiles: the r02 form (wave-aggregated LDS counters, any tile count)

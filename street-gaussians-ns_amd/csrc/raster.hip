@@ -112,12 +112,12 @@ __global__ __launch_bounds__(256) void build_grec_kernel(int n, const float *__r
 
 __global__ __launch_bounds__(256) void pack_records_kernel(int64_t n_isect, const int32_t *__restrict__ ids,
                                                            const float4 *__restrict__ grec,
-                                                           float4 *__restrict__ recs) {
+                                                           float4 *__restrict__ recs, int idmask) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of one record
     if (t >= 3 * n_isect) return;
     const int64_t p = t / 3;
     const int j = (int)(t - 3 * p);
-    recs[t] = grec[3 * (int64_t)ids[p] + j];
+    recs[t] = grec[3 * (int64_t)(ids[p] & idmask) + j];   // idmask strips the quadrant bits of a masked list
 }
 
 __device__ __forceinline__ int wave_max_i(int v) {
@@ -158,6 +158,17 @@ __device__ __forceinline__ unsigned quadrant_mask(const Rec &g, float qcx, float
     return (unsigned)(__ballot(hit) & 0xFull);
 }
 
+// Quadrant masks handed in with the list (sgn_raster_opts.ids_qmask, include/sgn_rast.h: sgn_bin_intersect with
+// quadrant_masks): bits 28-31 of an id word say which quadrants the entry can touch — the exact convex test, done once
+// by the emission — and the kernels neither run the box test above per entry nor evaluate the ~10 % of quadrants the
+// box lets through although the ellipse misses them.  A row build_grec_kernel made inert (window passes: ex < 0) keeps
+// answering "none".
+constexpr int QM_SHIFT = SGN_QMASK_ID_BITS;
+__device__ __forceinline__ int qm_idmask(int use_qm) { return use_qm ? (SGN_QMASK_MAX_IDS - 1) : -1; }
+__device__ __forceinline__ unsigned qm_bits(int raw_id, float ex) {
+    return __float_as_int(ex) < 0 ? 0u : ((unsigned)raw_id >> QM_SHIFT);
+}
+
 // Batched path: every lane holds ONE row of the batch and tests all four quadrants for it (lane-parallel over
 // 64 entries instead of once per entry), so entries that cannot touch this wave's pixels are never visited.
 __device__ __forceinline__ unsigned row_quadrants(float gx, float gy, float ex, float ey, int tile_x0, int tile_y0,
@@ -196,10 +207,12 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
                                                 int32_t *__restrict__ tile_kmax, float4 (*stage)[64 * 3],
                                                 const float *__restrict__ depths = nullptr,
                                                 float *__restrict__ out_depth = nullptr,
-                                                float (*stage_d)[64] = nullptr) {
+                                                float (*stage_d)[64] = nullptr, int use_qm = 0) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
+    const bool qm_on = GATHER && use_qm != 0 && B == 16;      // wave-uniform
+    const int idmask = qm_idmask(GATHER ? use_qm : 0);
     int q0 = ADAPT ? 0 : wv * QPW;             // first quadrant (pixel slot) of this wave
     int qlo = 0, qhi = QPW;                    // active slots of this wave (wave-uniform)
     if constexpr (ADAPT) {
@@ -274,20 +287,23 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
     const int L = range.y - range.x;
     if (L > 0 && L < batch_thresh) {
         // short list: chase ids -> rows with scalar loads, one entry ahead (operands arrive in SGPRs)
-        const int id0 = GATHER ? ids[range.x] : range.x;
-        Rec cur = recs[id0];
+        int idc = GATHER ? ids[range.x] : range.x;           // raw id word (mask bits included)
+        Rec cur = recs[idc & idmask];
         float dcur = 0.f;
-        if constexpr (DEPTH) dcur = depths[GATHER ? id0 : cur.gid];
+        if constexpr (DEPTH) dcur = depths[GATHER ? (idc & idmask) : cur.gid];
         int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
         for (int k = range.x; k < range.y; ++k) {
             const int kn = (k + 1 < range.y) ? k + 1 : k;
-            const Rec nxt = recs[GATHER ? idn : kn];  // scalar prefetch of the next record
+            const Rec nxt = recs[GATHER ? (idn & idmask) : kn];  // scalar prefetch of the next record
             float dnxt = 0.f;
-            if constexpr (DEPTH) dnxt = depths[GATHER ? idn : nxt.gid];
+            if constexpr (DEPTH) dnxt = depths[GATHER ? (idn & idmask) : nxt.gid];
+            const int idnn = idn;
             if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
-            if (!entry(cur, k, quadrant_mask(cur, qcx, qcy, qtest), dcur)) break;
+            const unsigned qm = qm_on ? qm_bits(idc, cur.ex) : quadrant_mask(cur, qcx, qcy, qtest);
+            if (!entry(cur, k, qm, dcur)) break;
             cur = nxt;
             dcur = dnxt;
+            idc = idnn;
         }
     } else if (L > 0) {
         // long list: the one-entry scalar look-ahead leaves a lone wave latency-bound (a dependent id -> row
@@ -296,14 +312,19 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
         // ds_read_b128 (no barrier: the workgroup is this one wave and its LDS ops retire in order).
         const int nb = (L + 63) >> 6;
         float rd = 0.f;      // DEPTH: the depth of this lane's row of the batch in flight
+        int rid = 0;         // raw id word of this lane's row (quadrant bits on top)
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = range.x + (bidx << 6) + lane;
             if (k < range.y) {
-                const int id = GATHER ? ids[k] : k;
+                rid = GATHER ? ids[k] : k;
+                const int id = rid & idmask;
                 const float4 *p = reinterpret_cast<const float4 *>(recs + id);
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
                 if constexpr (DEPTH) rd = depths[GATHER ? id : __float_as_int(r2.y)];
             }
+        };
+        auto row_mask = [&](const float4 &r0, const float4 &r2) __attribute__((always_inline)) -> unsigned {
+            return qm_on ? qm_bits(rid, r2.z) : row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest);
         };
         // this wave's quadrants as a bit mask (all four, or the single one of a split tile)
         unsigned mine_q = 0u;
@@ -314,7 +335,7 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
         if constexpr (DEPTH) stage_d[0][lane] = rd;
-        unsigned qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
+        unsigned qrow = row_mask(r0, r2) & mine_q;
         bool go = true;
         for (int bi = 0; bi < nb && go; ++bi) {
             const int cnt = min(64, L - (bi << 6));
@@ -339,7 +360,7 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
                 if constexpr (DEPTH) stage_d[(bi + 1) & 1][lane] = rd;
-                qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
+                qrow = row_mask(r0, r2) & mine_q;
             }
         }
     }
@@ -378,7 +399,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
                                                         int32_t *__restrict__ tile_kmax,
                                                         const float *__restrict__ depths,
                                                         float *__restrict__ out_depth,
-                                                        const int32_t *__restrict__ skip_flag) {
+                                                        const int32_t *__restrict__ skip_flag, int use_qm) {
     if (skip_flag != nullptr && *skip_flag == 0) return;   // the caller already holds this pass's result (sgn_depth_reuse)
     constexpr int WPT = ADAPT ? 4 : 4 / QPW;   // waves launched per tile
     // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile) so the waves that do the
@@ -391,7 +412,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int
     __shared__ float stage_d[DEPTH ? 2 : 1][64];
     raster_fwd_tile<EXACT, GATHER, QPW, ADAPT, DEPTH>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, out_img, final_T,
                                                        final_idx, adapt_thresh, batch_thresh, tile_kmax, stage, depths,
-                                                       out_depth, stage_d);
+                                                       out_depth, stage_d, use_qm);
 }
 
 // ---------------------------------------------------------------- forward, packed-FP32 form (16x16 tiles)
@@ -434,7 +455,7 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
                                                            int32_t *__restrict__ tile_kmax,
                                                            const float *__restrict__ depths,
                                                            float *__restrict__ out_depth,
-                                                           const int32_t *__restrict__ skip_flag) {
+                                                           const int32_t *__restrict__ skip_flag, int use_qm) {
     if (skip_flag != nullptr && *skip_flag == 0) return;   // the caller already holds this pass's result (sgn_depth_reuse)
     __shared__ float4 stage[2][64 * 3];
     __shared__ float stage_d[DEPTH ? 2 : 1][64];
@@ -465,9 +486,11 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
     if (is_long) {
         raster_fwd_tile<EXACT, GATHER, 1, false, DEPTH>(tile, wv, W, H, 16, tiles_x, bins, recs, ids, bg, out_img, final_T,
                                                         final_idx, 0, batch_thresh, tile_kmax, stage, depths, out_depth,
-                                                        stage_d);
+                                                        stage_d, use_qm);
         return;
     }
+    const bool qm_on = GATHER && use_qm != 0;            // wave-uniform
+    const int idmask = qm_idmask(GATHER ? use_qm : 0);
     const unsigned shift_q = 2u * wv;                    // this wave's quadrants: bits shift_q, shift_q + 1
     const int lane = threadIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -525,39 +548,46 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
     };
 
     if (L > 0 && L < batch_thresh) {
-        const int id0 = GATHER ? ids[range.x] : range.x;
-        Rec cur = recs[id0];
+        int idc = GATHER ? ids[range.x] : range.x;           // raw id word (quadrant bits on top)
+        Rec cur = recs[idc & idmask];
         float dcur = 0.f;
-        if constexpr (DEPTH) dcur = depths[GATHER ? id0 : cur.gid];
+        if constexpr (DEPTH) dcur = depths[GATHER ? (idc & idmask) : cur.gid];
         int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
         for (int k = range.x; k < range.y; ++k) {
             const int kn = (k + 1 < range.y) ? k + 1 : k;
-            const Rec nxt = recs[GATHER ? idn : kn];
+            const Rec nxt = recs[GATHER ? (idn & idmask) : kn];
             float dnxt = 0.f;
-            if constexpr (DEPTH) dnxt = depths[GATHER ? idn : nxt.gid];
+            if constexpr (DEPTH) dnxt = depths[GATHER ? (idn & idmask) : nxt.gid];
+            const int idnn = idn;
             if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
-            const unsigned m = (quadrant_mask(cur, qcx, qcy, true) >> shift_q) & 3u;
+            const unsigned m = ((qm_on ? qm_bits(idc, cur.ex) : quadrant_mask(cur, qcx, qcy, true)) >> shift_q) & 3u;
             if (m != 0u && !entry(cur, k, m, dcur)) break;
             cur = nxt;
             dcur = dnxt;
+            idc = idnn;
         }
     } else if (L > 0) {
         const int nb = (L + 63) >> 6;
         float rd = 0.f;
+        int rid = 0;
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = range.x + (bidx << 6) + lane;
             if (k < range.y) {
-                const int id = GATHER ? ids[k] : k;
+                rid = GATHER ? ids[k] : k;
+                const int id = rid & idmask;
                 const float4 *p = reinterpret_cast<const float4 *>(recs + id);
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
                 if constexpr (DEPTH) rd = depths[GATHER ? id : __float_as_int(r2.y)];
             }
         };
+        auto row_mask = [&](const float4 &r0, const float4 &r2) __attribute__((always_inline)) -> unsigned {
+            return qm_on ? qm_bits(rid, r2.z) : row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, true);
+        };
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
         if constexpr (DEPTH) stage_d[0][lane] = rd;
-        unsigned qrow = (row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, true) >> shift_q) & 3u;
+        unsigned qrow = (row_mask(r0, r2) >> shift_q) & 3u;
         bool go = true;
         for (int bi = 0; bi < nb && go; ++bi) {
             const int cnt = min(64, L - (bi << 6));
@@ -582,7 +612,7 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
                 if constexpr (DEPTH) stage_d[(bi + 1) & 1][lane] = rd;
-                qrow = (row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, true) >> shift_q) & 3u;
+                qrow = (row_mask(r0, r2) >> shift_q) & 3u;
             }
         }
     }
@@ -654,8 +684,10 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
                                                 const float *__restrict__ v_out,
                                                 const float *__restrict__ v_out_alpha, float alpha_clamp,
                                                 float *__restrict__ grad_ws, int dbg, int adapt_thresh,
-                                                int batch_thresh) {
+                                                int batch_thresh, int use_qm) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
+    const bool qm_on = GATHER && use_qm != 0 && B == 16;      // wave-uniform
+    const int idmask = qm_idmask(GATHER ? use_qm : 0);
     const int q0 = ADAPT ? 0 : wv * QPW;
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
@@ -799,25 +831,33 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
 
     const int L = kmax - range.x + 1;   // entries of the reverse walk
     if (L < batch_thresh) {
-        Rec cur = recs[GATHER ? ids[kmax] : kmax];
+        int idc = GATHER ? ids[kmax] : kmax;                 // raw id word (quadrant bits on top)
+        Rec cur = recs[idc & idmask];
         int idn = GATHER ? ids[max(kmax - 1, range.x)] : 0;
         for (int k = kmax; k >= range.x; --k) {
             const int kn = (k - 1 >= range.x) ? k - 1 : k;
-            const Rec nxt = recs[GATHER ? idn : kn];
+            const Rec nxt = recs[GATHER ? (idn & idmask) : kn];
+            const int idnn = idn;
             if constexpr (GATHER) idn = ids[max(k - 2, range.x)];
-            entry(cur, k, quadrant_mask(cur, qcx, qcy, qtest));
+            entry(cur, k, qm_on ? qm_bits(idc, cur.ex) : quadrant_mask(cur, qcx, qcy, qtest));
             cur = nxt;
+            idc = idnn;
         }
     } else {
         // long walk: 64-entry batches staged through wave-private LDS (see the forward kernel)
         __shared__ float4 stage[2][64 * 3];
         const int nb = (L + 63) >> 6;
+        int rid = 0;         // raw id word of this lane's row
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = kmax - (bidx << 6) - lane;
             if (k >= range.x) {
-                const float4 *p = reinterpret_cast<const float4 *>(recs + (GATHER ? ids[k] : k));
+                rid = GATHER ? ids[k] : k;
+                const float4 *p = reinterpret_cast<const float4 *>(recs + (rid & idmask));
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
             }
+        };
+        auto row_mask = [&](const float4 &r0, const float4 &r2) __attribute__((always_inline)) -> unsigned {
+            return qm_on ? qm_bits(rid, r2.z) : row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest);
         };
         unsigned mine_q = 0u;
 #pragma unroll
@@ -826,7 +866,7 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         fetch(0, r0, r1, r2);
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
-        unsigned qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
+        unsigned qrow = row_mask(r0, r2) & mine_q;
         for (int bi = 0; bi < nb; ++bi) {
             const int cnt = min(64, L - (bi << 6));
             unsigned long long todo = __ballot(lane < cnt && qrow != 0u);
@@ -846,7 +886,7 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
             if (bi + 1 < nb) {
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
-                qrow = row_quadrants(r0.x, r0.y, r2.z, r2.w, tx * 16, ty * 16, qtest) & mine_q;
+                qrow = row_mask(r0, r2) & mine_q;
             }
         }
     }
@@ -876,7 +916,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                                                         const float *__restrict__ v_out_alpha,
                                                         float alpha_clamp, float *__restrict__ grad_ws, int dbg,
                                                         int adapt_thresh, int swz, int batch_thresh,
-                                                        const int32_t *__restrict__ tile_order) {
+                                                        const int32_t *__restrict__ tile_order, int use_qm) {
     if constexpr (MODE == 0) {
         constexpr int WPT = ADAPT ? 4 : 4 / QPW;
         // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile), see the forward kernel
@@ -885,7 +925,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         const int wv = ADAPT ? (int)(blockIdx.x / n_tiles) : (int)(blockIdx.x % WPT);
         raster_bwd_tile<EXACT, REDUCE, GATHER, QPW, ADAPT>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, final_T,
                                                            final_idx, v_out, v_out_alpha, alpha_clamp, grad_ws, dbg,
-                                                           adapt_thresh, batch_thresh);
+                                                           adapt_thresh, batch_thresh, use_qm);
     } else {
         static_assert(MODE == 2, "MODE 1 lives in raster_bwd_short_kernel");
         static_assert(QPW == 1 && !ADAPT, "long tiles: four lean waves per tile");
@@ -900,7 +940,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         __builtin_amdgcn_s_setprio(3);
         raster_bwd_tile<EXACT, REDUCE, GATHER, 1, false>(tile_order[blockIdx.x >> 2], blockIdx.x & 3, W, H, B, tiles_x,
                                                          bins, recs, ids, bg, final_T, final_idx, v_out, v_out_alpha,
-                                                         alpha_clamp, grad_ws, dbg, adapt_thresh, batch_thresh);
+                                                         alpha_clamp, grad_ws, dbg, adapt_thresh, batch_thresh, use_qm);
     }
 }
 
@@ -919,12 +959,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, SGN_BWD_S
     const int32_t *__restrict__ ids, const float *__restrict__ bg, const float *__restrict__ final_T,
     const int32_t *__restrict__ final_idx, const float *__restrict__ v_out, const float *__restrict__ v_out_alpha,
     float alpha_clamp, float *__restrict__ grad_ws, int dbg, int adapt_thresh, int swz, int batch_thresh,
-    const int32_t *__restrict__ tile_order) {
+    const int32_t *__restrict__ tile_order, int use_qm) {
     const int n_long = tile_order[n_tiles];
     if ((int)blockIdx.x < n_long) return;
     raster_bwd_tile<EXACT, REDUCE, GATHER, 4, false>(tile_order[blockIdx.x], 0, W, H, B, tiles_x, bins, recs, ids, bg,
                                                      final_T, final_idx, v_out, v_out_alpha, alpha_clamp, grad_ws, dbg,
-                                                     adapt_thresh, batch_thresh);
+                                                     adapt_thresh, batch_thresh, use_qm);
 }
 
 // rows [row0, row0 + n) of the packed gradient workspace -> the n rows of the four output arrays
@@ -963,6 +1003,7 @@ sgn_raster_opts resolve_opts(const sgn_raster_opts *o) {
         r.exact_exp = r.exact_exp ? 1 : 0;
         r.reduce_mode = r.reduce_mode ? 1 : 0;
         r.gather = r.gather ? 1 : 0;
+        r.ids_qmask = r.ids_qmask ? 1 : 0;
         r.waves_fwd = (r.waves_fwd == 4 || r.waves_fwd == 2 || r.waves_fwd == 1) ? r.waves_fwd : 0;
         r.waves_bwd = (r.waves_bwd == 4 || r.waves_bwd == 1) ? r.waves_bwd : 0;
         sgn_raster_opts d;
@@ -991,6 +1032,7 @@ SGN_EXPORT void sgn_raster_default_opts(sgn_raster_opts *out) {
     out->batch_bwd = 128;      // backward: same for reverse walks
     out->xcd_swizzle = 0;
     out->debug_flags = 0;
+    out->ids_qmask = 0;        // the list carries no quadrant masks unless its builder says so
 }
 
 SGN_EXPORT size_t sgn_raster_workspace_bytes(int n, int64_t n_isect, const sgn_raster_opts *opts) {
@@ -1006,7 +1048,7 @@ SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
 // builds the per-Gaussian rows and (stream mode) the depth-ordered record stream
 static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
                         const float *colors, const float *opac, int opac_is_logit, int id_lo, int id_hi, int window,
-                        int gather, void *recs, hipStream_t s) {
+                        int gather, void *recs, hipStream_t s, int idmask = -1) {
     float4 *grec = (float4 *)recs;                       // rows first,
     float4 *stream_recs = (float4 *)recs + 3 * (size_t)n; // then the optional depth-ordered stream
     sgn_timing_begin(SGN_T_PACK, s);
@@ -1014,7 +1056,7 @@ static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float 
                        opac_is_logit, id_lo, id_hi, window, grec, (const int32_t *)nullptr);
     if (!gather)
         hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(3 * n_isect, 256)), dim3(256), 0, s, n_isect, ids,
-                           grec, stream_recs);
+                           grec, stream_recs, idmask);
     sgn_timing_end(SGN_T_PACK, s);
     return 0;
 }
@@ -1059,10 +1101,11 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     SGN_ARG_CHECK(n_isect == 0 || (gaussian_ids_sorted && xys && conics && colors && opacities && recs_ws), -5);
     SGN_ARG_CHECK(n >= 0 && recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect, &o), -6);
     SGN_ARG_CHECK(!window || (0 <= id_lo && id_lo <= id_hi && id_hi <= n), -7);
+    SGN_ARG_CHECK(!o.ids_qmask || (block_width == 16 && n < SGN_QMASK_MAX_IDS), -11);
     hipStream_t s = (hipStream_t)stream;
     if (n_isect > 0 && !(rows_built && o.gather))
         pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
-                     window, o.gather, recs_ws, s);
+                     window, o.gather, recs_ws, s, o.ids_qmask ? SGN_QMASK_MAX_IDS - 1 : -1);
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     const Rec *rows = (const Rec *)recs_ws;
     const Rec *stream_recs = rows + n;
@@ -1072,11 +1115,11 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD, DE>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
                        img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
                        gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, o.adapt_fwd, o.xcd_swizzle, o.batch_fwd,   \
-                       tile_order, tile_kmax, depths, out_depth, skip_flag)
+                       tile_order, tile_kmax, depths, out_depth, skip_flag, o.ids_qmask)
 #define SGN_LAUNCH_FWD_PK(EX, GA, DE)                                                                                \
     hipLaunchKernelGGL((raster_fwd_pk_kernel<EX, GA, DE>), dim3(((tiles_x * tiles_y + 7) / 8) * 32 + 32), dim3(64), 0, s, img_w, img_h,    \
                        tiles_x, tiles_x * tiles_y, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, background3,  \
-                       out_img, final_Ts, final_idx, o.xcd_swizzle, o.batch_fwd, tile_order, tile_kmax, depths, out_depth, skip_flag)
+                       out_img, final_Ts, final_idx, o.xcd_swizzle, o.batch_fwd, tile_order, tile_kmax, depths, out_depth, skip_flag, o.ids_qmask)
 #define SGN_LAUNCH_FWD3(EX, GA, DE)                                                     \
     do {                                                                                \
         if (o.waves_fwd == 2 && block_width == 16) SGN_LAUNCH_FWD_PK(EX, GA, DE);       \
@@ -1193,6 +1236,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     SGN_ARG_CHECK(v_xy && v_conic && v_colors && v_opacity && grad_ws && opacities && conics, -4);
     SGN_ARG_CHECK(grad_ws_bytes >= sgn_raster_bwd_workspace_bytes(n), -5);
     SGN_ARG_CHECK(alpha_clamp_bwd > 0.f && alpha_clamp_bwd < 1.f, -6);
+    SGN_ARG_CHECK(!o.ids_qmask || (block_width == 16 && n < SGN_QMASK_MAX_IDS), -10);
     hipStream_t s = (hipStream_t)stream;
     SGN_HIP_CHECK(hipMemsetAsync(grad_ws, 0, (size_t)n * SGN_RECORD_FLOATS * sizeof(float), s));
     if (n_isect > 0) {
@@ -1201,7 +1245,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect, &o), -8);
         if (!recs_packed)
             pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
-                         window, o.gather, recs_ws, s);
+                         window, o.gather, recs_ws, s, o.ids_qmask ? SGN_QMASK_MAX_IDS - 1 : -1);
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
         const Rec *rows = (const Rec *)recs_ws;
         const Rec *stream_recs = rows + n;
@@ -1220,7 +1264,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
 #define SGN_BWD_ARGS(GA)                                                                                         \
     img_w, img_h, block_width, tiles_x, n_tiles, (const int2 *)tile_bins, GA ? rows : stream_recs,               \
         gaussian_ids_sorted, background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd,          \
-        (float *)grad_ws, o.debug_flags, o.adapt_bwd, o.xcd_swizzle, o.batch_bwd, tile_order
+        (float *)grad_ws, o.debug_flags, o.adapt_bwd, o.xcd_swizzle, o.batch_bwd, tile_order, o.ids_qmask
 #define SGN_LAUNCH_BWDQ(EX, RM, GA, Q, AD)                                                                       \
     hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q, AD, 0>), dim3(n_tiles * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
                        SGN_BWD_ARGS(GA))

@@ -70,7 +70,7 @@ SIGNATURES = {
     "sgn_depth_rank_workspace_bytes": (_sz, [_i]),
     "sgn_depth_rank": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sgn_bin_intersect_workspace_bytes": (_sz, [_i64]),
-    "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "sgn_rows_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_raster_workspace_bytes": (_sz, [_i, _i64, _vp]),
     "sgn_tile_order": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp]),
@@ -90,7 +90,7 @@ _lib = None
 class RasterOpts(C.Structure):
     """`sgn_raster_opts` of include/sgn_rast.h: kernel-selection options handed to the raster entry points per call."""
     _fields_ = [(k, C.c_int) for k in ("exact_exp", "reduce_mode", "gather", "waves_fwd", "waves_bwd", "adapt_fwd", "adapt_bwd",
-                                       "batch_fwd", "batch_bwd", "xcd_swizzle", "debug_flags")]
+                                       "batch_fwd", "batch_bwd", "xcd_swizzle", "debug_flags", "ids_qmask")]
 
     def copy(self) -> "RasterOpts":
         out = RasterOpts()

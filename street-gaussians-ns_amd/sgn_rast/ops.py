@@ -60,7 +60,9 @@ class _State:
         self.order_cache = collections.OrderedDict()                   # (id(tile_bins), thresh) -> (tile_bins, order)
         self.last_count: dict = {}     # key -> slowly decaying maximum of the counts seen (views of one scene differ)
         self.pending_checks: list = []
-        self.side = None               # [pinned int32[4,8] (count + up to 7 deferred-check flags per prepare), next slot]
+        self.side = None               # [pinned int32[4,8] (count, up to 6 deferred-check flags, walk statistic), next slot]
+        self.walk_stat = None          # device int32[1]: the last backward's walked / listed permille, not yet read back
+        self.walked_permille = None    # ... and the last value the host has seen (quadrant-mask policy)
         self.eager_side = None         # [pinned int32[8] ring for the eager flag read-back, next slot]
         self.depth_state = {"want": False, "unused": 0, "cache": None}
         self.depth_caches = collections.OrderedDict()                  # binning key -> first pass's channel + state
@@ -468,6 +470,33 @@ def bin_and_sort_gaussians(num_points, num_intersects, xys, depths, radii, cum_t
 
 
 tile_culling_enabled = True   # exact alpha-cutoff tile culling inside rasterize_gaussians (results unchanged)
+# Quadrant masks (r03): with the culling on (16x16 tiles) the emission also decides, per (tile, Gaussian) pair, which of
+# the tile's four 8x8 quadrants the Gaussian can reach and hands the four bits to the raster kernels in the top of the
+# id word (include/sgn_rast.h: sgn_bin_intersect(quadrant_masks)); results unchanged (tests/test_gpu_quadrant_masks.py).
+# What they cost and earn (profiles/r03x_*): the emission pays per LISTED pair (+14 us event-timed, +31 us inside the
+# step, for the benchmark scene's 8.3 M pairs), the raster kernels earn per WALKED entry (forward -3.5 %, backward -5.8 %).
+# Where tiles saturate early (benchmark scene: a tenth of the listed entries is ever walked) that is a loss of ~1 %;
+# where they do not (street-like and translucent content: 90-100 % walked) a gain of 2-3 %.  So "auto" (default) turns
+# them on when the last backward's tile order reported that at least QMASK_MIN_WALKED_PERMILLE of the listed entries
+# were walked (sgn_tile_order's statistic, read back with the next binning's count); "on" / "off" force it.
+quadrant_masks = os.environ.get("SGN_QUAD_MASKS", "auto")
+QMASK_MIN_WALKED_PERMILLE = 200       # break-even measured at ~150 (31 us / 8.3 M listed vs 20.5 us / 0.84 M walked)
+QMASK_ID_BITS = 28
+quadrant_mask_stats = {"binnings_with_masks": 0, "walked_permille": None}
+
+
+def _quadrant_masks_wanted() -> bool:
+    if quadrant_masks in ("on", "1", True):
+        return True
+    if quadrant_masks == "auto":
+        w = _S().walked_permille
+        return w is not None and w >= QMASK_MIN_WALKED_PERMILLE
+    return False
+
+
+def _ids_only(ids: torch.Tensor) -> torch.Tensor:
+    """The Gaussian ids of a list, whatever rides on top of them."""
+    return (ids & ((1 << QMASK_ID_BITS) - 1)) if getattr(ids, "_sgn_qmask", False) else ids
 
 
 def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics=None,
@@ -479,8 +508,9 @@ def bin_gaussians_fused(num_points, xys, depths, radii, num_tiles_hit, tile_boun
     (tile, Gaussian) pairs that cannot reach alpha >= 1/255 on any pixel centre of the tile are dropped: the
     list becomes a sub-sequence of upstream's and the rasterizer's outputs are unchanged.
     Returns (num_intersects, gaussian_ids_sorted, tile_bins)."""
-    return _bin_finish(_bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width,
-                                          conics, opacity, opacity_is_logit, cull))
+    n_isect, ids, bins = _bin_finish(_bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds,
+                                                        block_width, conics, opacity, opacity_is_logit, cull))
+    return n_isect, _ids_only(ids), bins
 
 
 
@@ -501,6 +531,7 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     radii_c = radii.detach().to(torch.int32).contiguous()
     xys_c = _f32c(xys)
     do_cull = int(bool(cull and conics is not None and opacity is not None))
+    st["qmask"] = bool(do_cull and int(block_width) == 16 and n < (1 << QMASK_ID_BITS) and _quadrant_masks_wanted())
     conics_c = _f32c(conics) if do_cull else None
     opac_c = _f32c(opacity).reshape(-1) if do_cull else None
     cum_r = torch.empty(n, **i32)
@@ -522,14 +553,17 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     # pending argument checks ride along: their flags reach the host in the same transfer as the count, so the
     # deferred assertion costs no round trip of its own.  The copies are queued on the current stream (a side stream
     # would add an event hop of ~15 us before the copy even starts); work queued afterwards simply follows them.
-    flags = [S.pending_checks.pop() for _ in range(min(len(S.pending_checks), 7))]
+    flags = [S.pending_checks.pop() for _ in range(min(len(S.pending_checks), 6))]
     pinned[0:1].copy_(cum_r[n - 1:n], non_blocking=True)
     for i, f in enumerate(flags):
         pinned[1 + i:2 + i].copy_(f, non_blocking=True)
+    walk_stat, S.walk_stat = S.walk_stat, None          # the last backward's walked / listed statistic rides along too
+    if walk_stat is not None:
+        pinned[7:8].copy_(walk_stat, non_blocking=True)
     done = torch.cuda.Event()
     done.record()
     st.update(cum_r=cum_r, gid_by_rank=gid_by_rank, bin_recs=bin_recs, ws=ws, done=done, pinned=pinned,
-              n_flags=len(flags), keep=(xys_c, radii_c, conics_c, opac_c, flags))
+              n_flags=len(flags), has_walk_stat=walk_stat is not None, keep=(xys_c, radii_c, conics_c, opac_c, flags))
     return st
 
 
@@ -561,8 +595,14 @@ def _bin_finish(st):
         ws2 = L.workspace(lib.sgn_bin_intersect_workspace_bytes(count_or_cap), st["dev"])
         L.check(lib.sgn_bin_intersect(n, count_or_cap, L.ptr(st["bin_recs"]), L.ptr(st["cum_r"]),
                                       L.ptr(st["gid_by_rank"]), st["tx"], st["ty"], st["block"], L.ptr(ids),
-                                      L.ptr(tile_bins), L.ptr(ws2), ws2.numel(), count_dev, L.stream_ptr()),
+                                      L.ptr(tile_bins), int(st["qmask"]), L.ptr(ws2), ws2.numel(), count_dev,
+                                      L.stream_ptr()),
                 "sgn_bin_intersect")
+        return ids
+
+    def tagged(ids):
+        ids._sgn_qmask = st["qmask"]        # what the list carries travels with the list (cache, window passes)
+        quadrant_mask_stats["binnings_with_masks"] += int(st["qmask"])
         return ids
 
     key = (st["dev"], n, st["tx"], st["ty"], st["block"])
@@ -574,6 +614,8 @@ def _bin_finish(st):
         spec_ids = run(cap, C.c_void_p(st["cum_r"].data_ptr() + 4 * (n - 1)))
     st["done"].synchronize()
     num_intersects = int(st["pinned"][0])
+    if st.get("has_walk_stat"):
+        S.walked_permille = quadrant_mask_stats["walked_permille"] = int(st["pinned"][7])
     failed = any(int(st["pinned"][1 + i]) for i in range(st["n_flags"]))
     assert not failed, "quats must be normalized"
     if S.pending_checks:                   # checks queued after the prefetch (rare): one more read-back
@@ -581,13 +623,13 @@ def _bin_finish(st):
     _last_count[key] = max(num_intersects, int(0.9 * _last_count.get(key, 0)))
     if spec_ids is not None and 0 < num_intersects <= cap:
         binning_stats["speculative_hits"] += 1
-        return num_intersects, spec_ids[:num_intersects], tile_bins
+        return num_intersects, tagged(spec_ids[:num_intersects]), tile_bins
     if spec_ids is not None:
         binning_stats["speculative_misses"] += 1
     if num_intersects < 1:
         tile_bins.zero_()
         return num_intersects, torch.zeros(0, **i32), tile_bins
-    return num_intersects, run(num_intersects, None), tile_bins
+    return num_intersects, tagged(run(num_intersects, None)), tile_bins
 
 
 binning_stats = {"speculative_hits": 0, "speculative_misses": 0, "binnings": 0}
@@ -887,6 +929,7 @@ class _RasterizeGaussians(Function):
             num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
                 num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
                 opacity_is_logit)
+        ro.ids_qmask = int(bool(getattr(gaussian_ids_sorted, "_sgn_qmask", False)))   # the backward runs with `ro` too
         if proved and num_intersects >= 1:
             # the depth pass, proven on the host: its image comes from the first pass's fourth channel, and its node
             # SHARES that pass's per-pixel state and tile statistics (same geometry and opacities: same values)
@@ -985,6 +1028,8 @@ class _RasterizeGaussians(Function):
             # plus per-tile classification, no launch — the one-wave kernel then ran 323 instead of 288 us on the
             # benchmark scene: a late long walk is a lone-wave tail; profiles/r03f_*)
             order = _tile_order(tile_bins, ctx.tile_kmax, ctx.ro.adapt_bwd)
+            if order is not None and not ctx.window and ctx.id_range == (0, n):
+                _S().walk_stat = order[-1:]          # rides to the host with the next binning's count (mask policy)
             L.check(lib.sgn_raster_bwd(
                 H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
                 L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity), ctx.opacity_is_logit, ctx.id_range[0],
