@@ -224,7 +224,7 @@ def require_device(*tensors: torch.Tensor) -> torch.device:
         dev = dev or t.device
         if t.device != dev:
             raise SgnRastError("all tensors must live on the same device")
-    if dev is not None and dev.index is not None and dev.index != torch.cuda.current_device():
+    if dev is not None and dev.index is not None and dev.index != current_device():
         # kernels are queued on the CURRENT device's current stream (one process per GPU: bench.py / dp.py set it)
         raise SgnRastError(f"tensors live on {dev} but the current device is cuda:{torch.cuda.current_device()}; "
                            "wrap the call in torch.cuda.device(...)")
@@ -232,22 +232,32 @@ def require_device(*tensors: torch.Tensor) -> torch.device:
 
 
 def ptr(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Device address of a tensor for a `void *` parameter (a plain int: ctypes converts it; building a c_void_p object
+    per argument was ~60 small allocations per train step), NULL for None."""
+    return None if t is None else t.data_ptr()
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def current_device() -> int:
+    """`torch.cuda.current_device()` without its lazy-init bookkeeping (the library is only ever called with device
+    tensors in hand, so the runtime is up): ~40 calls per train step."""
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
 
 
 def stream_handle() -> int:
     """The current HIP stream of the current device as an integer.  `torch.cuda.current_stream()` builds a Python
     Stream object every time (~9 us; ten calls per train step showed up as 90 us of host time under cProfile)."""
     if _raw_stream is not None:
-        return int(_raw_stream(torch.cuda.current_device()))
+        return _raw_stream(current_device())
     return int(torch.cuda.current_stream().cuda_stream)
 
 
-def stream_ptr() -> C.c_void_p:
-    return C.c_void_p(stream_handle())
+def stream_ptr() -> int:
+    """The current stream for a `sgn_stream_t` parameter (an int, see `ptr`)."""
+    return stream_handle()
 
 
 _aux_streams: dict = {}
@@ -262,8 +272,14 @@ def aux_stream(device) -> "torch.cuda.Stream":
     return _aux_streams[dev]
 
 
-def aux_stream_ptr(device) -> C.c_void_p:
-    return C.c_void_p(aux_stream(device).cuda_stream)
+_aux_handles: dict = {}
+
+
+def aux_stream_ptr(device) -> int:
+    h = _aux_handles.get(device)
+    if h is None:
+        h = _aux_handles[device] = int(aux_stream(device).cuda_stream)
+    return h
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:

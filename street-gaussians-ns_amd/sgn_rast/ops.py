@@ -35,7 +35,15 @@ def set_alpha_clamp_bwd(value: float) -> None:
     _alpha_clamp_bwd = float(value)
 
 
+def _i32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype is torch.int32 and t.is_contiguous():
+        return t.detach()
+    return t.detach().to(torch.int32).contiguous()
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype is torch.float32 and t.is_contiguous():          # the usual case: one call instead of three
+        return t.detach()
     return t.detach().to(torch.float32).contiguous()
 
 
@@ -102,13 +110,17 @@ class _State:
         self.depth_state["cache"] = None
 
 
+_have_gpu = None
 _states: "collections.OrderedDict" = collections.OrderedDict()
 _MAX_STATES = 16        # programs that keep creating streams must not pin a cache (device memory) per stream for ever
 
 
 def _S() -> _State:
     """The state object of the current device's current stream."""
-    k = (torch.cuda.current_device(), L.stream_handle()) if torch.cuda.is_available() else (-1, 0)
+    global _have_gpu
+    if _have_gpu is None:
+        _have_gpu = torch.cuda.is_available()
+    k = (L.current_device(), L.stream_handle()) if _have_gpu else (-1, 0)
     st = _states.get(k)
     if st is None:
         st = _states[k] = _State()
@@ -528,7 +540,7 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     st = dict(n=n, tx=tx, ty=ty, block=int(block_width), dev=dev, tile_bins=torch.empty(tx * ty, 2, **i32))
     if n == 0:
         return st
-    radii_c = radii.detach().to(torch.int32).contiguous()
+    radii_c = _i32c(radii)
     xys_c = _f32c(xys)
     do_cull = int(bool(cull and conics is not None and opacity is not None))
     st["qmask"] = bool(do_cull and int(block_width) == 16 and n < (1 << QMASK_ID_BITS) and _quadrant_masks_wanted())
@@ -679,7 +691,7 @@ binning_cache_enabled = True
 
 
 def _bin_key(tensors, tile_bounds, block_width, flags):
-    return tuple((t.data_ptr(), t._version, tuple(t.shape), tuple(t.stride()), t.dtype) for t in tensors) + (
+    return tuple((t.data_ptr(), t._version, t.shape, t.stride(), t.dtype) for t in tensors) + (
         tuple(int(b) for b in tile_bounds), int(block_width), flags, L.stream_handle())
 
 
@@ -731,9 +743,10 @@ def prefetch_binning(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
 
 
 def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics,
-                          opacity, opacity_is_logit):
-    key, tensors, cull = _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
-                                    opacity_is_logit)
+                          opacity, opacity_is_logit, pre=None):
+    # `pre`: the caller's own (key, tensors, cull) of these very arguments (the key walks six tensors)
+    key, tensors, cull = pre if pre is not None else _cache_key(
+        xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity, opacity_is_logit)
     S = _S()
     if binning_cache_enabled:
         val = S.find_binning(key)
@@ -928,7 +941,7 @@ class _RasterizeGaussians(Function):
         else:
             num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
                 num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
-                opacity_is_logit)
+                opacity_is_logit, pre=(key, _t, cull))
         ro.ids_qmask = int(bool(getattr(gaussian_ids_sorted, "_sgn_qmask", False)))   # the backward runs with `ro` too
         if proved and num_intersects >= 1:
             # the depth pass, proven on the host: its image comes from the first pass's fourth channel, and its node
