@@ -27,7 +27,7 @@ import time
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "street-gaussians-ns_amd")]
+sys.path[:0] = [ROOT, os.path.join(ROOT, os.environ.get("SGN_BENCH_PKG", "street-gaussians-ns_amd"))]   # (A/B of host-side changes)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
