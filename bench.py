@@ -24,6 +24,11 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this platform needs dmabuf IPC (the host driver has no legacy IPC: RCCL otherwise fails
+# with `hipIpcGetMemHandle: invalid argument`); already exported on the boxes, kept here for any other launcher —
+# before the HIP runtime comes up
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

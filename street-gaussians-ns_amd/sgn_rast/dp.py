@@ -49,6 +49,7 @@ def init_from_env(backend: Optional[str] = None, timeout_s: Optional[float] = No
             # two ranks on one device); production is RCCL
             backend = os.environ.get("SGN_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC (see bench.py); no-op once HIP is up
             torch.cuda.set_device(local)
             # a timed-out or failed collective aborts the communicator and raises / exits instead of spinning forever
             os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
