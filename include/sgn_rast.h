@@ -344,7 +344,10 @@ int sgn_depth_reuse(int img_h, int img_w, const int32_t *flag, const float *dept
  * 0.999 in forward and 0.99 in backward).  Outputs are fully written (zero-filled first).
  * v_conic[:,1] is the TRUE derivative dL/d(conic.y) (sum of v_sigma dx dy: what autograd through gsplat's
  * _torch_impl gives); sgn_project_bwd spreads v_conic.y / 2 over the two off-diagonal slots of the symmetric
- * matrix gradient.  (Rounds 1-2 carried half of it here with the un-halved matrix: same end-to-end gradients.) */
+ * matrix gradient.  (Rounds 1-2 carried half of it here with the un-halved matrix: same end-to-end gradients.)
+ * opacity_is_logit: 0 = `opacities` are probabilities, v_opacity is w.r.t. them (upstream); 1 = they are logits, the
+ * kernels apply the sigmoid and v_opacity is w.r.t. the logits (fused API); 2 = they are probabilities that the caller
+ * obtained as sigmoid(logits) (sgn_splatfacto.py:949) and v_opacity is wanted w.r.t. those logits: v * o * (1 - o). */
 size_t sgn_raster_bwd_workspace_bytes(int n);
 int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
@@ -359,6 +362,9 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                                                opts->waves_bwd == 0 its first n_long tiles (walks >= adapt_bwd) run four
                                                lean waves per tile, persistent and longest first, the rest one wave per
                                                tile; NULL = in-kernel split of long walks*/,
+                   const float *colors_pre_clamp /*NULL, or [n,3] (window: [id_hi - id_lo, 3]): the caller's colours were
+                                                   clamp(pre, min = 0) of this tensor (sgn_splatfacto.py:940) and
+                                                   v_colors is wanted w.r.t. `pre`: zero where pre < 0*/,
                    const sgn_raster_opts *opts, sgn_stream_t stream,
                    sgn_stream_t aux_stream /*NULL, or a second stream of the same device: the two halves of the
                                              adaptive scheme touch disjoint tiles and then run concurrently (forked

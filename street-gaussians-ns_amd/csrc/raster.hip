@@ -971,6 +971,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, SGN_BWD_S
 __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, int row0, const float *__restrict__ ws,
                                                            const float *__restrict__ conics,
                                                            const float *__restrict__ opac, int opac_is_logit,
+                                                           const float *__restrict__ colors_pre,
                                                            float *__restrict__ v_xy, float *__restrict__ v_conic,
                                                            float *__restrict__ v_colors,
                                                            float *__restrict__ v_opac) {
@@ -985,10 +986,19 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, int row0, cons
     v_xy[2 * i] = fmaf(A, a.x, B * a.y);
     v_xy[2 * i + 1] = fmaf(B, a.x, C * a.y);
     v_conic[3 * i] = 0.5f * a.z; v_conic[3 * i + 1] = a.w; v_conic[3 * i + 2] = 0.5f * b.x;
-    v_colors[3 * i] = b.y; v_colors[3 * i + 1] = b.z; v_colors[3 * i + 2] = b.w;
+    float v0 = b.y, v1 = b.z, v2 = b.w;
+    if (colors_pre != nullptr) {   // the colours were clamp(pre, min = 0): gradient w.r.t. `pre` (torch: grad * (pre >= 0))
+        v0 = colors_pre[3 * i] >= 0.f ? v0 : 0.f;
+        v1 = colors_pre[3 * i + 1] >= 0.f ? v1 : 0.f;
+        v2 = colors_pre[3 * i + 2] >= 0.f ? v2 : 0.f;
+    }
+    v_colors[3 * i] = v0; v_colors[3 * i + 1] = v1; v_colors[3 * i + 2] = v2;
     float vo = c.x;
-    if (opac_is_logit) {  // chain through the fused sigmoid
+    if (opac_is_logit == 1) {         // opac holds logits: chain through the fused sigmoid
         const float sg = 1.f / (1.f + expf(-opac[i]));
+        vo = vo * sg * (1.f - sg);
+    } else if (opac_is_logit == 2) {  // opac holds sigmoid OUTPUTS, the gradient w.r.t. their logits is wanted
+        const float sg = opac[i];
         vo = vo * sg * (1.f - sg);
     }
     v_opac[i] = vo;
@@ -1225,9 +1235,11 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
                               const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd,
                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
                               size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
-                              const int32_t *tile_order, const sgn_raster_opts *opts, sgn_stream_t stream,
-                              sgn_stream_t aux_stream) {
+                              const int32_t *tile_order, const float *colors_pre_clamp,
+                              const sgn_raster_opts *opts, sgn_stream_t stream, sgn_stream_t aux_stream) {
     const sgn_raster_opts o = resolve_opts(opts);
+    SGN_ARG_CHECK(opacity_is_logit >= 0 && opacity_is_logit <= 2, -11);
+    const int logit_rows = opacity_is_logit == 1;     // 2: the values ARE probabilities, only the gradient is converted
     SGN_ARG_CHECK(!window || (0 <= id_lo && id_lo <= id_hi && id_hi <= n), -9);
     SGN_ARG_CHECK(img_h > 0 && img_w > 0 && n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
@@ -1244,7 +1256,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
                           final_Ts && final_idx && v_out_img && v_out_alpha && recs_ws, -7);
         SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect, &o), -8);
         if (!recs_packed)
-            pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
+            pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, logit_rows, id_lo, id_hi,
                          window, o.gather, recs_ws, s, o.ids_qmask ? SGN_QMASK_MAX_IDS - 1 : -1);
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
         const Rec *rows = (const Rec *)recs_ws;
@@ -1302,8 +1314,8 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         const int n_out = window ? id_hi - id_lo : n, row0 = window ? id_lo : 0;
         if (n_out > 0)
             hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n_out, 256)), dim3(256), 0, s, n_out, row0,
-                               (const float *)grad_ws, conics, opacities, opacity_is_logit, v_xy, v_conic, v_colors,
-                               v_opacity);
+                               (const float *)grad_ws, conics, opacities, opacity_is_logit, colors_pre_clamp, v_xy,
+                               v_conic, v_colors, v_opacity);
     }
     sgn_timing_end(SGN_T_UNPACK, s);
     SGN_LAUNCH_CHECK();

@@ -81,7 +81,7 @@ SIGNATURES = {
     "sgn_depth_reuse": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "sgn_raster_bwd_workspace_bytes": (_sz, [_i]),
     "sgn_raster_bwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
-                            _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
+                            _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

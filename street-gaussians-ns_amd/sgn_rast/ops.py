@@ -202,6 +202,68 @@ class _SphericalHarmonics(Function):
         return None, None, v_coeffs, None
 
 
+# The reference builds its coefficient tensor as `torch.cat((features_dc, features_rest), dim=1)` of two leaf parameters
+# (sgn_splatfacto.py:858) — 192 MB at 1 M Gaussians.  A dense SH gradient [N,K,3] is then cut back into the two leaves by
+# autograd: CatBackward hands out strided views of it and AccumulateGrad copies each view into a contiguous `.grad`
+# (a 180 MB read + write per step, ~50 us, plus the 192 MB allocation).  When the graph behind `coeffs` PROVES that
+# shape — a CatBackward0 over dim 1 whose two inputs are float32 leaves [N,1,3] / [N,K-1,3], no hook on the
+# concatenation, nobody retaining its gradient — the SH node takes the two leaves as its autograd inputs and its
+# backward writes their gradients directly (the kernel the data-parallel exchange already uses, one view): same
+# values, no dense tensor, no copies.  Anything else takes the dense path.  `SGN_SH_SPLIT_BWD=0` switches it off.
+sh_split_backward = os.environ.get("SGN_SH_SPLIT_BWD", "1") != "0"
+sh_split_stats = {"split": 0, "dense": 0}
+
+
+def _cat_leaves(coeffs: torch.Tensor):
+    """(features_dc, features_rest) if ``coeffs`` is provably ``torch.cat((dc, rest), dim=1)`` of those two leaves."""
+    fn = coeffs.grad_fn
+    if fn is None or type(fn).__name__ != "CatBackward0" or getattr(fn, "_saved_dim", None) != 1:
+        return None
+    if coeffs._backward_hooks or coeffs.retains_grad or coeffs._version != 0:
+        return None                                    # someone wants the dense gradient / wrote into the concatenation
+    nxt = fn.next_functions
+    if len(nxt) != 2:
+        return None
+    dc, rest = (getattr(f[0], "variable", None) for f in nxt)      # AccumulateGrad nodes carry their leaf
+    if dc is None or rest is None or dc.dim() != 3 or rest.dim() != 3:
+        return None
+    n, k = coeffs.shape[0], coeffs.shape[1]
+    ok = (dc.shape == (n, 1, 3) and rest.shape == (n, k - 1, 3) and k > 1
+          and dc.dtype is torch.float32 and rest.dtype is torch.float32 and coeffs.dtype is torch.float32
+          and dc.is_cuda and rest.is_cuda and dc.is_contiguous() and rest.is_contiguous())
+    return (dc, rest) if ok else None
+
+
+class _SphericalHarmonicsSplit(Function):
+    """spherical_harmonics over a proven `cat((features_dc, features_rest), 1)`: reads the concatenation, differentiates
+    into the two leaves."""
+    @staticmethod
+    def forward(ctx, degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor, dc: torch.Tensor,
+                rest: torch.Tensor):
+        L.require_device(viewdirs, coeffs)
+        num_points, k = coeffs.shape[0], coeffs.shape[-2]
+        ctx.degrees_to_use, ctx.k = degrees_to_use, k
+        deg_from_sh(k)
+        viewdirs = _f32c(viewdirs)
+        colors = torch.empty(num_points, 3, dtype=torch.float32, device=coeffs.device)
+        L.check(L.load().sgn_sh_fwd(num_points, k, degrees_to_use, L.ptr(viewdirs), L.ptr(_f32c(coeffs)),
+                                    L.ptr(colors), L.stream_ptr()), "sgn_sh_fwd")
+        ctx.save_for_backward(viewdirs)
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors: torch.Tensor):
+        (viewdirs,) = ctx.saved_tensors
+        n = v_colors.shape[0]
+        v_colors = _f32c(v_colors)
+        f32 = dict(dtype=torch.float32, device=v_colors.device)
+        v_dc, v_rest = torch.empty(n, 1, 3, **f32), torch.empty(n, ctx.k - 1, 3, **f32)
+        L.check(L.load().sgn_sh_bwd_multi(n, ctx.k, ctx.degrees_to_use, 1, L.ptr(viewdirs), None, None, None, None,
+                                          L.ptr(v_colors), 1.0, L.ptr(v_rest), L.ptr(v_dc), L.stream_ptr()),
+                "sgn_sh_bwd_multi")
+        return None, None, None, v_dc, v_rest
+
+
 def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor,
                         method: str = "fast") -> torch.Tensor:
     """gsplat/sh.py spherical_harmonics (sgn_splatfacto.py:939; scene_graph.py:285).
@@ -212,6 +274,12 @@ def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: tor
     assert coeffs.shape[-2] >= num_sh_bases(degrees_to_use)
     assert method in ("poly", "fast"), "Invalid method."
     claimed = _sh_exchange is not None and _sh_exchange.claims_coeffs(coeffs)
+    if _sh_exchange is None and sh_split_backward and coeffs.is_contiguous():
+        leaves = _cat_leaves(coeffs)
+        if leaves is not None:
+            sh_split_stats["split"] += 1
+            return _SphericalHarmonicsSplit.apply(degrees_to_use, viewdirs.contiguous(), coeffs.detach(), *leaves)
+    sh_split_stats["dense"] += 1
     return _SphericalHarmonics.apply(degrees_to_use, viewdirs.contiguous(), coeffs.contiguous(), claimed)
 
 
@@ -220,30 +288,10 @@ class _ProjectGaussians(Function):
     @staticmethod
     def forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
                 block_width, clip_thresh=0.01):
-        num_points = means3d.shape[-2]
-        if num_points < 1 or means3d.shape[-1] != 3:
-            raise ValueError(f"Invalid shape for means3d: {means3d.shape}")
-        dev = L.require_device(means3d, scales, quats, viewmat)
-        means3d_c, scales_c, quats_c = _f32c(means3d), _f32c(scales), _f32c(quats)
-        viewmat_c = _f32c(viewmat).reshape(-1)[:12].contiguous()
-        n = num_points
-        f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
-        cov3d = torch.empty(n, 6, **f32)
-        xys = torch.empty(n, 2, **f32)
-        depths = torch.empty(n, **f32)
-        radii = torch.empty(n, **i32)
-        conics = torch.empty(n, 3, **f32)
-        compensation = torch.empty(n, **f32)
-        num_tiles_hit = torch.empty(n, **i32)
-        L.check(L.load().sgn_project_fwd(
-            n, L.ptr(means3d_c), L.ptr(scales_c), float(glob_scale), L.ptr(quats_c), L.ptr(viewmat_c),
-            float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width), int(block_width),
-            float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
-            L.ptr(compensation), L.ptr(num_tiles_hit), L.stream_ptr()), "sgn_project_fwd")
-        ctx.glob_scale, ctx.fx, ctx.fy = float(glob_scale), float(fx), float(fy)
-        ctx.save_for_backward(means3d_c, scales_c, quats_c, viewmat_c, cov3d, radii, conics, compensation)
-        ctx.mark_non_differentiable(radii, num_tiles_hit)
-        return xys, depths, radii, conics, compensation, num_tiles_hit, cov3d
+        outs, saved = _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
+                                       img_width, block_width, clip_thresh)
+        ctx.save_for_backward(*saved)
+        return outs
 
     @staticmethod
     def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_compensation, v_num_tiles_hit, v_cov3d):
@@ -266,6 +314,114 @@ class _ProjectGaussians(Function):
         # viewmat gradient: never requested by the reference (camera optimiser "off",
         # sgn_config.py:44) -> None, as upstream returns when viewmat.requires_grad is False.
         return v_mean, v_scale, None, v_quat, None, None, None, None, None, None, None, None, None
+
+
+# The reference hands `project_gaussians` its activated parameters — `torch.exp(scales)` (sgn_splatfacto.py:857) and
+# `quats / quats.norm(dim=-1, keepdim=True)` (:864) of two leaf parameters — and autograd then carries the projection's
+# gradient back through those expressions: ~10 small kernels and four graph nodes per step (division and norm
+# backward, their reductions, the accumulation of the two paths into `quats.grad`, the exp backward).  When the graph
+# behind the two arguments PROVES those shapes (ExpBackward0 over a leaf; DivBackward0 of a leaf by its own 2-norm over
+# the last dim with keepdim; nobody hooked or retained the activated tensors), the projection node takes the two LEAVES
+# as its autograd inputs and its backward returns their gradients from the kernel the fused API already has
+# (sgn_project_bwd_fused: activations differentiated inside).  The forward still runs on the caller's activated values,
+# bit for bit; gradients agree with the chain through torch to fp32 rounding.  `SGN_ACT_PROOFS=0` switches it off.
+activation_proofs = os.environ.get("SGN_ACT_PROOFS", "1") != "0"
+activation_proof_stats = {"project": 0, "opacity": 0, "colors": 0}
+_MINUS_ONE_DIMS = (1, -1, (1 << 64) - 1)      # how autograd saves dim=-1 of a 2-D tensor
+
+
+def _unhooked(t: torch.Tensor) -> bool:
+    return not t._backward_hooks and not t.retains_grad and t._version == 0
+
+
+def _leaf_of(node) -> Optional[torch.Tensor]:
+    v = getattr(node, "variable", None)            # AccumulateGrad nodes carry their leaf
+    if v is None or not v.is_cuda or v.dtype is not torch.float32 or not v.is_contiguous():
+        return None
+    return v
+
+
+def _activation_leaves(scales: torch.Tensor, quats: torch.Tensor):
+    """(log-scales leaf, raw quats leaf) if ``scales`` is provably ``exp(leaf)`` and ``quats`` provably
+    ``leaf / leaf.norm(dim=-1, keepdim=True)``; None otherwise."""
+    fs, fq = scales.grad_fn, quats.grad_fn
+    if fs is None or fq is None or type(fs).__name__ != "ExpBackward0" or type(fq).__name__ != "DivBackward0":
+        return None
+    if not (_unhooked(scales) and _unhooked(quats)) or scales.dim() != 2 or quats.dim() != 2:
+        return None
+    ls = _leaf_of(fs.next_functions[0][0])
+    nq = fq.next_functions
+    if ls is None or len(nq) != 2 or nq[1][0] is None or type(nq[1][0]).__name__ != "LinalgVectorNormBackward0":
+        return None
+    rq, norm = _leaf_of(nq[0][0]), nq[1][0]
+    if rq is None or _leaf_of(norm.next_functions[0][0]) is not rq:
+        return None
+    dims = tuple(getattr(norm, "_saved_dim", ()) or ())
+    if getattr(norm, "_saved_ord", None) != 2 or not getattr(norm, "_saved_keepdim", False) or len(dims) != 1 \
+            or int(dims[0]) not in _MINUS_ONE_DIMS:
+        return None
+    if ls.shape != scales.shape or rq.shape != quats.shape or quats.shape[1] != 4 or scales.shape[1] != 3:
+        return None
+    return ls, rq
+
+
+def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
+                     block_width, clip_thresh):
+    """Shared by the two projection nodes: launches sgn_project_fwd, returns (outputs, tensors to save)."""
+    num_points = means3d.shape[-2]
+    if num_points < 1 or means3d.shape[-1] != 3:
+        raise ValueError(f"Invalid shape for means3d: {means3d.shape}")
+    dev = L.require_device(means3d, scales, quats, viewmat)
+    means3d_c, scales_c, quats_c = _f32c(means3d), _f32c(scales), _f32c(quats)
+    viewmat_c = _f32c(viewmat).reshape(-1)[:12].contiguous()
+    n = num_points
+    f32, i32 = dict(dtype=torch.float32, device=dev), dict(dtype=torch.int32, device=dev)
+    cov3d = torch.empty(n, 6, **f32)
+    xys = torch.empty(n, 2, **f32)
+    depths = torch.empty(n, **f32)
+    radii = torch.empty(n, **i32)
+    conics = torch.empty(n, 3, **f32)
+    compensation = torch.empty(n, **f32)
+    num_tiles_hit = torch.empty(n, **i32)
+    L.check(L.load().sgn_project_fwd(
+        n, L.ptr(means3d_c), L.ptr(scales_c), float(glob_scale), L.ptr(quats_c), L.ptr(viewmat_c),
+        float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width), int(block_width),
+        float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
+        L.ptr(compensation), L.ptr(num_tiles_hit), L.stream_ptr()), "sgn_project_fwd")
+    ctx.glob_scale, ctx.fx, ctx.fy = float(glob_scale), float(fx), float(fy)
+    ctx.mark_non_differentiable(radii, num_tiles_hit)
+    return (xys, depths, radii, conics, compensation, num_tiles_hit, cov3d), \
+        (means3d_c, scales_c, quats_c, viewmat_c, cov3d, radii, conics, compensation)
+
+
+class _ProjectGaussiansAct(Function):
+    """project_gaussians over PROVEN activations: forward on the caller's activated values, backward straight into the
+    log-scale and raw-quaternion leaves (see the note above)."""
+    @staticmethod
+    def forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
+                block_width, clip_thresh, log_scales, raw_quats):
+        outs, saved = _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
+                                       img_width, block_width, clip_thresh)
+        means3d_c, _s, _q, viewmat_c, cov3d, radii, conics, compensation = saved
+        ctx.save_for_backward(means3d_c, log_scales, raw_quats, viewmat_c, cov3d, radii, conics, compensation)
+        return outs
+
+    @staticmethod
+    def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_compensation, v_num_tiles_hit, v_cov3d):
+        means3d, log_scales, raw_quats, viewmat, cov3d, radii, conics, compensation = ctx.saved_tensors
+        n, dev = means3d.shape[0], means3d.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        v_xys = _f32c(v_xys) if v_xys is not None else torch.zeros(n, 2, **f32)
+        v_depths = _f32c(v_depths) if v_depths is not None else None
+        v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros(n, 3, **f32)
+        v_comp = _f32c(v_compensation) if v_compensation is not None else None
+        v_mean, v_ls, v_rq = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32)
+        L.check(L.load().sgn_project_bwd_fused(
+            n, L.ptr(means3d), L.ptr(log_scales), ctx.glob_scale, L.ptr(raw_quats), None, None, L.ptr(viewmat),
+            ctx.fx, ctx.fy, L.ptr(cov3d), L.ptr(radii), L.ptr(conics), L.ptr(compensation), L.ptr(v_xys),
+            L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comp), L.ptr(v_mean), L.ptr(v_ls), L.ptr(v_rq),
+            L.stream_ptr()), "sgn_project_bwd_fused")
+        return (v_mean, None, None, None, None, None, None, None, None, None, None, None, None, v_ls, v_rq)
 
 
 # Upstream asserts `(quats.norm(dim=-1) - 1 < 1e-6).all()` on every project_gaussians call: four small kernels and a
@@ -404,9 +560,16 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     ``viewmat`` is the world->camera matrix ([3,4] or [4,4]; only rows 0-2 are read)."""
     assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
     token = _check_quats(quats)
-    out = _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
-                                  viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
-                                  clip_thresh)
+    leaves = _activation_leaves(scales, quats) if activation_proofs and scales.is_cuda else None
+    if leaves is not None:
+        activation_proof_stats["project"] += 1
+        out = _ProjectGaussiansAct.apply(means3d.contiguous(), scales.detach().contiguous(), glob_scale,
+                                         quats.detach().contiguous(), viewmat.contiguous(), fx, fy, cx, cy,
+                                         img_height, img_width, block_width, clip_thresh, *leaves)
+    else:
+        out = _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
+                                      viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
+                                      clip_thresh)
     _start_early_rank(out[1], out[2])  # depth ranking queued behind the projection, before the host waits
     _finish_quat_check(token)          # eager mode: the projection is already queued while the host waits here
     return out
@@ -870,7 +1033,11 @@ class _RasterizeGaussians(Function):
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
                 block_width, background=None, return_alpha=False, opacity_is_logit=False, id_range=None,
-                want_depth=False, colors_are_depths=False):
+                want_depth=False, colors_are_depths=False, opacity_logits=None, colors_pre=None):
+        # opacity_logits / colors_pre (proven by rasterize_gaussians, see _sigmoid_leaf / _clamp_pre): `opacity` is
+        # sigmoid(opacity_logits) and `colors` is clamp(colors_pre, min=0); both arrive DETACHED and the gradients go
+        # to the two extra inputs instead (the activations' backward runs inside sgn_raster_bwd's unpack kernel)
+        ctx.grad_to_logits, ctx.grad_to_pre = opacity_logits is not None, colors_pre is not None
         dev = L.require_device(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
         num_points = xys.size(0)
         tile_bounds = ((img_width + block_width - 1) // block_width,
@@ -1000,7 +1167,7 @@ class _RasterizeGaussians(Function):
         ctx.opacity_shape = opacity.shape
         ctx.recs = recs
         ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys_c, conics_c, colors_c, opac_c, bg_c,
-                              final_Ts, final_idx)
+                              final_Ts, final_idx, *([_f32c(colors_pre)] if colors_pre is not None else []))
         if want_depth:
             if out_depth is None:                 # nothing visible / a path without the channel: the two-pass image
                 out_depth = torch.zeros(img_height, img_width, **f32)
@@ -1015,7 +1182,8 @@ class _RasterizeGaussians(Function):
     @staticmethod
     def backward(ctx, v_out_img, v_out_alpha=None, _v_depth=None):
         (gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity, background, final_Ts,
-         final_idx) = ctx.saved_tensors
+         final_idx) = ctx.saved_tensors[:9]
+        colors_pre = ctx.saved_tensors[9] if ctx.grad_to_pre else None
         dev = xys.device
         n = xys.shape[0]                     # rows of the caller's tensors (= the window's rows in window mode)
         H, W = ctx.img_height, ctx.img_width
@@ -1045,15 +1213,41 @@ class _RasterizeGaussians(Function):
                 _S().walk_stat = order[-1:]          # rides to the host with the next binning's count (mask policy)
             L.check(lib.sgn_raster_bwd(
                 H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
-                L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity), ctx.opacity_is_logit, ctx.id_range[0],
+                L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity),
+                2 if ctx.grad_to_logits else ctx.opacity_is_logit, ctx.id_range[0],
                 ctx.id_range[1], ctx.window, L.ptr(background), L.ptr(final_Ts),
                 L.ptr(final_idx), L.ptr(v_out_img), L.ptr(v_out_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
                 L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
-                L.ptr(gws), gws.numel(), L.ptr(order), ro_ptr, L.stream_ptr(),
+                L.ptr(gws), gws.numel(), L.ptr(order), L.ptr(colors_pre), ro_ptr, L.stream_ptr(),
                 L.aux_stream_ptr(dev) if concurrent_backward else None), "sgn_raster_bwd")
         v_opacity = v_opacity.reshape(ctx.opacity_shape)
-        # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha)
-        return (v_xy, None, None, v_conic, None, v_colors, v_opacity) + (None,) * 9
+        # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha,
+        #  opacity_is_logit, id_range, want_depth, colors_are_depths, opacity_logits, colors_pre)
+        return (v_xy, None, None, v_conic, None, None if ctx.grad_to_pre else v_colors,
+                None if ctx.grad_to_logits else v_opacity) + (None,) * 9 + (
+            v_opacity if ctx.grad_to_logits else None, v_colors if ctx.grad_to_pre else None)
+
+
+def _sigmoid_leaf(opacity: torch.Tensor) -> Optional[torch.Tensor]:
+    """The logits leaf if ``opacity`` is provably ``torch.sigmoid(leaf)`` (sgn_splatfacto.py:949)."""
+    fn = opacity.grad_fn
+    if fn is None or type(fn).__name__ != "SigmoidBackward0" or not _unhooked(opacity):
+        return None
+    leaf = _leaf_of(fn.next_functions[0][0])
+    return leaf if leaf is not None and leaf.shape == opacity.shape else None
+
+
+def _clamp_pre(colors: torch.Tensor) -> Optional[torch.Tensor]:
+    """``pre`` if ``colors`` is provably ``torch.clamp(pre, min=0.0)`` with no upper bound (sgn_splatfacto.py:940)."""
+    fn = colors.grad_fn
+    if fn is None or type(fn).__name__ != "ClampBackward1" or not _unhooked(colors):
+        return None
+    if getattr(fn, "_saved_max", 0) is not None or getattr(fn, "_saved_min", None) != 0:
+        return None
+    pre = fn._saved_self
+    ok = (pre.shape == colors.shape and pre.dtype is torch.float32 and pre.is_cuda and pre.is_contiguous()
+          and pre.requires_grad)
+    return pre if ok else None
 
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height: int,
@@ -1074,11 +1268,17 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
         raise ValueError("xys must have dimensions (N, 2)")
     if colors.ndimension() != 2:
         raise ValueError("colors must have dimensions (N, D)")
+    logits = pre = None
+    if activation_proofs and opacity.is_cuda and colors.shape[-1] == 3:
+        logits, pre = _sigmoid_leaf(opacity), _clamp_pre(colors)
+        activation_proof_stats["opacity"] += logits is not None
+        activation_proof_stats["colors"] += pre is not None
     return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(),
-                                     conics.contiguous(), num_tiles_hit.contiguous(), colors.contiguous(),
-                                     opacity.contiguous(), img_height, img_width, block_width,
-                                     background.contiguous(), return_alpha, False, None, False,
-                                     depth_channel != "off" and _provably_depths(colors, depths))
+                                     conics.contiguous(), num_tiles_hit.contiguous(),
+                                     (colors.detach() if pre is not None else colors).contiguous(),
+                                     (opacity.detach() if logits is not None else opacity).contiguous(), img_height,
+                                     img_width, block_width, background.contiguous(), return_alpha, False, None, False,
+                                     depth_channel != "off" and _provably_depths(colors, depths), logits, pre)
 
 
 # -------------------------------------------------------------- _torch_impl
