@@ -745,6 +745,10 @@ def main():
         line["config"]["early_rank"] = dict(mode=ops.early_rank, **ops.early_rank_stats)
         line["config"]["depth_channel"] = dict(mode=ops.depth_channel, **ops.depth_stats)
         line["config"]["quadrant_masks"] = dict(mode=ops.quadrant_masks, **ops.quadrant_mask_stats)
+        # how often the operators could PROVE the reference's activation / concatenation expressions on the autograd
+        # graph and differentiated straight into the leaf parameters ("graph proofs")
+        line["config"]["graph_proofs"] = dict(enabled=dict(sh_split=bool(ops.sh_split_backward), activations=bool(ops.activation_proofs)),
+                                              sh=dict(ops.sh_split_stats), **ops.activation_proof_stats)
         if args.street:
             line["metric"] = "train-step images/sec (fwd+bwd), non-uniform street-like content (profiling workload)"
             line["config"]["workload"] = "street: " + line["config"]["workload"]
