@@ -75,6 +75,7 @@ class _ProjectFused(Function):
             saved += [oid, pos]
         ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(radii, nth)
+        ctx.set_materialize_grads(False)     # unused outputs arrive as None (ops._project_forward has the note)
         return xys, depths, radii, conics, comp, nth, cov3d
 
     @staticmethod

@@ -390,6 +390,9 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
         L.ptr(compensation), L.ptr(num_tiles_hit), L.stream_ptr()), "sgn_project_fwd")
     ctx.glob_scale, ctx.fx, ctx.fy = float(glob_scale), float(fx), float(fy)
     ctx.mark_non_differentiable(radii, num_tiles_hit)
+    # seven outputs, two or three of which the loss ever reaches: without this autograd materialises a zero tensor (an
+    # allocation and a fill kernel each) for every unused one before calling backward, which handles None itself
+    ctx.set_materialize_grads(False)
     return (xys, depths, radii, conics, compensation, num_tiles_hit, cov3d), \
         (means3d_c, scales_c, quats_c, viewmat_c, cov3d, radii, conics, compensation)
 
@@ -1038,6 +1041,7 @@ class _RasterizeGaussians(Function):
         # sigmoid(opacity_logits) and `colors` is clamp(colors_pre, min=0); both arrive DETACHED and the gradients go
         # to the two extra inputs instead (the activations' backward runs inside sgn_raster_bwd's unpack kernel)
         ctx.grad_to_logits, ctx.grad_to_pre = opacity_logits is not None, colors_pre is not None
+        ctx.set_materialize_grads(False)       # an unused alpha / depth output arrives as None, not as a zero image
         dev = L.require_device(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
         num_points = xys.size(0)
         tile_bounds = ((img_width + block_width - 1) // block_width,
@@ -1190,6 +1194,8 @@ class _RasterizeGaussians(Function):
         f32 = dict(dtype=torch.float32, device=dev)
         if v_out_alpha is None:
             v_out_alpha = torch.zeros(H, W, **f32)
+        if v_out_img is None:                # only the alpha (or depth) output reached the loss
+            v_out_img = torch.zeros(H, W, 3, **f32)
         v_out_img, v_out_alpha = _f32c(v_out_img), _f32c(v_out_alpha)
         v_xy = torch.empty(n, 2, **f32)
         v_conic = torch.empty(n, 3, **f32)
