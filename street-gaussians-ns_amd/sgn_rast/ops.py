@@ -230,7 +230,7 @@ def _cat_leaves(coeffs: torch.Tensor):
     n, k = coeffs.shape[0], coeffs.shape[1]
     ok = (dc.shape == (n, 1, 3) and rest.shape == (n, k - 1, 3) and k > 1
           and dc.dtype is torch.float32 and rest.dtype is torch.float32 and coeffs.dtype is torch.float32
-          and dc.is_cuda and rest.is_cuda and dc.is_contiguous() and rest.is_contiguous())
+          and (dc.is_cuda and rest.is_cuda or not _proofs_need_device) and dc.is_contiguous() and rest.is_contiguous())
     return (dc, rest) if ok else None
 
 
@@ -328,6 +328,7 @@ class _ProjectGaussians(Function):
 activation_proofs = os.environ.get("SGN_ACT_PROOFS", "1") != "0"
 activation_proof_stats = {"project": 0, "opacity": 0, "colors": 0}
 _MINUS_ONE_DIMS = (1, -1, (1 << 64) - 1)      # how autograd saves dim=-1 of a 2-D tensor
+_proofs_need_device = True    # tests/test_host_logic.py clears it to pin the graph matching itself on CPU tensors
 
 
 def _unhooked(t: torch.Tensor) -> bool:
@@ -336,7 +337,7 @@ def _unhooked(t: torch.Tensor) -> bool:
 
 def _leaf_of(node) -> Optional[torch.Tensor]:
     v = getattr(node, "variable", None)            # AccumulateGrad nodes carry their leaf
-    if v is None or not v.is_cuda or v.dtype is not torch.float32 or not v.is_contiguous():
+    if v is None or (_proofs_need_device and not v.is_cuda) or v.dtype is not torch.float32 or not v.is_contiguous():
         return None
     return v
 
@@ -1251,8 +1252,8 @@ def _clamp_pre(colors: torch.Tensor) -> Optional[torch.Tensor]:
     if getattr(fn, "_saved_max", 0) is not None or getattr(fn, "_saved_min", None) != 0:
         return None
     pre = fn._saved_self
-    ok = (pre.shape == colors.shape and pre.dtype is torch.float32 and pre.is_cuda and pre.is_contiguous()
-          and pre.requires_grad)
+    ok = (pre.shape == colors.shape and pre.dtype is torch.float32 and (pre.is_cuda or not _proofs_need_device)
+          and pre.is_contiguous() and pre.requires_grad)
     return pre if ok else None
 
 

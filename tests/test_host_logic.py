@@ -249,3 +249,44 @@ def test_empty_view_returns_the_reference_empty_outputs_and_still_reaches_the_re
     res = step.train_step(P, cam, w_img, w_a, ops=oracle_ops, reducer=Reducer(), caller_syncs=True)
     assert Reducer.called == 1 and float(res.loss) == 0.0
     assert all(p.grad is None for p in P.values())
+
+
+def test_graph_proofs_recognise_the_reference_expressions_on_this_torch(monkeypatch):
+    """The graph proofs of `ops` read autograd node types and saved attributes, which belong to the
+    installed PyTorch, not to a documented API: pin, on CPU tensors, that the reference's five expressions
+    (sgn_splatfacto.py:857,858,864,940,949) are still recognised and that near misses are not.  (If a PyTorch upgrade
+    renames a node the operators silently fall back to their plain autograd path: correct, slower — this test is what
+    notices.)"""
+    monkeypatch.setattr(ops, "_proofs_need_device", False)
+    n, k = 50, 16
+    dc = torch.randn(n, 1, 3, requires_grad=True)
+    rest = torch.randn(n, k - 1, 3, requires_grad=True)
+    ls = torch.randn(n, 3, requires_grad=True)
+    rq = torch.randn(n, 4, requires_grad=True)
+    lo = torch.randn(n, 1, requires_grad=True)
+    coeffs = torch.cat((dc, rest), dim=1)                                     # :858
+    got = ops._cat_leaves(coeffs)
+    assert got is not None and got[0] is dc and got[1] is rest
+    leaves = ops._activation_leaves(torch.exp(ls), rq / rq.norm(dim=-1, keepdim=True))     # :857, :864
+    assert leaves is not None and leaves[0] is ls and leaves[1] is rq
+    assert ops._sigmoid_leaf(torch.sigmoid(lo)) is lo                        # :949
+    sh = torch.randn(n, 3, requires_grad=True) * 1.0
+    pre = ops._clamp_pre(torch.clamp(sh + 0.5, min=0.0))                     # :940
+    assert pre is not None and type(pre.grad_fn).__name__ == "AddBackward0" and pre.shape == (n, 3)
+    # near misses
+    assert ops._cat_leaves(torch.cat((dc, rest), dim=1) * 1.0) is None
+    assert ops._cat_leaves(torch.cat((dc * 1.0, rest), dim=1)) is None
+    assert ops._cat_leaves(torch.cat((dc, rest), dim=1).detach()) is None
+    hooked = torch.cat((dc, rest), dim=1)
+    hooked.register_hook(lambda g: g)
+    assert ops._cat_leaves(hooked) is None
+    kept = torch.cat((dc, rest), dim=1)
+    kept.retain_grad()
+    assert ops._cat_leaves(kept) is None
+    assert ops._activation_leaves(torch.exp(ls) * 1.0, rq / rq.norm(dim=-1, keepdim=True)) is None
+    assert ops._activation_leaves(torch.exp(ls), rq / rq.norm(dim=-1)[:, None]) is None
+    assert ops._activation_leaves(torch.exp(ls), rq / rq.norm(p=1, dim=-1, keepdim=True)) is None
+    assert ops._activation_leaves(torch.exp(ls), rq / (rq * 1.0).norm(dim=-1, keepdim=True)) is None
+    assert ops._sigmoid_leaf(torch.sigmoid(lo * 1.0)) is None
+    assert ops._clamp_pre(torch.clamp(sh + 0.5, min=0.0, max=1.0)) is None
+    assert ops._clamp_pre(torch.clamp(sh + 0.5, min=0.1)) is None
