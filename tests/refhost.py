@@ -27,7 +27,8 @@ import torch
 from torch.overrides import TorchFunctionMode
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REFERENCE = os.environ.get("SGN_REFERENCE_ROOT", "/root/reference")
+_SCRATCH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_refscratch")     # tests/stage_reference.py
+REFERENCE = os.environ.get("SGN_REFERENCE_ROOT") or ("/root/reference" if os.path.isdir("/root/reference") else _SCRATCH)
 STUBS = os.path.join(HERE, "stubs")
 _NATIVE = ("gsplat", "gsplat._torch_impl", "gsplat.project_gaussians", "gsplat.rasterize", "gsplat.sh", "gsplat.utils",
            "pytorch_msssim", "nvdiffrast", "nvdiffrast.torch")

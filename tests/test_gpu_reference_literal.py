@@ -93,7 +93,14 @@ def test_single_model_runs_literally_on_the_hip_ops(ns):
     camera = refhost.nerfstudio_camera(ns, cam, time=0.0).to(DEV)
     batch = _batch()
     ops.clear_binning_cache()
+    sh0, act0 = dict(ops.sh_split_stats), dict(ops.activation_proof_stats)
     out = model.get_outputs(camera)                                            # the reference's code, literally
+    # the reference's own argument expressions (sgn_splatfacto.py:857,858,864,940,949) are what the graph proofs of the
+    # operators recognise: the literal run differentiates straight into the leaf parameters
+    assert ops.sh_split_stats["split"] == sh0["split"] + 1
+    assert ops.activation_proof_stats["project"] == act0["project"] + 1
+    assert ops.activation_proof_stats["opacity"] >= act0["opacity"] + 1
+    assert ops.activation_proof_stats["colors"] == act0["colors"] + 1
     losses = model.get_loss_dict(out, batch)
     sum(losses.values()).backward()
     assert set(out) == {"rgb", "accumulation", "depth", "sky"}
