@@ -71,6 +71,7 @@ class _State:
         self.side = None               # [pinned int32[4,8] (count, up to 6 deferred-check flags, walk statistic), next slot]
         self.walk_stat = None          # device int32[1]: the last backward's walked / listed permille, not yet read back
         self.walked_permille = None    # ... and the last value the host has seen (quadrant-mask policy)
+        self.stat_skipped = 0          # binnings since the statistic was last read back (every eighth one carries it)
         self.eager_side = None         # [pinned int32[8] ring for the eager flag read-back, next slot]
         self.depth_state = {"want": False, "unused": 0, "cache": None}
         self.depth_caches = collections.OrderedDict()                  # binning key -> first pass's channel + state
@@ -736,8 +737,14 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     pinned[0:1].copy_(cum_r[n - 1:n], non_blocking=True)
     for i, f in enumerate(flags):
         pinned[1 + i:2 + i].copy_(f, non_blocking=True)
-    walk_stat, S.walk_stat = S.walk_stat, None          # the last backward's walked / listed statistic rides along too
+    # the last backward's walked / listed statistic rides along too — not every time: each tiny device-to-host copy is a
+    # ~5 us item on the queue, and the policy it feeds does not need a fresh value per step
+    walk_stat, S.walk_stat = S.walk_stat, None
+    if walk_stat is not None and S.walked_permille is not None and S.stat_skipped < 7:
+        S.stat_skipped += 1
+        walk_stat = None
     if walk_stat is not None:
+        S.stat_skipped = 0
         pinned[7:8].copy_(walk_stat, non_blocking=True)
     done = torch.cuda.Event()
     done.record()
