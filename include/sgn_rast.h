@@ -140,6 +140,26 @@ int sgn_project_bwd_fused(int n, const float *means_local, const float *log_scal
                           const float *v_compensation, float *v_means_local, float *v_log_scales,
                           float *v_quats_raw, sgn_stream_t stream);
 
+/* Backward of the DROP-IN call `project_gaussians(means, scales, g, X / X.norm(dim=-1, keepdim=True))`
+ * (sgn_splatfacto.py:857-873) taken one step further back than sgn_project_bwd: gradients w.r.t. the means, the
+ * LOGARITHM of the scales (v_scale * scale — `scales` arrives activated, as the caller computed it, no second exp) and
+ * the UN-normalised quaternions X.  Used by the graph proofs of the drop-in operators (sgn_rast/proofs.py) when the
+ * autograd graph behind the two arguments shows `torch.exp(...)` and `X / X.norm(...)`; replaces the ~10 small kernels
+ * of torch's exp / div / norm backward.  World-frame means, no pose. */
+int sgn_project_bwd_act(int n, const float *means3d, const float *scales_activated, float glob_scale,
+                        const float *quats_unnormalised, const float *viewmat12, float fx, float fy,
+                        const float *cov3d, const int32_t *radii, const float *conics, const float *compensation,
+                        const float *v_xy, const float *v_depth, const float *v_conic, const float *v_compensation,
+                        float *v_mean3d, float *v_log_scales, float *v_quats_unnormalised, sgn_stream_t stream);
+
+/* Fourier DC fan-out (sgn_splatfacto_scene_graph.py:239-247: an object's effective DC term is
+ * `sum(features_dc * idft[..., None], dim=1, keepdim=True)`): for each listed part p, rows [row0[p], row0[p] + rows[p])
+ * of v_dc_eff [.,3] become  out_p[r, f, :] = v_dc_eff[row0[p] + r, :] * weights_p[f]  ([rows[p], n_fourier[p], 3]).
+ * The four arrays are HOST arrays of length n_parts (weights / out hold device pointers); one launch per 32 parts. */
+int sgn_fourier_dc_bwd(int n_parts, const int32_t *row0_host, const int32_t *rows_host, const int32_t *n_fourier_host,
+                       const float *const *weights_host, float *const *out_host, const float *v_dc_eff,
+                       sgn_stream_t stream);
+
 /* colors = [clamp(. + 0.5, min 0)] SH(degree, means - cam_pos, [dc_eff | features_rest]),
  * dc_eff = sum_f features_dc[:, f, :] * idft[object, f]  (Fourier DC term,
  * sgn_splatfacto_scene_graph.py:239-247,420-433; n_fourier = 1 and idft = {1} for plain models).
@@ -265,7 +285,9 @@ int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const in
  * (:270-276).  mismatch[c] (device, int32, c < n_cand <= 4) becomes 0 iff the window tensors equal rows
  * [cand_lo_host[c], cand_lo_host[c] + n_win) of the full-scene tensors BIT FOR BIT (xys [.,2], depths, radii,
  * num_tiles_hit; conics [.,3] and opacities too when given - the exact tile culling depends on them); the caller may
- * then rasterize the window over the depth list binned for the full scene (sgn_raster_fwd with id range + window). */
+ * then rasterize the window over the depth list binned for the full scene (sgn_raster_fwd with id range + window).
+ * Any tensor pair may be omitted (NULL on BOTH sides) when the caller has settled it another way — the Python host
+ * proves the four differentiable tensors from the autograd graph and sends only radii / num_tiles_hit. */
 int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *cand_lo_host, const float *xys_w,
                    const float *depths_w, const int32_t *radii_w, const int32_t *num_tiles_hit_w, const float *conics_w,
                    const float *opacities_w, const float *xys, const float *depths, const int32_t *radii,

@@ -974,8 +974,13 @@ SGN_EXPORT int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *
                               const int32_t *radii, const int32_t *num_tiles_hit, const float *conics,
                               const float *opacities, int32_t *mismatch, sgn_stream_t stream) {
     SGN_ARG_CHECK(n_win > 0 && n_full >= n_win && n_cand >= 1 && n_cand <= 4 && cand_lo_host && mismatch, -1);
-    SGN_ARG_CHECK(xys_w && depths_w && radii_w && num_tiles_hit_w && xys && depths && radii && num_tiles_hit, -2);
+    // any subset of the six tensors may be compared (a caller that has settled some of them another way passes NULL for
+    // both sides of those), but each pair must be given or omitted together, and at least one must be given
+    SGN_ARG_CHECK((xys_w == nullptr) == (xys == nullptr) && (depths_w == nullptr) == (depths == nullptr) &&
+                      (radii_w == nullptr) == (radii == nullptr) &&
+                      (num_tiles_hit_w == nullptr) == (num_tiles_hit == nullptr), -2);
     SGN_ARG_CHECK((conics_w == nullptr) == (conics == nullptr) && (opacities_w == nullptr) == (opacities == nullptr), -3);
+    SGN_ARG_CHECK(xys_w || depths_w || radii_w || num_tiles_hit_w || conics_w || opacities_w, -5);
     MatchArgs a;
     const void *w[6] = {xys_w, depths_w, radii_w, num_tiles_hit_w, conics_w, opacities_w};
     const void *f[6] = {xys, depths, radii, num_tiles_hit, conics, opacities};
@@ -988,7 +993,11 @@ SGN_EXPORT int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *
     }
     hipStream_t s = (hipStream_t)stream;
     SGN_HIP_CHECK(hipMemsetAsync(mismatch, 0, sizeof(int32_t) * n_cand, s));
-    hipLaunchKernelGGL(rows_match_kernel, dim3(sgn_cdiv((int64_t)n_win * 3, 256)), dim3(256), 0, s, n_win, a, mismatch);
+    int max_width = 1;
+    for (int t = 0; t < 6; ++t)
+        if (w[t] != nullptr && width[t] > max_width) max_width = width[t];
+    hipLaunchKernelGGL(rows_match_kernel, dim3(sgn_cdiv((int64_t)n_win * max_width, 256)), dim3(256), 0, s, n_win, a,
+                       mismatch);
     SGN_LAUNCH_CHECK();
     return 0;
 }

@@ -49,14 +49,18 @@ struct Loaded {
     float es[3];            // exp(log_scale) (fused only)
 };
 
-template <bool FUSED>
+// MODE 0: activated inputs as upstream hands them.  MODE 1: the fused front end (log-scales, raw quaternions, optional
+// pose).  MODE 2 (backward of the drop-in graph proofs, sgn_project_bwd_act): ACTIVATED scales as the caller computed
+// them (exp of something: d/d log-scale = v_scale * scale, no second exp) and the UN-normalised quaternions X the
+// caller divided by their norm (sgn_splatfacto.py:864); world-frame means, no pose.
+template <int MODE>
 __device__ __forceinline__ Loaded load_gaussian(int i, const float *__restrict__ means,
                                                 const float *__restrict__ scales,
                                                 const float *__restrict__ quats, float glob_scale, Fuse f) {
     Loaded L;
     const float m0 = means[3 * i], m1 = means[3 * i + 1], m2 = means[3 * i + 2];
     const float q0 = quats[4 * i], q1 = quats[4 * i + 1], q2 = quats[4 * i + 2], q3 = quats[4 * i + 3];
-    if constexpr (!FUSED) {
+    if constexpr (MODE == 0) {
         L.p[0] = m0; L.p[1] = m1; L.p[2] = m2;
         L.q[0] = q0; L.q[1] = q1; L.q[2] = q2; L.q[3] = q3;
 #pragma unroll
@@ -80,14 +84,14 @@ __device__ __forceinline__ Loaded load_gaussian(int i, const float *__restrict__
         L.q[0] = rw * L.inv_norm; L.q[1] = rx * L.inv_norm; L.q[2] = ry * L.inv_norm; L.q[3] = rz * L.inv_norm;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            L.es[c] = expf(scales[3 * i + c]);
+            L.es[c] = MODE == 2 ? scales[3 * i + c] : expf(scales[3 * i + c]);
             L.s[c] = glob_scale * L.es[c];
         }
     }
     return L;
 }
 
-template <bool FUSED>
+template <int FUSED>
 __global__ __launch_bounds__(256) void project_fwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ scales,
     const float *__restrict__ quats, Cam cam, Fuse fuse, float *__restrict__ cov3d, float *__restrict__ xys,
@@ -179,7 +183,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     num_tiles_hit[i] = o_n;
 }
 
-template <bool FUSED>
+template <int FUSED>
 __global__ __launch_bounds__(256) void project_bwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ scales,
     const float *__restrict__ quats, Cam cam, Fuse fuse, const float *__restrict__ cov3d,
@@ -304,7 +308,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
                          z * (vR[2][1] + vR[1][2]) + w * (vR[0][2] - vR[2][0]));
         o_vq[3] = 2.f * (x * (vR[2][0] + vR[0][2]) + y * (vR[2][1] + vR[1][2]) -
                          2.f * z * (vR[0][0] + vR[1][1]) + w * (vR[1][0] - vR[0][1]));
-        if constexpr (FUSED) {
+        if constexpr (FUSED != 0) {
             // chain rules of the fused front end: exp, normalisation, Hamilton product, rigid transform
 #pragma unroll
             for (int c = 0; c < 3; ++c) o_vs[c] = o_vs[c] * LG.es[c];            // d/d log_scale
@@ -372,7 +376,7 @@ SGN_EXPORT int sgn_project_fwd(int n, const float *means3d, const float *scales,
                       conics && compensation && num_tiles_hit, -4);
     const Cam cam = make_cam(viewmat12, fx, fy, cx, cy, img_h, img_w, block_width, clip_thresh, glob_scale);
     sgn_timing_begin(SGN_T_PROJECT_FWD, stream);
-    hipLaunchKernelGGL(project_fwd_kernel<false>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+    hipLaunchKernelGGL(project_fwd_kernel<0>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means3d, scales, quats, cam, Fuse{nullptr, nullptr}, cov3d, xys, depths, radii, conics,
                        compensation, num_tiles_hit);
     sgn_timing_end(SGN_T_PROJECT_FWD, stream);
@@ -394,7 +398,7 @@ SGN_EXPORT int sgn_project_bwd(int n, const float *means3d, const float *scales,
     SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
     const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
     sgn_timing_begin(SGN_T_PROJECT_BWD, stream);
-    hipLaunchKernelGGL(project_bwd_kernel<false>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+    hipLaunchKernelGGL(project_bwd_kernel<0>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means3d, scales, quats, cam, Fuse{nullptr, nullptr}, cov3d, radii, conics, compensation, v_xy,
                        v_depth, v_conic, v_compensation, v_cov2d, v_cov3d, v_mean3d, v_scale, v_quat);
     sgn_timing_end(SGN_T_PROJECT_BWD, stream);
@@ -418,7 +422,7 @@ SGN_EXPORT int sgn_project_fwd_fused(int n, const float *means_local, const floa
     SGN_ARG_CHECK((object_ids == nullptr) == (poses == nullptr), -5);
     const Cam cam = make_cam(viewmat12, fx, fy, cx, cy, img_h, img_w, block_width, clip_thresh, glob_scale);
     sgn_timing_begin(SGN_T_PROJECT_FWD, stream);
-    hipLaunchKernelGGL(project_fwd_kernel<true>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+    hipLaunchKernelGGL(project_fwd_kernel<1>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means_local, log_scales, quats_raw, cam, Fuse{object_ids, poses}, cov3d, xys, depths, radii,
                        conics, compensation, num_tiles_hit);
     sgn_timing_end(SGN_T_PROJECT_FWD, stream);
@@ -441,10 +445,36 @@ SGN_EXPORT int sgn_project_bwd_fused(int n, const float *means_local, const floa
     SGN_ARG_CHECK((object_ids == nullptr) == (poses == nullptr), -6);
     const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
     sgn_timing_begin(SGN_T_PROJECT_BWD, stream);
-    hipLaunchKernelGGL(project_bwd_kernel<true>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+    hipLaunchKernelGGL(project_bwd_kernel<1>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means_local, log_scales, quats_raw, cam, Fuse{object_ids, poses}, cov3d, radii, conics,
                        compensation, v_xy, v_depth, v_conic, v_compensation, nullptr, nullptr, v_means_local,
                        v_log_scales, v_quats_raw);
+    sgn_timing_end(SGN_T_PROJECT_BWD, stream);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward of `project_gaussians(means, scales, g, X / |X|)` (the drop-in call, sgn_splatfacto.py:857-873) taken
+// one step further back than sgn_project_bwd: gradients w.r.t. the means, the LOGARITHM of the scales (v_scale * scale)
+// and the UN-normalised quaternions X.  What the graph proofs of the drop-in operators call when the autograd graph
+// shows `scales = exp(...)` and `quats = X / X.norm(dim=-1, keepdim=True)` (sgn_rast/proofs.py).
+SGN_EXPORT int sgn_project_bwd_act(int n, const float *means3d, const float *scales_activated, float glob_scale,
+                                   const float *quats_unnormalised, const float *viewmat12, float fx, float fy,
+                                   const float *cov3d, const int32_t *radii, const float *conics,
+                                   const float *compensation, const float *v_xy, const float *v_depth,
+                                   const float *v_conic, const float *v_compensation, float *v_mean3d,
+                                   float *v_log_scales, float *v_quats_unnormalised, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0, -1);
+    if (n == 0) return 0;
+    SGN_ARG_CHECK(means3d && scales_activated && quats_unnormalised && viewmat12 && cov3d && radii && conics && v_xy &&
+                      v_conic && v_mean3d && v_log_scales && v_quats_unnormalised, -4);
+    SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
+    const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
+    sgn_timing_begin(SGN_T_PROJECT_BWD, stream);
+    hipLaunchKernelGGL(project_bwd_kernel<2>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
+                       means3d, scales_activated, quats_unnormalised, cam, Fuse{nullptr, nullptr}, cov3d, radii, conics,
+                       compensation, v_xy, v_depth, v_conic, v_compensation, nullptr, nullptr, v_mean3d,
+                       v_log_scales, v_quats_unnormalised);
     sgn_timing_end(SGN_T_PROJECT_BWD, stream);
     SGN_LAUNCH_CHECK();
     return 0;

@@ -578,3 +578,66 @@ SGN_EXPORT int sgn_sh_bwd_multi(int n, int k, int degree, int n_views, const flo
     SGN_LAUNCH_CHECK();
     return 0;
 }
+
+// ---- Fourier DC fan-out (drop-in graph proofs over the scene graph's aggregation) -------------------------------------
+// The scene graph builds an object's effective DC term as `sum(features_dc * idft[..., None], dim=1, keepdim=True)`
+// (sgn_splatfacto_scene_graph.py:239-247) and concatenates those per-object terms (:356).  When the SH node's backward
+// holds the gradient of the concatenated effective term, v_dc_eff [N,3], each Fourier leaf's gradient is
+// v_features_dc[r, f, :] = v_dc_eff[row0 + r, :] * idft[f]: one launch for all the objects instead of three autograd
+// nodes and two kernels per object.
+namespace {
+constexpr int FOURIER_MAX_PARTS = 32;
+struct FourierParts {
+    int n_parts;
+    int cum[FOURIER_MAX_PARTS + 1];   // cumulative row counts of the listed parts
+    int row0[FOURIER_MAX_PARTS];      // first row of the part in v_dc_eff
+    int F[FOURIER_MAX_PARTS];
+    const float *w[FOURIER_MAX_PARTS];
+    float *out[FOURIER_MAX_PARTS];
+};
+
+__global__ __launch_bounds__(256) void fourier_dc_bwd_kernel(FourierParts P, const float *__restrict__ v_dc_eff) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= P.cum[P.n_parts]) return;
+    int p = 0;
+    while (p + 1 < P.n_parts && t >= P.cum[p + 1]) ++p;
+    const int r = t - P.cum[p];
+    const size_t row = (size_t)P.row0[p] + r;
+    const float v0 = v_dc_eff[3 * row], v1 = v_dc_eff[3 * row + 1], v2 = v_dc_eff[3 * row + 2];
+    const int F = P.F[p];
+    float *o = P.out[p] + (size_t)r * F * 3;
+    const float *w = P.w[p];
+    for (int f = 0; f < F; ++f) {
+        const float wf = w[f];
+        o[3 * f] = v0 * wf; o[3 * f + 1] = v1 * wf; o[3 * f + 2] = v2 * wf;
+    }
+}
+}  // namespace
+
+SGN_EXPORT int sgn_fourier_dc_bwd(int n_parts, const int32_t *row0_host, const int32_t *rows_host,
+                                  const int32_t *n_fourier_host, const float *const *weights_host,
+                                  float *const *out_host, const float *v_dc_eff, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n_parts >= 0, -1);
+    if (n_parts == 0) return 0;
+    SGN_ARG_CHECK(row0_host && rows_host && n_fourier_host && weights_host && out_host && v_dc_eff, -2);
+    for (int base = 0; base < n_parts; base += FOURIER_MAX_PARTS) {
+        FourierParts P;
+        P.n_parts = n_parts - base < FOURIER_MAX_PARTS ? n_parts - base : FOURIER_MAX_PARTS;
+        P.cum[0] = 0;
+        for (int i = 0; i < P.n_parts; ++i) {
+            SGN_ARG_CHECK(rows_host[base + i] >= 0 && row0_host[base + i] >= 0, -3);
+            SGN_ARG_CHECK(n_fourier_host[base + i] >= 1 && n_fourier_host[base + i] <= 64, -4);
+            SGN_ARG_CHECK(weights_host[base + i] && out_host[base + i], -5);
+            P.cum[i + 1] = P.cum[i] + rows_host[base + i];
+            P.row0[i] = row0_host[base + i];
+            P.F[i] = n_fourier_host[base + i];
+            P.w[i] = weights_host[base + i];
+            P.out[i] = out_host[base + i];
+        }
+        if (P.cum[P.n_parts] == 0) continue;
+        hipLaunchKernelGGL(fourier_dc_bwd_kernel, dim3(sgn_cdiv(P.cum[P.n_parts], 256)), dim3(256), 0,
+                           (hipStream_t)stream, P, v_dc_eff);
+    }
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

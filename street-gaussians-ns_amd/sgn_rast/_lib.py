@@ -33,6 +33,9 @@ SIGNATURES = {
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_project_bwd_fused": (_i, [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp, _vp]),
+    "sgn_project_bwd_act": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                 _vp, _vp, _vp, _vp]),
+    "sgn_fourier_dc_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_sh_fwd_fused": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sgn_sh_bwd_fused": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sgn_cube_texture_fwd": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -23,6 +23,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
+from . import proofs
 
 # gsplat 0.1.x clamps alpha at 0.999 in rasterize_forward and 0.99 in rasterize_backward.
 UPSTREAM_ALPHA_CLAMP_BWD = 0.99
@@ -62,7 +63,8 @@ class _State:
     BIN_ENTRIES = 4
 
     def __init__(self):
-        self.bin_cache = {"key": None, "keep": None, "val": None}      # the most recent binning (window matching)
+        # the most recent binning (window matching); "info": what the autograd graph said about its tensors
+        self.bin_cache = {"key": None, "keep": None, "val": None, "info": None}
         self.bin_older = collections.OrderedDict()                     # key -> (keep, val) of the three before it
         self.bin_pending = {"key": None, "state": None, "keep": None}
         self.order_cache = collections.OrderedDict()                   # (id(tile_bins), thresh) -> (tile_bins, order)
@@ -86,14 +88,16 @@ class _State:
             return None
         self._retire_current()
         self.bin_cache["key"], (self.bin_cache["keep"], self.bin_cache["val"]) = key, hit
+        self.bin_cache["info"] = None
         return hit[1]
 
     def has_binning(self, key) -> bool:
         return self.bin_cache["key"] == key or key in self.bin_older
 
-    def store_binning(self, key, keep, val) -> None:
+    def store_binning(self, key, keep, val, info=None) -> None:
         self._retire_current()
         self.bin_cache["key"], self.bin_cache["keep"], self.bin_cache["val"] = key, keep, val
+        self.bin_cache["info"] = info        # holds autograd nodes of the step: only ever on the most recent entry
 
     def _retire_current(self) -> None:
         k = self.bin_cache["key"]
@@ -104,7 +108,7 @@ class _State:
                 self.depth_caches.pop(old, None)
 
     def clear_binning(self) -> None:
-        self.bin_cache["key"] = self.bin_cache["keep"] = self.bin_cache["val"] = None
+        self.bin_cache["key"] = self.bin_cache["keep"] = self.bin_cache["val"] = self.bin_cache["info"] = None
         self.bin_older.clear()
         self.order_cache.clear()
         self.depth_caches.clear()
@@ -180,6 +184,7 @@ class _SphericalHarmonics(Function):
         L.require_device(viewdirs, coeffs)
         num_points, k = coeffs.shape[0], coeffs.shape[-2]
         ctx.degrees_to_use, ctx.k, ctx.claimed = degrees_to_use, k, bool(claimed)
+        ctx.set_materialize_grads(False)
         deg_from_sh(k)
         viewdirs = _f32c(viewdirs)
         coeffs_c = _f32c(coeffs)
@@ -191,7 +196,11 @@ class _SphericalHarmonics(Function):
 
     @staticmethod
     def backward(ctx, v_colors: torch.Tensor):
+        if v_colors is None and _sh_exchange is None:   # the colours took no part in the loss (accumulation-only pass)
+            return None, None, None, None
         (viewdirs,) = ctx.saved_tensors
+        if v_colors is None:
+            v_colors = torch.zeros(viewdirs.shape[0], 3, dtype=torch.float32, device=viewdirs.device)
         n = v_colors.shape[0]
         v_colors = _f32c(v_colors)
         if _sh_exchange is not None and _sh_exchange.tap_dirs(viewdirs, v_colors, ctx.degrees_to_use, ctx.k,
@@ -206,44 +215,30 @@ class _SphericalHarmonics(Function):
 # The reference builds its coefficient tensor as `torch.cat((features_dc, features_rest), dim=1)` of two leaf parameters
 # (sgn_splatfacto.py:858) — 192 MB at 1 M Gaussians.  A dense SH gradient [N,K,3] is then cut back into the two leaves by
 # autograd: CatBackward hands out strided views of it and AccumulateGrad copies each view into a contiguous `.grad`
-# (a 180 MB read + write per step, ~50 us, plus the 192 MB allocation).  When the graph behind `coeffs` PROVES that
-# shape — a CatBackward0 over dim 1 whose two inputs are float32 leaves [N,1,3] / [N,K-1,3], no hook on the
-# concatenation, nobody retaining its gradient — the SH node takes the two leaves as its autograd inputs and its
-# backward writes their gradients directly (the kernel the data-parallel exchange already uses, one view): same
-# values, no dense tensor, no copies.  Anything else takes the dense path.  `SGN_SH_SPLIT_BWD=0` switches it off.
+# (a 180 MB read + write per step, ~50 us, plus the 192 MB allocation).  In the scene graph the two halves are themselves
+# row-wise concatenations over the sub-models, the objects' DC term a Fourier sum (scene_graph.py:239-247, 355-360): two
+# more levels of strided views, ~20 copy kernels and ~40 graph nodes.  When the graph behind `coeffs` PROVES that shape
+# (proofs.sh_source; no hook on the concatenation, nobody retaining its gradient) the SH node takes the LEAVES as its
+# autograd inputs and its backward writes their gradients directly: one kernel for band 0 / the rest, one more for all
+# Fourier fan-outs; same values, no dense tensor, no copies.  Anything else takes the dense path.
+# `SGN_SH_SPLIT_BWD=0` switches it off.
 sh_split_backward = os.environ.get("SGN_SH_SPLIT_BWD", "1") != "0"
 sh_split_stats = {"split": 0, "dense": 0}
 
 
-def _cat_leaves(coeffs: torch.Tensor):
-    """(features_dc, features_rest) if ``coeffs`` is provably ``torch.cat((dc, rest), dim=1)`` of those two leaves."""
-    fn = coeffs.grad_fn
-    if fn is None or type(fn).__name__ != "CatBackward0" or getattr(fn, "_saved_dim", None) != 1:
-        return None
-    if coeffs._backward_hooks or coeffs.retains_grad or coeffs._version != 0:
-        return None                                    # someone wants the dense gradient / wrote into the concatenation
-    nxt = fn.next_functions
-    if len(nxt) != 2:
-        return None
-    dc, rest = (getattr(f[0], "variable", None) for f in nxt)      # AccumulateGrad nodes carry their leaf
-    if dc is None or rest is None or dc.dim() != 3 or rest.dim() != 3:
-        return None
-    n, k = coeffs.shape[0], coeffs.shape[1]
-    ok = (dc.shape == (n, 1, 3) and rest.shape == (n, k - 1, 3) and k > 1
-          and dc.dtype is torch.float32 and rest.dtype is torch.float32 and coeffs.dtype is torch.float32
-          and (dc.is_cuda and rest.is_cuda or not _proofs_need_device) and dc.is_contiguous() and rest.is_contiguous())
-    return (dc, rest) if ok else None
+def _proofs_on(flag: bool) -> bool:
+    return flag and proofs.enabled()
 
 
 class _SphericalHarmonicsSplit(Function):
-    """spherical_harmonics over a proven `cat((features_dc, features_rest), 1)`: reads the concatenation, differentiates
-    into the two leaves."""
+    """spherical_harmonics over a proven `cat((DC, REST), 1)`: reads the concatenation, differentiates into the leaves
+    (`src`: proofs.ShSource; the leaves follow as autograd inputs, DC parts first, then the REST leaves)."""
     @staticmethod
-    def forward(ctx, degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor, dc: torch.Tensor,
-                rest: torch.Tensor):
+    def forward(ctx, degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor, src, *leaves):
         L.require_device(viewdirs, coeffs)
         num_points, k = coeffs.shape[0], coeffs.shape[-2]
-        ctx.degrees_to_use, ctx.k = degrees_to_use, k
+        ctx.degrees_to_use, ctx.k, ctx.src = degrees_to_use, k, src
+        ctx.set_materialize_grads(False)
         deg_from_sh(k)
         viewdirs = _f32c(viewdirs)
         colors = torch.empty(num_points, 3, dtype=torch.float32, device=coeffs.device)
@@ -253,16 +248,43 @@ class _SphericalHarmonicsSplit(Function):
         return colors
 
     @staticmethod
-    def backward(ctx, v_colors: torch.Tensor):
+    def backward(ctx, v_colors):
+        src = ctx.src
+        n_leaves = len(src.dc) + len(src.rest)
+        if v_colors is None:                     # the colours took no part in the loss (an accumulation-only pass)
+            return (None,) * (4 + n_leaves)
         (viewdirs,) = ctx.saved_tensors
         n = v_colors.shape[0]
         v_colors = _f32c(v_colors)
         f32 = dict(dtype=torch.float32, device=v_colors.device)
+        lib = L.load()
         v_dc, v_rest = torch.empty(n, 1, 3, **f32), torch.empty(n, ctx.k - 1, 3, **f32)
-        L.check(L.load().sgn_sh_bwd_multi(n, ctx.k, ctx.degrees_to_use, 1, L.ptr(viewdirs), None, None, None, None,
-                                          L.ptr(v_colors), 1.0, L.ptr(v_rest), L.ptr(v_dc), L.stream_ptr()),
+        L.check(lib.sgn_sh_bwd_multi(n, ctx.k, ctx.degrees_to_use, 1, L.ptr(viewdirs), None, None, None, None,
+                                     L.ptr(v_colors), 1.0, L.ptr(v_rest), L.ptr(v_dc), L.stream_ptr()),
                 "sgn_sh_bwd_multi")
-        return None, None, None, v_dc, v_rest
+        # DC: plain parts are row windows of v_dc; the Fourier parts fan out in ONE launch
+        grads, row, four = [], 0, []
+        for part in src.dc:
+            rows = part.leaf.shape[0]
+            if part.weights is None:
+                grads.append(v_dc if rows == n else v_dc[row:row + rows])
+            else:
+                out = torch.empty(part.leaf.shape, **f32)
+                four.append((row, rows, part.leaf.shape[1], part.weights, out))
+                grads.append(out)
+            row += rows
+        if four:
+            m = len(four)
+            i32s, ptrs = C.c_int32 * m, C.c_void_p * m
+            L.check(lib.sgn_fourier_dc_bwd(m, i32s(*[f[0] for f in four]), i32s(*[f[1] for f in four]),
+                                           i32s(*[f[2] for f in four]), ptrs(*[f[3].data_ptr() for f in four]),
+                                           ptrs(*[f[4].data_ptr() for f in four]), L.ptr(v_dc), L.stream_ptr()),
+                    "sgn_fourier_dc_bwd")
+        if len(src.rest) == 1:
+            grads.append(v_rest)
+        else:
+            grads.extend(v_rest.split([r.shape[0] for r in src.rest]))
+        return (None, None, None, None) + tuple(grads)
 
 
 def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor,
@@ -275,11 +297,13 @@ def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: tor
     assert coeffs.shape[-2] >= num_sh_bases(degrees_to_use)
     assert method in ("poly", "fast"), "Invalid method."
     claimed = _sh_exchange is not None and _sh_exchange.claims_coeffs(coeffs)
-    if _sh_exchange is None and sh_split_backward and coeffs.is_contiguous():
-        leaves = _cat_leaves(coeffs)
-        if leaves is not None:
+    if _sh_exchange is None and _proofs_on(sh_split_backward) and coeffs.is_contiguous() and (
+            coeffs.is_cuda or not proofs.need_device):
+        src = proofs.sh_source(coeffs)
+        if src is not None:
             sh_split_stats["split"] += 1
-            return _SphericalHarmonicsSplit.apply(degrees_to_use, viewdirs.contiguous(), coeffs.detach(), *leaves)
+            return _SphericalHarmonicsSplit.apply(degrees_to_use, viewdirs.contiguous(), coeffs.detach(), src,
+                                                  *[p.leaf for p in src.dc], *src.rest)
     sh_split_stats["dense"] += 1
     return _SphericalHarmonics.apply(degrees_to_use, viewdirs.contiguous(), coeffs.contiguous(), claimed)
 
@@ -318,53 +342,18 @@ class _ProjectGaussians(Function):
 
 
 # The reference hands `project_gaussians` its activated parameters — `torch.exp(scales)` (sgn_splatfacto.py:857) and
-# `quats / quats.norm(dim=-1, keepdim=True)` (:864) of two leaf parameters — and autograd then carries the projection's
-# gradient back through those expressions: ~10 small kernels and four graph nodes per step (division and norm
-# backward, their reductions, the accumulation of the two paths into `quats.grad`, the exp backward).  When the graph
-# behind the two arguments PROVES those shapes (ExpBackward0 over a leaf; DivBackward0 of a leaf by its own 2-norm over
-# the last dim with keepdim; nobody hooked or retained the activated tensors), the projection node takes the two LEAVES
-# as its autograd inputs and its backward returns their gradients from the kernel the fused API already has
-# (sgn_project_bwd_fused: activations differentiated inside).  The forward still runs on the caller's activated values,
-# bit for bit; gradients agree with the chain through torch to fp32 rounding.  `SGN_ACT_PROOFS=0` switches it off.
+# `quats / quats.norm(dim=-1, keepdim=True)` (:864) — and autograd then carries the projection's gradient back through
+# those expressions: ~10 small kernels and four graph nodes per step (division and norm backward, their reductions, the
+# accumulation of the two paths, the exp backward), in the scene graph additionally the row-wise split of the scale
+# gradient over the sub-models.  When the graph behind the two arguments PROVES those shapes (proofs.exp_leaves: exp of a
+# leaf or of a row-wise concatenation of leaves; proofs.normalised_source: X divided by its own 2-norm over the last dim
+# with keepdim; nobody hooked or retained the activated tensors), the projection node takes the log-scale LEAVES and X as
+# its autograd inputs and its backward returns their gradients from one kernel (sgn_project_bwd_act: exp and
+# normalisation differentiated inside, from the caller's activated scales and from X — nothing is recomputed from the
+# leaves' current values).  The forward still runs on the caller's activated values, bit for bit; gradients agree with
+# the chain through torch to fp32 rounding.  `SGN_ACT_PROOFS=0` switches it off.
 activation_proofs = os.environ.get("SGN_ACT_PROOFS", "1") != "0"
-activation_proof_stats = {"project": 0, "opacity": 0, "colors": 0}
-_MINUS_ONE_DIMS = (1, -1, (1 << 64) - 1)      # how autograd saves dim=-1 of a 2-D tensor
-_proofs_need_device = True    # tests/test_host_logic.py clears it to pin the graph matching itself on CPU tensors
-
-
-def _unhooked(t: torch.Tensor) -> bool:
-    return not t._backward_hooks and not t.retains_grad and t._version == 0
-
-
-def _leaf_of(node) -> Optional[torch.Tensor]:
-    v = getattr(node, "variable", None)            # AccumulateGrad nodes carry their leaf
-    if v is None or (_proofs_need_device and not v.is_cuda) or v.dtype is not torch.float32 or not v.is_contiguous():
-        return None
-    return v
-
-
-def _activation_leaves(scales: torch.Tensor, quats: torch.Tensor):
-    """(log-scales leaf, raw quats leaf) if ``scales`` is provably ``exp(leaf)`` and ``quats`` provably
-    ``leaf / leaf.norm(dim=-1, keepdim=True)``; None otherwise."""
-    fs, fq = scales.grad_fn, quats.grad_fn
-    if fs is None or fq is None or type(fs).__name__ != "ExpBackward0" or type(fq).__name__ != "DivBackward0":
-        return None
-    if not (_unhooked(scales) and _unhooked(quats)) or scales.dim() != 2 or quats.dim() != 2:
-        return None
-    ls = _leaf_of(fs.next_functions[0][0])
-    nq = fq.next_functions
-    if ls is None or len(nq) != 2 or nq[1][0] is None or type(nq[1][0]).__name__ != "LinalgVectorNormBackward0":
-        return None
-    rq, norm = _leaf_of(nq[0][0]), nq[1][0]
-    if rq is None or _leaf_of(norm.next_functions[0][0]) is not rq:
-        return None
-    dims = tuple(getattr(norm, "_saved_dim", ()) or ())
-    if getattr(norm, "_saved_ord", None) != 2 or not getattr(norm, "_saved_keepdim", False) or len(dims) != 1 \
-            or int(dims[0]) not in _MINUS_ONE_DIMS:
-        return None
-    if ls.shape != scales.shape or rq.shape != quats.shape or quats.shape[1] != 4 or scales.shape[1] != 3:
-        return None
-    return ls, rq
+activation_proof_stats = {"project": 0, "opacity": 0, "colors": 0, "window": 0}
 
 
 def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
@@ -401,32 +390,34 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
 
 class _ProjectGaussiansAct(Function):
     """project_gaussians over PROVEN activations: forward on the caller's activated values, backward straight into the
-    log-scale and raw-quaternion leaves (see the note above)."""
+    un-normalised quaternions ``x`` and the log-scale leaves (see the note above)."""
     @staticmethod
     def forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
-                block_width, clip_thresh, log_scales, raw_quats):
+                block_width, clip_thresh, x, *log_scale_leaves):
         outs, saved = _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
                                        img_width, block_width, clip_thresh)
-        means3d_c, _s, _q, viewmat_c, cov3d, radii, conics, compensation = saved
-        ctx.save_for_backward(means3d_c, log_scales, raw_quats, viewmat_c, cov3d, radii, conics, compensation)
+        means3d_c, scales_c, _q, viewmat_c, cov3d, radii, conics, compensation = saved
+        ctx.leaf_rows = [v.shape[0] for v in log_scale_leaves]
+        ctx.save_for_backward(means3d_c, scales_c, x, viewmat_c, cov3d, radii, conics, compensation)
         return outs
 
     @staticmethod
     def backward(ctx, v_xys, v_depths, v_radii, v_conics, v_compensation, v_num_tiles_hit, v_cov3d):
-        means3d, log_scales, raw_quats, viewmat, cov3d, radii, conics, compensation = ctx.saved_tensors
+        means3d, scales, x, viewmat, cov3d, radii, conics, compensation = ctx.saved_tensors
         n, dev = means3d.shape[0], means3d.device
         f32 = dict(dtype=torch.float32, device=dev)
         v_xys = _f32c(v_xys) if v_xys is not None else torch.zeros(n, 2, **f32)
         v_depths = _f32c(v_depths) if v_depths is not None else None
         v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros(n, 3, **f32)
         v_comp = _f32c(v_compensation) if v_compensation is not None else None
-        v_mean, v_ls, v_rq = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32)
-        L.check(L.load().sgn_project_bwd_fused(
-            n, L.ptr(means3d), L.ptr(log_scales), ctx.glob_scale, L.ptr(raw_quats), None, None, L.ptr(viewmat),
+        v_mean, v_ls, v_x = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32)
+        L.check(L.load().sgn_project_bwd_act(
+            n, L.ptr(means3d), L.ptr(scales), ctx.glob_scale, L.ptr(x), L.ptr(viewmat),
             ctx.fx, ctx.fy, L.ptr(cov3d), L.ptr(radii), L.ptr(conics), L.ptr(compensation), L.ptr(v_xys),
-            L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comp), L.ptr(v_mean), L.ptr(v_ls), L.ptr(v_rq),
-            L.stream_ptr()), "sgn_project_bwd_fused")
-        return (v_mean, None, None, None, None, None, None, None, None, None, None, None, None, v_ls, v_rq)
+            L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comp), L.ptr(v_mean), L.ptr(v_ls), L.ptr(v_x),
+            L.stream_ptr()), "sgn_project_bwd_act")
+        v_leaves = (v_ls,) if len(ctx.leaf_rows) == 1 else v_ls.split(ctx.leaf_rows)
+        return (v_mean, None, None, None, None, None, None, None, None, None, None, None, None, v_x) + tuple(v_leaves)
 
 
 # Upstream asserts `(quats.norm(dim=-1) - 1 < 1e-6).all()` on every project_gaussians call: four small kernels and a
@@ -565,12 +556,15 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     ``viewmat`` is the world->camera matrix ([3,4] or [4,4]; only rows 0-2 are read)."""
     assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
     token = _check_quats(quats)
-    leaves = _activation_leaves(scales, quats) if activation_proofs and scales.is_cuda else None
-    if leaves is not None:
+    ls_leaves = x = None
+    if _proofs_on(activation_proofs) and scales.is_cuda:
+        ls_leaves = proofs.exp_leaves(scales)
+        x = proofs.normalised_source(quats) if ls_leaves is not None else None
+    if x is not None:
         activation_proof_stats["project"] += 1
         out = _ProjectGaussiansAct.apply(means3d.contiguous(), scales.detach().contiguous(), glob_scale,
                                          quats.detach().contiguous(), viewmat.contiguous(), fx, fy, cx, cy,
-                                         img_height, img_width, block_width, clip_thresh, *leaves)
+                                         img_height, img_width, block_width, clip_thresh, x, *ls_leaves)
     else:
         out = _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
                                       viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
@@ -936,7 +930,7 @@ def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bo
     _bin_pending["key"] = _bin_pending["state"] = _bin_pending["keep"] = None
     val = _bin_finish(state)
     if binning_cache_enabled:
-        S.store_binning(key, tuple(t.detach() for t in tensors), val)
+        S.store_binning(key, tuple(t.detach() for t in tensors), val, _window_info(tensors, cull))
     return val
 
 
@@ -953,8 +947,51 @@ window_matching_enabled = True
 window_stats = {"tried": 0, "hit": 0}
 
 
+def _window_info(tensors, cull):
+    """What the autograd graph says about a binning's geometry tensors (kept with the most recent cache entry): the
+    split / concatenation shape of xys, depths, conics (proofs.split_cat) and the logit leaves behind the opacities with
+    their version counters — the facts a later sub-model call is matched against WITHOUT touching the device."""
+    if not (window_matching_enabled and _proofs_on(activation_proofs)):
+        return None
+    xys, depths = tensors[0], tensors[1]
+    if xys.grad_fn is None:
+        return None
+    info = dict(xys=proofs.split_cat(xys), depths=proofs.split_cat(depths))
+    if cull:
+        info["conics"] = proofs.split_cat(tensors[4])
+        leaves = proofs.sigmoid_leaves(tensors[5])
+        info["opacity"] = None if leaves is None else (leaves, tuple(v._version for v in leaves))
+    return info
+
+
+def _proven_window(info, xys, depths, conics, opacity, cull):
+    """(lo, hi) if the graph PROVES that xys / depths / conics / opacities of this call are copies of rows [lo, hi) of the
+    cached scene's tensors (same split of the same projection, a run of the same logit leaves, nothing written since)."""
+    if info is None or info.get("xys") is None:
+        return None
+    win = proofs.window_of_split(proofs.split_cat(xys), info["xys"])
+    if win is None or proofs.window_of_split(proofs.split_cat(depths), info["depths"]) != win:
+        return None
+    if cull:
+        if proofs.window_of_split(proofs.split_cat(conics), info.get("conics")) != win or info.get("opacity") is None:
+            return None
+        full_leaves, versions = info["opacity"]
+        mine = proofs.sigmoid_leaves(opacity)
+        if mine is None or proofs.window_of_leaves(mine, full_leaves) != win:
+            return None
+        if any(v._version != ver for v, ver in zip(full_leaves, versions)):
+            return None
+    return win
+
+
 def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacity, cull):
-    """(lo, cached value, n_full) when the call's geometry equals rows [lo, lo + n) of the cached scene, else None."""
+    """(lo, cached value, n_full) when the call's geometry equals rows [lo, lo + n) of the cached scene, else None.
+
+    Two stages.  The autograd graph usually settles four of the six tensors on the host (`_proven_window`: the
+    sub-model's xys / depths / conics are concatenations of parts of the very split the cached tensors were concatenated
+    from, its opacities the sigmoid of a run of the same leaves); the two integer tensors (radii, num_tiles_hit) carry no
+    graph and are compared on the device — 8 bytes per row at the one proven offset.  Without a proof all six tensors are
+    compared at the two candidate offsets (head and tail window), 36 bytes per row."""
     S = _S()
     ck, keep, val = S.bin_cache["key"], S.bin_cache["keep"], S.bin_cache["val"]
     if ck is None or not window_matching_enabled or not binning_cache_enabled or n <= 0:
@@ -976,15 +1013,22 @@ def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacit
         if c._version != ck[i][1] or c.data_ptr() != ck[i][0]:
             return None
     window_stats["tried"] += 1
+    proven = _proven_window(S.bin_cache["info"], xys, depths, conics, opacity, cull)
+    if proven is not None and proven[1] - proven[0] != n:
+        proven = None
     dev = xys.device
     lib = L.load()
-    cands = sorted({0, n_full - n})
+    cands = [proven[0]] if proven is not None else sorted({0, n_full - n})
     lo_host = (C.c_int32 * len(cands))(*cands)
     flags = torch.empty(4, dtype=torch.int32, device=dev)
     w = [t.detach().contiguous() for t in mine] + [None] * (6 - len(mine))
     f = [c.contiguous() for c in keep] + [None] * (6 - len(keep))
     if cull:
         w[5], f[5] = w[5].reshape(-1), f[5].reshape(-1)
+    if proven is not None:                       # the graph settled these four: only the integer tensors go to the device
+        activation_proof_stats["window"] += 1
+        for i in (0, 1, 4, 5):
+            w[i] = f[i] = None
     L.check(lib.sgn_rows_match(n, n_full, len(cands), lo_host, *[L.ptr(t) for t in w], *[L.ptr(t) for t in f],
                                L.ptr(flags), L.stream_ptr()), "sgn_rows_match")
     if S.side is None:
@@ -1023,20 +1067,7 @@ def _depth_wanted() -> bool:
     return depth_channel == "on" or (depth_channel == "auto" and _S().depth_state["want"])
 
 
-def _provably_depths(colors: torch.Tensor, depths: torch.Tensor) -> bool:
-    """Host-side proof, on the autograd graph, that ``colors`` is literally ``depths[:, None].repeat(1, 3)`` of this
-    very ``depths`` tensor (sgn_splatfacto.py:988) — available whenever the projection carries a graph (training).
-    With it the depth pass needs no device-side comparison and none of the conditional launches behind it."""
-    fn, src = colors.grad_fn, depths.grad_fn
-    if fn is None or src is None or type(fn).__name__ != "RepeatBackward0":
-        return False
-    if tuple(getattr(fn, "_saved_repeats", ())) != (1, 3):
-        return False
-    inner = fn.next_functions[0][0]
-    if inner is None or type(inner).__name__ != "UnsqueezeBackward0" or getattr(inner, "_saved_dim", None) not in (1, -1):
-        return False
-    node, nr = inner.next_functions[0]
-    return node is src and nr == depths.output_nr
+_provably_depths = proofs.repeated_depths     # host-side proof that colours are `depths[:, None].repeat(1, 3)` (:988)
 
 
 # --------------------------------------------------------------- rasterize
@@ -1044,11 +1075,12 @@ class _RasterizeGaussians(Function):
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
                 block_width, background=None, return_alpha=False, opacity_is_logit=False, id_range=None,
-                want_depth=False, colors_are_depths=False, opacity_logits=None, colors_pre=None):
-        # opacity_logits / colors_pre (proven by rasterize_gaussians, see _sigmoid_leaf / _clamp_pre): `opacity` is
-        # sigmoid(opacity_logits) and `colors` is clamp(colors_pre, min=0); both arrive DETACHED and the gradients go
-        # to the two extra inputs instead (the activations' backward runs inside sgn_raster_bwd's unpack kernel)
-        ctx.grad_to_logits, ctx.grad_to_pre = opacity_logits is not None, colors_pre is not None
+                want_depth=False, colors_are_depths=False, colors_pre=None, *opacity_logits):
+        # opacity_logits / colors_pre (proven by rasterize_gaussians, see proofs.sigmoid_leaves / clamp_pre): `opacity`
+        # is sigmoid(cat(opacity_logits, 0)) and `colors` is clamp(colors_pre, min=0); both arrive DETACHED and the
+        # gradients go to the extra inputs instead (the activations' backward runs inside sgn_raster_bwd's unpack kernel)
+        ctx.grad_to_logits, ctx.grad_to_pre = len(opacity_logits) > 0, colors_pre is not None
+        ctx.logit_rows = [v.shape[0] for v in opacity_logits]
         ctx.set_materialize_grads(False)       # an unused alpha / depth output arrives as None, not as a zero image
         dev = L.require_device(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
         num_points = xys.size(0)
@@ -1089,7 +1121,7 @@ class _RasterizeGaussians(Function):
         plain = win is None and id_range is None and num_points > 0 and bool(ro.gather) and cull
         dcache = S.depth_caches.get(key)
         reuse = (plain and hit and not want_depth and depth_channel != "off" and dcache is not None
-                 and colors_c.shape == (num_points, 3))
+                 and colors_c.shape == (num_points, 3) and dcache["D"].shape == (img_height, img_width))
         if plain and hit and not reuse and depth_channel == "auto" and not want_depth:
             _depth_state["want"] = True        # a second pass over the same geometry: accumulate from the next step on
         accumulate = plain and not reuse and not hit and (want_depth or _depth_wanted())
@@ -1135,6 +1167,7 @@ class _RasterizeGaussians(Function):
             _depth_state["unused"] = 0
         elif num_intersects < 1:
             recs = None
+            out_depth = None            # never written (no forward ran): the want_depth branch below returns zeros
             out_img = torch.ones(img_height, img_width, 3, **f32) * bg_c
             gaussian_ids_sorted = torch.zeros(0, dtype=torch.int32, device=dev)
             tile_bins = torch.zeros(tile_bounds[0] * tile_bounds[1], 2, dtype=torch.int32, device=dev)
@@ -1202,7 +1235,11 @@ class _RasterizeGaussians(Function):
         f32 = dict(dtype=torch.float32, device=dev)
         if v_out_alpha is None:
             v_out_alpha = torch.zeros(H, W, **f32)
-        if v_out_img is None:                # only the alpha (or depth) output reached the loss
+        # only the alpha output reached the loss (the scene graph's accumulation passes, scene_graph.py:364-366): the
+        # colour gradient is exactly zero — hand autograd None instead, and the clamp / SH / concatenation backward
+        # behind the colours (a dense [n,K,3] gradient and its split over the leaves) is skipped altogether
+        no_color_grad = v_out_img is None
+        if v_out_img is None:
             v_out_img = torch.zeros(H, W, 3, **f32)
         v_out_img, v_out_alpha = _f32c(v_out_img), _f32c(v_out_alpha)
         v_xy = torch.empty(n, 2, **f32)
@@ -1235,33 +1272,16 @@ class _RasterizeGaussians(Function):
                 L.ptr(gws), gws.numel(), L.ptr(order), L.ptr(colors_pre), ro_ptr, L.stream_ptr(),
                 L.aux_stream_ptr(dev) if concurrent_backward else None), "sgn_raster_bwd")
         v_opacity = v_opacity.reshape(ctx.opacity_shape)
+        if no_color_grad:
+            v_colors = None
+        v_logits = ()
+        if ctx.grad_to_logits:
+            v_logits = (v_opacity,) if len(ctx.logit_rows) == 1 else v_opacity.split(ctx.logit_rows)
         # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha,
-        #  opacity_is_logit, id_range, want_depth, colors_are_depths, opacity_logits, colors_pre)
+        #  opacity_is_logit, id_range, want_depth, colors_are_depths, colors_pre, *opacity_logits)
         return (v_xy, None, None, v_conic, None, None if ctx.grad_to_pre else v_colors,
                 None if ctx.grad_to_logits else v_opacity) + (None,) * 9 + (
-            v_opacity if ctx.grad_to_logits else None, v_colors if ctx.grad_to_pre else None)
-
-
-def _sigmoid_leaf(opacity: torch.Tensor) -> Optional[torch.Tensor]:
-    """The logits leaf if ``opacity`` is provably ``torch.sigmoid(leaf)`` (sgn_splatfacto.py:949)."""
-    fn = opacity.grad_fn
-    if fn is None or type(fn).__name__ != "SigmoidBackward0" or not _unhooked(opacity):
-        return None
-    leaf = _leaf_of(fn.next_functions[0][0])
-    return leaf if leaf is not None and leaf.shape == opacity.shape else None
-
-
-def _clamp_pre(colors: torch.Tensor) -> Optional[torch.Tensor]:
-    """``pre`` if ``colors`` is provably ``torch.clamp(pre, min=0.0)`` with no upper bound (sgn_splatfacto.py:940)."""
-    fn = colors.grad_fn
-    if fn is None or type(fn).__name__ != "ClampBackward1" or not _unhooked(colors):
-        return None
-    if getattr(fn, "_saved_max", 0) is not None or getattr(fn, "_saved_min", None) != 0:
-        return None
-    pre = fn._saved_self
-    ok = (pre.shape == colors.shape and pre.dtype is torch.float32 and (pre.is_cuda or not _proofs_need_device)
-          and pre.is_contiguous() and pre.requires_grad)
-    return pre if ok else None
+            v_colors if ctx.grad_to_pre else None,) + tuple(v_logits)
 
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height: int,
@@ -1282,17 +1302,18 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
         raise ValueError("xys must have dimensions (N, 2)")
     if colors.ndimension() != 2:
         raise ValueError("colors must have dimensions (N, D)")
-    logits = pre = None
-    if activation_proofs and opacity.is_cuda and colors.shape[-1] == 3:
-        logits, pre = _sigmoid_leaf(opacity), _clamp_pre(colors)
-        activation_proof_stats["opacity"] += logits is not None
+    logits, pre = (), None
+    if _proofs_on(activation_proofs) and opacity.is_cuda and colors.shape[-1] == 3:
+        logits, pre = proofs.sigmoid_leaves(opacity) or (), proofs.clamp_pre(colors)
+        activation_proof_stats["opacity"] += len(logits) > 0
         activation_proof_stats["colors"] += pre is not None
     return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(),
                                      conics.contiguous(), num_tiles_hit.contiguous(),
                                      (colors.detach() if pre is not None else colors).contiguous(),
-                                     (opacity.detach() if logits is not None else opacity).contiguous(), img_height,
+                                     (opacity.detach() if logits else opacity).contiguous(), img_height,
                                      img_width, block_width, background.contiguous(), return_alpha, False, None, False,
-                                     depth_channel != "off" and _provably_depths(colors, depths), logits, pre)
+                                     depth_channel != "off" and proofs.enabled() and _provably_depths(colors, depths),
+                                     pre, *logits)
 
 
 # -------------------------------------------------------------- _torch_impl

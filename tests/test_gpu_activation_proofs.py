@@ -2,7 +2,7 @@
 
 The reference hands `project_gaussians` `torch.exp(scales)` and `quats / quats.norm(dim=-1, keepdim=True)` of two leaf
 parameters (`sgn_splatfacto.py:857,864`).  When the autograd graph behind the two arguments proves exactly that, the
-projection node differentiates into the leaves itself (`ops._activation_leaves`, `ops._ProjectGaussiansAct`) instead of
+projection node differentiates into the leaves itself (`proofs.exp_leaves` / `proofs.normalised_source`, `ops._ProjectGaussiansAct`) instead of
 leaving ~10 small kernels of division / norm / exp backward to autograd.  Asserted: identical forward outputs (bit for
 bit: the forward runs on the caller's activated values either way), leaf gradients equal to the chain through torch to
 fp32 rounding, and every call shape the proof must refuse still takes the plain node.
@@ -162,3 +162,106 @@ def test_raster_proofs_refuse_what_they_cannot_prove(variant, expect):
     _rgb, c, o, took = _raster(True, variant)
     assert took == expect
     assert c is not None and o is not None
+
+
+def _scene_graph_step(on):
+    """The drop-in scene-graph step (the reference's SHIPPED model, sgn_config.py:42) on a small scene: parameters are
+    row-wise concatenations over four sub-models, quaternion products, Fourier DC sums."""
+    from sgn_rast import ops, scenes, step
+    old = (ops.activation_proofs, ops.sh_split_backward)
+    ops.activation_proofs = ops.sh_split_backward = on
+    try:
+        ops.clear_binning_cache()
+        cam = scenes.make_camera(160, 96, 140.0)
+        models, poses, idft = scenes.make_scene_graph(4000, cam, n_objects=3, object_frac=0.25, z_range=(2.0, 8.0))
+        poses[1:, 11] = torch.tensor([4.0, 5.0, 6.0])
+        poses[1:, 9] = torch.tensor([-1.0, 0.2, 1.0]); poses[1:, 10] = 0.0
+        cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+        Ms = [step.leaf_params({k: v.to(DEV) for k, v in m.items()}) for m in models]
+        w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+        before = (dict(ops.activation_proof_stats), dict(ops.sh_split_stats))
+        out = step.render_scene_graph(Ms, poses.to(DEV), idft.to(DEV), cam)
+        loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum() + (out.object_acc * w_a).sum()
+                + 0.5 * (out.background_acc * w_a).sum()) / (cam.height * cam.width)
+        loss.backward()
+        torch.cuda.synchronize()
+        fired = {k: ops.activation_proof_stats[k] - before[0][k] for k in before[0]}
+        fired["sh"] = ops.sh_split_stats["split"] - before[1]["split"]
+        return out, Ms, fired
+    finally:
+        ops.activation_proofs, ops.sh_split_backward = old
+
+
+def test_scene_graph_aggregates_are_proven_and_gradients_equal_the_chain_through_torch():
+    a, Ma, fa = _scene_graph_step(True)
+    b, Mb, fb = _scene_graph_step(False)
+    # main projection; sigmoid over the concatenated logits in the main pass and both sub-model passes; the SH node of
+    # the main pass and the two of each sub-model pass (scene_graph.py:285 and sgn_splatfacto.py:939) — all proven
+    assert fa["project"] == 1 and fa["opacity"] == 3 and fa["sh"] == 5, fa
+    assert fb["project"] == 0 and fb["opacity"] == 0 and fb["sh"] == 0, fb
+    for name in ("rgb", "alpha", "depth", "object_acc", "background_acc"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name          # forwards are the same kernels
+    for i, (ma, mb) in enumerate(zip(Ma, Mb)):
+        for k in ma:
+            assert mb[k].grad is not None and float(mb[k].grad.abs().sum()) > 0, (i, k)
+            assert ma[k].grad is not None and ma[k].grad.shape == ma[k].shape, (i, k)
+            r = rel_l2(ma[k].grad.cpu(), mb[k].grad.cpu())
+            assert r < 1e-5, (i, k, r)
+    for pa, pb in zip(a.xys_parts, b.xys_parts):                              # what each sub-model's after_train reads
+        assert rel_l2(pa.grad.cpu(), pb.grad.cpu()) < 1e-5
+
+
+def test_alpha_only_pass_hands_autograd_no_colour_gradient():
+    """An accumulation-only loss (the scene graph's object / background passes): the colour gradient is exactly zero, and
+    the node returns None for it, so the SH / clamp / concatenation backward behind the colours never runs."""
+    from sgn_rast import ops
+    ops.clear_binning_cache()
+    n = 3000
+    cam, P = small_scene(n=n, w=160, h=96, focal=160.0)
+    from helpers import activated
+    scales, quats, _o, _c = activated(P)
+    with torch.no_grad():
+        xys, depths, radii, conics, _cp, nth, _cv = ops.project_gaussians(
+            P["means"].to(DEV), scales.to(DEV), 1, quats.to(DEV), cam.viewmat[:3, :].to(DEV), cam.fx, cam.fy, cam.cx,
+            cam.cy, cam.height, cam.width, 16)
+    calls = []
+    rgbs = torch.rand(n, 3, device=DEV, requires_grad=True)
+    shifted = rgbs * 1.0
+    shifted.register_hook(lambda g: calls.append(g))
+    opac = torch.sigmoid(P["opacity_logits"].to(DEV)).requires_grad_(True)
+    _img, alpha = ops.rasterize_gaussians(xys, depths, radii, conics, nth, shifted, opac, cam.height, cam.width, 16,
+                                          background=torch.zeros(3, device=DEV), return_alpha=True)
+    alpha.sum().backward()
+    assert not calls and rgbs.grad is None                     # nothing flowed towards the colours
+    assert opac.grad is not None and float(opac.grad.abs().sum()) > 0
+
+
+def test_hooks_placed_after_the_call_see_the_documented_outcome():
+    """The proofs are evaluated when the operator is called.  A hook or `retain_grad()` placed on an
+    activated tensor BEFORE the call refuses the proof (the tensor then receives its gradient as usual); one placed
+    AFTER the call is not seen: the operator's gradient goes straight to the leaf and the activated tensor's hook fires
+    with nothing from that operator.  This test pins both halves of that contract."""
+    from sgn_rast import ops
+    n = 2000
+    cam, P = small_scene(n=n, w=128, h=96, focal=128.0)
+
+    def run(when):
+        ops.clear_binning_cache()
+        ls = P["log_scales"].to(DEV).requires_grad_(True)
+        rq = P["quats"].to(DEV).requires_grad_(True)
+        scales, quats = torch.exp(ls), rq / rq.norm(dim=-1, keepdim=True)
+        seen = []
+        if when == "before":
+            scales.register_hook(lambda g: seen.append(g))
+        outs = ops.project_gaussians(P["means"].to(DEV), scales, 1, quats, cam.viewmat[:3, :].to(DEV), cam.fx, cam.fy,
+                                     cam.cx, cam.cy, cam.height, cam.width, 16)
+        if when == "after":
+            scales.register_hook(lambda g: seen.append(g))
+        (outs[0].sum() + outs[3].sum()).backward()
+        return seen, ls.grad
+
+    seen_b, g_b = run("before")
+    seen_a, g_a = run("after")
+    assert len(seen_b) == 1 and float(seen_b[0].abs().sum()) > 0         # opted out: the plain node, the hook sees it all
+    assert len(seen_a) == 0                                              # documented: bypassed
+    assert rel_l2(g_a.cpu(), g_b.cpu()) < 2e-6                           # the LEAF gradient is the same either way

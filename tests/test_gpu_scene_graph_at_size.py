@@ -1,0 +1,166 @@
+"""GPU (-m gpu): the reference's SHIPPED model — the scene graph (`sgn_config.py:42`; BASELINE.json configs[2] shape:
+background + rigid objects, four raster passes per step, `sgn_splatfacto_scene_graph.py:255-303,332-366`) — against the
+C oracle AT SIZE: 1 M Gaussians, 8 objects, 1920x1280, production kernel options (VERDICT r03 "missing #3": the
+four-pass step with window recognition / `id_range` inert rows had only been compared at 4 000 Gaussians, 160x96).
+
+Method as in `test_gpu_grad_at_size.py`: the loss weights vanish outside a band of tile rows, so the oracle composites
+that band only (`oracle_ops.PIXEL_ROWS`) while everything else — aggregation, projection, SH, binning of all N
+Gaussians over the full grid, the window / id-range passes over the cached depth list — runs as in `bench.py
+--scene-graph`.  All FOUR passes are in the loss (rgb, accumulation, object accumulation, background accumulation) and
+the depth image is compared too; every leaf of every sub-model and the retained per-model `xys.grad`
+(what each sub-model's `after_train` reads, `sgn_splatfacto.py:523-524`) is checked.
+
+Both call patterns: the DROP-IN one (the reference's own aggregation in torch, sub-model passes handed torch.cat
+copies -> `ops._match_window`) and the FUSED one (`sgn_rast.fused`: rigid transform, Fourier DC, activations in the
+kernels; sub-model passes as `id_range` over the shared list).
+
+Tolerance: rel-L2 <= 1e-4 per tensor, image bands mean |err| < 1e-6.
+"""
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BAND_TILE_ROWS = 3
+N_OBJECTS = 8
+LEAVES = ("means", "log_scales", "quats", "opacity_logits", "features_dc", "features_rest")
+
+
+def _loss(out, cam, w):
+    n_pix = cam.height * cam.width
+    return ((out.rgb * w["img"]).sum() + (out.alpha * w["a"]).sum() + (out.object_acc * w["obj"]).sum()
+            + (out.background_acc * w["bg"]).sum()) / n_pix
+
+
+def _weights(cam, row_lo, row_hi, dev="cpu"):
+    g = torch.Generator().manual_seed(23)
+    mask = torch.zeros(cam.height, 1)
+    mask[row_lo:row_hi] = 1.0
+    w = dict(img=torch.rand(cam.height, cam.width, 3, generator=g) * mask[..., None],
+             a=torch.rand(cam.height, cam.width, generator=g) * mask,
+             obj=torch.rand(cam.height, cam.width, generator=g) * mask,
+             bg=torch.rand(cam.height, cam.width, generator=g) * mask)
+    return {k: v.to(dev) for k, v in w.items()}
+
+
+@pytest.fixture(scope="module")
+def production_defaults():
+    from sgn_rast import _lib as L
+    L.load()
+    L.reset_options()
+    o = L.opts()
+    assert (o.exact_exp, o.reduce_mode, o.gather, o.waves_fwd, o.waves_bwd) == (0, 1, 1, 2, 0)
+    assert (o.adapt_fwd, o.adapt_bwd, o.batch_fwd, o.batch_bwd) == (1024, 256, 256, 128)
+    yield L
+    L.reset_options()
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from sgn_rast import scenes
+    cam, raw = scenes.make_scene("metric")
+    models, poses, idft = scenes.make_scene_graph(raw["means"].shape[0], cam, n_objects=N_OBJECTS, object_frac=0.1)
+    return cam, models, poses, idft
+
+
+@pytest.fixture(scope="module")
+def expected(scene, production_defaults):
+    """Band placement from a full HIP forward, then the reference's composition on the C oracle in that band."""
+    import oracle_ops
+    from sgn_rast import ops, scenes, step
+    cam, models, poses, idft = scene
+    H, W = cam.height, cam.width
+    tiles_x = (W + 15) // 16
+    cam_d = scenes.Camera(W, H, cam.fx, cam.fy, cam.cx, cam.cy, cam.viewmat.to(DEV), cam.cam_pos.to(DEV))
+    M0 = [step.leaf_params({k: v.to(DEV) for k, v in m.items()}) for m in models]
+    ops.clear_binning_cache()
+    out0 = step.render_scene_graph(M0, poses.to(DEV), idft.to(DEV), cam_d)
+    saved = out0.rgb.grad_fn.saved_tensors
+    bins, final_idx = saved[1].cpu(), saved[8].cpu()
+    lens = (bins[:, 1] - bins[:, 0]).reshape(-1, tiles_x)
+    fi_tile = final_idx[: (H // 16) * 16].reshape(H // 16, 16, tiles_x, 16).amax(dim=(1, 3))
+    walks = (fi_tile - bins[:, 0].reshape(-1, tiles_x)[: H // 16] + 1) * (lens[: H // 16] > 0)
+    # the band must see objects AND background: the tile row with the longest reverse walk among the rows the
+    # objects-only pass covers
+    obj_rows = out0.object_acc.detach().cpu()[: (H // 16) * 16].reshape(H // 16, -1).amax(dim=1) > 0.5
+    assert bool(obj_rows.any())
+    hot_row = int((walks.amax(dim=1) * obj_rows).argmax())
+    tr_lo = max(0, min(hot_row - BAND_TILE_ROWS // 2, H // 16 - BAND_TILE_ROWS))
+    row_lo, row_hi = tr_lo * 16, (tr_lo + BAND_TILE_ROWS) * 16
+    band = slice(tr_lo, tr_lo + BAND_TILE_ROWS)
+    assert int(walks[band].max()) >= 128, "LDS-batched reverse walk (>= 128 entries) must be exercised"
+    assert int(lens[band].max()) >= 256, "LDS-batched forward list (>= 256 entries) must be exercised"
+    del out0, saved, M0
+
+    w = _weights(cam, row_lo, row_hi)
+    Mc = [step.leaf_params(m) for m in models]
+    oracle_ops.PIXEL_ROWS = (row_lo, row_hi)
+    try:
+        exp = step.render_scene_graph(Mc, poses, idft, cam, ops=oracle_ops)
+        _loss(exp, cam, w).backward()
+    finally:
+        oracle_ops.PIXEL_ROWS = None
+    rows = slice(row_lo, row_hi)
+    assert float(exp.object_acc[rows].max()) > 0.5 and float(exp.background_acc[rows].max()) > 0.5
+    assert float(exp.object_acc[rows].min()) < 0.5, "the band must also hold pixels no object reaches"
+    return dict(out=exp, leaves=Mc, rows=(row_lo, row_hi))
+
+
+@pytest.mark.parametrize("path", ["dropin", "fused"])
+@pytest.mark.parametrize("reduce_mode", [1, 0])
+def test_scene_graph_step_matches_oracle_at_size(path, reduce_mode, scene, expected, production_defaults):
+    from sgn_rast import ops, scenes, step
+    lib = production_defaults
+    cam, models, poses, idft = scene
+    exp, Mc, (row_lo, row_hi) = expected["out"], expected["leaves"], expected["rows"]
+    H, W = cam.height, cam.width
+    w = _weights(cam, row_lo, row_hi, DEV)
+    cam_d = scenes.Camera(W, H, cam.fx, cam.fy, cam.cx, cam.cy, cam.viewmat.to(DEV), cam.cam_pos.to(DEV))
+    counts = [m["means"].shape[0] for m in models]
+    lib.set_options(reduce_mode=reduce_mode)
+    try:
+        Md = [step.leaf_params({k: v.to(DEV) for k, v in m.items()}) for m in models]
+        ops.clear_binning_cache()
+        hits0, binnings0 = ops.window_stats["hit"], ops.binning_stats["binnings"]
+        got = step.render_scene_graph(Md, poses.to(DEV), idft.to(DEV), cam_d, fused=(path == "fused"))
+        _loss(got, cam, w).backward()
+        torch.cuda.synchronize()
+        # ONE binning serves the four passes on either path (window recognition / id_range)
+        assert ops.binning_stats["binnings"] - binnings0 == 1, path
+        if path == "dropin":
+            assert ops.window_stats["hit"] - hits0 == 2, "both sub-model passes must ride the cached list"
+    finally:
+        lib.set_options(reduce_mode=1)
+
+    n = exp.radii.numel()
+    # torch's exp / matmul / quaternion glue runs on the GPU for one side, on the CPU for the other (1-ulp inputs):
+    # a handful of radii may land on the other side of an integer (see test_gpu_grad_at_size.py)
+    assert int((got.radii.cpu() != exp.radii).sum()) <= max(2, n // 50_000), path
+    assert int((got.num_tiles_hit.cpu() != exp.num_tiles_hit).sum()) <= max(2, n // 50_000), path
+    torch.testing.assert_close(got.xys.detach().cpu(), exp.xys.detach(), rtol=4e-6, atol=2e-4)
+    rows = slice(row_lo, row_hi)
+    for attr in ("rgb", "alpha", "object_acc", "background_acc"):
+        err = (getattr(got, attr).detach().cpu()[rows] - getattr(exp, attr).detach()[rows]).abs()
+        assert float(err.mean()) < 1e-6 and float((err > 1e-5).float().mean()) < 2e-3, (path, attr, float(err.mean()))
+    # depth (not in the loss, no gradient): expected-depth image d / alpha where alpha > 1e-3, else 10 (:995)
+    d_err = (got.depth.detach().cpu()[rows] - exp.depth.detach()[rows]).abs() / exp.depth.detach()[rows].abs().clamp(min=1)
+    assert float(d_err.mean()) < 1e-5 and float((d_err > 1e-3).float().mean()) < 2e-3, (path, float(d_err.mean()))
+
+    # every leaf of every sub-model
+    for i, (md, mc) in enumerate(zip(Md, Mc)):
+        for k in LEAVES:
+            assert mc[k].grad is not None and float(mc[k].grad.abs().sum()) > 0, (i, k)
+            r = rel_l2(md[k].grad.cpu(), mc[k].grad)
+            assert r < 1e-4, (path, reduce_mode, "model", i, k, r)
+    # the retained gradient of the projected centres, per sub-model (what each sub-model's after_train reads)
+    if path == "dropin":
+        for i, (pg, pe) in enumerate(zip(got.xys_parts, exp.xys_parts)):
+            assert rel_l2(pg.grad.cpu(), pe.grad) < 1e-4, (path, "xys_parts", i)
+    else:
+        whole = got.xys.grad.cpu()
+        lo = 0
+        for i, (c, pe) in enumerate(zip(counts, exp.xys_parts)):
+            assert rel_l2(whole[lo:lo + c], pe.grad) < 1e-4, (path, "xys slice", i)
+            lo += c

@@ -2,7 +2,7 @@
 
 The reference builds the SH coefficients as `torch.cat((features_dc, features_rest), dim=1)` of two leaf parameters
 (`sgn_splatfacto.py:858`).  When the autograd graph behind `coeffs` proves exactly that, `spherical_harmonics` writes the
-two leaves' gradients itself instead of a dense [N,K,3] tensor that autograd then copies apart (`ops._cat_leaves`,
+two leaves' gradients itself instead of a dense [N,K,3] tensor that autograd then copies apart (`proofs.sh_source`,
 `ops._SphericalHarmonicsSplit`).  Asserted here: same colours, same gradients (bit for bit) as the dense path for every
 active degree; and every shape of call the proof must NOT accept still takes the dense path with upstream's semantics
 (hooks fire, retained gradients appear).

@@ -252,41 +252,118 @@ def test_empty_view_returns_the_reference_empty_outputs_and_still_reaches_the_re
 
 
 def test_graph_proofs_recognise_the_reference_expressions_on_this_torch(monkeypatch):
-    """The graph proofs of `ops` read autograd node types and saved attributes, which belong to the
-    installed PyTorch, not to a documented API: pin, on CPU tensors, that the reference's five expressions
-    (sgn_splatfacto.py:857,858,864,940,949) are still recognised and that near misses are not.  (If a PyTorch upgrade
-    renames a node the operators silently fall back to their plain autograd path: correct, slower — this test is what
-    notices.)"""
-    monkeypatch.setattr(ops, "_proofs_need_device", False)
+    """The graph proofs (`sgn_rast.proofs`) read autograd node types and saved attributes, which belong to
+    the installed PyTorch, not to a documented API: pin, on CPU tensors, that the reference's expressions
+    (sgn_splatfacto.py:857,858,864,940,949,988) are still recognised and that near misses are not.  (If a PyTorch
+    upgrade renames a node, `proofs.enabled()` switches every proof off after its own self-test and the operators take
+    their plain autograd path: correct, slower — this test is what notices.)"""
+    from sgn_rast import proofs
+    monkeypatch.setattr(proofs, "need_device", False)
+    assert proofs.selftest() and proofs.enabled()
     n, k = 50, 16
     dc = torch.randn(n, 1, 3, requires_grad=True)
     rest = torch.randn(n, k - 1, 3, requires_grad=True)
     ls = torch.randn(n, 3, requires_grad=True)
     rq = torch.randn(n, 4, requires_grad=True)
     lo = torch.randn(n, 1, requires_grad=True)
-    coeffs = torch.cat((dc, rest), dim=1)                                     # :858
-    got = ops._cat_leaves(coeffs)
-    assert got is not None and got[0] is dc and got[1] is rest
-    leaves = ops._activation_leaves(torch.exp(ls), rq / rq.norm(dim=-1, keepdim=True))     # :857, :864
-    assert leaves is not None and leaves[0] is ls and leaves[1] is rq
-    assert ops._sigmoid_leaf(torch.sigmoid(lo)) is lo                        # :949
+    src = proofs.sh_source(torch.cat((dc, rest), dim=1))                      # :858
+    assert src is not None and src.dc[0].leaf is dc and src.dc[0].weights is None and src.rest == (rest,)
+    assert proofs.exp_leaves(torch.exp(ls)) == (ls,)                          # :857
+    assert proofs.normalised_source(rq / rq.norm(dim=-1, keepdim=True)) is rq  # :864
+    assert proofs.sigmoid_leaves(torch.sigmoid(lo)) == (lo,)                  # :949
     sh = torch.randn(n, 3, requires_grad=True) * 1.0
-    pre = ops._clamp_pre(torch.clamp(sh + 0.5, min=0.0))                     # :940
+    pre = proofs.clamp_pre(torch.clamp(sh + 0.5, min=0.0))                    # :940
     assert pre is not None and type(pre.grad_fn).__name__ == "AddBackward0" and pre.shape == (n, 3)
     # near misses
-    assert ops._cat_leaves(torch.cat((dc, rest), dim=1) * 1.0) is None
-    assert ops._cat_leaves(torch.cat((dc * 1.0, rest), dim=1)) is None
-    assert ops._cat_leaves(torch.cat((dc, rest), dim=1).detach()) is None
+    assert proofs.sh_source(torch.cat((dc, rest), dim=1) * 1.0) is None
+    assert proofs.sh_source(torch.cat((dc * 1.0, rest), dim=1)) is None
+    assert proofs.sh_source(torch.cat((dc, rest), dim=1).detach()) is None
+    assert proofs.sh_source(torch.cat((rest, dc), dim=1)) is None
     hooked = torch.cat((dc, rest), dim=1)
     hooked.register_hook(lambda g: g)
-    assert ops._cat_leaves(hooked) is None
+    assert proofs.sh_source(hooked) is None
     kept = torch.cat((dc, rest), dim=1)
     kept.retain_grad()
-    assert ops._cat_leaves(kept) is None
-    assert ops._activation_leaves(torch.exp(ls) * 1.0, rq / rq.norm(dim=-1, keepdim=True)) is None
-    assert ops._activation_leaves(torch.exp(ls), rq / rq.norm(dim=-1)[:, None]) is None
-    assert ops._activation_leaves(torch.exp(ls), rq / rq.norm(p=1, dim=-1, keepdim=True)) is None
-    assert ops._activation_leaves(torch.exp(ls), rq / (rq * 1.0).norm(dim=-1, keepdim=True)) is None
-    assert ops._sigmoid_leaf(torch.sigmoid(lo * 1.0)) is None
-    assert ops._clamp_pre(torch.clamp(sh + 0.5, min=0.0, max=1.0)) is None
-    assert ops._clamp_pre(torch.clamp(sh + 0.5, min=0.1)) is None
+    assert proofs.sh_source(kept) is None
+    assert proofs.exp_leaves(torch.exp(ls) * 1.0) is None
+    assert proofs.exp_leaves(torch.exp(ls * 1.0)) is None
+    assert proofs.normalised_source(rq / rq.norm(dim=-1)[:, None]) is None
+    assert proofs.normalised_source(rq / rq.norm(p=1, dim=-1, keepdim=True)) is None
+    assert proofs.normalised_source(rq / (rq * 1.0).norm(dim=-1, keepdim=True)) is None
+    assert proofs.sigmoid_leaves(torch.sigmoid(lo * 1.0)) is None
+    assert proofs.clamp_pre(torch.clamp(sh + 0.5, min=0.0, max=1.0)) is None
+    assert proofs.clamp_pre(torch.clamp(sh + 0.5, min=0.1)) is None
+    written = torch.exp(ls)
+    written.mul_(1.0)                                                          # modified after it was made
+    assert proofs.exp_leaves(written) is None
+
+
+def test_graph_proofs_follow_the_scene_graph_aggregation(monkeypatch):
+    """The scene graph's parameters are row-wise concatenations over the sub-models
+    (sgn_splatfacto_scene_graph.py:355-360), the objects' quaternions products with the box rotation (:416, through the
+    pytorch3d shim), their DC term a Fourier sum (:239-247), and the sub-model passes receive concatenations of the
+    per-model SPLITS of the main projection (:153-215, 249-276).  Every one of those shapes must be proven, and the
+    windows must come out right."""
+    from sgn_rast import proofs
+    from sgn_rast.quat import quaternion_raw_multiply
+    monkeypatch.setattr(proofs, "need_device", False)
+    counts, k, F = [30, 7, 9], 16, 5
+    mk = lambda *s: torch.randn(*s).requires_grad_(True)
+    models = [dict(ls=mk(c, 3), rq=mk(c, 4), lo=mk(c, 1), rest=mk(c, k - 1, 3),
+                   dc=mk(c, 1 if i == 0 else F, 3)) for i, c in enumerate(counts)]
+    cat = lambda key: torch.concat([m[key] for m in models], dim=0)               # get_aggreated_variable :138-146
+    assert proofs.exp_leaves(torch.exp(cat("ls"))) == tuple(m["ls"] for m in models)
+    assert proofs.sigmoid_leaves(torch.sigmoid(cat("lo"))) == tuple(m["lo"] for m in models)
+    q_o2w = torch.tensor([0.9, 0.1, -0.3, 0.2], dtype=torch.float64)
+    x = torch.cat([models[0]["rq"]] + [quaternion_raw_multiply(q_o2w, m["rq"]).float() for m in models[1:]], dim=0)
+    assert proofs.normalised_source(x / x.norm(dim=-1, keepdim=True)) is x       # a non-leaf X is fine
+    w = [torch.randn(1, F) for _ in models]
+    dcs = [models[0]["dc"]] + [torch.sum(m["dc"] * w[i][..., None], dim=1, keepdim=True)   # get_fourier_features
+                               for i, m in enumerate(models) if i > 0]
+    src = proofs.sh_source(torch.cat((torch.cat(dcs, dim=0), cat("rest")), dim=1))
+    assert src is not None and [p.leaf for p in src.dc] == [m["dc"] for m in models]
+    assert src.dc[0].weights is None and torch.equal(src.dc[2].weights, w[2][0])
+    assert src.rest == tuple(m["rest"] for m in models)
+    # a Fourier sum whose weights carry a gradient, or summed over another dim, is not the reference's expression
+    wg = torch.randn(1, F, requires_grad=True)
+    bad = torch.cat((torch.cat([dcs[0], torch.sum(models[1]["dc"] * wg[..., None], dim=1, keepdim=True), dcs[2]], 0),
+                     cat("rest")), dim=1)
+    assert proofs.sh_source(bad) is None
+    # sub-model windows: objects = parts 1.., background = part 0
+    xys = mk(sum(counts), 2) * 1.0
+    parts = torch.split(xys, counts)
+    sc = proofs.split_cat
+    full = sc(torch.concat(parts, dim=0))
+    assert full is not None and full.whole and full.rows == (0, 46)
+    assert proofs.window_of_split(sc(torch.cat(parts[1:], dim=0)), full) == (30, 46)
+    assert proofs.window_of_split(sc(torch.cat(parts[:1], dim=0)), full) == (0, 30)
+    assert sc(torch.cat([parts[2], parts[1]], dim=0)) is None
+    other = torch.split(mk(sum(counts), 2) * 1.0, counts)
+    assert proofs.window_of_split(sc(torch.cat(other[1:], dim=0)), full) is None   # parts of another projection
+    assert proofs.window_of_split(sc(torch.cat(parts[1:], dim=0)), sc(torch.concat(parts[:2], dim=0))) is None
+    written = torch.cat(parts[1:], dim=0)
+    written.add_(0.0)
+    assert sc(written) is None
+    leaves = [m["lo"] for m in models]
+    assert proofs.window_of_leaves(leaves[1:], leaves) == (30, 46)
+    assert proofs.window_of_leaves(leaves[:1], leaves) == (0, 30)
+    assert proofs.window_of_leaves([leaves[2], leaves[1]], leaves) is None
+
+
+def test_graph_proofs_gate_on_the_torch_version(monkeypatch, caplog):
+    """An untested PyTorch series runs the matchers' self-test once; if an expression is no longer recognised every proof
+    is switched off with ONE logged notice (VERDICT r03 #6b)."""
+    import logging
+    from sgn_rast import proofs
+    monkeypatch.setattr(proofs, "_enabled", None)
+    monkeypatch.setattr(proofs, "TESTED_TORCH_SERIES", ("0.0",))
+    assert proofs.enabled()                                   # untested series, self-test passes: proofs stay on
+    monkeypatch.setattr(proofs, "_enabled", None)
+    monkeypatch.setattr(proofs, "selftest", lambda: False)
+    with caplog.at_level(logging.WARNING, logger="sgn_rast.proofs"):
+        assert not proofs.enabled() and not proofs.enabled()
+    assert sum("not recognised" in r.message for r in caplog.records) == 1
+    monkeypatch.setattr(proofs, "_enabled", None)
+    monkeypatch.setenv("SGN_GRAPH_PROOFS", "0")
+    assert not proofs.enabled()
+    monkeypatch.setattr(proofs, "_enabled", None)
