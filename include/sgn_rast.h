@@ -280,6 +280,17 @@ int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const in
                       int32_t *gaussian_ids_sorted /*[n_isect]*/, int32_t *tile_bins /*[tiles,2]*/,
                       int quadrant_masks, void *ws, size_t ws_bytes, const int32_t *n_isect_dev, sgn_stream_t stream);
 
+/* Sub-list of a binned scene for an id window (no upstream counterpart; the scene graph's objects-only accumulation
+ * pass, sgn_splatfacto_scene_graph.py:364-365, served from the main pass's depth list): keeps, in order, the entries of
+ * gaussian_ids_sorted whose id (low SGN_QMASK_ID_BITS bits when ids_qmask) lies in [id_lo, id_hi), and writes the bins of
+ * the kept list.  ids_out needs room for as many entries as the source list (the kept count stays on the device; the
+ * raster kernels read bins only).  Relative order is preserved, so a pass over the sub-list equals the reference's own
+ * re-binned pass bit for bit.  ws: sgn_list_window_workspace_bytes(n_tiles). */
+size_t sgn_list_window_workspace_bytes(int n_tiles);
+int sgn_list_window(int n_tiles, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, int id_lo, int id_hi,
+                    int ids_qmask, int32_t *ids_out, int32_t *tile_bins_out /*[n_tiles,2]*/, void *ws, size_t ws_bytes,
+                    sgn_stream_t stream);
+
 /* Window recognition for the drop-in scene-graph path (no upstream counterpart).  The reference renders its sub-model
  * passes (sgn_splatfacto_scene_graph.py:364-366) from torch.cat COPIES of per-model slices of the main projection
  * (:270-276).  mismatch[c] (device, int32, c < n_cand <= 4) becomes 0 iff the window tensors equal rows

@@ -1094,3 +1094,101 @@ SGN_EXPORT int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32
     SGN_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------- list window
+// Sub-list of a binned scene for an id window.  The scene graph renders its objects-only and background-only
+// accumulation passes (sgn_splatfacto_scene_graph.py:364-366) from subsets of the Gaussians of the main pass; the host
+// serves them from the main pass's depth list (id range / window recognition) instead of ranking, emitting and sorting
+// again.  Walking the FULL list with the other Gaussians made inert is fine for the background (90 % of the entries are
+// its own and the tiles saturate as early as in the main pass) and ruinous for the objects: a tenth of the entries are
+// live, nothing saturates, so every tile walks its whole list — 0.2 ms forward and 0.3 ms backward for a pass that
+// draws 100 k Gaussians.  This keeps, in order, the entries whose id lies in [id_lo, id_hi): one wave per tile counts,
+// one workgroup scans the tile counts, one wave per tile writes — two reads of the list, no sort, bit-identical
+// relative order (so image and gradients equal those of the reference's own re-binned pass).
+namespace {
+__device__ __forceinline__ bool in_window(int raw, int idmask, int lo, int hi) {
+    const int id = raw & idmask;
+    return id >= lo && id < hi;
+}
+
+__global__ __launch_bounds__(256) void list_window_count_kernel(int n_tiles, const int32_t *__restrict__ ids,
+                                                                const int2 *__restrict__ bins, int lo, int hi,
+                                                                int idmask, int32_t *__restrict__ counts) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const int2 r = bins[t];
+    int c = 0;
+    for (int k = r.x + lane; k < r.y; k += 64) c += in_window(ids[k], idmask, lo, hi) ? 1 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+    if (lane == 0) counts[t] = c;
+}
+
+// exclusive scan of the tile counts in place, total behind them; one workgroup, any n
+__global__ __launch_bounds__(1024) void list_window_scan_kernel(int n_tiles, int32_t *__restrict__ counts) {
+    __shared__ int wave_sum[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_tiles ? counts[i] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += u;
+        }
+        if (lane == 63) wave_sum[wave] = inc;
+        __syncthreads();
+        int before = carry;
+        for (int w = 0; w < wave; ++w) before += wave_sum[w];
+        if (i < n_tiles) counts[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counts[n_tiles] = carry;
+}
+
+__global__ __launch_bounds__(256) void list_window_write_kernel(int n_tiles, const int32_t *__restrict__ ids,
+                                                                const int2 *__restrict__ bins, int lo, int hi,
+                                                                int idmask, const int32_t *__restrict__ starts,
+                                                                int32_t *__restrict__ ids_out, int2 *__restrict__ bins_out) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const int2 r = bins[t];
+    const int first = starts[t];
+    int at = first;
+    for (int k0 = r.x; k0 < r.y; k0 += 64) {
+        const int k = k0 + lane;
+        const int raw = k < r.y ? ids[k] : 0;
+        const bool keep = k < r.y && in_window(raw, idmask, lo, hi);
+        const unsigned long long m = __ballot(keep);
+        if (keep) ids_out[at + __popcll(m & ((1ull << lane) - 1ull))] = raw;
+        at += __popcll(m);
+    }
+    if (lane == 0) bins_out[t] = make_int2(first, at);
+}
+}  // namespace
+
+SGN_EXPORT size_t sgn_list_window_workspace_bytes(int n_tiles) { return sizeof(int32_t) * ((size_t)(n_tiles > 0 ? n_tiles : 0) + 1); }
+
+SGN_EXPORT int sgn_list_window(int n_tiles, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, int id_lo,
+                               int id_hi, int ids_qmask, int32_t *ids_out, int32_t *tile_bins_out, void *ws,
+                               size_t ws_bytes, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n_tiles > 0 && gaussian_ids_sorted && tile_bins && ids_out && tile_bins_out && ws, -1);
+    SGN_ARG_CHECK(id_lo >= 0 && id_hi >= id_lo, -2);
+    SGN_ARG_CHECK(ws_bytes >= sgn_list_window_workspace_bytes(n_tiles), -3);
+    hipStream_t s = (hipStream_t)stream;
+    int32_t *counts = (int32_t *)ws;
+    const int idmask = ids_qmask ? (SGN_QMASK_MAX_IDS - 1) : -1;
+    hipLaunchKernelGGL(list_window_count_kernel, dim3(sgn_cdiv(n_tiles, 4)), dim3(256), 0, s, n_tiles, gaussian_ids_sorted,
+                       (const int2 *)tile_bins, id_lo, id_hi, idmask, counts);
+    hipLaunchKernelGGL(list_window_scan_kernel, dim3(1), dim3(1024), 0, s, n_tiles, counts);
+    hipLaunchKernelGGL(list_window_write_kernel, dim3(sgn_cdiv(n_tiles, 4)), dim3(256), 0, s, n_tiles, gaussian_ids_sorted,
+                       (const int2 *)tile_bins, id_lo, id_hi, idmask, counts, ids_out, (int2 *)tile_bins_out);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

@@ -911,7 +911,7 @@ def prefetch_binning(xys, depths, radii, conics, num_tiles_hit, opacity, img_hei
 
 
 def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics,
-                          opacity, opacity_is_logit, pre=None):
+                          opacity, opacity_is_logit, pre=None, logit_leaves=()):
     # `pre`: the caller's own (key, tensors, cull) of these very arguments (the key walks six tensors)
     key, tensors, cull = pre if pre is not None else _cache_key(
         xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity, opacity_is_logit)
@@ -930,7 +930,7 @@ def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bo
     _bin_pending["key"] = _bin_pending["state"] = _bin_pending["keep"] = None
     val = _bin_finish(state)
     if binning_cache_enabled:
-        S.store_binning(key, tuple(t.detach() for t in tensors), val, _window_info(tensors, cull))
+        S.store_binning(key, tuple(t.detach() for t in tensors), val, _window_info(tensors, cull, logit_leaves))
     return val
 
 
@@ -947,7 +947,7 @@ window_matching_enabled = True
 window_stats = {"tried": 0, "hit": 0}
 
 
-def _window_info(tensors, cull):
+def _window_info(tensors, cull, logit_leaves=()):
     """What the autograd graph says about a binning's geometry tensors (kept with the most recent cache entry): the
     split / concatenation shape of xys, depths, conics (proofs.split_cat) and the logit leaves behind the opacities with
     their version counters — the facts a later sub-model call is matched against WITHOUT touching the device."""
@@ -959,12 +959,13 @@ def _window_info(tensors, cull):
     info = dict(xys=proofs.split_cat(xys), depths=proofs.split_cat(depths))
     if cull:
         info["conics"] = proofs.split_cat(tensors[4])
-        leaves = proofs.sigmoid_leaves(tensors[5])
-        info["opacity"] = None if leaves is None else (leaves, tuple(v._version for v in leaves))
+        # the rasterize wrapper has already proven `opacity == sigmoid(cat(logit_leaves))` (and detached it)
+        leaves = tuple(logit_leaves) or proofs.sigmoid_leaves(tensors[5])
+        info["opacity"] = None if not leaves else (leaves, tuple(v._version for v in leaves))
     return info
 
 
-def _proven_window(info, xys, depths, conics, opacity, cull):
+def _proven_window(info, xys, depths, conics, opacity, cull, logit_leaves=()):
     """(lo, hi) if the graph PROVES that xys / depths / conics / opacities of this call are copies of rows [lo, hi) of the
     cached scene's tensors (same split of the same projection, a run of the same logit leaves, nothing written since)."""
     if info is None or info.get("xys") is None:
@@ -976,15 +977,15 @@ def _proven_window(info, xys, depths, conics, opacity, cull):
         if proofs.window_of_split(proofs.split_cat(conics), info.get("conics")) != win or info.get("opacity") is None:
             return None
         full_leaves, versions = info["opacity"]
-        mine = proofs.sigmoid_leaves(opacity)
-        if mine is None or proofs.window_of_leaves(mine, full_leaves) != win:
+        mine = tuple(logit_leaves) or proofs.sigmoid_leaves(opacity)
+        if not mine or proofs.window_of_leaves(mine, full_leaves) != win:
             return None
         if any(v._version != ver for v, ver in zip(full_leaves, versions)):
             return None
     return win
 
 
-def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacity, cull):
+def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacity, cull, logit_leaves=()):
     """(lo, cached value, n_full) when the call's geometry equals rows [lo, lo + n) of the cached scene, else None.
 
     Two stages.  The autograd graph usually settles four of the six tensors on the host (`_proven_window`: the
@@ -1013,7 +1014,7 @@ def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacit
         if c._version != ck[i][1] or c.data_ptr() != ck[i][0]:
             return None
     window_stats["tried"] += 1
-    proven = _proven_window(S.bin_cache["info"], xys, depths, conics, opacity, cull)
+    proven = _proven_window(S.bin_cache["info"], xys, depths, conics, opacity, cull, logit_leaves)
     if proven is not None and proven[1] - proven[0] != n:
         proven = None
     dev = xys.device
@@ -1047,6 +1048,26 @@ def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacit
             window_stats["hit"] += 1
             return lo, val, n_full
     return None
+
+
+# A window that covers a small part of the scene (the objects-only pass: a tenth of the Gaussians) does not walk the
+# shared list with everything else made inert — nothing saturates then, every tile walks its whole list, 0.5 ms per step
+# at 1 M Gaussians for a pass that draws 100 k — but its own sub-list (sgn_list_window: two reads of the list, no sort,
+# same relative order, hence the same image and gradients).  Larger windows (the background: 90 %) keep the shared list.
+list_window_enabled = os.environ.get("SGN_LIST_WINDOW", "1") != "0"
+list_window_max_frac = 0.5
+window_stats["sub_lists"] = 0
+
+
+def _list_window(ids: torch.Tensor, tile_bins: torch.Tensor, lo: int, hi: int, qmask: int):
+    lib = L.load()
+    n_tiles = tile_bins.shape[0]
+    ids_out, bins_out = torch.empty_like(ids), torch.empty_like(tile_bins)
+    ws = L.workspace(lib.sgn_list_window_workspace_bytes(n_tiles), ids.device)
+    L.check(lib.sgn_list_window(n_tiles, L.ptr(ids), L.ptr(tile_bins), int(lo), int(hi), int(qmask), L.ptr(ids_out),
+                                L.ptr(bins_out), L.ptr(ws), ws.numel(), L.stream_ptr()), "sgn_list_window")
+    ids_out._sgn_qmask = bool(qmask)
+    return ids_out, bins_out
 
 
 # ------------------------------------------------------------ depth channel
@@ -1110,7 +1131,8 @@ class _RasterizeGaussians(Function):
         # a sub-model's copy of a window of the cached scene?  (drop-in scene-graph path; see _match_window)
         n_full, window, win = num_points, 0, None
         if id_range is None and not hit and _bin_pending["key"] != key:
-            win = _match_window(key[len(_t):], num_points, xys, depths, radii, num_tiles_hit, conics, opacity, cull)
+            win = _match_window(key[len(_t):], num_points, xys, depths, radii, num_tiles_hit, conics, opacity, cull,
+                                opacity_logits)
         if win is not None:
             lo, cached, n_full = win
             id_lo, id_hi, window = lo, lo + num_points, 1
@@ -1152,8 +1174,13 @@ class _RasterizeGaussians(Function):
         else:
             num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
                 num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
-                opacity_is_logit, pre=(key, _t, cull))
+                opacity_is_logit, pre=(key, _t, cull), logit_leaves=opacity_logits)
         ro.ids_qmask = int(bool(getattr(gaussian_ids_sorted, "_sgn_qmask", False)))   # the backward runs with `ro` too
+        if (num_intersects >= 1 and list_window_enabled and (id_hi - id_lo) < list_window_max_frac * n_full
+                and (id_lo, id_hi) != (0, n_full)):
+            # a SMALL window of a shared list (the scene graph's objects-only pass): walk its own entries only
+            gaussian_ids_sorted, tile_bins = _list_window(gaussian_ids_sorted, tile_bins, id_lo, id_hi, ro.ids_qmask)
+            window_stats["sub_lists"] += 1
         if proved and num_intersects >= 1:
             # the depth pass, proven on the host: its image comes from the first pass's fourth channel, and its node
             # SHARES that pass's per-pixel state and tile statistics (same geometry and opacities: same values)
