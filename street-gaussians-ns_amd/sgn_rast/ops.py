@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -224,6 +225,7 @@ class _SphericalHarmonics(Function):
 # `SGN_SH_SPLIT_BWD=0` switches it off.
 sh_split_backward = os.environ.get("SGN_SH_SPLIT_BWD", "1") != "0"
 sh_split_stats = {"split": 0, "dense": 0}
+_sh_memo = None        # (weakref to the last proven coefficient tensor, its ShSource)
 
 
 def _proofs_on(flag: bool) -> bool:
@@ -299,7 +301,14 @@ def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: tor
     claimed = _sh_exchange is not None and _sh_exchange.claims_coeffs(coeffs)
     if _sh_exchange is None and _proofs_on(sh_split_backward) and coeffs.is_contiguous() and (
             coeffs.is_cuda or not proofs.need_device):
-        src = proofs.sh_source(coeffs)
+        # the scene graph's sub-model passes evaluate the SH twice from the SAME concatenation (scene_graph.py:285, then
+        # render_gaussian_attrs :939): the second call reuses the first one's reading of the graph
+        global _sh_memo
+        if _sh_memo is not None and _sh_memo[0]() is coeffs and coeffs._version == 0 and proofs.unhooked(coeffs):
+            src = _sh_memo[1]
+        else:
+            src = proofs.sh_source(coeffs)
+            _sh_memo = (weakref.ref(coeffs), src) if src is not None else None
         if src is not None:
             sh_split_stats["split"] += 1
             return _SphericalHarmonicsSplit.apply(degrees_to_use, viewdirs.contiguous(), coeffs.detach(), src,
@@ -1177,7 +1186,7 @@ class _RasterizeGaussians(Function):
                 opacity_is_logit, pre=(key, _t, cull), logit_leaves=opacity_logits)
         ro.ids_qmask = int(bool(getattr(gaussian_ids_sorted, "_sgn_qmask", False)))   # the backward runs with `ro` too
         if (num_intersects >= 1 and list_window_enabled and (id_hi - id_lo) < list_window_max_frac * n_full
-                and (id_lo, id_hi) != (0, n_full)):
+                and (id_lo, id_hi) != (0, n_full) and ro.gather):      # (stream mode re-packs n_isect records: full list)
             # a SMALL window of a shared list (the scene graph's objects-only pass): walk its own entries only
             gaussian_ids_sorted, tile_bins = _list_window(gaussian_ids_sorted, tile_bins, id_lo, id_hi, ro.ids_qmask)
             window_stats["sub_lists"] += 1
