@@ -19,7 +19,7 @@ def one():
     for m in Ms:
         for p in m.values():
             p.grad = None
-    out = step.render_scene_graph(Ms, poses, idft, cam, 3, 16, fused=False)
+    out = step.render_scene_graph(Ms, poses, idft, cam, 3, 16, fused=os.environ.get("SGN_SG_FUSED", "0") == "1")
     loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum() + (out.object_acc * w_a).sum()) / (cam.height * cam.width)
     loss.backward()
 

@@ -47,6 +47,65 @@ def make_pose_table(rotations: torch.Tensor, translations: torch.Tensor) -> torc
     return table.to(torch.float32).contiguous()
 
 
+_LAYOUTS: dict = {}
+
+
+def object_ids_for(counts, device) -> torch.Tensor:
+    """int32 [sum(counts)]: row i of the aggregated scene belongs to sub-model ``object_ids[i]`` (0 = background).
+    Depends on the model sizes only (they change at densification, not per step), so it is built on the host once per
+    layout — ``repeat_interleave`` with device counts would sync every step."""
+    key = (str(device), tuple(int(c) for c in counts))
+    if key not in _LAYOUTS:
+        if len(_LAYOUTS) > 64:
+            _LAYOUTS.clear()
+        _LAYOUTS[key] = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32),
+                                                torch.tensor([int(c) for c in counts])).to(device)
+    return _LAYOUTS[key]
+
+
+def cat_features_dc(parts) -> torch.Tensor:
+    """``torch.cat`` of the sub-models' ``features_dc`` [n_i, F_i, 3] with every part zero-padded to the widest Fourier
+    dimension (background: F = 1, objects: ``fourier_features_dim``, sgn_config.py:56,66); the padded coefficients meet
+    zero weights in :func:`scene_graph_tables`' idft rows."""
+    fmax = max(int(p.shape[1]) for p in parts)
+    if all(int(p.shape[1]) == fmax for p in parts):
+        return torch.cat(list(parts), dim=0)
+    padded = [p if int(p.shape[1]) == fmax else torch.cat([p, p.new_zeros(p.shape[0], fmax - int(p.shape[1]), 3)], dim=1)
+              for p in parts]
+    return torch.cat(padded, dim=0)
+
+
+def scene_graph_tables(counts, object_poses, object_idft, device) -> dict:
+    """The small per-step tables of the fused scene-graph front end (``sgn_splatfacto_scene_graph.py:332-360`` folded into
+    the kernels): ``counts`` Gaussians per visible sub-model, background first; ``object_poses`` one
+    ``(rot [3,3], center [3], quat_o2w [4] wxyz)`` per visible object (host arrays: what ``anno.rot``, ``anno.center``
+    and ``quaternion_from_matrix(anno.rot)`` are at ``:410-413``); ``object_idft`` per object the [F] inverse-DFT weights
+    of the frame (``IDFT``, ``:420-433``) or None for a model without Fourier DC.  Returns
+    ``dict(object_ids=int32 [N], poses=float32 [M,16], idft=float32 [M,Fmax])`` on ``device``; row 0 is the background
+    (identity pose, weight 1 on coefficient 0)."""
+    import numpy as np
+    m = 1 + len(object_poses)
+    assert len(counts) == m and len(object_idft) == len(object_poses)
+    table = np.zeros((m, 16), dtype=np.float32)
+    table[0, [0, 4, 8]] = 1.0
+    table[0, 12] = 1.0
+    fmax = max([1] + [int(len(w)) for w in object_idft if w is not None])
+    idft = np.zeros((m, fmax), dtype=np.float32)
+    idft[0, 0] = 1.0
+    for k, (rot, center, quat) in enumerate(object_poses, start=1):
+        table[k, :9] = np.asarray(rot, dtype=np.float64).reshape(9)
+        table[k, 9:12] = np.asarray(center, dtype=np.float64).reshape(3)
+        table[k, 12:16] = np.asarray(quat, dtype=np.float64).reshape(4)
+        w = object_idft[k - 1]
+        if w is None:
+            idft[k, 0] = 1.0
+        else:
+            w = w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w)
+            idft[k, :len(w)] = w.reshape(-1)
+    both = torch.from_numpy(np.concatenate([table, idft], axis=1)).to(device)        # one host-to-device copy
+    return dict(object_ids=object_ids_for(counts, device), poses=both[:, :16].contiguous(), idft=both[:, 16:].contiguous())
+
+
 class _ProjectFused(Function):
     @staticmethod
     def forward(ctx, means, log_scales, quats_raw, object_ids, poses, viewmat, fx, fy, cx, cy, img_height,

@@ -163,25 +163,17 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
     cat = lambda key: torch.cat([m[key] for m in models], dim=0)                        # :355-360
     if fused:
         from . import fused as F_
-        Fmax = max(m["features_dc"].shape[1] for m in models)
-        pad = lambda d: d if d.shape[1] == Fmax else torch.cat(
-            [d, torch.zeros(d.shape[0], Fmax - d.shape[1], 3, device=dev, dtype=d.dtype)], dim=1)
         P = dict(means=cat("means"), log_scales=cat("log_scales"), quats=cat("quats"),
                  opacity_logits=cat("opacity_logits"), features_rest=cat("features_rest"),
-                 features_dc=torch.cat([pad(m["features_dc"]) for m in models], dim=0))
-        # per-Gaussian object id: depends on the model sizes only (they change at densification, not per step), so it
-        # is built on the host once per layout — repeat_interleave with device counts would sync every step
-        key = ("oid", str(dev), tuple(counts))
-        if key not in _CONST:
-            if len(_CONST) > 64:
-                _CONST.clear()
-            _CONST[key] = torch.repeat_interleave(torch.arange(len(models), dtype=torch.int32),
-                                                  torch.tensor(counts)).to(dev)
-        object_ids = _CONST[key]
+                 features_dc=F_.cat_features_dc([m["features_dc"] for m in models]))
+        object_ids = F_.object_ids_for(counts, dev)       # per layout, built once (no per-step device work)
         # Fourier weights padded to the widest model: rows beyond a model's own dimension stay zero
         Fs = [m["features_dc"].shape[1] for m in models]
+        Fmax = max(Fs)
         mask_key = ("fmask", str(dev), tuple(Fs), Fmax)
         if mask_key not in _CONST:
+            if len(_CONST) > 64:
+                _CONST.clear()
             _CONST[mask_key] = (torch.arange(Fmax)[None, :] < torch.tensor(Fs)[:, None]).to(dev, torch.float32)
         idft_p = torch.zeros(len(models), Fmax, device=dev)
         fw = min(Fmax, idft.shape[1])

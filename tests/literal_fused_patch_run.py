@@ -1,6 +1,6 @@
 """Child process of tests/test_gpu_reference_literal.py::test_patched_call_sites_run_on_the_fused_ops (test
 infrastructure).  argv[1] = a directory holding a copy of the reference's model files WITH
-integration/fused_callsites.patch applied.  Runs the patched `SplatfactoModel.get_outputs` + loss + backward literally
+integration/fused_callsites.patch — and optionally integration/fused_scene_graph.patch on top — applied.  Runs the patched `SplatfactoModel.get_outputs` + loss + backward literally
 on the HIP ops (fused front ends) and compares with the un-patched call pattern's replay (`sgn_rast.step.render`, which
 test_gpu_reference_literal.py pins to the un-patched literal run bit for bit).  Prints one line per check."""
 import os
@@ -72,8 +72,34 @@ graph, stamps = refhost.build_scene_graph(ns, [to_dev(m) for m in models], poses
 graph = graph.to(DEV)
 frame = 1
 camera = refhost.nerfstudio_camera(ns, cam, time=float(stamps[frame])).to(DEV)
+sg_patched = "sgn_fused.scene_graph_tables" in open(ns.graph.__file__).read()
 ops.clear_binning_cache()
-out = graph.get_outputs(camera)
+b0, w0 = dict(ops.binning_stats), dict(ops.window_stats)
+import torch.utils._python_dispatch as _pd
+
+
+class _CountCats(_pd.TorchDispatchMode):
+    n = 0
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        if func.overloadpacket in (torch.ops.aten.cat, torch.ops.aten.mm, torch.ops.aten.matmul):
+            _CountCats.n += 1
+        return func(*args, **(kwargs or {}))
+
+
+with _CountCats():
+    out = graph.get_outputs(camera)
+n_glue = _CountCats.n
+if sg_patched:
+    # ONE binning for the four passes, the objects over their own sub-list, and the aggregation's per-object matmuls /
+    # per-sub-model concatenations are gone from the step (un-patched: ~70 cat / mm calls at three objects)
+    good = (ops.binning_stats["binnings"] - b0["binnings"] == 1 and ops.window_stats["sub_lists"] - w0["sub_lists"] == 1
+            and n_glue <= 16)
+    ok = ok and good
+    print(f"fused-patch scene graph (aggregation patched): 1 binning, 1 sub-list, {n_glue} cat/mm calls -> "
+          f"{'PASS' if good else 'FAIL'}")
+else:
+    print(f"fused-patch scene graph (call sites only): {n_glue} cat/mm calls -> PASS")
 (out["rgb"].sum() + out["accumulation"].sum() + out["object_acc"].sum()).backward()
 p_t, idft = refhost.scene_graph_tables(ns, models, poses, frame)
 Ms = [step.leaf_params(to_dev(m)) for m in models]

@@ -221,7 +221,9 @@ def test_scene_graph_runs_literally_on_the_hip_ops(ns):
          f"worst leaf-grad rel-L2 {worst:.2e}; loss {float(loss):.6f}")
 
 
-def test_patched_call_sites_run_on_the_fused_ops(tmp_path):
+@pytest.mark.parametrize("patches", [("fused_callsites.patch",), ("fused_callsites.patch", "fused_scene_graph.patch")],
+                         ids=["callsites", "callsites+scene_graph"])
+def test_patched_call_sites_run_on_the_fused_ops(tmp_path, patches):
     """`integration/fused_callsites.patch` — the minimal edit of the reference's
     `sgn_splatfacto.py` that routes it onto `sgn_rast.fused` (no exp / normalise / sigmoid / cat / view-direction
     kernels, no second rasterization for depth).  Applied to a copy of the staged reference files, the patched
@@ -234,13 +236,14 @@ def test_patched_call_sites_run_on_the_fused_ops(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dst = tmp_path / "ref_patched"
     shutil.copytree(refhost.REFERENCE, dst)
-    patch = os.path.join(root, "integration", "fused_callsites.patch")
-    r = subprocess.run(["patch", "-p1", "-i", patch], cwd=dst, capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
+    for name in patches:
+        r = subprocess.run(["patch", "-p1", "-i", os.path.join(root, "integration", name)], cwd=dst, capture_output=True,
+                           text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
     r = subprocess.run([sys.executable, os.path.join(root, "tests", "literal_fused_patch_run.py"), str(dst)],
                        capture_output=True, text=True, timeout=600)
     for line in r.stdout.splitlines():
         if line.startswith("fused-patch"):
             _log(line)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert r.stdout.count("PASS") >= 11 and "FAIL" not in r.stdout
+    assert r.stdout.count("PASS") >= 12 and "FAIL" not in r.stdout
