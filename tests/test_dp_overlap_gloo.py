@@ -153,12 +153,13 @@ def test_overlapped_exchange_equals_sequential_and_keeps_the_sequence(tmp_path):
             assert torch.equal(a, b), (step_i, name)                        # overlap changes timing, not results
             assert torch.equal(b, r1[(True, step_i)][name]), (step_i, name)  # replicas agree bit for bit
             assert float(b.abs().sum()) > 0, (step_i, name)
-    assert r0[("stats", True)] == {"bucket_early": 3, "bucket_late": 0}
-    assert r1[("stats", True)] == {"bucket_early": 2, "bucket_late": 1}      # the silent rank sent it from finish()
-    assert r0[("stats", False)] == {"bucket_early": 0, "bucket_late": 3}
+    early_late = lambda st: (st["bucket_early"], st["bucket_late"])
+    assert early_late(r0[("stats", True)]) == (3, 0)
+    assert early_late(r1[("stats", True)]) == (2, 1)      # the silent rank sent it from finish()
+    assert early_late(r0[("stats", False)]) == (0, 3)
     assert r0["violation"] == "detected" and r1["violation"] == "detected"
     assert r0["held_back"] and r1["held_back"]
-    assert r0["late_stats"] == {"bucket_early": 0, "bucket_late": 1}
+    assert early_late(r0["late_stats"]) == (0, 1)
 
 
 def test_watchdog_fires_once_when_the_loop_stops_beating():
