@@ -291,6 +291,15 @@ int sgn_list_window(int n_tiles, const int32_t *gaussian_ids_sorted, const int32
                     int ids_qmask, int32_t *ids_out, int32_t *tile_bins_out /*[n_tiles,2]*/, void *ws, size_t ws_bytes,
                     sgn_stream_t stream);
 
+/* The distinct Gaussian ids a forward pass WALKED (entries [tile_bins[t].x, tile_stats[2t]] of every tile's list:
+ * tile_stats is sgn_raster_fwd's per-tile output) — a superset of the rows its backward can give a non-zero gradient,
+ * known right after the forward.  The data-parallel row exchange (sgn_rast/dp.py) sends these rows instead of dense
+ * gradients.  stamps [n] (int32, zero-filled once, then owned by this call sequence) records the epoch (non-zero, a new
+ * value per call) an id was last listed in; list needs n entries; *count receives the number listed.  No upstream
+ * counterpart (the reference is single-GPU). */
+int sgn_mark_walked(int n_tiles, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const int32_t *tile_stats,
+                    int ids_qmask, int epoch, int32_t *stamps, int32_t *list, int32_t *count, sgn_stream_t stream);
+
 /* Window recognition for the drop-in scene-graph path (no upstream counterpart).  The reference renders its sub-model
  * passes (sgn_splatfacto_scene_graph.py:364-366) from torch.cat COPIES of per-model slices of the main projection
  * (:270-276).  mismatch[c] (device, int32, c < n_cand <= 4) becomes 0 iff the window tensors equal rows

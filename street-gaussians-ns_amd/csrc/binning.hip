@@ -1192,3 +1192,42 @@ SGN_EXPORT int sgn_list_window(int n_tiles, const int32_t *gaussian_ids_sorted, 
     SGN_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------- walked ids
+// Which Gaussians can receive a gradient from this view?  Only those a tile walked before it saturated: entries
+// [bins[t].x, kmax[t]] of the tile's depth list (kmax: the deepest list position any pixel of the tile composited, left
+// behind by the forward).  On content whose tiles saturate that is under 1 % of the scene (profiles/r04_touched_fraction),
+// which is what the data-parallel row exchange sends instead of dense gradients (sgn_rast/dp.py).  This kernel turns the
+// forward's (ids, bins, kmax) into the LIST of distinct walked ids — known right after the forward, so its length
+// reaches the host (and the other ranks) long before the backward ends and the exchange needs no host sync of its own.
+// stamps[id] holds the epoch of the last step that listed the id (no clearing pass); list order is arbitrary.
+namespace {
+__global__ __launch_bounds__(256) void mark_walked_kernel(int n_tiles, const int32_t *__restrict__ ids,
+                                                          const int2 *__restrict__ bins,
+                                                          const int32_t *__restrict__ kmax, int idmask, int epoch,
+                                                          int32_t *__restrict__ stamps, int32_t *__restrict__ list,
+                                                          int32_t *__restrict__ count) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const int2 r = bins[t];
+    const int last = min(kmax[2 * t], r.y - 1);
+    for (int k = r.x + lane; k <= last; k += 64) {
+        const int id = ids[k] & idmask;
+        if (atomicExch(stamps + id, epoch) != epoch) list[atomicAdd(count, 1)] = id;
+    }
+}
+}  // namespace
+
+SGN_EXPORT int sgn_mark_walked(int n_tiles, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                               const int32_t *tile_stats, int ids_qmask, int epoch, int32_t *stamps, int32_t *list,
+                               int32_t *count, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n_tiles > 0 && gaussian_ids_sorted && tile_bins && tile_stats && stamps && list && count, -1);
+    SGN_ARG_CHECK(epoch != 0, -2);
+    hipStream_t s = (hipStream_t)stream;
+    SGN_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    const int idmask = ids_qmask ? (SGN_QMASK_MAX_IDS - 1) : -1;
+    hipLaunchKernelGGL(mark_walked_kernel, dim3(sgn_cdiv(n_tiles, 4)), dim3(256), 0, s, n_tiles, gaussian_ids_sorted,
+                       (const int2 *)tile_bins, tile_stats, idmask, epoch, stamps, list, count);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}

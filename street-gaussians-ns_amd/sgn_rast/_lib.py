@@ -76,6 +76,7 @@ SIGNATURES = {
     "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "sgn_list_window_workspace_bytes": (_sz, [_i]),
     "sgn_list_window": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_mark_walked": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_rows_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_raster_workspace_bytes": (_sz, [_i, _i64, _vp]),
     "sgn_tile_order": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp]),

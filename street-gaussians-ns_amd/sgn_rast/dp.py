@@ -175,8 +175,13 @@ class GradAllReducer:
         self._hooks = []
         self.stats = {"bucket_early": 0, "bucket_late": 0, "sparse_steps": 0, "dense_steps": 0,
                       "touched_fraction": None, "rows_sent": 0}
+        self._early = None              # (count event state) of this step's forward-time announcement
+        self._mark = None               # persistent device buffers of sgn_mark_walked
         if self.sparse:
-            self.overlap = False        # the row exchange is sized by counts that exist only after the backward
+            self.overlap = False        # the row exchange replaces the bucket and the early all-gathers
+            if self.active and sh_exchange.dc.is_cuda:
+                from . import ops
+                ops._touch_sink = self
         if self.overlap:
             if sh_exchange is not None:
                 sh_exchange.early_start = True
@@ -203,6 +208,43 @@ class GradAllReducer:
         self.stats["bucket_early" if early else "bucket_late"] += 1
 
     # ------------------------------------------------------------------- the compacted row exchange (round 4)
+    def after_forward(self, ids, tile_bins, tile_kmax, n, qmask) -> None:
+        """ops._touch_sink: called by rasterize_gaussians right after a full forward pass.  Lists the distinct Gaussians
+        the pass walked (sgn_mark_walked: a superset of the rows the backward can touch, known NOW), and announces
+        ``[count, can, degree, k]`` to the other ranks — the step's first collective — so that by the time the backward
+        has run every rank knows every count without a host sync of its own."""
+        ex = self.sh_exchange
+        if not (self.sparse and self.active) or ex is None or n != ex.dc.shape[0]:
+            return
+        if self._early is not None:
+            if self._early["ids_ptr"] != ids.data_ptr():
+                self._early["views"] += 1        # a second view before finish(): the list covers the first only
+            return
+        from . import _lib as L
+        dev = ids.device
+        if self._mark is None or self._mark["n"] != n:
+            self._mark = dict(n=n, stamps=torch.zeros(n, dtype=torch.int32, device=dev),
+                              list=torch.empty(n, dtype=torch.int32, device=dev),
+                              count=torch.zeros(1, dtype=torch.int32, device=dev), epoch=0,
+                              pinned=torch.zeros(2, 4 * max(self.world, 1), dtype=torch.int64).pin_memory(), slot=0)
+        m = self._mark
+        m["epoch"] = m["epoch"] % 2_000_000_000 + 1
+        L.check(L.load().sgn_mark_walked(tile_bins.shape[0], L.ptr(ids), L.ptr(tile_bins), L.ptr(tile_kmax), int(qmask),
+                                         m["epoch"], L.ptr(m["stamps"]), L.ptr(m["list"]), L.ptr(m["count"]),
+                                         L.stream_ptr()), "sgn_mark_walked")
+        f = ex._fwd
+        can = int(f["claimed"] == 1 and f["other"] == 0 and f["cam"] and not ex.started)
+        info = torch.tensor([0, can, f["degree"], f["k"]], dtype=torch.int64, device=dev)
+        info[0:1].copy_(m["count"])
+        every = _all_gather_sync(info, self.group)                     # stream-ordered on RCCL: no host wait here
+        pinned = m["pinned"][m["slot"] % 2][: every.numel()]
+        m["slot"] += 1
+        pinned.copy_(every.reshape(-1), non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        self._early = dict(pinned=pinned, done=done, ids_ptr=ids.data_ptr(), views=1, list=m["list"], can=can,
+                           keep=every)
+
     def _finish_sparse(self) -> bool:
         """One view's backward leaves most gradient rows EXACTLY zero: a Gaussian behind saturated pixels, outside the
         frustum or culled receives nothing (measured per view, `profiles/r04_touched_fraction.json`: 0.3-0.8 % of the
@@ -241,34 +283,55 @@ class GradAllReducer:
             can, degree, k, cam, means = False, 0, 0, None, None
         widths = [int(p[0].numel()) if n > 0 else 0 for p in rows_p]
         count, idx, packed = 0, None, None
-        if can and ran and c is not None:
+        early, self._early = self._early, None
+        ex._fwd = dict(claimed=0, other=0, degree=-1, k=0, cam=False)
+
+        def cols_of():
             cols = []
             for p in rows_p:
                 cols.append(torch.zeros(n, int(p[0].numel()), dtype=torch.float32, device=dev) if p.grad is None
                             else p.grad.detach().reshape(n, -1))
             cols.append(c["v"].reshape(n, 3))
-            packed = torch.cat(cols, dim=1)                            # [n, W]: every per-Gaussian gradient word
-            idx = (packed != 0).any(dim=1).nonzero().squeeze(1)        # host sync 1: the backward has finished
-            count = int(idx.numel())
-        info = torch.tensor([count, int(can), int(degree), int(k)], dtype=torch.int64, device=dev)
-        every = _all_gather_sync(info, self.group).cpu().tolist()      # host sync 2: every rank's count
+            return cols
+        if early is not None:
+            # the announcement left right after the forward; its answer has been on the host since (no stall)
+            if early["views"] != 1:
+                raise RuntimeError("GradAllReducer(sparse=True): more than one view was rendered between two finish() "
+                                   "calls — the walked-row list covers the first one only; use sparse=False")
+            if early["can"] and not (can and c is not None):
+                raise RuntimeError("GradAllReducer(sparse=True): the forward announced a claimed SH node with a known "
+                                   "camera, the backward did not deliver it (graph changed between forward and backward?)")
+            early["done"].synchronize()
+            every = early["pinned"].reshape(self.world, 4).tolist()
+            count = int(every[dist.get_rank(self.group)][0])
+            if can and c is not None and count:
+                idx = early["list"][:count].long()
+                packed = torch.cat([col.index_select(0, idx) for col in cols_of()], dim=1)      # [count, W]
+        else:
+            if can and ran and c is not None:
+                full = torch.cat(cols_of(), dim=1)                         # [n, W]: every per-Gaussian gradient word
+                idx = (full != 0).any(dim=1).nonzero().squeeze(1)          # host sync: the backward has finished
+                count = int(idx.numel())
+                packed = full.index_select(0, idx)
+            info = torch.tensor([count, int(can), int(degree), int(k)], dtype=torch.int64, device=dev)
+            every = _all_gather_sync(info, self.group).cpu().tolist()      # host sync: every rank's count
         counts = [int(e[0]) for e in every]
         total_ok = all(int(e[1]) == 1 for e in every)
-        degs = {(int(e[2]), int(e[3])) for e in every if int(e[0]) > 0}
+        degs = {(int(e[2]), int(e[3])) for e in every if int(e[0]) > 0 and int(e[2]) >= 0}
         sparse = (total_ok and len(degs) <= 1 and n > 0
                   and sum(counts) <= self.sparse_max_fraction * self.world * n)
         if not sparse:
             self.stats["dense_steps"] += 1
             return False
-        if degs:
-            degree, k = next(iter(degs))
+        if c is None and degs:
+            degree, k = next(iter(degs))          # a silent rank takes the step's shape from the ranks that rendered
         W = sum(widths) + 3
         maxc = max(counts)
         send = torch.zeros(1 + maxc, 1 + W, dtype=torch.float32, device=dev)
         send[0, :3] = cam
         if count:
             send[1:1 + count, 0] = idx.to(torch.int32).view(torch.float32)       # ids ride as bit patterns
-            send[1:1 + count, 1:] = packed[idx]
+            send[1:1 + count, 1:] = packed
         got = _all_gather_sync(send, self.group, wait=False)            # [world, 1 + maxc, 1 + W]
         pending = [(dist.all_reduce(p.grad if p.grad is not None else _zero_grad(p), op=self._op, group=self.group,
                                     async_op=True), p) for p in other]
@@ -341,11 +404,14 @@ class GradAllReducer:
                 p.grad /= self.world
 
     def remove(self) -> None:
-        """Detach the overlap hooks (a reducer that is being replaced)."""
+        """Detach the overlap hooks and the forward sink (a reducer that is being replaced)."""
         for h in self._hooks:
             h.remove()
         self._hooks = []
         self.overlap = False
+        from . import ops
+        if ops._touch_sink is self:
+            ops._touch_sink = None
 
 
 def _zero_grad(p: torch.Tensor) -> torch.Tensor:
@@ -433,6 +499,7 @@ class SHGradExchange:
         self._works = []
         self._view = None
         self.early_start = False  # GradAllReducer(overlap=True): send the all-gathers from the claimed node's backward
+        self._fwd = dict(claimed=0, other=0, degree=-1, k=0, cam=False)     # see _note_forward
 
     @property
     def started(self) -> bool:
@@ -461,21 +528,33 @@ class SHGradExchange:
         fused._sh_exchange = None
 
     # ------------------------------------------------------------------ claims (forward time, host only)
-    def claims_coeffs(self, coeffs: torch.Tensor) -> bool:
+    def claims_coeffs(self, coeffs: torch.Tensor, degree: Optional[int] = None) -> bool:
         """Is ``coeffs`` exactly ``torch.cat((features_dc, features_rest), dim=1)`` of the registered leaves?"""
-        if not self.active or self.dc.shape[1] != 1:
-            return False
-        fn = coeffs.grad_fn
-        if fn is None or type(fn).__name__ != "CatBackward0" or getattr(fn, "_saved_dim", 1) != 1:
-            return False
-        nxt = fn.next_functions
-        return len(nxt) == 2 and all(getattr(f[0], "variable", None) is leaf
-                                     for f, leaf in zip(nxt, (self.dc, self.rest)))
+        ok = False
+        if self.active and self.dc.shape[1] == 1:
+            fn = coeffs.grad_fn
+            if fn is not None and type(fn).__name__ == "CatBackward0" and getattr(fn, "_saved_dim", 1) == 1:
+                nxt = fn.next_functions
+                ok = len(nxt) == 2 and all(getattr(f[0], "variable", None) is leaf
+                                           for f, leaf in zip(nxt, (self.dc, self.rest)))
+        self._note_forward(ok, degree, coeffs.shape[1], cam_known=self._view is not None)
+        return ok
 
-    def claims_leaves(self, features_dc, features_rest, object_ids, poses, idft) -> bool:
-        if not self.active or features_dc is not self.dc or features_rest is not self.rest:
-            return False
-        return object_ids is None and poses is None and self.dc.shape[1] == 1
+    def claims_leaves(self, features_dc, features_rest, object_ids, poses, idft, degree: Optional[int] = None) -> bool:
+        ok = (self.active and features_dc is self.dc and features_rest is self.rest
+              and object_ids is None and poses is None and self.dc.shape[1] == 1)
+        k = 1 + (features_rest.shape[1] if features_rest is not None else 0)
+        self._note_forward(ok, degree, k, cam_known=True)
+        return ok
+
+    def _note_forward(self, claimed: bool, degree, k, cam_known: bool) -> None:
+        """What the forward pass of this step has shown so far (the row exchange announces it to the other ranks right
+        after the forward): SH nodes claimed / not claimed, their degree, whether the camera position will be known."""
+        f = self._fwd
+        if claimed and f["claimed"] == 0:
+            f.update(claimed=1, degree=-1 if degree is None else int(degree), k=int(k), cam=bool(cam_known))
+        elif self.active:
+            f["other"] += 1
 
     # ------------------------------------------------------------------ taps (backward time; record only)
     def tap_dirs(self, viewdirs, v_colors, degree, k, claimed: bool) -> bool:

@@ -245,7 +245,7 @@ def spherical_harmonics_fused(degrees_to_use: int, means, cam_pos, features_dc, 
     k = 1 + (features_rest.shape[1] if features_rest is not None else 0)
     assert k >= (degrees_to_use + 1) ** 2
     claimed = _sh_exchange is not None and _sh_exchange.claims_leaves(features_dc, features_rest, object_ids, poses,
-                                                                      idft)
+                                                                      idft, degrees_to_use)
     return _SHFused.apply(degrees_to_use, means.detach(), cam_pos, features_dc.contiguous(),
                           None if features_rest is None else features_rest.contiguous(), object_ids, idft, poses,
                           post_half_clamp, claimed)

@@ -298,7 +298,7 @@ def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: tor
     polynomial; the kernel evaluates the "fast" recurrences)."""
     assert coeffs.shape[-2] >= num_sh_bases(degrees_to_use)
     assert method in ("poly", "fast"), "Invalid method."
-    claimed = _sh_exchange is not None and _sh_exchange.claims_coeffs(coeffs)
+    claimed = _sh_exchange is not None and _sh_exchange.claims_coeffs(coeffs, degrees_to_use)
     if _sh_exchange is None and _proofs_on(sh_split_backward) and coeffs.is_contiguous() and (
             coeffs.is_cuda or not proofs.need_device):
         # the scene graph's sub-model passes evaluate the SH twice from the SAME concatenation (scene_graph.py:285, then
@@ -1100,6 +1100,11 @@ def _depth_wanted() -> bool:
 _provably_depths = proofs.repeated_depths     # host-side proof that colours are `depths[:, None].repeat(1, 3)` (:988)
 
 
+# Optional hook for data-parallel training (sgn_rast.dp.GradAllReducer(sparse=True)): `after_forward(ids, bins, kmax, n,
+# qmask)` is told, right after a full (non-window) forward pass, which list entries the pass walked.  None normally.
+_touch_sink = None
+
+
 # --------------------------------------------------------------- rasterize
 class _RasterizeGaussians(Function):
     @staticmethod
@@ -1239,6 +1244,9 @@ class _RasterizeGaussians(Function):
                     _depth_state["want"], _depth_state["unused"] = False, 0
             elif not hit:
                 S.depth_caches.pop(key, None)  # re-binned without the channel: a stale image must not answer later
+        if _touch_sink is not None and num_intersects >= 1 and win is None and id_range is None and not proved:
+            # data-parallel row exchange: which Gaussians this view's backward can touch (the walked entries)
+            _touch_sink.after_forward(gaussian_ids_sorted, tile_bins, tile_kmax, n_full, ro.ids_qmask)
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
         ctx.num_intersects = num_intersects
         ctx.opacity_is_logit = int(bool(opacity_is_logit))
