@@ -300,6 +300,19 @@ int sgn_list_window(int n_tiles, const int32_t *gaussian_ids_sorted, const int32
 int sgn_mark_walked(int n_tiles, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const int32_t *tile_stats,
                     int ids_qmask, int epoch, int32_t *stamps, int32_t *list, int32_t *count, sgn_stream_t stream);
 
+/* The two data movements of the data-parallel row exchange (sgn_rast/dp.py; no upstream counterpart).
+ * sgn_rows_pack: message = [header row | count rows] of row_words floats each; header = header3 (3 floats) + zeros;
+ * row i = [bits of id = list[i] | rows id of the n_tensors (<= 8) per-Gaussian float tensors side by side (widths_host[j]
+ * floats each; a NULL source contributes zeros)].  srcs_host / widths_host are HOST arrays (device pointers inside).
+ * sgn_rows_scatter: the rows of ONE rank's message added (x scale) into the dense per-tensor sums dsts_host[j][id]; the
+ * last tail_words floats of each row are copied to tail_out[id] (may be NULL with tail_words 0 ... and are NOT scaled).
+ * Ids are unique within a message; call once per rank, in rank order, for replica-identical sums. */
+int sgn_rows_pack(int count, const int32_t *list, int n_tensors, const float *const *srcs_host,
+                  const int32_t *widths_host, const float *header3, float *out, int row_words, sgn_stream_t stream);
+int sgn_rows_scatter(int count, const float *rows /*incl. header row*/, int row_words, int n_tensors,
+                     float *const *dsts_host, const int32_t *widths_host, float scale, int tail_words, float *tail_out,
+                     sgn_stream_t stream);
+
 /* Window recognition for the drop-in scene-graph path (no upstream counterpart).  The reference renders its sub-model
  * passes (sgn_splatfacto_scene_graph.py:364-366) from torch.cat COPIES of per-model slices of the main projection
  * (:270-276).  mismatch[c] (device, int32, c < n_cand <= 4) becomes 0 iff the window tensors equal rows

@@ -293,6 +293,8 @@ class GradAllReducer:
                             else p.grad.detach().reshape(n, -1))
             cols.append(c["v"].reshape(n, 3))
             return cols
+        hip = dev.type == "cuda"
+        list32 = None
         if early is not None:
             # the announcement left right after the forward; its answer has been on the host since (no stall)
             if early["views"] != 1:
@@ -305,14 +307,14 @@ class GradAllReducer:
             every = early["pinned"].reshape(self.world, 4).tolist()
             count = int(every[dist.get_rank(self.group)][0])
             if can and c is not None and count:
-                idx = early["list"][:count].long()
-                packed = torch.cat([col.index_select(0, idx) for col in cols_of()], dim=1)      # [count, W]
+                list32 = early["list"][:count]
         else:
             if can and ran and c is not None:
                 full = torch.cat(cols_of(), dim=1)                         # [n, W]: every per-Gaussian gradient word
                 idx = (full != 0).any(dim=1).nonzero().squeeze(1)          # host sync: the backward has finished
                 count = int(idx.numel())
-                packed = full.index_select(0, idx)
+                list32 = idx.to(torch.int32)
+                del full
             info = torch.tensor([count, int(can), int(degree), int(k)], dtype=torch.int64, device=dev)
             every = _all_gather_sync(info, self.group).cpu().tolist()      # host sync: every rank's count
         counts = [int(e[0]) for e in every]
@@ -326,29 +328,60 @@ class GradAllReducer:
         if c is None and degs:
             degree, k = next(iter(degs))          # a silent rank takes the step's shape from the ranks that rendered
         W = sum(widths) + 3
+        row_words = 1 + W
         maxc = max(counts)
-        send = torch.zeros(1 + maxc, 1 + W, dtype=torch.float32, device=dev)
-        send[0, :3] = cam
-        if count:
-            send[1:1 + count, 0] = idx.to(torch.int32).view(torch.float32)       # ids ride as bit patterns
-            send[1:1 + count, 1:] = packed
+        scale = 1.0 / self.world if self.average else 1.0
+        if hip:
+            import ctypes as C
+            from . import _lib as L
+            lib = L.load()
+            nt = len(rows_p) + 1
+            f32c = lambda t: t if (t.dtype is torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+            srcs = [None if (p.grad is None or c is None) else f32c(p.grad.detach()) for p in rows_p]
+            srcs.append(None if c is None else f32c(c["v"]))
+            wid = (C.c_int32 * nt)(*(widths + [3]))
+            send = torch.empty(1 + maxc, row_words, dtype=torch.float32, device=dev)
+            L.check(lib.sgn_rows_pack(count if list32 is not None else 0, L.ptr(list32), nt,
+                                      (C.c_void_p * nt)(*[None if t is None else t.data_ptr() for t in srcs]), wid,
+                                      L.ptr(cam.contiguous()), L.ptr(send), row_words, L.stream_ptr()), "sgn_rows_pack")
+        else:
+            send = torch.zeros(1 + maxc, row_words, dtype=torch.float32, device=dev)
+            send[0, :3] = cam
+            if list32 is not None and count:
+                idx = list32.long()
+                send[1:1 + count, 0] = list32.view(torch.float32)                      # ids ride as bit patterns
+                send[1:1 + count, 1:] = torch.cat([col.index_select(0, idx) for col in cols_of()], dim=1)
         got = _all_gather_sync(send, self.group, wait=False)            # [world, 1 + maxc, 1 + W]
         pending = [(dist.all_reduce(p.grad if p.grad is not None else _zero_grad(p), op=self._op, group=self.group,
                                     async_op=True), p) for p in other]
         got = got()                                                     # wait (stream-ordered on RCCL)
-        scale = 1.0 / self.world if self.average else 1.0
-        acc = torch.zeros(n, W - 3, dtype=torch.float32, device=dev)
         v_all = torch.zeros(self.world, n, 3, dtype=torch.float32, device=dev)
-        for r in range(self.world):                                     # rank order: the same sum on every replica
-            cr = counts[r]
-            if cr:
-                ids = got[r, 1:1 + cr, 0].contiguous().view(torch.int32).long()
-                acc.index_add_(0, ids, got[r, 1:1 + cr, 1:1 + W - 3])   # ids are unique within a rank: no collisions
-                v_all[r].index_copy_(0, ids, got[r, 1:1 + cr, 1 + W - 3:])
-        off = 0
-        for p, w in zip(rows_p, widths):
-            p.grad = (acc[:, off:off + w] * scale).reshape(p.shape)
-            off += w
+        if hip:
+            flat = torch.zeros(n * sum(widths), dtype=torch.float32, device=dev)       # one fill for every dense sum
+            outs, off = [], 0
+            for p, w in zip(rows_p, widths):
+                outs.append(flat[off:off + n * w].view(p.shape))
+                off += n * w
+            ng = len(rows_p)
+            dsts = (C.c_void_p * ng)(*[o.data_ptr() for o in outs])
+            wid_g = (C.c_int32 * ng)(*widths)
+            for r in range(self.world):                                 # rank order: the same sum on every replica
+                L.check(lib.sgn_rows_scatter(counts[r], L.ptr(got[r]), row_words, ng, dsts, wid_g, float(scale), 3,
+                                             L.ptr(v_all[r]), L.stream_ptr()), "sgn_rows_scatter")
+            for p, o in zip(rows_p, outs):
+                p.grad = o
+        else:
+            acc = torch.zeros(n, W - 3, dtype=torch.float32, device=dev)
+            for r in range(self.world):                                 # rank order: the same sum on every replica
+                cr = counts[r]
+                if cr:
+                    ids = got[r, 1:1 + cr, 0].contiguous().view(torch.int32).long()
+                    acc.index_add_(0, ids, got[r, 1:1 + cr, 1:1 + W - 3])   # ids are unique within a rank
+                    v_all[r].index_copy_(0, ids, got[r, 1:1 + cr, 1 + W - 3:])
+            off = 0
+            for p, w in zip(rows_p, widths):
+                p.grad = (acc[:, off:off + w] * scale).reshape(p.shape)
+                off += w
         cams = got[:, 0, :3].contiguous()
         low = ex.multi_fn(degree, k, None, means, cams, None, None, v_all, scale)
         low = low if isinstance(low, tuple) else (low[:, 0:1, :], low[:, 1:, :])
