@@ -228,22 +228,34 @@ class GradAllReducer:
                               count=torch.zeros(1, dtype=torch.int32, device=dev), epoch=0,
                               pinned=torch.zeros(2, 4 * max(self.world, 1), dtype=torch.int64).pin_memory(), slot=0)
         m = self._mark
+        if m.get("side") is not None:
+            torch.cuda.current_stream(dev).wait_stream(m["side"])      # the last announcement has read `count`
         m["epoch"] = m["epoch"] % 2_000_000_000 + 1
         L.check(L.load().sgn_mark_walked(tile_bins.shape[0], L.ptr(ids), L.ptr(tile_bins), L.ptr(tile_kmax), int(qmask),
                                          m["epoch"], L.ptr(m["stamps"]), L.ptr(m["list"]), L.ptr(m["count"]),
                                          L.stream_ptr()), "sgn_mark_walked")
         f = ex._fwd
         can = int(f["claimed"] == 1 and f["other"] == 0 and f["cam"] and not ex.started)
-        info = torch.tensor([0, can, f["degree"], f["k"]], dtype=torch.int64, device=dev)
-        info[0:1].copy_(m["count"])
-        every = _all_gather_sync(info, self.group)                     # stream-ordered on RCCL: no host wait here
-        pinned = m["pinned"][m["slot"] % 2][: every.numel()]
-        m["slot"] += 1
-        pinned.copy_(every.reshape(-1), non_blocking=True)
-        done = torch.cuda.Event()
-        done.record()
+        key = (can, f["degree"], f["k"])
+        if m.get("tmpl_key") != key:            # (changes when the SH degree ramps: one small upload then)
+            m["tmpl_key"], m["tmpl"] = key, torch.tensor([0, can, f["degree"], f["k"]], dtype=torch.int64, device=dev)
+        # the announcement travels on a side stream: the forward's own stream never waits for the collective
+        main = torch.cuda.current_stream(dev)
+        if m.get("side") is None:
+            m["side"] = torch.cuda.Stream(dev)
+        side = m["side"]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            info = m["tmpl"].clone()
+            info[0:1].copy_(m["count"])
+            every = _all_gather_sync(info, self.group)                 # stream-ordered on RCCL: no host wait here
+            pinned = m["pinned"][m["slot"] % 2][: every.numel()]
+            m["slot"] += 1
+            pinned.copy_(every.reshape(-1), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(side)
         self._early = dict(pinned=pinned, done=done, ids_ptr=ids.data_ptr(), views=1, list=m["list"], can=can,
-                           keep=every)
+                           keep=(every, info))
 
     def _finish_sparse(self) -> bool:
         """One view's backward leaves most gradient rows EXACTLY zero: a Gaussian behind saturated pixels, outside the
