@@ -335,9 +335,13 @@ int sgn_rows_match(int n_win, int n_full, int n_cand, const int32_t *cand_lo_hos
  * Results do not depend on the order; on skewed content it removes the tail of late-starting long tiles, and n_long
  * drives the backward's two-kernel adaptive scheme (sgn_raster_bwd).  `order` has n_tiles + 2 entries; the last one is
  * 0, or - with tile_stats, images of up to 16384 tiles - 1000 * (list entries the forward WALKED before its tiles
- * saturated) / (entries listed): the statistic the host's quadrant-mask policy reads back (sgn_bin_intersect). */
+ * saturated) / (entries listed): the statistic the host's quadrant-mask policy reads back (sgn_bin_intersect).
+ * scratch (sgn_tile_order_scratch_bytes(n_tiles); int32 words, ZERO-FILLED before its first use, left zero-filled by
+ * every call, one per stream: calls that share it must be stream-ordered) selects the multi-workgroup form (any tile
+ * count below 2^26, the statistic included); NULL keeps the single-workgroup kernels. */
+size_t sgn_tile_order_scratch_bytes(int n_tiles);
 int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_stats, int long_thresh, int small_q16,
-                   int32_t *order, sgn_stream_t stream);
+                   int32_t *order, void *scratch, size_t scratch_bytes, sgn_stream_t stream);
 
 /* _C.rasterize_forward (3-channel path; reference call sites sgn_splatfacto.py:954-967,
  * :982-994).  `recs_ws` (>= sgn_raster_workspace_bytes(n, n_isect)) receives the depth-ordered

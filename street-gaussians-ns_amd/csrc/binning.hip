@@ -1082,9 +1082,110 @@ __global__ __launch_bounds__(1024) void tile_order_big_kernel(int n_tiles, const
 }
 }  // namespace
 
+// Multi-workgroup form (round 4).  The single-workgroup kernels above are one CU doing ~500 ballots back to back while
+// 255 CUs wait: 10-30 us per launch, two to four launches per step, on the critical path in front of each raster
+// kernel.  Here every workgroup classes 256 tiles (one wave-aggregated LDS atomic per class and wave), reserves a range
+// per class with ONE global atomic per class present, and leaves a packed (class, rank) word per tile; the LAST
+// workgroup to finish (arrival counter) turns the 64 class totals into starts and scatters the permutation.
+// Cross-workgroup data follows MI355X_MICROARCH.md "inter-workgroup visibility": records and totals are written with
+// agent-scope (write-through) stores / atomics and drained before the arrival, and read back with agent-scope loads.
+// `scratch` ([0,64) class totals, [64] arrivals, [66,70) two 64-bit sums, [72, 72 + n_tiles) records) must be zero on
+// first use; the last workgroup leaves it zero again.  Ranks inside a class follow arrival order (launch order only —
+// results never depend on it).
+namespace {
+constexpr int ORDER_SCRATCH_HEAD = 72;
+typedef __attribute__((address_space(1))) int32_t g_i32;
+__global__ __launch_bounds__(256) void tile_order_mb_kernel(int n_tiles, const int2 *__restrict__ bins,
+                                                            const int32_t *__restrict__ kmax, int long_thresh,
+                                                            int small_q16, int32_t *__restrict__ order,
+                                                            int32_t *__restrict__ scratch) {
+    __shared__ int lhist[64], lbase[64], start[64];
+    __shared__ int is_last;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int t = blockIdx.x * 256 + tid;
+    const bool act = t < n_tiles;
+    if (tid < 64) lhist[tid] = 0;
+    __syncthreads();
+    const int b = act ? len_bucket(order_len(t, bins, kmax, long_thresh, small_q16)) : 0;
+    const int lrank = bucket_slot(lhist, b, act);
+    long long walked = 0, listed = 0;
+    if (kmax != nullptr && act) {
+        const int2 r = bins[t];
+        const int len = max(r.y - r.x, 0);
+        listed = len;
+        walked = len > 0 ? min(len, max(0, kmax[2 * t] - r.x + 1)) : 0;
+    }
+    __syncthreads();
+    if (tid < 64) lbase[tid] = lhist[tid] > 0 ? atomicAdd(scratch + tid, lhist[tid]) : 0;
+    if (kmax != nullptr) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            walked += __shfl_xor(walked, d, 64);
+            listed += __shfl_xor(listed, d, 64);
+        }
+        if (lane == 0 && listed > 0) {
+            atomicAdd((unsigned long long *)(scratch + 66), (unsigned long long)walked);
+            atomicAdd((unsigned long long *)(scratch + 68), (unsigned long long)listed);
+        }
+    }
+    __syncthreads();
+    if (act)
+        __hip_atomic_store((g_i32 *)(scratch + ORDER_SCRATCH_HEAD + t), (b << 26) | (lbase[b] + lrank), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the arrival
+    __syncthreads();
+    if (tid == 0) is_last = atomicAdd(scratch + 64, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!is_last) return;
+    // ---- the last workgroup: class totals -> starts (longest class first), then the scatter
+    if (tid < 64) {
+        const int tot = __hip_atomic_load((g_i32 *)(scratch + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int above = tot;           // inclusive suffix sum over classes >= mine, then exclusive
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int u = __shfl_down(above, d, 64);
+            if (lane + d < 64) above += u;
+        }
+        start[tid] = above - tot;
+        const int b_long = long_thresh > 0 ? len_bucket(long_thresh) : 64;
+        if (tid == min(b_long, 63)) order[n_tiles] = b_long < 64 ? above : 0;
+        if (tid == 0) {
+            int stat = 0;
+            if (kmax != nullptr) {
+                const unsigned long long w = __hip_atomic_load((unsigned long long *)(scratch + 66), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long l = __hip_atomic_load((unsigned long long *)(scratch + 68), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT);
+                stat = l ? (int)((1000ull * w) / l) : 0;
+            }
+            order[n_tiles + 1] = stat;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_tiles; i += 256) {
+        const int rec = __hip_atomic_load((g_i32 *)(scratch + ORDER_SCRATCH_HEAD + i), __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+        order[start[rec >> 26] + (rec & ((1 << 26) - 1))] = i;
+    }
+    __syncthreads();
+    if (tid < ORDER_SCRATCH_HEAD) scratch[tid] = 0;       // ready for the next launch (the records are overwritten)
+}
+}  // namespace
+
+SGN_EXPORT size_t sgn_tile_order_scratch_bytes(int n_tiles) {
+    return sizeof(int32_t) * (size_t)(ORDER_SCRATCH_HEAD + (n_tiles > 0 ? n_tiles : 0));
+}
+
 SGN_EXPORT int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_stats, int long_thresh,
-                              int small_q16, int32_t *order, sgn_stream_t stream) {
+                              int small_q16, int32_t *order, void *scratch, size_t scratch_bytes, sgn_stream_t stream) {
     SGN_ARG_CHECK(n_tiles > 0 && tile_bins && order, -1);
+    if (scratch != nullptr && n_tiles < (1 << 26)) {
+        SGN_ARG_CHECK(scratch_bytes >= sgn_tile_order_scratch_bytes(n_tiles), -2);
+        hipLaunchKernelGGL(tile_order_mb_kernel, dim3(sgn_cdiv(n_tiles, 256)), dim3(256), 0, (hipStream_t)stream, n_tiles,
+                           (const int2 *)tile_bins, tile_stats, long_thresh, small_q16, order, (int32_t *)scratch);
+        SGN_LAUNCH_CHECK();
+        return 0;
+    }
     if (n_tiles <= ORDER_PER_THREAD * 1024)
         hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles,
                            (const int2 *)tile_bins, tile_stats, long_thresh, small_q16, order);

@@ -81,7 +81,8 @@ SIGNATURES = {
     "sgn_rows_scatter": (_i, [_i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp]),
     "sgn_rows_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_raster_workspace_bytes": (_sz, [_i, _i64, _vp]),
-    "sgn_tile_order": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp]),
+    "sgn_tile_order_scratch_bytes": (_sz, [_i]),
+    "sgn_tile_order": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "sgn_raster_fwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                             _sz, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),

@@ -18,7 +18,11 @@ from . import _lib as L
 
 
 class Stats:
-    def __init__(self):
+    def __init__(self, group=None):
+        # the process group the statistics are reduced over (:meth:`sync`); None = the default group.  Which rank plays
+        # "first view of the step" below is decided INSIDE that group (a sub-group that does not hold global
+        # rank 0 must still have exactly one rank that counts every Gaussian once).
+        self.group = group
         self.xys_grad_norm: Optional[torch.Tensor] = None
         self.vis_counts: Optional[torch.Tensor] = None
         self.max_2Dsize: Optional[torch.Tensor] = None
@@ -54,12 +58,15 @@ class Stats:
 
     def _is_follower_rank(self) -> bool:
         import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_rank() > 0
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1 and dist.get_rank(self.group) > 0
 
     def sync(self, group=None) -> None:
         from .dp import sync_densify_stats
         if self.xys_grad_norm is not None:
-            sync_densify_stats(self.xys_grad_norm, self.vis_counts, self.max_2Dsize, group=group)
+            sync_densify_stats(self.xys_grad_norm, self.vis_counts, self.max_2Dsize,
+                               group=group if group is not None else self.group)
 
 
 # ======================================================================================================================
@@ -144,7 +151,7 @@ class Densifier:
         # device=self.device)`); "cpu" = on the host and copied over — the same numbers on any device, for
         # trajectory comparisons between a GPU run and a CPU run
         self.rng_device = rng_device
-        self.stats = stats if stats is not None else Stats()
+        self.stats = stats if stats is not None else Stats(group=group)
         self.last_size = (1, 1)
         self.record: Dict[str, float] = {}
 

@@ -79,6 +79,7 @@ class _State:
         self.depth_state = {"want": False, "unused": 0, "cache": None}
         self.depth_caches = collections.OrderedDict()                  # binning key -> first pass's channel + state
         self.early = {"entry": None, "misses": 0, "pause": 0}
+        self.order_scratch: dict = {}  # n_tiles -> persistent zero-filled scratch of the multi-workgroup tile order
 
     # -- binning cache: most recent entry + a short LRU behind it
     def find_binning(self, key):
@@ -128,9 +129,13 @@ def _S() -> _State:
         _have_gpu = torch.cuda.is_available()
     k = (L.current_device(), L.stream_handle()) if _have_gpu else (-1, 0)
     st = _states.get(k)
+    if st is not None:
+        if len(_states) > 1:
+            _states.move_to_end(k)                  # true LRU: the stream in use is the last to be evicted
+        return st
     if st is None:
         st = _states[k] = _State()
-        while len(_states) > _MAX_STATES:          # least recently CREATED goes (its caches are only speed)
+        while len(_states) > _MAX_STATES:          # least recently USED goes (its caches are only speed)
             _, old = _states.popitem(last=False)
             old.clear_binning()
             failed = False                          # deferred argument checks of that stream are settled, not dropped
@@ -825,6 +830,7 @@ binning_stats = {"speculative_hits": 0, "speculative_misses": 0, "binnings": 0}
 
 
 tile_order_enabled = True
+tile_order_multiblock = os.environ.get("SGN_TILE_ORDER_MB", "1") != "0"   # the multi-workgroup form of sgn_tile_order
 concurrent_backward = True   # lend sgn_raster_bwd a second stream: its short-walk and long-walk kernels overlap
 small_splat_q16 = 0       # experimental: > 0 sends tiles with < q/16 evaluated (entry, quadrant) pairs per walked entry to the 4-waves kernel (no gain measured: profiles/r02_street_balance.md)
 
@@ -847,9 +853,18 @@ def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = Non
         return oc[ok][1]
     n_tiles = tile_bins.shape[0]
     order = torch.empty(n_tiles + 2, dtype=torch.int32, device=tile_bins.device)   # permutation, n_long, cursor
-    L.check(L.load().sgn_tile_order(n_tiles, L.ptr(tile_bins), L.ptr(tile_kmax), int(long_thresh),
-                                    int(small_splat_q16) if tile_kmax is not None else 0, L.ptr(order),
-                                    L.stream_ptr()), "sgn_tile_order")
+    lib = L.load()
+    S = _S()
+    scratch = S.order_scratch.get(n_tiles) if tile_order_multiblock else None
+    if scratch is None and tile_order_multiblock:
+        # zero-filled once per (stream, tile count); every launch leaves it zero-filled (include/sgn_rast.h)
+        if len(S.order_scratch) > 8:
+            S.order_scratch.clear()
+        scratch = S.order_scratch[n_tiles] = torch.zeros(int(lib.sgn_tile_order_scratch_bytes(n_tiles)) // 4,
+                                                         dtype=torch.int32, device=tile_bins.device)
+    L.check(lib.sgn_tile_order(n_tiles, L.ptr(tile_bins), L.ptr(tile_kmax), int(long_thresh),
+                               int(small_splat_q16) if tile_kmax is not None else 0, L.ptr(order), L.ptr(scratch),
+                               4 * scratch.numel() if scratch is not None else 0, L.stream_ptr()), "sgn_tile_order")
     if tile_kmax is None:
         oc[ok] = (tile_bins, order)          # (keeps tile_bins alive: its id cannot be recycled while the entry lives)
         while len(oc) > 4:

@@ -397,26 +397,42 @@ def test_tile_order_is_a_permutation_longest_first_and_changes_nothing(hip):
     lens = lens[torch.randperm(lens.numel(), generator=g)]
     start = torch.cumsum(lens, 0) - lens
     bins = torch.stack([start, start + lens], 1).to(torch.int32).to(DEV)
-    order = torch.empty(bins.shape[0] + 2, dtype=torch.int32, device=DEV)
-    L.check(L.load().sgn_tile_order(bins.shape[0], L.ptr(bins), None, 512, 0, L.ptr(order), L.stream_ptr()),
-            "sgn_tile_order")
-    assert int(order[-2]) == int((lens >= 512).sum()) and int(order[-1]) == 0   # n_long (512: class boundary), cursor
-    o = order[:-2].cpu().long()
-    assert torch.equal(torch.sort(o).values, torch.arange(bins.shape[0]))
-    cls = torch.where(lens[o] > 0, 1 + 2 * torch.floor(torch.log2(lens[o].clamp_min(1).double())).long(), 0)
-    assert bool((cls[1:] <= cls[:-1] + 1).all()) and int(lens[o][0]) >= int(lens.max()) // 2
+    lib = L.load()
+    nt = bins.shape[0]
+    scratch = torch.zeros(int(lib.sgn_tile_order_scratch_bytes(nt)) // 4, dtype=torch.int32, device=DEV)
+    # forward's statistics for the backward order: walk depth = half of each list, (entry, quadrant) pairs = 4 per entry
+    kmax = torch.stack([start + lens // 2 - 1, 4 * (lens // 2)], 1).to(torch.int32).to(DEV)
+    walked = torch.where(lens > 0, torch.minimum(lens, (lens // 2).clamp_min(0)), torch.zeros_like(lens))
+    for sc in (None, scratch, scratch):               # single-workgroup form, multi-workgroup form (twice: self-cleaning)
+        for stats in (None, kmax):
+            order = torch.empty(nt + 2, dtype=torch.int32, device=DEV)
+            L.check(lib.sgn_tile_order(nt, L.ptr(bins), L.ptr(stats), 512, 0, L.ptr(order), L.ptr(sc),
+                                       0 if sc is None else 4 * sc.numel(), L.stream_ptr()), "sgn_tile_order")
+            ln = lens if stats is None else walked
+            assert int(order[-2]) == int((ln >= 512).sum())                  # n_long (512 is a class boundary)
+            if stats is None:
+                assert int(order[-1]) == 0
+            else:
+                assert abs(int(order[-1]) - int(1000 * walked.sum() // lens.sum())) <= 1   # walked / listed permille
+            o = order[:-2].cpu().long()
+            assert torch.equal(torch.sort(o).values, torch.arange(nt))
+            cls = torch.where(ln[o] > 0, 1 + 2 * torch.floor(torch.log2(ln[o].clamp_min(1).double())).long(), 0)
+            assert bool((cls[1:] <= cls[:-1] + 1).all()) and int(ln[o][0]) >= int(ln.max()) // 2
+            if sc is not None:
+                assert int(sc[:72].abs().sum()) == 0                       # left zero-filled for the next launch
     cam, raw = scenes.make_scene("c1", device=DEV)
     w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
     res = []
-    for enabled in (True, False):
-        ops.tile_order_enabled = enabled
+    for enabled, mb in ((True, True), (True, False), (False, True)):
+        ops.tile_order_enabled, ops.tile_order_multiblock = enabled, mb
         ops.clear_binning_cache()
         try:
             P = step.leaf_params(raw)
             out = step.train_step(P, cam, w_img, w_a)
             res.append((out.rgb.detach().clone(), out.alpha.detach().clone(), {k: v.grad.clone() for k, v in P.items()}))
         finally:
-            ops.tile_order_enabled = True
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-    for k in res[0][2]:
-        assert rel_l2(res[0][2][k], res[1][2][k]) < 1e-5, k
+            ops.tile_order_enabled = ops.tile_order_multiblock = True
+    for other in res[1:]:
+        assert torch.equal(res[0][0], other[0]) and torch.equal(res[0][1], other[1])
+        for k in res[0][2]:
+            assert rel_l2(res[0][2][k], other[2][k]) < 1e-5, k
