@@ -1162,10 +1162,20 @@ __global__ __launch_bounds__(256) void tile_order_mb_kernel(int n_tiles, const i
         }
     }
     __syncthreads();
-    for (int i = tid; i < n_tiles; i += 256) {
-        const int rec = __hip_atomic_load((g_i32 *)(scratch + ORDER_SCRATCH_HEAD + i), __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
-        order[start[rec >> 26] + (rec & ((1 << 26) - 1))] = i;
+    // sixteen records per thread requested before the first is used: the loop is a chain of L2 round trips otherwise
+    for (int i0 = 0; i0 < n_tiles; i0 += 256 * 16) {
+        int rec[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = i0 + j * 256 + tid;
+            rec[j] = i < n_tiles ? __hip_atomic_load((g_i32 *)(scratch + ORDER_SCRATCH_HEAD + i), __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i = i0 + j * 256 + tid;
+            if (i < n_tiles) order[start[rec[j] >> 26] + (rec[j] & ((1 << 26) - 1))] = i;
+        }
     }
     __syncthreads();
     if (tid < ORDER_SCRATCH_HEAD) scratch[tid] = 0;       // ready for the next launch (the records are overwritten)
