@@ -1130,8 +1130,8 @@ __global__ __launch_bounds__(256) void tile_order_mb_kernel(int n_tiles, const i
     }
     __syncthreads();
     if (act)
-        __hip_atomic_store((g_i32 *)(scratch + ORDER_SCRATCH_HEAD + t), (b << 26) | (lbase[b] + lrank), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((g_i32 *)(scratch + ORDER_SCRATCH_HEAD + t), (int)(((unsigned)b << 26) | (unsigned)(lbase[b] + lrank)),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains before the arrival
     __syncthreads();
     if (tid == 0) is_last = atomicAdd(scratch + 64, 1) == (int)gridDim.x - 1;
@@ -1174,7 +1174,7 @@ __global__ __launch_bounds__(256) void tile_order_mb_kernel(int n_tiles, const i
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int i = i0 + j * 256 + tid;
-            if (i < n_tiles) order[start[rec[j] >> 26] + (rec[j] & ((1 << 26) - 1))] = i;
+            if (i < n_tiles) order[start[(unsigned)rec[j] >> 26] + (rec[j] & ((1 << 26) - 1))] = i;
         }
     }
     __syncthreads();
