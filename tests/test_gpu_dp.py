@@ -81,3 +81,86 @@ def test_exchange_and_reducer_over_single_rank_rccl_group(fused):
             assert rel_l2(Pc[k].grad, Pa[k].grad) < 1e-5, k
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scene_n", [("c1", 5000), ("c1", 40000)])
+def test_walked_list_is_a_superset_of_the_touched_rows(scene_n):
+    """sgn_mark_walked (the row exchange's forward-time announcement): the distinct ids of the entries each tile walked —
+    every Gaussian whose gradient row the backward makes non-zero MUST be in the list (a missing one would be a dropped
+    gradient on the other ranks), the list holds no duplicates, and its length is the count left on the device."""
+    from sgn_rast import _lib as L, ops, scenes, step
+    name, n = scene_n
+    cam, raw = scenes.make_scene(name, n_override=n)
+    cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+    w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+    P = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+    seen = {}
+
+    class Sink:
+        def after_forward(self, ids, tile_bins, tile_kmax, n_full, qmask):
+            lib = L.load()
+            stamps = torch.zeros(n_full, dtype=torch.int32, device=DEV)
+            lst = torch.full((n_full,), -1, dtype=torch.int32, device=DEV)
+            count = torch.zeros(1, dtype=torch.int32, device=DEV)
+            for epoch in (5, 6):                     # a second epoch over the same stamps: no clearing pass needed
+                L.check(lib.sgn_mark_walked(tile_bins.shape[0], L.ptr(ids), L.ptr(tile_bins), L.ptr(tile_kmax), int(qmask),
+                                            epoch, L.ptr(stamps), L.ptr(lst), L.ptr(count), L.stream_ptr()), "mark")
+                seen[epoch] = (lst.clone(), int(count.item()))
+    ops._touch_sink = Sink()
+    try:
+        ops.clear_binning_cache()
+        step.train_step(P, cam, w_img, w_a)
+    finally:
+        ops._touch_sink = None
+    torch.cuda.synchronize()
+    touched = ((P["opacity_logits"].grad.reshape(n) != 0) | (P["means"].grad != 0).any(1) | (P["quats"].grad != 0).any(1)
+               | (P["log_scales"].grad != 0).any(1) | (P["features_dc"].grad.reshape(n, 3) != 0).any(1)
+               | (P["features_rest"].grad.reshape(n, -1) != 0).any(1))
+    assert int(touched.sum()) > 100
+    for epoch, (lst, count) in seen.items():
+        ids = lst[:count].long()
+        assert count > 0 and int(ids.min()) >= 0 and int(ids.max()) < n and int((lst[count:] != -1).sum()) == 0
+        assert ids.unique().numel() == count, "duplicates in the walked list"
+        listed = torch.zeros(n, dtype=torch.bool, device=DEV)
+        listed[ids] = True
+        assert int((touched & ~listed).sum()) == 0, "a touched row is missing from the walked list"
+        assert count <= int(touched.sum()) * 3 + 64, (count, int(touched.sum()))     # ... and it is not a loose superset
+
+
+def test_row_exchange_over_single_rank_rccl_group():
+    """`GradAllReducer(sparse=True)` on the real kernels over a 1-rank RCCL group: the walked list from the forward, the
+    announcement on its side stream, sgn_rows_pack / all_gather / sgn_rows_scatter, the SH rebuild — gradients equal the
+    plain single-process step's, untouched rows are exact zeros, and content that touches too many rows takes the dense
+    sequence."""
+    import torch.distributed as dist
+    from sgn_rast import dp, ops, scenes, step
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        for n, frac, expect in ((40000, 0.9, "sparse"), (3000, 0.05, "dense")):
+            cam, raw = scenes.make_scene("c1", n_override=n)
+            cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+            w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+            Pa = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+            ops.clear_binning_cache()
+            step.train_step(Pa, cam, w_img, w_a)
+            Pb = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+            ex = dp.SHGradExchange(Pb["features_dc"], Pb["features_rest"], force=True).install().set_view(Pb["means"], cam.cam_pos)
+            red = dp.GradAllReducer(list(Pb.values()), big=[Pb["features_rest"]], sh_exchange=ex, force=True, sparse=True,
+                                    sparse_max_fraction=frac)
+            try:
+                assert ops._touch_sink is red
+                for _ in range(2):                                  # twice: persistent buffers, epochs, pinned slots
+                    ops.clear_binning_cache()
+                    step.train_step(Pb, cam, w_img, w_a, reducer=red)
+            finally:
+                ex.remove()
+                red.remove()
+            assert ops._touch_sink is None
+            torch.cuda.synchronize()
+            assert red.stats[expect + "_steps"] == 2, (n, red.stats)
+            for k in Pa:
+                assert rel_l2(Pb[k].grad, Pa[k].grad) < 1e-5, (n, k)
+                assert torch.equal(Pb[k].grad.reshape(n, -1).abs().sum(1) == 0, Pa[k].grad.reshape(n, -1).abs().sum(1) == 0), k
+    finally:
+        dist.destroy_process_group()
