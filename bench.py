@@ -316,8 +316,10 @@ def main():
             # the harness knows its camera: gather 12 B of camera position instead of [N,3] view directions
             ex = dp.SHGradExchange(P["features_dc"], P["features_rest"], force=force_dp).install().set_view(
                 P["means"], cam.cam_pos)
-        return dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex, force=force_dp,
+        red_ = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], sh_exchange=ex, force=force_dp,
                                  overlap=not args.no_dp_overlap, sparse=args.dp_exchange == "rows")
+        red_.timing = True       # device events around the waits for collectives: `exposed_comm_ms` in the line
+        return red_
 
     # N > 1: the plain exchange is measured first and its line kept; the optimised exchange must then run, agree with it
     # and finish, or the kept line is what rank 0 prints (no RCCL run of either has ever been possible before the
@@ -609,11 +611,10 @@ def main():
     c4_extra = None
     if (world > 1 or force_dp) and args.scene == "metric" and sg is None and sky is None and not args.no_c4_extra \
             and not args.street and not args.translucent and not args.n:
+        from sgn_rast import fused as fused_
         keep = (P, cam, w_img, w_a, reducer, ring)
-        if reducer is not None:
-            if reducer.sh_exchange is not None:
-                reducer.sh_exchange.remove()
-            reducer.remove()
+        hooks = (ops._sh_exchange, fused_._sh_exchange, ops._touch_sink)      # the kept reducer's taps: put aside
+        ops._sh_exchange = fused_._sh_exchange = ops._touch_sink = None
         cam, raw4 = scenes.make_scene("c4", seed=0, yaw=0.01 * rank, device=dev)
         P = step.leaf_params(raw4)
         del raw4
@@ -625,12 +626,12 @@ def main():
         c4_extra = timed_variant()
         c4_extra["workload"] = f"c4: {P['means'].shape[0]} Gaussians, {cam.width}x{cam.height}, SH deg 3, fwd+bwd"
         c4_extra["reducer_stats"] = dict(reducer.stats)
+        c4_extra["exposed_comm_ms"] = reducer.exposed_ms()
         if reducer.sh_exchange is not None:
             reducer.sh_exchange.remove()
         reducer.remove()
         P, cam, w_img, w_a, reducer, ring = keep
-        if reducer is not None and reducer.sh_exchange is not None:
-            reducer.sh_exchange.install()
+        ops._sh_exchange, fused_._sh_exchange, ops._touch_sink = hooks
         ops.clear_binning_cache()
 
     # forward only (eval / render): what `scripts/eval.py:98-112` times per eval image — get_outputs_for_camera under
@@ -787,7 +788,10 @@ def main():
                                     "collective_timeout_s": dp.DEFAULT_TIMEOUT_S, "watchdog_s": args.dp_watchdog,
                                     "visible_devices": torch.cuda.device_count(),
                                     "peer_access": dp.peer_access_matrix(),
-                                    "reducer_stats": dict(reducer.stats) if reducer is not None else None}
+                                    "reducer_stats": dict(reducer.stats) if reducer is not None else None,
+                                    # mean device time per step the compute stream waited for each collective (events
+                                    # on the compute stream around the waits): the EXPOSED communication
+                                    "exposed_comm_ms": reducer.exposed_ms() if reducer is not None else None}
             if dp_paths is not None:
                 # both exchanges were measured, the plain one first (kept as the fallback line while the other ran)
                 line["config"]["dp"]["paths"] = dp_paths

@@ -173,6 +173,22 @@ int sgn_sh_bwd_fused(int n, int k, int degree, const float *means, const float *
                      const int32_t *object_ids, const float *idft, const float *poses, int post_half_clamp,
                      const float *colors, const float *v_colors, float *v_features_dc, float *v_features_rest, sgn_stream_t stream);
 
+/* The fused SH front end over UN-CONCATENATED sub-models (round 4; the scene graph keeps one features_dc /
+ * features_rest parameter per sub-model: sgn_splatfacto_scene_graph.py:355-360 concatenates them every step, 180 MB each
+ * way at 1 M Gaussians).  n_parts <= 32 parts in aggregated order; the four HOST arrays hold, per part: its rows, its
+ * Fourier dimension (1..16), device pointers to features_dc [rows, F, 3] and features_rest [rows, k-1, 3].  means /
+ * colors / v_colors are the aggregated [N,3] arrays (N = sum of rows); the part index is the object index: pose row
+ * (poses [n_parts,16], NULL = no rigid transform) and idft row (idft [n_parts, idft_stride]).  The backward writes each
+ * part's gradients into that part's own arrays (v_features_*_host). */
+int sgn_sh_fwd_parts(int n_parts, const int32_t *rows_host, const int32_t *n_fourier_host,
+                     const float *const *features_dc_host, const float *const *features_rest_host, int k, int degree,
+                     const float *means, const float *cam_pos3, const float *idft, int idft_stride, const float *poses,
+                     int post_half_clamp, float *colors, sgn_stream_t stream);
+int sgn_sh_bwd_parts(int n_parts, const int32_t *rows_host, const int32_t *n_fourier_host, int k, int degree,
+                     const float *means, const float *cam_pos3, const float *idft, int idft_stride, const float *poses,
+                     int post_half_clamp, const float *colors, const float *v_colors, float *const *v_features_dc_host,
+                     float *const *v_features_rest_host, sgn_stream_t stream);
+
 /* Data-parallel SH gradient: v_coeffs[n,k,c] = scale * sum_r basis_k(dir_{r,n}) * v_colors_all[r,n,c]
  * over the n_views ranks' all-gathered colour gradients.  Directions come either from viewdirs_all [R,n,3]
  * (drop-in path) or from means [n,3] (+ optional object_ids/poses) and cam_pos_all [R,3] (fused path); exactly one

@@ -197,9 +197,14 @@ EDITS_SG = [
      "                object_quats.append(obj_model.quats)\n"
      "                sgn_poses.append((anno.rot, anno.center, quaternion_from_matrix(anno.rot)))\n"),
     ("        self.features_dc = torch.cat([self.background_model.features_dc, *object_features_dc], dim=0)\n",
-     "        self.features_dc = sgn_fused.cat_features_dc([self.background_model.features_dc, *object_features_dc])\n"
+     "        # sgn_fused: the SH coefficients stay one tensor per sub-model (sgn_sh_fwd_parts reads them where they are)\n"
+     "        self.features_dc = ((self.background_model.features_dc, *object_features_dc) if self.config.sh_degree > 0\n"
+     "                            else sgn_fused.cat_features_dc([self.background_model.features_dc, *object_features_dc]))\n"
      "        self.sgn_tables = sgn_fused.scene_graph_tables(\n"
      "            [self.background_model.num_points] + [m.shape[0] for m in object_means], sgn_poses, sgn_idft, self.device)\n"),
+    ("        self.features_rest = self.get_aggreated_variable(\"features_rest\")\n",
+     "        self.features_rest = (tuple(self.all_models[name].features_rest for name in self.visible_model_names)\n"
+     "                              if self.config.sh_degree > 0 else self.get_aggreated_variable(\"features_rest\"))\n"),
 ]
 
 

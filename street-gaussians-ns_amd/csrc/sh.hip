@@ -347,6 +347,146 @@ __global__ __launch_bounds__(WAVES * 64) void sh_bwd_fused_kernel(
     }
 }
 
+// ---- fused SH over UN-CONCATENATED sub-models (round 4) ---------------------------------------------------------------
+// The scene graph keeps one `features_dc` / `features_rest` parameter per sub-model (background F = 1, objects
+// F = fourier_features_dim); the fused front end above still wanted ONE [N,F,3] / [N,K-1,3] tensor, i.e. the caller's
+// `torch.cat` (180 MB read + 180 MB write per step at 1 M Gaussians for features_rest, a zero-padded copy for
+// features_dc) and autograd's split of the gradient on the way back.  Here the kernel takes the sub-models as they are:
+// a by-value table of up to 32 parts (rows, first row in the aggregated order, pointers, Fourier dimension), the grid is
+// the concatenation of the parts' own spans of 64 rows (a wave never straddles two parts), the part index IS the object
+// index (pose row / idft row), and the backward writes each part's gradients into that part's own tensors.
+constexpr int SH_MAX_PARTS = 32;
+struct ShParts {
+    int n_parts;
+    int span0[SH_MAX_PARTS + 1];        // first 64-row span of part p in the grid; span0[n_parts] = total spans
+    int row0[SH_MAX_PARTS];             // first row of part p in the aggregated (means / colours) order
+    int rows[SH_MAX_PARTS];
+    int F[SH_MAX_PARTS];
+    const float *dc[SH_MAX_PARTS];      // [rows, F, 3]
+    const float *rest[SH_MAX_PARTS];    // [rows, K-1, 3]
+    float *v_dc[SH_MAX_PARTS];
+    float *v_rest[SH_MAX_PARTS];
+};
+
+__device__ __forceinline__ int sh_part_of(const ShParts &P, int span) {
+    int p = 0;
+    while (p + 1 < P.n_parts && span >= P.span0[p + 1]) ++p;
+    return p;
+}
+
+template <int K, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sh_fwd_parts_kernel(
+    ShParts P, int deg, const float *__restrict__ means, const float *__restrict__ cam_pos,
+    const float *__restrict__ idft, int idft_stride, const float *__restrict__ poses, int post,
+    float *__restrict__ colors) {
+    constexpr int KC = (K - 1) * 3, LS = (KC | 1);
+    __shared__ float lds[WAVES][64 * (KC > 0 ? LS : 1)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int span = blockIdx.x * WAVES + wave;
+    const bool live = span < P.span0[P.n_parts];
+    const int p = live ? sh_part_of(P, span) : 0;
+    const int r0 = live ? (span - P.span0[p]) * 64 : 0;           // first row of the span INSIDE its part
+    const int cnt = live ? max(0, min(64, P.rows[p] - r0)) : 0;
+    float *my = lds[wave];
+    if constexpr (KC > 0) stage_rows<KC, LS>(my, P.rest[p] + (size_t)r0 * KC, cnt, lane);
+    __syncthreads();
+    if (lane >= cnt) return;
+    const int r = r0 + lane, i = P.row0[p] + r;
+    float b[25];
+    float m0 = means[3 * i], m1 = means[3 * i + 1], m2 = means[3 * i + 2];
+    if (poses != nullptr) {                                      // local -> world (scene_graph.py:414); row p
+        const float *Q = poses + 16 * (size_t)p;
+        const float w0 = Q[0] * m0 + Q[1] * m1 + Q[2] * m2 + Q[9];
+        const float w1 = Q[3] * m0 + Q[4] * m1 + Q[5] * m2 + Q[10];
+        const float w2 = Q[6] * m0 + Q[7] * m1 + Q[8] * m2 + Q[11];
+        m0 = w0; m1 = w1; m2 = w2;
+    }
+    const int nb = sh_bases(m0 - cam_pos[0], m1 - cam_pos[1], m2 - cam_pos[2], deg, b);
+    const int F = P.F[p];
+    const float *w = idft + (size_t)p * idft_stride;
+    const float *dc = P.dc[p] + (size_t)r * F * 3;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int f = 0; f < F; ++f) {
+        const float wf = w[f];
+        d0 += dc[3 * f] * wf; d1 += dc[3 * f + 1] * wf; d2 += dc[3 * f + 2] * wf;
+    }
+    float a0 = b[0] * d0, a1 = b[0] * d1, a2 = b[0] * d2;
+    if constexpr (KC > 0) {
+        const float *row = my + lane * LS;
+#pragma unroll
+        for (int k = 1; k < K; ++k) {
+            if (k < nb) {
+                a0 += b[k] * row[3 * (k - 1)];
+                a1 += b[k] * row[3 * (k - 1) + 1];
+                a2 += b[k] * row[3 * (k - 1) + 2];
+            }
+        }
+    }
+    if (post) { a0 = fmaxf(a0 + 0.5f, 0.f); a1 = fmaxf(a1 + 0.5f, 0.f); a2 = fmaxf(a2 + 0.5f, 0.f); }
+    colors[3 * i] = a0; colors[3 * i + 1] = a1; colors[3 * i + 2] = a2;
+}
+
+template <int K, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void sh_bwd_parts_kernel(
+    ShParts P, int deg, const float *__restrict__ means, const float *__restrict__ cam_pos,
+    const float *__restrict__ idft, int idft_stride, const float *__restrict__ poses, int post,
+    const float *__restrict__ colors, const float *__restrict__ v_colors) {
+    constexpr int KC = (K - 1) * 3, LS = (KC | 1);
+    __shared__ float lds[WAVES][64 * (KC > 0 ? LS : 1)];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int span = blockIdx.x * WAVES + wave;
+    const bool live = span < P.span0[P.n_parts];
+    const int p = live ? sh_part_of(P, span) : 0;
+    const int r0 = live ? (span - P.span0[p]) * 64 : 0;
+    const int cnt = live ? max(0, min(64, P.rows[p] - r0)) : 0;
+    float *my = lds[wave];
+    if (lane < cnt) {
+        const int r = r0 + lane, i = P.row0[p] + r;
+        float b[25];
+        float m0 = means[3 * i], m1 = means[3 * i + 1], m2 = means[3 * i + 2];
+        if (poses != nullptr) {
+            const float *Q = poses + 16 * (size_t)p;
+            const float w0 = Q[0] * m0 + Q[1] * m1 + Q[2] * m2 + Q[9];
+            const float w1 = Q[3] * m0 + Q[4] * m1 + Q[5] * m2 + Q[10];
+            const float w2 = Q[6] * m0 + Q[7] * m1 + Q[8] * m2 + Q[11];
+            m0 = w0; m1 = w1; m2 = w2;
+        }
+        const int nb = sh_bases(m0 - cam_pos[0], m1 - cam_pos[1], m2 - cam_pos[2], deg, b);
+        float v0 = v_colors[3 * i], v1 = v_colors[3 * i + 1], v2 = v_colors[3 * i + 2];
+        if (post) {  // clamp(x + 0.5, min=0): gradient passes where the output is positive
+            v0 = colors[3 * i] > 0.f ? v0 : 0.f;
+            v1 = colors[3 * i + 1] > 0.f ? v1 : 0.f;
+            v2 = colors[3 * i + 2] > 0.f ? v2 : 0.f;
+        }
+        const int F = P.F[p];
+        const float *w = idft + (size_t)p * idft_stride;
+        float *vd = P.v_dc[p] + (size_t)r * F * 3;
+        for (int f = 0; f < F; ++f) {
+            const float wf = w[f] * b[0];
+            vd[3 * f] = wf * v0; vd[3 * f + 1] = wf * v1; vd[3 * f + 2] = wf * v2;
+        }
+        if constexpr (KC > 0) {
+            float *row = my + lane * LS;
+#pragma unroll
+            for (int k = 1; k < K; ++k) {
+                const float bk = (k < nb) ? b[k] : 0.f;
+                row[3 * (k - 1)] = bk * v0; row[3 * (k - 1) + 1] = bk * v1; row[3 * (k - 1) + 2] = bk * v2;
+            }
+        }
+    }
+    __syncthreads();
+    if constexpr (KC > 0) {
+        if (cnt > 0) {
+            float *dst = P.v_rest[p] + (size_t)r0 * KC;
+            const int total = cnt * KC;
+            for (int e = lane; e < total; e += 64) {
+                const int r = e / KC, c = e - r * KC;
+                dst[e] = my[r * LS + c];
+            }
+        }
+    }
+}
+
 // ---- multi-view SH backward for data-parallel training ---------------------------------
 // v_coeffs[n,k,c] = sum_r basis_k(dir_{r,n}) * v_colors[r,n,c]: the SH gradient of ONE view is a rank-1 outer
 // product (K bases x 3 channels) of two things that are tiny on the wire — the 3-float colour gradient and the
@@ -638,6 +778,107 @@ SGN_EXPORT int sgn_fourier_dc_bwd(int n_parts, const int32_t *row0_host, const i
         hipLaunchKernelGGL(fourier_dc_bwd_kernel, dim3(sgn_cdiv(P.cum[P.n_parts], 256)), dim3(256), 0,
                            (hipStream_t)stream, P, v_dc_eff);
     }
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fused SH over un-concatenated sub-models: entry points
+namespace {
+static int fill_parts(ShParts &P, int n_parts, const int32_t *rows_host, const int32_t *n_fourier_host,
+                      const float *const *dc_host, const float *const *rest_host, float *const *v_dc_host,
+                      float *const *v_rest_host, int k, bool backward) {
+    if (n_parts < 1 || n_parts > SH_MAX_PARTS || !rows_host || !n_fourier_host || !dc_host) return -1;
+    P.n_parts = n_parts;
+    int span = 0, row = 0;
+    for (int p = 0; p < n_parts; ++p) {
+        if (rows_host[p] < 0 || n_fourier_host[p] < 1 || n_fourier_host[p] > 16) return -2;
+        P.span0[p] = span; P.row0[p] = row; P.rows[p] = rows_host[p]; P.F[p] = n_fourier_host[p];
+        P.dc[p] = backward ? nullptr : dc_host[p];
+        P.rest[p] = (backward || k == 1) ? nullptr : rest_host[p];
+        P.v_dc[p] = backward ? v_dc_host[p] : nullptr;
+        P.v_rest[p] = (backward && k > 1) ? v_rest_host[p] : nullptr;
+        if (rows_host[p] > 0) {
+            if (!backward && (!dc_host[p] || (k > 1 && !rest_host[p]))) return -3;
+            if (backward && (!v_dc_host[p] || (k > 1 && !v_rest_host[p]))) return -3;
+        }
+        span += (rows_host[p] + 63) / 64;
+        row += rows_host[p];
+    }
+    P.span0[n_parts] = span;
+    for (int p = n_parts; p < SH_MAX_PARTS; ++p) { P.row0[p] = 0; P.rows[p] = 0; P.F[p] = 1; P.dc[p] = P.rest[p] = nullptr; P.v_dc[p] = P.v_rest[p] = nullptr; }
+    for (int p = n_parts + 1; p <= SH_MAX_PARTS; ++p) P.span0[p] = span;
+    return span;
+}
+template <int K>
+static void launch_fwd_parts(const ShParts &P, int spans, int deg, const float *means, const float *cam, const float *idft,
+                             int stride, const float *poses, int post, float *colors, hipStream_t s) {
+    constexpr int WAVES = (K > 16) ? 2 : 4;
+    hipLaunchKernelGGL((sh_fwd_parts_kernel<K, WAVES>), dim3(sgn_cdiv(spans, WAVES)), dim3(WAVES * 64), 0, s, P, deg, means,
+                       cam, idft, stride, poses, post, colors);
+}
+template <int K>
+static void launch_bwd_parts(const ShParts &P, int spans, int deg, const float *means, const float *cam, const float *idft,
+                             int stride, const float *poses, int post, const float *colors, const float *v_colors,
+                             hipStream_t s) {
+    constexpr int WAVES = (K > 16) ? 2 : 4;
+    hipLaunchKernelGGL((sh_bwd_parts_kernel<K, WAVES>), dim3(sgn_cdiv(spans, WAVES)), dim3(WAVES * 64), 0, s, P, deg, means,
+                       cam, idft, stride, poses, post, colors, v_colors);
+}
+}  // namespace
+
+SGN_EXPORT int sgn_sh_fwd_parts(int n_parts, const int32_t *rows_host, const int32_t *n_fourier_host,
+                                const float *const *features_dc_host, const float *const *features_rest_host, int k,
+                                int degree, const float *means, const float *cam_pos3, const float *idft,
+                                int idft_stride, const float *poses, int post_half_clamp, float *colors,
+                                sgn_stream_t stream) {
+    SGN_ARG_CHECK(degree >= 0 && degree <= 4, -2);
+    SGN_ARG_CHECK(k == 1 || k == 4 || k == 9 || k == 16 || k == 25, -3);
+    SGN_ARG_CHECK((degree + 1) * (degree + 1) <= k, -4);
+    SGN_ARG_CHECK(means && cam_pos3 && idft && colors && idft_stride >= 1 && (k == 1 || features_rest_host), -6);
+    ShParts P;
+    const int spans = fill_parts(P, n_parts, rows_host, n_fourier_host, features_dc_host, features_rest_host, nullptr, nullptr,
+                                 k, false);
+    SGN_ARG_CHECK(spans >= 0, -7);
+    if (spans == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    sgn_timing_begin(SGN_T_SH_FWD, s);
+    switch (k) {
+        case 1: launch_fwd_parts<1>(P, spans, degree, means, cam_pos3, idft, idft_stride, poses, post_half_clamp, colors, s); break;
+        case 4: launch_fwd_parts<4>(P, spans, degree, means, cam_pos3, idft, idft_stride, poses, post_half_clamp, colors, s); break;
+        case 9: launch_fwd_parts<9>(P, spans, degree, means, cam_pos3, idft, idft_stride, poses, post_half_clamp, colors, s); break;
+        case 16: launch_fwd_parts<16>(P, spans, degree, means, cam_pos3, idft, idft_stride, poses, post_half_clamp, colors, s); break;
+        default: launch_fwd_parts<25>(P, spans, degree, means, cam_pos3, idft, idft_stride, poses, post_half_clamp, colors, s); break;
+    }
+    sgn_timing_end(SGN_T_SH_FWD, s);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_sh_bwd_parts(int n_parts, const int32_t *rows_host, const int32_t *n_fourier_host, int k, int degree,
+                                const float *means, const float *cam_pos3, const float *idft, int idft_stride,
+                                const float *poses, int post_half_clamp, const float *colors, const float *v_colors,
+                                float *const *v_features_dc_host, float *const *v_features_rest_host,
+                                sgn_stream_t stream) {
+    SGN_ARG_CHECK(degree >= 0 && degree <= 4, -2);
+    SGN_ARG_CHECK(k == 1 || k == 4 || k == 9 || k == 16 || k == 25, -3);
+    SGN_ARG_CHECK((degree + 1) * (degree + 1) <= k, -4);
+    SGN_ARG_CHECK(means && cam_pos3 && idft && colors && v_colors && v_features_dc_host && idft_stride >= 1 &&
+                      (k == 1 || v_features_rest_host), -6);
+    ShParts P;
+    const int spans = fill_parts(P, n_parts, rows_host, n_fourier_host, nullptr, nullptr, v_features_dc_host,
+                                 v_features_rest_host, k, true);
+    SGN_ARG_CHECK(spans >= 0, -7);
+    if (spans == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    sgn_timing_begin(SGN_T_SH_BWD, s);
+    switch (k) {
+        case 1: launch_bwd_parts<1>(P, spans, degree, means, cam_pos3, idft, idft_stride, poses, post_half_clamp, colors, v_colors, s); break;
+        case 4: launch_bwd_parts<4>(P, spans, degree, means, cam_pos3, idft, idft_stride, poses, post_half_clamp, colors, v_colors, s); break;
+        case 9: launch_bwd_parts<9>(P, spans, degree, means, cam_pos3, idft, idft_stride, poses, post_half_clamp, colors, v_colors, s); break;
+        case 16: launch_bwd_parts<16>(P, spans, degree, means, cam_pos3, idft, idft_stride, poses, post_half_clamp, colors, v_colors, s); break;
+        default: launch_bwd_parts<25>(P, spans, degree, means, cam_pos3, idft, idft_stride, poses, post_half_clamp, colors, v_colors, s); break;
+    }
+    sgn_timing_end(SGN_T_SH_BWD, s);
     SGN_LAUNCH_CHECK();
     return 0;
 }

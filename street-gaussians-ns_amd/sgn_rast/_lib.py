@@ -38,6 +38,8 @@ SIGNATURES = {
     "sgn_fourier_dc_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_sh_fwd_fused": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sgn_sh_bwd_fused": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_sh_fwd_parts": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "sgn_sh_bwd_parts": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "sgn_cube_texture_fwd": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_cube_texture_bwd": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_sky_fwd": (_i, [_i, _i, _f, _f, _f, _f, _vp, _i, _vp, _i, _i, _vp, _vp, _vp]),

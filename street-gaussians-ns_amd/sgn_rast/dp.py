@@ -175,8 +175,15 @@ class GradAllReducer:
         self._hooks = []
         self.stats = {"bucket_early": 0, "bucket_late": 0, "sparse_steps": 0, "dense_steps": 0,
                       "touched_fraction": None, "rows_sent": 0}
+        # timing=True (bench.py): device events around the waits for the step's collectives, so the line can say how much
+        # communication the compute stream was actually held up by (`exposed_ms()`); two event records per wait
+        self.timing = False
+        self._spans = []                # (label, start event, end event) not yet read
+        self._exposed = {}              # label -> [sum ms, count]
         self._early = None              # (count event state) of this step's forward-time announcement
         self._mark = None               # persistent device buffers of sgn_mark_walked
+        if sh_exchange is not None:
+            sh_exchange._span_fn = self._span
         if self.sparse:
             self.overlap = False        # the row exchange replaces the bucket and the early all-gathers
             if self.active and sh_exchange.dc.is_cuda:
@@ -206,6 +213,37 @@ class GradAllReducer:
         work = dist.all_reduce(flat, op=self._op, group=self.group, async_op=True)
         self._bucket = (flat, work, [p.grad._version for p in self.small])
         self.stats["bucket_early" if early else "bucket_late"] += 1
+
+    # ------------------------------------------------------------------- exposed-communication timing
+    def _span(self, label: str):
+        """Context manager: device time the current stream spends inside the block (a wait for a collective)."""
+        reducer = self
+
+        class _Span:
+            def __enter__(self_inner):
+                self_inner.on = reducer.timing and torch.cuda.is_available() and reducer.active
+                if self_inner.on:
+                    self_inner.a = torch.cuda.Event(enable_timing=True)
+                    self_inner.a.record()
+                return self_inner
+
+            def __exit__(self_inner, *exc):
+                if self_inner.on:
+                    b = torch.cuda.Event(enable_timing=True)
+                    b.record()
+                    reducer._spans.append((label, self_inner.a, b))
+                return False
+        return _Span()
+
+    def exposed_ms(self) -> dict:
+        """{label: mean ms per step the compute stream waited for that collective} (synchronises the recorded events)."""
+        for label, a, b in self._spans:
+            b.synchronize()
+            acc = self._exposed.setdefault(label, [0.0, 0])
+            acc[0] += a.elapsed_time(b)
+            acc[1] += 1
+        self._spans = []
+        return {k: v[0] / max(v[1], 1) for k, v in self._exposed.items()}
 
     # ------------------------------------------------------------------- the compacted row exchange (round 4)
     def after_forward(self, ids, tile_bins, tile_kmax, n, qmask) -> None:
@@ -366,7 +404,8 @@ class GradAllReducer:
         got = _all_gather_sync(send, self.group, wait=False)            # [world, 1 + maxc, 1 + W]
         pending = [(dist.all_reduce(p.grad if p.grad is not None else _zero_grad(p), op=self._op, group=self.group,
                                     async_op=True), p) for p in other]
-        got = got()                                                     # wait (stream-ordered on RCCL)
+        with self._span("rows_all_gather"):
+            got = got()                                                 # wait (stream-ordered on RCCL)
         v_all = torch.zeros(self.world, n, 3, dtype=torch.float32, device=dev)
         if hip:
             flat = torch.zeros(n * sum(widths), dtype=torch.float32, device=dev)       # one fill for every dense sum
@@ -435,7 +474,8 @@ class GradAllReducer:
             if any(p.grad._version != v for p, v in zip(self.small, versions)):
                 raise RuntimeError("GradAllReducer(overlap=True): a gradient changed after its bucket had left — more "
                                    "than one backward pass between two finish() calls; use overlap=False")
-            work.wait()
+            with self._span("bucket_all_reduce"):
+                work.wait()
             if self.average and not self._avg_in_collective:
                 flat /= self.world
             off = 0
@@ -443,8 +483,10 @@ class GradAllReducer:
                 n = p.grad.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
+        with self._span("big_all_reduces"):
+            for w, p in pending:
+                w.wait()
         for w, p in pending:
-            w.wait()
             if self.average and not self._avg_in_collective:
                 p.grad /= self.world
 
@@ -701,8 +743,14 @@ class SHGradExchange:
                 if leaf.grad is None:
                     leaf.grad = torch.zeros_like(leaf)
                 dense.append(dist.all_reduce(leaf.grad, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in self._works:
-            w.wait()
+        span = getattr(self, "_span_fn", None)
+        if span is not None:
+            with span("sh_all_gathers"):
+                for w in self._works:
+                    w.wait()
+        else:
+            for w in self._works:
+                w.wait()
         self._works.clear()
         low = None
         if c is not None:

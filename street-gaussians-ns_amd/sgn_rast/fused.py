@@ -234,6 +234,58 @@ class _SHFused(Function):
         return None, None, None, v_dc, v_rest, None, None, None, None, None
 
 
+SH_MAX_PARTS = 32
+
+
+class _SHFusedParts(Function):
+    """spherical_harmonics_fused over UN-concatenated sub-models: ``parts`` = dc_0..dc_{m-1}, rest_0..rest_{m-1}."""
+    @staticmethod
+    def forward(ctx, degree, means, cam_pos, idft, poses, post, m, *parts):
+        import ctypes as C
+        dcs, rests = parts[:m], parts[m:]
+        dev = L.require_device(means, cam_pos, idft, poses, *parts)
+        k = 1 + rests[0].shape[1]
+        rows = [int(d.shape[0]) for d in dcs]
+        Fs = [int(d.shape[1]) for d in dcs]
+        n = sum(rows)
+        assert means.shape[0] == n and all(r.shape[0] == c and r.shape[1] == k - 1 for r, c in zip(rests, rows))
+        means_c, cam_c = _f32c(means), _f32c(cam_pos).reshape(-1)[:3].contiguous()
+        idft_c = _f32c(idft)
+        assert idft_c.dim() == 2 and idft_c.shape[0] == m and idft_c.shape[1] >= max(Fs)
+        pos = _f32c(poses) if poses is not None else None
+        dcs_c, rests_c = [_f32c(d) for d in dcs], [_f32c(r) for r in rests]
+        colors = torch.empty(n, 3, dtype=torch.float32, device=dev)
+        i32s, ptrs = C.c_int32 * m, C.c_void_p * m
+        ctx.rows_a, ctx.F_a = i32s(*rows), i32s(*Fs)
+        L.check(L.load().sgn_sh_fwd_parts(m, ctx.rows_a, ctx.F_a, ptrs(*[t.data_ptr() for t in dcs_c]),
+                                          ptrs(*[t.data_ptr() for t in rests_c]), k, int(degree), L.ptr(means_c),
+                                          L.ptr(cam_c), L.ptr(idft_c), int(idft_c.shape[1]), L.ptr(pos), int(bool(post)),
+                                          L.ptr(colors), L.stream_ptr()), "sgn_sh_fwd_parts")
+        ctx.meta = (int(degree), k, m, int(bool(post)), [tuple(d.shape) for d in dcs], [tuple(r.shape) for r in rests])
+        ctx.has_pose = pos is not None
+        ctx.save_for_backward(means_c, cam_c, idft_c, colors, *([pos] if pos is not None else []))
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        import ctypes as C
+        degree, k, m, post, dc_shapes, rest_shapes = ctx.meta
+        if v_colors is None:
+            return (None,) * (7 + 2 * m)
+        saved = ctx.saved_tensors
+        means, cam, idft, colors = saved[:4]
+        pos = saved[4] if ctx.has_pose else None
+        f32 = dict(dtype=torch.float32, device=means.device)
+        v_dc = [torch.empty(sh, **f32) for sh in dc_shapes]
+        v_rest = [torch.empty(sh, **f32) for sh in rest_shapes]
+        ptrs = C.c_void_p * m
+        L.check(L.load().sgn_sh_bwd_parts(m, ctx.rows_a, ctx.F_a, k, degree, L.ptr(means), L.ptr(cam), L.ptr(idft),
+                                          int(idft.shape[1]), L.ptr(pos), post, L.ptr(colors), L.ptr(_f32c(v_colors)),
+                                          ptrs(*[t.data_ptr() for t in v_dc]), ptrs(*[t.data_ptr() for t in v_rest]),
+                                          L.stream_ptr()), "sgn_sh_bwd_parts")
+        return (None,) * 7 + tuple(v_dc) + tuple(v_rest)
+
+
 def spherical_harmonics_fused(degrees_to_use: int, means, cam_pos, features_dc, features_rest,
                               object_ids: Optional[torch.Tensor] = None, idft: Optional[torch.Tensor] = None,
                               poses: Optional[torch.Tensor] = None, post_half_clamp: bool = True) -> torch.Tensor:
@@ -242,6 +294,23 @@ def spherical_harmonics_fused(degrees_to_use: int, means, cam_pos, features_dc, 
     the colour post-processing in one pass; with ``poses`` the means are LOCAL and moved to the world frame
     in-kernel (no gradient to ``means``, as in the reference: ``.detach()``
     at sgn_splatfacto.py:934)."""
+    if isinstance(features_dc, (list, tuple)):
+        # un-concatenated sub-models (round 4): one features_dc [n_p, F_p, 3] / features_rest [n_p, K-1, 3] pair per
+        # sub-model in aggregated order; part p uses pose row p and idft row p (`fused.scene_graph_tables`); no torch.cat
+        m = len(features_dc)
+        assert isinstance(features_rest, (list, tuple)) and len(features_rest) == m and 1 <= m
+        assert idft is not None, "the per-part form needs the idft table (one row per sub-model)"
+        k = 1 + features_rest[0].shape[1]
+        assert k >= (degrees_to_use + 1) ** 2 and k > 1
+        if _sh_exchange is not None:
+            _sh_exchange._note_forward(False, degrees_to_use, k, True)      # per-rank tables: never claimed (see dp.py)
+        if m <= SH_MAX_PARTS:
+            return _SHFusedParts.apply(degrees_to_use, means.detach(), cam_pos, idft, poses, post_half_clamp, m,
+                                       *[d.contiguous() for d in features_dc], *[r.contiguous() for r in features_rest])
+        # more sub-models than the kernel's table holds: the concatenated form
+        counts = [d.shape[0] for d in features_dc]
+        object_ids = object_ids if object_ids is not None else object_ids_for(counts, means.device)
+        features_dc, features_rest = cat_features_dc(features_dc), torch.cat(list(features_rest), dim=0)
     k = 1 + (features_rest.shape[1] if features_rest is not None else 0)
     assert k >= (degrees_to_use + 1) ** 2
     claimed = _sh_exchange is not None and _sh_exchange.claims_leaves(features_dc, features_rest, object_ids, poses,

@@ -32,6 +32,16 @@ def _zeros3(dev, dtype=torch.float32) -> torch.Tensor:
     return _CONST[key]
 
 
+def _zero_colors(n: int, dev) -> torch.Tensor:
+    """[n,3] zeros for an accumulation-only pass, made once per size (a 12 MB fill per sub-model pass otherwise)."""
+    key = ("zero_colors", str(dev), int(n))
+    if key not in _CONST:
+        if len(_CONST) > 64:
+            _CONST.clear()
+        _CONST[key] = torch.zeros(n, 3, device=dev)
+    return _CONST[key]
+
+
 def leaf_params(raw: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     """Raw scene tensors -> autograd leaves (what nn.Parameter would be in SplatfactoModel)."""
     return {k: v.detach().clone().requires_grad_(True) for k, v in raw.items()}
@@ -148,7 +158,7 @@ def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int 
 
 def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Camera, sh_degree_to_use: int = 3,
                        block_width: int = 16, ops=_hip_ops, fused: bool = False,
-                       caller_syncs: bool = True) -> SimpleNamespace:
+                       caller_syncs: bool = True, sh_parts: bool = True) -> SimpleNamespace:
     """Replay of ``SplatfactoSceneGraphModel.get_outputs`` in training mode
     (``sgn_splatfacto_scene_graph.py:305-366``): ``models[0]`` is the background, ``models[i>0]`` rigid objects
     whose parameters live in the object's local frame; ``poses[i]`` = [R(9) t(3) q_o2w(4)], ``idft[i]`` = Fourier
@@ -163,9 +173,14 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
     cat = lambda key: torch.cat([m[key] for m in models], dim=0)                        # :355-360
     if fused:
         from . import fused as F_
+        # the SH coefficients stay UN-concatenated (one pair per sub-model: sgn_sh_fwd_parts); `sh_parts=False` keeps the
+        # round-3 form (torch.cat of features_rest, zero-padded cat of features_dc) for A/B and for the tests
+        if sh_parts and len(models) <= F_.SH_MAX_PARTS:
+            sh_dc, sh_rest = [m["features_dc"] for m in models], [m["features_rest"] for m in models]
+        else:
+            sh_dc, sh_rest = F_.cat_features_dc([m["features_dc"] for m in models]), cat("features_rest")
         P = dict(means=cat("means"), log_scales=cat("log_scales"), quats=cat("quats"),
-                 opacity_logits=cat("opacity_logits"), features_rest=cat("features_rest"),
-                 features_dc=F_.cat_features_dc([m["features_dc"] for m in models]))
+                 opacity_logits=cat("opacity_logits"), features_rest=sh_rest, features_dc=sh_dc)
         object_ids = F_.object_ids_for(counts, dev)       # per layout, built once (no per-step device work)
         # Fourier weights padded to the widest model: rows beyond a model's own dimension stay zero
         Fs = [m["features_dc"].shape[1] for m in models]
@@ -223,7 +238,7 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
         if fused:
             # colour is irrelevant for an accumulation-only pass; the full geometry tensors + id_range reuse the
             # main pass's binning (one-entry cache) instead of slicing and sorting again
-            rgbs = torch.zeros(sum(counts), 3, device=dev)
+            rgbs = _zero_colors(sum(counts), dev)
             _, acc = raster(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit, rgbs, opac_arg, H, W,
                             block_width, background=bg_zero, return_alpha=True, id_range=(lo, hi))
             return acc

@@ -283,3 +283,40 @@ def test_fused_quaternion_multiply_equals_pytorch3d_formula(per_row):
     assert rel_l2(got[1], b.grad) < 1e-6
     if per_row:
         assert rel_l2(got[2], a.grad) < 1e-6
+
+
+@pytest.mark.parametrize("degree,k", [(3, 16), (1, 4), (0, 4), (4, 25)])
+def test_sh_over_unconcatenated_sub_models_equals_the_concatenated_form(degree, k):
+    """`spherical_harmonics_fused` handed one (features_dc, features_rest) pair per sub-model (`sgn_sh_fwd_parts`: no
+    torch.cat, gradients written into each sub-model's own tensors) == the round-3 form on the zero-padded / concatenated
+    tensors with per-Gaussian object ids: colours bit-equal, gradients bit-equal (same per-row arithmetic), for parts whose
+    sizes are not multiples of the 64-row spans, an empty part, different Fourier dimensions, with and without poses."""
+    from sgn_rast import fused
+    g = torch.Generator().manual_seed(11)
+    counts, Fs = [1000, 0, 65, 63, 200, 1], [1, 5, 5, 3, 5, 2]
+    n, m = sum(counts), len(counts)
+    means = (torch.randn(n, 3, generator=g) * 2).to(DEV)
+    cam = torch.randn(3, generator=g).to(DEV)
+    R = torch.linalg.qr(torch.randn(m, 3, 3, generator=g))[0]
+    poses = fused.make_pose_table(R, torch.randn(m, 3, generator=g)).to(DEV)
+    idft = torch.zeros(m, max(Fs))
+    for p, f in enumerate(Fs):
+        idft[p, :f] = torch.randn(f, generator=g)
+    idft = idft.to(DEV)
+    w = torch.randn(n, 3, generator=g).to(DEV)
+    for use_poses in (True, False):
+        dcs = [torch.randn(c, f, 3, generator=g).to(DEV).requires_grad_(True) for c, f in zip(counts, Fs)]
+        rests = [torch.randn(c, k - 1, 3, generator=g).to(DEV).requires_grad_(True) for c in counts]
+        a = fused.spherical_harmonics_fused(degree, means, cam, dcs, rests, idft=idft, poses=poses if use_poses else None)
+        (a * w).sum().backward()
+        ga = [t.grad.clone() for t in dcs + rests]
+        for t in dcs + rests:
+            t.grad = None
+        oid = fused.object_ids_for(counts, DEV)
+        b = fused.spherical_harmonics_fused(degree, means, cam, fused.cat_features_dc(dcs), torch.cat(rests, 0),
+                                            object_ids=oid if use_poses else oid, idft=idft,
+                                            poses=poses if use_poses else None)
+        (b * w).sum().backward()
+        assert torch.equal(a, b), (degree, k, use_poses)
+        for x, t in zip(ga, dcs + rests):
+            assert torch.equal(x, t.grad), (degree, k, use_poses, tuple(t.shape))
