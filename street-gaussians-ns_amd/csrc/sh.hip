@@ -787,7 +787,8 @@ namespace {
 static int fill_parts(ShParts &P, int n_parts, const int32_t *rows_host, const int32_t *n_fourier_host,
                       const float *const *dc_host, const float *const *rest_host, float *const *v_dc_host,
                       float *const *v_rest_host, int k, bool backward) {
-    if (n_parts < 1 || n_parts > SH_MAX_PARTS || !rows_host || !n_fourier_host || !dc_host) return -1;
+    if (n_parts < 1 || n_parts > SH_MAX_PARTS || !rows_host || !n_fourier_host) return -1;
+    if (backward ? !v_dc_host : !dc_host) return -1;
     P.n_parts = n_parts;
     int span = 0, row = 0;
     for (int p = 0; p < n_parts; ++p) {
