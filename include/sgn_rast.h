@@ -429,7 +429,7 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    const float *conics, const float *colors, const float *opacities, int opacity_is_logit,
                    int id_lo, int id_hi, int window /*as in sgn_raster_fwd; the four outputs then have id_hi - id_lo rows*/,
                    const float *background3, const float *final_Ts, const int32_t *final_idx,
-                   const float *v_out_img /*[H,W,3]*/, const float *v_out_alpha /*[H,W]*/,
+                   const float *v_out_img /*[H,W,3]; NULL = zeros (only alpha reached the loss)*/, const float *v_out_alpha /*[H,W]*/,
                    float alpha_clamp_bwd, float *v_xy /*[n,2]*/, float *v_conic /*[n,3]*/,
                    float *v_colors /*[n,3]*/, float *v_opacity /*[n]*/, void *recs_ws,
                    size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,

@@ -738,9 +738,10 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
         const int pix = inside ? pixi[q] : 0;
         const float Tf = inside ? final_T[pix] : 1.f;
         T[q] = Tf;
-        vo0[q] = inside ? v_out[3 * pix] : 0.f;
-        vo1[q] = inside ? v_out[3 * pix + 1] : 0.f;
-        vo2[q] = inside ? v_out[3 * pix + 2] : 0.f;
+        // v_out == NULL: the image took no part in the loss (an accumulation-only pass): zeros, and no 29 MB read
+        vo0[q] = (inside && v_out != nullptr) ? v_out[3 * pix] : 0.f;
+        vo1[q] = (inside && v_out != nullptr) ? v_out[3 * pix + 1] : 0.f;
+        vo2[q] = (inside && v_out != nullptr) ? v_out[3 * pix + 2] : 0.f;
         const float voa = inside ? v_out_alpha[pix] : 0.f;
         c0[q] = Tf * (voa - fmaf(bg0, vo0[q], fmaf(bg1, vo1[q], bg2 * vo2[q])));
         bv[q] = 0.f;
@@ -1253,7 +1254,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     SGN_HIP_CHECK(hipMemsetAsync(grad_ws, 0, (size_t)n * SGN_RECORD_FLOATS * sizeof(float), s));
     if (n_isect > 0) {
         SGN_ARG_CHECK(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background3 &&
-                          final_Ts && final_idx && v_out_img && v_out_alpha && recs_ws, -7);
+                          final_Ts && final_idx && v_out_alpha && recs_ws, -7);     // (v_out_img may be NULL: zeros)
         SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect, &o), -8);
         if (!recs_packed)
             pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, logit_rows, id_lo, id_hi,

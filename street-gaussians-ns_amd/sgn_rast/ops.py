@@ -1297,10 +1297,9 @@ class _RasterizeGaussians(Function):
         # only the alpha output reached the loss (the scene graph's accumulation passes, scene_graph.py:364-366): the
         # colour gradient is exactly zero — hand autograd None instead, and the clamp / SH / concatenation backward
         # behind the colours (a dense [n,K,3] gradient and its split over the leaves) is skipped altogether
-        no_color_grad = v_out_img is None
-        if v_out_img is None:
-            v_out_img = torch.zeros(H, W, 3, **f32)
-        v_out_img, v_out_alpha = _f32c(v_out_img), _f32c(v_out_alpha)
+        no_color_grad = v_out_img is None                   # (the kernel takes NULL for "zeros": no fill, no read)
+        v_out_img = None if v_out_img is None else _f32c(v_out_img)
+        v_out_alpha = _f32c(v_out_alpha)
         v_xy = torch.empty(n, 2, **f32)
         v_conic = torch.empty(n, 3, **f32)
         v_colors = torch.empty(n, 3, **f32)
