@@ -305,11 +305,14 @@ class GradAllReducer:
         replica): geometry by scatter-add, the SH gradient through the low-rank rebuild kernel on the scattered colour
         gradients.
 
-        Sequence (fixed, every rank, every step): all-gather of ``[count, can]`` -> host; then EITHER the row all-gather
-        (+ one dense all-reduce per registered tensor that is not per-Gaussian) OR, if some rank cannot take part or the
-        mean touched fraction exceeds ``sparse_max_fraction``, the dense sequence of :meth:`finish`.  Two host syncs per
-        step (the local count, the gathered counts): the price of exact sizes — a capacity guessed from earlier steps
-        could overflow on a view that sees more, and a dropped row is a wrong gradient.
+        Sequence (fixed, every rank, every step): all-gather of ``[count, can, degree, K]`` -> host; then EITHER the row
+        all-gather (+ one dense all-reduce per registered tensor that is not per-Gaussian) OR, if some rank cannot take part
+        or the mean touched fraction exceeds ``sparse_max_fraction``, the dense sequence of :meth:`finish`.  Sizes are
+        EXACT (a capacity guessed from earlier steps could overflow on a view that sees more, and a dropped row is a wrong
+        gradient), and they cost no host sync: on the GPU the rows are listed and announced right after the FORWARD
+        (:meth:`after_forward`: the walked entries of the depth lists, a superset of what the backward can touch), so the
+        answer is on the host long before the backward ends.  Without that hook (CPU tensors in the gloo tests, a rank
+        whose view saw nothing) the rows are found from the gradients and announced here, with two host syncs.
 
         Returns False when the step must take the dense sequence."""
         ex = self.sh_exchange
