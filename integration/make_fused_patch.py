@@ -122,10 +122,9 @@ EDITS_SG = [
     ("    def get_fourier_features(self, frame, trackId, obj_model: SplatfactoModel):\n",
      "    def get_fourier_features(self, frame, trackId, obj_model: SplatfactoModel, weights_only=False):\n"),
     ("        idft_base = IDFT(t, obj_model.config.fourier_features_dim).to(self.device)\n",
-     "        idft_base = IDFT(t, obj_model.config.fourier_features_dim)\n"
-     "        if weights_only:\n"
-     "            return idft_base[0]  # sgn_fused: sum_f features_dc[:, f] * idft[f] runs inside the SH kernel\n"
-     "        idft_base = idft_base.to(self.device)\n"),
+     "        if weights_only:  # sgn_fused: sum_f features_dc[:, f] * idft[f] runs inside the SH kernel\n"
+     "            return sgn_fused.memo(IDFT, float(t), obj_model.config.fourier_features_dim)[0]\n"
+     "        idft_base = IDFT(t, obj_model.config.fourier_features_dim).to(self.device)\n"),
     # get_submodel_output: a sub-model pass is an id window of the main pass (same projection, same depth list)
     ("        if object_means is None:\n"
      "            submodel_means = self.aggregate_submodel_var(\"means\", submodel_names)\n"
@@ -195,7 +194,7 @@ EDITS_SG = [
      "                object_quats.append(obj_quats)\n",
      "                object_means.append(obj_model.means)  # sgn_fused: LOCAL frame; R, t and q_o2w are applied in-kernel\n"
      "                object_quats.append(obj_model.quats)\n"
-     "                sgn_poses.append((anno.rot, anno.center, quaternion_from_matrix(anno.rot)))\n"),
+     "                sgn_poses.append((anno.rot, anno.center, sgn_fused.memo(quaternion_from_matrix, anno.rot)))\n"),
     ("        self.features_dc = torch.cat([self.background_model.features_dc, *object_features_dc], dim=0)\n",
      "        # sgn_fused: the SH coefficients stay one tensor per sub-model (sgn_sh_fwd_parts reads them where they are)\n"
      "        self.features_dc = ((self.background_model.features_dc, *object_features_dc) if self.config.sh_degree > 0\n"

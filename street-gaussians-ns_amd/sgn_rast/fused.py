@@ -75,6 +75,24 @@ def cat_features_dc(parts) -> torch.Tensor:
     return torch.cat(padded, dim=0)
 
 
+_MEMO: dict = {}
+
+
+def memo(fn, *args):
+    """``fn(*args)`` remembered by value of its arguments (numpy arrays by their bytes).  For the PURE per-object host
+    functions of the scene graph's aggregation — ``quaternion_from_matrix(anno.rot)`` (a numpy eigen-decomposition,
+    ``sgn_splatfacto_scene_graph.py:412``) and ``IDFT(t, dim)`` (a dozen small CPU tensor ops, ``:420-433``): the training
+    loop comes back to the same frames every epoch, and these cost 0.6 ms of host time per step at eight visible objects
+    (profiles/r04q_*).  Same function, same arguments, same result; bounded to 65536 entries."""
+    key = (fn,) + tuple(a.tobytes() if hasattr(a, "tobytes") else a for a in args)
+    hit = _MEMO.get(key)
+    if hit is None:
+        if len(_MEMO) >= 65536:
+            _MEMO.clear()
+        hit = _MEMO[key] = fn(*args)
+    return hit
+
+
 def scene_graph_tables(counts, object_poses, object_idft, device) -> dict:
     """The small per-step tables of the fused scene-graph front end (``sgn_splatfacto_scene_graph.py:332-360`` folded into
     the kernels): ``counts`` Gaussians per visible sub-model, background first; ``object_poses`` one

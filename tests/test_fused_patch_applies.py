@@ -31,7 +31,7 @@ def test_patches_apply_cleanly_and_compile(tmp_path):
     # the aggregation glue is gone from the step: no object2world_gs call, no Fourier sum, no per-sub-model concatenation
     body = sg[sg.index("    def get_outputs("):sg.index("    def get_loss_dict(")]
     assert "object2world_gs(" not in body and "aggregate_submodel_var(" not in sg[sg.index("def get_submodel_output"):sg.index("    def get_outputs(")]
-    assert sg.count("sgn_fused.") == 2 and "id_range=id_range" in sg
+    assert sg.count("sgn_fused.") == 4 and "id_range=id_range" in sg
 
 
 def test_patches_are_what_the_generator_produces(tmp_path):
