@@ -390,6 +390,30 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                                               once (the caller answers the pass with sgn_depth_reuse); needs
                                               rows_built = 1 in gather mode*/,
                    const sgn_raster_opts *opts, sgn_stream_t stream);
+/* sgn_raster_fwd with TWO GROUP ACCUMULATIONS riding on the same walk (no upstream counterpart): besides everything
+ * sgn_raster_fwd writes, the final transmittance / final index / per-tile walk depth of the pass that would render only
+ * the Gaussians with id < split ("head") and of the pass that would render only those with id >= split ("tail") over
+ * the same depth list — the scene graph's background-only and objects-only accumulation passes
+ * (sgn_splatfacto_scene_graph.py:364-366), for which the reference rasterizes twice more.  Every entry belongs to one
+ * group, its alpha is the one the main pass evaluates anyway; per entry the group costs one more transmittance
+ * recursion with the single pass's arithmetic, so the group state is BIT-EQUAL to what sgn_raster_fwd calls with id
+ * ranges [0, split) / [split, n) write as final_Ts / final_idx / tile_stats[:, 0] (tests/test_gpu_groups.py); a group's
+ * backward is sgn_raster_bwd with that id range, v_out_img = NULL and the group's state.
+ *   group_state [4][H*W]: T_head, T_tail (float), then final index head, tail (int32);
+ *   group_stats [2][tiles*2]: like tile_stats, head then tail.
+ * ONE group (own_group: 0 head, 1 tail, -1 none) may come with its own compacted list (own_ids / own_bins from
+ * sgn_list_window — the list its backward will walk): its indices are then positions of THAT list, and when it is still
+ * alive after the main pass and the other group have finished (a few objects in front of a saturated background) it
+ * goes on along its own list instead of dragging the shared walk to the end.  The other group's indices are positions
+ * of the shared list.  Packed forward of the gather mode only (opts->gather = 1, waves_fwd = 2; 16x16 tiles; the whole
+ * scene): -12 otherwise. */
+int sgn_raster_fwd_groups(int img_h, int img_w, int n, int64_t n_isect, const int32_t *gaussian_ids_sorted,
+                          const int32_t *tile_bins, const float *xys, const float *conics, const float *colors,
+                          const float *opacities, int opacity_is_logit, const float *background3, float *out_img,
+                          float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes, int rows_built,
+                          const int32_t *tile_order, int32_t *tile_stats, const float *depths, float *out_depth,
+                          int split, int own_group, const int32_t *own_ids, const int32_t *own_bins /*[tiles,2]*/,
+                          float *group_state, int32_t *group_stats, const sgn_raster_opts *opts, sgn_stream_t stream);
 /* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built
  * while the host waits for the intersection count (keeps the GPU busy across that sync).  Pre-built rows are used by
  * sgn_raster_fwd when opts->gather != 0 (pass rows_built = 1); in stream mode it re-packs them itself. */

@@ -198,7 +198,31 @@ __device__ __forceinline__ unsigned row_quadrants(float gx, float gy, float ex, 
 // per-Gaussian depth is not part of the 48-byte row: it comes from `depths[id]` with one more scalar load next to the
 // row's (scalar-chase path) or rides in a 64-float side array of the LDS stage (batched path); same operation order
 // as the colour channels, so in exact-exp mode D is bit-equal to channel 0 of the two-pass result.
-template <bool EXACT, bool GATHER, int QPW, bool ADAPT, bool DEPTH>
+// GROUPS (r04): TWO MORE accumulations ride on the walk — the alpha images of the passes that would render only the
+// Gaussians with id < split (the "head" group) and only those with id >= split (the "tail" group) of the same list:
+// the scene graph's background-only and objects-only accumulation passes (sgn_splatfacto_scene_graph.py:364-366), which
+// the reference pays two more rasterizations for.  Each entry belongs to exactly one group (its id: wave-uniform), and
+// its alpha — the expensive part — is the one the main pass evaluates anyway; per entry the group costs one more
+// transmittance recursion (nT = T (1 - a), the 1e-4 stop, the last index), with the arithmetic and the bookkeeping of
+// the single pass, so T / final index per group are BIT-EQUAL to the separate pass's.  A group's final index is recorded
+// in the index space its backward will walk: positions of the shared list, or — when the group has its own compacted
+// list (sgn_list_window: the small group) — positions of THAT list (its tile's first position + the number of the
+// group's entries met before).  The shared walk goes on while the main pass or a group WITHOUT its own list is alive;
+// a group with its own list that is still alive then (a few objects in front of a saturated background never finish)
+// continues on its own list from where the shared walk left it — walking the shared list to its end for it would
+// visit ten times the entries the separate passes do (measured: 394 instead of 549 images/s on the scene graph).
+// (Few pointers on purpose: the scalar-chase walk keeps two 48-byte rows in SGPRs; with ten group pointers live as
+// well the GROUPS kernels spilled 33 SGPRs, part of them to scratch memory.)
+struct FwdGroups {
+    int split;                  // ids >= split: tail group
+    int own;                    // the group that has its own compacted list: -1 none, 0 head, 1 tail
+    const int2 *own_bins;       // its bins and ids (own >= 0)
+    const int32_t *own_ids;
+    float *state;               // [4][H*W]: T_head, T_tail, then (int32) final index head, tail
+    int32_t *kmax;              // [2][n_tiles*2] deepest composited position per tile, head then tail (zero-filled by the caller)
+};
+
+template <bool EXACT, bool GATHER, int QPW, bool ADAPT, bool DEPTH, bool GROUPS = false>
 __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, int B, int tiles_x,
                                                 const int2 *__restrict__ bins, const Rec *__restrict__ recs,
                                                 const int32_t *__restrict__ ids, const float *__restrict__ bg,
@@ -207,8 +231,10 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
                                                 int32_t *__restrict__ tile_kmax, float4 (*stage)[64 * 3],
                                                 const float *__restrict__ depths = nullptr,
                                                 float *__restrict__ out_depth = nullptr,
-                                                float (*stage_d)[64] = nullptr, int use_qm = 0) {
+                                                float (*stage_d)[64] = nullptr, int use_qm = 0,
+                                                const FwdGroups *Gp = nullptr) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
+    static_assert(!GROUPS || (GATHER && !ADAPT), "group accumulations: gather mode, fixed wave shape");
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
     const bool qm_on = GATHER && use_qm != 0 && B == 16;      // wave-uniform
@@ -243,31 +269,53 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
         if constexpr (DEPTH) Dq[q] = 0.f;
         last[q] = 0;
     }
+    // GROUPS: per-pixel state of the two group passes (same liveness convention), entries of each group met so far
+    float TH[GROUPS ? QPW : 1], TT[GROUPS ? QPW : 1];
+    int lastH[GROUPS ? QPW : 1], lastT[GROUPS ? QPW : 1];
+    int cO = 0, baseO = 0, split = 0, own = -1;   // own: the group with its own list; cO: its entries met so far
+    int rO = -1;                // where the shared walk stopped, in entries of the own group (-1: at the end of the list)
+    if constexpr (GROUPS) {
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) { TH[q] = TT[q] = T[q]; lastH[q] = lastT[q] = 0; }
+        split = Gp->split;
+        own = Gp->own;
+        if (own >= 0) baseO = Gp->own_bins[tile].x;
+    }
 
     // centre of quadrant (lane & 3)'s pixel centres, for the quadrant-reject test (16x16 tiles only)
     const bool qtest = (B == 16);
     const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
 
     // one depth-list entry for this wave's pixels; returns false once every pixel of the wave is finished
+    // (GROUPS: `tail` says which group the entry belongs to, `kg` is its position in that group's index space)
     int n_eval = 0;   // (entry, quadrant) pairs this wave evaluated (wave-uniform): the backward's size-of-splat hint
-    auto entry = [&](const Rec &cur, int k, unsigned qm, float dep) __attribute__((always_inline)) -> bool {
-        unsigned long long live[QPW], any_live = 0ull;
+    auto entry = [&](const Rec &cur, int k, unsigned qm, float dep, bool tail, int kg, bool own_walk) __attribute__((always_inline)) -> bool {
+        unsigned long long live[QPW], liveg[QPW], any_live = 0ull;
 #pragma unroll
         for (int q = 0; q < QPW; ++q) {
             live[q] = __ballot(T[q] > 0.f);
-            any_live |= live[q];
+            liveg[q] = 0ull;
+            if constexpr (GROUPS) {
+                liveg[q] = __ballot((tail ? TT[q] : TH[q]) > 0.f);
+                // the shared walk is kept alive by the main pass and by the groups that have no list of their own; a
+                // group's walk of its own list by that group alone (the main pass takes no part in it)
+                if (own_walk) { live[q] = 0ull; any_live |= liveg[q]; }
+                else any_live |= live[q] | __ballot((own != 0 && TH[q] > 0.f) || (own != 1 && TT[q] > 0.f));
+            } else {
+                any_live |= live[q];
+            }
         }
         if (any_live == 0ull) return false;
 #pragma unroll
         for (int q = 0; q < QPW; ++q) {
-            if (live[q] == 0ull || !((qm >> (q0 + q)) & 1u)) continue;  // wave-uniform
-            ++n_eval;
+            if ((live[q] | liveg[q]) == 0ull || !((qm >> (q0 + q)) & 1u)) continue;  // wave-uniform
+            if (live[q] != 0ull) ++n_eval;
             const float dx = cur.x - px[q], dy = cur.y - py[q];
             float s = (cur.ha * dx) * dx;
             s = fmaf(cur.hc * dy, dy, s);
             const float sigma = fmaf(cur.b * dx, dy, s);
             const float alpha = fminf(0.999f, cur.opac * sgn_exp<EXACT>(-sigma));
-            const bool valid = T[q] > 0.f && sigma >= 0.f && alpha >= (1.f / 255.f);
+            const bool valid = !(GROUPS && own_walk) && T[q] > 0.f && sigma >= 0.f && alpha >= (1.f / 255.f);
             // branch-free update: lanes that skip or stop add vis = 0 (fma(c, 0, C) == C exactly)
             const float nT = T[q] * (1.f - alpha);
             const bool stop = valid && nT <= 1e-4f;
@@ -280,8 +328,27 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
             last[q] = acc ? k : last[q];
             const float Tk = acc ? nT : T[q];
             T[q] = stop ? -Tk : Tk;  // terminating Gaussian is NOT composited; T keeps its last value
+            if constexpr (GROUPS) {   // the entry's own group: the same recursion on the group's transmittance
+                const float Tg = tail ? TT[q] : TH[q];
+                const bool validg = Tg > 0.f && sigma >= 0.f && alpha >= (1.f / 255.f);
+                const float nTg = Tg * (1.f - alpha);
+                const bool stopg = validg && nTg <= 1e-4f;
+                const bool accg = validg && !stopg;
+                const float Tkg = accg ? nTg : Tg;
+                const float Tng = stopg ? -Tkg : Tkg;
+                if (tail) { TT[q] = Tng; lastT[q] = accg ? kg : lastT[q]; }
+                else { TH[q] = Tng; lastH[q] = accg ? kg : lastH[q]; }
+            }
         }
         return true;
+    };
+    // GROUPS: group and group-space position of list position k holding raw id word `raw` (wave-uniform)
+    auto group_of = [&](int raw, int k, bool &tail, int &kg) __attribute__((always_inline)) {
+        tail = false; kg = k;
+        if constexpr (GROUPS) {
+            tail = (raw & idmask) >= split;
+            if (own == (int)tail) { kg = baseO + cO; ++cO; }
+        }
     };
 
     const int L = range.y - range.x;
@@ -300,7 +367,12 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
             const int idnn = idn;
             if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
             const unsigned qm = qm_on ? qm_bits(idc, cur.ex) : quadrant_mask(cur, qcx, qcy, qtest);
-            if (!entry(cur, k, qm, dcur)) break;
+            bool tail; int kg;
+            group_of(idc, k, tail, kg);
+            if (!entry(cur, k, qm, dcur, tail, kg, false)) {
+                if constexpr (GROUPS) rO = (own == (int)tail) ? cO - 1 : cO;   // this entry is still to come
+                break;
+            }
             cur = nxt;
             dcur = dnxt;
             idc = idnn;
@@ -336,10 +408,14 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
         if constexpr (DEPTH) stage_d[0][lane] = rd;
         unsigned qrow = row_mask(r0, r2) & mine_q;
+        bool trow = GROUPS && (rid & idmask) >= split;    // GROUPS: this lane's row belongs to the tail group
         bool go = true;
         for (int bi = 0; bi < nb && go; ++bi) {
             const int cnt = min(64, L - (bi << 6));
             unsigned long long todo = __ballot(lane < cnt && qrow != 0u);  // entries that can touch my pixels
+            const unsigned long long tmask = GROUPS ? __ballot(lane < cnt && trow) : 0ull;   // the batch's tail entries
+            const unsigned long long omask =       // ... and the entries of the group that has its own list
+                !GROUPS || own < 0 ? 0ull : (own == 1 ? tmask : (__ballot(lane < cnt) & ~tmask));
             const unsigned qcur = qrow;
             if (bi + 1 < nb) fetch(bi + 1, r0, r1, r2);   // next batch: in flight while this one is composited
             const float4 *sb = stage[bi & 1];
@@ -354,15 +430,64 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
                 const unsigned qm = (unsigned)__builtin_amdgcn_readlane((int)qcur, j);
                 float dep = 0.f;
                 if constexpr (DEPTH) dep = stage_d[bi & 1][j];
-                if (!entry(cur, range.x + (bi << 6) + j, qm, dep)) { go = false; break; }
+                const int k = range.x + (bi << 6) + j;
+                bool tail = false; int kg = k;
+                if constexpr (GROUPS) {     // entries of the batch before j that belong to the own-list group
+                    tail = (tmask >> j) & 1ull;
+                    if ((omask >> j) & 1ull) kg = baseO + cO + __popcll(omask & ((1ull << j) - 1ull));
+                }
+                if (!entry(cur, k, qm, dep, tail, kg, false)) {
+                    if constexpr (GROUPS) rO = cO + __popcll(omask & ((1ull << j) - 1ull));
+                    go = false;
+                    break;
+                }
             }
+            if constexpr (GROUPS) cO += __popcll(omask);
             if (go && bi + 1 < nb) {                      // first use of the prefetched registers
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
                 if constexpr (DEPTH) stage_d[(bi + 1) & 1][lane] = rd;
                 qrow = row_mask(r0, r2) & mine_q;
+                trow = GROUPS && (rid & idmask) >= split;
             }
         }
+    }
+    if constexpr (GROUPS) {
+        // a group with its own list that outlived the shared walk: the rest of ITS list (scalar chase, one entry ahead)
+        auto own_rest = [&](bool tail, const int2 *gbins, const int32_t *gids, int from) __attribute__((always_inline)) {
+            const int end = gbins[tile].y;
+            if (from >= end) return;
+            int idc = gids[from];
+            Rec cur = recs[idc & idmask];
+            int idn = gids[min(from + 1, end - 1)];
+            for (int p = from; p < end; ++p) {
+                const Rec nxt = recs[idn & idmask];
+                const int idnn = idn;
+                idn = gids[min(p + 2, end - 1)];
+                const unsigned qm = qm_on ? qm_bits(idc, cur.ex) : quadrant_mask(cur, qcx, qcy, qtest);
+                if (!entry(cur, 0, qm, 0.f, tail, p, true)) break;
+                cur = nxt;
+                idc = idnn;
+            }
+        };
+        if (rO < 0) rO = cO;
+        if (own >= 0) own_rest(own == 1, Gp->own_bins, Gp->own_ids, baseO + rO);
+        const int HW = W * H, n_tiles2 = 2 * tiles_x * ((H + B - 1) / B);
+        float *gT = Gp->state;
+        int32_t *gI = reinterpret_cast<int32_t *>(Gp->state + 2 * (size_t)HW);
+        int lh = 0, lt = 0;
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) {
+            lh = max(lh, inside[q] ? lastH[q] : 0);
+            lt = max(lt, inside[q] ? lastT[q] : 0);
+            if (inside[q]) {
+                gT[pix[q]] = fabsf(TH[q]); gI[pix[q]] = lastH[q];
+                gT[HW + pix[q]] = fabsf(TT[q]); gI[HW + pix[q]] = lastT[q];
+            }
+        }
+        lh = wave_max_i(lh); lt = wave_max_i(lt);
+        if (lane == 0 && lh > 0) atomicMax(Gp->kmax + 2 * tile, lh);
+        if (lane == 0 && lt > 0) atomicMax(Gp->kmax + n_tiles2 + 2 * tile, lt);
     }
     if (tile_kmax) {   // [2t]: deepest list position any pixel of the tile composited (the backward's walk starts
                        // there); [2t + 1]: (entry, quadrant) pairs evaluated: pairs / walk ~ 1 means small splats
@@ -443,50 +568,21 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat2(float v) { return v2f{v, v}; }
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <bool EXACT, bool GATHER, bool DEPTH>
-__global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int tiles_x, int n_tiles_,
-                                                           const int2 *__restrict__ bins,
-                                                           const Rec *__restrict__ recs,
-                                                           const int32_t *__restrict__ ids,
-                                                           const float *__restrict__ bg, float *__restrict__ out_img,
-                                                           float *__restrict__ final_T,
-                                                           int32_t *__restrict__ final_idx, int swz,
-                                                           int batch_thresh, const int32_t *__restrict__ tile_order,
-                                                           int32_t *__restrict__ tile_kmax,
-                                                           const float *__restrict__ depths,
-                                                           float *__restrict__ out_depth,
-                                                           const int32_t *__restrict__ skip_flag, int use_qm) {
-    if (skip_flag != nullptr && *skip_flag == 0) return;   // the caller already holds this pass's result (sgn_depth_reuse)
-    __shared__ float4 stage[2][64 * 3];
-    __shared__ float stage_d[DEPTH ? 2 : 1][64];
-    // The first n_long tiles of the launch order (sgn_tile_order with long_thresh: the longest lists) get four waves
-    // each, the others two.  Blocks come in groups of eight tiles (8 x 4, then 8 x 2 blocks): block b runs on XCD
-    // b % 8, so a tile's waves share an XCD (and its L2) and are dispatched together, longest tiles first.  No block
-    // inside the two regions is empty: interleaving waves that exit at once with working ones left half of the SIMDs
-    // idle (the dispatcher places consecutive workgroups round-robin), 267 vs 159 us on the benchmark scene.
-    const int n_long = tile_order ? min(max(tile_order[n_tiles_], 0), n_tiles_) : 0;
-    const int b_long = ((n_long + 7) >> 3) << 5;
-    const int b = (int)blockIdx.x;
-    int t_idx, wv;
-    const bool is_long = b < b_long;
-    if (is_long) {
-        t_idx = (b >> 5) * 8 + (b & 7);
-        wv = (b >> 3) & 3;
-        if (t_idx >= n_long) return;
-    } else {
-        const int b2 = b - b_long;
-        t_idx = n_long + (b2 >> 4) * 8 + (b2 & 7);
-        wv = (b2 >> 3) & 1;
-        if (t_idx >= n_tiles_) return;
-    }
-    int tile = xcd_tile(t_idx, n_tiles_, swz);
-    if (tile_order) tile = tile_order[tile];
+template <bool EXACT, bool GATHER, bool DEPTH, bool GROUPS>
+__device__ __forceinline__ void raster_fwd_pk_body(int tile, int wv, bool is_long, int W, int H, int tiles_x, int n_tiles_,
+                                                   const int2 *__restrict__ bins, const Rec *__restrict__ recs,
+                                                   const int32_t *__restrict__ ids, const float *__restrict__ bg,
+                                                   float *__restrict__ out_img, float *__restrict__ final_T,
+                                                   int32_t *__restrict__ final_idx, int batch_thresh,
+                                                   int32_t *__restrict__ tile_kmax, const float *__restrict__ depths,
+                                                   float *__restrict__ out_depth, int use_qm, const FwdGroups &G,
+                                                   float4 (*stage)[64 * 3], float (*stage_d)[64]) {
     const int2 range = bins[tile];
     const int L = range.y - range.x;
     if (is_long) {
-        raster_fwd_tile<EXACT, GATHER, 1, false, DEPTH>(tile, wv, W, H, 16, tiles_x, bins, recs, ids, bg, out_img, final_T,
-                                                        final_idx, 0, batch_thresh, tile_kmax, stage, depths, out_depth,
-                                                        stage_d, use_qm);
+        raster_fwd_tile<EXACT, GATHER, 1, false, DEPTH, GROUPS>(tile, wv, W, H, 16, tiles_x, bins, recs, ids, bg, out_img,
+                                                                final_T, final_idx, 0, batch_thresh, tile_kmax, stage,
+                                                                depths, out_depth, stage_d, use_qm, &G);
         return;
     }
     const bool qm_on = GATHER && use_qm != 0;            // wave-uniform
@@ -505,13 +601,39 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
     v2f C0 = {0.f, 0.f}, C1 = C0, C2 = C0, Dp = C0;
     int last0 = 0, last1 = 0;
     const float qcx = (float)(tx * 16 + (lane & 1) * 8) + 4.0f, qcy = (float)(ty * 16 + ((lane >> 1) & 1) * 8) + 4.0f;
+    // GROUPS (see FwdGroups): the two group passes' transmittances / last positions, group entries met so far
+    v2f TH = T, TT = T;
+    int lastH0 = 0, lastH1 = 0, lastT0 = 0, lastT1 = 0;
+    const int own = GROUPS ? G.own : -1;   // the group with its own list (-1: none)
+    int cO = 0, baseO = 0;      // its entries met so far, its tile's first position in that list
+    int rO = -1;                // where the shared walk stopped, in entries of the own group (-1: at the end of the list)
+    if constexpr (GROUPS) {
+        if (own >= 0) baseO = G.own_bins[tile].x;
+    }
 
     int n_eval = 0;
     // m: which of this wave's two quadrants the entry can touch (bit 0 = slot 0, bit 1 = slot 1), never 0
-    auto entry = [&](const Rec &cur, int k, unsigned m, float dep) __attribute__((always_inline)) -> bool {
-        const bool l0 = T.x > 0.f, l1 = T.y > 0.f;
+    // (GROUPS: `tail` = the entry's group, `kg` = its position in that group's index space)
+    auto entry = [&](const Rec &cur, int k, unsigned m, float dep, bool tail, int kg, bool own_walk) __attribute__((always_inline)) -> bool {
+        // (own_walk: a group's walk of the rest of its OWN list — the main pass takes no part in it)
+        const bool l0 = !(GROUPS && own_walk) && T.x > 0.f, l1 = !(GROUPS && own_walk) && T.y > 0.f;
         const unsigned long long b0 = __ballot(l0), b1 = __ballot(l1);
-        if ((b0 | b1) == 0ull) return false;
+        bool g0 = false, g1 = false;
+        if constexpr (GROUPS) {
+            const v2f Tg = tail ? TT : TH;
+            g0 = Tg.x > 0.f; g1 = Tg.y > 0.f;
+            const unsigned long long bg = __ballot(g0 || g1);
+            if (own_walk) {
+                if (bg == 0ull) return false;
+            } else {
+                // the shared walk is kept alive by the main pass and by the groups that have no list of their own
+                if ((b0 | b1 | __ballot((own != 0 && (TH.x > 0.f || TH.y > 0.f)) ||
+                                        (own != 1 && (TT.x > 0.f || TT.y > 0.f)))) == 0ull) return false;
+                if ((b0 | b1 | bg) == 0ull) return true;          // neither the main pass nor this entry's group
+            }
+        } else {
+            if ((b0 | b1) == 0ull) return false;
+        }
         n_eval += __popc(m & ((b0 ? 1u : 0u) | (b1 ? 2u : 0u)));
         {
             const v2f dx = splat2(cur.x) - px;
@@ -543,6 +665,25 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
             last0 = (ok0 && !stop0) ? k : last0;
             last1 = (ok1 && !stop1) ? k : last1;
             T = v2f{stop0 ? -T.x : nT.x, stop1 ? -T.y : nT.y};
+            if constexpr (GROUPS) {   // the entry's own group: the same recursion on the group's transmittance
+                const v2f Tg = tail ? TT : TH;
+                const bool okg0 = g0 && sigma.x >= 0.f && a0 >= (1.f / 255.f);
+                const bool okg1 = g1 && sigma.y >= 0.f && a1 >= (1.f / 255.f);
+                const v2f ag = {okg0 ? a0 : 0.f, okg1 ? a1 : 0.f};
+                const v2f nTg = Tg * (splat2(1.f) - ag);
+                const bool sg0 = __float_as_uint(nTg.x) <= 0x38D1B717u;
+                const bool sg1 = __float_as_uint(nTg.y) <= 0x38D1B717u;
+                const v2f Tn = {sg0 ? -Tg.x : nTg.x, sg1 ? -Tg.y : nTg.y};
+                if (tail) {
+                    TT = Tn;
+                    lastT0 = (okg0 && !sg0) ? kg : lastT0;
+                    lastT1 = (okg1 && !sg1) ? kg : lastT1;
+                } else {
+                    TH = Tn;
+                    lastH0 = (okg0 && !sg0) ? kg : lastH0;
+                    lastH1 = (okg1 && !sg1) ? kg : lastH1;
+                }
+            }
         }
         return true;
     };
@@ -561,7 +702,15 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
             const int idnn = idn;
             if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
             const unsigned m = ((qm_on ? qm_bits(idc, cur.ex) : quadrant_mask(cur, qcx, qcy, true)) >> shift_q) & 3u;
-            if (m != 0u && !entry(cur, k, m, dcur)) break;
+            bool tail = false; int kg = k;
+            if constexpr (GROUPS) {
+                tail = (idc & idmask) >= G.split;
+                if (own == (int)tail) { kg = baseO + cO; ++cO; }
+            }
+            if (m != 0u && !entry(cur, k, m, dcur, tail, kg, false)) {
+                if constexpr (GROUPS) rO = (own == (int)tail) ? cO - 1 : cO;   // this entry is still to come
+                break;
+            }
             cur = nxt;
             dcur = dnxt;
             idc = idnn;
@@ -588,10 +737,14 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
         stage[0][lane * 3 + 0] = r0; stage[0][lane * 3 + 1] = r1; stage[0][lane * 3 + 2] = r2;
         if constexpr (DEPTH) stage_d[0][lane] = rd;
         unsigned qrow = (row_mask(r0, r2) >> shift_q) & 3u;
+        bool trow = GROUPS && (rid & idmask) >= G.split;      // GROUPS: this lane's row belongs to the tail group
         bool go = true;
         for (int bi = 0; bi < nb && go; ++bi) {
             const int cnt = min(64, L - (bi << 6));
             unsigned long long todo = __ballot(lane < cnt && qrow != 0u);
+            const unsigned long long tmask = GROUPS ? __ballot(lane < cnt && trow) : 0ull;
+            const unsigned long long omask =       // the batch's entries of the group that has its own list
+                !GROUPS || own < 0 ? 0ull : (own == 1 ? tmask : (__ballot(lane < cnt) & ~tmask));
             const unsigned qcur = qrow;
             if (bi + 1 < nb) fetch(bi + 1, r0, r1, r2);
             const float4 *sb = stage[bi & 1];
@@ -606,14 +759,62 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
                 const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)qcur, j);
                 float dep = 0.f;
                 if constexpr (DEPTH) dep = stage_d[bi & 1][j];
-                if (!entry(cur, range.x + (bi << 6) + j, m, dep)) { go = false; break; }
+                const int k = range.x + (bi << 6) + j;
+                bool tail = false; int kg = k;
+                if constexpr (GROUPS) {
+                    tail = (tmask >> j) & 1ull;
+                    if ((omask >> j) & 1ull) kg = baseO + cO + __popcll(omask & ((1ull << j) - 1ull));
+                }
+                if (!entry(cur, k, m, dep, tail, kg, false)) {
+                    if constexpr (GROUPS) rO = cO + __popcll(omask & ((1ull << j) - 1ull));
+                    go = false;
+                    break;
+                }
             }
+            if constexpr (GROUPS) cO += __popcll(omask);
             if (go && bi + 1 < nb) {
                 float4 *sn = stage[(bi + 1) & 1];
                 sn[lane * 3 + 0] = r0; sn[lane * 3 + 1] = r1; sn[lane * 3 + 2] = r2;
                 if constexpr (DEPTH) stage_d[(bi + 1) & 1][lane] = rd;
                 qrow = (row_mask(r0, r2) >> shift_q) & 3u;
+                trow = GROUPS && (rid & idmask) >= G.split;
             }
+        }
+    }
+    if constexpr (GROUPS) {
+        // a group with its own list that outlived the shared walk: the rest of ITS list (scalar chase, one entry ahead)
+        auto own_rest = [&](bool tail, const int2 *gbins, const int32_t *gids, int from) __attribute__((always_inline)) {
+            const int end = gbins[tile].y;
+            if (from >= end) return;
+            int idc = gids[from];
+            Rec cur = recs[idc & idmask];
+            int idn = gids[min(from + 1, end - 1)];
+            for (int p = from; p < end; ++p) {
+                const Rec nxt = recs[idn & idmask];
+                const int idnn = idn;
+                idn = gids[min(p + 2, end - 1)];
+                const unsigned m = ((qm_on ? qm_bits(idc, cur.ex) : quadrant_mask(cur, qcx, qcy, true)) >> shift_q) & 3u;
+                if (m != 0u && !entry(cur, 0, m, 0.f, tail, p, true)) break;
+                cur = nxt;
+                idc = idnn;
+            }
+        };
+        if (rO < 0) rO = cO;
+        if (own >= 0) own_rest(own == 1, G.own_bins, G.own_ids, baseO + rO);
+        int lh = wave_max_i(max(in0 ? lastH0 : 0, in1 ? lastH1 : 0));
+        int lt = wave_max_i(max(in0 ? lastT0 : 0, in1 ? lastT1 : 0));
+        if (lane == 0 && lh > 0) atomicMax(G.kmax + 2 * tile, lh);
+        if (lane == 0 && lt > 0) atomicMax(G.kmax + 2 * n_tiles_ + 2 * tile, lt);
+        const int HW = W * H;
+        float *gT = G.state;
+        int32_t *gI = reinterpret_cast<int32_t *>(G.state + 2 * (size_t)HW);
+        if (in0) {
+            gT[pix] = fabsf(TH.x); gI[pix] = lastH0;
+            gT[HW + pix] = fabsf(TT.x); gI[HW + pix] = lastT0;
+        }
+        if (in1) {
+            gT[pix + 8] = fabsf(TH.y); gI[pix + 8] = lastH1;
+            gT[HW + pix + 8] = fabsf(TT.y); gI[HW + pix + 8] = lastT1;
         }
     }
     if (tile_kmax) {
@@ -639,6 +840,93 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
         out_img[3 * pix + 25] = fmaf(Tq, bg1, C1.y);
         out_img[3 * pix + 26] = fmaf(Tq, bg2, C2.y);
         if constexpr (DEPTH) out_depth[pix + 8] = Dp.y;
+    }
+}
+
+template <bool EXACT, bool GATHER, bool DEPTH, bool GROUPS = false>
+__global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int tiles_x, int n_tiles_,
+                                                           const int2 *__restrict__ bins,
+                                                           const Rec *__restrict__ recs,
+                                                           const int32_t *__restrict__ ids,
+                                                           const float *__restrict__ bg, float *__restrict__ out_img,
+                                                           float *__restrict__ final_T,
+                                                           int32_t *__restrict__ final_idx, int swz,
+                                                           int batch_thresh, const int32_t *__restrict__ tile_order,
+                                                           int32_t *__restrict__ tile_kmax,
+                                                           const float *__restrict__ depths,
+                                                           float *__restrict__ out_depth,
+                                                           const int32_t *__restrict__ skip_flag, int use_qm,
+                                                           const FwdGroups G) {
+    static_assert(!GROUPS || GATHER, "group accumulations: gather mode");
+    if (skip_flag != nullptr && *skip_flag == 0) return;   // the caller already holds this pass's result (sgn_depth_reuse)
+    __shared__ float4 stage[2][64 * 3];
+    __shared__ float stage_d[DEPTH ? 2 : 1][64];
+    // The first n_long tiles of the launch order (sgn_tile_order with long_thresh: the longest lists) get four waves
+    // each, the others two.  Blocks come in groups of eight tiles (8 x 4, then 8 x 2 blocks): block b runs on XCD
+    // b % 8, so a tile's waves share an XCD (and its L2) and are dispatched together, longest tiles first.  No block
+    // inside the two regions is empty: interleaving waves that exit at once with working ones left half of the SIMDs
+    // idle (the dispatcher places consecutive workgroups round-robin), 267 vs 159 us on the benchmark scene.
+    const int n_long = tile_order ? min(max(tile_order[n_tiles_], 0), n_tiles_) : 0;
+    const int b_long = ((n_long + 7) >> 3) << 5;
+    const int b = (int)blockIdx.x;
+    int t_idx, wv;
+    const bool is_long = b < b_long;
+    if (is_long) {
+        t_idx = (b >> 5) * 8 + (b & 7);
+        wv = (b >> 3) & 3;
+        if (t_idx >= n_long) return;
+    } else {
+        const int b2 = b - b_long;
+        t_idx = n_long + (b2 >> 4) * 8 + (b2 & 7);
+        wv = (b2 >> 3) & 1;
+        if (t_idx >= n_tiles_) return;
+    }
+    int tile = xcd_tile(t_idx, n_tiles_, swz);
+    if (tile_order) tile = tile_order[tile];
+    if constexpr (GROUPS) {
+        // A tile that holds NO entry of the group with its own list (most tiles: the objects cover a part of the image)
+        // needs no group arithmetic at all: the other group's pass IS the main pass there — same list, same arithmetic —
+        // and the own-list group's pass is empty.  Such tiles run the plain walk and copy its per-pixel state.
+        bool mixed = true;
+        if (G.own >= 0) {
+            const int2 ob = G.own_bins[tile];
+            mixed = ob.y > ob.x;
+        }
+        if (mixed) {
+            raster_fwd_pk_body<EXACT, GATHER, DEPTH, true>(tile, wv, is_long, W, H, tiles_x, n_tiles_, bins, recs, ids, bg,
+                                                           out_img, final_T, final_idx, batch_thresh, tile_kmax, depths,
+                                                           out_depth, use_qm, G, stage, stage_d);
+            return;
+        }
+        raster_fwd_pk_body<EXACT, GATHER, DEPTH, false>(tile, wv, is_long, W, H, tiles_x, n_tiles_, bins, recs, ids, bg,
+                                                        out_img, final_T, final_idx, batch_thresh, tile_kmax, depths,
+                                                        out_depth, use_qm, G, stage, stage_d);
+        const int lane = threadIdx.x, tx = tile % tiles_x, ty = tile / tiles_x, HW = W * H;
+        const int other = 1 - G.own;
+        float *gT = G.state;
+        int32_t *gI = reinterpret_cast<int32_t *>(G.state + 2 * (size_t)HW);
+        int lm = 0;
+        auto copy_px = [&](int j, int i) __attribute__((always_inline)) {
+            if (j < W && i < H) {
+                const int pix = i * W + j;
+                const int im = final_idx[pix];          // written by this very lane a moment ago
+                gT[other * HW + pix] = final_T[pix]; gI[other * HW + pix] = im;
+                gT[G.own * HW + pix] = 1.f; gI[G.own * HW + pix] = 0;
+                lm = max(lm, im);
+            }
+        };
+        if (is_long) {                                  // four waves, one 8x8 quadrant each
+            copy_px(tx * 16 + (wv & 1) * 8 + (lane & 7), ty * 16 + (wv >> 1) * 8 + (lane >> 3));
+        } else {                                        // two waves, a 16x8 half each
+            copy_px(tx * 16 + (lane & 7), ty * 16 + wv * 8 + (lane >> 3));
+            copy_px(tx * 16 + 8 + (lane & 7), ty * 16 + wv * 8 + (lane >> 3));
+        }
+        lm = wave_max_i(lm);
+        if (lane == 0 && lm > 0) atomicMax(G.kmax + other * 2 * n_tiles_ + 2 * tile, lm);
+    } else {
+        raster_fwd_pk_body<EXACT, GATHER, DEPTH, false>(tile, wv, is_long, W, H, tiles_x, n_tiles_, bins, recs, ids, bg,
+                                                        out_img, final_T, final_idx, batch_thresh, tile_kmax, depths,
+                                                        out_depth, use_qm, G, stage, stage_d);
     }
 }
 
@@ -1093,15 +1381,19 @@ SGN_EXPORT int sgn_raster_build_rows(int n, const float *xys, const float *conic
     return 0;
 }
 
-SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
-                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
-                              const float *conics, const float *colors, const float *opacities,
-                              int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
-                              float *out_img, float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes,
-                              int rows_built, const int32_t *tile_order, int32_t *tile_kmax,
-                              const float *depths, float *out_depth, const int32_t *skip_flag,
-                              const sgn_raster_opts *opts, sgn_stream_t stream) {
+static int raster_fwd_impl(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                           const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                           const float *conics, const float *colors, const float *opacities,
+                           int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
+                           float *out_img, float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes,
+                           int rows_built, const int32_t *tile_order, int32_t *tile_kmax,
+                           const float *depths, float *out_depth, const int32_t *skip_flag,
+                           const sgn_raster_opts *opts, sgn_stream_t stream, const FwdGroups *groups) {
     const sgn_raster_opts o = resolve_opts(opts);
+    // group accumulations ride on the packed two-waves-per-tile forward of the gather mode only
+    SGN_ARG_CHECK(groups == nullptr || (o.gather && o.waves_fwd == 2 && block_width == 16 && !window && !skip_flag), -12);
+    FwdGroups Gv = {};
+    if (groups) Gv = *groups;
     SGN_ARG_CHECK((depths == nullptr) == (out_depth == nullptr), -8);
     SGN_ARG_CHECK(skip_flag == nullptr || (rows_built && o.gather), -9);   // a skipped pass builds no rows of its own
     SGN_ARG_CHECK(!(window && depths), -10);                               // the depth channel is a whole-scene pass
@@ -1121,16 +1413,22 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
     const Rec *rows = (const Rec *)recs_ws;
     const Rec *stream_recs = rows + n;
     if (tile_kmax) SGN_HIP_CHECK(hipMemsetAsync(tile_kmax, 0, sizeof(int32_t) * 2 * tiles_x * tiles_y, s));
+    if (groups) SGN_HIP_CHECK(hipMemsetAsync(Gv.kmax, 0, sizeof(int32_t) * 4 * tiles_x * tiles_y, s));
     sgn_timing_begin(SGN_T_RASTER_FWD, s);
 #define SGN_LAUNCH_FWD(EX, GA, Q, AD, DE)                                                                            \
     hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD, DE>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
                        img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
                        gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, o.adapt_fwd, o.xcd_swizzle, o.batch_fwd,   \
                        tile_order, tile_kmax, depths, out_depth, skip_flag, o.ids_qmask)
-#define SGN_LAUNCH_FWD_PK(EX, GA, DE)                                                                                \
-    hipLaunchKernelGGL((raster_fwd_pk_kernel<EX, GA, DE>), dim3(((tiles_x * tiles_y + 7) / 8) * 32 + 32), dim3(64), 0, s, img_w, img_h,    \
+#define SGN_LAUNCH_FWD_PKG(EX, GA, DE, GR)                                                                           \
+    hipLaunchKernelGGL((raster_fwd_pk_kernel<EX, GA, DE, GR>), dim3(((tiles_x * tiles_y + 7) / 8) * 32 + 32), dim3(64), 0, s, img_w, img_h,    \
                        tiles_x, tiles_x * tiles_y, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, background3,  \
-                       out_img, final_Ts, final_idx, o.xcd_swizzle, o.batch_fwd, tile_order, tile_kmax, depths, out_depth, skip_flag, o.ids_qmask)
+                       out_img, final_Ts, final_idx, o.xcd_swizzle, o.batch_fwd, tile_order, tile_kmax, depths, out_depth, skip_flag, o.ids_qmask, Gv)
+#define SGN_LAUNCH_FWD_PK(EX, GA, DE)                                                   \
+    do {                                                                                \
+        if (GA && groups) SGN_LAUNCH_FWD_PKG(EX, GA, DE, GA);                           \
+        else SGN_LAUNCH_FWD_PKG(EX, GA, DE, false);                                     \
+    } while (0)
 #define SGN_LAUNCH_FWD3(EX, GA, DE)                                                     \
     do {                                                                                \
         if (o.waves_fwd == 2 && block_width == 16) SGN_LAUNCH_FWD_PK(EX, GA, DE);       \
@@ -1147,10 +1445,59 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
 #undef SGN_LAUNCH_FWD2
 #undef SGN_LAUNCH_FWD3
 #undef SGN_LAUNCH_FWD_PK
+#undef SGN_LAUNCH_FWD_PKG
 #undef SGN_LAUNCH_FWD
     sgn_timing_end(SGN_T_RASTER_FWD, s);
     SGN_LAUNCH_CHECK();
     return 0;
+}
+
+SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                              const float *conics, const float *colors, const float *opacities,
+                              int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
+                              float *out_img, float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes,
+                              int rows_built, const int32_t *tile_order, int32_t *tile_kmax,
+                              const float *depths, float *out_depth, const int32_t *skip_flag,
+                              const sgn_raster_opts *opts, sgn_stream_t stream) {
+    return raster_fwd_impl(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                           opacities, opacity_is_logit, id_lo, id_hi, window, background3, out_img, final_Ts, final_idx,
+                           recs_ws, recs_ws_bytes, rows_built, tile_order, tile_kmax, depths, out_depth, skip_flag, opts,
+                           stream, nullptr);
+}
+
+// The forward with the two GROUP accumulations riding on it (FwdGroups above): besides everything sgn_raster_fwd
+// writes, the final transmittance / final index / per-tile walk depth of the pass that would render only ids < split
+// ("head") and of the pass that would render only ids >= split ("tail") over the same list — bit-equal to what two more
+// sgn_raster_fwd calls with id ranges [0, split) / [split, n) produce (tests/test_gpu_groups.py).  `own_group` (0 head,
+// 1 tail, -1 none) + `own_ids` / `own_bins`: ONE group may come with its own compacted list (sgn_list_window) — the one
+// its backward will walk: its final indices are then positions of that list, and it finishes its walk there.
+// group_state [4][H*W]: T_head, T_tail, (int32) idx_head, idx_tail; group_stats [2][tiles*2] like tile_stats.
+// Packed two-waves-per-tile forward of the gather mode only (opts: gather = 1, waves_fwd = 2; block_width 16), whole
+// scene (no id window), rows already built or built here; -12 otherwise.
+SGN_EXPORT int sgn_raster_fwd_groups(int img_h, int img_w, int n, int64_t n_isect, const int32_t *gaussian_ids_sorted,
+                                     const int32_t *tile_bins, const float *xys, const float *conics,
+                                     const float *colors, const float *opacities, int opacity_is_logit,
+                                     const float *background3, float *out_img, float *final_Ts, int32_t *final_idx,
+                                     void *recs_ws, size_t recs_ws_bytes, int rows_built, const int32_t *tile_order,
+                                     int32_t *tile_kmax, const float *depths, float *out_depth, int split,
+                                     int own_group, const int32_t *own_ids, const int32_t *own_bins,
+                                     float *group_state, int32_t *group_stats, const sgn_raster_opts *opts,
+                                     sgn_stream_t stream) {
+    SGN_ARG_CHECK(group_state && group_stats, -13);
+    SGN_ARG_CHECK(split >= 0 && split <= n, -14);
+    SGN_ARG_CHECK(own_group >= -1 && own_group <= 1 && ((own_group >= 0) == (own_ids != nullptr)) &&
+                      ((own_group >= 0) == (own_bins != nullptr)), -15);
+    FwdGroups g;
+    g.split = split;
+    g.own = own_group;
+    g.own_bins = (const int2 *)own_bins;
+    g.own_ids = own_ids;
+    g.state = group_state;
+    g.kmax = group_stats;
+    return raster_fwd_impl(img_h, img_w, 16, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities,
+                           opacity_is_logit, 0, n, 0, background3, out_img, final_Ts, final_idx, recs_ws, recs_ws_bytes,
+                           rows_built, tile_order, tile_kmax, depths, out_depth, nullptr, opts, stream, &g);
 }
 
 // ------------------------------------------------------------------ reuse of the depth channel (r03)

@@ -87,6 +87,8 @@ SIGNATURES = {
     "sgn_tile_order": (_i, [_i, _vp, _vp, _i, _i, _vp, _vp, _sz, _vp]),
     "sgn_raster_fwd": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                             _sz, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sgn_raster_fwd_groups": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i,
+                                   _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "sgn_colors_match_depths": (_i, [_i, _vp, _vp, _vp, _vp]),
     "sgn_depth_reuse": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

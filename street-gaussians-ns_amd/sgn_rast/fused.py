@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Optional
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -340,7 +342,7 @@ def spherical_harmonics_fused(degrees_to_use: int, means, cam_pos, features_dc, 
 
 def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors, opacity_logits, img_height,
                               img_width, block_width, background=None, return_alpha=False, id_range=None,
-                              depth_channel=False):
+                              depth_channel=False, group_split=None):
     """``rasterize_gaussians(..., torch.sigmoid(opacity_logits), ...)`` with the sigmoid (and its backward)
     folded into the record build / gradient unpack kernels.
 
@@ -353,11 +355,32 @@ def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors,
     ``depth_channel=True`` returns ``(img, alpha, depth)`` with ``depth[H,W] = sum_g depths_g alpha_g T_g`` accumulated
     by the SAME pass (one fma per evaluated pair) — the image the reference pays a second rasterization of
     ``depths.repeat(1, 3)`` for (``sgn_splatfacto.py:982-994``); it carries no gradient (the reference's depth output
-    enters no loss)."""
+    enters no loss).
+
+    ``group_split=s`` returns ``(img, alpha, depth or None, acc_head, acc_tail)``: besides the pass itself, the
+    accumulation images of the two passes that would render only the Gaussians ``id < s`` / only those ``id >= s`` —
+    what two more calls with ``id_range=(0, s)`` / ``(s, N)`` return as their alpha (bit-equal), i.e. the scene graph's
+    ``background_acc`` / ``object_acc`` (``sgn_splatfacto_scene_graph.py:364-366``) — accumulated by the SAME walk
+    (``sgn_raster_fwd_groups``: each entry belongs to one group and its alpha is evaluated once); each of the two that
+    reaches the loss costs one alpha-only reverse walk in the backward.  Kernel options the combined walk does not
+    cover fall back to the three calls."""
     assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
     if background is None:
         background = torch.ones(3, dtype=torch.float32, device=colors.device)
-    return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(), conics.contiguous(),
-                                     num_tiles_hit.contiguous(), colors.contiguous(), opacity_logits.contiguous(),
-                                     img_height, img_width, block_width, background.contiguous(), return_alpha, True,
-                                     id_range, bool(depth_channel))
+    args = (xys.contiguous(), depths.contiguous(), radii.contiguous(), conics.contiguous(), num_tiles_hit.contiguous(),
+            colors.contiguous(), opacity_logits.contiguous(), img_height, img_width, block_width, background.contiguous())
+    if group_split is not None:
+        assert id_range is None, "group_split splits the whole scene"
+        ro, n = L.opts(), xys.shape[0]
+        s = min(max(int(group_split), 0), n)
+        if group_accumulation_enabled and ro.gather and ro.waves_fwd == 2 and block_width == 16:
+            return _RasterizeGaussians.apply(*args, True, True, None, bool(depth_channel), False, None, s)
+        main = _RasterizeGaussians.apply(*args, True, True, None, bool(depth_channel))
+        accs = [_RasterizeGaussians.apply(*args, True, True, (lo, hi), False)[1] if hi > lo
+                else torch.zeros(img_height, img_width, dtype=torch.float32, device=xys.device)
+                for lo, hi in ((0, s), (s, n))]
+        return main[0], main[1], (main[2] if depth_channel else None), accs[0], accs[1]
+    return _RasterizeGaussians.apply(*args, return_alpha, True, id_range, bool(depth_channel))
+
+
+group_accumulation_enabled = os.environ.get("SGN_GROUP_ACC", "1") != "0"   # A/B: "0" = the three separate passes

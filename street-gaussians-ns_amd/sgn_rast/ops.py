@@ -1106,6 +1106,7 @@ def _list_window(ids: torch.Tensor, tile_bins: torch.Tensor, lo: int, hi: int, q
 # "on" / "off" force it.  The fused API asks for the channel explicitly (rasterize_gaussians_fused(depth_channel=True)).
 depth_channel = os.environ.get("SGN_DEPTH_CHANNEL", "auto")
 depth_stats = {"accumulated": 0, "reused": 0, "proved_on_host": 0}
+group_stats = {"passes": 0, "backward_passes": 0}    # forwards that carried the two group accumulations; their backwards
 
 
 def _depth_wanted() -> bool:
@@ -1125,7 +1126,7 @@ class _RasterizeGaussians(Function):
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
                 block_width, background=None, return_alpha=False, opacity_is_logit=False, id_range=None,
-                want_depth=False, colors_are_depths=False, colors_pre=None, *opacity_logits):
+                want_depth=False, colors_are_depths=False, colors_pre=None, group_split=None, *opacity_logits):
         # opacity_logits / colors_pre (proven by rasterize_gaussians, see proofs.sigmoid_leaves / clamp_pre): `opacity`
         # is sigmoid(cat(opacity_logits, 0)) and `colors` is clamp(colors_pre, min=0); both arrive DETACHED and the
         # gradients go to the extra inputs instead (the activations' backward runs inside sgn_raster_bwd's unpack kernel)
@@ -1171,7 +1172,7 @@ class _RasterizeGaussians(Function):
         # pass's fourth channel), or a first pass that should accumulate the channel?
         plain = win is None and id_range is None and num_points > 0 and bool(ro.gather) and cull
         dcache = S.depth_caches.get(key)
-        reuse = (plain and hit and not want_depth and depth_channel != "off" and dcache is not None
+        reuse = (plain and hit and not want_depth and group_split is None and depth_channel != "off" and dcache is not None
                  and colors_c.shape == (num_points, 3) and dcache["D"].shape == (img_height, img_width))
         if plain and hit and not reuse and depth_channel == "auto" and not want_depth:
             _depth_state["want"] = True        # a second pass over the same geometry: accumulate from the next step on
@@ -1229,6 +1230,47 @@ class _RasterizeGaussians(Function):
             tile_bins = torch.zeros(tile_bounds[0] * tile_bounds[1], 2, dtype=torch.int32, device=dev)
             final_Ts = torch.ones(img_height, img_width, **f32)
             final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
+        elif group_split is not None:
+            # the main pass with the two group accumulations riding on it (sgn_raster_fwd_groups): head = ids below the
+            # split, tail = the others.  The smaller group, if small enough, gets its own compacted list: its backward
+            # walks that list, so its indices are recorded in that list's positions (and its forward walk finishes
+            # there); the other one walks the shared list (with the first group's rows inert).
+            assert win is None and id_range is None and ro.gather and ro.waves_fwd == 2 and block_width == 16
+            if not rows_built:
+                recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
+            order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
+            n_tiles = tile_bins.shape[0]
+            tile_kmax = torch.empty(n_tiles, 2, dtype=torch.int32, device=dev)
+            split = min(max(int(group_split), 0), n_full)
+            sizes = (split, n_full - split)
+            small = 0 if sizes[0] <= sizes[1] else 1
+            own = small if (list_window_enabled and 0 < sizes[small] < list_window_max_frac * n_full) else -1
+            state = torch.empty(4, img_height, img_width, **f32)          # T_head, T_tail, idx_head, idx_tail
+            kmax = torch.empty(2, n_tiles, 2, dtype=torch.int32, device=dev)
+            groups = []
+            for gi, (lo, hi) in enumerate(((0, split), (split, n_full))):
+                g_ids, g_bins = (_list_window(gaussian_ids_sorted, tile_bins, lo, hi, ro.ids_qmask) if gi == own
+                                 else (gaussian_ids_sorted, tile_bins))
+                window_stats["sub_lists"] += int(gi == own)
+                groups.append(dict(lo=lo, hi=hi, own=gi == own, ids=g_ids, bins=g_bins, T=state[gi],
+                                   idx=state[2 + gi].view(torch.int32), kmax=kmax[gi]))
+            og = groups[own] if own >= 0 else None
+            L.check(lib.sgn_raster_fwd_groups(
+                img_height, img_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
+                L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), L.ptr(bg_c),
+                L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), rows_built, L.ptr(order),
+                L.ptr(tile_kmax), L.ptr(depths_c) if accumulate else None, L.ptr(out_depth), split, own,
+                L.ptr(og["ids"]) if og else None, L.ptr(og["bins"]) if og else None, L.ptr(state), L.ptr(kmax),
+                ro_ptr, stream_ptr), "sgn_raster_fwd_groups")
+            group_stats["passes"] += 1
+            ctx.groups = groups
+            if accumulate:
+                depth_stats["accumulated"] += 1
+                S.depth_caches[key] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
+                while len(S.depth_caches) > _State.BIN_ENTRIES:
+                    S.depth_caches.popitem(last=False)
+            elif not hit:
+                S.depth_caches.pop(key, None)
         else:
             if not rows_built:
                 recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
@@ -1272,6 +1314,15 @@ class _RasterizeGaussians(Function):
         ctx.recs = recs
         ctx.save_for_backward(gaussian_ids_sorted, tile_bins, xys_c, conics_c, colors_c, opac_c, bg_c,
                               final_Ts, final_idx, *([_f32c(colors_pre)] if colors_pre is not None else []))
+        if group_split is not None:
+            if want_depth and out_depth is None:
+                out_depth = torch.zeros(img_height, img_width, **f32)
+            if out_depth is not None:
+                ctx.mark_non_differentiable(out_depth)
+            gs = getattr(ctx, "groups", None)
+            accs = [(1 - g["T"]) if gs is not None else torch.zeros(img_height, img_width, **f32)
+                    for g in (gs or (None, None))]
+            return out_img, 1 - final_Ts, out_depth, accs[0], accs[1]
         if want_depth:
             if out_depth is None:                 # nothing visible / a path without the channel: the two-pass image
                 out_depth = torch.zeros(img_height, img_width, **f32)
@@ -1284,7 +1335,7 @@ class _RasterizeGaussians(Function):
         return out_img
 
     @staticmethod
-    def backward(ctx, v_out_img, v_out_alpha=None, _v_depth=None):
+    def backward(ctx, v_out_img, v_out_alpha=None, _v_depth=None, v_acc_head=None, v_acc_tail=None):
         (gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity, background, final_Ts,
          final_idx) = ctx.saved_tensors[:9]
         colors_pre = ctx.saved_tensors[9] if ctx.grad_to_pre else None
@@ -1292,6 +1343,11 @@ class _RasterizeGaussians(Function):
         n = xys.shape[0]                     # rows of the caller's tensors (= the window's rows in window mode)
         H, W = ctx.img_height, ctx.img_width
         f32 = dict(dtype=torch.float32, device=dev)
+        groups = getattr(ctx, "groups", None)
+        # the two group accumulations (sgn_raster_fwd_groups): each one that reached the loss is one more reverse walk
+        # — of the group's own list or of the shared one — with the state its forward recorded; alpha only
+        group_work = [(g, v) for g, v in zip(groups or (), (v_acc_head, v_acc_tail)) if v is not None and g["hi"] > g["lo"]]
+        main = not (group_work and v_out_img is None and v_out_alpha is None)     # (nothing but group outputs in the loss)
         if v_out_alpha is None:
             v_out_alpha = torch.zeros(H, W, **f32)
         # only the alpha output reached the loss (the scene graph's accumulation passes, scene_graph.py:364-366): the
@@ -1300,16 +1356,15 @@ class _RasterizeGaussians(Function):
         no_color_grad = v_out_img is None                   # (the kernel takes NULL for "zeros": no fill, no read)
         v_out_img = None if v_out_img is None else _f32c(v_out_img)
         v_out_alpha = _f32c(v_out_alpha)
-        v_xy = torch.empty(n, 2, **f32)
-        v_conic = torch.empty(n, 3, **f32)
-        v_colors = torch.empty(n, 3, **f32)
-        v_opacity = torch.empty(n, **f32)
-        if ctx.num_intersects < 1:
-            v_xy.zero_(); v_conic.zero_(); v_colors.zero_(); v_opacity.zero_()
-        else:
+
+        def one_pass(ids, bins, Ts, idx, kmax, v_img, v_alpha, id_range, window, recs, pre):
+            v_xy = torch.empty(n, 2, **f32)
+            v_conic = torch.empty(n, 3, **f32)
+            v_colors = torch.empty(n, 3, **f32)
+            v_opacity = torch.empty(n, **f32)
             lib = L.load()
             ro_ptr = C.byref(ctx.ro)
-            recs, packed = ctx.recs, 1
+            packed = 1
             if recs is None:
                 recs = L.workspace(lib.sgn_raster_workspace_bytes(ctx.n_full, ctx.num_intersects, ro_ptr), dev)
                 packed = 0
@@ -1317,18 +1372,42 @@ class _RasterizeGaussians(Function):
             # the backward's own launch order, by REVERSE-WALK length (tried in r03: the forward's order by list length
             # plus per-tile classification, no launch — the one-wave kernel then ran 323 instead of 288 us on the
             # benchmark scene: a late long walk is a lone-wave tail; profiles/r03f_*)
-            order = _tile_order(tile_bins, ctx.tile_kmax, ctx.ro.adapt_bwd)
-            if order is not None and not ctx.window and ctx.id_range == (0, n):
+            order = _tile_order(bins, kmax, ctx.ro.adapt_bwd)
+            if order is not None and not window and id_range == (0, n):
                 _S().walk_stat = order[-1:]          # rides to the host with the next binning's count (mask policy)
             L.check(lib.sgn_raster_bwd(
-                H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
+                H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(ids), L.ptr(bins),
                 L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity),
-                2 if ctx.grad_to_logits else ctx.opacity_is_logit, ctx.id_range[0],
-                ctx.id_range[1], ctx.window, L.ptr(background), L.ptr(final_Ts),
-                L.ptr(final_idx), L.ptr(v_out_img), L.ptr(v_out_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
+                2 if ctx.grad_to_logits else ctx.opacity_is_logit, id_range[0],
+                id_range[1], window, L.ptr(background), L.ptr(Ts),
+                L.ptr(idx), L.ptr(v_img), L.ptr(v_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
                 L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
-                L.ptr(gws), gws.numel(), L.ptr(order), L.ptr(colors_pre), ro_ptr, L.stream_ptr(),
+                L.ptr(gws), gws.numel(), L.ptr(order), L.ptr(pre), ro_ptr, L.stream_ptr(),
                 L.aux_stream_ptr(dev) if concurrent_backward else None), "sgn_raster_bwd")
+            return v_xy, v_conic, v_colors, v_opacity
+
+        if ctx.num_intersects < 1 or not (main or group_work):
+            v_xy, v_conic = torch.zeros(n, 2, **f32), torch.zeros(n, 3, **f32)
+            v_colors, v_opacity = torch.zeros(n, 3, **f32), torch.zeros(n, **f32)
+        else:
+            grads = None
+            if main:
+                grads = one_pass(gaussian_ids_sorted, tile_bins, final_Ts, final_idx, ctx.tile_kmax, v_out_img,
+                                 v_out_alpha, ctx.id_range, ctx.window, ctx.recs, colors_pre)
+            else:
+                no_color_grad = True
+            for g, v in group_work:
+                group_stats["backward_passes"] += 1
+                # its own list holds the group's entries only: the main pass's rows serve; on the shared list the other
+                # group's rows must be inert, so the rows are built again for the id range (recs = None)
+                part = one_pass(g["ids"], g["bins"], g["T"], g["idx"], g["kmax"], None, _f32c(v), (g["lo"], g["hi"]), 0,
+                                ctx.recs if g["own"] else None, None)
+                if grads is None:
+                    grads = part
+                else:
+                    for a, b in zip((grads[0], grads[1], grads[3]), (part[0], part[1], part[3])):
+                        a.add_(b)                  # (a group pass has no colour gradient: v_out_img = NULL)
+            v_xy, v_conic, v_colors, v_opacity = grads
         v_opacity = v_opacity.reshape(ctx.opacity_shape)
         if no_color_grad:
             v_colors = None
@@ -1336,10 +1415,10 @@ class _RasterizeGaussians(Function):
         if ctx.grad_to_logits:
             v_logits = (v_opacity,) if len(ctx.logit_rows) == 1 else v_opacity.split(ctx.logit_rows)
         # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha,
-        #  opacity_is_logit, id_range, want_depth, colors_are_depths, colors_pre, *opacity_logits)
+        #  opacity_is_logit, id_range, want_depth, colors_are_depths, colors_pre, group_split, *opacity_logits)
         return (v_xy, None, None, v_conic, None, None if ctx.grad_to_pre else v_colors,
                 None if ctx.grad_to_logits else v_opacity) + (None,) * 9 + (
-            v_colors if ctx.grad_to_pre else None,) + tuple(v_logits)
+            v_colors if ctx.grad_to_pre else None, None) + tuple(v_logits)
 
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height: int,
@@ -1371,7 +1450,7 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
                                      (opacity.detach() if logits else opacity).contiguous(), img_height,
                                      img_width, block_width, background.contiguous(), return_alpha, False, None, False,
                                      depth_channel != "off" and proofs.enabled() and _provably_depths(colors, depths),
-                                     pre, *logits)
+                                     pre, None, *logits)
 
 
 # -------------------------------------------------------------- _torch_impl

@@ -114,7 +114,8 @@ def render(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, b
 def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int = 3, block_width: int = 16,
                  background: Optional[torch.Tensor] = None, with_depth: bool = False,
                  object_ids: Optional[torch.Tensor] = None, poses: Optional[torch.Tensor] = None,
-                 idft: Optional[torch.Tensor] = None, depth_channel: bool = True) -> SimpleNamespace:
+                 idft: Optional[torch.Tensor] = None, depth_channel: bool = True,
+                 group_split: Optional[int] = None) -> SimpleNamespace:
     """Same result as :func:`render` on the scene-graph-aggregated parameters, through the fused front
     ends (:mod:`sgn_rast.fused`): raw parameters in, no activation / concat / transform kernels.
     ``P["means"]`` / ``P["quats"]`` are in each object's LOCAL frame when ``object_ids``/``poses`` are given;
@@ -137,10 +138,16 @@ def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int 
     rgbs = fused.spherical_harmonics_fused(sh_degree_to_use, P["means"], cam.cam_pos, P["features_dc"],
                                            P["features_rest"], object_ids=object_ids, idft=idft, poses=poses)
     if with_depth and depth_channel:
-        # the depth image rides in the colour pass as a fourth channel (no second rasterization)
-        rgb, alpha, depth_im = fused.rasterize_gaussians_fused(
-            xys, depths, radii, conics, num_tiles_hit, rgbs, P["opacity_logits"], H, W, block_width,
-            background=background, return_alpha=True, depth_channel=True)
+        # the depth image rides in the colour pass as a fourth channel (no second rasterization) — and, with
+        # `group_split`, so do the accumulations of the ids below / from the split (the scene graph's two sub-model passes)
+        if group_split is not None:
+            rgb, alpha, depth_im, out.acc_head, out.acc_tail = fused.rasterize_gaussians_fused(
+                xys, depths, radii, conics, num_tiles_hit, rgbs, P["opacity_logits"], H, W, block_width,
+                background=background, return_alpha=True, depth_channel=True, group_split=group_split)
+        else:
+            rgb, alpha, depth_im = fused.rasterize_gaussians_fused(
+                xys, depths, radii, conics, num_tiles_hit, rgbs, P["opacity_logits"], H, W, block_width,
+                background=background, return_alpha=True, depth_channel=True)
         out.rgb, out.alpha, out.rgbs = rgb, alpha, rgbs
         out.depth = torch.where(alpha[..., None] > 1e-3, depth_im[..., None] / alpha[..., None], 10)   # :995
         return out
@@ -158,7 +165,7 @@ def render_fused(P: Dict[str, torch.Tensor], cam: Camera, sh_degree_to_use: int 
 
 def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Camera, sh_degree_to_use: int = 3,
                        block_width: int = 16, ops=_hip_ops, fused: bool = False,
-                       caller_syncs: bool = True, sh_parts: bool = True) -> SimpleNamespace:
+                       caller_syncs: bool = True, sh_parts: bool = True, groups: bool = True) -> SimpleNamespace:
     """Replay of ``SplatfactoSceneGraphModel.get_outputs`` in training mode
     (``sgn_splatfacto_scene_graph.py:305-366``): ``models[0]`` is the background, ``models[i>0]`` rigid objects
     whose parameters live in the object's local frame; ``poses[i]`` = [R(9) t(3) q_o2w(4)], ``idft[i]`` = Fourier
@@ -194,8 +201,13 @@ def render_scene_graph(models, poses: torch.Tensor, idft: torch.Tensor, cam: Cam
         fw = min(Fmax, idft.shape[1])
         idft_p[:, :fw] = idft[:, :fw]
         idft_p = idft_p * _CONST[mask_key]
+        # `groups`: object_acc / background_acc ride on the main pass's walk (rasterize_gaussians_fused(group_split));
+        # False keeps the round-3 form, two more id-range passes, for A/B and for the tests
         out = render_fused(P, cam, sh_degree_to_use, block_width, with_depth=True, object_ids=object_ids,
-                           poses=poses, idft=idft_p)
+                           poses=poses, idft=idft_p, group_split=counts[0] if groups else None)
+        if groups:
+            out.object_acc, out.background_acc = out.acc_tail, out.acc_head                 # :364-366
+            return out
         opac_arg, raster = P["opacity_logits"], F_.rasterize_gaussians_fused
     else:
         world_means, world_quats, dcs = [], [], []

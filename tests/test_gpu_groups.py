@@ -1,0 +1,134 @@
+"""GPU (-m gpu): the two group accumulations that ride on the main forward walk (`sgn_raster_fwd_groups`,
+`rasterize_gaussians_fused(group_split=...)`) against what they replace — two more passes of the same operator with id
+ranges [0, split) and [split, N) (the scene graph's background-only / objects-only accumulation passes,
+sgn_splatfacto_scene_graph.py:364-366).  Forward: BIT-EQUAL images (main pass, depth channel and both accumulations),
+with the hardware exp and the portable one, on the scalar-chase path, the LDS-batched path and the four-waves-per-tile
+path of the packed forward, with each group on its own compacted list or on the shared one.  Backward: the gradients of a
+loss over all five outputs equal the three-pass gradients to accumulation-order rounding."""
+import pytest
+import torch
+
+from helpers import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _inputs(n, split_frac, seed, W=320, H=192, focal=260.0, z=(1.5, 9.0)):
+    from sgn_rast import fused, scenes
+    cam = scenes.make_camera(W, H, focal)
+    raw = scenes.make_gaussians(n, cam, seed=seed, z_range=z)
+    P = {k: v.to(DEV).requires_grad_(True) for k, v in raw.items()}
+    xys, depths, radii, conics, _c, nth, _cov = fused.project_gaussians_fused(
+        P["means"], P["log_scales"], P["quats"], cam.viewmat[:3, :].to(DEV), cam.fx, cam.fy, cam.cx, cam.cy, H, W, 16)
+    g = torch.Generator().manual_seed(seed + 1)
+    colors = torch.rand(n, 3, generator=g).to(DEV)
+    geo = [t.detach() for t in (xys, depths, radii, conics, nth)]
+    return cam, geo, colors, P["opacity_logits"].detach(), int(n * split_frac)
+
+
+def _run(geo, colors, logits, cam, split, grouped, weights=None):
+    from sgn_rast import fused, ops
+    xys, depths, radii, conics, nth = geo
+    leaves = [xys.clone().requires_grad_(True), conics.clone().requires_grad_(True), colors.clone().requires_grad_(True),
+              logits.clone().requires_grad_(True)]
+    fused.group_accumulation_enabled = grouped
+    ops.clear_binning_cache()
+    try:
+        out = fused.rasterize_gaussians_fused(leaves[0], depths, radii, leaves[1], nth, leaves[2], leaves[3], cam.height,
+                                              cam.width, 16, background=torch.zeros(3, device=DEV), return_alpha=True,
+                                              depth_channel=True, group_split=split)
+    finally:
+        fused.group_accumulation_enabled = True
+    if weights is not None:
+        loss = sum((o * w).sum() for o, w in zip((out[0], out[1], out[3], out[4]), weights))
+        loss.backward()
+    torch.cuda.synchronize()
+    return out, [l.grad for l in leaves]
+
+
+CASES = [
+    # (n, split fraction, options, own-list fraction)        what it exercises
+    (6000, 0.85, dict(), 0.5),                               # production: tail group on its own list, head shared
+    (6000, 0.85, dict(exact_exp=1), 0.5),
+    (6000, 0.85, dict(), 1.1),                               # both groups on their own lists
+    (6000, 0.85, dict(), 0.0),                               # both on the shared list
+    (6000, 0.40, dict(batch_fwd=8, batch_bwd=8), 0.5),       # LDS-batched walks everywhere, head group small
+    (20000, 0.9, dict(adapt_fwd=32, batch_fwd=1 << 30), 0.5),  # four waves per tile, scalar chase
+    (20000, 0.9, dict(adapt_fwd=32, batch_fwd=16, exact_exp=1), 0.5),  # four waves per tile, batched
+    (3000, 0.0, dict(), 0.5),                                # empty head group
+    (3000, 1.0, dict(), 0.5),                                # empty tail group
+]
+
+
+@pytest.mark.parametrize("n,frac,kw,own", CASES)
+def test_group_accumulations_equal_the_separate_passes(n, frac, kw, own):
+    from sgn_rast import _lib as L, ops
+    cam, geo, colors, logits, split = _inputs(n, frac, seed=n % 97)
+    g = torch.Generator().manual_seed(3)
+    H, W = cam.height, cam.width
+    weights = [torch.rand(H, W, 3, generator=g).to(DEV)] + [torch.rand(H, W, generator=g).to(DEV) for _ in range(3)]
+    saved = ops.list_window_max_frac
+    ops.list_window_max_frac = own
+    try:
+        with L.options(**kw):
+            before = ops.group_stats["passes"]
+            a, ga = _run(geo, colors, logits, cam, split, True, weights)
+            assert ops.group_stats["passes"] == before + 1
+            b, gb = _run(geo, colors, logits, cam, split, False, weights)
+            assert ops.group_stats["passes"] == before + 1
+    finally:
+        ops.list_window_max_frac = saved
+    for name, x, y in zip(("img", "alpha", "depth", "acc_head", "acc_tail"), a, b):
+        assert torch.equal(x, y), (name, float((x - y).abs().max()))
+    assert float(a[3].max()) > 0.2 or split == 0
+    assert float(a[4].max()) > 0.2 or split == n
+    for name, x, y in zip(("xys", "conics", "colors", "opacity_logits"), ga, gb):
+        assert rel_l2(x, y) < 2e-5, (name, rel_l2(x, y))
+        assert torch.equal(x.reshape(n, -1).abs().sum(1) == 0, y.reshape(n, -1).abs().sum(1) == 0), name
+
+
+def test_only_the_group_outputs_in_the_loss():
+    """Nothing but an accumulation reaches the loss: the main pass's reverse walk is skipped, no colour gradient."""
+    from sgn_rast import ops
+    cam, geo, colors, logits, split = _inputs(5000, 0.8, seed=11)
+    g = torch.Generator().manual_seed(5)
+    H, W = cam.height, cam.width
+    w = torch.rand(H, W, generator=g).to(DEV)
+    zero3, zero = torch.zeros(H, W, 3, device=DEV), torch.zeros(H, W, device=DEV)
+    before = ops.group_stats["backward_passes"]
+    for grouped in (True, False):
+        xys, depths, radii, conics, nth = geo
+        leaves = [xys.clone().requires_grad_(True), logits.clone().requires_grad_(True)]
+        from sgn_rast import fused
+        fused.group_accumulation_enabled = grouped
+        ops.clear_binning_cache()
+        try:
+            out = fused.rasterize_gaussians_fused(leaves[0], depths, radii, conics, nth, colors, leaves[1], H, W, 16,
+                                                  background=torch.zeros(3, device=DEV), return_alpha=True,
+                                                  depth_channel=True, group_split=split)
+        finally:
+            fused.group_accumulation_enabled = True
+        (out[4] * w).sum().backward()
+        torch.cuda.synchronize()
+        if grouped:
+            first = [l.grad.clone() for l in leaves]
+    assert ops.group_stats["backward_passes"] == before + 1
+    for x, y in zip(first, [l.grad for l in leaves]):
+        assert rel_l2(x, y) < 2e-5
+    assert float(first[0][:split].abs().max()) == 0.0 and float(first[0][split:].abs().max()) > 0
+
+
+def test_unsupported_kernel_options_fall_back_to_three_passes():
+    from sgn_rast import _lib as L, ops
+    cam, geo, colors, logits, split = _inputs(4000, 0.7, seed=2)
+    ref, _ = _run(geo, colors, logits, cam, split, True)
+    for kw in (dict(waves_fwd=4), dict(gather=0)):
+        with L.options(**kw):
+            before = ops.group_stats["passes"]
+            out, _ = _run(geo, colors, logits, cam, split, True)
+            assert ops.group_stats["passes"] == before          # the combined walk was not used
+        for name, x, y in zip(("img", "alpha", "depth", "acc_head", "acc_tail"), out, ref):
+            if name == "depth" and "gather" in kw:
+                continue                              # (the depth channel is a gather-mode feature)
+            assert float((x - y).abs().max()) < 2e-5, (kw, name)
