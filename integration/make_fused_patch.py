@@ -35,7 +35,7 @@ EDITS = [
     ("        scales_crop = torch.exp(scales_crop)\n"
      "        colors_crop = torch.cat((features_dc_crop, features_rest_crop), dim=1)\n",
      "        colors_crop = (features_dc_crop, features_rest_crop)  # sgn_fused: un-concatenated SH leaves\n"
-     "        self.sgn_main_attrs = None\n"),
+     "        self.sgn_main_attrs, self.sgn_group_acc = None, []\n"),
     ("self.num_tiles_hit, _ = project_gaussians(  # type: ignore\n"
      "            means_crop,\n"
      "            scales_crop,\n"
@@ -61,10 +61,13 @@ EDITS = [
     ("        output_names = ['rgb', 'accumulation', 'depth']\n",
      "        self.sgn_main_attrs = gaussian_attrs  # the scene graph's sub-model passes are id windows of this pass\n"
      "        output_names = ['rgb', 'accumulation', 'depth']\n"),
+    ("        out = self.render_gaussian_attrs(camera, gaussian_attrs, output_names)\n",
+     "        out = self.render_gaussian_attrs(camera, gaussian_attrs, output_names,\n"
+     "                                         group_split=getattr(self, \"sgn_group_split\", None))\n"),
     ("    def render_gaussian_attrs(self, camera: Cameras, gaussian_attrs: Dict[str, Union[torch.Tensor, List]], "
      "output_names: List[str]=[]) -> Dict[str, Union[torch.Tensor, List]]:\n",
      "    def render_gaussian_attrs(self, camera: Cameras, gaussian_attrs: Dict[str, Union[torch.Tensor, List]], "
-     "output_names: List[str]=[], id_range=None) -> Dict[str, Union[torch.Tensor, List]]:\n"),
+     "output_names: List[str]=[], id_range=None, group_split=None) -> Dict[str, Union[torch.Tensor, List]]:\n"),
     # render_gaussian_attrs: fused SH for the un-concatenated leaves
     ("        if self.config.sh_degree > 0:\n"
      "            viewdirs = means.detach() - camera.camera_to_worlds.detach()[..., :3, 3]  # (N, 3)\n",
@@ -88,7 +91,8 @@ EDITS = [
     ("            opacities = torch.sigmoid(opacities)\n",
      "            pass  # sgn_fused: sigmoid in-kernel\n"),
     ("            rgb, alpha = rasterize_gaussians(  # type: ignore\n",
-     "            rgb, alpha, depth_channel = sgn_fused.rasterize_gaussians_fused(  # depth rides as a 4th channel\n"),
+     "            # sgn_fused: depth rides as a 4th channel; with group_split so do the accumulations of ids < / >= the split\n"
+     "            rgb, alpha, depth_channel, *self.sgn_group_acc = sgn_fused.rasterize_gaussians_fused(\n"),
     ("                background=background,\n"
      "                return_alpha=True,\n"
      "            )  # type: ignore\n",
@@ -96,6 +100,7 @@ EDITS = [
      "                return_alpha=True,\n"
      "                depth_channel=True,\n"
      "                id_range=id_range,\n"
+     "                group_split=group_split,\n"
      "            )  # type: ignore\n"),
     ("            depth_im = rasterize_gaussians(\n"
      "                xys,\n"
@@ -171,6 +176,11 @@ EDITS_SG = [
      "        assert self.visible_model_names[first:first + len(submodel_names)] == list(submodel_names)\n"
      "        counts = [self.all_models[name].num_points for name in self.visible_model_names]\n"
      "        id_range = (sum(counts[:first]), sum(counts[:first + len(submodel_names)]))\n"
+     "        if output_names == ['accumulation'] and len(self.sgn_group_acc) == 2 and id_range in (\n"
+     "                (0, self.sgn_group_split), (self.sgn_group_split, sum(counts))):\n"
+     "            # the main pass's own walk accumulated this image (rasterize_gaussians_fused(group_split=...))\n"
+     "            camera.rescale_output_resolution(camera_downscale)\n"
+     "            return {'accumulation': self.sgn_group_acc[0 if id_range[0] == 0 else 1][..., None]}\n"
      "        gaussian_attrs = {k: v for k, v in self.sgn_main_attrs.items() if k != \"sky_capture\"}\n"
      "        if sky_capture is not None:\n"
      "            gaussian_attrs[\"sky_capture\"] = sky_capture\n"
@@ -200,7 +210,9 @@ EDITS_SG = [
      "        self.features_dc = ((self.background_model.features_dc, *object_features_dc) if self.config.sh_degree > 0\n"
      "                            else sgn_fused.cat_features_dc([self.background_model.features_dc, *object_features_dc]))\n"
      "        self.sgn_tables = sgn_fused.scene_graph_tables(\n"
-     "            [self.background_model.num_points] + [m.shape[0] for m in object_means], sgn_poses, sgn_idft, self.device)\n"),
+     "            [self.background_model.num_points] + [m.shape[0] for m in object_means], sgn_poses, sgn_idft, self.device)\n"
+     "        # background_acc / object_acc (below) ride on the main pass: ids below / from this split\n"
+     "        self.sgn_group_split = self.background_model.num_points if self.training else None\n"),
     ("        self.features_rest = self.get_aggreated_variable(\"features_rest\")\n",
      "        self.features_rest = (tuple(self.all_models[name].features_rest for name in self.visible_model_names)\n"
      "                              if self.config.sh_degree > 0 else self.get_aggreated_variable(\"features_rest\"))\n"),

@@ -58,16 +58,25 @@ def test_packed_forward_runs_on_the_packed_fp32_pipe(raster_asm):
     update and the three colour sums are v_pk_* instructions, and nothing spills."""
     ks = _kernels(raster_asm)
     pk = {k: t for k, t in ks.items() if "raster_fwd_pk_kernel" in k}
-    assert len(pk) == 8                                            # exact x gather x depth channel
+    assert len(pk) == 12                                           # exact x gather x depth channel, + the gather ones with groups
+    groups = {k: t for k, t in pk.items() if re.search(r"pk_kernelILb[01]ELb1ELb[01]ELb1EEE", k)}
+    assert len(groups) == 4                                        # (r04) sgn_raster_fwd_groups: exact x depth channel
+    for k, t in groups.items():
+        # the walk with the two group accumulations AND the plain walk (tiles without an entry of the own-list group)
+        # are both in the kernel; the ten-pointer descriptor of its first version spilled SGPRs to scratch memory
+        assert re.search(r"ScratchSize: 0\b", t), "the group forward spills to scratch"
+        plain = next(t2 for k2, t2 in pk.items() if k2 == k.replace("ELb1EEE", "ELb0EEE"))
+        assert t.count("v_pk_fma_f32") > 2 * plain.count("v_pk_fma_f32") - 4, k
+    pk = {k: t for k, t in pk.items() if k not in groups}
     for k, t in pk.items():
         assert re.search(r"ScratchSize: 0\b", t), "the packed forward spills to scratch"
         assert "s_load_dwordx8" in t and "ds_read_b128" in t      # scalar-chase and LDS-batched paths both compiled in
         # two code paths (scalar chase, LDS batches) x (3 colour + 2 quadratic-form) packed FMAs, + the 1-px long-tile body
         assert t.count("v_pk_fma_f32") >= 10 and t.count("v_pk_mul_f32") >= 12, k
-    fast = next(t for k, t in pk.items() if "ILb0ELb1ELb0E" in k)
+    fast = next(t for k, t in pk.items() if "ILb0ELb1ELb0ELb0E" in k)
     assert fast.count("v_exp_f32") >= 4                            # hardware exp, two per entry and path
     # the depth channel (r03) is ONE more packed fma per entry and path in the two-pixel body, nothing else
-    deep = next(t for k, t in pk.items() if "ILb0ELb1ELb1E" in k)
+    deep = next(t for k, t in pk.items() if "ILb0ELb1ELb1ELb0E" in k)
     assert 0 < deep.count("v_pk_fma_f32") - fast.count("v_pk_fma_f32") <= 3
     assert re.search(r"ScratchSize: 0\b", deep)
 
