@@ -295,6 +295,16 @@ class GradAllReducer:
         self._early = dict(pinned=pinned, done=done, ids_ptr=ids.data_ptr(), views=1, list=m["list"], can=can,
                            keep=(every, info))
 
+    def extra_pass(self) -> None:
+        """ops._touch_sink: a rasterize pass over an id range / with group accumulations ran (the scene graph's sub-model
+        passes): its backward reaches rows the walked list of the full pass does not hold — counted like another view, so
+        `_finish_sparse` refuses the step loudly instead of dropping gradient rows on the other ranks."""
+        if self.sparse and self.active:
+            if self._early is not None:
+                self._early["views"] += 1
+            else:
+                self._extra_before = True
+
     def _finish_sparse(self) -> bool:
         """One view's backward leaves most gradient rows EXACTLY zero: a Gaussian behind saturated pixels, outside the
         frustum or culled receives nothing (measured per view, `profiles/r04_touched_fraction.json`: 0.3-0.8 % of the
@@ -337,6 +347,9 @@ class GradAllReducer:
         widths = [int(p[0].numel()) if n > 0 else 0 for p in rows_p]
         count, idx, packed = 0, None, None
         early, self._early = self._early, None
+        extra_before, self._extra_before = getattr(self, "_extra_before", False), False
+        if extra_before and early is not None:
+            early["views"] += 1
         ex._fwd = dict(claimed=0, other=0, degree=-1, k=0, cam=False)
 
         def cols_of():
@@ -351,8 +364,9 @@ class GradAllReducer:
         if early is not None:
             # the announcement left right after the forward; its answer has been on the host since (no stall)
             if early["views"] != 1:
-                raise RuntimeError("GradAllReducer(sparse=True): more than one view was rendered between two finish() "
-                                   "calls — the walked-row list covers the first one only; use sparse=False")
+                raise RuntimeError("GradAllReducer(sparse=True): more than one view (or a sub-model / group pass of the "
+                                   "scene graph) was rendered between two finish() calls — the walked-row list covers "
+                                   "the first full pass only; use sparse=False")
             if early["can"] and not (can and c is not None):
                 raise RuntimeError("GradAllReducer(sparse=True): the forward announced a claimed SH node with a known "
                                    "camera, the backward did not deliver it (graph changed between forward and backward?)")

@@ -1304,6 +1304,13 @@ class _RasterizeGaussians(Function):
         if _touch_sink is not None and num_intersects >= 1 and win is None and id_range is None and not proved:
             # data-parallel row exchange: which Gaussians this view's backward can touch (the walked entries)
             _touch_sink.after_forward(gaussian_ids_sorted, tile_bins, tile_kmax, n_full, ro.ids_qmask)
+        if _touch_sink is not None and num_intersects >= 1 and (win is not None or id_range is not None
+                                                                  or group_split is not None):
+            # a sub-model pass / group accumulation walks entries the full pass's list of walked rows does not cover
+            # (its transmittance falls more slowly): the sink must not take that list for the step's touched rows
+            extra = getattr(_touch_sink, "extra_pass", None)
+            if extra is not None:
+                extra()
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
         ctx.num_intersects = num_intersects
         ctx.opacity_is_logit = int(bool(opacity_is_logit))

@@ -367,3 +367,19 @@ def test_graph_proofs_gate_on_the_torch_version(monkeypatch, caplog):
     monkeypatch.setenv("SGN_GRAPH_PROOFS", "0")
     assert not proofs.enabled()
     monkeypatch.setattr(proofs, "_enabled", None)
+
+
+def test_row_exchange_counts_sub_model_passes_as_views():
+    """A rasterize pass over an id range / with group accumulations reaches rows the full pass's walked list does not
+    hold: the sink counts it as another view (and `_finish_sparse` then refuses the step instead of dropping rows)."""
+    from types import SimpleNamespace
+    from sgn_rast import dp
+    r = SimpleNamespace(sparse=True, active=True, _early=dict(views=1))
+    dp.GradAllReducer.extra_pass(r)
+    assert r._early["views"] == 2
+    r = SimpleNamespace(sparse=True, active=True, _early=None)
+    dp.GradAllReducer.extra_pass(r)                       # before the step's full pass: remembered for finish()
+    assert r._extra_before is True
+    r = SimpleNamespace(sparse=False, active=True, _early=dict(views=1))
+    dp.GradAllReducer.extra_pass(r)
+    assert r._early["views"] == 1
