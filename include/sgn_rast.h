@@ -469,6 +469,22 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                                              adaptive scheme touch disjoint tiles and then run concurrently (forked
                                              behind `stream`'s queue, joined before the gradients are unpacked)*/);
 
+/* One of SEVERAL reverse walks whose gradients belong to the same tensors (the main pass of sgn_raster_fwd_groups and
+ * the group accumulations that reached the loss): all of them accumulate into ONE packed gradient workspace and the last
+ * one unpacks — instead of a 48 MB clear, an unpack and four tensor additions per extra walk.  Arguments as
+ * sgn_raster_bwd; first != 0 clears grad_ws, last != 0 unpacks it (only then are v_xy / v_conic / v_colors / v_opacity
+ * written).  Whole-tensor passes only (window = 0), all with the same conics / opacities / opacity_is_logit; -13
+ * otherwise. */
+int sgn_raster_bwd_part(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                        const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                        const float *conics, const float *colors, const float *opacities, int opacity_is_logit,
+                        int id_lo, int id_hi, int window, const float *background3, const float *final_Ts,
+                        const int32_t *final_idx, const float *v_out_img, const float *v_out_alpha,
+                        float alpha_clamp_bwd, float *v_xy, float *v_conic, float *v_colors, float *v_opacity,
+                        void *recs_ws, size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
+                        const int32_t *tile_order, const float *colors_pre_clamp, const sgn_raster_opts *opts,
+                        sgn_stream_t stream, sgn_stream_t aux_stream, int first, int last);
+
 /* pytorch3d.transforms.quaternion_multiply as object2world_gs uses it (sgn_splatfacto_scene_graph.py:416): Hamilton
  * product a (x) b, real part first, result standardised to a non-negative real part.  `a` is EITHER one quaternion
  * for all rows, passed as a HOST array of 4 floats (a_host4; the reference's quat_o2w is a CPU tensor), OR one per row

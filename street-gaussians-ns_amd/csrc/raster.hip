@@ -1575,7 +1575,7 @@ SGN_EXPORT int sgn_depth_reuse(int img_h, int img_w, const int32_t *flag, const 
     return 0;
 }
 
-SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+static int raster_bwd_impl(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
                               const float *conics, const float *colors, const float *opacities,
                               int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
@@ -1584,7 +1584,8 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
                               size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
                               const int32_t *tile_order, const float *colors_pre_clamp,
-                              const sgn_raster_opts *opts, sgn_stream_t stream, sgn_stream_t aux_stream) {
+                              const sgn_raster_opts *opts, sgn_stream_t stream, sgn_stream_t aux_stream,
+                              int keep_ws, int defer_unpack) {
     const sgn_raster_opts o = resolve_opts(opts);
     SGN_ARG_CHECK(opacity_is_logit >= 0 && opacity_is_logit <= 2, -11);
     const int logit_rows = opacity_is_logit == 1;     // 2: the values ARE probabilities, only the gradient is converted
@@ -1598,7 +1599,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     SGN_ARG_CHECK(alpha_clamp_bwd > 0.f && alpha_clamp_bwd < 1.f, -6);
     SGN_ARG_CHECK(!o.ids_qmask || (block_width == 16 && n < SGN_QMASK_MAX_IDS), -10);
     hipStream_t s = (hipStream_t)stream;
-    SGN_HIP_CHECK(hipMemsetAsync(grad_ws, 0, (size_t)n * SGN_RECORD_FLOATS * sizeof(float), s));
+    if (!keep_ws) SGN_HIP_CHECK(hipMemsetAsync(grad_ws, 0, (size_t)n * SGN_RECORD_FLOATS * sizeof(float), s));
     if (n_isect > 0) {
         SGN_ARG_CHECK(gaussian_ids_sorted && tile_bins && xys && conics && colors && opacities && background3 &&
                           final_Ts && final_idx && v_out_alpha && recs_ws, -7);     // (v_out_img may be NULL: zeros)
@@ -1658,7 +1659,7 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
         sgn_timing_end(SGN_T_RASTER_BWD, s);
     }
     sgn_timing_begin(SGN_T_UNPACK, s);
-    {   // window: the outputs (and `opacities`) hold rows [id_lo, id_hi) only
+    if (!defer_unpack) {   // window: the outputs (and `opacities`) hold rows [id_lo, id_hi) only
         const int n_out = window ? id_hi - id_lo : n, row0 = window ? id_lo : 0;
         if (n_out > 0)
             hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n_out, 256)), dim3(256), 0, s, n_out, row0,
@@ -1668,4 +1669,37 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     sgn_timing_end(SGN_T_UNPACK, s);
     SGN_LAUNCH_CHECK();
     return 0;
+}
+
+SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                              const float *conics, const float *colors, const float *opacities,
+                              int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
+                              const float *final_Ts, const int32_t *final_idx,
+                              const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd,
+                              float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
+                              size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
+                              const int32_t *tile_order, const float *colors_pre_clamp,
+                              const sgn_raster_opts *opts, sgn_stream_t stream, sgn_stream_t aux_stream) {
+    return raster_bwd_impl(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi, window, background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors, v_opacity, recs_ws, recs_ws_bytes, recs_packed, grad_ws, grad_ws_bytes, tile_order, colors_pre_clamp, opts, stream, aux_stream, 0, 0);
+}
+
+// One of SEVERAL reverse walks whose gradients belong to the same tensors (the main pass of sgn_raster_fwd_groups and the
+// group accumulations that reached the loss): all of them accumulate into ONE packed gradient workspace and the last one
+// unpacks — instead of a 48 MB clear, an unpack and four tensor additions per extra walk.  `first` != 0 clears the
+// workspace, `last` != 0 unpacks it into v_xy / v_conic / v_colors / v_opacity (only then are those written; every
+// walk of the sequence must be a whole-tensor pass — window = 0 — with the same opacities / conics / opacity_is_logit).
+SGN_EXPORT int sgn_raster_bwd_part(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                              const float *conics, const float *colors, const float *opacities,
+                              int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
+                              const float *final_Ts, const int32_t *final_idx,
+                              const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd,
+                              float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
+                              size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
+                              const int32_t *tile_order, const float *colors_pre_clamp,
+                              const sgn_raster_opts *opts, sgn_stream_t stream, sgn_stream_t aux_stream,
+                                   int first, int last) {
+    SGN_ARG_CHECK(!window, -13);
+    return raster_bwd_impl(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi, window, background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors, v_opacity, recs_ws, recs_ws_bytes, recs_packed, grad_ws, grad_ws_bytes, tile_order, colors_pre_clamp, opts, stream, aux_stream, first ? 0 : 1, last ? 0 : 1);
 }

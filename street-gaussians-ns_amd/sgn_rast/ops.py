@@ -1364,57 +1364,61 @@ class _RasterizeGaussians(Function):
         v_out_img = None if v_out_img is None else _f32c(v_out_img)
         v_out_alpha = _f32c(v_out_alpha)
 
-        def one_pass(ids, bins, Ts, idx, kmax, v_img, v_alpha, id_range, window, recs, pre):
-            v_xy = torch.empty(n, 2, **f32)
-            v_conic = torch.empty(n, 3, **f32)
-            v_colors = torch.empty(n, 3, **f32)
-            v_opacity = torch.empty(n, **f32)
+        def one_pass(ids, bins, Ts, idx, kmax, v_img, v_alpha, id_range, window, recs, pre, out=None, part=None):
+            # `out` / `part`: one walk of a sequence that accumulates into one gradient workspace (sgn_raster_bwd_part):
+            # out = (v_xy, v_conic, v_colors, v_opacity, workspace) shared by the sequence, part = (first, last)
             lib = L.load()
+            if out is None:
+                out = (torch.empty(n, 2, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, **f32),
+                       L.workspace(lib.sgn_raster_bwd_workspace_bytes(ctx.n_full), dev))
+            v_xy, v_conic, v_colors, v_opacity, gws = out
             ro_ptr = C.byref(ctx.ro)
             packed = 1
             if recs is None:
                 recs = L.workspace(lib.sgn_raster_workspace_bytes(ctx.n_full, ctx.num_intersects, ro_ptr), dev)
                 packed = 0
-            gws = L.workspace(lib.sgn_raster_bwd_workspace_bytes(ctx.n_full), dev)
             # the backward's own launch order, by REVERSE-WALK length (tried in r03: the forward's order by list length
             # plus per-tile classification, no launch — the one-wave kernel then ran 323 instead of 288 us on the
             # benchmark scene: a late long walk is a lone-wave tail; profiles/r03f_*)
             order = _tile_order(bins, kmax, ctx.ro.adapt_bwd)
             if order is not None and not window and id_range == (0, n):
                 _S().walk_stat = order[-1:]          # rides to the host with the next binning's count (mask policy)
-            L.check(lib.sgn_raster_bwd(
-                H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(ids), L.ptr(bins),
-                L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity),
-                2 if ctx.grad_to_logits else ctx.opacity_is_logit, id_range[0],
-                id_range[1], window, L.ptr(background), L.ptr(Ts),
-                L.ptr(idx), L.ptr(v_img), L.ptr(v_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
-                L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
-                L.ptr(gws), gws.numel(), L.ptr(order), L.ptr(pre), ro_ptr, L.stream_ptr(),
-                L.aux_stream_ptr(dev) if concurrent_backward else None), "sgn_raster_bwd")
-            return v_xy, v_conic, v_colors, v_opacity
+            args = (H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(ids), L.ptr(bins),
+                    L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity),
+                    2 if ctx.grad_to_logits else ctx.opacity_is_logit, id_range[0],
+                    id_range[1], window, L.ptr(background), L.ptr(Ts),
+                    L.ptr(idx), L.ptr(v_img), L.ptr(v_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
+                    L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
+                    L.ptr(gws), gws.numel(), L.ptr(order), L.ptr(pre), ro_ptr, L.stream_ptr(),
+                    L.aux_stream_ptr(dev) if concurrent_backward else None)
+            if part is None:
+                L.check(lib.sgn_raster_bwd(*args), "sgn_raster_bwd")
+            else:
+                L.check(lib.sgn_raster_bwd_part(*args, int(part[0]), int(part[1])), "sgn_raster_bwd_part")
+            return out
 
         if ctx.num_intersects < 1 or not (main or group_work):
             v_xy, v_conic = torch.zeros(n, 2, **f32), torch.zeros(n, 3, **f32)
             v_colors, v_opacity = torch.zeros(n, 3, **f32), torch.zeros(n, **f32)
         else:
-            grads = None
+            # the walks of this node: the main pass, then every group accumulation in the loss — its own list holds the
+            # group's entries only, so the main pass's rows serve; on the shared list the other group's rows must be
+            # inert, so the rows are built again for the id range (recs = None).  More than one walk: all accumulate
+            # into one gradient workspace and the last one unpacks (sgn_raster_bwd_part).
+            walks = []
             if main:
-                grads = one_pass(gaussian_ids_sorted, tile_bins, final_Ts, final_idx, ctx.tile_kmax, v_out_img,
-                                 v_out_alpha, ctx.id_range, ctx.window, ctx.recs, colors_pre)
+                walks.append((gaussian_ids_sorted, tile_bins, final_Ts, final_idx, ctx.tile_kmax, v_out_img, v_out_alpha,
+                              ctx.id_range, ctx.window, ctx.recs, colors_pre))
             else:
                 no_color_grad = True
             for g, v in group_work:
                 group_stats["backward_passes"] += 1
-                # its own list holds the group's entries only: the main pass's rows serve; on the shared list the other
-                # group's rows must be inert, so the rows are built again for the id range (recs = None)
-                part = one_pass(g["ids"], g["bins"], g["T"], g["idx"], g["kmax"], None, _f32c(v), (g["lo"], g["hi"]), 0,
-                                ctx.recs if g["own"] else None, None)
-                if grads is None:
-                    grads = part
-                else:
-                    for a, b in zip((grads[0], grads[1], grads[3]), (part[0], part[1], part[3])):
-                        a.add_(b)                  # (a group pass has no colour gradient: v_out_img = NULL)
-            v_xy, v_conic, v_colors, v_opacity = grads
+                walks.append((g["ids"], g["bins"], g["T"], g["idx"], g["kmax"], None, _f32c(v), (g["lo"], g["hi"]), 0,
+                              ctx.recs if g["own"] else None, colors_pre if main else None))
+            out = None
+            for wi, w in enumerate(walks):
+                out = one_pass(*w, out=out, part=None if len(walks) == 1 else (wi == 0, wi == len(walks) - 1))
+            v_xy, v_conic, v_colors, v_opacity = out[:4]
         v_opacity = v_opacity.reshape(ctx.opacity_shape)
         if no_color_grad:
             v_colors = None
