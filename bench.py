@@ -804,6 +804,9 @@ def main():
         line["config"]["early_rank"] = dict(mode=ops.early_rank, **ops.early_rank_stats)
         line["config"]["depth_channel"] = dict(mode=ops.depth_channel, **ops.depth_stats)
         line["config"]["quadrant_masks"] = dict(mode=ops.quadrant_masks, **ops.quadrant_mask_stats)
+        # fused scene graph: forwards whose walk also accumulated background_acc / object_acc (sgn_raster_fwd_groups)
+        from sgn_rast import fused as _F
+        line["config"]["group_accumulations"] = dict(enabled=bool(_F.group_accumulation_enabled), **ops.group_stats)
         # how often the operators could PROVE the reference's activation / concatenation expressions on the autograd
         # graph and differentiated straight into the leaf parameters ("graph proofs")
         line["config"]["graph_proofs"] = dict(enabled=dict(sh_split=bool(ops.sh_split_backward), activations=bool(ops.activation_proofs)),

@@ -17,6 +17,7 @@ run depth --with-depth
 run sky --sky
 run train --photometric --adam
 run forcedp --force-dp
+SGN_GROUP_ACC=0 run sg_nogroups --scene-graph
 timeout 300 python profiles/scripts/host_profile_sg.py > $O/host_profile_sg_dropin.log 2>&1; head -2 $O/host_profile_sg_dropin.log | tail -1
 SGN_SG_FUSED=1 timeout 300 python profiles/scripts/host_profile_sg.py > $O/host_profile_sg_fused.log 2>&1; head -2 $O/host_profile_sg_fused.log | tail -1
 timeout 300 python profiles/scripts/host_profile2.py > $O/host_bound_step.log 2>&1; head -2 $O/host_bound_step.log | tail -1
@@ -26,3 +27,18 @@ trace dropin
 trace fused --path fused
 trace sg_dropin --scene-graph
 trace sg_fused --scene-graph --path fused
+
+cd $REPO
+tail -5 $O/tests.log > $O/tests_tail.log
+# the reference's OWN scene-graph code at benchmark size (only where the staged checkout travels with the call:
+# `python tests/stage_reference.py stage` before, `... clean` after)
+if [ -d tests/_refscratch ]; then
+  R=$REPO/tests/_refscratch
+  rm -rf /tmp/ref_p1 /tmp/ref_p2; cp -r $R /tmp/ref_p1; cp -r $R /tmp/ref_p2
+  (cd /tmp/ref_p1 && patch -p1 -s < $REPO/integration/fused_callsites.patch)
+  (cd /tmp/ref_p2 && patch -p1 -s < $REPO/integration/fused_callsites.patch && patch -p1 -s < $REPO/integration/fused_scene_graph.patch)
+  for v in "$R unpatched" "/tmp/ref_p1 callsites" "/tmp/ref_p2 callsites+scene_graph"; do
+    set -- $v
+    timeout 600 python profiles/scripts/literal_sg_timing.py $1 $2 2>&1 | grep -E "literal scene graph|Error|error" | tee -a $O/literal_sg_timing.log
+  done
+fi

@@ -654,6 +654,8 @@ class SHGradExchange:
     def _note_forward(self, claimed: bool, degree, k, cam_known: bool) -> None:
         """What the forward pass of this step has shown so far (the row exchange announces it to the other ranks right
         after the forward): SH nodes claimed / not claimed, their degree, whether the camera position will be known."""
+        if not torch.is_grad_enabled():
+            return          # an evaluation forward between two steps: no backward follows, nothing to announce
         f = self._fwd
         if claimed and f["claimed"] == 0:
             f.update(claimed=1, degree=-1 if degree is None else int(degree), k=int(k), cam=bool(cam_known))

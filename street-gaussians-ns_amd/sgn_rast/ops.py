@@ -1119,6 +1119,9 @@ _provably_depths = proofs.repeated_depths     # host-side proof that colours are
 # Optional hook for data-parallel training (sgn_rast.dp.GradAllReducer(sparse=True)): `after_forward(ids, bins, kmax, n,
 # qmask)` is told, right after a full (non-window) forward pass, which list entries the pass walked.  None normally.
 _touch_sink = None
+# grad mode where the operator was CALLED (inside Function.forward it always reads "off", and ctx.needs_input_grad ignores
+# it): the rasterize wrappers note it just before `apply`
+_grad_mode_at_call = [True]
 
 
 # --------------------------------------------------------------- rasterize
@@ -1301,14 +1304,18 @@ class _RasterizeGaussians(Function):
                     _depth_state["want"], _depth_state["unused"] = False, 0
             elif not hit:
                 S.depth_caches.pop(key, None)  # re-binned without the channel: a stale image must not answer later
-        if _touch_sink is not None and num_intersects >= 1 and win is None and id_range is None and not proved:
+        # (the sink hears of passes that WILL have a backward only: a forward under no_grad — an evaluation image between
+        # two training steps — announces nothing; such an announcement used to stay behind and count as a second view of
+        # the next step whenever its list happened to land on another address)
+        sink = _touch_sink if (_grad_mode_at_call[0] and any(ctx.needs_input_grad)) else None
+        if sink is not None and num_intersects >= 1 and win is None and id_range is None and not proved:
             # data-parallel row exchange: which Gaussians this view's backward can touch (the walked entries)
-            _touch_sink.after_forward(gaussian_ids_sorted, tile_bins, tile_kmax, n_full, ro.ids_qmask)
-        if _touch_sink is not None and num_intersects >= 1 and (win is not None or id_range is not None
-                                                                  or group_split is not None):
+            sink.after_forward(gaussian_ids_sorted, tile_bins, tile_kmax, n_full, ro.ids_qmask)
+        if sink is not None and num_intersects >= 1 and (win is not None or id_range is not None
+                                                           or group_split is not None):
             # a sub-model pass / group accumulation walks entries the full pass's list of walked rows does not cover
             # (its transmittance falls more slowly): the sink must not take that list for the step's touched rows
-            extra = getattr(_touch_sink, "extra_pass", None)
+            extra = getattr(sink, "extra_pass", None)
             if extra is not None:
                 extra()
         ctx.img_width, ctx.img_height, ctx.block_width = img_width, img_height, block_width
@@ -1455,6 +1462,7 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
         logits, pre = proofs.sigmoid_leaves(opacity) or (), proofs.clamp_pre(colors)
         activation_proof_stats["opacity"] += len(logits) > 0
         activation_proof_stats["colors"] += pre is not None
+    _grad_mode_at_call[0] = torch.is_grad_enabled()
     return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(),
                                      conics.contiguous(), num_tiles_hit.contiguous(),
                                      (colors.detach() if pre is not None else colors).contiguous(),

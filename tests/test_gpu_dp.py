@@ -150,8 +150,12 @@ def test_row_exchange_over_single_rank_rccl_group():
                                     sparse_max_fraction=frac)
             try:
                 assert ops._touch_sink is red
-                for _ in range(2):                                  # twice: persistent buffers, epochs, pinned slots
+                for it in range(2):                                 # twice: persistent buffers, epochs, pinned slots
                     ops.clear_binning_cache()
+                    if it == 1:          # an evaluation image between two steps announces nothing (no backward follows)
+                        with torch.no_grad():
+                            step.render(Pb, cam, with_depth=True)
+                        ops.clear_binning_cache()
                     step.train_step(Pb, cam, w_img, w_a, reducer=red)
             finally:
                 ex.remove()
