@@ -29,7 +29,7 @@ trace sg_dropin --scene-graph
 trace sg_fused --scene-graph --path fused
 
 cd $REPO
-tail -5 $O/tests.log > $O/tests_tail.log
+grep -E "passed|failed" $O/tests.log | tail -2 > $O/tests_tail.log
 # the reference's OWN scene-graph code at benchmark size (only where the staged checkout travels with the call:
 # `python tests/stage_reference.py stage` before, `... clean` after)
 if [ -d tests/_refscratch ]; then
