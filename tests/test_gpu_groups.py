@@ -132,3 +132,48 @@ def test_unsupported_kernel_options_fall_back_to_three_passes():
             if name == "depth" and "gather" in kw:
                 continue                              # (the depth channel is a gather-mode feature)
             assert float((x - y).abs().max()) < 2e-5, (kw, name)
+
+
+def test_odd_image_size_and_partial_tiles():
+    """Image sizes that are no multiple of the tile: the partial tiles' out-of-image pixels take no part in any pass."""
+    from sgn_rast import ops
+    cam, geo, colors, logits, split = _inputs(5000, 0.8, seed=31, W=333, H=211, focal=250.0)
+    g = torch.Generator().manual_seed(9)
+    weights = [torch.rand(211, 333, 3, generator=g).to(DEV)] + [torch.rand(211, 333, generator=g).to(DEV) for _ in range(3)]
+    a, ga = _run(geo, colors, logits, cam, split, True, weights)
+    b, gb = _run(geo, colors, logits, cam, split, False, weights)
+    for name, x, y in zip(("img", "alpha", "depth", "acc_head", "acc_tail"), a, b):
+        assert torch.equal(x, y), name
+    for x, y in zip(ga, gb):
+        assert rel_l2(x, y) < 2e-5
+
+
+def test_scene_graph_step_at_size_grouped_equals_separate_passes():
+    """The fused scene-graph step of `bench.py --scene-graph` (1 M Gaussians, 8 objects, 1920x1280, production kernel
+    options): object / background accumulation from the main pass's walk are BIT-EQUAL to the two id-window passes, and
+    so are rgb, alpha and depth; every leaf gradient of a loss over all of them agrees to accumulation-order rounding."""
+    from sgn_rast import _lib as L, ops, scenes, step
+    L.reset_options()
+    cam, raw = scenes.make_scene("metric")
+    models, poses, idft = scenes.make_scene_graph(raw["means"].shape[0], cam, n_objects=8, object_frac=0.1)
+    cam_d = scenes.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.viewmat.to(DEV), cam.cam_pos.to(DEV))
+    w_img, w_a = step.loss_weights(cam, seed=3, device=DEV)
+    res = {}
+    for groups in (True, False):
+        Ms = [step.leaf_params({k: v.to(DEV) for k, v in m.items()}) for m in models]
+        ops.clear_binning_cache()
+        before = ops.group_stats["passes"]
+        out = step.render_scene_graph(Ms, poses.to(DEV), idft.to(DEV), cam_d, fused=True, groups=groups)
+        assert ops.group_stats["passes"] == before + int(groups)
+        loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum() + (out.object_acc * w_a).sum()
+                + (out.background_acc * w_a.flip(0)).sum()) / (cam.height * cam.width)
+        loss.backward()
+        torch.cuda.synchronize()
+        res[groups] = (out, Ms)
+    a, b = res[True][0], res[False][0]
+    for name in ("rgb", "alpha", "depth", "object_acc", "background_acc"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    assert float(a.object_acc.max()) > 0.5 and float(a.background_acc.max()) > 0.5
+    for Ma, Mb in zip(res[True][1], res[False][1]):
+        for k in Ma:
+            assert rel_l2(Ma[k].grad, Mb[k].grad) < 5e-5, k
