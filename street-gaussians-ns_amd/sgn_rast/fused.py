@@ -370,7 +370,7 @@ def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors,
         background = torch.ones(3, dtype=torch.float32, device=colors.device)
     args = (xys.contiguous(), depths.contiguous(), radii.contiguous(), conics.contiguous(), num_tiles_hit.contiguous(),
             colors.contiguous(), opacity_logits.contiguous(), img_height, img_width, block_width, background.contiguous())
-    _ops._grad_mode_at_call[0] = torch.is_grad_enabled()
+    _ops._call_state.grad = torch.is_grad_enabled()
     if group_split is not None:
         assert id_range is None, "group_split splits the whole scene"
         ro, n = L.opts(), xys.shape[0]

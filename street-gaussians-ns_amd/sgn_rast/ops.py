@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 import weakref
 from typing import Optional, Tuple
 
@@ -1120,8 +1121,8 @@ _provably_depths = proofs.repeated_depths     # host-side proof that colours are
 # qmask)` is told, right after a full (non-window) forward pass, which list entries the pass walked.  None normally.
 _touch_sink = None
 # grad mode where the operator was CALLED (inside Function.forward it always reads "off", and ctx.needs_input_grad ignores
-# it): the rasterize wrappers note it just before `apply`
-_grad_mode_at_call = [True]
+# it): the rasterize wrappers note it just before `apply` (same thread: `apply` runs the forward synchronously)
+_call_state = threading.local()
 
 
 # --------------------------------------------------------------- rasterize
@@ -1307,7 +1308,7 @@ class _RasterizeGaussians(Function):
         # (the sink hears of passes that WILL have a backward only: a forward under no_grad — an evaluation image between
         # two training steps — announces nothing; such an announcement used to stay behind and count as a second view of
         # the next step whenever its list happened to land on another address)
-        sink = _touch_sink if (_grad_mode_at_call[0] and any(ctx.needs_input_grad)) else None
+        sink = _touch_sink if (getattr(_call_state, "grad", True) and any(ctx.needs_input_grad)) else None
         if sink is not None and num_intersects >= 1 and win is None and id_range is None and not proved:
             # data-parallel row exchange: which Gaussians this view's backward can touch (the walked entries)
             sink.after_forward(gaussian_ids_sorted, tile_bins, tile_kmax, n_full, ro.ids_qmask)
@@ -1462,7 +1463,7 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
         logits, pre = proofs.sigmoid_leaves(opacity) or (), proofs.clamp_pre(colors)
         activation_proof_stats["opacity"] += len(logits) > 0
         activation_proof_stats["colors"] += pre is not None
-    _grad_mode_at_call[0] = torch.is_grad_enabled()
+    _call_state.grad = torch.is_grad_enabled()
     return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(),
                                      conics.contiguous(), num_tiles_hit.contiguous(),
                                      (colors.detach() if pre is not None else colors).contiguous(),
