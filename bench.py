@@ -688,6 +688,11 @@ def main():
     kernels = {k: (c, (t / c if c else 0.0)) for k, (c, t) in rep.items()}  # avg ms per launch
     if watchdog is not None:
         watchdog.stop()      # every collective of the run is behind us; what follows is rank-local (CPU baseline ...)
+    if reducer is not None:
+        # ... so the reducer's taps come off the operators NOW: the statistics pass below is a forward with a graph on
+        # rank 0 only, and with the hooks on it would announce its walked rows to ranks that are no longer listening
+        from sgn_rast import fused as fused_off
+        ops._sh_exchange = fused_off._sh_exchange = ops._touch_sink = None
 
     # what the raster kernels really touch (untimed, one forward): pairs LISTED after exact tile culling, list entries
     # WALKED before the tiles saturate (the backward's reverse walk starts at the deepest composited position the
