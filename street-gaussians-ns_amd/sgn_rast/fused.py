@@ -375,6 +375,14 @@ def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors,
         assert id_range is None, "group_split splits the whole scene"
         ro, n = L.opts(), xys.shape[0]
         s = min(max(int(group_split), 0), n)
+        if s == 0 or s == n:
+            # one group is empty (a frame without a visible object): the other one's pass IS the main pass — its
+            # accumulation is the alpha image itself, the empty group's is zero.  (Carried through the group kernel, the
+            # empty group would never finish and keep every tile's walk alive to the end of its list.)
+            main = _RasterizeGaussians.apply(*args, True, True, None, bool(depth_channel))
+            zero = torch.zeros(img_height, img_width, dtype=torch.float32, device=xys.device)
+            accs = (zero, main[1]) if s == 0 else (main[1], zero)
+            return main[0], main[1], (main[2] if depth_channel else None), accs[0], accs[1]
         if group_accumulation_enabled and ro.gather and ro.waves_fwd == 2 and block_width == 16:
             return _RasterizeGaussians.apply(*args, True, True, None, bool(depth_channel), False, None, s)
         main = _RasterizeGaussians.apply(*args, True, True, None, bool(depth_channel))
