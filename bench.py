@@ -446,16 +446,17 @@ def main():
         for _ in range(max(0, settle)):
             one_step()
         torch.cuda.synchronize()
-        for _ in range(args.warmup):
-            out_ = one_step()
-        torch.cuda.synchronize()
         # A full (generation-2) garbage collection over the ~1e6 objects that importing torch leaves behind takes ~50 ms
         # on this host and lands somewhere inside a 200-step window (profiles/r02e: one 20-step chunk at 4.07 ms/step,
         # the rest at 1.60).  Standard remedy for latency-sensitive loops: collect now and move the survivors to the
         # permanent generation; garbage created by the steps themselves is still collected (young generations).
+        # BEFORE the warm-up steps, not between them and the timed region: the device sits idle through those ~50 ms,
+        # and a short run (the driver's --steps 20 --warmup 5) then starts its clock on a GPU that has just idled.
         gc.collect()
         if os.environ.get("SGN_BENCH_GC_FREEZE", "1") == "1":
             gc.freeze()
+        for _ in range(args.warmup):
+            out_ = one_step()
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
