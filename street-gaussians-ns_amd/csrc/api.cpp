@@ -1,13 +1,18 @@
 // api.cpp — error plumbing shared by every entry point of libsgnrast.so (host only).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "sgn_rast.h"
+
+#define SGN_GRAPH_KEY_WORDS 12      // as in sgn_common.h (this file is built without the device headers' helpers)
 
 static thread_local char g_err[512] = "";
 
@@ -38,6 +43,75 @@ int sgn_fork_events(hipEvent_t *fork, hipEvent_t *join) {
     cache.push_back(p);
     *fork = p.a; *join = p.b;
     return 0;
+}
+
+// ---------------------------------------------------------------- launch chains replayed as HIP graphs
+// (sgn_common.h: sgn_graph_find / sgn_graph_capture_begin / _end.)  A resource cache per (thread, device): up to 8
+// instantiated graphs, least recently used out; one capture stream.  No configuration lives here: the key is the
+// chain's own arguments.
+namespace {
+struct GraphEntry { int dev; uint64_t key[SGN_GRAPH_KEY_WORDS]; hipGraphExec_t exec; uint64_t used; };
+struct GraphState { std::vector<GraphEntry> entries; std::vector<std::pair<int, hipStream_t>> streams; uint64_t tick = 0; };
+thread_local GraphState g_graphs;
+int graphs_on() {
+    static const int on = [] { const char *e = getenv("SGN_HIP_GRAPHS"); return (e && e[0] == '1') ? 1 : 0; }();
+    return on;
+}
+}  // namespace
+
+int sgn_timing_enabled();
+
+hipGraphExec_t sgn_graph_find(const uint64_t *key) {
+    if (!graphs_on() || sgn_timing_enabled()) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (auto &e : g_graphs.entries)
+        if (e.dev == dev && memcmp(e.key, key, sizeof(e.key)) == 0) { e.used = ++g_graphs.tick; return e.exec; }
+    return nullptr;
+}
+
+hipStream_t sgn_graph_capture_begin() {
+    if (!graphs_on() || sgn_timing_enabled()) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipStream_t cs = nullptr;
+    for (auto &p : g_graphs.streams)
+        if (p.first == dev) cs = p.second;
+    if (cs == nullptr) {
+        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        g_graphs.streams.emplace_back(dev, cs);
+    }
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return cs;
+}
+
+hipGraphExec_t sgn_graph_capture_end(const uint64_t *key) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    hipStream_t cs = nullptr;
+    for (auto &p : g_graphs.streams)
+        if (p.first == dev) cs = p.second;
+    if (cs == nullptr) return nullptr;
+    hipGraph_t graph = nullptr;
+    if (hipStreamEndCapture(cs, &graph) != hipSuccess || graph == nullptr) { (void)hipGetLastError(); return nullptr; }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess || exec == nullptr) { (void)hipGetLastError(); return nullptr; }
+    if (g_graphs.entries.size() >= 8) {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_graphs.entries.size(); ++i)
+            if (g_graphs.entries[i].used < g_graphs.entries[lru].used) lru = i;
+        (void)hipGraphExecDestroy(g_graphs.entries[lru].exec);
+        g_graphs.entries.erase(g_graphs.entries.begin() + (long)lru);
+    }
+    GraphEntry ge;
+    ge.dev = dev;
+    memcpy(ge.key, key, sizeof(ge.key));
+    ge.exec = exec;
+    ge.used = ++g_graphs.tick;
+    g_graphs.entries.push_back(ge);
+    return exec;
 }
 
 // ---------------------------------------------------------------- kernel timing (bench/profiles)
