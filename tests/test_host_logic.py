@@ -383,3 +383,21 @@ def test_row_exchange_counts_sub_model_passes_as_views():
     r = SimpleNamespace(sparse=False, active=True, _early=dict(views=1))
     dp.GradAllReducer.extra_pass(r)
     assert r._early["views"] == 1
+
+
+def test_memo_remembers_pure_host_functions_by_value():
+    """`fused.memo` (the scene-graph patch's per-object `quaternion_from_matrix` / `IDFT`): same function + equal
+    arguments -> the remembered result, numpy arguments by their bytes, anything else a new evaluation."""
+    import numpy as np
+    from sgn_rast import fused
+    calls = []
+
+    def f(a, k=0):
+        calls.append(1)
+        return float(np.sum(a)) + k
+
+    rot = np.arange(9.0).reshape(3, 3)
+    assert fused.memo(f, rot) == 36.0 and fused.memo(f, rot.copy()) == 36.0 and len(calls) == 1
+    assert fused.memo(f, rot + 1) == 45.0 and len(calls) == 2            # other bytes: evaluated
+    assert fused.memo(f, rot, 2) == 38.0 and len(calls) == 3             # other scalar argument: evaluated
+    assert fused.memo(f, rot, 2) == 38.0 and len(calls) == 3
