@@ -178,3 +178,27 @@ def test_scene_graph_step_at_size_grouped_equals_separate_passes():
     for Ma, Mb in zip(res[True][1], res[False][1]):
         for k in Ma:
             assert rel_l2(Ma[k].grad, Mb[k].grad) < 5e-5, k
+
+
+def test_groups_over_a_list_that_carries_quadrant_masks():
+    """The depth list may carry quadrant masks in the top bits of its id words (`sgn_bin_intersect(quadrant_masks)`,
+    the "auto" policy turns them on for content that does not saturate): group membership is decided on the id bits
+    only, the compacted own list keeps the masks, and everything stays bit-equal to the separate passes."""
+    from sgn_rast import ops
+    cam, geo, colors, logits, split = _inputs(8000, 0.85, seed=17)
+    g = torch.Generator().manual_seed(4)
+    H, W = cam.height, cam.width
+    weights = [torch.rand(H, W, 3, generator=g).to(DEV)] + [torch.rand(H, W, generator=g).to(DEV) for _ in range(3)]
+    saved = ops.quadrant_masks
+    ops.quadrant_masks = "on"
+    try:
+        before = ops.quadrant_mask_stats["binnings_with_masks"]
+        a, ga = _run(geo, colors, logits, cam, split, True, weights)
+        b, gb = _run(geo, colors, logits, cam, split, False, weights)
+        assert ops.quadrant_mask_stats["binnings_with_masks"] >= before + 2
+    finally:
+        ops.quadrant_masks = saved
+    for name, x, y in zip(("img", "alpha", "depth", "acc_head", "acc_tail"), a, b):
+        assert torch.equal(x, y), name
+    for x, y in zip(ga, gb):
+        assert rel_l2(x, y) < 2e-5
