@@ -202,3 +202,29 @@ def test_groups_over_a_list_that_carries_quadrant_masks():
         assert torch.equal(x, y), name
     for x, y in zip(ga, gb):
         assert rel_l2(x, y) < 2e-5
+
+
+def test_translucent_content_and_no_depth_channel():
+    """Nothing saturates (opacity logits - 2.5): main pass and both groups walk every list to its end, the small group's
+    walk of its own list starts exactly where the shared walk ended (nothing left).  Also without the depth channel."""
+    from sgn_rast import fused, ops
+    cam, geo, colors, logits, split = _inputs(7000, 0.8, seed=23)
+    logits = logits - 2.5
+    xys, depths, radii, conics, nth = geo
+    bg = torch.zeros(3, device=DEV)
+    outs = {}
+    for grouped in (True, False):
+        fused.group_accumulation_enabled = grouped
+        ops.clear_binning_cache()
+        try:
+            outs[grouped] = fused.rasterize_gaussians_fused(xys, depths, radii, conics, nth, colors, logits, cam.height,
+                                                            cam.width, 16, background=bg, return_alpha=True,
+                                                            depth_channel=False, group_split=split)
+        finally:
+            fused.group_accumulation_enabled = True
+    torch.cuda.synchronize()
+    a, b = outs[True], outs[False]
+    assert a[2] is None and b[2] is None
+    for i in (0, 1, 3, 4):
+        assert torch.equal(a[i], b[i]), i
+    assert float(a[1].min()) < 0.999          # really translucent: some pixel never saturates
