@@ -228,3 +228,23 @@ def test_translucent_content_and_no_depth_channel():
     for i in (0, 1, 3, 4):
         assert torch.equal(a[i], b[i]), i
     assert float(a[1].min()) < 0.999          # really translucent: some pixel never saturates
+
+
+def test_skewed_street_content_at_production_options():
+    """Street-like content (a few thousand-entry lists, most of the image thin): the four-waves-per-tile body and the
+    LDS-batched walks at the PRODUCTION thresholds, 400 k Gaussians at 1920x1280, split in the middle of the ids."""
+    from sgn_rast import _lib as L, fused, ops, scenes
+    L.reset_options()
+    cam = scenes.make_camera(1920, 1280, 2000.0)
+    raw = scenes.make_street_gaussians(400_000, cam, seed=3)
+    P = {k: v.to(DEV) for k, v in raw.items()}
+    xys, depths, radii, conics, _c, nth, _cov = fused.project_gaussians_fused(
+        P["means"], P["log_scales"], P["quats"], cam.viewmat[:3, :].to(DEV), cam.fx, cam.fy, cam.cx, cam.cy, 1280, 1920, 16)
+    g = torch.Generator().manual_seed(1)
+    colors = torch.rand(400_000, 3, generator=g).to(DEV)
+    geo = [t.detach() for t in (xys, depths, radii, conics, nth)]
+    for split in (40_000, 360_000):            # the small group in front / at the back of the id order
+        a, _ = _run(geo, colors, P["opacity_logits"], cam, split, True)
+        b, _ = _run(geo, colors, P["opacity_logits"], cam, split, False)
+        for name, x, y in zip(("img", "alpha", "depth", "acc_head", "acc_tail"), a, b):
+            assert torch.equal(x, y), (split, name)
