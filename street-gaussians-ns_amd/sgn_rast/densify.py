@@ -18,55 +18,110 @@ from . import _lib as L
 
 
 class Stats:
+    """The three running statistics of ``after_train`` for ONE model (the scene graph keeps one per sub-model).
+
+    View-parallel training (one view per rank and step) must equal ONE process that accumulates the same views in the
+    order ``world * step + rank``.  The reference's first update after a refinement counts EVERY Gaussian once, visible
+    or not (``:524-527``: ``vis_counts = torch.ones_like(...)``); the later ones count the visible Gaussians only.  The
+    statistics of the ranks are SUMMED (:meth:`sync`), so exactly one view of the interval may play "first" — and it has
+    to be the globally first one that SAW the model: in the scene graph a sub-model is updated only on the steps whose
+    frame shows it (``sgn_splatfacto_scene_graph.py:186-190`` sets ``xys = None`` on the others and ``after_train``
+    returns), so rank 0 need not hold that view.  Every rank therefore starts an interval from zeros, counts visible
+    Gaussians only, and remembers the key ``world * step + rank`` and the visibility mask of ITS first view;
+    :meth:`sync` finds the smallest key (one MIN all-reduce of a scalar) and the rank that holds it adds the missing
+    ``1 - visible`` — after which SUM / SUM / MAX give what the single process has (counts and sizes bit for bit, the
+    gradient-norm sums up to the association of the fp32 additions; the replicas agree bit for bit either way).  A rank
+    that never saw the model in the interval joins the collectives with zeros (a rank that skipped them would hang the
+    others).
+    """
+
+    _NO_VIEW = (1 << 62)
+
     def __init__(self, group=None):
-        # the process group the statistics are reduced over (:meth:`sync`); None = the default group.  Which rank plays
-        # "first view of the step" below is decided INSIDE that group (a sub-group that does not hold global
-        # rank 0 must still have exactly one rank that counts every Gaussian once).
+        # the process group the statistics are reduced over (:meth:`sync`); None = the default group
         self.group = group
         self.xys_grad_norm: Optional[torch.Tensor] = None
         self.vis_counts: Optional[torch.Tensor] = None
         self.max_2Dsize: Optional[torch.Tensor] = None
+        self._first_key: Optional[int] = None          # world > 1: key of this rank's first view of the interval ...
+        self._first_visible: Optional[torch.Tensor] = None   # ... and which Gaussians it saw
+        self._updates = 0                              # fallback step counter for callers that pass no step
+        self.last_dim = 0.0            # larger image dimension of the most recent render that updated the statistics
+        self.synced_dim: Optional[float] = None        # ... and its MAX over the ranks, from the last :meth:`sync`
 
     def reset(self) -> None:                 # end of refinement_after (:644-646)
         self.xys_grad_norm = self.vis_counts = self.max_2Dsize = None
+        self._first_key = self._first_visible = None
+
+    def _world_rank(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1, 0
+        return dist.get_world_size(self.group), dist.get_rank(self.group)
+
+    def _accumulate(self, g: torch.Tensor, r: torch.Tensor, max_dim: float, first: bool) -> None:
+        """The arithmetic of ``:520-541`` as one HIP pass (tests substitute the reference's torch expressions)."""
+        L.require_device(g, r)
+        L.check(L.load().sgn_densify_stats(g.shape[0], L.ptr(g), L.ptr(r), float(max_dim), int(first),
+                                           L.ptr(self.xys_grad_norm), L.ptr(self.vis_counts), L.ptr(self.max_2Dsize),
+                                           L.stream_ptr()), "sgn_densify_stats")
 
     @torch.no_grad()
-    def update(self, xys_grad: torch.Tensor, radii: torch.Tensor, last_size) -> None:
-        """``xys_grad`` = ``self.xys.grad`` [N,2]; ``radii`` [N] int; ``last_size`` = (H, W) of the render."""
-        L.require_device(xys_grad, radii)
+    def update(self, xys_grad: torch.Tensor, radii: torch.Tensor, last_size, step: Optional[int] = None) -> None:
+        """``xys_grad`` = ``self.xys.grad`` [N,2]; ``radii`` [N] int; ``last_size`` = (H, W) of the render; ``step`` =
+        the training step (orders the views of different ranks; defaults to a per-object call counter, which is the
+        same thing when every rank updates on every step)."""
         n = xys_grad.shape[0]
         g = xys_grad.detach().contiguous().float()
         r = radii.detach().to(torch.int32).contiguous()
+        self._updates += 1
         first = self.xys_grad_norm is None
         if first:
             f32 = dict(dtype=torch.float32, device=g.device)
-            if self._is_follower_rank():
-                # The reference's first update after a refinement counts EVERY Gaussian once, visible or not (:524-527:
-                # `vis_counts = torch.ones_like(...)`).  Under view-parallel training the statistics of the ranks are
-                # SUMMED (`sync`), so only ONE rank's first view may do that — otherwise a Gaussian no rank saw would
-                # count `world` times and N ranks would not equal one rank accumulating N views per step.  Ranks > 0
-                # therefore start from zeros and take the "later view" branch (visible Gaussians only).
+            world, rank = self._world_rank()
+            if world > 1:
                 self.xys_grad_norm, self.vis_counts = torch.zeros(n, **f32), torch.zeros(n, **f32)
                 self.max_2Dsize = torch.zeros(n, **f32)
+                self._first_key = world * int(self._updates if step is None else step) + rank
+                self._first_visible = r > 0
                 first = False
             else:
                 self.xys_grad_norm, self.vis_counts = torch.empty(n, **f32), torch.empty(n, **f32)
                 self.max_2Dsize = torch.empty(n, **f32)
-        L.check(L.load().sgn_densify_stats(n, L.ptr(g), L.ptr(r), float(max(last_size[0], last_size[1])), int(first),
-                                           L.ptr(self.xys_grad_norm), L.ptr(self.vis_counts), L.ptr(self.max_2Dsize),
-                                           L.stream_ptr()), "sgn_densify_stats")
+        self.last_dim = float(max(last_size[0], last_size[1]))
+        self._accumulate(g, r, self.last_dim, first)
 
-    def _is_follower_rank(self) -> bool:
+    def sync(self, group=None, n: Optional[int] = None, device=None) -> bool:
+        """Reduce over the ranks (call on EVERY rank, also on one that has no statistics: pass ``n`` / ``device`` so it
+        can join with zeros).  Returns False when no rank saw the model since the last reset (nothing to decide on)."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()):
-            return False
-        return dist.get_world_size(self.group) > 1 and dist.get_rank(self.group) > 0
-
-    def sync(self, group=None) -> None:
         from .dp import sync_densify_stats
-        if self.xys_grad_norm is not None:
-            sync_densify_stats(self.xys_grad_norm, self.vis_counts, self.max_2Dsize,
-                               group=group if group is not None else self.group)
+        group = group if group is not None else self.group
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            self.synced_dim = None
+            return self.xys_grad_norm is not None
+        dev = self.xys_grad_norm.device if self.xys_grad_norm is not None else torch.device(device or "cpu")
+        key = self._NO_VIEW if self._first_key is None else self._first_key
+        # (the image size the thresholds are scaled by rides along, negated: a sub-model's `last_size` is set by the
+        # frames that show it (scene_graph.py:222-224), which differ per rank — replicas must scale by the same number)
+        lowest = torch.tensor([key, -int(self.last_dim)], dtype=torch.int64, device=dev)
+        dist.all_reduce(lowest, op=dist.ReduceOp.MIN, group=group)
+        lowest, dim = (int(v) for v in lowest.tolist())
+        self.synced_dim = float(-dim)
+        if lowest == self._NO_VIEW:
+            return False
+        if self.xys_grad_norm is None:
+            if n is None:
+                raise RuntimeError("Stats.sync: this rank has no statistics for a model another rank saw; pass n and "
+                                   "device so it can take part in the reduction with zeros")
+            f32 = dict(dtype=torch.float32, device=dev)
+            self.xys_grad_norm, self.vis_counts, self.max_2Dsize = (torch.zeros(n, **f32), torch.zeros(n, **f32),
+                                                                    torch.zeros(n, **f32))
+        elif key == lowest:
+            # this rank rendered the interval's first view of the model: count every Gaussian once, like `ones_like`
+            self.vis_counts += (~self._first_visible).to(self.vis_counts.dtype)
+        sync_densify_stats(self.xys_grad_norm, self.vis_counts, self.max_2Dsize, group=group)
+        return True
 
 
 # ======================================================================================================================
@@ -163,7 +218,7 @@ class Densifier:
             return
         if xys_grad is None:                      # this rank's view saw nothing: zero gradient, nothing visible
             xys_grad = torch.zeros(radii.shape[0], 2, dtype=torch.float32, device=radii.device)
-        self.stats.update(xys_grad, radii, self.last_size)
+        self.stats.update(xys_grad, radii, self.last_size, step=step)
 
     # ------------------------------------------------------------------------------------------ optimiser surgery
     @staticmethod
@@ -241,17 +296,23 @@ class Densifier:
         """:550-646.  Returns True when the set of Gaussians changed (callers then rebuild whatever is sized by N:
         gradient reducers, cached object-id tables).  Call on EVERY rank at the same step."""
         c, S = self.cfg, self.stats
-        if step <= c.warmup_length or S.xys_grad_norm is None:
+        if step <= c.warmup_length:
             return False
-        S.sync(self.group)                               # replicas decide on the statistics of ALL views
-        self.record.clear()
         P = self.params
+        # replicas decide on the statistics of ALL views; a rank that never saw this model since the last refinement
+        # (a scene-graph object outside its frames) joins the reduction with zeros, and when NO rank saw it every rank
+        # returns here, as the reference does on `xys_grad_norm is None` (:554-555)
+        if not S.sync(self.group, n=P["means"].shape[0], device=P["means"].device):
+            return False
+        self.record.clear()
         n_before = P["means"].shape[0]
         reset_interval = c.reset_alpha_every * c.refine_every
         do_densify = step < c.stop_split_at and step % reset_interval > c.num_train_data + c.refine_every
         deleted = None
         if do_densify:
-            avg = (S.xys_grad_norm / S.vis_counts) * 0.5 * max(self.last_size[0], self.last_size[1])
+            # (view-parallel: the size of the frames that showed this model, agreed between the ranks by Stats.sync)
+            dim = S.synced_dim if getattr(S, "synced_dim", None) else max(self.last_size[0], self.last_size[1])
+            avg = (S.xys_grad_norm / S.vis_counts) * 0.5 * dim
             high = avg > c.densify_grad_thresh
             splits = torch.exp(P["log_scales"]).max(dim=-1).values > c.densify_size_thresh
             if step < c.stop_screen_size_at:
@@ -286,3 +347,42 @@ class Densifier:
                 st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(st["exp_avg"]), torch.zeros_like(st["exp_avg_sq"])
         S.reset()
         return deleted is not None or P["means"].shape[0] != n_before
+
+
+class SceneGraphDensifier:
+    """The scene graph's densification: ONE :class:`Densifier` (and one :class:`Stats`) per sub-model over the SHARED
+    per-name optimisers, as ``SplatfactoSceneGraphModel.get_training_callbacks`` registers every sub-model's own
+    ``after_train`` / ``refinement_after`` (``sgn_splatfacto_scene_graph.py:127-135``) against optimisers whose single
+    param group lists the sub-models' parameters in model order (``get_gaussian_param_groups``, ``:110-119``;
+    ``dup_in_optim`` / ``remove_from_optim`` address them by ``_model_idx_in_scene_graph``, ``sgn_splatfacto.py:459-505``
+    — here by identity).
+
+    ``after_train`` takes the step's VISIBLE sub-models only: the reference sets ``xys = None`` on the others
+    (``:186-190``) and their ``after_train`` returns.  Under view-parallel training the ranks see different frames, hence
+    different visible sets; every sub-model's statistics are reduced on their own (:meth:`Stats.sync`: the interval's
+    first view of THAT model counts every Gaussian once, a rank that never saw it joins with zeros), in model order on
+    every rank, so replicas stay bit-identical.  ``models`` is the live list of parameter dictionaries (entries are
+    replaced in place when a sub-model's Gaussians change)."""
+
+    def __init__(self, models, optimizers: Dict[str, torch.optim.Optimizer], config=DensifyConfig(), seed: int = 0,
+                 group=None, stats_factory=Stats, **densifier_kw):
+        cfgs = list(config) if isinstance(config, (list, tuple)) else [config] * len(models)
+        assert len(cfgs) == len(models)
+        self.models = models
+        self.parts = [Densifier(m, optimizers, cfgs[i], seed=seed * 1009 + i, group=group,
+                                stats=stats_factory(group=group), **densifier_kw) for i, m in enumerate(models)]
+
+    def after_train(self, step: int, visible, xys_grads, radii_parts, last_size) -> None:
+        """``visible``: indices of the sub-models in this step's render, in render order; ``xys_grads[j]`` /
+        ``radii_parts[j]``: the retained ``xys.grad`` (None: the view saw nothing) and the radii of ``visible[j]``."""
+        for j, i in enumerate(visible):
+            self.parts[i].after_train(step, xys_grads[j], radii_parts[j], last_size)
+
+    def refinement_after(self, step: int):
+        """Every sub-model in model order (the same collectives in the same order on every rank).  Returns the list of
+        "changed" flags; ``models[i]`` is that sub-model's current parameter dictionary afterwards."""
+        changed = []
+        for i, d in enumerate(self.parts):
+            changed.append(d.refinement_after(step))
+            self.models[i] = d.params
+        return changed

@@ -203,15 +203,18 @@ class GradAllReducer:
             if ex is None or not ex.active or ex.started:       # never ahead of step 1
                 self._issue_bucket(early=True)
 
-    def _issue_bucket(self, early: bool) -> None:
+    def _issue_bucket(self, early: bool, absent=frozenset()) -> None:
         if not self.small or self._bucket is not None:
             return
-        for p in self.small:
+        members = [p for p in self.small if id(p) not in absent] if absent else self.small
+        if not members:
+            return
+        for p in members:
             if p.grad is None:
                 p.grad = torch.zeros_like(p)
-        flat = torch.cat([p.grad.reshape(-1) for p in self.small])
+        flat = torch.cat([p.grad.reshape(-1) for p in members])
         work = dist.all_reduce(flat, op=self._op, group=self.group, async_op=True)
-        self._bucket = (flat, work, [p.grad._version for p in self.small])
+        self._bucket = (flat, work, [p.grad._version for p in members], members)
         self.stats["bucket_early" if early else "bucket_late"] += 1
 
     # ------------------------------------------------------------------- exposed-communication timing
@@ -467,17 +470,30 @@ class GradAllReducer:
         self.stats["touched_fraction"] = sum(counts) / float(self.world * n)
         return True
 
-    def finish(self) -> None:
-        """Call after ``loss.backward()``."""
-        if self.sparse and self.active and self._finish_sparse():
+    def finish(self, absent: Iterable[torch.Tensor] = ()) -> None:
+        """Call after ``loss.backward()``.
+
+        ``absent``: registered parameters that NO rank's view could reach this step — the scene graph's sub-models that
+        are in no rank's frame (which objects a frame shows comes from the replicated annotations, so every rank can
+        name the same set without communicating; it MUST be the same set on every rank).  They are left out of the
+        collectives and keep ``grad = None``, so the optimiser skips them as it does in the reference, whose sub-model
+        outside the frame gets no gradient at all (``sgn_splatfacto_scene_graph.py:322-352``) — a zero gradient would
+        still move them by Adam's momentum.  A parameter that is NOT absent but received no gradient on this rank (its
+        sub-model is in another rank's frame only, or this rank's view saw nothing) takes part with zeros."""
+        absent = frozenset(id(p) for p in absent)
+        if absent:
+            for p in self.params:
+                if id(p) in absent and p.grad is not None:
+                    raise RuntimeError("GradAllReducer.finish: a parameter named absent received a gradient on this rank")
+        if self.sparse and self.active and not absent and self._finish_sparse():
             return
         pending = []
         if self.sh_exchange is not None:
             self.sh_exchange.start()                     # 1. all-gathers (no-op if the SH backward already sent them)
         if self.active:
-            self._issue_bucket(early=False)              # 2. the flat bucket (no-op if the hook already sent it)
+            self._issue_bucket(early=False, absent=absent)   # 2. the flat bucket (no-op if the hook already sent it)
             for p in self.params:                        # 3. big tensors, one all-reduce each, in params order
-                if id(p) in self.big_ids:
+                if id(p) in self.big_ids and id(p) not in absent:
                     if p.grad is None:
                         p.grad = torch.zeros_like(p)
                     pending.append((dist.all_reduce(p.grad, op=self._op, group=self.group, async_op=True), p))
@@ -485,10 +501,11 @@ class GradAllReducer:
             self.sh_exchange.finish()                    # 4. rebuild (overlaps 2-3) or dense fallback
         if not self.active:
             return
+        self._arrived = 0
         if self._bucket is not None:
-            flat, work, versions = self._bucket
-            self._bucket, self._arrived = None, 0
-            if any(p.grad._version != v for p, v in zip(self.small, versions)):
+            flat, work, versions, members = self._bucket
+            self._bucket = None
+            if any(p.grad._version != v for p, v in zip(members, versions)):
                 raise RuntimeError("GradAllReducer(overlap=True): a gradient changed after its bucket had left — more "
                                    "than one backward pass between two finish() calls; use overlap=False")
             with self._span("bucket_all_reduce"):
@@ -496,7 +513,7 @@ class GradAllReducer:
             if self.average and not self._avg_in_collective:
                 flat /= self.world
             off = 0
-            for p in self.small:
+            for p in members:
                 n = p.grad.numel()
                 p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n

@@ -83,7 +83,7 @@ def make_scene(name: str, seed: int = 0, yaw: float = 0.0, device="cpu", n_overr
 
 
 def make_scene_graph(n_total: int, cam: Camera, n_objects: int = 8, object_frac: float = 0.1, fourier_dim: int = 5,
-                     seed: int = 0, z_range=(2.0, 60.0), device="cpu"):
+                     seed: int = 0, z_range=(2.0, 60.0), device="cpu", object_depth=(8.0, 48.0), object_extent=1.0):
     """Background + ``n_objects`` rigid objects (configs[2] shape: scene-graph dynamic objects).  Returns
     (models, poses [M,16], idft [M,F]); object parameters are in the object's local frame, its Gaussians
     spread ~1.5 m around the pose centre; ``features_dc`` of objects carries ``fourier_dim`` coefficients
@@ -97,7 +97,7 @@ def make_scene_graph(n_total: int, cam: Camera, n_objects: int = 8, object_frac:
     Rs, ts, idfts = [torch.eye(3)], [torch.zeros(3)], [torch.cat([torch.ones(1), torch.zeros(fourier_dim - 1)])]
     for k in range(n_objects):
         m = make_gaussians(n_obj, cam0, seed=seed + 1 + k, z_range=z_range)
-        m["means"] = torch.randn(n_obj, 3, generator=g) * torch.tensor([1.0, 0.6, 1.5])
+        m["means"] = torch.randn(n_obj, 3, generator=g) * torch.tensor([1.0, 0.6, 1.5]) * object_extent
         dc = torch.randn(n_obj, fourier_dim, 3, generator=g) * 0.1
         dc[:, 0] += m["features_dc"][:, 0]
         m["features_dc"] = dc
@@ -105,7 +105,7 @@ def make_scene_graph(n_total: int, cam: Camera, n_objects: int = 8, object_frac:
         yaw = float(torch.rand(1, generator=g)) * 6.28
         c, s = math.cos(yaw), math.sin(yaw)
         Rs.append(torch.tensor([[c, 0.0, s], [0.0, 1.0, 0.0], [-s, 0.0, c]]))
-        z = 8.0 + 40.0 * float(torch.rand(1, generator=g))
+        z = object_depth[0] + (object_depth[1] - object_depth[0]) * float(torch.rand(1, generator=g))
         x = (float(torch.rand(1, generator=g)) * 2 - 1) * 0.8 * z * (cam.width / 2.0 / cam.fx)
         ts.append(torch.tensor([x, 0.4 * z * (cam.height / 2.0 / cam.fy) * 0.5, z]))
         t_norm = float(torch.rand(1, generator=g))

@@ -24,32 +24,22 @@ def rel_l2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
-class TorchStats:
-    """`sgn_rast.densify.Stats` interface with `SplatfactoModel.after_train`'s own arithmetic in plain torch
-    (sgn_splatfacto.py:520-541) — lets the CPU tests drive `Densifier` without the HIP statistics kernel."""
+from sgn_rast import densify as _densify
 
-    def __init__(self):
-        self.xys_grad_norm = self.vis_counts = self.max_2Dsize = None
 
-    def reset(self):
-        self.xys_grad_norm = self.vis_counts = self.max_2Dsize = None
+class TorchStats(_densify.Stats):
+    """`sgn_rast.densify.Stats` with `SplatfactoModel.after_train`'s own arithmetic in plain torch
+    (sgn_splatfacto.py:520-541) in place of the HIP statistics kernel — lets the CPU tests drive `Densifier`, and its
+    view-parallel bookkeeping (first view of the interval, joining with zeros: the product's code), without a GPU."""
 
-    @torch.no_grad()
-    def update(self, xys_grad, radii, last_size):
-        visible = (radii > 0).flatten()
-        grads = xys_grad.detach().norm(dim=-1)
-        if self.xys_grad_norm is None:
-            self.xys_grad_norm = grads
-            self.vis_counts = torch.ones_like(grads)
+    def _accumulate(self, g, r, max_dim, first):
+        visible = (r > 0).flatten()
+        grads = g.norm(dim=-1)
+        if first:
+            self.xys_grad_norm.copy_(grads)
+            self.vis_counts.fill_(1.0)
+            self.max_2Dsize.zero_()
         else:
             self.vis_counts[visible] = self.vis_counts[visible] + 1
             self.xys_grad_norm[visible] = grads[visible] + self.xys_grad_norm[visible]
-        if self.max_2Dsize is None:
-            self.max_2Dsize = torch.zeros_like(radii, dtype=torch.float32)
-        self.max_2Dsize[visible] = torch.maximum(self.max_2Dsize[visible],
-                                                 radii.detach()[visible] / float(max(last_size[0], last_size[1])))
-
-    def sync(self, group=None):
-        from sgn_rast.dp import sync_densify_stats
-        if self.xys_grad_norm is not None:
-            sync_densify_stats(self.xys_grad_norm, self.vis_counts, self.max_2Dsize, group=group)
+        self.max_2Dsize[visible] = torch.maximum(self.max_2Dsize[visible], r[visible] / float(max_dim))
