@@ -335,11 +335,18 @@ def main():
     if args.scene_graph:
         models, poses, idft = scenes.make_scene_graph(n_gauss, cam, n_objects=8, object_frac=0.1, device=dev)
         sg = ([step.leaf_params(m) for m in models], poses, idft)
-        if world > 1:
+        if world > 1 or force_dp:
+            # The scene graph's backward reaches every sub-model's leaves through four raster nodes (main, depth, two
+            # accumulations): the row exchange serves ONE full pass of ONE model (its walked list, its claimed SH node),
+            # so this step takes the DENSE exchange — the flat bucket of the small per-Gaussian gradients of all nine
+            # sub-models + one all-reduce per features_rest tensor, overlapped with the backward — and says so.
             if reducer is not None and reducer.sh_exchange is not None:
                 reducer.sh_exchange.remove()
             reducer.remove()
-            reducer = dp.GradAllReducer([p for m in sg[0] for p in m.values()], overlap=not args.no_dp_overlap)
+            sg_leaves = [p for m in sg[0] for p in m.values()]
+            reducer = dp.GradAllReducer(sg_leaves, big=[m["features_rest"] for m in sg[0]], force=force_dp,
+                                        overlap=not args.no_dp_overlap)
+            reducer.timing = True
 
     sky = None
     if args.sky:
@@ -436,6 +443,14 @@ def main():
             else:
                 torch.distributed.barrier()
 
+    ranks_seen = None
+    if world > 1 or force_dp:
+        props = torch.cuda.get_device_properties(local)
+        mine = {"rank": rank, "device": local, "name": props.name,
+                "pci": f"{getattr(props, 'pci_domain_id', 0):04x}:{getattr(props, 'pci_bus_id', 0):02x}:{getattr(props, 'pci_device_id', 0):02x}"}
+        ranks_seen = [None] * world
+        torch.distributed.all_gather_object(ranks_seen, mine)
+
     if os.environ.get("SGN_BENCH_HANG_RANK") == str(rank) and world > 1:
         time.sleep(3600)     # failure-containment test: this rank never joins the collectives (profiles/scripts/r03c.sh)
     import gc
@@ -476,6 +491,10 @@ def main():
         return dt_, out_
 
     def exchange_name(safe):
+        if sg is not None:
+            return ("DENSE: flat bucket of the small per-Gaussian gradients of all sub-models + one all-reduce per "
+                    "features_rest tensor" + ("" if args.no_dp_overlap else ", overlapped with the backward")
+                    + " (the row exchange serves one full pass of one model, not the scene graph's four raster nodes)")
         if safe:
             return "dense all-reduce of every gradient after the backward (SUM, divided on the device)"
         if args.dp_exchange == "rows":
@@ -533,6 +552,26 @@ def main():
     elif world > 1:
         kept["line"] = headline_line(dt, f"dp{world} (view-parallel; {exchange_name(False)})")
     n_isect = int(out.num_tiles_hit.sum().item())
+
+    # scene graph under the N-rank harness: the reducer's gradients against plain per-tensor all-reduces of the same
+    # step's local gradients (SUM, divided on the device) — nothing but `all_reduce`, issued after the backward
+    sg_check = None
+    if sg is not None and reducer is not None:
+        held, reducer = reducer, None
+        one_step()
+        ref = []
+        for p_ in sg_leaves:
+            g_ = p_.grad.detach().clone()
+            torch.distributed.all_reduce(g_, op=torch.distributed.ReduceOp.SUM)
+            ref.append(g_ / world)
+        reducer = held
+        one_step()
+        worst = torch.stack([(p_.grad - r_).norm() / r_.norm().clamp_min(1e-30) for p_, r_ in zip(sg_leaves, ref)]).max()
+        torch.distributed.all_reduce(worst, op=torch.distributed.ReduceOp.MAX)
+        sg_check = {"grad_rel_l2_vs_plain_all_reduce": float(worst.item()), "leaves": len(sg_leaves)}
+        del ref
+        if not sg_check["grad_rel_l2_vs_plain_all_reduce"] < 1e-4:
+            raise RuntimeError(f"scene-graph reducer disagrees with plain all-reduces: {sg_check}")
 
     # the same function through the fused front ends (extension API), reported beside the headline
     fused_extra = None
@@ -801,6 +840,11 @@ def main():
             if dp_paths is not None:
                 # both exchanges were measured, the plain one first (kept as the fallback line while the other ran)
                 line["config"]["dp"]["paths"] = dp_paths
+            if sg_check is not None:
+                line["config"]["dp"]["scene_graph_check"] = sg_check
+            line["config"]["dp"]["exchange"] = exchange_name(safe_reducer is not None and reducer is safe_reducer)
+            # which devices the ranks of this run really sat on (one line per rank: rank, local device, its bus id)
+            line["config"]["dp"]["ranks_seen"] = ranks_seen
             if os.environ.get("SGN_BENCH_SHARE_GPU") == "1":
                 line["config"]["note"] = "ranks SHARE GPUs (functional check of the N-rank path, not a scaling number)"
         line["config"]["settle_steps"] = max(0, args.settle)   # untimed, before the W warm-up steps

@@ -328,6 +328,11 @@ int sgn_rows_pack(int count, const int32_t *list, int n_tensors, const float *co
 int sgn_rows_scatter(int count, const float *rows /*incl. header row*/, int row_words, int n_tensors,
                      float *const *dsts_host, const int32_t *widths_host, float scale, int tail_words, float *tail_out,
                      sgn_stream_t stream);
+/* Contract check of the row exchange: *count = rows of the n_tensors per-Gaussian gradient tensors (NULL = no gradient)
+ * that hold a non-zero word although sgn_mark_walked did not list their id in `epoch` (stamps[id] != epoch) — rows the
+ * exchange would not send (a regulariser on per-Gaussian parameters, any loss term beside the rendered images). */
+int sgn_rows_outside(int n, int n_tensors, const float *const *srcs_host, const int32_t *widths_host,
+                     const int32_t *stamps, int epoch, int32_t *count, sgn_stream_t stream);
 
 /* Window recognition for the drop-in scene-graph path (no upstream counterpart).  The reference renders its sub-model
  * passes (sgn_splatfacto_scene_graph.py:364-366) from torch.cat COPIES of per-model slices of the main projection

@@ -1193,7 +1193,10 @@ __global__ __launch_bounds__(256) void tile_order_mb_kernel(int n_tiles, const i
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int i = i0 + j * 256 + tid;
-            if (i < n_tiles) order[start[(unsigned)rec[j] >> 26] + (rec[j] & ((1 << 26) - 1))] = i;
+            // (the position is < n_tiles whenever the scratch head was zero on entry, which every completed launch
+            // guarantees; an aborted launch or a foreign buffer must not turn into an out-of-bounds store)
+            const int at = start[(unsigned)rec[j] >> 26] + (rec[j] & ((1 << 26) - 1));
+            if (i < n_tiles && (unsigned)at < (unsigned)n_tiles) order[at] = i;
         }
     }
     __syncthreads();

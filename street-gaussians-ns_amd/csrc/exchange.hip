@@ -81,10 +81,37 @@ __global__ __launch_bounds__(256) void rows_pack_kernel(int count, const int32_t
     int at = 1;
     for (int j = 0; j < T.n_tensors; ++j) {
         const int w = T.width[j];
-        const float *s = T.src[j] + (size_t)id * w;
-        for (int k = 0; k < w; ++k) o[at + k] = s != nullptr ? s[k] : 0.f;
+        // a tensor without a gradient this step arrives as NULL (its rows are zeros): test BEFORE offsetting
+        const float *base = T.src[j];
+        if (base != nullptr) {
+            const float *s = base + (size_t)id * w;
+            for (int k = 0; k < w; ++k) o[at + k] = s[k];
+        } else {
+            for (int k = 0; k < w; ++k) o[at + k] = 0.f;
+        }
         at += w;
     }
+}
+
+// Contract check of the row exchange: rows with a non-zero gradient word whose id the forward did NOT list (stamp !=
+// epoch).  The exchange sends listed rows only, so such a row — a regulariser on per-Gaussian parameters, anything the
+// caller adds to the loss besides the rendered images — would be dropped; sgn_rast/dp.py runs this on the first steps
+// and falls back to the dense sequence for good when it counts one.
+__global__ __launch_bounds__(256) void rows_outside_kernel(int n, RowTensors T, const int32_t *__restrict__ stamps,
+                                                           int epoch, int32_t *__restrict__ count) {
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    bool hit = false;
+    if (id < n && stamps[id] != epoch) {
+        for (int j = 0; j < T.n_tensors; ++j) {
+            const float *base = T.src[j];
+            if (base == nullptr) continue;
+            const int w = T.width[j];
+            const float *s = base + (size_t)id * w;
+            for (int k = 0; k < w; ++k) hit |= s[k] != 0.f;
+        }
+    }
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && m != 0ull) atomicAdd(count, __popcll(m));
 }
 
 __global__ __launch_bounds__(256) void rows_scatter_kernel(int count, const float *__restrict__ rows, RowTensors T,
@@ -123,6 +150,24 @@ SGN_EXPORT int sgn_rows_pack(int count, const int32_t *list, int n_tensors, cons
     SGN_ARG_CHECK(words == row_words && row_words >= 3, -4);
     hipLaunchKernelGGL(rows_pack_kernel, dim3(sgn_cdiv(count > 0 ? count : 1, 256)), dim3(256), 0, (hipStream_t)stream,
                        count, list, T, row_words, header3, out);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
+SGN_EXPORT int sgn_rows_outside(int n, int n_tensors, const float *const *srcs_host, const int32_t *widths_host,
+                                const int32_t *stamps, int epoch, int32_t *count, sgn_stream_t stream) {
+    SGN_ARG_CHECK(n >= 0 && n_tensors >= 1 && n_tensors <= ROWS_MAX_TENSORS && srcs_host && widths_host && stamps &&
+                      count && epoch != 0, -1);
+    RowTensors T;
+    T.n_tensors = n_tensors;
+    for (int j = 0; j < n_tensors; ++j) {
+        SGN_ARG_CHECK(widths_host[j] >= 1 && widths_host[j] <= 64, -3);
+        T.width[j] = widths_host[j]; T.src[j] = srcs_host[j]; T.dst[j] = nullptr;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SGN_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(rows_outside_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, T, stamps, epoch, count);
     SGN_LAUNCH_CHECK();
     return 0;
 }

@@ -81,6 +81,7 @@ SIGNATURES = {
     "sgn_mark_walked": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_rows_pack": (_i, [_i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "sgn_rows_scatter": (_i, [_i, _vp, _i, _i, _vp, _vp, _f, _i, _vp, _vp]),
+    "sgn_rows_outside": (_i, [_i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "sgn_rows_match": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_raster_workspace_bytes": (_sz, [_i, _i64, _vp]),
     "sgn_tile_order_scratch_bytes": (_sz, [_i]),

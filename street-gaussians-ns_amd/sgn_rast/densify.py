@@ -37,9 +37,12 @@ class Stats:
 
     _NO_VIEW = (1 << 62)
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, force: bool = False):
         # the process group the statistics are reduced over (:meth:`sync`); None = the default group
         self.group = group
+        # force: keep the view-parallel bookkeeping and make the collectives in a 1-rank group too (self-test of the
+        # N-rank path on one GPU, like GradAllReducer(force=True); same values as the plain form)
+        self.force = bool(force)
         self.xys_grad_norm: Optional[torch.Tensor] = None
         self.vis_counts: Optional[torch.Tensor] = None
         self.max_2Dsize: Optional[torch.Tensor] = None
@@ -79,7 +82,7 @@ class Stats:
         if first:
             f32 = dict(dtype=torch.float32, device=g.device)
             world, rank = self._world_rank()
-            if world > 1:
+            if world > 1 or self.force:
                 self.xys_grad_norm, self.vis_counts = torch.zeros(n, **f32), torch.zeros(n, **f32)
                 self.max_2Dsize = torch.zeros(n, **f32)
                 self._first_key = world * int(self._updates if step is None else step) + rank
@@ -97,7 +100,7 @@ class Stats:
         import torch.distributed as dist
         from .dp import sync_densify_stats
         group = group if group is not None else self.group
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not self.force):
             self.synced_dim = None
             return self.xys_grad_norm is not None
         dev = self.xys_grad_norm.device if self.xys_grad_norm is not None else torch.device(device or "cpu")

@@ -146,13 +146,22 @@ class GradAllReducer:
     def __init__(self, params: Sequence[torch.Tensor], big: Iterable[torch.Tensor] = (),
                  average: bool = True, group=None, sh_exchange: "Optional[SHGradExchange]" = None,
                  force: bool = False, overlap: bool = False, collective_average: Optional[bool] = None,
-                 sparse: bool = False, sparse_max_fraction: float = 0.3):
+                 sparse: bool = False, sparse_max_fraction: float = 0.3, sparse_check=8):
         self.sh_exchange = sh_exchange
         # sparse=True: the compacted row exchange (see _finish_sparse) whenever every rank can take part and the mean
         # touched fraction stays below sparse_max_fraction; the dense sequence otherwise — decided per step from
         # all-gathered counts, identically on every rank
         self.sparse = bool(sparse) and sh_exchange is not None
         self.sparse_max_fraction = float(sparse_max_fraction)
+        # CONTRACT of the row exchange on the GPU: the rows it sends are the rows the forward WALKED, and every
+        # per-Gaussian `.grad` is then REPLACED by the scattered sums — so a gradient row that does not come from the
+        # rasterizer's walk (a scale / opacity regulariser on per-Gaussian parameters, any loss term beside the rendered
+        # images) would be dropped, this rank's own rows included.  `sparse_check`: on the first that-many row-exchange
+        # steps ("always": on every one; 0: never) the gradients are scanned for non-zero rows OUTSIDE the list
+        # (sgn_rows_outside, ~44 B per Gaussian, one small MAX all-reduce and a host read); one such row on any rank
+        # sends that step — and every later one — down the dense sequence, with `stats["outside_rows"]` saying why.
+        self.sparse_check = sparse_check
+        self._checked_steps = 0
         skip = sh_exchange.leaf_ids() if sh_exchange is not None else set()
         self.params = [p for p in params if id(p) not in skip]
         self.big_ids = {id(p) for p in big if id(p) not in skip}
@@ -174,7 +183,7 @@ class GradAllReducer:
         self._arrived = 0
         self._hooks = []
         self.stats = {"bucket_early": 0, "bucket_late": 0, "sparse_steps": 0, "dense_steps": 0,
-                      "touched_fraction": None, "rows_sent": 0}
+                      "touched_fraction": None, "rows_sent": 0, "outside_rows": 0, "checked_steps": 0}
         # timing=True (bench.py): device events around the waits for the step's collectives, so the line can say how much
         # communication the compute stream was actually held up by (`exposed_ms()`); two event records per wait
         self.timing = False
@@ -330,6 +339,7 @@ class GradAllReducer:
         Returns False when the step must take the dense sequence."""
         ex = self.sh_exchange
         if ex is None or not ex.active or ex.started:
+            self._drop_announcement()
             return False
         c = ex._claimed
         leaves = [p for p in self.small if p.dim() >= 1]
@@ -392,6 +402,8 @@ class GradAllReducer:
         degs = {(int(e[2]), int(e[3])) for e in every if int(e[0]) > 0 and int(e[2]) >= 0}
         sparse = (total_ok and len(degs) <= 1 and n > 0
                   and sum(counts) <= self.sparse_max_fraction * self.world * n)
+        if sparse and hip and self._check_due():
+            sparse = self._rows_inside_the_list(rows_p, widths, c, n, dev)
         if not sparse:
             self.stats["dense_steps"] += 1
             return False
@@ -470,6 +482,56 @@ class GradAllReducer:
         self.stats["touched_fraction"] = sum(counts) / float(self.world * n)
         return True
 
+    def _check_due(self) -> bool:
+        k = self.sparse_check
+        return k == "always" or (isinstance(k, int) and self._checked_steps < k)
+
+    def _rows_inside_the_list(self, rows_p, widths, c, n, dev) -> bool:
+        """The checked mode of the row exchange (see `sparse_check`): False — identically on every rank — when some
+        rank holds a non-zero gradient row the forward did not list; the exchange is then switched off for good."""
+        import ctypes as C
+        from . import _lib as L
+        m = self._mark
+        outside = torch.zeros(1, dtype=torch.int32, device=dev)
+        if m is not None and m["n"] == n and c is not None:
+            f32c = lambda t: t if (t.dtype is torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+            srcs = [None if p.grad is None else f32c(p.grad.detach()) for p in rows_p]
+            nt = len(rows_p)
+            if any(t is not None for t in srcs):
+                L.check(L.load().sgn_rows_outside(n, nt, (C.c_void_p * nt)(*[None if t is None else t.data_ptr() for t in srcs]),
+                                                  (C.c_int32 * nt)(*widths), L.ptr(m["stamps"]), int(m["epoch"]),
+                                                  L.ptr(outside), L.stream_ptr()), "sgn_rows_outside")
+        worst = outside.to(torch.int64)
+        if dist.get_backend(self.group) == "gloo" and worst.is_cuda:
+            host = worst.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            worst = host
+        else:
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=self.group)
+        worst = int(worst.item())
+        self._checked_steps += 1
+        self.stats["checked_steps"] = self._checked_steps
+        if worst > 0:
+            self.stats["outside_rows"] = worst
+            self.sparse = False
+            import warnings
+            warnings.warn(f"GradAllReducer(sparse=True): {worst} per-Gaussian gradient row(s) are non-zero outside the "
+                          "rows the forward walked (a loss term beside the rendered images?) — the row exchange would "
+                          "drop them; using the dense exchange from now on")
+            return False
+        return True
+
+    def _drop_announcement(self) -> None:
+        """The step goes dense although `after_forward` may already have announced its walked rows: settle that
+        collective and forget it, so the NEXT step does not find a stale announcement (it would count a second view and
+        raise on a valid step)."""
+        early, self._early = self._early, None
+        self._extra_before = False
+        if early is not None:
+            early["done"].synchronize()
+        if self.sh_exchange is not None:
+            self.sh_exchange._fwd = dict(claimed=0, other=0, degree=-1, k=0, cam=False)
+
     def finish(self, absent: Iterable[torch.Tensor] = ()) -> None:
         """Call after ``loss.backward()``.
 
@@ -485,6 +547,8 @@ class GradAllReducer:
             for p in self.params:
                 if id(p) in absent and p.grad is not None:
                     raise RuntimeError("GradAllReducer.finish: a parameter named absent received a gradient on this rank")
+        if self.sparse and self.active and absent:
+            self._drop_announcement()
         if self.sparse and self.active and not absent and self._finish_sparse():
             return
         pending = []

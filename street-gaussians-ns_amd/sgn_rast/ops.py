@@ -841,7 +841,8 @@ def _fwd_long_thresh(ro) -> int:
     return int(ro.adapt_fwd if ro.adapt_fwd > 0 else 1024) if ro.waves_fwd == 2 else 0
 
 
-def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = None, long_thresh: int = 0):
+def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = None, long_thresh: int = 0,
+                pairs_known: bool = True):
     """Launch order of the raster workgroups (longest first).  Forward: by depth-list length, one tiny kernel per
     binning, shared by every pass that reuses it.  Backward (``tile_kmax`` from its forward): by reverse-walk length,
     with the count of walks >= ``long_thresh`` behind the permutation (the two-kernel adaptive scheme)."""
@@ -864,7 +865,8 @@ def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = Non
         scratch = S.order_scratch[n_tiles] = torch.zeros(int(lib.sgn_tile_order_scratch_bytes(n_tiles)) // 4,
                                                          dtype=torch.int32, device=tile_bins.device)
     L.check(lib.sgn_tile_order(n_tiles, L.ptr(tile_bins), L.ptr(tile_kmax), int(long_thresh),
-                               int(small_splat_q16) if tile_kmax is not None else 0, L.ptr(order), L.ptr(scratch),
+                               int(small_splat_q16) if (tile_kmax is not None and pairs_known) else 0, L.ptr(order),
+                               L.ptr(scratch),
                                4 * scratch.numel() if scratch is not None else 0, L.stream_ptr()), "sgn_tile_order")
     if tile_kmax is None:
         oc[ok] = (tile_bins, order)          # (keeps tile_bins alive: its id cannot be recycled while the entry lives)
@@ -1388,7 +1390,9 @@ class _RasterizeGaussians(Function):
             # the backward's own launch order, by REVERSE-WALK length (tried in r03: the forward's order by list length
             # plus per-tile classification, no launch — the one-wave kernel then ran 323 instead of 288 us on the
             # benchmark scene: a late long walk is a lone-wave tail; profiles/r03f_*)
-            order = _tile_order(bins, kmax, ctx.ro.adapt_bwd)
+            # (a group walk's statistics hold the walk depth only — sgn_raster_fwd_groups records no per-tile pair count
+            # for the head / tail groups — so the small-splat classification, which reads that count, stays off for it)
+            order = _tile_order(bins, kmax, ctx.ro.adapt_bwd, pairs_known=kmax is ctx.tile_kmax)
             if order is not None and not window and id_range == (0, n):
                 _S().walk_stat = order[-1:]          # rides to the host with the next binning's count (mask policy)
             args = (H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(ids), L.ptr(bins),

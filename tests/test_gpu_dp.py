@@ -168,3 +168,92 @@ def test_row_exchange_over_single_rank_rccl_group():
                 assert torch.equal(Pb[k].grad.reshape(n, -1).abs().sum(1) == 0, Pa[k].grad.reshape(n, -1).abs().sum(1) == 0), k
     finally:
         dist.destroy_process_group()
+
+
+def _one_step_with_extra_loss(P, cam, w_img, w_a, reducer, extra):
+    """`step.train_step`'s sequence with a loss term beside the rendered images."""
+    from sgn_rast import step
+    for p in P.values():
+        p.grad = None
+    out = step.render(P, cam, 3, 16, caller_syncs=False)
+    loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum()) / (cam.height * cam.width) + extra(P)
+    loss.backward()
+    if reducer is not None:
+        reducer.finish()
+
+
+def test_row_exchange_contract_check_catches_gradient_rows_outside_the_walk():
+    """the GPU row exchange sends the rows the forward walked and REPLACES every per-Gaussian
+    gradient — a scale regulariser touches every row.  The checked mode (first `sparse_check` steps) must see it, send
+    that step and all later ones down the dense sequence, and the regulariser's rows must survive."""
+    import warnings
+    import torch.distributed as dist
+    from sgn_rast import dp, ops, scenes, step
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        n = 40000
+        cam, raw = scenes.make_scene("c1", n_override=n)
+        cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+        w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+        reg = lambda P: 1e-3 * (P["log_scales"] ** 2).sum()
+        Pa = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+        ops.clear_binning_cache()
+        _one_step_with_extra_loss(Pa, cam, w_img, w_a, None, reg)
+        Pb = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+        ex = dp.SHGradExchange(Pb["features_dc"], Pb["features_rest"], force=True).install().set_view(Pb["means"], cam.cam_pos)
+        red = dp.GradAllReducer(list(Pb.values()), big=[Pb["features_rest"]], sh_exchange=ex, force=True, sparse=True,
+                                sparse_max_fraction=0.9)
+        try:
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                for _ in range(2):
+                    ops.clear_binning_cache()
+                    _one_step_with_extra_loss(Pb, cam, w_img, w_a, red, reg)
+        finally:
+            ex.remove()
+            red.remove()
+        torch.cuda.synchronize()
+        assert red.stats["outside_rows"] > n // 2 and red.stats["sparse_steps"] == 0 and red.stats["dense_steps"] == 1
+        assert red.sparse is False and any("outside the rows the forward walked" in str(w.message) for w in caught)
+        for k in Pa:
+            assert rel_l2(Pb[k].grad, Pa[k].grad) < 1e-5, k
+        assert int((Pb["log_scales"].grad != 0).any(1).sum()) > n // 2          # the regulariser's rows are there
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_exchange_with_a_per_gaussian_parameter_that_gets_no_gradient():
+    """a registered [n, ...] parameter outside the loss reaches sgn_rows_pack as a NULL source (the
+    kernel offset the pointer before testing it).  Its rows travel as zeros; the others equal the plain step's."""
+    import torch.distributed as dist
+    from sgn_rast import dp, ops, scenes, step
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        n = 40000
+        cam, raw = scenes.make_scene("c1", n_override=n)
+        cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+        w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+        Pa = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+        ops.clear_binning_cache()
+        step.train_step(Pa, cam, w_img, w_a)
+        Pb = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+        unused = torch.zeros(n, 5, device=DEV, requires_grad=True)               # e.g. a per-Gaussian semantic feature
+        ex = dp.SHGradExchange(Pb["features_dc"], Pb["features_rest"], force=True).install().set_view(Pb["means"], cam.cam_pos)
+        red = dp.GradAllReducer(list(Pb.values()) + [unused], big=[Pb["features_rest"]], sh_exchange=ex, force=True,
+                                sparse=True, sparse_max_fraction=0.9, sparse_check="always")
+        try:
+            for _ in range(2):
+                ops.clear_binning_cache()
+                step.train_step(Pb, cam, w_img, w_a, reducer=red)
+        finally:
+            ex.remove()
+            red.remove()
+        torch.cuda.synchronize()
+        assert red.stats["sparse_steps"] == 2 and red.stats["outside_rows"] == 0 and red.stats["checked_steps"] == 2
+        assert unused.grad is not None and not unused.grad.any()
+        for k in Pa:
+            assert rel_l2(Pb[k].grad, Pa[k].grad) < 1e-5, k
+    finally:
+        dist.destroy_process_group()
