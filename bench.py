@@ -515,6 +515,32 @@ def main():
                            "backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None},
                 "roofline": None, "note": "fallback line: a later phase of the run failed (config.dp.abandoned_phase)"}
 
+    def repeat_chunks(first_dt, min_total_s=0.5, max_chunks=40):
+        """The driver's command times K = 20 steps — 25 ms, box-to-box spread +-4 %.  `value` stays
+        the contract's: exactly K steps between barrier + synchronize pairs.  Beside it: MORE chunks of exactly K steps,
+        each bracketed the same way (max over ranks), until >= 0.5 s of timed steps have been seen, and their median /
+        min / max — the figure to compare across boxes.  Same chunk count on every rank (decided on reduced times)."""
+        times, total = [first_dt], first_dt
+        while total < min_total_s and len(times) < max_chunks:
+            barrier(); torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(args.steps):
+                one_step()
+            torch.cuda.synchronize(); barrier()
+            d_ = time.perf_counter() - t0_
+            if world > 1:
+                t_ = torch.tensor([d_], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(t_, op=torch.distributed.ReduceOp.MAX)
+                d_ = float(t_.item())
+            times.append(d_); total += d_
+        per = sorted(1e3 * t_ / args.steps for t_ in times)
+        med = per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2])
+        return {"chunks": len(times), "steps_per_chunk": args.steps, "timed_s": total,
+                "ms_per_step_median": med, "ms_per_step_mean": 1e3 * total / (args.steps * len(times)),
+                "ms_per_step_min": per[0], "ms_per_step_max": per[-1],
+                "value_at_median": world * 1e3 / med,
+                "note": "chunk 1 is the line's `value` (exactly K steps, as the contract says); the others follow it"}
+
     dp_paths, safe_reducer = None, None
     dt, out = measure_headline(args.settle)
     if safe_first:
@@ -552,6 +578,7 @@ def main():
     elif world > 1:
         kept["line"] = headline_line(dt, f"dp{world} (view-parallel; {exchange_name(False)})")
     n_isect = int(out.num_tiles_hit.sum().item())
+    repeat = repeat_chunks(dt)
 
     # scene graph under the N-rank harness: the reducer's gradients against plain per-tensor all-reduces of the same
     # step's local gradients (SUM, divided on the device) — nothing but `all_reduce`, issued after the backward
@@ -646,6 +673,23 @@ def main():
             ops.activation_proofs, ops.sh_split_backward = saved_p
         no_proofs_extra["note"] = ("library defaults with SGN_ACT_PROOFS=0 SGN_SH_SPLIT_BWD=0: every operator takes its "
                                    "plain autograd node (gradients to the activated tensors, dense SH gradient)")
+
+    # what the documented (default) sort ranking costs: the same step with the returning-atomic ranking forced, if
+    # this device passes the probe under load (the line's `value` is measured with the default)
+    sort_ab = None
+    if args.path == "dropin" and not args.no_fused_extra and world == 1 and L.sort_rank_mode() == 0:
+        try:
+            bad = L.sort_selftest_under_load(rounds=64)
+            if bad == 0:
+                with L.force_sort_rank("atomic"):
+                    ab = timed_variant()
+                sort_ab = {"atomic_probe_under_load": "passed (2048 probe sorts per ranking, 0 mismatching pairs)",
+                           "with_atomic_ranking": ab,
+                           "cost_of_default_ms_per_step": 1e3 * dt / args.steps - ab["ms_per_step"]}
+            else:
+                sort_ab = {"atomic_probe_under_load": f"FAILED: {bad} mismatching pairs"}
+        except Exception as e:
+            sort_ab = {"atomic_probe_under_load": f"error: {e!r}"}
 
     # north_star quotes the 8-GPU target on C4 (2 M Gaussians): the same harness on that scene, beside the headline
     c4_extra = None
@@ -755,39 +799,47 @@ def main():
         n_pix = cam.height * cam.width
         # dominant single kernel (the "sort" slot spans 18 launches, so it is not a candidate)
         dom = max(("raster_bwd", "raster_fwd", "pack_records"), key=lambda k: kernels[k][1])
-        # algorithmic bytes per launch of the dominant kernel
-        alg = {"raster_bwd": 112 * n_isect + 24 * n_pix,      # gather 40 + grad scatter 72 per isect; 24 B/pixel
-               "raster_fwd": 40 * n_isect + 20 * n_pix,       # gather 40 per isect; 20 B/pixel written
-               "pack_records": 40 * n_isect}[dom]             # the same 40 B/isect gather, done once
         dur_s = kernels[dom][1] * 1e-3
-        achieved = alg / dur_s / 1e9 if dur_s > 0 else 0.0
+        # SURVEY.md section 8d's per-unit bytes of the dominant kernel: per list entry / per pixel
+        bytes_per_entry = {"raster_bwd": 112, "raster_fwd": 40, "pack_records": 40}[dom]   # gather 40 (+ grad scatter 72)
+        pix_bytes = {"raster_bwd": 24, "raster_fwd": 20, "pack_records": 0}[dom]
+        # (1) THE ROOFLINE FIGURE: bytes of the units the launch PROCESSES — the list entries it
+        # walks before its tile saturates (the forward stops at T <= 1e-4, the backward starts at final_idx: reference
+        # semantics), plus the per-pixel bytes — over the launch time.  Cannot exceed the measured traffic, let alone 1.
+        processed = None
+        if walk is not None and dur_s > 0:
+            n_units = walk["entries_walked"] if dom != "pack_records" else n_gauss
+            processed = bytes_per_entry * n_units + pix_bytes * n_pix
+        achieved = processed / dur_s / 1e9 if processed is not None else None
+        # (2) the section-8d BUDGET: every upstream-semantic intersection charged, whether or not a tile still walks it.
+        # A rate at which the reference's byte budget is retired; > 1 where tiles saturate early; NOT a utilisation.
+        budget = bytes_per_entry * n_isect + pix_bytes * n_pix
         step_bytes = 748 * n_gauss + 316 * n_isect + 44 * n_pix
-        # PMC numbers come from separate rocprofv3 passes (counters cannot be read from inside this process);
-        # profiles/roofline_pmc.json holds them per kernel with the files they were read from.  They belong to the
-        # default workload only.
-        traffic, pmc, kernel_bound = None, None, None
-        default_workload = (args.scene == "metric" and not args.n and not args.street and not args.translucent
-                            and sg is None)
+        # (3) counters: separate rocprofv3 passes (they cannot be read from inside this process), kept per kernel and
+        # workload in profiles/roofline_pmc.json with the source tables, the git head and the hash of raster.hip they
+        # were taken on; a different raster.hip marks them STALE and they are not replayed as this run's.
+        import hashlib
+        workload_key = ("scene_graph_" + args.path if sg is not None else "street" if args.street else
+                        args.scene if not (args.n or args.translucent or args.sky) else None)
+        traffic, pmc, pmc_info = None, None, {"file": "profiles/roofline_pmc.json"}
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "roofline_pmc.json")))
-            if dom in pj:
-                kernel_bound = pj[dom].get("bound")      # what limits the KERNEL (its counters): any workload
-                if default_workload:                     # the counter VALUES belong to the default workload only
-                    pmc = pj[dom]
-                    traffic = pmc.get("hbm_traffic_bytes")
-        except Exception:
-            pass
-        bytes_per_walked = {"raster_bwd": 112, "raster_fwd": 40, "pack_records": 40}[dom]
-        pix_bytes = {"raster_bwd": 24, "raster_fwd": 20, "pack_records": 0}[dom]
-        roof_extra = {}
-        if walk is not None and dur_s > 0:
-            wb = bytes_per_walked * walk["entries_walked"] + pix_bytes * n_pix
-            roof_extra["walked"] = dict(walk, bytes=wb, GBps=wb / dur_s / 1e9, frac=wb / dur_s / 1e9 / HBM_PEAK_GBS,
-                                        note="section 8d's per-intersection bytes charged only to the list entries the "
-                                             "kernel walks before its tile saturates (+ the per-pixel bytes)")
+            here = hashlib.sha256(open(os.path.join(ROOT, "street-gaussians-ns_amd", "csrc", "raster.hip"), "rb").read()).hexdigest()
+            pmc_info.update(round=pj.get("round"), git_head=pj.get("git_head"),
+                            stale=pj.get("raster_hip_sha256") != here)
+            wl = (pj.get("workloads") or {}).get(workload_key) if workload_key else None
+            if wl is not None and dom in wl and not pmc_info["stale"]:
+                pmc = wl[dom]
+                traffic = pmc.get("hbm_traffic_bytes")
+        except Exception as e:
+            pmc_info["error"] = repr(e)
+        roof_extra = {"pmc": pmc_info}
+        if walk is not None:
+            roof_extra["walked"] = dict(walk)
         if traffic is not None and dur_s > 0:
             roof_extra["hbm_measured"] = {"traffic_bytes": traffic, "GBps": traffic / dur_s / 1e9,
-                                          "frac": traffic / dur_s / 1e9 / HBM_PEAK_GBS, "source": pmc.get("hbm_source")}
+                                          "frac": traffic / dur_s / 1e9 / HBM_PEAK_GBS, "source": pmc.get("hbm_source"),
+                                          "traffic_over_processed": traffic / processed if processed else None}
         if pmc is not None and "valu" in pmc and walk is not None and dur_s > 0:
             v = pmc["valu"]
             # live part: this run's launch duration and pair count; PMC part: instructions per evaluated pair, the
@@ -801,7 +853,31 @@ def main():
                                   "issue_cycle_frac": insts * v["issue_cycles_per_inst"] / simd_cycles,
                                   "active_counter_vs_saturated_mix": v.get("counter_frac_calibrated"),
                                   "source": v.get("source")}
-        measured_bound = kernel_bound
+        # (4) every library kernel of the step against the HBM roofline: algorithmic bytes of THIS pipeline per step
+        # (DESIGN.md section 6 lists the per-unit figures) / the slot's event-timed device time per step / 8 TB/s
+        per_kernel = None
+        if walk is not None:
+            Ic, Wk = walk["pairs_listed"], walk["entries_walked"]
+            alg_step = {"project_fwd": 100 * n_gauss, "project_bwd": 188 * n_gauss, "sh_fwd": 216 * n_gauss,
+                        "sh_bwd": 216 * n_gauss, "scan": 16 * n_gauss,
+                        "map_isect": (76 + 40) * n_gauss + 6 * Ic,                      # count pass + emission
+                        "sort": (16 + 4 * 20) * n_gauss + 2 * (2 + 12) * Ic,            # depth rank + tile sort
+                        "tile_bins": 2 * Ic, "pack_records": 88 * n_gauss, "unpack_grads": 84 * n_gauss,
+                        "raster_fwd": 40 * Wk + 20 * n_pix, "raster_bwd": 112 * Wk + 24 * n_pix}
+            per_kernel = {}
+            for k_, (cnt_, avg_) in kernels.items():
+                if cnt_ and k_ in alg_step:
+                    ms_ = cnt_ * avg_ / k_steps
+                    per_kernel[k_] = {"ms_per_step": round(ms_, 4), "launch_brackets_per_step": round(cnt_ / k_steps, 2),
+                                      "alg_MB_per_step": round(alg_step[k_] / 1e6, 2),
+                                      "hbm_frac": round(alg_step[k_] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        measured_bound = (pmc or {}).get("bound")
+        if sg is not None:
+            # the scene graph's raster slots average launches over DIFFERENT lists (main pass, accumulation walks, group
+            # walks): no single per-launch byte count describes them, and the section-8d budget of one pass printed over
+            # that average was the "1.007 of peak" of round 4 — the per-launch figures of this workload are in the kernel
+            # trace and counter tables under profiles/ (r05_*_sg_*), not in this line
+            budget = None
         line = {
             "metric": "train-step images/sec (fwd+bwd) @1M Gaussians 1920x1280",
             "value": world * args.steps / dt, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -813,18 +889,26 @@ def main():
                        "parallelism": (f"dp{world} (view-parallel; {exchange_name(safe_reducer is not None and reducer is safe_reducer)})"
                                        if world > 1 else "single"),
                        "n_gaussians": n_gauss, "n_isect": n_isect},
-            # achieved / peak / frac follow SURVEY.md section 8d's contract formula (every upstream-semantic intersection
-            # charged: "how fast the reference's byte budget is retired"; it exceeds 1 where tiles saturate early, so it
-            # is NOT a utilisation).  `bound` is what the counters say limits the kernel; the utilisation figures are
-            # `walked` (bytes of the entries really walked), `hbm_measured` (PMC traffic) and `valu` (issue cycles).
-            "roofline": dict({"bound": measured_bound or "hbm", "kernel": dom, "achieved": achieved,
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "frac_is": "section-8d algorithmic bytes / launch time / 8 TB/s (budget retirement rate, "
-                                         "not a utilisation)",
-                              "traffic": traffic, "avg_launch_ms": kernels[dom][1], "alg_bytes_per_launch": alg,
-                              "step_alg_bytes": step_bytes,
-                              "step_hbm_frac": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS}, **roof_extra),
+            # roofline: bound "hbm" is the roofline the fraction is priced against (north_star:
+            # achieved fraction of the HBM roofline); `limiter` is what the counters say holds the kernel (VALU issue).
+            "roofline": dict({"bound": "hbm", "limiter": measured_bound or "valu (see DESIGN.md section 4)", "kernel": dom,
+                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": (achieved / HBM_PEAK_GBS) if achieved is not None else None,
+                              "frac_is": "bytes of the units the launch PROCESSES (list entries walked before their tile "
+                                         "saturates x section-8d bytes per entry + per-pixel bytes) / launch time / 8 TB/s",
+                              "traffic": traffic, "avg_launch_ms": kernels[dom][1], "alg_bytes_per_launch": processed,
+                              "budget_rate": None if budget is None else {
+                                              "bytes": budget, "GBps": budget / dur_s / 1e9 if dur_s > 0 else None,
+                                              "over_peak": budget / dur_s / 1e9 / HBM_PEAK_GBS if dur_s > 0 else None,
+                                              "note": "SURVEY.md section 8d's formula charged to every upstream-semantic "
+                                                      "intersection (I), walked or not: the rate the reference's byte "
+                                                      "budget is retired at; exceeds the peak where tiles saturate "
+                                                      "early; NOT a utilisation"},
+                              "step_alg_bytes_8d": step_bytes,
+                              "step_budget_over_peak": step_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+                              "per_kernel": per_kernel}, **roof_extra),
             "kernels_avg_ms": {k: round(v[1], 4) for k, v in kernels.items()},
+            "repeat": repeat,
         }
         line["config"]["path"] = args.path
         if world > 1 or force_dp:
@@ -849,7 +933,7 @@ def main():
                 line["config"]["note"] = "ranks SHARE GPUs (functional check of the N-rank path, not a scaling number)"
         line["config"]["settle_steps"] = max(0, args.settle)   # untimed, before the W warm-up steps
         line["config"]["quat_check"] = ops.quat_check
-        line["config"]["sort_ranking"] = dict(L.SORT_RANKING)
+        line["config"]["sort_ranking"] = dict(L.sort_ranking_report(), **(sort_ab or {}))
         line["config"]["speculative_binning"] = dict(enabled=bool(ops.speculative_binning), **ops.binning_stats)
         line["config"]["early_rank"] = dict(mode=ops.early_rank, **ops.early_rank_stats)
         line["config"]["depth_channel"] = dict(mode=ops.depth_channel, **ops.depth_stats)

@@ -225,22 +225,20 @@ int sgn_map_isect(int n, const float *xys, const float *depths, const int32_t *r
 size_t sgn_sort_workspace_bytes(int64_t n_isect);
 int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const int64_t *keys_in,
                    const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out, void *ws,
-                   size_t ws_bytes, sgn_stream_t stream);
+                   size_t ws_bytes, int sort_rank_mode, sgn_stream_t stream);
 
-/* Which in-wave ranking the scatter pass of every sort in this library uses (radix_sort.hip):
- *   0  ballot-match ranking — documented ISA semantics only; the state of a process until the probe has passed;
+/* `sort_rank_mode` — an ARGUMENT of every sorting entry point (sgn_sort_pairs, sgn_depth_rank, sgn_bin_prepare,
+ * sgn_bin_intersect), not library state: which in-wave ranking the scatter pass of the radix sort uses (radix_sort.hip)
+ *   0  ballot-match ranking — documented ISA semantics only: THE DEFAULT of the host side;
  *   1  one returning LDS atomic per key — 8x fewer ranking instructions, stable only if same-address lanes of one
  *      ds_add_rtn_u32 are served in ascending lane order (observed on gfx950, not documented).
- * sgn_sort_selftest sorts adversarial probes (all-equal keys, lane-interleaved keys, runs, hashes; both sort-tile
- * sizes) with BOTH rankings on the device of `stream`, compares every output pair on the device, synchronises the
- * stream and switches the process to mode 1 iff nothing differed; it returns the number of mismatching pairs (0 =
- * passed) or < 0 on error.  The host side runs it once per process (`sgn_rast._lib.load()` on a GPU);
- * sgn_sort_set_rank_mode forces a mode (tests, A/B runs).  This is the library's only process-wide state besides the
- * opt-in timing slots: a verified hardware capability, not a configuration switch. */
-int sgn_sort_rank_mode(void);
-void sgn_sort_set_rank_mode(int atomic_ranking);
+ * sgn_sort_selftest QUEUES rounds x 16 adversarial probe sorts (all-equal keys, lane-interleaved keys, runs, hashes; both
+ * sort-tile sizes) with BOTH rankings on `stream` and ADDS the number of differing output pairs to *mismatches (device
+ * int32 the caller zeroed); asynchronous and stateless, so several instances can run on several streams at once.  The
+ * host side (sgn_rast/_lib.py) passes 1 only when asked to (SGN_SORT_RANK=atomic) and only on a device where the probe,
+ * run under load, counted zero. */
 size_t sgn_sort_selftest_workspace_bytes(void);
-int sgn_sort_selftest(void *ws, size_t ws_bytes, sgn_stream_t stream);
+int sgn_sort_selftest(void *ws, size_t ws_bytes, int rounds, int32_t *mismatches, sgn_stream_t stream);
 
 /* _C.get_tile_bin_edges; tile_bins [n_tiles,2] is zero-filled here first. */
 int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_tiles, int32_t *tile_bins,
@@ -266,13 +264,14 @@ int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t 
                     int block_width, int32_t *cum_by_rank /*[n] inclusive scan of kept-tile counts, rank order*/,
                     int32_t *gid_by_rank /*[n] out; in when rank_ready*/,
                     int rank_ready /*1: gid_by_rank already holds sgn_depth_rank(n, depths, radii, ...)*/,
-                    float *bin_records /*[n,8] out*/, void *ws, size_t ws_bytes, sgn_stream_t stream);
+                    float *bin_records /*[n,8] out*/, void *ws, size_t ws_bytes, int sort_rank_mode,
+                    sgn_stream_t stream);
 /* The first stage of sgn_bin_prepare on its own: gid_by_rank[r] = id of the Gaussian of depth rank r (stable: ties by
  * id; radii <= 0 last).  It reads depths and radii only, so a caller can queue it right behind the projection — before
  * opacities and colours exist — and hand the result to sgn_bin_prepare(rank_ready = 1). */
 size_t sgn_depth_rank_workspace_bytes(int n);
 int sgn_depth_rank(int n, const float *depths, const int32_t *radii, int32_t *gid_by_rank /*[n]*/, void *ws,
-                   size_t ws_bytes, sgn_stream_t stream);
+                   size_t ws_bytes, int sort_rank_mode, sgn_stream_t stream);
 size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect);
 /* n_isect_dev == NULL: n_isect is the intersection count the host has read back (cum_by_rank[n-1]).
  * n_isect_dev != NULL (speculative form, no upstream counterpart): the call is queued BEFORE the host knows the count;
@@ -294,7 +293,8 @@ size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect);
 int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                       const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
                       int32_t *gaussian_ids_sorted /*[n_isect]*/, int32_t *tile_bins /*[tiles,2]*/,
-                      int quadrant_masks, void *ws, size_t ws_bytes, const int32_t *n_isect_dev, sgn_stream_t stream);
+                      int quadrant_masks, void *ws, size_t ws_bytes, const int32_t *n_isect_dev, int sort_rank_mode,
+                      sgn_stream_t stream);
 
 /* Sub-list of a binned scene for an id window (no upstream counterpart; the scene graph's objects-only accumulation
  * pass, sgn_splatfacto_scene_graph.py:364-365, served from the main pass's depth list): keeps, in order, the entries of

@@ -43,6 +43,29 @@ def find(rows, key):
     return next(v for k, v in rows.items() if key in k)
 
 
+WORKLOADS = {      # key in roofline_pmc.json (what bench.py looks up) -> file suffix of the counter tables
+    "metric": "", "street": "_street", "scene_graph_dropin": "_sg", "scene_graph_fused": "_sgf",
+}
+RASTER_KEYS = (("raster_bwd", "raster_bwd_short_kernel"), ("raster_fwd", "raster_fwd_pk_kernel"))
+
+
+def kernel_table(a, b, fs, ws):
+    """Every raster / sub-list kernel instance of a workload: time, counters, HBM bytes per launch (gfx950: FETCH_SIZE in
+    KiB counting 64 B per 128 B request -> doubled; WRITE_SIZE in KiB)."""
+    rows = []
+    for name, ka in a.items():
+        if not any(t in name for t in ("raster_", "list_window", "build_grec", "unpack_grads")):
+            continue
+        kb = b.get(name, {})
+        f, w = fs.get(name, {}).get("FETCH_SIZE"), ws.get(name, {}).get("WRITE_SIZE")
+        rows.append({"kernel": name[:100], "avg_us": ka.get("avg_us"), "calls": ka.get("dispatches"),
+                     "SQ_INSTS_VALU": ka.get("SQ_INSTS_VALU"), "SQ_ACTIVE_INST_VALU": ka.get("SQ_ACTIVE_INST_VALU"),
+                     "SQ_WAVE_CYCLES": ka.get("SQ_WAVE_CYCLES"), "SQ_INSTS_SALU": kb.get("SQ_INSTS_SALU"),
+                     "fetch_KiB_raw": f, "write_KiB": w,
+                     "hbm_bytes": None if f is None or w is None else int((2 * f + w) * 1024)})
+    return sorted(rows, key=lambda r: -(r["avg_us"] or 0) * (r["calls"] or 1))
+
+
 def main(tag):
     cal = table(os.path.join(P, f"{tag}_calib_pmc_a.md"))
     cost = {}
@@ -54,54 +77,69 @@ def main(tag):
     c = {k: v["issue_cycles_per_inst"] for k, v in cost.items()}
     mix = json.loads(subprocess.check_output([sys.executable, os.path.join(P, "scripts", "valu_mix.py"), "--json"],
                                              stderr=subprocess.DEVNULL, text=True))
-    a, b = table(os.path.join(P, f"{tag}_pmc_a.md")), table(os.path.join(P, f"{tag}_pmc_b.md"))
-    fs, ws = table(os.path.join(P, f"{tag}_pmc_fetch_size.md")), table(os.path.join(P, f"{tag}_pmc_write_size.md"))
-    bench = json.loads(open(os.path.join(P, f"{tag}_bench_default.json.log")).read().strip().splitlines()[-1])
-    pairs = bench["roofline"]["walked"]["quadrant_pairs_evaluated_fwd"]
+    sha_file = os.path.join(P, f"{tag}_raster_hip.sha256")
+    measured_sha = open(sha_file).read().split()[0] if os.path.exists(sha_file) else None
+    import hashlib
+    here_sha = hashlib.sha256(open(os.path.join(ROOT, "street-gaussians-ns_amd", "csrc", "raster.hip"), "rb").read()).hexdigest()
+    if measured_sha is not None and measured_sha != here_sha:
+        print(f"WARNING: the counters were taken on another raster.hip ({measured_sha[:12]} vs {here_sha[:12]} here)")
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip()
     out = {"_comment": __doc__.split("Inputs")[0].strip() + f"  Generated from profiles/{tag}_*; see the script for the "
-           "formulas.", "round": tag, "workload": bench["config"]["workload"],
-           "calibration": cost}
-    for name, key in (("raster_bwd", "raster_bwd_short_kernel"), ("raster_fwd", "raster_fwd_pk_kernel")):
-        ka, kb, st = find(a, key), find(b, key), mix[name]["classes"]
-        tot = ka["SQ_INSTS_VALU"]
-        counted = sum(kb[f"SQ_INSTS_VALU_{t}"] for t in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "CVT"))
-        other = tot - counted
-        s_dpp = st.get("dpp", 0) / max(1, st.get("dpp", 0) + st.get("add", 0))
-        oth_cls = {"cmp": c["k_cmp"], "select": c["k_min"], "mov": c["k_mov"], "permlane": c["k_permswap"],
-                   "pk": 5.0, "other": c["k_mov"]}     # v_pk_*: 5.0 cycles (profiles/r01d_profile.md, r02 notes)
-        w = sum(st.get(k, 0) for k in oth_cls)
-        c_other = sum(st.get(k, 0) * v for k, v in oth_cls.items()) / max(1, w)
-        cycles = (kb["SQ_INSTS_VALU_FMA_F32"] * c["k_fma"] + kb["SQ_INSTS_VALU_MUL_F32"] * c["k_mul"] +
-                  kb["SQ_INSTS_VALU_ADD_F32"] * (s_dpp * c["k_dpp"] + (1 - s_dpp) * c["k_mul"]) +
-                  kb["SQ_INSTS_VALU_TRANS_F32"] * c["k_exp"] + (kb["SQ_INSTS_VALU_INT32"] + kb["SQ_INSTS_VALU_CVT"]) * c["k_mov"] +
-                  other * c_other)
-        simd_cycles = ka["GRBM_GUI_ACTIVE"] / XCDS * SIMDS
-        fetch_kib, write_kib = find(fs, key)["FETCH_SIZE"], find(ws, key)["WRITE_SIZE"]
-        out[name] = {
-            "kernel": key, "avg_us_under_pmc": ka["avg_us"],
-            "bound": "valu",
-            "hbm_traffic_bytes": int((2 * fetch_kib + write_kib) * 1024),
-            "hbm_source": f"profiles/{tag}_pmc_fetch_size.md ({fetch_kib:.0f} KiB raw, doubled) + "
-                          f"profiles/{tag}_pmc_write_size.md ({write_kib:.0f} KiB)",
-            "valu": {
-                "simds": SIMDS, "clock_ghz": ka["GRBM_GUI_ACTIVE"] / XCDS / (ka["avg_us"] * 1e3),
-                "valu_insts_per_launch": tot, "pairs_per_launch": pairs, "valu_insts_per_pair": tot / pairs,
-                "issue_cycles_per_inst": cycles / tot,
-                "issue_cycle_frac_under_pmc": cycles / simd_cycles,
-                "counter_frac_calibrated": (ka["SQ_ACTIVE_INST_VALU"] / simd_cycles) /
-                                           (cal_frac(cal, "k_mix")),
-                "dynamic_mix": {k: kb[f"SQ_INSTS_VALU_{k}"] for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "CVT")},
-                "uncounted": other, "c_other": c_other, "dpp_share_of_adds": s_dpp, "static_mix": st,
-                "source": f"profiles/{tag}_pmc_a.md, {tag}_pmc_b.md, {tag}_calib_pmc_a.md, scripts/valu_mix.py, "
-                          "scripts/make_roofline_pmc.py",
-            },
-        }
+           "formulas.", "round": tag, "git_head": head, "raster_hip_sha256": measured_sha or here_sha,
+           "calibration": cost, "workloads": {}}
+    for wkey, suf in WORKLOADS.items():
+        files = [os.path.join(P, f"{tag}_pmc_{x}{suf}.md") for x in ("a", "b", "fetch_size", "write_size")]
+        bench_file = os.path.join(P, f"{tag}_bench_{'default' if wkey == 'metric' else suf[1:]}.json.log")
+        if not all(os.path.exists(f) for f in files):
+            continue
+        a, b, fs, ws = (table(f) for f in files)
+        W = {"table": kernel_table(a, b, fs, ws), "source": [os.path.relpath(f, ROOT) for f in files]}
+        bench = json.loads(open(bench_file).read().strip().splitlines()[-1]) if os.path.exists(bench_file) else None
+        W["workload"] = bench["config"]["workload"] if bench else wkey
+        pairs = ((bench or {}).get("roofline", {}).get("walked") or {}).get("quadrant_pairs_evaluated_fwd")
+        for name, key in RASTER_KEYS:
+            try:
+                ka, kb, st = find(a, key), find(b, key), mix[name]["classes"]
+                fetch_kib, write_kib = find(fs, key)["FETCH_SIZE"], find(ws, key)["WRITE_SIZE"]
+            except StopIteration:
+                continue
+            tot = ka["SQ_INSTS_VALU"]
+            counted = sum(kb[f"SQ_INSTS_VALU_{t}"] for t in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "CVT"))
+            other = tot - counted
+            s_dpp = st.get("dpp", 0) / max(1, st.get("dpp", 0) + st.get("add", 0))
+            oth_cls = {"cmp": c["k_cmp"], "select": c["k_min"], "mov": c["k_mov"], "permlane": c["k_permswap"],
+                       "pk": 5.0, "other": c["k_mov"]}     # v_pk_*: 5.0 cycles (profiles/r01d_profile.md, r02 notes)
+            w = sum(st.get(k, 0) for k in oth_cls)
+            c_other = sum(st.get(k, 0) * v for k, v in oth_cls.items()) / max(1, w)
+            cycles = (kb["SQ_INSTS_VALU_FMA_F32"] * c["k_fma"] + kb["SQ_INSTS_VALU_MUL_F32"] * c["k_mul"] +
+                      kb["SQ_INSTS_VALU_ADD_F32"] * (s_dpp * c["k_dpp"] + (1 - s_dpp) * c["k_mul"]) +
+                      kb["SQ_INSTS_VALU_TRANS_F32"] * c["k_exp"] + (kb["SQ_INSTS_VALU_INT32"] + kb["SQ_INSTS_VALU_CVT"]) * c["k_mov"] +
+                      other * c_other)
+            simd_cycles = ka["GRBM_GUI_ACTIVE"] / XCDS * SIMDS
+            W[name] = {
+                "kernel": key, "avg_us_under_pmc": ka["avg_us"], "bound": "valu",
+                "hbm_traffic_bytes": int((2 * fetch_kib + write_kib) * 1024),
+                "hbm_source": f"profiles/{tag}_pmc_fetch_size{suf}.md ({fetch_kib:.0f} KiB raw, doubled) + "
+                              f"profiles/{tag}_pmc_write_size{suf}.md ({write_kib:.0f} KiB)",
+                "valu": {
+                    "simds": SIMDS, "clock_ghz": ka["GRBM_GUI_ACTIVE"] / XCDS / (ka["avg_us"] * 1e3),
+                    "valu_insts_per_launch": tot, "pairs_per_launch": pairs,
+                    "valu_insts_per_pair": tot / pairs if pairs else None,
+                    "issue_cycles_per_inst": cycles / tot,
+                    "issue_cycle_frac_under_pmc": cycles / simd_cycles,
+                    "counter_frac_calibrated": (ka["SQ_ACTIVE_INST_VALU"] / simd_cycles) / (cal_frac(cal, "k_mix")),
+                    "dynamic_mix": {k: kb[f"SQ_INSTS_VALU_{k}"] for k in ("ADD_F32", "MUL_F32", "FMA_F32", "TRANS_F32", "INT32", "CVT")},
+                    "uncounted": other, "c_other": c_other, "dpp_share_of_adds": s_dpp, "static_mix": st,
+                    "source": f"profiles/{tag}_pmc_a{suf}.md, {tag}_pmc_b{suf}.md, {tag}_calib_pmc_a.md, scripts/valu_mix.py, "
+                              "scripts/make_roofline_pmc.py",
+                },
+            }
+            v = W[name]["valu"]
+            print(wkey, name, "us %.1f  insts/pair %s  cycles/inst %.2f  issue frac %.3f  ACTIVE frac %.3f  hbm %.1f MB" % (
+                ka["avg_us"], v["valu_insts_per_pair"] and round(v["valu_insts_per_pair"], 1), v["issue_cycles_per_inst"],
+                v["issue_cycle_frac_under_pmc"], v["counter_frac_calibrated"], W[name]["hbm_traffic_bytes"] / 1e6))
+        out["workloads"][wkey] = W
     json.dump(out, open(os.path.join(P, "roofline_pmc.json"), "w"), indent=1)
-    for n in ("raster_bwd", "raster_fwd"):
-        v = out[n]["valu"]
-        print(n, "insts/pair %.1f  cycles/inst %.2f  issue frac %.3f  ACTIVE-counter frac (calibrated on k_mix) %.3f  hbm %d MB" % (
-            v["valu_insts_per_pair"], v["issue_cycles_per_inst"], v["issue_cycle_frac_under_pmc"],
-            v["counter_frac_calibrated"], out[n]["hbm_traffic_bytes"] / 1e6))
     print({k: round(v["issue_cycles_per_inst"], 2) for k, v in cost.items()})
 
 

@@ -779,9 +779,9 @@ SGN_EXPORT int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_
 // ---- fused path entry points (declared in sgn_rast.h) ------------------------------------------
 size_t sgn_sort_pairs32_ws_bytes(int64_t n);
 void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const int32_t *vin, uint32_t *kout,
-                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev = nullptr);
+                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode);
 void sgn_sort_pairs16_launch(uint32_t n, int end_bit, const uint16_t *kin, const int32_t *vin, uint16_t *kout,
-                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev = nullptr);
+                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode);
 
 // The depth ranking needs depths and radii only, i.e. it can be queued the moment the projection is: the caller's
 // colour evaluation and activations then run BEHIND ~80 us of device work instead of in front of an idle GPU (the
@@ -801,7 +801,7 @@ SGN_EXPORT size_t sgn_depth_rank_workspace_bytes(int n) {
 }
 
 SGN_EXPORT int sgn_depth_rank(int n, const float *depths, const int32_t *radii, int32_t *gid_by_rank, void *ws,
-                              size_t ws_bytes, sgn_stream_t stream) {
+                              size_t ws_bytes, int sort_rank_mode, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     if (n == 0) return 0;
     SGN_ARG_CHECK(depths && radii && gid_by_rank && ws, -2);
@@ -813,13 +813,13 @@ SGN_EXPORT int sgn_depth_rank(int n, const float *depths, const int32_t *radii, 
     uint32_t *dkeys_sorted = (uint32_t *)p; p += al256((size_t)n * 4);
     auto chain = [&](hipStream_t st) {      // 13 launches: keys, then four passes of histogram / scan / scatter
         hipLaunchKernelGGL(depth_keys_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, st, n, depths, radii, dkeys, dvals);
-        sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, p, st);
+        sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, p, st, nullptr, sort_rank_mode);
     };
     // the same chain on the same buffers as an earlier call (steady state of a training loop): replayed as ONE graph
     // launch (SGN_HIP_GRAPHS=1; sgn_common.h)
     const uint64_t key[SGN_GRAPH_KEY_WORDS] = {1u, (uint64_t)n, (uint64_t)(uintptr_t)depths, (uint64_t)(uintptr_t)radii,
                                                (uint64_t)(uintptr_t)gid_by_rank, (uint64_t)(uintptr_t)ws,
-                                               (uint64_t)sgn_sort_rank_mode()};
+                                               (uint64_t)(sort_rank_mode != 0)};
     hipGraphExec_t g = sgn_graph_find(key);
     if (g == nullptr) {
         if (hipStream_t cs = sgn_graph_capture_begin()) {
@@ -854,7 +854,7 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
                                const float *conics, const float *opacities, int opacity_is_logit, int cull,
                                int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
                                int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
-                               sgn_stream_t stream) {
+                               int sort_rank_mode, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     if (n == 0) return 0;
@@ -877,7 +877,7 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
     sgn_timing_end(SGN_T_MAP, s);
     if (!rank_ready) {       // rank_ready: gid_by_rank already holds sgn_depth_rank's result for these depths / radii
         sgn_timing_begin(SGN_T_SORT, s);
-        sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s);
+        sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, sort_ws, s, nullptr, sort_rank_mode);
         sgn_timing_end(SGN_T_SORT, s);
     }
     // cum_by_rank[r] = sum of the kept-tile counts of ranks <= r: the scan's first pass gathers cnt_gid[gid_by_rank[r]]
@@ -892,7 +892,7 @@ SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
 SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                                  const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
                                  int32_t *gaussian_ids_sorted, int32_t *tile_bins, int quadrant_masks, void *ws,
-                                 size_t ws_bytes, const int32_t *n_isect_dev, sgn_stream_t stream) {
+                                 size_t ws_bytes, const int32_t *n_isect_dev, int sort_rank_mode, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0 && n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     SGN_ARG_CHECK(tile_bins != nullptr, -3);
@@ -921,7 +921,7 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
         sgn_sort_pairs16_launch((uint32_t)n_isect, tile_bits, k16, tvals, k16s, gaussian_ids_sorted, sort_ws, s,
-                                n_isect_dev);
+                                n_isect_dev, sort_rank_mode);
         sgn_timing_end(SGN_T_SORT, s);
         sgn_timing_begin(SGN_T_BINS, s);
         hipLaunchKernelGGL(tile_bins32_kernel<uint16_t>, dim3(sgn_cdiv(n_isect, 256 * 8)), dim3(256), 0, s, n_isect, k16s,
@@ -935,7 +935,7 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
         sgn_sort_pairs32_launch((uint32_t)n_isect, tile_bits, tkeys, tvals, tkeys_sorted, gaussian_ids_sorted, sort_ws,
-                                s, n_isect_dev);
+                                s, n_isect_dev, sort_rank_mode);
         sgn_timing_end(SGN_T_SORT, s);
         sgn_timing_begin(SGN_T_BINS, s);
         hipLaunchKernelGGL(tile_bins32_kernel<uint32_t>, dim3(sgn_cdiv(n_isect, 256 * 4)), dim3(256), 0, s, n_isect,

@@ -19,8 +19,6 @@
 // HBM traffic per key per pass: sizeof(key) (hist) + 2 * (sizeof(key) + payload).
 #include "sgn_common.h"
 
-#include <atomic>
-
 namespace {
 
 constexpr int RS_THREADS = 256;
@@ -31,11 +29,13 @@ constexpr int RS_WAVES = 4;
 //   true : ONE returning LDS atomic per key on the digit's per-wave counter (8x fewer instructions in the ranking
 //          section, -7 us per binning).  Stable iff lanes of one ds_add_rtn_u32 that hit the same address are served in
 //          ascending lane order — how the gfx950 LDS resolves same-address lanes, observed rather than documented.
-// The bit-exact depth order of every tile list depends on it, so the library does not take it on faith (VERDICT r02
-// weak #3): sgn_sort_selftest() sorts adversarial same-digit / lane-interleaved probes with BOTH rankings
-// on the device it is asked about, compares every output pair, and only an all-equal verdict switches the process to
-// the atomic form (g_rank_mode); anything else keeps the documented one.  sgn_sort_rank_mode() reports which one runs
-// (bench.py prints it).  tests/test_gpu_sort_stability.py stresses whichever is active and both forced.
+// The bit-exact depth order of every tile list depends on it, so the DEFAULT is the documented form and the choice is an
+// ARGUMENT of every sorting entry point (`sort_rank_mode`: 0 ballot, 1 atomic) — the library keeps no state about it
+// (round 5; rounds 2-4 kept a process-wide switch that a load-time probe flipped).  sgn_sort_selftest() queues
+// adversarial same-digit / lane-interleaved probes sorted with BOTH rankings and counts differing output pairs on the
+// device; the host side (sgn_rast/_lib.py) runs it only when asked for the atomic form (SGN_SORT_RANK=atomic), UNDER
+// LOAD (a second instance and a GEMM on other streams, >= 1000 sorts), per device, and passes 1 only where it counted
+// zero.  tests/test_gpu_sort_stability.py stresses both forms.
 #if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
 #error "radix_sort.hip is written for gfx950 (MI355X) only"
 #endif
@@ -359,16 +359,13 @@ void sort_launch_ipt(uint32_t n, int begin_bit, int end_bit, const K *keys_in, c
     }
 }
 
-// 0: ballot-match ranking (documented semantics; the state of a process that never ran the probe, or failed it),
-// 1: returning-atomic ranking (this process proved it on its device with sgn_sort_selftest, or forced it for an A/B).
-std::atomic<int> g_rank_mode{0};
-
+// rank_mode 0: ballot-match ranking (documented semantics), 1: returning-atomic ranking (the caller proved it on its
+// device with sgn_sort_selftest, or forces it for an A/B)
 template <typename K, bool HAS_VAL, int BITS>
 void sort_launch(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const int32_t *vals_in, K *keys_out,
-                 int32_t *vals_out, void *ws, hipStream_t s, const int32_t *n_dev = nullptr, int force_mode = -1,
-                 int force_ipt = 0) {
+                 int32_t *vals_out, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode, int force_ipt = 0) {
     // n_dev != nullptr: n is the CAPACITY the launch is sized for, the element count is read on the device
-    const bool atomic = (force_mode >= 0 ? force_mode : g_rank_mode.load(std::memory_order_relaxed)) != 0;
+    const bool atomic = rank_mode != 0;
     const int ipt = force_ipt ? force_ipt : rs_pick_ipt(n);
 #define SGN_RS_GO(IPT, AT) \
     sort_launch_ipt<K, HAS_VAL, BITS, IPT, AT>(n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out, ws, s, n_dev)
@@ -415,20 +412,14 @@ __global__ __launch_bounds__(256) void rs_probe_compare_kernel(uint32_t n, const
 // internal (fused binning path, binning.hip)
 size_t sgn_sort_pairs32_ws_bytes(int64_t n) { return sort_ws_bytes<uint32_t, true, 8>(n); }
 void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const int32_t *vin, uint32_t *kout,
-                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev) {
-    sort_launch<uint32_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s, n_dev);
+                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode) {
+    sort_launch<uint32_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s, n_dev, rank_mode);
 }
 
 // 16-bit keys (tile ids of images with <= 65536 tiles); same workspace layout and size as the 32-bit entry
 void sgn_sort_pairs16_launch(uint32_t n, int end_bit, const uint16_t *kin, const int32_t *vin, uint16_t *kout,
-                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev) {
-    sort_launch<uint16_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s, n_dev);
-}
-
-// ---- which ranking runs
-SGN_EXPORT int sgn_sort_rank_mode(void) { return g_rank_mode.load(std::memory_order_relaxed); }
-SGN_EXPORT void sgn_sort_set_rank_mode(int atomic_ranking) {
-    g_rank_mode.store(atomic_ranking ? 1 : 0, std::memory_order_relaxed);
+                             int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode) {
+    sort_launch<uint16_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s, n_dev, rank_mode);
 }
 
 constexpr uint32_t RS_PROBE_N = 1u << 16;   // 64 K pairs per probe: 64 tiles of 1024 keys, 16 tiles of 4096
@@ -436,12 +427,12 @@ SGN_EXPORT size_t sgn_sort_selftest_workspace_bytes(void) {
     return 6 * align256((size_t)RS_PROBE_N * 4) + 256 + sort_ws_bytes<uint32_t, true, 8>(RS_PROBE_N);
 }
 
-// Sorts eight adversarial 64 K-pair probes (one 8-bit pass each, both tile sizes) with the ballot ranking and with the
-// returning-atomic ranking on the device of `stream`, compares every output pair on the device, waits for the stream
-// and, iff nothing differed, switches this process to the atomic ranking.  Returns the number of mismatching pairs
-// (0 = the atomic ranking is stable here; > 0 = the process stays on the documented ballot ranking) or < 0 on error.
-SGN_EXPORT int sgn_sort_selftest(void *ws, size_t ws_bytes, sgn_stream_t stream) {
-    SGN_ARG_CHECK(ws != nullptr && ws_bytes >= sgn_sort_selftest_workspace_bytes(), -1);
+// QUEUES `rounds` x (eight adversarial 64 K-pair probes, one 8-bit pass each, both tile sizes) sorted with the ballot
+// ranking and with the returning-atomic ranking on `stream`, every output pair compared on the device; differing pairs
+// are ADDED to *mismatches (device int32; the caller zeroes it, synchronises and reads it).  Asynchronous and
+// stateless, so several instances (own workspaces) can run on several streams at once: the host's "under load" probe.
+SGN_EXPORT int sgn_sort_selftest(void *ws, size_t ws_bytes, int rounds, int32_t *mismatches, sgn_stream_t stream) {
+    SGN_ARG_CHECK(ws != nullptr && ws_bytes >= sgn_sort_selftest_workspace_bytes() && rounds >= 1 && mismatches, -1);
     hipStream_t s = (hipStream_t)stream;
     char *p = (char *)ws;
     auto take = [&](size_t b) { char *q = p; p += align256(b); return q; };
@@ -451,31 +442,28 @@ SGN_EXPORT int sgn_sort_selftest(void *ws, size_t ws_bytes, sgn_stream_t stream)
     int32_t *va = (int32_t *)take((size_t)RS_PROBE_N * 4);
     uint32_t *kb = (uint32_t *)take((size_t)RS_PROBE_N * 4);
     int32_t *vb = (int32_t *)take((size_t)RS_PROBE_N * 4);
-    int32_t *bad = (int32_t *)take(256);
+    (void)take(256);
     void *sws = (void *)p;
-    SGN_HIP_CHECK(hipMemsetAsync(bad, 0, sizeof(int32_t), s));
     const uint32_t n = RS_PROBE_N - 37;       // a ragged last tile
-    for (int pattern = 0; pattern < 8; ++pattern) {
-        hipLaunchKernelGGL(rs_probe_fill_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, pattern, kin, vin);
-        for (int ipt : {RS_IPT_SMALL, RS_IPT_LARGE}) {
-            sort_launch<uint32_t, true, 8>(n, 0, 8, kin, vin, kb, vb, sws, s, nullptr, /*ballot*/ 0, ipt);
-            sort_launch<uint32_t, true, 8>(n, 0, 8, kin, vin, ka, va, sws, s, nullptr, /*atomic*/ 1, ipt);
-            hipLaunchKernelGGL(rs_probe_compare_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, ka, va, kb, vb, bad);
+    for (int r = 0; r < rounds; ++r)
+        for (int pattern = 0; pattern < 8; ++pattern) {
+            hipLaunchKernelGGL(rs_probe_fill_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, pattern, kin, vin);
+            for (int ipt : {RS_IPT_SMALL, RS_IPT_LARGE}) {
+                sort_launch<uint32_t, true, 8>(n, 0, 8, kin, vin, kb, vb, sws, s, nullptr, /*ballot*/ 0, ipt);
+                sort_launch<uint32_t, true, 8>(n, 0, 8, kin, vin, ka, va, sws, s, nullptr, /*atomic*/ 1, ipt);
+                hipLaunchKernelGGL(rs_probe_compare_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, ka, va, kb, vb,
+                                   mismatches);
+            }
         }
-    }
     SGN_LAUNCH_CHECK();
-    int32_t h_bad = -1;
-    SGN_HIP_CHECK(hipMemcpyAsync(&h_bad, bad, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    SGN_HIP_CHECK(hipStreamSynchronize(s));
-    g_rank_mode.store(h_bad == 0 ? 1 : 0, std::memory_order_relaxed);
-    return h_bad;
+    return 0;
 }
 
 SGN_EXPORT size_t sgn_sort_workspace_bytes(int64_t n_isect) { return sort_ws_bytes<uint64_t, true, 8>(n_isect); }
 
 SGN_EXPORT int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const int64_t *keys_in,
                               const int32_t *vals_in, int64_t *keys_out, int32_t *vals_out, void *ws,
-                              size_t ws_bytes, sgn_stream_t stream) {
+                              size_t ws_bytes, int sort_rank_mode, sgn_stream_t stream) {
     SGN_ARG_CHECK(n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
     SGN_ARG_CHECK(begin_bit >= 0 && end_bit <= 64 && begin_bit < end_bit, -2);
     if (n_isect == 0) return 0;
@@ -485,7 +473,7 @@ SGN_EXPORT int sgn_sort_pairs(int64_t n_isect, int begin_bit, int end_bit, const
     hipStream_t s = (hipStream_t)stream;
     sgn_timing_begin(SGN_T_SORT, s);
     sort_launch<uint64_t, true, 8>((uint32_t)n_isect, begin_bit, end_bit, (const uint64_t *)keys_in, vals_in,
-                                   (uint64_t *)keys_out, vals_out, ws, s);
+                                   (uint64_t *)keys_out, vals_out, ws, s, nullptr, sort_rank_mode);
     sgn_timing_end(SGN_T_SORT, s);
     SGN_LAUNCH_CHECK();
     return 0;

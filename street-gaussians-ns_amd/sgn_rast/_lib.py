@@ -64,18 +64,16 @@ SIGNATURES = {
     "sgn_scan_i32": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
     "sgn_map_isect": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "sgn_sort_workspace_bytes": (_sz, [_i64]),
-    "sgn_sort_pairs": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "sgn_sort_rank_mode": (_i, []),
-    "sgn_sort_set_rank_mode": (None, [_i]),
+    "sgn_sort_pairs": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "sgn_sort_selftest_workspace_bytes": (_sz, []),
-    "sgn_sort_selftest": (_i, [_vp, _sz, _vp]),
+    "sgn_sort_selftest": (_i, [_vp, _sz, _i, _vp, _vp]),
     "sgn_tile_bins": (_i, [_i64, _vp, _i, _vp, _vp]),
     "sgn_bin_prepare_workspace_bytes": (_sz, [_i]),
-    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _vp]),
+    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _i, _vp]),
     "sgn_depth_rank_workspace_bytes": (_sz, [_i]),
-    "sgn_depth_rank": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sgn_depth_rank": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "sgn_bin_intersect_workspace_bytes": (_sz, [_i64]),
-    "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
+    "sgn_bin_intersect": (_i, [_i, _i64, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _sz, _vp, _i, _vp]),
     "sgn_list_window_workspace_bytes": (_sz, [_i]),
     "sgn_list_window": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "sgn_mark_walked": (_i, [_i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
@@ -197,30 +195,100 @@ def load() -> C.CDLL:
             fn.restype = res
             fn.argtypes = args
         _lib = lib
-        _probe_sort_ranking(lib)
     return _lib
 
 
-SORT_RANKING = {"mode": "ballot", "probe": "not run (no GPU in this process)"}
+# ---------------------------------------------------------------------------------------------- sort ranking
+# Which in-wave ranking the radix sorts use is an ARGUMENT of every sorting entry point (include/sgn_rast.h,
+# `sort_rank_mode`); the library keeps no state about it.  The host's policy, PER DEVICE:
+#   default              0 = the ballot-match ranking: documented ISA semantics only (north_star: bit-exact sort keys);
+#   SGN_SORT_RANK=atomic 1 = one returning LDS atomic per key (-7 us per binning) — but only on a device that has passed
+#                        `sort_selftest_under_load` (>= 1000 probe sorts while a second instance and a GEMM run on other
+#                        streams); a device that fails stays on 0, with a warning;
+#   SGN_SORT_RANK=atomic-unchecked   1 without the probe (A/B runs).
+# `force_sort_rank` overrides it inside a `with` block (tests, bench.py's A/B line).
+_SORT_RANK: dict = {}          # device index -> {"mode": 0 | 1, "probe": str}
+_sort_rank_forced = None
 
 
-def _probe_sort_ranking(lib) -> None:
-    """Once per process, on a GPU: let the library prove its fast in-wave sort ranking on THIS device
-    (`sgn_sort_selftest`, include/sgn_rast.h) — it stays on the documented ballot ranking unless every probe pair
-    matches.  `SGN_SORT_RANK=ballot|atomic` skips the probe and forces a mode (A/B runs); the outcome is kept in
-    `SORT_RANKING` (bench.py prints it)."""
-    forced = os.environ.get("SGN_SORT_RANK", "auto").lower()
-    if forced in ("ballot", "atomic"):
-        lib.sgn_sort_set_rank_mode(1 if forced == "atomic" else 0)
-        SORT_RANKING.update(mode=forced, probe="forced by SGN_SORT_RANK")
-        return
-    if not torch.cuda.is_available():
-        return
-    ws = torch.empty(int(lib.sgn_sort_selftest_workspace_bytes()), dtype=torch.uint8, device="cuda")
-    bad = int(lib.sgn_sort_selftest(C.c_void_p(ws.data_ptr()), ws.numel(), C.c_void_p(stream_handle())))
-    mode = "atomic" if lib.sgn_sort_rank_mode() == 1 else "ballot"
-    SORT_RANKING.update(mode=mode, probe=("passed: 16 probe sorts, 0 mismatching pairs" if bad == 0 else
-                                         f"FAILED ({bad}): staying on the documented ballot ranking"))
+def sort_selftest_under_load(rounds: int = 64, device=None) -> int:
+    """Mismatching output pairs (0 = the atomic ranking reproduced the documented one) over `rounds` x 16 probe sorts per
+    ranking on the current stream of `device`, while a second instance (own workspace, another stream) and a chain of
+    GEMMs (a third stream) keep the LDS and the CUs busy."""
+    lib = load()
+    dev = torch.device("cuda", current_device() if device is None else device)
+    with torch.cuda.device(dev):
+        main = torch.cuda.current_stream(dev)
+        side, load_s = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        nbytes = int(lib.sgn_sort_selftest_workspace_bytes())
+        ws = [torch.empty(nbytes, dtype=torch.uint8, device=dev) for _ in range(2)]
+        bad = torch.zeros(2, dtype=torch.int32, device=dev)
+        a = torch.randn(2048, 2048, device=dev)
+        side.wait_stream(main); load_s.wait_stream(main)
+        with torch.cuda.stream(load_s):
+            for _ in range(max(8, rounds // 2)):
+                a = torch.mm(a, a).clamp_(-1.0, 1.0)
+        for i, st in enumerate((main, side)):
+            check(lib.sgn_sort_selftest(C.c_void_p(ws[i].data_ptr()), nbytes, int(rounds),
+                                        C.c_void_p(bad[i:i + 1].data_ptr()), C.c_void_p(st.cuda_stream)),
+                  "sgn_sort_selftest")
+        main.wait_stream(side); main.wait_stream(load_s)
+        for t in ws + [bad, a]:
+            t.record_stream(side); t.record_stream(load_s)
+        return int(bad.sum().item())
+
+
+def _decide_sort_ranking(dev_index: int) -> dict:
+    want = os.environ.get("SGN_SORT_RANK", "ballot").lower()
+    if want == "atomic-unchecked":
+        return {"mode": 1, "probe": "forced by SGN_SORT_RANK=atomic-unchecked (no probe)"}
+    if want != "atomic" or not torch.cuda.is_available():
+        return {"mode": 0, "probe": "not needed: the documented ballot ranking is the default"}
+    rounds = int(os.environ.get("SGN_SORT_PROBE_ROUNDS", "64"))
+    bad = sort_selftest_under_load(rounds, dev_index)
+    if bad == 0:
+        return {"mode": 1, "probe": f"passed under load on device {dev_index}: {2 * 16 * rounds} probe sorts per ranking, "
+                                    "0 mismatching pairs"}
+    import warnings
+    warnings.warn(f"SGN_SORT_RANK=atomic: the probe counted {bad} mismatching pairs on device {dev_index}; staying on "
+                  "the documented ballot ranking there")
+    return {"mode": 0, "probe": f"FAILED ({bad} mismatching pairs) on device {dev_index}: ballot ranking"}
+
+
+def sort_rank_mode() -> int:
+    """The `sort_rank_mode` argument for a sort on the CURRENT device (0 ballot / 1 atomic)."""
+    if _sort_rank_forced is not None:
+        return _sort_rank_forced
+    d = current_device() if torch.cuda.is_available() else -1
+    e = _SORT_RANK.get(d)
+    if e is None:
+        e = _SORT_RANK[d] = _decide_sort_ranking(d)
+    return e["mode"]
+
+
+def sort_ranking_report() -> dict:
+    """{"mode": "ballot" | "atomic", "probe": ...} of the current device (bench.py prints it)."""
+    mode = sort_rank_mode()
+    d = current_device() if torch.cuda.is_available() else -1
+    e = _SORT_RANK.get(d) or {"probe": "forced"}
+    return {"mode": "atomic" if mode else "ballot", "probe": e["probe"] if _sort_rank_forced is None else "forced (A/B)"}
+
+
+class force_sort_rank:
+    """`with force_sort_rank("atomic"):` — every sort issued inside uses that ranking (tests, A/B measurements)."""
+
+    def __init__(self, mode):
+        self.mode = 1 if mode in (1, "atomic") else 0
+
+    def __enter__(self):
+        global _sort_rank_forced
+        self.before, _sort_rank_forced = _sort_rank_forced, self.mode
+        return self
+
+    def __exit__(self, *exc):
+        global _sort_rank_forced
+        _sort_rank_forced = self.before
+        return False
 
 
 def check(rc: int, what: str) -> None:

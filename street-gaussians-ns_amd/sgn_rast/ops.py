@@ -531,7 +531,7 @@ def _start_early_rank(depths: torch.Tensor, radii: torch.Tensor) -> None:
         with torch.cuda.stream(aux):
             gid = torch.empty(n, dtype=torch.int32, device=d.device)
             ws = L.workspace(lib.sgn_depth_rank_workspace_bytes(n), d.device)
-            L.check(lib.sgn_depth_rank(n, L.ptr(d), L.ptr(r), L.ptr(gid), L.ptr(ws), ws.numel(),
+            L.check(lib.sgn_depth_rank(n, L.ptr(d), L.ptr(r), L.ptr(gid), L.ptr(ws), ws.numel(), L.sort_rank_mode(),
                                        C.c_void_p(aux.cuda_stream)), "sgn_depth_rank")
             done = torch.cuda.Event()
             done.record(aux)
@@ -539,8 +539,8 @@ def _start_early_rank(depths: torch.Tensor, radii: torch.Tensor) -> None:
     else:
         gid = torch.empty(n, dtype=torch.int32, device=d.device)
         ws = L.workspace(lib.sgn_depth_rank_workspace_bytes(n), d.device)
-        L.check(lib.sgn_depth_rank(n, L.ptr(d), L.ptr(r), L.ptr(gid), L.ptr(ws), ws.numel(), L.stream_ptr()),
-                "sgn_depth_rank")
+        L.check(lib.sgn_depth_rank(n, L.ptr(d), L.ptr(r), L.ptr(gid), L.ptr(ws), ws.numel(), L.sort_rank_mode(),
+                                   L.stream_ptr()), "sgn_depth_rank")
     _early["entry"] = dict(key=key, keep=(d, r), gid=gid, done=done)
     early_rank_stats["started"] += 1
 
@@ -632,7 +632,8 @@ def sort_intersects(isect_ids: torch.Tensor, gaussian_ids: torch.Tensor, n_tiles
         ws = L.workspace(lib.sgn_sort_workspace_bytes(n), dev)
         end_bit = 32 + max(1, int(n_tiles - 1).bit_length())
         L.check(lib.sgn_sort_pairs(n, 0, end_bit, L.ptr(isect_ids), L.ptr(gaussian_ids), L.ptr(keys_sorted),
-                                   L.ptr(vals_sorted), L.ptr(ws), ws.numel(), L.stream_ptr()), "sgn_sort_pairs")
+                                   L.ptr(vals_sorted), L.ptr(ws), ws.numel(), L.sort_rank_mode(), L.stream_ptr()),
+                "sgn_sort_pairs")
     return keys_sorted, vals_sorted
 
 
@@ -731,7 +732,7 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     L.check(lib.sgn_bin_prepare(n, L.ptr(xys_c), L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(conics_c), L.ptr(opac_c),
                                 int(bool(opacity_is_logit)), do_cull, tx, ty, int(block_width), L.ptr(cum_r),
                                 L.ptr(gid_by_rank), int(early is not None), L.ptr(bin_recs), L.ptr(ws), ws.numel(),
-                                L.stream_ptr()),
+                                L.sort_rank_mode(), L.stream_ptr()),
             "sgn_bin_prepare")
     S = _S()
     if S.side is None:
@@ -791,7 +792,7 @@ def _bin_finish(st):
         L.check(lib.sgn_bin_intersect(n, count_or_cap, L.ptr(st["bin_recs"]), L.ptr(st["cum_r"]),
                                       L.ptr(st["gid_by_rank"]), st["tx"], st["ty"], st["block"], L.ptr(ids),
                                       L.ptr(tile_bins), int(st["qmask"]), L.ptr(ws2), ws2.numel(), count_dev,
-                                      L.stream_ptr()),
+                                      L.sort_rank_mode(), L.stream_ptr()),
                 "sgn_bin_intersect")
         return ids
 

@@ -7,10 +7,16 @@ from torch.autograd import Function
 from oracle import c_oracle as CO
 
 ALPHA_CLAMP_BWD = 0.99  # gsplat 0.1.x backward clamp
-# (row_lo, row_hi) or None: restrict the compositing (forward and backward) to a band of pixel rows.  Used by the
-# BASELINE-size gradient parity tests together with loss weights that vanish outside the band, so the band's
-# backward IS the full backward; image rows outside the band come back as zeros (not compared).
+# (row_lo, row_hi), a list of such ranges (disjoint bands), or None: restrict the compositing (forward and backward) to
+# bands of pixel rows.  Used by the BASELINE-size gradient parity tests together with loss weights that vanish outside the
+# bands, so the bands' backward IS the full backward; image rows outside come back as zeros (not compared).
 PIXEL_ROWS = None
+
+
+def _bands(rows):
+    if rows is None or isinstance(rows[0], int):
+        return [rows]
+    return list(rows)
 
 
 class _Project(Function):
@@ -62,7 +68,10 @@ class _Raster(Function):
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, nth, colors, opacity, H, W, block, background, return_alpha):
         cum, keys, vals, ks, vs, bins = CO.bin_and_sort(xys, depths, radii, nth, H, W, block)
-        img, fT, fi = CO.raster_fwd(H, W, block, vs, bins, xys, conics, colors, opacity, background, rows=PIXEL_ROWS)
+        img = fT = fi = None
+        for band in _bands(PIXEL_ROWS):           # (outputs are zero outside a band: disjoint bands add up)
+            o = CO.raster_fwd(H, W, block, vs, bins, xys, conics, colors, opacity, background, rows=band)
+            img, fT, fi = o if img is None else (img + o[0], fT + o[1], fi + o[2])
         ctx.dims = (H, W, block)
         ctx.rows = PIXEL_ROWS
         ctx.oshape = opacity.shape
@@ -79,8 +88,12 @@ class _Raster(Function):
         H, W, block = ctx.dims
         if v_alpha is None:
             v_alpha = torch.zeros(H, W)
-        v_xy, v_conic, v_col, v_op = CO.raster_bwd(H, W, block, vs, bins, xys, conics, colors, opacity, bg, fT, fi,
-                                                    v_img, v_alpha, ALPHA_CLAMP_BWD, rows=ctx.rows)
+        acc = None
+        for band in _bands(ctx.rows):
+            o = CO.raster_bwd(H, W, block, vs, bins, xys, conics, colors, opacity, bg, fT, fi, v_img, v_alpha,
+                              ALPHA_CLAMP_BWD, rows=band)
+            acc = o if acc is None else tuple(a + b for a, b in zip(acc, o))
+        v_xy, v_conic, v_col, v_op = acc
         return (v_xy, None, None, v_conic, None, v_col, v_op.reshape(ctx.oshape)) + (None,) * 5
 
 

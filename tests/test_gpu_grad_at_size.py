@@ -2,13 +2,14 @@
 production kernel thresholds (VERDICT r01 "weak #1": raster_bwd, the dominant kernel of the headline number, was only
 oracle-checked on 3k-Gaussian scenes with forced thresholds).
 
-Method: the loss weights (v_out of the rasterizer) vanish outside a band of tile rows, so every term of the
-backward belongs to a band pixel and the oracle only has to composite that band (`oracle_ops.PIXEL_ROWS`; pixels are
-independent, so the band of the image is the band of the full image).  Everything else — projection, SH, binning of
+Method: the loss weights (v_out of the rasterizer) vanish outside two bands of tile rows, so every term of the
+backward belongs to a band pixel and the oracle only has to composite those bands (`oracle_ops.PIXEL_ROWS`; pixels
+are independent, so a band of the image is that band of the full image).  Everything else — projection, SH, binning of
 all N Gaussians over the full 1920x1280 grid, the HIP kernels' launch shape, adaptive split and LDS batching — runs
-exactly as in `bench.py`.  The band is put on the tile row that holds the LONGEST depth list, and the tests assert
+exactly as in `bench.py`.  One band is put on the tile row that holds the LONGEST depth list, and the tests assert
 that the production thresholds (long-walk kernel >= 256 reverse-walk entries, LDS batches >= 128) are reached
-naturally where the scene is supposed to reach them.
+naturally where the scene is supposed to reach them; the second band (round 5) lies at a seeded
+random place elsewhere in the image, so the hottest row is not the only one ever compared at these sizes.
 
 Tolerance: rel-L2 <= 1e-4 per tensor (fp32 atomics order + v_exp_f32 / v_rcp_f32 vs libm in the oracle), SURVEY.md
 §8c; the image band itself mean |err| < 1e-6.
@@ -33,12 +34,22 @@ def _scene(name):
     return cam, raw
 
 
-def _band_weights(cam, row_lo, row_hi, seed=7):
+def _band_weights(cam, row_lo, row_hi, seed=7, more=()):
     from sgn_rast import step
     w_img, w_a = step.loss_weights(cam, seed=seed)
     mask = torch.zeros(cam.height, 1)
-    mask[row_lo:row_hi] = 1.0
+    for lo, hi in ((row_lo, row_hi),) + tuple(more):
+        mask[lo:hi] = 1.0
     return w_img * mask[..., None], w_a * mask
+
+
+def _second_band(name, n_tile_rows, hot_lo):
+    """A seeded random band of BAND_TILE_ROWS tile rows that does not touch the hot one."""
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    while True:
+        lo = int(torch.randint(0, n_tile_rows - BAND_TILE_ROWS + 1, (1,), generator=g))
+        if lo + BAND_TILE_ROWS <= hot_lo or lo >= hot_lo + BAND_TILE_ROWS:
+            return lo
 
 
 def _hip_step(cam, raw, w_img, w_a):
@@ -90,7 +101,9 @@ def test_train_step_gradients_match_oracle_at_size(name, production_defaults):
     hot_row = int(walks.amax(dim=1).argmax())
     tr_lo = max(0, min(hot_row - BAND_TILE_ROWS // 2, H // 16 - BAND_TILE_ROWS))
     row_lo, row_hi = tr_lo * 16, (tr_lo + BAND_TILE_ROWS) * 16
-    w_img, w_a = _band_weights(cam, row_lo, row_hi)
+    tr2 = _second_band(name, H // 16, tr_lo)
+    rows2 = (tr2 * 16, (tr2 + BAND_TILE_ROWS) * 16)
+    w_img, w_a = _band_weights(cam, row_lo, row_hi, more=(rows2,))
     del out0, saved, P0
 
     # 2. the thresholds of the production kernels are reached naturally in this band
@@ -104,7 +117,7 @@ def test_train_step_gradients_match_oracle_at_size(name, production_defaults):
 
     # 3. expected: the reference's call-site replay on the C oracle, compositing restricted to the band
     Pc = step.leaf_params(raw)
-    oracle_ops.PIXEL_ROWS = (row_lo, row_hi)
+    oracle_ops.PIXEL_ROWS = [(row_lo, row_hi), rows2]
     try:
         exp = step.train_step(Pc, cam, w_img, w_a, ops=oracle_ops)
     finally:
@@ -122,10 +135,10 @@ def test_train_step_gradients_match_oracle_at_size(name, production_defaults):
         assert int((got.radii.cpu() != exp.radii).sum()) <= max(2, n // 100_000)
         assert int((got.num_tiles_hit.cpu() != exp.num_tiles_hit).sum()) <= max(2, n // 100_000)
         torch.testing.assert_close(got.xys.detach().cpu(), exp.xys.detach(), rtol=2e-6, atol=1e-4)
-        band = slice(row_lo, row_hi)
-        for attr in ("rgb", "alpha"):
-            err = (getattr(got, attr).detach().cpu()[band] - getattr(exp, attr).detach()[band]).abs()
-            assert float(err.mean()) < 1e-6 and float((err > 1e-5).float().mean()) < 2e-3, (attr, float(err.mean()))
+        for band in (slice(row_lo, row_hi), slice(*rows2)):
+            for attr in ("rgb", "alpha"):
+                err = (getattr(got, attr).detach().cpu()[band] - getattr(exp, attr).detach()[band]).abs()
+                assert float(err.mean()) < 1e-6 and float((err > 1e-5).float().mean()) < 2e-3, (attr, float(err.mean()))
         # retained gradient of the autograd intermediate the densification reads (sgn_splatfacto.py:523-524)
         assert rel_l2(got.xys.grad.cpu(), exp.xys.grad) < 1e-4, ("xys.grad", reduce_mode)
         for k in Pd:

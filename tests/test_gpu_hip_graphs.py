@@ -22,7 +22,7 @@ g = torch.Generator().manual_seed(0)
 n = 200_000
 ok = True
 def rank(depths, radii, gid, ws):
-    L.check(lib.sgn_depth_rank(n, L.ptr(depths), L.ptr(radii), L.ptr(gid), L.ptr(ws), ws.numel(), L.stream_ptr()), "rank")
+    L.check(lib.sgn_depth_rank(n, L.ptr(depths), L.ptr(radii), L.ptr(gid), L.ptr(ws), ws.numel(), L.sort_rank_mode(), L.stream_ptr()), "rank")
 def expect(depths, radii):
     key = torch.where(radii > 0, depths, torch.full_like(depths, float("inf")))
     return torch.sort(key, stable=True).indices.to(torch.int32)

@@ -158,7 +158,7 @@ def test_sort_full_key_range_bits(hip):
     ws = L.workspace(lib.sgn_sort_workspace_bytes(n), kd.device)
     for end_bit in (40, 41, 47, 64):      # 5, 6, 6, 8 passes: both ping-pong parities
         L.check(lib.sgn_sort_pairs(n, 0, end_bit, L.ptr(kd), L.ptr(vd), L.ptr(ko), L.ptr(vo), L.ptr(ws),
-                                   ws.numel(), L.stream_ptr()), "sort")
+                                   ws.numel(), L.sort_rank_mode(), L.stream_ptr()), "sort")
         rk, order = torch.sort(keys, stable=True)
         assert torch.equal(ko.cpu(), rk) and torch.equal(vo.cpu(), vals[order]), end_bit
 
