@@ -47,7 +47,9 @@ typedef struct sgn_raster_opts {
                            exp_portable), 0 (default) = hardware v_exp_f32 */
     int reduce_mode;    /* backward wave reduction: 1 (default) = transposed reduction on v_permlane32_swap /
                            v_permlane16_swap + DPP row adds (8 swaps + 12 DPP adds for the nine per-Gaussian sums);
-                           0 = nine butterfly reductions (54 shuffles), kept for A/B measurements and tests */
+                           0 = nine butterfly reductions (54 shuffles), kept for A/B measurements and tests;
+                           2 = (round-5 experiment) the 64 -> 16 stage as nine v_mfma_f32_16x16x4_f32 column sums on the
+                           otherwise idle matrix pipe + 6 selects + 12 DPP adds */
     int gather;         /* 1 (default): kernels chase gaussian_ids_sorted[k] -> per-Gaussian row with dependent scalar
                            loads (no pack pass); 0: they stream a depth-ordered 48-byte record per intersection */
     int waves_fwd;      /* forward kernel: 2 (default) = packed FP32, two waves per 16x16 tile, two pixels per lane; the

@@ -1026,11 +1026,17 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
         const int pix = inside ? pixi[q] : 0;
         const float Tf = inside ? final_T[pix] : 1.f;
         T[q] = Tf;
+        // A pixel nothing was composited onto (its transmittance stayed EXACTLY 1: the first composited entry makes it
+        // <= 254/255) takes no part in the reverse walk; upstream never reads its incoming gradients.  The body below is
+        // branch-free — a masked lane contributes `0 * v_out` — so a non-finite value there would reach the sums as
+        // 0 x NaN.  Such values are ordinary: `depth / alpha` under a `where(alpha > eps, ...)` (sgn_splatfacto.py:995)
+        // has gradient 0 / 0 on every uncovered pixel.  Their gradients are therefore not loaded at all (round 5).
+        const bool live = inside && Tf < 1.f;
         // v_out == NULL: the image took no part in the loss (an accumulation-only pass): zeros, and no 29 MB read
-        vo0[q] = (inside && v_out != nullptr) ? v_out[3 * pix] : 0.f;
-        vo1[q] = (inside && v_out != nullptr) ? v_out[3 * pix + 1] : 0.f;
-        vo2[q] = (inside && v_out != nullptr) ? v_out[3 * pix + 2] : 0.f;
-        const float voa = inside ? v_out_alpha[pix] : 0.f;
+        vo0[q] = (live && v_out != nullptr) ? v_out[3 * pix] : 0.f;
+        vo1[q] = (live && v_out != nullptr) ? v_out[3 * pix + 1] : 0.f;
+        vo2[q] = (live && v_out != nullptr) ? v_out[3 * pix + 2] : 0.f;
+        const float voa = live ? v_out_alpha[pix] : 0.f;
         c0[q] = Tf * (voa - fmaf(bg0, vo0[q], fmaf(bg1, vo1[q], bg2 * vo2[q])));
         bv[q] = 0.f;
     }
@@ -1096,6 +1102,31 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
                 const float mine = (c == 0) ? t0 : (c == 1) ? t1 : t2;
                 if ((c < 2 || lane == 2) && !(dbg & 1))
                     unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + (c * 4 + rowmap), mine);
+            } else if constexpr (REDUCE == 2) {
+                // Round 5 experiment: the first two stages of the reduction (64 lanes -> 16 column sums) on the MATRIX
+                // pipe instead of the VALU's cross-lane network.  v_mfma_f32_16x16x4_f32 with A = ones computes
+                // D[i][j] = sum_k B[k][j]: B is one VGPR per lane, (k, j) <-> lane is a bijection, and every lane ends
+                // with the sum of "its" column j = lane % 16 in all four D registers (all rows i are equal).  The MFMA
+                // unit is idle in this kernel and issues beside the VALU of the other waves; what is left for the
+                // VALU is the packing of four values per register (row r takes value r: 6 v_cndmask) and the twelve
+                // DPP row adds.  Products are 1.0 * v (exact); the four-term sums are fp32 accumulations.
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                auto colsum = [&](float v) __attribute__((always_inline)) -> float {
+                    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, v, z4, 0, 0, 0);
+                    return d[0];
+                };
+                const float d0 = colsum(m_x), d1 = colsum(m_y), d2 = colsum(s_xx), d3 = colsum(s_xy);
+                const float d4 = colsum(s_yy), d5 = colsum(g_r), d6 = colsum(g_g), d7 = colsum(g_b);
+                const float d8 = colsum(g_o);
+                const int c = lane & 15, row = lane >> 4;
+                float t0 = (row == 0) ? d0 : (row == 1) ? d1 : (row == 2) ? d2 : d3;   // grad_ws words 0..3
+                float t1 = (row == 0) ? d4 : (row == 1) ? d5 : (row == 2) ? d6 : d7;   // words 4..7
+                float t2 = d8;                                                          // word 8 (row 0 writes it)
+                t0 = row_sum_dpp(t0); t1 = row_sum_dpp(t1); t2 = row_sum_dpp(t2);
+                const float mine = (c == 0) ? t0 : (c == 1) ? t1 : t2;
+                if ((c < 2 || lane == 2) && !(dbg & 1))
+                    unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + (c * 4 + row), mine);
             } else {
                 if (!(dbg & 2)) {          // dbg bit1: ablation only, skip the wave reduction (results are wrong)
                     m_x = wave_sum(m_x); m_y = wave_sum(m_y);
@@ -1300,7 +1331,7 @@ sgn_raster_opts resolve_opts(const sgn_raster_opts *o) {
     if (o) {
         r = *o;
         r.exact_exp = r.exact_exp ? 1 : 0;
-        r.reduce_mode = r.reduce_mode ? 1 : 0;
+        r.reduce_mode = (r.reduce_mode == 2) ? 2 : (r.reduce_mode ? 1 : 0);
         r.gather = r.gather ? 1 : 0;
         r.ids_qmask = r.ids_qmask ? 1 : 0;
         r.waves_fwd = (r.waves_fwd == 4 || r.waves_fwd == 2 || r.waves_fwd == 1) ? r.waves_fwd : 0;
@@ -1644,9 +1675,11 @@ static int raster_bwd_impl(int img_h, int img_w, int block_width, int n, int64_t
     } while (0)
 #define SGN_LAUNCH_BWD2(EX, RM) do { if (o.gather) SGN_LAUNCH_BWD(EX, RM, true); else SGN_LAUNCH_BWD(EX, RM, false); } while (0)
         if (o.exact_exp) {
-            if (o.reduce_mode) SGN_LAUNCH_BWD2(true, 1); else SGN_LAUNCH_BWD2(true, 0);
+            if (o.reduce_mode == 2) SGN_LAUNCH_BWD2(true, 2);
+            else if (o.reduce_mode) SGN_LAUNCH_BWD2(true, 1); else SGN_LAUNCH_BWD2(true, 0);
         } else {
-            if (o.reduce_mode) SGN_LAUNCH_BWD2(false, 1); else SGN_LAUNCH_BWD2(false, 0);
+            if (o.reduce_mode == 2) SGN_LAUNCH_BWD2(false, 2);
+            else if (o.reduce_mode) SGN_LAUNCH_BWD2(false, 1); else SGN_LAUNCH_BWD2(false, 0);
         }
 #undef SGN_LAUNCH_BWD2
 #undef SGN_LAUNCH_BWD

@@ -395,3 +395,39 @@ def test_two_models_interleaved_on_one_stream_keep_their_binnings():
     finally:
         ops.depth_channel = old
         ops.clear_binning_cache()
+
+
+def test_non_finite_gradients_on_uncovered_pixels_do_not_reach_any_gaussian():
+    """`depth / alpha` under `where(alpha > eps, ., const)` (sgn_splatfacto.py:995) has gradient 0 / 0 on every pixel no
+    Gaussian covers.  Upstream's backward never reads the incoming gradient of such a pixel (it takes no part in the
+    reverse walk); the branch-free kernels here mask lanes by multiplying with 0, so they must not LOAD it either
+    (found in round 5 by the scene-graph data-parallel test, whose loss includes the depth image)."""
+    from sgn_rast import ops, scenes
+    cam, raw = scenes.make_scene("c1", n_override=400)          # sparse: many uncovered pixels
+    H, W = cam.height, cam.width
+    P = {k: v.to(DEV) for k, v in raw.items()}
+    with torch.no_grad():
+        xys, depths, radii, conics, _c, nth, _cov = ops.project_gaussians(
+            P["means"], torch.exp(P["log_scales"]) * 0.3, 1, P["quats"] / P["quats"].norm(dim=-1, keepdim=True),
+            cam.viewmat[:3, :].to(DEV), cam.fx, cam.fy, cam.cx, cam.cy, H, W, 16)
+        opac = torch.sigmoid(P["opacity_logits"])
+        rgbs = torch.rand(xys.shape[0], 3, device=DEV, generator=torch.Generator(DEV).manual_seed(1))
+    g = torch.Generator().manual_seed(2)
+    w_img, w_a = torch.rand(H, W, 3, generator=g).to(DEV), torch.rand(H, W, generator=g).to(DEV)
+    grads = []
+    for poison in (False, True):
+        leaves = [t.detach().clone().requires_grad_(True) for t in (xys, conics, rgbs, opac)]
+        ops.clear_binning_cache()
+        img, alpha = ops.rasterize_gaussians(leaves[0], depths, radii, leaves[1], nth, leaves[2], leaves[3], H, W, 16,
+                                             torch.zeros(3, device=DEV), True)
+        uncovered = alpha.detach() == 0
+        assert 0.05 < float(uncovered.float().mean()) < 0.95
+        v_img, v_a = w_img.clone(), w_a.clone()
+        if poison:
+            v_img[uncovered] = float("nan")
+            v_a[uncovered] = float("inf")
+        torch.autograd.backward([img, alpha], [v_img, v_a])
+        grads.append([t.grad.clone() for t in leaves])
+    for a, b in zip(*grads):
+        assert torch.isfinite(b).all()
+        assert rel_l2(b, a) < 1e-5

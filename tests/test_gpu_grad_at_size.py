@@ -123,7 +123,7 @@ def test_train_step_gradients_match_oracle_at_size(name, production_defaults):
     finally:
         oracle_ops.PIXEL_ROWS = None
 
-    for reduce_mode in (1, 0):
+    for reduce_mode in (1, 0, 2):
         lib.set_options(reduce_mode=reduce_mode)
         Pd, got = _hip_step(cam, raw, w_img, w_a)
         # The library's projection is bit-exact on identical inputs (test_project_forward_bit_exact; at this size:

@@ -303,10 +303,10 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
 
 @pytest.mark.parametrize("block,size", [(16, (128, 128)), (16, (130, 70)), (8, (100, 60))])
 @pytest.mark.parametrize("clamp", [0.99, 0.999])
-@pytest.mark.parametrize("reduce_mode", [0, 1])
+@pytest.mark.parametrize("reduce_mode", [0, 1, 2])
 def test_rasterize_backward(hip, c_oracle, block, size, clamp, reduce_mode):
     from sgn_rast import _lib as L, ops
-    L.set_options(reduce_mode=reduce_mode)   # 0: butterfly shuffles, 1: transposed permlane-swap reduction
+    L.set_options(reduce_mode=reduce_mode)   # 0: butterfly shuffles, 1: transposed permlane-swap reduction, 2: MFMA column sums
     cam, P = small_scene(n=3000, w=size[0], h=size[1], focal=float(size[0]))
     P["opacity_logits"][:200] = 9.0   # opacity ~0.9999: exercises the 0.999 (fwd) / 0.99 (bwd) clamps
     R = _raster_inputs(c_oracle, cam, P, block)

@@ -42,10 +42,10 @@ def test_raster_kernels_have_no_scratch_and_scalar_operands(raster_asm):
     ks = _kernels(raster_asm)
     fwd = [t for k, t in ks.items() if "raster_fwd_kernel" in k]
     bwd = [t for k, t in ks.items() if "raster_bwd_kernel" in k or "raster_bwd_short_kernel" in k]
-    # forward: exact x gather x {4 waves, 1 wave, adaptive} x {3 channels, + depth channel}; backward: exact x reduce x
+    # forward: exact x gather x {4 waves, 1 wave, adaptive} x {3 channels, + depth channel}; backward: exact x reduce (3) x
     # gather x {4 waves, 1 wave, legacy in-kernel adaptive, long-walk half of the two-kernel scheme} + its short-walk
     # half (own kernel)
-    assert len(fwd) == 24 and len(bwd) == 40
+    assert len(fwd) == 24 and len(bwd) == 60
     for t in fwd + bwd:
         assert re.search(r"ScratchSize: 0\b", t), "a raster kernel spills to scratch"
         assert "s_load_dwordx8" in t and "s_load_dwordx4" in t     # 48-byte row / record in SGPRs
@@ -87,7 +87,7 @@ def test_short_walk_backward_is_held_at_four_waves_and_not_slp_packed(raster_asm
     (it would starve the concurrently running long-walk kernel): the occupancy attribute must have taken."""
     ks = _kernels(raster_asm)
     short = {k: t for k, t in ks.items() if "raster_bwd_short_kernel" in k}
-    assert len(short) == 8
+    assert len(short) == 12
     for k, t in short.items():
         assert "v_pk_fma_f32" not in t and "v_pk_mul_f32" not in t, k
         m = re.search(r"; Occupancy: (\d+)", t)
@@ -99,12 +99,15 @@ def test_backward_uses_the_permlane_swap_reduction(raster_asm):
     for k, t in ks.items():
         if "raster_bwd_kernel" not in k and "raster_bwd_short_kernel" not in k:
             continue
-        reduce_mode = int(re.search(r"raster_bwd_(?:short_)?kernelILb[01]ELi([01])E", k).group(1))
+        reduce_mode = int(re.search(r"raster_bwd_(?:short_)?kernelILb[01]ELi([012])E", k).group(1))
         swaps = t.count("v_permlane32_swap") + t.count("v_permlane16_swap")
         if reduce_mode == 1:
             assert swaps == 16 and t.count("row_half_mirror") >= 6        # 8 swaps + 12 DPP adds per code path, 2 paths
+            assert "v_mfma" not in t
+        elif reduce_mode == 2:        # round-5 experiment: column sums on the matrix pipe, nine MFMAs per code path
+            assert swaps == 0 and t.count("v_mfma_f32_16x16x4_f32") == 18 and t.count("row_half_mirror") >= 6
         else:
-            assert swaps == 0
+            assert swaps == 0 and "v_mfma" not in t
 
 
 def test_sky_backward_keeps_lds_and_global_atomics_apart(tmp_path_factory):
