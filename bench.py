@@ -48,7 +48,9 @@ def parse():
                          "warm-up (W=5, K=20 is a 30 ms window).  Default 0: exactly W warm-up steps, as the contract "
                          "says; measured on two boxes, 100 settle steps made no difference (629 vs 632 images/s)")
     ap.add_argument("--scene", default="metric", choices=["c1", "c2", "metric", "c4"])
-    ap.add_argument("--n", type=int, default=0, help="override the number of Gaussians")
+    ap.add_argument("--n", "--gaussians", dest="n", type=int, default=0,
+                    help="override the number of Gaussians (under torch.distributed.run spell it --gaussians: the "
+                         "launcher's own parser takes `--n` for an abbreviation of its --nnodes / --nproc-per-node)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=8,
                     help="tile rows composited by the pure-PyTorch CPU baseline sample (of 80 at 1920x1280; projection, SH "

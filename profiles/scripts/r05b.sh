@@ -13,7 +13,7 @@ ab metric 1; ab metric 2
 ab street 1 --street; ab street 2 --street
 ab translucent 1 --translucent; ab translucent 2 --translucent
 done
-dp8() { name=$1; shift; SGN_DP_BACKEND=gloo SGN_BENCH_SHARE_GPU=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 8 --steps 5 --warmup 2 --no-cpu-baseline --no-fused-extra --no-c4-extra --n 200000 "$@" > $O/bench_$name.json 2> $O/bench_$name.err; python profiles/scripts/benchline.py $name < $O/bench_$name.json; tail -2 $O/bench_$name.err | cut -c1-300; }
+dp8() { name=$1; shift; SGN_DP_BACKEND=gloo SGN_BENCH_SHARE_GPU=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 8 --steps 5 --warmup 2 --no-cpu-baseline --no-fused-extra --no-c4-extra --gaussians 200000 "$@" > $O/bench_$name.json 2> $O/bench_$name.err; python profiles/scripts/benchline.py $name < $O/bench_$name.json; tail -2 $O/bench_$name.err | cut -c1-300; }
 dp8 dp8_gloo
 dp8 dp8_gloo_sg --scene-graph
 python - <<'PY'

@@ -65,9 +65,11 @@ def weights(view: int, device="cpu"):
             (("rgb", (H_, W_, 3)), ("alpha", (H_, W_)), ("depth", (H_, W_, 1)), ("obj", (H_, W_)), ("bg", (H_, W_)))}
 
 
-def render_loss(models, view: int, poses0, ops=None, fused=False, device="cpu", **kw):
+def render_loss(models, view: int, poses0, ops=None, fused=False, device="cpu", depth_in_loss=True, **kw):
     """One frame through `step.render_scene_graph`, ALL FOUR passes in the loss (rgb + alpha, depth, object
-    accumulation, background accumulation).  Returns (loss, out, visible indices)."""
+    accumulation, background accumulation).  Returns (loss, out, visible indices).  `depth_in_loss=False` leaves the
+    depth image out: the fused front end returns it as a NON-differentiable fourth channel of the colour pass (the
+    reference never differentiates it: `depth` is an output, not a loss term, sgn_splatfacto.py:982-996, 1079-1094)."""
     cam, vis, poses, idft = frame(view, poses0, device)
     sub = [models[i] for i in vis]
     if ops is not None:
@@ -76,7 +78,7 @@ def render_loss(models, view: int, poses0, ops=None, fused=False, device="cpu", 
     w = weights(view, device)
     loss = ((out.rgb * w["rgb"]).sum() + (out.alpha * w["alpha"]).sum() + (out.object_acc * w["obj"]).sum()
             + (out.background_acc * w["bg"]).sum()) / (H_ * W_)
-    if not getattr(out, "empty", False):
+    if depth_in_loss and not getattr(out, "empty", False):
         loss = loss + (out.depth.clamp(max=10.0) * w["depth"]).sum() / (10.0 * H_ * W_)
     return loss, out, vis
 

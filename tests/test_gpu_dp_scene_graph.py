@@ -48,9 +48,10 @@ def test_scene_graph_gradients_through_the_reducer_match_the_oracle(rccl_single_
         for view in (2, 3, 4):                 # three frames with different visible sets; 4 shows neither 2, 3 nor 5
             sg_dp.zero_grads(Mc); sg_dp.zero_grads(Md)
             ops.clear_binning_cache()
-            loss_c, out_c, vis = sg_dp.render_loss(Mc, view, poses0, ops=oracle_ops)
+            # (drop-in: all four passes in the loss; fused: the depth image is a non-differentiable channel, left out)
+            loss_c, out_c, vis = sg_dp.render_loss(Mc, view, poses0, ops=oracle_ops, depth_in_loss=not fused)
             loss_c.backward()
-            loss_d, out_d, vis_d = sg_dp.render_loss(Md, view, poses0, fused=fused, device=DEV)
+            loss_d, out_d, vis_d = sg_dp.render_loss(Md, view, poses0, fused=fused, device=DEV, depth_in_loss=not fused)
             loss_d.backward()
             assert vis == vis_d
             shown = set(vis)
@@ -86,7 +87,8 @@ def test_scene_graph_training_with_per_sub_model_densification_on_device(rccl_si
     counts = [[m["means"].shape[0] for m in models]]
     for step in range(1, 13):
         sg_dp.zero_grads(models)
-        loss, out, vis = sg_dp.render_loss(models, 2 * step + 1, poses0, fused=fused, device=DEV)   # (odd views: object 3 shows)
+        loss, out, vis = sg_dp.render_loss(models, 2 * step + 1, poses0, fused=fused, device=DEV,
+                                           depth_in_loss=not fused)                      # (odd views: object 3 shows)
         loss.backward()
         red.finish(absent=[p for i, m in enumerate(models) if i not in set(vis) for p in m.values()])
         optim.step_many(opts.values())
