@@ -82,7 +82,9 @@ def test_scene_graph_training_with_per_sub_model_densification_on_device(rccl_si
     opts = sg_dp.make_optimizers(models, opt_cls=optim.FusedAdam)
     cfg = sg_dp.densify_config()
     D = densify.SceneGraphDensifier(models, opts, cfg, seed=5, stats_factory=lambda group=None: densify.Stats(group, force=True))
-    shadow = [TorchStats() for _ in models]          # plain single-process bookkeeping, torch arithmetic, on the device
+    # plain single-process bookkeeping in the reference's torch arithmetic — on the CPU: torch's GPU kernel divides by a
+    # scalar through its reciprocal (1 ulp off `radii / max_dim`), the HIP kernel divides like the CPU does
+    shadow = [TorchStats() for _ in models]
     red = _reducer(models, True)
     counts = [[m["means"].shape[0] for m in models]]
     for step in range(1, 13):
@@ -95,8 +97,8 @@ def test_scene_graph_training_with_per_sub_model_densification_on_device(rccl_si
         grads, radii = sg_dp.sub_stats(out, models, vis)
         D.after_train(step, vis, grads, radii, (sg_dp.H_, sg_dp.W_))
         for j, i in enumerate(vis):
-            g = grads[j] if grads[j] is not None else torch.zeros(radii[j].shape[0], 2, device=DEV)
-            shadow[i].update(g, radii[j], (sg_dp.H_, sg_dp.W_))
+            g = grads[j].cpu() if grads[j] is not None else torch.zeros(radii[j].shape[0], 2)
+            shadow[i].update(g, radii[j].cpu(), (sg_dp.H_, sg_dp.W_))
         if step % cfg.refine_every == 0:
             for i, d in enumerate(D.parts):           # what the decisions will read == the reference's bookkeeping
                 S = d.stats
@@ -105,9 +107,9 @@ def test_scene_graph_training_with_per_sub_model_densification_on_device(rccl_si
                     continue
                 assert S.sync(n=d.params["means"].shape[0], device=DEV)       # (idempotent for one rank but for the mask)
                 S._first_visible = torch.ones_like(S._first_visible)          # ... which has been added now
-                assert torch.equal(S.vis_counts, shadow[i].vis_counts), i
-                assert torch.equal(S.max_2Dsize, shadow[i].max_2Dsize), i
-                assert torch.allclose(S.xys_grad_norm, shadow[i].xys_grad_norm, rtol=1e-6, atol=0), i
+                assert torch.equal(S.vis_counts.cpu(), shadow[i].vis_counts), i
+                assert torch.equal(S.max_2Dsize.cpu(), shadow[i].max_2Dsize), i
+                assert torch.allclose(S.xys_grad_norm.cpu(), shadow[i].xys_grad_norm, rtol=1e-6, atol=0), i
                 assert S.synced_dim == float(max(sg_dp.H_, sg_dp.W_))
             changed = D.refinement_after(step)
             for sh in shadow:
