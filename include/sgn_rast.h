@@ -421,6 +421,32 @@ int sgn_raster_fwd_groups(int img_h, int img_w, int n, int64_t n_isect, const in
                           const int32_t *tile_order, int32_t *tile_stats, const float *depths, float *out_depth,
                           int split, int own_group, const int32_t *own_ids, const int32_t *own_bins /*[tiles,2]*/,
                           float *group_state, int32_t *group_stats, const sgn_raster_opts *opts, sgn_stream_t stream);
+/* ONE call per autograd node (round 5; no upstream counterpart: upstream's rasterize_gaussians drives its five `_C`
+ * calls from Python).  The whole forward of `rasterize_gaussians` over the full scene in gather mode: sgn_bin_prepare ->
+ * asynchronous read-back of the intersection count -> sgn_raster_build_rows -> SPECULATIVE sgn_bin_intersect (sized by
+ * isect_capacity, the true count read on the device) -> wait for the count (the path's one host sync, upstream's
+ * `.item()`) -> sgn_tile_order -> sgn_raster_fwd, all on `stream`, temporaries carved from ONE caller-provided arena
+ * (sgn_rasterize_arena_bytes).  The outputs the node keeps for its backward are the caller's: gaussian_ids_sorted
+ * [isect_capacity], tile_bins [tiles,2], tile_order [tiles+2], tile_stats [tiles,2], rows (sgn_raster_workspace_bytes(n,
+ * 0, opts)), final_Ts, final_idx.  *n_isect_host receives the true count.  Returns 0; SGN_E_CAPACITY when the count
+ * exceeds isect_capacity (nothing rasterized: call again with more room); with a count of 0 it returns 0 without touching
+ * out_img / final_Ts / final_idx (tile_bins is zero-filled): the caller writes the background image.
+ * gid_by_rank_ready: NULL, or sgn_depth_rank's result for these depths / radii (started earlier).  count_pinned: pinned
+ * host int32 the count is copied to (NULL: a pageable copy).  extra_dev / extra_pinned: one more device int32 to bring
+ * along in the same transfer (the host's walk statistic), or NULL.  order_scratch as in sgn_tile_order. */
+#define SGN_E_CAPACITY (-100)
+size_t sgn_rasterize_arena_bytes(int n, int64_t isect_capacity);
+int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const int32_t *radii, const float *conics,
+                          const float *colors, const float *opacities, int opacity_is_logit, int cull, int img_h,
+                          int img_w, int block_width, const float *background3, const int32_t *gid_by_rank_ready,
+                          int quadrant_masks, float *out_img, float *final_Ts, int32_t *final_idx,
+                          int32_t *gaussian_ids_sorted, int64_t isect_capacity, int32_t *tile_bins,
+                          int32_t *tile_order, int32_t *tile_stats, void *rows, size_t rows_bytes,
+                          void *order_scratch, size_t order_scratch_bytes, void *arena, size_t arena_bytes,
+                          int32_t *count_pinned, const int32_t *extra_dev, int32_t *extra_pinned,
+                          int64_t *n_isect_host, int sort_rank_mode, const sgn_raster_opts *opts,
+                          sgn_stream_t stream);
+
 /* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built
  * while the host waits for the intersection count (keeps the GPU busy across that sync).  Pre-built rows are used by
  * sgn_raster_fwd when opts->gather != 0 (pass rows_built = 1); in stream mode it re-packs them itself. */

@@ -45,6 +45,113 @@ int sgn_fork_events(hipEvent_t *fork, hipEvent_t *join) {
     return 0;
 }
 
+// ---------------------------------------------------------------- one C-ABI call per autograd node (round 5)
+// sgn_rasterize_fwd_all: the whole forward of `rasterize_gaussians` for the plain case (the full scene, gather mode) — the
+// sequence the Python host otherwise drives call by call (sgn_rast/ops.py `_RasterizeGaussians.forward`): first half of
+// the binning, the asynchronous read-back of the intersection count, the per-Gaussian rows, the SPECULATIVE second half
+// of the binning (emission + tile sort + bins sized by the caller's capacity, the true count read on the device), the
+// wait for the count — the path's one host sync, as upstream's `.item()` — the launch order and the forward kernels.
+// Host only: it calls the library's own entry points on the caller's stream and carves its temporaries from ONE arena.
+namespace {
+inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+int sync_event(hipEvent_t *ev) {          // one untimed event per (thread, device), like the fork / join pair above
+    struct One { int dev; hipEvent_t e; };
+    static thread_local std::vector<One> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    for (auto &p : cache)
+        if (p.dev == dev) { *ev = p.e; return 0; }
+    One o;
+    o.dev = dev;
+    if (hipEventCreateWithFlags(&o.e, hipEventDisableTiming) != hipSuccess) return 2;
+    cache.push_back(o);
+    *ev = o.e;
+    return 0;
+}
+}  // namespace
+
+extern "C" __attribute__((visibility("default")))
+size_t sgn_rasterize_arena_bytes(int n, int64_t isect_capacity) {
+    const size_t nn = (size_t)(n > 0 ? n : 1);
+    return 2 * al256(nn * 4) + al256(nn * 32) + al256(sgn_bin_prepare_workspace_bytes(n)) +
+           al256(sgn_bin_intersect_workspace_bytes(isect_capacity)) + 256;
+}
+
+extern "C" __attribute__((visibility("default")))
+int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const int32_t *radii, const float *conics,
+                          const float *colors, const float *opacities, int opacity_is_logit, int cull, int img_h,
+                          int img_w, int block_width, const float *background3, const int32_t *gid_by_rank_ready,
+                          int quadrant_masks, float *out_img, float *final_Ts, int32_t *final_idx,
+                          int32_t *gaussian_ids_sorted, int64_t isect_capacity, int32_t *tile_bins,
+                          int32_t *tile_order, int32_t *tile_stats, void *rows, size_t rows_bytes,
+                          void *order_scratch, size_t order_scratch_bytes, void *arena, size_t arena_bytes,
+                          int32_t *count_pinned, const int32_t *extra_dev, int32_t *extra_pinned,
+                          int64_t *n_isect_host, int sort_rank_mode, const sgn_raster_opts *opts,
+                          sgn_stream_t stream) {
+    if (n < 1 || !xys || !depths || !radii || !colors || !opacities || !background3 || !out_img || !final_Ts ||
+        !final_idx || !gaussian_ids_sorted || !tile_bins || !tile_order || !tile_stats || !rows || !arena ||
+        !n_isect_host || isect_capacity < 1 || block_width < 2 || block_width > 16 || img_h < 1 || img_w < 1) {
+        sgn_set_error("sgn_rasterize_fwd_all: argument check failed");
+        return -1;
+    }
+    if (arena_bytes < sgn_rasterize_arena_bytes(n, isect_capacity)) {
+        sgn_set_error("sgn_rasterize_fwd_all: arena too small");
+        return -2;
+    }
+    sgn_raster_opts o;
+    sgn_raster_default_opts(&o);
+    if (opts) o = *opts;
+    if (!o.gather) {
+        sgn_set_error("sgn_rasterize_fwd_all: gather mode only (opts->gather = 1)");
+        return -3;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
+    const int n_tiles = tiles_x * tiles_y;
+    char *p = (char *)arena;
+    int32_t *cum_r = (int32_t *)p; p += al256((size_t)n * 4);
+    int32_t *gid_own = (int32_t *)p; p += al256((size_t)n * 4);
+    float *bin_recs = (float *)p; p += al256((size_t)n * 32);
+    void *ws1 = p; const size_t ws1_bytes = sgn_bin_prepare_workspace_bytes(n); p += al256(ws1_bytes);
+    void *ws2 = p; const size_t ws2_bytes = sgn_bin_intersect_workspace_bytes(isect_capacity);
+    int32_t *gid = gid_by_rank_ready ? const_cast<int32_t *>(gid_by_rank_ready) : gid_own;
+    const int do_cull = (cull && conics && opacities) ? 1 : 0;
+    int rc = sgn_bin_prepare(n, xys, depths, radii, do_cull ? conics : nullptr, do_cull ? opacities : nullptr,
+                             opacity_is_logit, do_cull, tiles_x, tiles_y, block_width, cum_r, gid,
+                             gid_by_rank_ready ? 1 : 0, bin_recs, ws1, ws1_bytes, sort_rank_mode, stream);
+    if (rc) return rc;
+    // the count starts its way to the host now; everything queued below runs while it travels
+    int32_t pageable = -1;
+    int32_t *dst = count_pinned ? count_pinned : &pageable;
+    hipError_t e = hipMemcpyAsync(dst, cum_r + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && extra_dev && extra_pinned)
+        e = hipMemcpyAsync(extra_pinned, extra_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    hipEvent_t ev = nullptr;
+    if (e == hipSuccess && sync_event(&ev) != 0) e = hipErrorUnknown;
+    if (e == hipSuccess) e = hipEventRecord(ev, s);
+    if (e != hipSuccess) { sgn_set_error("sgn_rasterize_fwd_all: count read-back: %s", hipGetErrorString(e)); return (int)e; }
+    rc = sgn_raster_build_rows(n, xys, conics, colors, opacities, opacity_is_logit, 0, n, 0, rows, rows_bytes, nullptr,
+                               stream);
+    if (rc) return rc;
+    rc = sgn_bin_intersect(n, isect_capacity, bin_recs, cum_r, gid, tiles_x, tiles_y, block_width, gaussian_ids_sorted,
+                           tile_bins, quadrant_masks, ws2, ws2_bytes, cum_r + (n - 1), sort_rank_mode, stream);
+    if (rc) return rc;
+    e = hipEventSynchronize(ev);                       // the path's one host sync (upstream: `.item()` on the count)
+    if (e != hipSuccess) { sgn_set_error("sgn_rasterize_fwd_all: %s", hipGetErrorString(e)); return (int)e; }
+    const int64_t count = (int64_t)*dst;
+    *n_isect_host = count;
+    if (count > isect_capacity) return SGN_E_CAPACITY;   // the list did not fit: call again with more room
+    if (count < 1) return 0;                             // nothing visible: the caller writes the background image
+    rc = sgn_tile_order(n_tiles, tile_bins, nullptr, (o.waves_fwd == 2) ? (o.adapt_fwd > 0 ? o.adapt_fwd : 1024) : 0, 0,
+                        tile_order, order_scratch, order_scratch_bytes, stream);
+    if (rc) return rc;
+    sgn_raster_opts oo = o;
+    oo.ids_qmask = quadrant_masks ? 1 : 0;
+    return sgn_raster_fwd(img_h, img_w, block_width, n, count, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                          opacities, opacity_is_logit, 0, n, 0, background3, out_img, final_Ts, final_idx, rows,
+                          rows_bytes, 1, tile_order, tile_stats, nullptr, nullptr, nullptr, &oo, stream);
+}
+
 // ---------------------------------------------------------------- launch chains replayed as HIP graphs
 // (sgn_common.h: sgn_graph_find / sgn_graph_capture_begin / _end.)  A resource cache per (thread, device): up to 8
 // instantiated graphs, least recently used out; one capture stream.  No configuration lives here: the key is the

@@ -1128,6 +1128,100 @@ _touch_sink = None
 _call_state = threading.local()
 
 
+# One library call per autograd node (round 5).  `sgn_rasterize_fwd_all` runs the forward's whole
+# launch sequence — first half of the binning, count read-back, rows, speculative second half, the wait, launch order,
+# forward kernels — behind ONE ctypes call with ONE arena for its temporaries, instead of six calls and a dozen
+# allocations driven from here.  It serves the plain case (the full scene, a fresh binning, no depth channel / reuse /
+# window / groups, a capacity known from earlier calls of the same shape); everything else, and a capacity miss, takes the
+# call-by-call path below, which stays the reference for behaviour.  Same kernels, same order, same results.
+# `SGN_COMPOSITE=0` switches it off.
+composite_forward = os.environ.get("SGN_COMPOSITE", "1") != "0"
+composite_stats = {"forwards": 0, "capacity_misses": 0}
+_E_CAPACITY = -100
+
+
+def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colors_c, opac_c, opacity_is_logit,
+                       img_height, img_width, block_width, tile_bounds, bg_c, out_img, final_Ts, final_idx, ro, ro_ptr,
+                       logit_leaves, stream_ptr):
+    """(num_intersects, ids, tile_bins, order, tile_kmax, rows) or None (no capacity known yet / the list did not fit:
+    the caller takes the call-by-call path)."""
+    if not speculative_binning or depths.dtype is not torch.float32 or radii.dtype is not torch.int32:
+        return None
+    dev = xys_c.device
+    tx, ty = int(tile_bounds[0]), int(tile_bounds[1])
+    ckey = (dev, n, tx, ty, int(block_width))
+    last = S.last_count.get(ckey, 0)
+    if last <= 0:
+        return None
+    cap = min(int(last * _SPEC_MARGIN) + 1024, (1 << 31) - 1)
+    lib = L.load()
+    i32 = dict(dtype=torch.int32, device=dev)
+    n_tiles = tx * ty
+    qmask = bool(cull and int(block_width) == 16 and n < (1 << QMASK_ID_BITS) and _quadrant_masks_wanted())
+    ids = torch.empty(cap, **i32)
+    tile_bins = torch.empty(n_tiles, 2, **i32)
+    order = torch.empty(n_tiles + 2, **i32)
+    tile_kmax = torch.empty(n_tiles, 2, **i32)
+    rows = L.workspace(lib.sgn_raster_workspace_bytes(n, 0, ro_ptr), dev)
+    arena = L.workspace(lib.sgn_rasterize_arena_bytes(n, cap), dev)
+    scratch = None
+    if tile_order_enabled and tile_order_multiblock:
+        scratch = S.order_scratch.get(n_tiles)
+        if scratch is None:
+            if len(S.order_scratch) > 8:
+                S.order_scratch.clear()
+            scratch = S.order_scratch[n_tiles] = torch.zeros(int(lib.sgn_tile_order_scratch_bytes(n_tiles)) // 4, **i32)
+    early = _take_early_rank(depths, radii)
+    if S.side is None:
+        S.side = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]
+    pool = S.side
+    pinned = pool[0][pool[1] % 4]
+    pool[1] += 1
+    walk_stat, S.walk_stat = S.walk_stat, None          # the last backward's walked / listed statistic rides along
+    if walk_stat is not None and S.walked_permille is not None and S.stat_skipped < 7:
+        S.stat_skipped += 1
+        walk_stat = None
+    if walk_stat is not None:
+        S.stat_skipped = 0
+    n_host = C.c_int64(0)
+    rc = lib.sgn_rasterize_fwd_all(
+        n, L.ptr(xys_c), L.ptr(_f32c(depths)), L.ptr(_i32c(radii)), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c),
+        int(bool(opacity_is_logit)), int(bool(cull)), int(img_height), int(img_width), int(block_width), L.ptr(bg_c),
+        L.ptr(early), int(qmask), L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(ids), cap, L.ptr(tile_bins),
+        L.ptr(order), L.ptr(tile_kmax), L.ptr(rows), rows.numel(), L.ptr(scratch),
+        4 * scratch.numel() if scratch is not None else 0, L.ptr(arena), arena.numel(), pinned[0:1].data_ptr(),
+        L.ptr(walk_stat), pinned[7:8].data_ptr() if walk_stat is not None else None, C.byref(n_host),
+        L.sort_rank_mode(), ro_ptr, stream_ptr)
+    binning_stats["binnings"] += 1
+    if walk_stat is not None and rc in (0, _E_CAPACITY):
+        S.walked_permille = quadrant_mask_stats["walked_permille"] = int(pinned[7])
+    count = int(n_host.value)
+    if rc == _E_CAPACITY:
+        # the view sees more than 1.3x the recent peak: remember the count and let the call-by-call path bin again
+        S.last_count[ckey] = max(count, int(0.9 * last))
+        binning_stats["speculative_misses"] += 1
+        composite_stats["capacity_misses"] += 1
+        return None
+    L.check(rc, "sgn_rasterize_fwd_all")
+    S.last_count[ckey] = max(count, int(0.9 * last))
+    binning_stats["speculative_hits"] += int(count >= 1)
+    composite_stats["forwards"] += 1
+    ids = ids[:max(count, 0)]
+    ids._sgn_qmask = qmask
+    quadrant_mask_stats["binnings_with_masks"] += int(qmask)
+    ro.ids_qmask = int(qmask)
+    if count < 1:
+        return count, ids, tile_bins, order, tile_kmax, None
+    if binning_cache_enabled:
+        S.store_binning(key, tuple(t.detach() for t in _t), (count, ids, tile_bins), _window_info(_t, cull, logit_leaves))
+    if tile_order_enabled:
+        oc = S.order_cache
+        oc[(id(tile_bins), _fwd_long_thresh(ro))] = (tile_bins, order)
+        while len(oc) > 4:
+            oc.popitem(last=False)
+    return count, ids, tile_bins, order, tile_kmax, rows
+
+
 # --------------------------------------------------------------- rasterize
 class _RasterizeGaussians(Function):
     @staticmethod
@@ -1192,122 +1286,140 @@ class _RasterizeGaussians(Function):
             L.check(lib.sgn_colors_match_depths(num_points, L.ptr(colors_c), L.ptr(depths_c), L.ptr(skip_flag),
                                                 stream_ptr), "sgn_colors_match_depths")
         out_depth = torch.empty(img_height, img_width, **f32) if accumulate else None
-        # ... and the per-Gaussian rows are built between the binning's first half and its host sync, so the GPU has
-        # work queued while the host wakes up (gather mode; the stream mode re-packs rows per intersection later)
-        recs, rows_built = None, 0
-        if num_points > 0 and ro.gather and not proved:
-            if win is None and not hit and _bin_pending["key"] != key:
-                _drop_pending()
-                _bin_pending["state"] = _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds,
-                                                           block_width, conics, opacity, opacity_is_logit, cull)
-                _bin_pending["key"], _bin_pending["keep"] = key, tuple(t.detach() for t in _t)
-            recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, 0, ro_ptr), dev)
-            L.check(lib.sgn_raster_build_rows(n_full, L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c),
-                                              int(bool(opacity_is_logit)), id_lo, id_hi, window, L.ptr(recs),
-                                              recs.numel(), L.ptr(skip_flag), stream_ptr), "sgn_raster_build_rows")
-            rows_built = 1
-        if win is not None:
-            num_intersects, gaussian_ids_sorted, tile_bins = cached
+        # ONE library call for the whole node where nothing special is asked (sgn_rasterize_fwd_all, round 5): the full scene,
+        # a fresh binning, no depth channel / reuse / groups, a capacity known from earlier calls
+        comp = None
+        if (composite_forward and plain and not hit and not reuse and not accumulate and group_split is None
+                and not want_depth and _bin_pending["key"] != key and not S.pending_checks):
+            comp = _forward_composite(S, key, _t, cull, num_points, xys_c, depths, radii, conics_c, colors_c, opac_c,
+                                      opacity_is_logit, img_height, img_width, block_width, tile_bounds, bg_c, out_img,
+                                      final_Ts, final_idx, ro, ro_ptr, opacity_logits, stream_ptr)
+        if comp is not None:
+            num_intersects, gaussian_ids_sorted, tile_bins, order, tile_kmax, recs = comp
+            if num_intersects < 1:
+                recs = None
+                out_img = torch.ones(img_height, img_width, 3, **f32) * bg_c
+                final_Ts = torch.ones(img_height, img_width, **f32)
+                final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
+                gaussian_ids_sorted = torch.zeros(0, dtype=torch.int32, device=dev)
+            S.depth_caches.pop(key, None)      # binned again without the channel: a stale image must not answer later
         else:
-            num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
-                num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
-                opacity_is_logit, pre=(key, _t, cull), logit_leaves=opacity_logits)
-        ro.ids_qmask = int(bool(getattr(gaussian_ids_sorted, "_sgn_qmask", False)))   # the backward runs with `ro` too
-        if (num_intersects >= 1 and list_window_enabled and (id_hi - id_lo) < list_window_max_frac * n_full
-                and (id_lo, id_hi) != (0, n_full) and ro.gather):      # (stream mode re-packs n_isect records: full list)
-            # a SMALL window of a shared list (the scene graph's objects-only pass): walk its own entries only
-            gaussian_ids_sorted, tile_bins = _list_window(gaussian_ids_sorted, tile_bins, id_lo, id_hi, ro.ids_qmask)
-            window_stats["sub_lists"] += 1
-        if proved and num_intersects >= 1:
-            # the depth pass, proven on the host: its image comes from the first pass's fourth channel, and its node
-            # SHARES that pass's per-pixel state and tile statistics (same geometry and opacities: same values)
-            final_Ts, final_idx, tile_kmax = dcache["T"], dcache["idx"], dcache["kmax"]
-            order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
-            L.check(lib.sgn_depth_reuse(img_height, img_width, None, L.ptr(dcache["D"]), L.ptr(final_Ts),
-                                        L.ptr(final_idx), L.ptr(bg_c), L.ptr(out_img), None, None, 0, None, None,
-                                        stream_ptr), "sgn_depth_reuse")
-            depth_stats["reused"] += 1
-            depth_stats["proved_on_host"] += 1
-            _depth_state["unused"] = 0
-        elif num_intersects < 1:
-            recs = None
-            out_depth = None            # never written (no forward ran): the want_depth branch below returns zeros
-            out_img = torch.ones(img_height, img_width, 3, **f32) * bg_c
-            gaussian_ids_sorted = torch.zeros(0, dtype=torch.int32, device=dev)
-            tile_bins = torch.zeros(tile_bounds[0] * tile_bounds[1], 2, dtype=torch.int32, device=dev)
-            final_Ts = torch.ones(img_height, img_width, **f32)
-            final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
-        elif group_split is not None:
-            # the main pass with the two group accumulations riding on it (sgn_raster_fwd_groups): head = ids below the
-            # split, tail = the others.  The smaller group, if small enough, gets its own compacted list: its backward
-            # walks that list, so its indices are recorded in that list's positions (and its forward walk finishes
-            # there); the other one walks the shared list (with the first group's rows inert).
-            assert win is None and id_range is None and ro.gather and ro.waves_fwd == 2 and block_width == 16
-            if not rows_built:
-                recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
-            order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
-            n_tiles = tile_bins.shape[0]
-            tile_kmax = torch.empty(n_tiles, 2, dtype=torch.int32, device=dev)
-            split = min(max(int(group_split), 0), n_full)
-            sizes = (split, n_full - split)
-            small = 0 if sizes[0] <= sizes[1] else 1
-            own = small if (list_window_enabled and 0 < sizes[small] < list_window_max_frac * n_full) else -1
-            state = torch.empty(4, img_height, img_width, **f32)          # T_head, T_tail, idx_head, idx_tail
-            kmax = torch.empty(2, n_tiles, 2, dtype=torch.int32, device=dev)
-            groups = []
-            for gi, (lo, hi) in enumerate(((0, split), (split, n_full))):
-                g_ids, g_bins = (_list_window(gaussian_ids_sorted, tile_bins, lo, hi, ro.ids_qmask) if gi == own
-                                 else (gaussian_ids_sorted, tile_bins))
-                window_stats["sub_lists"] += int(gi == own)
-                groups.append(dict(lo=lo, hi=hi, own=gi == own, ids=g_ids, bins=g_bins, T=state[gi],
-                                   idx=state[2 + gi].view(torch.int32), kmax=kmax[gi]))
-            og = groups[own] if own >= 0 else None
-            L.check(lib.sgn_raster_fwd_groups(
-                img_height, img_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
-                L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), L.ptr(bg_c),
-                L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), rows_built, L.ptr(order),
-                L.ptr(tile_kmax), L.ptr(depths_c) if accumulate else None, L.ptr(out_depth), split, own,
-                L.ptr(og["ids"]) if og else None, L.ptr(og["bins"]) if og else None, L.ptr(state), L.ptr(kmax),
-                ro_ptr, stream_ptr), "sgn_raster_fwd_groups")
-            group_stats["passes"] += 1
-            ctx.groups = groups
-            if accumulate:
-                depth_stats["accumulated"] += 1
-                S.depth_caches[key] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
-                while len(S.depth_caches) > _State.BIN_ENTRIES:
-                    S.depth_caches.popitem(last=False)
-            elif not hit:
-                S.depth_caches.pop(key, None)
-        else:
-            if not rows_built:
-                recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
-            # packed forward: the leading tiles of the order whose lists reach adapt_fwd entries get four waves
-            order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
-            tile_kmax = torch.empty(tile_bins.shape[0], 2, dtype=torch.int32, device=dev)   # walk depth, pairs
-            L.check(lib.sgn_raster_fwd(
-                img_height, img_width, block_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
-                L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), id_lo, id_hi,
-                window, L.ptr(bg_c), L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(),
-                rows_built, L.ptr(order), L.ptr(tile_kmax), L.ptr(depths_c) if accumulate else None,
-                L.ptr(out_depth), L.ptr(skip_flag), ro_ptr, stream_ptr), "sgn_raster_fwd")
-            if reuse:
-                L.check(lib.sgn_depth_reuse(img_height, img_width, L.ptr(skip_flag), L.ptr(dcache["D"]),
-                                            L.ptr(dcache["T"]), L.ptr(dcache["idx"]), L.ptr(bg_c), L.ptr(out_img),
-                                            L.ptr(final_Ts), L.ptr(final_idx), tile_kmax.numel(),
-                                            L.ptr(dcache["kmax"]), L.ptr(tile_kmax), stream_ptr), "sgn_depth_reuse")
-                recs = None                    # the rows were not built if the flag said "reuse": the backward packs them
+            # ... and the per-Gaussian rows are built between the binning's first half and its host sync, so the GPU has
+            # work queued while the host wakes up (gather mode; the stream mode re-packs rows per intersection later)
+            recs, rows_built = None, 0
+            if num_points > 0 and ro.gather and not proved:
+                if win is None and not hit and _bin_pending["key"] != key:
+                    _drop_pending()
+                    _bin_pending["state"] = _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds,
+                                                               block_width, conics, opacity, opacity_is_logit, cull)
+                    _bin_pending["key"], _bin_pending["keep"] = key, tuple(t.detach() for t in _t)
+                recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, 0, ro_ptr), dev)
+                L.check(lib.sgn_raster_build_rows(n_full, L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c),
+                                                  int(bool(opacity_is_logit)), id_lo, id_hi, window, L.ptr(recs),
+                                                  recs.numel(), L.ptr(skip_flag), stream_ptr), "sgn_raster_build_rows")
+                rows_built = 1
+            if win is not None:
+                num_intersects, gaussian_ids_sorted, tile_bins = cached
+            else:
+                num_intersects, gaussian_ids_sorted, tile_bins = _bin_gaussians_cached(
+                    num_points, xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity,
+                    opacity_is_logit, pre=(key, _t, cull), logit_leaves=opacity_logits)
+            ro.ids_qmask = int(bool(getattr(gaussian_ids_sorted, "_sgn_qmask", False)))   # the backward runs with `ro` too
+            if (num_intersects >= 1 and list_window_enabled and (id_hi - id_lo) < list_window_max_frac * n_full
+                    and (id_lo, id_hi) != (0, n_full) and ro.gather):      # (stream mode re-packs n_isect records: full list)
+                # a SMALL window of a shared list (the scene graph's objects-only pass): walk its own entries only
+                gaussian_ids_sorted, tile_bins = _list_window(gaussian_ids_sorted, tile_bins, id_lo, id_hi, ro.ids_qmask)
+                window_stats["sub_lists"] += 1
+            if proved and num_intersects >= 1:
+                # the depth pass, proven on the host: its image comes from the first pass's fourth channel, and its node
+                # SHARES that pass's per-pixel state and tile statistics (same geometry and opacities: same values)
+                final_Ts, final_idx, tile_kmax = dcache["T"], dcache["idx"], dcache["kmax"]
+                order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
+                L.check(lib.sgn_depth_reuse(img_height, img_width, None, L.ptr(dcache["D"]), L.ptr(final_Ts),
+                                            L.ptr(final_idx), L.ptr(bg_c), L.ptr(out_img), None, None, 0, None, None,
+                                            stream_ptr), "sgn_depth_reuse")
                 depth_stats["reused"] += 1
+                depth_stats["proved_on_host"] += 1
                 _depth_state["unused"] = 0
-            elif accumulate:
-                depth_stats["accumulated"] += 1
-                S.depth_caches[key] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
-                while len(S.depth_caches) > _State.BIN_ENTRIES:
-                    S.depth_caches.popitem(last=False)
-                _depth_state["unused"] += 1
-                if _depth_state["unused"] > 8 and depth_channel == "auto":   # the depth passes stopped coming
-                    _depth_state["want"], _depth_state["unused"] = False, 0
-            elif not hit:
-                S.depth_caches.pop(key, None)  # re-binned without the channel: a stale image must not answer later
+            elif num_intersects < 1:
+                recs = None
+                out_depth = None            # never written (no forward ran): the want_depth branch below returns zeros
+                out_img = torch.ones(img_height, img_width, 3, **f32) * bg_c
+                gaussian_ids_sorted = torch.zeros(0, dtype=torch.int32, device=dev)
+                tile_bins = torch.zeros(tile_bounds[0] * tile_bounds[1], 2, dtype=torch.int32, device=dev)
+                final_Ts = torch.ones(img_height, img_width, **f32)
+                final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
+            elif group_split is not None:
+                # the main pass with the two group accumulations riding on it (sgn_raster_fwd_groups): head = ids below the
+                # split, tail = the others.  The smaller group, if small enough, gets its own compacted list: its backward
+                # walks that list, so its indices are recorded in that list's positions (and its forward walk finishes
+                # there); the other one walks the shared list (with the first group's rows inert).
+                assert win is None and id_range is None and ro.gather and ro.waves_fwd == 2 and block_width == 16
+                if not rows_built:
+                    recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
+                order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
+                n_tiles = tile_bins.shape[0]
+                tile_kmax = torch.empty(n_tiles, 2, dtype=torch.int32, device=dev)
+                split = min(max(int(group_split), 0), n_full)
+                sizes = (split, n_full - split)
+                small = 0 if sizes[0] <= sizes[1] else 1
+                own = small if (list_window_enabled and 0 < sizes[small] < list_window_max_frac * n_full) else -1
+                state = torch.empty(4, img_height, img_width, **f32)          # T_head, T_tail, idx_head, idx_tail
+                kmax = torch.empty(2, n_tiles, 2, dtype=torch.int32, device=dev)
+                groups = []
+                for gi, (lo, hi) in enumerate(((0, split), (split, n_full))):
+                    g_ids, g_bins = (_list_window(gaussian_ids_sorted, tile_bins, lo, hi, ro.ids_qmask) if gi == own
+                                     else (gaussian_ids_sorted, tile_bins))
+                    window_stats["sub_lists"] += int(gi == own)
+                    groups.append(dict(lo=lo, hi=hi, own=gi == own, ids=g_ids, bins=g_bins, T=state[gi],
+                                       idx=state[2 + gi].view(torch.int32), kmax=kmax[gi]))
+                og = groups[own] if own >= 0 else None
+                L.check(lib.sgn_raster_fwd_groups(
+                    img_height, img_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
+                    L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), L.ptr(bg_c),
+                    L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(), rows_built, L.ptr(order),
+                    L.ptr(tile_kmax), L.ptr(depths_c) if accumulate else None, L.ptr(out_depth), split, own,
+                    L.ptr(og["ids"]) if og else None, L.ptr(og["bins"]) if og else None, L.ptr(state), L.ptr(kmax),
+                    ro_ptr, stream_ptr), "sgn_raster_fwd_groups")
+                group_stats["passes"] += 1
+                ctx.groups = groups
+                if accumulate:
+                    depth_stats["accumulated"] += 1
+                    S.depth_caches[key] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
+                    while len(S.depth_caches) > _State.BIN_ENTRIES:
+                        S.depth_caches.popitem(last=False)
+                elif not hit:
+                    S.depth_caches.pop(key, None)
+            else:
+                if not rows_built:
+                    recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
+                # packed forward: the leading tiles of the order whose lists reach adapt_fwd entries get four waves
+                order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
+                tile_kmax = torch.empty(tile_bins.shape[0], 2, dtype=torch.int32, device=dev)   # walk depth, pairs
+                L.check(lib.sgn_raster_fwd(
+                    img_height, img_width, block_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),
+                    L.ptr(xys_c), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)), id_lo, id_hi,
+                    window, L.ptr(bg_c), L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(recs), recs.numel(),
+                    rows_built, L.ptr(order), L.ptr(tile_kmax), L.ptr(depths_c) if accumulate else None,
+                    L.ptr(out_depth), L.ptr(skip_flag), ro_ptr, stream_ptr), "sgn_raster_fwd")
+                if reuse:
+                    L.check(lib.sgn_depth_reuse(img_height, img_width, L.ptr(skip_flag), L.ptr(dcache["D"]),
+                                                L.ptr(dcache["T"]), L.ptr(dcache["idx"]), L.ptr(bg_c), L.ptr(out_img),
+                                                L.ptr(final_Ts), L.ptr(final_idx), tile_kmax.numel(),
+                                                L.ptr(dcache["kmax"]), L.ptr(tile_kmax), stream_ptr), "sgn_depth_reuse")
+                    recs = None                    # the rows were not built if the flag said "reuse": the backward packs them
+                    depth_stats["reused"] += 1
+                    _depth_state["unused"] = 0
+                elif accumulate:
+                    depth_stats["accumulated"] += 1
+                    S.depth_caches[key] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
+                    while len(S.depth_caches) > _State.BIN_ENTRIES:
+                        S.depth_caches.popitem(last=False)
+                    _depth_state["unused"] += 1
+                    if _depth_state["unused"] > 8 and depth_channel == "auto":   # the depth passes stopped coming
+                        _depth_state["want"], _depth_state["unused"] = False, 0
+                elif not hit:
+                    S.depth_caches.pop(key, None)  # re-binned without the channel: a stale image must not answer later
         # (the sink hears of passes that WILL have a backward only: a forward under no_grad — an evaluation image between
         # two training steps — announces nothing; such an announcement used to stay behind and count as a second view of
         # the next step whenever its list happened to land on another address)

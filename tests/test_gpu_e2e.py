@@ -431,3 +431,51 @@ def test_non_finite_gradients_on_uncovered_pixels_do_not_reach_any_gaussian():
     for a, b in zip(*grads):
         assert torch.isfinite(b).all()
         assert rel_l2(b, a) < 1e-5
+
+
+def test_one_call_forward_equals_the_call_by_call_path():
+    """`sgn_rasterize_fwd_all` (one C-ABI call per autograd node, round 5) runs the same kernels in the same order as the
+    sequence the host otherwise drives call by call: list, bins, image, per-pixel state and gradients are BIT-EQUAL
+    (portable exp: no v_exp_f32 in the comparison), the capacity comes from earlier calls of the same shape, and a view
+    that sees more than the capacity falls back to the call-by-call path."""
+    from sgn_rast import _lib as L, ops, scenes, step
+    cam, raw = scenes.make_scene("c1", n_override=6000)
+    cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+    w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+    res = {}
+    with L.options(exact_exp=1):
+        for mode in (False, True):
+            ops.composite_forward = mode
+            ops.clear_binning_cache()
+            ops._S().last_count.clear()
+            try:
+                for it in range(3):                                  # the first call learns the capacity
+                    P = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+                    ops.clear_binning_cache()
+                    before = dict(ops.composite_stats)
+                    out = step.train_step(P, cam, w_img, w_a)
+                torch.cuda.synchronize()
+                node = out.rgb.grad_fn
+                sv = node.saved_tensors
+                res[mode] = (out.rgb.detach().clone(), out.alpha.detach().clone(), sv[0].clone(), sv[1].clone(),
+                             sv[8].clone(), node.tile_kmax.clone(), {k: p.grad.clone() for k, p in P.items()})
+                assert (ops.composite_stats["forwards"] - before["forwards"]) == (1 if mode else 0)
+            finally:
+                ops.composite_forward = True
+    a, b = res[False], res[True]
+    for i in range(6):
+        assert torch.equal(a[i], b[i]), i
+    for k in a[6]:
+        assert rel_l2(b[6][k], a[6][k]) < 1e-5, k                   # (atomics order: not bit-reproducible run to run)
+    # capacity miss: pretend the earlier views saw a tenth of this one
+    S = ops._S()
+    for ck in list(S.last_count):
+        S.last_count[ck] = max(1, S.last_count[ck] // 10)
+    misses = ops.composite_stats["capacity_misses"]
+    P = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+    ops.clear_binning_cache()
+    with L.options(exact_exp=1):
+        out = step.train_step(P, cam, w_img, w_a)
+    torch.cuda.synchronize()
+    assert ops.composite_stats["capacity_misses"] == misses + 1
+    assert torch.equal(out.rgb.detach(), a[0]) and torch.equal(out.rgb.grad_fn.saved_tensors[0], a[2])
