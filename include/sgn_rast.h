@@ -109,6 +109,18 @@ int sgn_project_fwd(int n, const float *means3d, const float *scales, float glob
  * next sync point (see sgn_rast/ops.py: deferred assertion). */
 int sgn_check_unit_quats(int n, const float *quats, float tol, int32_t *flag, sgn_stream_t stream);
 
+/* `project_gaussians` as ONE call (round 5; no upstream counterpart): sgn_check_unit_quats (check_quats != 0: the flag is
+ * copied to flag_pinned — pinned host int32, NULL = pageable — right away), sgn_project_fwd, and — gid_by_rank != NULL —
+ * sgn_depth_rank of the coming binning, all queued on `stream`; only then does the call wait for the flag and report
+ * *quats_bad_host (1: some row failed `norm - 1 < quat_tol`; the host raises upstream's assertion).  rank_ws:
+ * sgn_depth_rank_workspace_bytes(n). */
+int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
+                        const float *viewmat12, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                        int block_width, float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii,
+                        float *conics, float *compensation, int32_t *num_tiles_hit, int check_quats, float quat_tol,
+                        int32_t *flag_dev, int32_t *flag_pinned, int32_t *gid_by_rank, void *rank_ws,
+                        size_t rank_ws_bytes, int sort_rank_mode, int32_t *quats_bad_host, sgn_stream_t stream);
+
 /* _C.project_gaussians_backward (_ProjectGaussians.backward).  v_compensation may be NULL
  * (treated as zeros: the reference discards compensation, sgn_splatfacto.py:860,947); v_depth may be NULL too
  * (zeros: depths took no part in the loss).

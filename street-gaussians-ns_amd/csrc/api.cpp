@@ -70,6 +70,44 @@ int sync_event(hipEvent_t *ev) {          // one untimed event per (thread, devi
 }
 }  // namespace
 
+// sgn_project_fwd_all: `project_gaussians` as ONE call — upstream's quats assertion as a device pass whose flag travels to
+// the host while the projection and (optionally) the depth ranking of the coming binning are already queued; the host
+// waits for the flag last (the "eager" check of sgn_rast/ops.py, which otherwise takes three calls).
+extern "C" __attribute__((visibility("default")))
+int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
+                        const float *viewmat12, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                        int block_width, float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii,
+                        float *conics, float *compensation, int32_t *num_tiles_hit, int check_quats, float quat_tol,
+                        int32_t *flag_dev, int32_t *flag_pinned, int32_t *gid_by_rank, void *rank_ws,
+                        size_t rank_ws_bytes, int sort_rank_mode, int32_t *quats_bad_host, sgn_stream_t stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t ev = nullptr;
+    int32_t pageable = 0;
+    int32_t *dst = flag_pinned ? flag_pinned : &pageable;
+    if (check_quats) {
+        if (!flag_dev || !quats_bad_host) { sgn_set_error("sgn_project_fwd_all: check_quats needs flag_dev and quats_bad_host"); return -1; }
+        int rc = sgn_check_unit_quats(n, quats, quat_tol, flag_dev, stream);
+        if (rc) return rc;
+        hipError_t e = hipMemcpyAsync(dst, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && sync_event(&ev) != 0) e = hipErrorUnknown;
+        if (e == hipSuccess) e = hipEventRecord(ev, s);
+        if (e != hipSuccess) { sgn_set_error("sgn_project_fwd_all: flag read-back: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    int rc = sgn_project_fwd(n, means3d, scales, glob_scale, quats, viewmat12, fx, fy, cx, cy, img_h, img_w, block_width,
+                             clip_thresh, cov3d, xys, depths, radii, conics, compensation, num_tiles_hit, stream);
+    if (rc) return rc;
+    if (gid_by_rank != nullptr && n > 0) {
+        rc = sgn_depth_rank(n, depths, radii, gid_by_rank, rank_ws, rank_ws_bytes, sort_rank_mode, stream);
+        if (rc) return rc;
+    }
+    if (check_quats) {
+        const hipError_t e = hipEventSynchronize(ev);      // the projection (and the ranking) are queued: wait now
+        if (e != hipSuccess) { sgn_set_error("sgn_project_fwd_all: %s", hipGetErrorString(e)); return (int)e; }
+        *quats_bad_host = *dst;
+    }
+    return 0;
+}
+
 extern "C" __attribute__((visibility("default")))
 size_t sgn_rasterize_arena_bytes(int n, int64_t isect_capacity) {
     const size_t nn = (size_t)(n > 0 ? n : 1);

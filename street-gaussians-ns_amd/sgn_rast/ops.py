@@ -389,11 +389,45 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
     conics = torch.empty(n, 3, **f32)
     compensation = torch.empty(n, **f32)
     num_tiles_hit = torch.empty(n, **i32)
-    L.check(L.load().sgn_project_fwd(
-        n, L.ptr(means3d_c), L.ptr(scales_c), float(glob_scale), L.ptr(quats_c), L.ptr(viewmat_c),
-        float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width), int(block_width),
-        float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
-        L.ptr(compensation), L.ptr(num_tiles_hit), L.stream_ptr()), "sgn_project_fwd")
+    plan = getattr(_call_state, "project_plan", None)
+    _call_state.project_plan = None
+    if plan is not None:
+        # ONE library call (sgn_project_fwd_all, round 5): the quats check's device pass, the projection and the early
+        # depth ranking queued together, the wait for the check's flag last
+        lib = L.load()
+        S = _S()
+        flag = torch.empty(1, **i32) if plan["check"] else None
+        if plan["check"] and S.eager_side is None:
+            S.eager_side = [torch.empty(8, dtype=torch.int32).pin_memory(), 0]
+        slot = None
+        if plan["check"]:
+            ring = S.eager_side
+            slot = ring[0][ring[1] % 8:ring[1] % 8 + 1]
+            ring[1] += 1
+        gid = ws = None
+        if plan["rank"]:
+            gid = torch.empty(n, **i32)
+            ws = L.workspace(lib.sgn_depth_rank_workspace_bytes(n), dev)
+        bad = C.c_int32(0)
+        L.check(lib.sgn_project_fwd_all(
+            n, L.ptr(means3d_c), L.ptr(scales_c), float(glob_scale), L.ptr(quats_c), L.ptr(viewmat_c),
+            float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width), int(block_width),
+            float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
+            L.ptr(compensation), L.ptr(num_tiles_hit), int(plan["check"]), 1e-6, L.ptr(flag),
+            slot.data_ptr() if slot is not None else None, L.ptr(gid), L.ptr(ws), ws.numel() if ws is not None else 0,
+            L.sort_rank_mode(), C.byref(bad), L.stream_ptr()), "sgn_project_fwd_all")
+        plan["done"], plan["bad"] = True, int(bad.value)
+        if gid is not None:
+            d, r = depths.detach(), radii.detach()
+            S.early["entry"] = dict(key=(d.data_ptr(), d._version, r.data_ptr(), r._version, n, L.stream_handle()),
+                                    keep=(d, r), gid=gid, done=None)
+            early_rank_stats["started"] += 1
+    else:
+        L.check(L.load().sgn_project_fwd(
+            n, L.ptr(means3d_c), L.ptr(scales_c), float(glob_scale), L.ptr(quats_c), L.ptr(viewmat_c),
+            float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width), int(block_width),
+            float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
+            L.ptr(compensation), L.ptr(num_tiles_hit), L.stream_ptr()), "sgn_project_fwd")
     ctx.glob_scale, ctx.fx, ctx.fy = float(glob_scale), float(fx), float(fy)
     ctx.mark_non_differentiable(radii, num_tiles_hit)
     # seven outputs, two or three of which the loss ever reaches: without this autograd materialises a zero tensor (an
@@ -505,21 +539,29 @@ early_rank_stream = os.environ.get("SGN_EARLY_RANK_STREAM", "main")
 early_rank_stats = {"started": 0, "used": 0}
 
 
-def _start_early_rank(depths: torch.Tensor, radii: torch.Tensor) -> None:
-    n = depths.shape[0]
+def _early_rank_wanted(n: int, is_cuda: bool) -> bool:
+    """Speculation policy of the early depth rank (see above); keeps the miss / pause bookkeeping."""
     if early_rank == "off" or (early_rank == "auto" and quat_check not in ("eager", "eager-upstream")):
-        return
-    if n == 0 or not depths.is_cuda or not tile_culling_enabled:
-        return
+        return False
+    if n == 0 or not is_cuda or not tile_culling_enabled:
+        return False
     _early = _S().early
     if _early["pause"] > 0:
         _early["pause"] -= 1
-        return
+        return False
     if _early["entry"] is not None:                 # the previous ranking was never used
         _early["misses"] += 1
         if _early["misses"] >= 3:
             _early["misses"], _early["pause"], _early["entry"] = 0, 200, None
-            return
+            return False
+    return True
+
+
+def _start_early_rank(depths: torch.Tensor, radii: torch.Tensor) -> None:
+    n = depths.shape[0]
+    if not _early_rank_wanted(n, depths.is_cuda):
+        return
+    _early = _S().early
     lib = L.load()
     d, r = depths.detach(), radii.detach()
     key = (d.data_ptr(), d._version, r.data_ptr(), r._version, n, L.stream_handle())
@@ -570,7 +612,12 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     Returns ``(xys, depths, radii, conics, compensation, num_tiles_hit, cov3d)``;
     ``viewmat`` is the world->camera matrix ([3,4] or [4,4]; only rows 0-2 are read)."""
     assert block_width > 1 and block_width <= 16, "block_width must be between 2 and 16"
-    token = _check_quats(quats)
+    plan = None
+    if (composite_forward and quat_check in ("eager", "off") and quats.is_cuda and means3d.is_cuda
+            and early_rank_stream == "main" and means3d.shape[-2] >= 1 and means3d.shape[-1] == 3):
+        plan = dict(check=quat_check == "eager", rank=_early_rank_wanted(means3d.shape[-2], True), done=False, bad=0)
+    token = _check_quats(quats) if plan is None else None
+    _call_state.project_plan = plan
     ls_leaves = x = None
     if _proofs_on(activation_proofs) and scales.is_cuda:
         ls_leaves = proofs.exp_leaves(scales)
@@ -584,6 +631,9 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
         out = _ProjectGaussians.apply(means3d.contiguous(), scales.contiguous(), glob_scale, quats.contiguous(),
                                       viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
                                       clip_thresh)
+    if plan is not None and plan["done"]:
+        assert plan["bad"] == 0, "quats must be normalized"          # (upstream raises from this very call)
+        return out
     _start_early_rank(out[1], out[2])  # depth ranking queued behind the projection, before the host waits
     _finish_quat_check(token)          # eager mode: the projection is already queued while the host waits here
     return out
@@ -805,7 +855,8 @@ def _bin_finish(st):
     cap, spec_ids = 0, None
     S = _S()
     _last_count = S.last_count
-    if speculative_binning and _last_count.get(key, 0) > 0:
+    skip_spec, S.no_speculation_once = getattr(S, "no_speculation_once", False), False
+    if speculative_binning and _last_count.get(key, 0) > 0 and not skip_spec:
         cap = min(int(_last_count[key] * _SPEC_MARGIN) + 1024, (1 << 31) - 1)
         spec_ids = run(cap, C.c_void_p(st["cum_r"].data_ptr() + 4 * (n - 1)))
     st["done"].synchronize()
@@ -1192,17 +1243,18 @@ def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colo
         4 * scratch.numel() if scratch is not None else 0, L.ptr(arena), arena.numel(), pinned[0:1].data_ptr(),
         L.ptr(walk_stat), pinned[7:8].data_ptr() if walk_stat is not None else None, C.byref(n_host),
         L.sort_rank_mode(), ro_ptr, stream_ptr)
-    binning_stats["binnings"] += 1
     if walk_stat is not None and rc in (0, _E_CAPACITY):
         S.walked_permille = quadrant_mask_stats["walked_permille"] = int(pinned[7])
     count = int(n_host.value)
     if rc == _E_CAPACITY:
-        # the view sees more than 1.3x the recent peak: remember the count and let the call-by-call path bin again
-        S.last_count[ckey] = max(count, int(0.9 * last))
+        # the view sees more than 1.3x the recent peak: the call-by-call path bins again, WITHOUT speculating (its plain
+        # form with the real count, exactly what its own miss does; it also records the new count)
         binning_stats["speculative_misses"] += 1
         composite_stats["capacity_misses"] += 1
+        S.no_speculation_once = True
         return None
     L.check(rc, "sgn_rasterize_fwd_all")
+    binning_stats["binnings"] += 1
     S.last_count[ckey] = max(count, int(0.9 * last))
     binning_stats["speculative_hits"] += int(count >= 1)
     composite_stats["forwards"] += 1

@@ -177,7 +177,8 @@ def test_binning_cache_reuse_and_invalidation():
         return orig(*a, **k)
 
     ops._bin_prepare_async = counting
-    try:
+    ops.composite_forward = False        # (this test counts the call-by-call path's prepares; the one-call forward's use
+    try:                                 # of the cache is pinned by test_one_call_forward_equals_the_call_by_call_path)
         ops.clear_binning_cache()
         with torch.no_grad():
             out = step.render(P, cam, with_depth=True)
@@ -216,6 +217,7 @@ def test_binning_cache_reuse_and_invalidation():
             assert torch.equal(other, ref) and ops._bin_pending["key"] is None
     finally:
         ops._bin_prepare_async = orig
+        ops.composite_forward = True
         ops.binning_cache_enabled = True
         ops.clear_binning_cache()
 
@@ -436,46 +438,58 @@ def test_non_finite_gradients_on_uncovered_pixels_do_not_reach_any_gaussian():
 def test_one_call_forward_equals_the_call_by_call_path():
     """`sgn_rasterize_fwd_all` (one C-ABI call per autograd node, round 5) runs the same kernels in the same order as the
     sequence the host otherwise drives call by call: list, bins, image, per-pixel state and gradients are BIT-EQUAL
-    (portable exp: no v_exp_f32 in the comparison), the capacity comes from earlier calls of the same shape, and a view
-    that sees more than the capacity falls back to the call-by-call path."""
+    (portable exp: no v_exp_f32 in the comparison), the capacity comes from earlier calls of the same shape, its binning
+    lands in the cache like any other, and a view that sees more than the capacity falls back to the call-by-call path."""
     from sgn_rast import _lib as L, ops, scenes, step
     cam, raw = scenes.make_scene("c1", n_override=6000)
     cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
     w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+
+    def one(P):
+        for p in P.values():
+            p.grad = None
+        ops.clear_binning_cache()
+        out = step.render(P, cam, caller_syncs=False)
+        node = out.rgb.grad_fn
+        sv = node.saved_tensors                                     # (before the backward frees them)
+        keep = (out.rgb.detach().clone(), out.alpha.detach().clone(), sv[0].clone(), sv[1].clone(), sv[7].clone(),
+                sv[8].clone(), node.tile_kmax.clone())
+        ((out.rgb * w_img).sum() + (out.alpha * w_a).sum()).backward()
+        return out, keep + ({k: p.grad.clone() for k, p in P.items()},)
+
     res = {}
     with L.options(exact_exp=1):
         for mode in (False, True):
             ops.composite_forward = mode
-            ops.clear_binning_cache()
             ops._S().last_count.clear()
             try:
                 for it in range(3):                                  # the first call learns the capacity
                     P = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
-                    ops.clear_binning_cache()
                     before = dict(ops.composite_stats)
-                    out = step.train_step(P, cam, w_img, w_a)
-                torch.cuda.synchronize()
-                node = out.rgb.grad_fn
-                sv = node.saved_tensors
-                res[mode] = (out.rgb.detach().clone(), out.alpha.detach().clone(), sv[0].clone(), sv[1].clone(),
-                             sv[8].clone(), node.tile_kmax.clone(), {k: p.grad.clone() for k, p in P.items()})
+                    out, res[mode] = one(P)
                 assert (ops.composite_stats["forwards"] - before["forwards"]) == (1 if mode else 0)
+                if mode:                                             # the same tensors again: served from the cache
+                    n_bin = ops.binning_stats["binnings"]
+                    with torch.no_grad():
+                        again = ops.rasterize_gaussians(out.xys, out.depths, out.radii, out.conics, out.num_tiles_hit,
+                                                        out.rgbs, out.opacities, cam.height, cam.width, 16,
+                                                        torch.zeros(3, device=DEV))
+                    assert ops.binning_stats["binnings"] == n_bin and torch.equal(again, res[mode][0])
             finally:
                 ops.composite_forward = True
-    a, b = res[False], res[True]
-    for i in range(6):
-        assert torch.equal(a[i], b[i]), i
-    for k in a[6]:
-        assert rel_l2(b[6][k], a[6][k]) < 1e-5, k                   # (atomics order: not bit-reproducible run to run)
-    # capacity miss: pretend the earlier views saw a tenth of this one
-    S = ops._S()
-    for ck in list(S.last_count):
-        S.last_count[ck] = max(1, S.last_count[ck] // 10)
-    misses = ops.composite_stats["capacity_misses"]
-    P = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
-    ops.clear_binning_cache()
-    with L.options(exact_exp=1):
-        out = step.train_step(P, cam, w_img, w_a)
-    torch.cuda.synchronize()
-    assert ops.composite_stats["capacity_misses"] == misses + 1
-    assert torch.equal(out.rgb.detach(), a[0]) and torch.equal(out.rgb.grad_fn.saved_tensors[0], a[2])
+        torch.cuda.synchronize()
+        a, b = res[False], res[True]
+        for i in range(7):
+            assert torch.equal(a[i], b[i]), i
+        for k in a[7]:
+            assert rel_l2(b[7][k], a[7][k]) < 1e-5, k               # (atomics order: not bit-reproducible run to run)
+        # capacity miss: pretend the earlier views saw a tenth of this one
+        S = ops._S()
+        for ck in list(S.last_count):
+            S.last_count[ck] = max(1, S.last_count[ck] // 10)
+        misses, hits = ops.composite_stats["capacity_misses"], ops.binning_stats["speculative_hits"]
+        P = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+        out, c = one(P)
+        torch.cuda.synchronize()
+        assert ops.composite_stats["capacity_misses"] == misses + 1 and ops.binning_stats["speculative_hits"] == hits
+        assert torch.equal(c[0], a[0]) and torch.equal(c[2], a[2]) and torch.equal(c[3], a[3])
