@@ -475,6 +475,9 @@ def test_one_call_forward_equals_the_call_by_call_path():
                                                         out.rgbs, out.opacities, cam.height, cam.width, 16,
                                                         torch.zeros(3, device=DEV))
                     assert ops.binning_stats["binnings"] == n_bin and torch.equal(again, res[mode][0])
+                    # (a second pass over one geometry teaches the "auto" depth-channel policy to accumulate the channel
+                    # from the next step on, which takes the call-by-call path: put the policy back)
+                    ops._depth_state.update(want=False, unused=0)
             finally:
                 ops.composite_forward = True
         torch.cuda.synchronize()
