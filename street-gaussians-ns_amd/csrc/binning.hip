@@ -782,19 +782,12 @@ void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const
                              int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode);
 void sgn_sort_pairs16_launch(uint32_t n, int end_bit, const uint16_t *kin, const int32_t *vin, uint16_t *kout,
                              int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode);
+void sgn_sort_depth_rank_launch(uint32_t n, const float *depths, const int32_t *radii, uint32_t *kout, int32_t *vout,
+                                void *ws, hipStream_t s, int rank_mode);
 
 // The depth ranking needs depths and radii only, i.e. it can be queued the moment the projection is: the caller's
 // colour evaluation and activations then run BEHIND ~80 us of device work instead of in front of an idle GPU (the
 // drop-in path loses its lead over the device at upstream's eager argument check / the reference's `radii.sum() == 0`).
-__global__ __launch_bounds__(256) void depth_keys_kernel(int n, const float *__restrict__ depths,
-                                                         const int32_t *__restrict__ radii,
-                                                         uint32_t *__restrict__ dkeys, int32_t *__restrict__ dvals) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    dkeys[i] = radii[i] > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;   // as bin_count_kernel writes them
-    dvals[i] = i;
-}
-
 SGN_EXPORT size_t sgn_depth_rank_workspace_bytes(int n) {
     const size_t nn = (size_t)(n > 0 ? n : 1);
     return 3 * al256(nn * 4) + sgn_sort_pairs32_ws_bytes(n);
@@ -811,9 +804,9 @@ SGN_EXPORT int sgn_depth_rank(int n, const float *depths, const int32_t *radii, 
     uint32_t *dkeys = (uint32_t *)p; p += al256((size_t)n * 4);
     int32_t *dvals = (int32_t *)p;   p += al256((size_t)n * 4);
     uint32_t *dkeys_sorted = (uint32_t *)p; p += al256((size_t)n * 4);
-    auto chain = [&](hipStream_t st) {      // 13 launches: keys, then four passes of histogram / scan / scatter
-        hipLaunchKernelGGL(depth_keys_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, st, n, depths, radii, dkeys, dvals);
-        sgn_sort_pairs32_launch((uint32_t)n, 32, dkeys, dvals, dkeys_sorted, gid_by_rank, p, st, nullptr, sort_rank_mode);
+    auto chain = [&](hipStream_t st) {      // 12 launches: four passes of histogram / scan / scatter; the first pass
+        (void)dkeys; (void)dvals;           // reads its keys from (depths, radii) itself (round 5: no key kernel)
+        sgn_sort_depth_rank_launch((uint32_t)n, depths, radii, dkeys_sorted, gid_by_rank, p, st, sort_rank_mode);
     };
     // the same chain on the same buffers as an earlier call (steady state of a training loop): replayed as ONE graph
     // launch (SGN_HIP_GRAPHS=1; sgn_common.h)

@@ -53,11 +53,20 @@ __device__ __forceinline__ unsigned digit_of(K key, int shift, unsigned mask) {
     return (unsigned)(key >> shift) & mask;
 }
 
-template <typename K, int BITS, int RS_IPT>
+// FROM_DEPTH (round 5): the FIRST pass of the depth ranking reads its keys straight from the projection's outputs — key i
+// = bits of depths[i] for a visible Gaussian (radii[i] > 0; positive floats order like their bit patterns), all ones for
+// a culled one, payload i — instead of from a key / index pair a separate kernel wrote (depth_keys_kernel: one launch,
+// 8 MB written and 12 MB read again per million Gaussians).  `keys` then points at depths, `vals_in` at radii.
+__device__ __forceinline__ uint32_t depth_key(const void *depths, const void *radii, uint32_t i) {
+    return reinterpret_cast<const int32_t *>(radii)[i] > 0 ? reinterpret_cast<const uint32_t *>(depths)[i] : 0xFFFFFFFFu;
+}
+
+template <typename K, int BITS, int RS_IPT, bool FROM_DEPTH = false>
 __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(uint32_t n, const K *__restrict__ keys, int shift,
                                                              unsigned dmask, uint32_t nblk,
                                                              uint32_t *__restrict__ table,
-                                                             const int32_t *__restrict__ n_dev) {
+                                                             const int32_t *__restrict__ n_dev,
+                                                             const int32_t *__restrict__ radii = nullptr) {
     constexpr int NB = 1 << BITS;
     if (n_dev) n = min(n, (uint32_t)max(*n_dev, 0));   // speculative launch: n is the capacity, *n_dev the count
     constexpr int RS_TILE = RS_THREADS * RS_IPT;
@@ -65,6 +74,23 @@ __global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(uint32_t n, const K
     for (int d = threadIdx.x; d < NB; d += RS_THREADS) hist[d] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE;
+    if constexpr (FROM_DEPTH) {
+        static_assert(sizeof(K) == 4, "depth keys are 32-bit");
+        uint32_t kd[RS_IPT];
+#pragma unroll
+        for (int k = 0; k < RS_IPT; ++k) {                  // all loads first (two per key, coalesced)
+            const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+            kd[k] = (i < n) ? depth_key(keys, radii, i) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < RS_IPT; ++k) {
+            const uint32_t i = base + k * RS_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&hist[digit_of<uint32_t>(kd[k], shift, dmask)], 1u);
+        }
+        __syncthreads();
+        for (int d = threadIdx.x; d < NB; d += RS_THREADS) table[(size_t)d * nblk + blockIdx.x] = hist[d];
+        return;
+    }
     // Which key a thread counts does not matter for a histogram, so a thread takes 16-byte vectors of consecutive keys
     // (8 sixteen-bit tile ids per load instead of eight 2-byte loads: the 16-bit histogram of the 8.3 M-pair tile sort
     // took 11.2 us for 16.6 MB).  All loads are issued before the first LDS atomic.
@@ -168,7 +194,7 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(uint32_t nblk, uint
     if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-template <typename K, bool HAS_VAL, int BITS, int RS_IPT, bool ATOMIC>
+template <typename K, bool HAS_VAL, int BITS, int RS_IPT, bool ATOMIC, bool FROM_DEPTH = false>
 __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     uint32_t n, const K *__restrict__ keys_in, const int32_t *__restrict__ vals_in, K *__restrict__ keys_out,
     int32_t *__restrict__ vals_out, int shift, unsigned dmask, uint32_t nblk, const uint32_t *__restrict__ table,
@@ -203,8 +229,13 @@ __global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(
     for (int r = 0; r < RS_IPT; ++r) {
         const uint32_t li = wave * RS_WAVE_ITEMS + r * 64 + lane;  // index inside the tile
         const bool valid = li < tile_cnt;
-        key[r] = valid ? keys_in[tile_base + li] : (K)~(K)0;
-        if constexpr (HAS_VAL) val[r] = valid ? vals_in[tile_base + li] : 0;
+        if constexpr (FROM_DEPTH) {           // keys_in = depths, vals_in = radii (see depth_key)
+            key[r] = valid ? (K)depth_key(keys_in, vals_in, tile_base + li) : (K)~(K)0;
+            if constexpr (HAS_VAL) val[r] = (int32_t)(tile_base + li);
+        } else {
+            key[r] = valid ? keys_in[tile_base + li] : (K)~(K)0;
+            if constexpr (HAS_VAL) val[r] = valid ? vals_in[tile_base + li] : 0;
+        }
     }
     // the digit totals and this tile's column of the scanned table do not depend on the ranking: requested here, with
     // the keys, instead of after the ranking barrier (a strided global read per thread: ~2 us on the critical path of
@@ -328,7 +359,7 @@ size_t sort_ws_bytes(int64_t n) {
 // ping-pong LSD passes; the last pass lands in keys_out / vals_out
 template <typename K, bool HAS_VAL, int BITS, int RS_IPT, bool ATOMIC>
 void sort_launch_ipt(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const int32_t *vals_in, K *keys_out,
-                     int32_t *vals_out, void *ws, hipStream_t s, const int32_t *n_dev) {
+                     int32_t *vals_out, void *ws, hipStream_t s, const int32_t *n_dev, bool from_depth = false) {
     constexpr int NB = 1 << BITS;
     const uint32_t nblk = (uint32_t)sgn_cdiv(n, RS_THREADS * RS_IPT);
     char *p = (char *)ws;
@@ -349,11 +380,23 @@ void sort_launch_ipt(uint32_t n, int begin_bit, int end_bit, const K *keys_in, c
         const bool to_out = ((npass - 1 - pass) % 2) == 0;
         K *dst_k = to_out ? keys_out : alt_keys;
         int32_t *dst_v = to_out ? vals_out : alt_vals;
+        bool depth_pass = false;
+        if constexpr (sizeof(K) == 4 && HAS_VAL) depth_pass = from_depth && pass == 0;
+        if (depth_pass) {
+            if constexpr (sizeof(K) == 4 && HAS_VAL) {   // keys_in = depths, vals_in = radii
+                hipLaunchKernelGGL((rs_hist_kernel<K, BITS, RS_IPT, true>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, shift,
+                                   dmask, nblk, table, n_dev, src_v);
+                hipLaunchKernelGGL(rs_scan_kernel, dim3(NB), dim3(RS_THREADS), 0, s, nblk, table, totals);
+                hipLaunchKernelGGL((rs_scatter_kernel<K, HAS_VAL, BITS, RS_IPT, ATOMIC, true>), dim3(nblk), dim3(RS_THREADS), 0,
+                                   s, n, src_k, src_v, dst_k, dst_v, shift, dmask, nblk, table, totals, n_dev);
+            }
+        } else {
         hipLaunchKernelGGL((rs_hist_kernel<K, BITS, RS_IPT>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, shift, dmask,
-                           nblk, table, n_dev);
+                           nblk, table, n_dev, (const int32_t *)nullptr);
         hipLaunchKernelGGL(rs_scan_kernel, dim3(NB), dim3(RS_THREADS), 0, s, nblk, table, totals);
         hipLaunchKernelGGL((rs_scatter_kernel<K, HAS_VAL, BITS, RS_IPT, ATOMIC>), dim3(nblk), dim3(RS_THREADS), 0, s, n, src_k, src_v,
                            dst_k, dst_v, shift, dmask, nblk, table, totals, n_dev);
+        }
         src_k = dst_k;
         src_v = dst_v;
     }
@@ -363,12 +406,14 @@ void sort_launch_ipt(uint32_t n, int begin_bit, int end_bit, const K *keys_in, c
 // device with sgn_sort_selftest, or forces it for an A/B)
 template <typename K, bool HAS_VAL, int BITS>
 void sort_launch(uint32_t n, int begin_bit, int end_bit, const K *keys_in, const int32_t *vals_in, K *keys_out,
-                 int32_t *vals_out, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode, int force_ipt = 0) {
+                 int32_t *vals_out, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode, int force_ipt = 0,
+                 bool from_depth = false) {
     // n_dev != nullptr: n is the CAPACITY the launch is sized for, the element count is read on the device
     const bool atomic = rank_mode != 0;
     const int ipt = force_ipt ? force_ipt : rs_pick_ipt(n);
 #define SGN_RS_GO(IPT, AT) \
-    sort_launch_ipt<K, HAS_VAL, BITS, IPT, AT>(n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out, ws, s, n_dev)
+    sort_launch_ipt<K, HAS_VAL, BITS, IPT, AT>(n, begin_bit, end_bit, keys_in, vals_in, keys_out, vals_out, ws, s, n_dev, \
+                                               from_depth)
     if (ipt == RS_IPT_SMALL) { if (atomic) SGN_RS_GO(RS_IPT_SMALL, true); else SGN_RS_GO(RS_IPT_SMALL, false); }
     else                     { if (atomic) SGN_RS_GO(RS_IPT_LARGE, true); else SGN_RS_GO(RS_IPT_LARGE, false); }
 #undef SGN_RS_GO
@@ -414,6 +459,13 @@ size_t sgn_sort_pairs32_ws_bytes(int64_t n) { return sort_ws_bytes<uint32_t, tru
 void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const int32_t *vin, uint32_t *kout,
                              int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode) {
     sort_launch<uint32_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s, n_dev, rank_mode);
+}
+
+// the depth ranking: keys read from (depths, radii) by the first pass, payload = index (see FROM_DEPTH)
+void sgn_sort_depth_rank_launch(uint32_t n, const float *depths, const int32_t *radii, uint32_t *kout, int32_t *vout,
+                                void *ws, hipStream_t s, int rank_mode) {
+    sort_launch<uint32_t, true, 8>(n, 0, 32, (const uint32_t *)depths, radii, kout, vout, ws, s, nullptr, rank_mode, 0,
+                                   true);
 }
 
 // 16-bit keys (tile ids of images with <= 65536 tiles); same workspace layout and size as the 32-bit entry

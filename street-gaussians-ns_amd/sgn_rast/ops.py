@@ -1627,6 +1627,26 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
         raise ValueError("xys must have dimensions (N, 2)")
     if colors.ndimension() != 2:
         raise ValueError("colors must have dimensions (N, D)")
+    if colors.shape[-1] != 3:
+        # upstream's N-D path (`_RasterizeGaussians` dispatches D != 3 to nd_rasterize_forward).  The reference never
+        # takes it (sgn_splatfacto.py:988 repeats depth x3 to stay on three channels); served here by the 3-channel
+        # kernels, three channels per pass: the passes share ONE binning (the cache is keyed on the geometry tensors),
+        # the per-pixel walk is the same for every channel, so each output channel equals what an N-D kernel composites.
+        d = colors.shape[-1]
+        if d < 1:
+            raise ValueError("colors must have at least one channel")
+        imgs, alpha = [], None
+        for c0 in range(0, d, 3):
+            w = min(3, d - c0)
+            chunk, bg3 = colors[:, c0:c0 + w], background[c0:c0 + w]
+            if w < 3:
+                chunk = torch.cat([chunk, chunk.new_zeros(chunk.shape[0], 3 - w)], dim=1)
+                bg3 = torch.cat([bg3, bg3.new_zeros(3 - w)])
+            img, alpha = rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, chunk, opacity, img_height,
+                                             img_width, block_width, bg3, True)
+            imgs.append(img[..., :w])
+        out_img = torch.cat(imgs, dim=-1)
+        return (out_img, alpha) if return_alpha else out_img
     logits, pre = (), None
     if _proofs_on(activation_proofs) and opacity.is_cuda and colors.shape[-1] == 3:
         logits, pre = proofs.sigmoid_leaves(opacity) or (), proofs.clamp_pre(colors)

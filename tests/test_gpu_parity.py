@@ -388,6 +388,49 @@ def test_uint8_colors_and_single_output(hip, c_oracle):
     assert float((img.cpu() - exp_img).abs().mean()) < 1e-6
 
 
+@pytest.mark.parametrize("channels", [1, 2, 5, 7])
+def test_n_channel_colours_match_the_channel_generic_oracle(hip, c_oracle, torch_oracle, channels):
+    """upstream's N-D rasterize path (D != 3): image, alpha and the gradients of every input against the channel-generic
+    pure-PyTorch oracle; served by the 3-channel kernels three channels at a time over ONE binning."""
+    from sgn_rast import ops
+    cam, P = small_scene(n=1200)
+    R = _raster_inputs(c_oracle, cam, P)
+    g = torch.Generator().manual_seed(channels)
+    cols = torch.rand(R["xys"].shape[0], channels, generator=g)
+    bg = torch.rand(channels, generator=g)
+    w_img = torch.rand(cam.height, cam.width, channels, generator=g)
+    w_a = torch.rand(cam.height, cam.width, generator=g)
+
+    def run(fn, dev):
+        leaves = [R[k].to(dev).clone().requires_grad_(True) for k in ("xys", "conics")] + [
+            cols.to(dev).clone().requires_grad_(True), R["opac"].to(dev).clone().requires_grad_(True)]
+        img, alpha = fn(leaves[0], R["depths"].to(dev), R["radii"].to(dev), leaves[1], R["nth"].to(dev), leaves[2],
+                        leaves[3], cam.height, cam.width, 16, bg.to(dev), True)
+        ((img * w_img.to(dev)).sum() + (alpha * w_a.to(dev)).sum()).backward()
+        return img.detach().cpu(), alpha.detach().cpu(), [l.grad.cpu() for l in leaves]
+    ops.clear_binning_cache()
+    b0 = ops.binning_stats["binnings"]
+    ops.set_alpha_clamp_bwd(0.999)              # autograd through the oracle's forward clamps where the forward does
+    try:
+        got = run(hip.rasterize_gaussians, DEV)
+    finally:
+        ops.set_alpha_clamp_bwd(ops.UPSTREAM_ALPHA_CLAMP_BWD)
+    assert ops.binning_stats["binnings"] == b0 + 1                  # every 3-channel pass after the first reuses the list
+    exp = run(torch_oracle.rasterize_gaussians, "cpu")
+    assert got[0].shape == (cam.height, cam.width, channels)
+    assert float((got[0] - exp[0]).abs().mean()) < 1e-6 and float((got[1] - exp[1]).abs().mean()) < 1e-6
+    for a, b in zip(got[2], exp[2]):
+        assert rel_l2(a, b) < 1e-4
+    # a single output without alpha, and a background of the wrong length is refused like upstream
+    img = hip.rasterize_gaussians(R["xys"].to(DEV), R["depths"].to(DEV), R["radii"].to(DEV), R["conics"].to(DEV),
+                                  R["nth"].to(DEV), cols.to(DEV), R["opac"].to(DEV), cam.height, cam.width, 16, bg.to(DEV))
+    assert isinstance(img, torch.Tensor) and torch.equal(img.cpu(), got[0])
+    with pytest.raises(AssertionError):
+        hip.rasterize_gaussians(R["xys"].to(DEV), R["depths"].to(DEV), R["radii"].to(DEV), R["conics"].to(DEV),
+                                R["nth"].to(DEV), cols.to(DEV), R["opac"].to(DEV), cam.height, cam.width, 16,
+                                torch.zeros(3, device=DEV))
+
+
 def test_tile_order_is_a_permutation_longest_first_and_changes_nothing(hip):
     """sgn_tile_order: a permutation of the tiles, non-increasing in half-octave length class; rendering with and
     without it gives bit-identical images (forward) and equal gradients."""

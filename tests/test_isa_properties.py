@@ -131,7 +131,7 @@ def test_streaming_kernels_issue_their_loads_before_the_first_lds_write(tmp_path
     # the grid-stride loop prefetches the NEXT span: a second batch of twelve float4 loads after the LDS writes
     assert fwd.count("global_load_dwordx4") >= 24 and "s_cbranch" in fwd
     rs = _kernels(_asm(tmp_path_factory, "radix_sort"))
-    scat = next(t for k, t in rs.items() if "rs_scatter_kernelIjLb1ELi8ELi16ELb1E" in k)   # ATOMIC = true instantiation
+    scat = next(t for k, t in rs.items() if "rs_scatter_kernelIjLb1ELi8ELi16ELb1ELb0E" in k)   # ATOMIC = true instantiation
     first_wait = scat.index("s_waitcnt vmcnt(0)")
     # 16 keys + 16 values + the digit total and the scanned-table column of the thread's digit: all in flight before the
     # ranking starts (the last two used to be requested after the ranking barrier)
@@ -143,5 +143,5 @@ def test_streaming_kernels_issue_their_loads_before_the_first_lds_write(tmp_path
     # ranking: one returning LDS atomic per key (16 keys per thread in this instantiation), no ballot-match code
     assert scat.count("ds_add_rtn_u32") == 16 and "v_bitop3_b32" not in scat
     # ... and the documented ballot-match ranking is compiled next to it (what runs until sgn_sort_selftest has passed)
-    ballot = next(t for k, t in rs.items() if "rs_scatter_kernelIjLb1ELi8ELi16ELb0E" in k)
+    ballot = next(t for k, t in rs.items() if "rs_scatter_kernelIjLb1ELi8ELi16ELb0ELb0E" in k)
     assert "ds_add_rtn_u32" not in ballot and "v_bitop3_b32" in ballot and "v_mbcnt_hi_u32_b32" in ballot
