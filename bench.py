@@ -863,7 +863,7 @@ def main():
             alg_step = {"project_fwd": 100 * n_gauss, "project_bwd": 188 * n_gauss, "sh_fwd": 216 * n_gauss,
                         "sh_bwd": 216 * n_gauss, "scan": 16 * n_gauss,
                         "map_isect": (76 + 40) * n_gauss + 6 * Ic,                      # count pass + emission
-                        "sort": (16 + 4 * 20) * n_gauss + 2 * (2 + 12) * Ic,            # depth rank + tile sort
+                        "sort": (24 + 3 * 20) * n_gauss + 2 * (2 + 12) * Ic,            # depth rank + tile sort
                         "tile_bins": 2 * Ic, "pack_records": 88 * n_gauss, "unpack_grads": 84 * n_gauss,
                         "raster_fwd": 40 * Wk + 20 * n_pix, "raster_bwd": 112 * Wk + 24 * n_pix}
             per_kernel = {}

@@ -97,7 +97,11 @@ def main(tag):
         bench = json.loads(open(bench_file).read().strip().splitlines()[-1]) if os.path.exists(bench_file) else None
         W["workload"] = bench["config"]["workload"] if bench else wkey
         pairs = ((bench or {}).get("roofline", {}).get("walked") or {}).get("quadrant_pairs_evaluated_fwd")
-        for name, key in RASTER_KEYS:
+        # the per-kernel roofline entries bench.py replays belong to the benchmark scene only: there ONE kernel instance
+        # serves each raster slot.  On the other workloads a slot spans several instances (short- and long-walk halves of
+        # the backward running concurrently; main pass, window passes and group walks of the scene graph), so they keep
+        # the per-instance `table` above and nothing that could be mistaken for a per-slot figure.
+        for name, key in (RASTER_KEYS if wkey == "metric" else ()):
             try:
                 ka, kb, st = find(a, key), find(b, key), mix[name]["classes"]
                 fetch_kib, write_kib = find(fs, key)["FETCH_SIZE"], find(ws, key)["WRITE_SIZE"]
