@@ -9,7 +9,10 @@ three tile rows) do not reach ("96 % of the image's contrib
   force over upstream's bounding-box list);
 * early termination leaks nothing: giving every Gaussian that NO tile walked (it lies behind the saturation point of
   every tile that lists it) an absurd colour leaves the image bit-identical;
-* the backward is linear in the incoming gradients over the whole image: g(v1 + v2) = g(v1) + g(v2), g(2 v) = 2 g(v).
+* the backward is linear in the incoming gradients over the whole image: g(v1 + v2) = g(v1) + g(v2), g(2 v) = 2 g(v);
+* adjoint identity of the colour path over the whole image: the image is LINEAR in the colours, so rendering a colour
+  perturbation d gives the exact directional derivative, and <render(d) - render(0), w> must equal <d, v_colors(w)> — every
+  pixel and every composited (pixel, Gaussian) pair of the backward's `alpha * T` bookkeeping takes part.
 """
 import pytest
 import torch
@@ -203,3 +206,27 @@ def test_backward_is_linear_in_the_incoming_gradients_over_the_whole_image(rende
     for a, b, s, d in zip(g1, g2, g12, g2x):
         assert rel_l2(s, a + b) < 1e-4 and rel_l2(d, 2 * a) < 1e-4      # (fp32 atomics: the summation order differs run to run)
         assert float(a.abs().sum()) > 0
+
+
+def test_colour_gradient_is_the_adjoint_of_the_render_over_the_whole_image(rendered):
+    from sgn_rast import ops
+    r = rendered
+    cam = r["cam"]
+    H, W = cam.height, cam.width
+    out = r["out"]
+    g = torch.Generator().manual_seed(17)
+    w = torch.randn(H, W, 3, generator=g).to(DEV)
+    d = torch.randn(out.rgbs.shape[0], 3, generator=g).to(DEV)
+    geo = (out.xys.detach(), out.depths.detach(), out.radii, out.conics.detach(), out.num_tiles_hit)
+    cols = torch.zeros_like(d).requires_grad_(True)
+    ops.clear_binning_cache()
+    img0 = ops.rasterize_gaussians(*geo, cols, out.opacities.detach(), H, W, 16, torch.zeros(3, device=DEV))
+    (v_cols,) = torch.autograd.grad(img0, cols, w)
+    with torch.no_grad():
+        img_d = ops.rasterize_gaussians(*geo, d, out.opacities.detach(), H, W, 16, torch.zeros(3, device=DEV))
+    lhs = float((img_d.double() * w.double()).sum())              # <J d, w>   (render(0) is exactly zero: zero background)
+    rhs = float((d.double() * v_cols.double()).sum())             # <d, J^T w>
+    scale = float((img_d.double() * w.double()).abs().sum())
+    assert float(img0.abs().max()) == 0.0
+    assert abs(lhs - rhs) <= 1e-5 * scale, (lhs, rhs, scale)      # fp32 sums on both sides (atomics in v_colors)
+    assert scale > 0 and float(v_cols.abs().sum()) > 0
