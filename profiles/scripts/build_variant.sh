@@ -14,7 +14,7 @@ FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract
 [ "$tu" = raster ] && FL="$FL -fno-slp-vectorize"
 /opt/rocm/bin/hipcc $FL "$@" -c $tu.hip -o /tmp/${tu}_$name.o
 objs=""
-for o in project sh binning radix_sort raster cubemap loss optim quat api; do
+for o in project sh binning radix_sort raster cubemap loss optim quat exchange api; do
   if [ $o = $tu ]; then objs="$objs /tmp/${tu}_$name.o"; else objs="$objs $o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../sgn_rast/libsgnrast_$name.so $objs

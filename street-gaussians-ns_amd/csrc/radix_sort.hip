@@ -44,8 +44,14 @@ constexpr int RS_WAVES = 4;
 #ifndef SGN_RS_IPT_LARGE
 #define SGN_RS_IPT_LARGE 16
 #endif
+#ifndef SGN_RANK_BITS
+#define SGN_RANK_BITS 8
+#endif
+#ifndef SGN_RANK_IPT
+#define SGN_RANK_IPT 0
+#endif
 constexpr int RS_IPT_LARGE = SGN_RS_IPT_LARGE, RS_IPT_SMALL = 4;
-constexpr uint32_t RS_SMALL_N = 3u << 20;
+constexpr uint32_t RS_SMALL_N = 3u << 19;   // (r05h: at 2 M keys the 4096-key tiles win by 15 us, at 1 M they lose by 11)
 inline int rs_pick_ipt(int64_t n) { return n < (int64_t)RS_SMALL_N ? RS_IPT_SMALL : RS_IPT_LARGE; }
 
 template <typename K>
@@ -455,17 +461,22 @@ __global__ __launch_bounds__(256) void rs_probe_compare_kernel(uint32_t n, const
 }  // namespace
 
 // internal (fused binning path, binning.hip)
-size_t sgn_sort_pairs32_ws_bytes(int64_t n) { return sort_ws_bytes<uint32_t, true, 8>(n); }
+size_t sgn_sort_pairs32_ws_bytes(int64_t n) {
+    const size_t a = sort_ws_bytes<uint32_t, true, 8>(n), b = sort_ws_bytes<uint32_t, true, SGN_RANK_BITS>(n);
+    return a > b ? a : b;
+}
 void sgn_sort_pairs32_launch(uint32_t n, int end_bit, const uint32_t *kin, const int32_t *vin, uint32_t *kout,
                              int32_t *vout, void *ws, hipStream_t s, const int32_t *n_dev, int rank_mode) {
     sort_launch<uint32_t, true, 8>(n, 0, end_bit, kin, vin, kout, vout, ws, s, n_dev, rank_mode);
 }
 
-// the depth ranking: keys read from (depths, radii) by the first pass, payload = index (see FROM_DEPTH)
+// the depth ranking: keys read from (depths, radii) by the first pass, payload = index (see FROM_DEPTH).
+// SGN_RANK_BITS / SGN_RANK_IPT: A/B builds of round 5 (profiles/scripts/r05h.sh) — 11-bit digits make it three passes
+// instead of four at the price of a 2048-column table and two-key store runs; measured, the shipped form stays 8 bits.
 void sgn_sort_depth_rank_launch(uint32_t n, const float *depths, const int32_t *radii, uint32_t *kout, int32_t *vout,
                                 void *ws, hipStream_t s, int rank_mode) {
-    sort_launch<uint32_t, true, 8>(n, 0, 32, (const uint32_t *)depths, radii, kout, vout, ws, s, nullptr, rank_mode, 0,
-                                   true);
+    sort_launch<uint32_t, true, SGN_RANK_BITS>(n, 0, 32, (const uint32_t *)depths, radii, kout, vout, ws, s, nullptr,
+                                               rank_mode, SGN_RANK_IPT, true);
 }
 
 // 16-bit keys (tile ids of images with <= 65536 tiles); same workspace layout and size as the 32-bit entry
