@@ -81,6 +81,7 @@ class _State:
         self.depth_caches = collections.OrderedDict()                  # binning key -> first pass's channel + state
         self.early = {"entry": None, "misses": 0, "pause": 0}
         self.order_scratch: dict = {}  # n_tiles -> persistent zero-filled scratch of the multi-workgroup tile order
+        self.no_speculation_once = False   # the one-call forward missed its capacity: the next binning runs its plain form
 
     # -- binning cache: most recent entry + a short LRU behind it
     def find_binning(self, key):
@@ -855,7 +856,7 @@ def _bin_finish(st):
     cap, spec_ids = 0, None
     S = _S()
     _last_count = S.last_count
-    skip_spec, S.no_speculation_once = getattr(S, "no_speculation_once", False), False
+    skip_spec, S.no_speculation_once = S.no_speculation_once, False
     if speculative_binning and _last_count.get(key, 0) > 0 and not skip_spec:
         cap = min(int(_last_count[key] * _SPEC_MARGIN) + 1024, (1 << 31) - 1)
         spec_ids = run(cap, C.c_void_p(st["cum_r"].data_ptr() + 4 * (n - 1)))
