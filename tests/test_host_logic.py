@@ -401,3 +401,45 @@ def test_memo_remembers_pure_host_functions_by_value():
     assert fused.memo(f, rot + 1) == 45.0 and len(calls) == 2            # other bytes: evaluated
     assert fused.memo(f, rot, 2) == 38.0 and len(calls) == 3             # other scalar argument: evaluated
     assert fused.memo(f, rot, 2) == 38.0 and len(calls) == 3
+
+
+def test_sort_ranking_policy_defaults_to_the_documented_form(monkeypatch):
+    """Round 5: the in-wave ranking of the radix sorts is an argument of the calls; the host's default is 0 (ballot match:
+    documented ISA semantics), the atomic form an opt-in that needs a GPU probe — without a GPU it stays 0 whatever the
+    environment says; `force_sort_rank` overrides inside its block only."""
+    from sgn_rast import _lib as L
+    monkeypatch.setattr(L, "_SORT_RANK", {})
+    monkeypatch.delenv("SGN_SORT_RANK", raising=False)
+    assert L.sort_rank_mode() == 0 and L.sort_ranking_report()["mode"] == "ballot"
+    monkeypatch.setattr(L, "_SORT_RANK", {})
+    monkeypatch.setenv("SGN_SORT_RANK", "atomic")
+    if not torch.cuda.is_available():
+        assert L.sort_rank_mode() == 0                 # no device to prove it on
+    monkeypatch.setattr(L, "_SORT_RANK", {})
+    monkeypatch.setenv("SGN_SORT_RANK", "atomic-unchecked")
+    assert L.sort_rank_mode() == 1 and "unchecked" in L.sort_ranking_report()["probe"]
+    monkeypatch.setattr(L, "_SORT_RANK", {})
+    monkeypatch.delenv("SGN_SORT_RANK")
+    with L.force_sort_rank("atomic"):
+        assert L.sort_rank_mode() == 1
+        with L.force_sort_rank("ballot"):
+            assert L.sort_rank_mode() == 0
+        assert L.sort_rank_mode() == 1
+    assert L.sort_rank_mode() == 0
+
+
+def test_densification_statistics_bookkeeping_without_a_process_group():
+    """`Stats` outside torch.distributed: the reference's single-process arithmetic (first update counts every Gaussian
+    once), `sync` is a no-op that says whether there is anything to decide on, `reset` forgets the interval."""
+    from helpers import TorchStats
+    S = TorchStats()
+    assert S.sync() is False
+    g = torch.tensor([[3.0, 4.0], [0.0, 0.0], [1.0, 0.0]])
+    r = torch.tensor([5, 0, 2], dtype=torch.int32)
+    S.update(g, r, (10, 20), step=7)
+    assert torch.equal(S.vis_counts, torch.ones(3)) and torch.equal(S.xys_grad_norm, torch.tensor([5.0, 0.0, 1.0]))
+    assert torch.equal(S.max_2Dsize, torch.tensor([0.25, 0.0, 0.1])) and S._first_key is None
+    S.update(g, r, (10, 20), step=8)
+    assert torch.equal(S.vis_counts, torch.tensor([2.0, 1.0, 2.0])) and S.sync() is True and S.synced_dim is None
+    S.reset()
+    assert S.xys_grad_norm is None and S.sync() is False
