@@ -195,3 +195,40 @@ def test_raster_backward_alone_matches_oracle_at_metric_size(production_defaults
         finally:
             ops.set_alpha_clamp_bwd(0.99)
             lib.set_options(reduce_mode=1)
+
+
+@pytest.mark.parametrize("name", ["c2", "metric", "street", "c4"])
+def test_train_step_gradients_match_oracle_over_the_whole_image(name, production_defaults):
+    """No band ("96 % of the image's contribution to the 1 M-Gaussian gradients is never compared"):
+    loss weights on EVERY pixel, the C oracle composites and differentiates the whole 1920x1280 image (its pixel rows
+    split over the host's cores: per-Gaussian partial sums of disjoint row ranges, added up), and every leaf gradient of
+    the train step, the retained `xys.grad` and the whole rgb / alpha image are compared at the production thresholds."""
+    import os
+
+    import oracle_ops
+    from oracle import c_oracle as CO
+    from sgn_rast import step
+    cam, raw = _scene(name)
+    w_img, w_a = step.loss_weights(cam, seed=13)
+    Pc = step.leaf_params(raw)
+    oracle_ops.PIXEL_ROWS = None
+    threads = CO.THREADS
+    CO.THREADS = max(1, min(32, (os.cpu_count() or 2) - 1))
+    try:
+        exp = step.train_step(Pc, cam, w_img, w_a, ops=oracle_ops)
+    finally:
+        CO.THREADS = threads
+    Pd, got = _hip_step(cam, raw, w_img, w_a)
+    n = exp.radii.numel()
+    assert int((got.radii.cpu() != exp.radii).sum()) <= max(2, n // 100_000)       # (torch's exp: GPU vs CPU, see above)
+    for attr in ("rgb", "alpha"):
+        err = (getattr(got, attr).detach().cpu() - getattr(exp, attr).detach()).abs()
+        assert float(err.mean()) < 1e-6 and float((err > 1e-5).float().mean()) < 2e-3, (attr, float(err.mean()))
+    assert rel_l2(got.xys.grad.cpu(), exp.xys.grad) < 1e-4
+    for k in Pd:
+        r = rel_l2(Pd[k].grad.cpu(), Pc[k].grad)
+        assert r < 1e-4, (name, k, r)
+        assert float(Pc[k].grad.abs().sum()) > 0, k
+    # rows no pixel reaches get exact zeros from both sides
+    dead = (exp.radii == 0)
+    assert float(Pd["means"].grad.cpu()[dead].abs().sum()) == 0.0
