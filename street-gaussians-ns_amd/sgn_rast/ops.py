@@ -346,15 +346,53 @@ class _ProjectGaussians(Function):
         v_mean = torch.empty(n, 3, **f32)
         v_scale = torch.empty(n, 3, **f32)
         v_quat = torch.empty(n, 4, **f32)
+        want_viewmat = bool(ctx.needs_input_grad[4])
+        v_cov2d = torch.empty(n, 3, **f32) if want_viewmat else None
         L.check(L.load().sgn_project_bwd(
             n, L.ptr(means3d), L.ptr(scales), ctx.glob_scale, L.ptr(quats), L.ptr(viewmat), ctx.fx, ctx.fy,
             L.ptr(cov3d), L.ptr(radii), L.ptr(conics), L.ptr(compensation), L.ptr(v_xys), L.ptr(v_depths),
-            L.ptr(v_conics), L.ptr(v_comp), None, None, L.ptr(v_mean), L.ptr(v_scale), L.ptr(v_quat),
+            L.ptr(v_conics), L.ptr(v_comp), L.ptr(v_cov2d), None, L.ptr(v_mean), L.ptr(v_scale), L.ptr(v_quat),
             L.stream_ptr()), "sgn_project_bwd")
         # (means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block, clip)
-        # viewmat gradient: never requested by the reference (camera optimiser "off",
-        # sgn_config.py:44) -> None, as upstream returns when viewmat.requires_grad is False.
-        return v_mean, v_scale, None, v_quat, None, None, None, None, None, None, None, None, None
+        # viewmat gradient: never requested by the reference (camera optimiser "off", sgn_config.py:44: `None`, as
+        # upstream returns when viewmat.requires_grad is False); when it IS requested (round 5) it is assembled on the
+        # host from the kernel's per-Gaussian outputs — a cold path, a dozen torch ops
+        v_viewmat = _viewmat_grad(means3d, viewmat, ctx.fx, ctx.fy, cov3d, radii, v_mean, v_cov2d,
+                                  ctx.viewmat_shape) if want_viewmat else None
+        return v_mean, v_scale, None, v_quat, v_viewmat, None, None, None, None, None, None, None, None
+
+
+def _viewmat_grad(means3d, viewmat12, fx, fy, cov3d, radii, v_mean, v_cov2d, shape):
+    """dL/d(viewmat) of `project_gaussians` from what the backward kernel already returns (upstream computes it when
+    `viewmat.requires_grad`; the reference never asks).  With V = [R | t], p_v = R p + t, T = J(p_v) R and
+    cov2d = T Sigma T^T:
+        v_R = sum_i v_pv_i (x) p_i + J_i^T v_T_i,    v_t = sum_i v_pv_i,
+    where v_pv is the gradient of the view-space point — the kernel's `v_mean = R^T v_pv`, solved back — and
+    v_T = 2 G T Sigma with G the symmetric cov2d gradient (`v_cov2d`, off-diagonal halved).  Same conventions as the
+    analytic vjp of the means (un-clamped J); culled Gaussians contribute nothing."""
+    f64 = torch.float64
+    V = viewmat12.reshape(3, 4).to(f64)
+    R, t = V[:, :3], V[:, 3]
+    live = (radii > 0)
+    p = means3d.to(f64)
+    vm = torch.where(live[:, None], v_mean.to(f64), torch.zeros_like(p))
+    v_pv = torch.linalg.solve(R.T, vm.T).T                                   # v_mean = R^T v_pv
+    pv = p @ R.T + t
+    rz = 1.0 / torch.where(live, pv[:, 2], torch.ones_like(pv[:, 2]))
+    J = torch.zeros(p.shape[0], 2, 3, dtype=f64, device=p.device)
+    J[:, 0, 0], J[:, 0, 2] = fx * rz, -fx * pv[:, 0] * rz * rz
+    J[:, 1, 1], J[:, 1, 2] = fy * rz, -fy * pv[:, 1] * rz * rz
+    T = J @ R
+    c = cov3d.to(f64)
+    S = torch.stack([c[:, 0], c[:, 1], c[:, 2], c[:, 1], c[:, 3], c[:, 4], c[:, 2], c[:, 4], c[:, 5]], dim=-1).reshape(-1, 3, 3)
+    g = torch.where(live[:, None], v_cov2d.to(f64), torch.zeros(1, 3, dtype=f64, device=p.device))
+    G = torch.stack([g[:, 0], 0.5 * g[:, 1], 0.5 * g[:, 1], g[:, 2]], dim=-1).reshape(-1, 2, 2)
+    vT = 2.0 * G @ T @ S
+    v_R = v_pv.T @ p + (J.transpose(1, 2) @ vT).sum(dim=0)
+    out = torch.zeros(shape, dtype=torch.float32, device=p.device)
+    out[:3, :3] = v_R.to(torch.float32)
+    out[:3, 3] = v_pv.sum(dim=0).to(torch.float32)
+    return out
 
 
 # The reference hands `project_gaussians` its activated parameters — `torch.exp(scales)` (sgn_splatfacto.py:857) and
@@ -430,6 +468,7 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
             float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
             L.ptr(compensation), L.ptr(num_tiles_hit), L.stream_ptr()), "sgn_project_fwd")
     ctx.glob_scale, ctx.fx, ctx.fy = float(glob_scale), float(fx), float(fy)
+    ctx.viewmat_shape = tuple(viewmat.shape)
     ctx.mark_non_differentiable(radii, num_tiles_hit)
     # seven outputs, two or three of which the loss ever reaches: without this autograd materialises a zero tensor (an
     # allocation and a fill kernel each) for every unused one before calling backward, which handles None itself
@@ -620,7 +659,7 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     token = _check_quats(quats) if plan is None else None
     _call_state.project_plan = plan
     ls_leaves = x = None
-    if _proofs_on(activation_proofs) and scales.is_cuda:
+    if _proofs_on(activation_proofs) and scales.is_cuda and not viewmat.requires_grad:   # (viewmat gradient: plain node)
         ls_leaves = proofs.exp_leaves(scales)
         x = proofs.normalised_source(quats) if ls_leaves is not None else None
     if x is not None:

@@ -88,6 +88,53 @@ def test_project_backward(hip, c_oracle):
         assert rel_l2(leaf.grad.cpu(), e) < 1e-5
 
 
+@pytest.mark.parametrize("parts", [(1, 1, 0), (0, 0, 1), (1, 1, 1)], ids=["xys+depths", "conics", "all"])
+def test_viewmat_gradient_matches_autograd_through_the_torch_oracle(hip, torch_oracle, parts):
+    """Upstream returns a viewmat gradient when `viewmat.requires_grad` (the reference never asks: its camera optimiser is
+    off, sgn_config.py:44).  Assembled on the host from the backward kernel's per-Gaussian outputs; checked against
+    fp64 autograd through the pure-PyTorch oracle (centres within 1.3x the frustum, where the forward's clamp is
+    inactive), for a [3,4] and a [4,4] view matrix with a rolled camera; the other gradients stay what they were."""
+    import math
+    cam, P = small_scene(n=8000)
+    args = _project_args(cam, P)
+    g = torch.Generator().manual_seed(4)
+    n = args[0].shape[0]
+    w_xy, w_d, w_c = torch.randn(n, 2, generator=g), torch.randn(n, generator=g), torch.randn(n, 3, generator=g)
+    c, s_ = math.cos(0.07), math.sin(0.07)
+    roll = torch.tensor([[c, -s_, 0, 0], [s_, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]], dtype=torch.float64)
+    V0 = torch.eye(4, dtype=torch.float64)
+    V0[:3, :] = args[4].double()
+    V0 = roll @ V0
+
+    def run(fn, dev, dtype, full):
+        a = [t.to(dev, dtype) if torch.is_tensor(t) and t.is_floating_point() else t for t in args]
+        vm = (V0 if full else V0[:3, :]).detach().clone().to(dev, dtype).contiguous().requires_grad_(True)
+        leaves = [a[0].clone().requires_grad_(True), a[1].clone().requires_grad_(True), a[3].clone().requires_grad_(True)]
+        out = fn(leaves[0], leaves[1], 1.0, leaves[2], vm, *a[5:])
+        live = out[2] > 0
+        loss = (parts[0] * (out[0] * w_xy.to(dev, dtype))[live].sum() + parts[1] * (out[1] * w_d.to(dev, dtype))[live].sum()
+                + parts[2] * (out[3] * w_c.to(dev, dtype))[live].sum())
+        loss.backward()
+        return vm.grad.detach().cpu().double(), [l.grad.detach().cpu().double() for l in leaves]
+    for full in (False, True):
+        exp_v, exp_l = run(torch_oracle.project_gaussians, "cpu", torch.float64, full)
+        got_v, got_l = run(hip.project_gaussians, DEV, torch.float32, full)
+        assert got_v.shape == exp_v.shape == ((4, 4) if full else (3, 4))
+        assert rel_l2(got_v[:3], exp_v[:3]) < 1e-4, (full, got_v, exp_v)
+        assert float(got_v[3:].abs().sum()) == 0.0
+        for a_, b_ in zip(got_l, exp_l):
+            assert rel_l2(a_, b_) < 1e-4
+
+
+def test_without_a_viewmat_gradient_the_projection_node_returns_none_for_it(hip):
+    cam, P = small_scene(n=2000)
+    dargs = list(_project_args(cam, P, 16, DEV))
+    dargs[0].requires_grad_(True)
+    out = hip.project_gaussians(*dargs)
+    out[0].sum().backward()
+    assert dargs[4].grad is None and dargs[0].grad is not None
+
+
 # ----------------------------------------------------------------------- SH
 @pytest.mark.parametrize("k,deg", [(1, 0), (4, 1), (9, 2), (16, 3), (16, 0), (16, 2), (25, 4), (25, 3)])
 @pytest.mark.parametrize("n", [1, 63, 64, 1000, 4097])

@@ -13,6 +13,10 @@ three tile rows) do not reach ("96 % of the image's contrib
 * adjoint identity of the colour path over the whole image: the image is LINEAR in the colours, so rendering a colour
   perturbation d gives the exact directional derivative, and <render(d) - render(0), w> must equal <d, v_colors(w)> — every
   pixel and every composited (pixel, Gaussian) pair of the backward's `alpha * T` bookkeeping takes part.
+
+Scenes: the metric scene, the street-like one (long non-saturating lists) and "big" — SIX million Gaussians in the same
+view (the size of a full Waymo-sequence model; ~100 M upstream-semantic intersections): index arithmetic, the sort's
+large-N paths and the list windows far above the benchmark sizes.
 """
 import pytest
 import torch
@@ -25,14 +29,14 @@ DEV = "cuda"
 
 def _scene(name):
     from sgn_rast import scenes
-    cam, raw = scenes.make_scene("metric")
+    cam, raw = scenes.make_scene("metric", n_override=6_000_000 if name == "big" else 0)
     if name == "street":
         raw = scenes.make_street_gaussians(raw["means"].shape[0], cam, seed=0)
     cam_d = scenes.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.viewmat.to(DEV), cam.cam_pos.to(DEV))
     return cam_d, {k: v.to(DEV) for k, v in raw.items()}
 
 
-@pytest.fixture(scope="module", params=["metric", "street"])
+@pytest.fixture(scope="module", params=["metric", "street", "big"])
 def rendered(request):
     """One production forward per scene; everything the properties need, detached."""
     from sgn_rast import _lib as L, ops, step

@@ -443,3 +443,38 @@ def test_densification_statistics_bookkeeping_without_a_process_group():
     assert torch.equal(S.vis_counts, torch.tensor([2.0, 1.0, 2.0])) and S.sync() is True and S.synced_dim is None
     S.reset()
     assert S.xys_grad_norm is None and S.sync() is False
+
+
+@pytest.mark.parametrize("parts", [(1, 1, 0), (0, 0, 1), (1, 1, 1)], ids=["xys+depths", "conics", "all"])
+def test_viewmat_gradient_assembly_from_the_backward_kernels_outputs(torch_oracle, c_oracle, parts):
+    """`ops._viewmat_grad` turns the per-Gaussian `v_mean` / `v_cov2d` of the projection backward into dL/d(viewmat).
+    Here the C oracle's backward supplies those two (same formulas as the HIP kernel, test_gpu_parity) and fp64 autograd
+    through the pure-PyTorch oracle is the answer; tests/test_gpu_parity.py repeats it through the HIP node."""
+    import math
+    from helpers import activated, rel_l2, small_scene
+    cam, P = small_scene(n=4000)
+    scales, quats, _, _ = activated(P)
+    means, n = P["means"], P["means"].shape[0]
+    c, s = math.cos(0.07), math.sin(0.07)
+    V = torch.eye(4)
+    V[:3] = cam.viewmat[:3]
+    V = (torch.tensor([[c, -s, 0, 0], [s, c, 0, 0], [0, 0, 1, 0], [0, 0, 0, 1.0]]) @ V)[:3].contiguous()
+    g = torch.Generator().manual_seed(4)
+    w_xy, w_d, w_c = torch.randn(n, 2, generator=g), torch.randn(n, generator=g), torch.randn(n, 3, generator=g)
+    intr = (cam.fx, cam.fy, cam.cx, cam.cy, cam.height, cam.width, 16)
+    vm = V.double().clone().requires_grad_(True)
+    out = torch_oracle.project_gaussians(means.double(), scales.double(), 1.0, quats.double(), vm, *intr)
+    live = out[2] > 0
+    (parts[0] * (out[0] * w_xy.double())[live].sum() + parts[1] * (out[1] * w_d.double())[live].sum()
+     + parts[2] * (out[3] * w_c.double())[live].sum()).backward()
+    xys, depths, radii, conics, comp, nth, cov3d = c_oracle.project_fwd(means, scales, 1.0, quats, V, *intr)
+    assert torch.equal(radii > 0, live)
+    m = (radii > 0).float()
+    v_mean, _, _, v_cov2d, _ = c_oracle.project_bwd(means, scales, 1.0, quats, V, cam.fx, cam.fy, cov3d, radii, conics,
+                                                    comp, parts[0] * w_xy * m[:, None], parts[1] * w_d * m,
+                                                    parts[2] * w_c * m[:, None], torch.zeros(n))
+    for shape in ((3, 4), (4, 4)):
+        got = ops._viewmat_grad(means, V.reshape(-1), cam.fx, cam.fy, cov3d, radii, v_mean, v_cov2d, shape)
+        assert tuple(got.shape) == shape and got.dtype == torch.float32
+        assert rel_l2(got[:3].double(), vm.grad) < 1e-5
+        assert float(got[3:].abs().sum()) == 0.0
