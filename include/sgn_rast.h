@@ -109,17 +109,29 @@ int sgn_project_fwd(int n, const float *means3d, const float *scales, float glob
  * next sync point (see sgn_rast/ops.py: deferred assertion). */
 int sgn_check_unit_quats(int n, const float *quats, float tol, int32_t *flag, sgn_stream_t stream);
 
-/* `project_gaussians` as ONE call (round 5; no upstream counterpart): sgn_check_unit_quats (check_quats != 0: the flag is
- * copied to flag_pinned — pinned host int32, NULL = pageable — right away), sgn_project_fwd, and — gid_by_rank != NULL —
- * sgn_depth_rank of the coming binning, all queued on `stream`; only then does the call wait for the flag and report
- * *quats_bad_host (1: some row failed `norm - 1 < quat_tol`; the host raises upstream's assertion).  rank_ws:
- * sgn_depth_rank_workspace_bytes(n). */
+/* `project_gaussians` as ONE call (round 5; no upstream counterpart): sgn_project_fwd with upstream's quats assertion
+ * riding the projection kernel (check_quats != 0: a row of quats [n,4], 16-byte aligned, that fails `norm - 1 < quat_tol`
+ * STAMPS *flag_dev; the flag is copied to flag_pinned — pinned host int32, NULL = pageable — behind the kernel), and —
+ * gid_by_rank != NULL — sgn_depth_rank of the coming binning, all queued on `stream`; only then does the call wait for
+ * the flag and report *quats_bad_host (1: some row failed; the host raises upstream's assertion).  flag_stamp > 0: the
+ * value a failing row stores; the caller guarantees *flag_dev holds no value >= flag_stamp when the kernel runs (a word
+ * zeroed once, a counter per call on it), and nothing is cleared per call.  flag_stamp <= 0: the call clears the flag
+ * itself (one more launch) and stamps 1.  rank_ws: sgn_depth_rank_workspace_bytes(n).
+ * Where flag_pinned is mapped into the device's address space (hipHostMalloc'd memory is) and flag_stamp > 0, a failing
+ * row stores the stamp straight into *flag_pinned and no copy command is queued (flag_dev may then be NULL); the slot
+ * must not already hold a value >= flag_stamp.
+ * check_quats = 2: everything is queued as above but the call does NOT wait (flag_pinned required, quats_bad_host unused):
+ * the caller finishes its own host-side bookkeeping and then calls sgn_project_check_wait — same thread, same device,
+ * no other call of this library in between — which waits for the flag and reports it. */
 int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
                         const float *viewmat12, float fx, float fy, float cx, float cy, int img_h, int img_w,
                         int block_width, float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii,
                         float *conics, float *compensation, int32_t *num_tiles_hit, int check_quats, float quat_tol,
-                        int32_t *flag_dev, int32_t *flag_pinned, int32_t *gid_by_rank, void *rank_ws,
-                        size_t rank_ws_bytes, int sort_rank_mode, int32_t *quats_bad_host, sgn_stream_t stream);
+                        int32_t *flag_dev, int32_t flag_stamp, int32_t *flag_pinned, int32_t *gid_by_rank,
+                        void *rank_ws, size_t rank_ws_bytes, int sort_rank_mode, int32_t *quats_bad_host,
+                        sgn_stream_t stream);
+
+int sgn_project_check_wait(const int32_t *flag_pinned, int32_t flag_stamp, int32_t *quats_bad_host /*host*/);
 
 /* _C.project_gaussians_backward (_ProjectGaussians.backward).  v_compensation may be NULL
  * (treated as zeros: the reference discards compensation, sgn_splatfacto.py:860,947); v_depth may be NULL too
@@ -444,7 +456,8 @@ int sgn_raster_fwd_groups(int img_h, int img_w, int n, int64_t n_isect, const in
  * exceeds isect_capacity (nothing rasterized: call again with more room); with a count of 0 it returns 0 without touching
  * out_img / final_Ts / final_idx (tile_bins is zero-filled): the caller writes the background image.
  * gid_by_rank_ready: NULL, or sgn_depth_rank's result for these depths / radii (started earlier).  count_pinned: pinned
- * host int32 the count is copied to (NULL: a pageable copy).  extra_dev / extra_pinned: one more device int32 to bring
+ * host int32 the count arrives in (NULL: a pageable copy) — written by the scan kernel itself where the word is mapped into
+ * the device's address space (hipHostMalloc'd memory is: no copy command on the stream), copied otherwise.  extra_dev / extra_pinned: one more device int32 to bring
  * along in the same transfer (the host's walk statistic), or NULL.  order_scratch as in sgn_tile_order. */
 #define SGN_E_CAPACITY (-100)
 size_t sgn_rasterize_arena_bytes(int n, int64_t isect_capacity);

@@ -135,6 +135,6 @@ if __name__ == "__main__":
     elif mode == "gaps":
         gaps(path)
     elif mode == "timeline":
-        timeline(path, *(sys.argv[3:4] or ["project_fwd"]))
+        timeline(path, (sys.argv[3:4] or ["project_fwd"])[0], int((sys.argv[4:5] or ["-2"])[0]))
     else:
         pmc(path, sys.argv[3] if len(sys.argv) > 3 else "")

@@ -1,5 +1,6 @@
 // api.cpp — error plumbing shared by every entry point of libsgnrast.so (host only).
 #include <stdarg.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -68,45 +69,107 @@ int sync_event(hipEvent_t *ev) {          // one untimed event per (thread, devi
     *ev = o.e;
     return 0;
 }
+// The device's view of a word of pinned host memory (nullptr: not mapped — the caller falls back to a copy command).
+// Kernels store flags / counts there directly, so that a read-back needs only an event behind the kernel, not a copy.
+int32_t *mapped(int32_t *pinned) {
+    if (pinned == nullptr) return nullptr;
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, pinned, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (int32_t *)d;
+}
 }  // namespace
 
-// sgn_project_fwd_all: `project_gaussians` as ONE call — upstream's quats assertion as a device pass whose flag travels to
-// the host while the projection and (optionally) the depth ranking of the coming binning are already queued; the host
-// waits for the flag last (the "eager" check of sgn_rast/ops.py, which otherwise takes three calls).
+// sgn_project_fwd_all: `project_gaussians` as ONE call — upstream's quats assertion rides the projection kernel (the
+// quaternion is in its registers anyway; a failing row stamps the flag), the flag travels to the host while the depth
+// ranking of the coming binning is already queued, and the host waits for it last (the "eager" check of sgn_rast/ops.py,
+// which otherwise takes three calls and two more launches).  `flag_stamp` > 0: the caller guarantees that *flag_dev holds
+// no value >= flag_stamp (a word zeroed ONCE and a call counter): nothing is cleared; <= 0: the call clears the flag.
+int sgn_project_fwd_checked(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
+                            const float *viewmat12, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                            int block_width, float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii,
+                            float *conics, float *compensation, int32_t *num_tiles_hit, int32_t *quat_flag,
+                            float quat_tol, int32_t quat_stamp, sgn_stream_t stream);       // project.hip
+
 extern "C" __attribute__((visibility("default")))
 int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
                         const float *viewmat12, float fx, float fy, float cx, float cy, int img_h, int img_w,
                         int block_width, float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii,
                         float *conics, float *compensation, int32_t *num_tiles_hit, int check_quats, float quat_tol,
-                        int32_t *flag_dev, int32_t *flag_pinned, int32_t *gid_by_rank, void *rank_ws,
-                        size_t rank_ws_bytes, int sort_rank_mode, int32_t *quats_bad_host, sgn_stream_t stream) {
+                        int32_t *flag_dev, int32_t flag_stamp, int32_t *flag_pinned, int32_t *gid_by_rank,
+                        void *rank_ws, size_t rank_ws_bytes, int sort_rank_mode, int32_t *quats_bad_host,
+                        sgn_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t ev = nullptr;
     int32_t pageable = 0;
     int32_t *dst = flag_pinned ? flag_pinned : &pageable;
+    int32_t stamp = flag_stamp > 0 ? flag_stamp : 1;
     if (check_quats) {
-        if (!flag_dev || !quats_bad_host) { sgn_set_error("sgn_project_fwd_all: check_quats needs flag_dev and quats_bad_host"); return -1; }
-        int rc = sgn_check_unit_quats(n, quats, quat_tol, flag_dev, stream);
-        if (rc) return rc;
-        hipError_t e = hipMemcpyAsync(dst, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        const int mode = check_quats;
+        if (mode != 1 && mode != 2) { sgn_set_error("sgn_project_fwd_all: check_quats must be 0, 1 or 2"); return -3; }
+        if ((!flag_dev && !(flag_stamp > 0 && flag_pinned)) || (mode == 1 && !quats_bad_host) || (mode == 2 && !flag_pinned)) { sgn_set_error("sgn_project_fwd_all: check_quats needs flag_dev and quats_bad_host (1) / flag_pinned (2)"); return -1; }
+        if (n > 0 && (!quats || (reinterpret_cast<uintptr_t>(quats) & 15) != 0)) { sgn_set_error("sgn_project_fwd_all: quats must be 16-byte aligned"); return -2; }
+        if (flag_stamp <= 0) {
+            if (!flag_dev) { sgn_set_error("sgn_project_fwd_all: flag_stamp <= 0 needs flag_dev"); return -1; }
+            const hipError_t e = hipMemsetAsync(flag_dev, 0, sizeof(int32_t), s);
+            if (e != hipSuccess) { sgn_set_error("sgn_project_fwd_all: flag clear: %s", hipGetErrorString(e)); return (int)e; }
+        }
+    }
+    // flag_pinned mapped into the device's address space and stamped (flag_stamp > 0: stale slots never equal the stamp):
+    // a failing row stores straight into it and the read-back needs no copy command behind the kernel
+    int32_t *direct = (check_quats && flag_stamp > 0) ? mapped(flag_pinned) : nullptr;
+    int rc = sgn_project_fwd_checked(n, means3d, scales, glob_scale, quats, viewmat12, fx, fy, cx, cy, img_h, img_w,
+                                     block_width, clip_thresh, cov3d, xys, depths, radii, conics, compensation,
+                                     num_tiles_hit, check_quats ? (direct ? direct : flag_dev) : nullptr, quat_tol,
+                                     stamp, stream);
+    if (rc) return rc;
+    if (check_quats) {
+        hipError_t e = direct ? hipSuccess : hipMemcpyAsync(dst, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
         if (e == hipSuccess && sync_event(&ev) != 0) e = hipErrorUnknown;
         if (e == hipSuccess) e = hipEventRecord(ev, s);
         if (e != hipSuccess) { sgn_set_error("sgn_project_fwd_all: flag read-back: %s", hipGetErrorString(e)); return (int)e; }
     }
-    int rc = sgn_project_fwd(n, means3d, scales, glob_scale, quats, viewmat12, fx, fy, cx, cy, img_h, img_w, block_width,
-                             clip_thresh, cov3d, xys, depths, radii, conics, compensation, num_tiles_hit, stream);
-    if (rc) return rc;
     if (gid_by_rank != nullptr && n > 0) {
         rc = sgn_depth_rank(n, depths, radii, gid_by_rank, rank_ws, rank_ws_bytes, sort_rank_mode, stream);
         if (rc) return rc;
     }
-    if (check_quats) {
-        const hipError_t e = hipEventSynchronize(ev);      // the projection (and the ranking) are queued: wait now
+    if (check_quats == 1) {
+        const hipError_t e = hipEventSynchronize(ev);      // the ranking is queued behind the projection: wait now
         if (e != hipSuccess) { sgn_set_error("sgn_project_fwd_all: %s", hipGetErrorString(e)); return (int)e; }
-        *quats_bad_host = *dst;
+        *quats_bad_host = (n > 0 && *dst == stamp) ? 1 : 0;
     }
     return 0;
 }
+
+// The wait of a sgn_project_fwd_all(check_quats = 2) call, made by the same thread on the same device with nothing of this
+// library in between: the caller does its own host-side bookkeeping for the projection's outputs first, while the flag
+// is still on its way (the device is busy behind it; what the host does before this wait is off the critical path).
+extern "C" __attribute__((visibility("default")))
+int sgn_project_check_wait(const int32_t *flag_pinned, int32_t flag_stamp, int32_t *quats_bad_host) {
+    if (!flag_pinned || !quats_bad_host) { sgn_set_error("sgn_project_check_wait: NULL argument"); return -1; }
+    hipEvent_t ev = nullptr;
+    if (sync_event(&ev) != 0) { sgn_set_error("sgn_project_check_wait: no event"); return -2; }
+    const hipError_t e = hipEventSynchronize(ev);
+    if (e != hipSuccess) { sgn_set_error("sgn_project_check_wait: %s", hipGetErrorString(e)); return (int)e; }
+    *quats_bad_host = (*flag_pinned == (flag_stamp > 0 ? flag_stamp : 1)) ? 1 : 0;
+    return 0;
+}
+
+int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const int32_t *radii,
+                          const float *conics, const float *opacities, int opacity_is_logit, int cull,
+                          int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
+                          int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
+                          int sort_rank_mode, int32_t *total_host, sgn_stream_t stream);   // binning.hip
+int sgn_bin_intersect_zero(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
+                           const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
+                           int32_t *gaussian_ids_sorted, int32_t *tile_bins, int quadrant_masks, void *ws,
+                           size_t ws_bytes, const int32_t *n_isect_dev, int sort_rank_mode, int also_zero_words,
+                           sgn_stream_t stream);                                          // binning.hip
+int sgn_raster_fwd_precleared(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                              const float *conics, const float *colors, const float *opacities,
+                              int opacity_is_logit, const float *background3, float *out_img, float *final_Ts,
+                              int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes, const int32_t *tile_order,
+                              int32_t *tile_kmax, const sgn_raster_opts *opts, sgn_stream_t stream);   // raster.hip
 
 extern "C" __attribute__((visibility("default")))
 size_t sgn_rasterize_arena_bytes(int n, int64_t isect_capacity) {
@@ -154,14 +217,16 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
     void *ws2 = p; const size_t ws2_bytes = sgn_bin_intersect_workspace_bytes(isect_capacity);
     int32_t *gid = gid_by_rank_ready ? const_cast<int32_t *>(gid_by_rank_ready) : gid_own;
     const int do_cull = (cull && conics && opacities) ? 1 : 0;
-    int rc = sgn_bin_prepare(n, xys, depths, radii, do_cull ? conics : nullptr, do_cull ? opacities : nullptr,
-                             opacity_is_logit, do_cull, tiles_x, tiles_y, block_width, cum_r, gid,
-                             gid_by_rank_ready ? 1 : 0, bin_recs, ws1, ws1_bytes, sort_rank_mode, stream);
+    // the count goes straight from the scan into count_pinned where that is mapped into the device's address space (no
+    // copy command, no bubble behind it), by a copy otherwise; everything queued below runs while it travels
+    int32_t *direct = mapped(count_pinned);
+    int rc = sgn_bin_prepare_total(n, xys, depths, radii, do_cull ? conics : nullptr, do_cull ? opacities : nullptr,
+                                   opacity_is_logit, do_cull, tiles_x, tiles_y, block_width, cum_r, gid,
+                                   gid_by_rank_ready ? 1 : 0, bin_recs, ws1, ws1_bytes, sort_rank_mode, direct, stream);
     if (rc) return rc;
-    // the count starts its way to the host now; everything queued below runs while it travels
     int32_t pageable = -1;
     int32_t *dst = count_pinned ? count_pinned : &pageable;
-    hipError_t e = hipMemcpyAsync(dst, cum_r + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    hipError_t e = direct ? hipSuccess : hipMemcpyAsync(dst, cum_r + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && extra_dev && extra_pinned)
         e = hipMemcpyAsync(extra_pinned, extra_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
     hipEvent_t ev = nullptr;
@@ -171,8 +236,12 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
     rc = sgn_raster_build_rows(n, xys, conics, colors, opacities, opacity_is_logit, 0, n, 0, rows, rows_bytes, nullptr,
                                stream);
     if (rc) return rc;
-    rc = sgn_bin_intersect(n, isect_capacity, bin_recs, cum_r, gid, tiles_x, tiles_y, block_width, gaussian_ids_sorted,
-                           tile_bins, quadrant_masks, ws2, ws2_bytes, cum_r + (n - 1), sort_rank_mode, stream);
+    // tile_stats laid out right behind tile_bins (ONE buffer of the caller's): the emission clears both, and neither the
+    // bins nor the statistics cost a clear launch of their own
+    const bool stats_behind_bins = tile_stats == tile_bins + 2 * (size_t)n_tiles;
+    rc = sgn_bin_intersect_zero(n, isect_capacity, bin_recs, cum_r, gid, tiles_x, tiles_y, block_width,
+                                gaussian_ids_sorted, tile_bins, quadrant_masks, ws2, ws2_bytes, cum_r + (n - 1),
+                                sort_rank_mode, stats_behind_bins ? 2 * n_tiles : 0, stream);
     if (rc) return rc;
     e = hipEventSynchronize(ev);                       // the path's one host sync (upstream: `.item()` on the count)
     if (e != hipSuccess) { sgn_set_error("sgn_rasterize_fwd_all: %s", hipGetErrorString(e)); return (int)e; }
@@ -185,6 +254,10 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
     if (rc) return rc;
     sgn_raster_opts oo = o;
     oo.ids_qmask = quadrant_masks ? 1 : 0;
+    if (stats_behind_bins)
+        return sgn_raster_fwd_precleared(img_h, img_w, block_width, n, count, gaussian_ids_sorted, tile_bins, xys, conics,
+                                         colors, opacities, opacity_is_logit, background3, out_img, final_Ts, final_idx,
+                                         rows, rows_bytes, tile_order, tile_stats, &oo, stream);
     return sgn_raster_fwd(img_h, img_w, block_width, n, count, gaussian_ids_sorted, tile_bins, xys, conics, colors,
                           opacities, opacity_is_logit, 0, n, 0, background3, out_img, final_Ts, final_idx, rows,
                           rows_bytes, 1, tile_order, tile_stats, nullptr, nullptr, nullptr, &oo, stream);

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_partials_kernel(int nb, int
 template <bool SCANNED>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(int n, const int32_t *__restrict__ in,
                                                                   const int32_t *__restrict__ partial,
-                                                                  int32_t *__restrict__ out) {
+                                                                  int32_t *__restrict__ out,
+                                                                  int32_t *__restrict__ total_host) {
     __shared__ int lds4[4];
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
@@ -128,6 +129,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(int n, const i
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         run += v[k];
         if (base + k < n) out[base + k] = run;
+        // the grand total straight into (mapped, pinned) HOST memory: the caller's read-back of out[n-1] then needs no
+        // copy command behind this kernel (a ~4 us blit and a ~6 us bubble on the stream), only its event
+        if (total_host != nullptr && base + k == n - 1) {
+            __hip_atomic_store(total_host, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+        }
     }
 }
 
@@ -717,7 +724,7 @@ SGN_EXPORT size_t sgn_scan_workspace_bytes(int n) {
 
 // out[i] = sum_{r <= i} in[idx ? idx[r] : r];  with idx, `gathered` (n ints) receives in[idx[r]]
 static int scan_launch(int n, const int32_t *in, const int32_t *idx, int32_t *gathered, int32_t *out, void *ws,
-                       hipStream_t s) {
+                       hipStream_t s, int32_t *total_host = nullptr) {
     const int nb = sgn_cdiv(n, SCAN_CHUNK);
     int32_t *partial = (int32_t *)ws;
     sgn_timing_begin(SGN_T_SCAN, s);
@@ -725,11 +732,11 @@ static int scan_launch(int n, const int32_t *in, const int32_t *idx, int32_t *ga
                        partial);
     if (nb <= 4096) {       // every workgroup adds up the chunk totals before its own (<= 16 KB of reads each)
         hipLaunchKernelGGL(scan_final_kernel<false>, dim3(nb), dim3(SCAN_THREADS), 0, s, n, idx ? gathered : in, partial,
-                           out);
+                           out, total_host);
     } else {
         hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, partial);
         hipLaunchKernelGGL(scan_final_kernel<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, n, idx ? gathered : in, partial,
-                           out);
+                           out, total_host);
     }
     sgn_timing_end(SGN_T_SCAN, s);
     SGN_LAUNCH_CHECK();
@@ -843,11 +850,29 @@ static Cull make_cull(const float *conics, const float *opac, int opac_is_logit,
     return c;
 }
 
+// `total_host`: device-visible pointer into pinned host memory (or nullptr) that receives cum_by_rank[n-1] from the scan
+// itself (api.cpp sgn_rasterize_fwd_all: the count's read-back without a copy command)
+int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const int32_t *radii,
+                          const float *conics, const float *opacities, int opacity_is_logit, int cull,
+                          int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
+                          int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
+                          int sort_rank_mode, int32_t *total_host, sgn_stream_t stream);
+
 SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii,
                                const float *conics, const float *opacities, int opacity_is_logit, int cull,
                                int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
                                int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
                                int sort_rank_mode, sgn_stream_t stream) {
+    return sgn_bin_prepare_total(n, xys, depths, radii, conics, opacities, opacity_is_logit, cull, tiles_x, tiles_y,
+                                 block_width, cum_by_rank, gid_by_rank, rank_ready, bin_records, ws, ws_bytes,
+                                 sort_rank_mode, nullptr, stream);
+}
+
+int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const int32_t *radii,
+                          const float *conics, const float *opacities, int opacity_is_logit, int cull,
+                          int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
+                          int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
+                          int sort_rank_mode, int32_t *total_host, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     if (n == 0) return 0;
@@ -874,7 +899,7 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
         sgn_timing_end(SGN_T_SORT, s);
     }
     // cum_by_rank[r] = sum of the kept-tile counts of ranks <= r: the scan's first pass gathers cnt_gid[gid_by_rank[r]]
-    return scan_launch(n, cnt_gid, gid_by_rank, cnt_r, cum_by_rank, scan_ws, s);
+    return scan_launch(n, cnt_gid, gid_by_rank, cnt_r, cum_by_rank, scan_ws, s, total_host);
 }
 
 SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
@@ -882,10 +907,29 @@ SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {
     return 3 * al256(ni * 4) + sgn_sort_pairs32_ws_bytes(n_isect);
 }
 
+// `also_zero_words`: int32 words BEHIND tile_bins' 2 * n_tiles that the emission clears as well (the composite forward
+// puts the raster kernels' tile statistics there: one more clear that needs no launch of its own)
+int sgn_bin_intersect_zero(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
+                           const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
+                           int32_t *gaussian_ids_sorted, int32_t *tile_bins, int quadrant_masks, void *ws,
+                           size_t ws_bytes, const int32_t *n_isect_dev, int sort_rank_mode, int also_zero_words,
+                           sgn_stream_t stream);
+
 SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                                  const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
                                  int32_t *gaussian_ids_sorted, int32_t *tile_bins, int quadrant_masks, void *ws,
                                  size_t ws_bytes, const int32_t *n_isect_dev, int sort_rank_mode, sgn_stream_t stream) {
+    return sgn_bin_intersect_zero(n, n_isect, bin_records, cum_by_rank, gid_by_rank, tiles_x, tiles_y, block_width,
+                                  gaussian_ids_sorted, tile_bins, quadrant_masks, ws, ws_bytes, n_isect_dev,
+                                  sort_rank_mode, 0, stream);
+}
+
+int sgn_bin_intersect_zero(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
+                           const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
+                           int32_t *gaussian_ids_sorted, int32_t *tile_bins, int quadrant_masks, void *ws,
+                           size_t ws_bytes, const int32_t *n_isect_dev, int sort_rank_mode, int also_zero_words,
+                           sgn_stream_t stream) {
+    SGN_ARG_CHECK(also_zero_words >= 0, -7);
     SGN_ARG_CHECK(n >= 0 && n_isect >= 0 && n_isect < ((int64_t)1 << 31), -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     SGN_ARG_CHECK(tile_bins != nullptr, -3);
@@ -893,7 +937,7 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
     hipStream_t s = (hipStream_t)stream;
     const int n_tiles = tiles_x * tiles_y;
     if (n_isect == 0 || n == 0) {
-        SGN_HIP_CHECK(hipMemsetAsync(tile_bins, 0, (size_t)n_tiles * 2 * sizeof(int32_t), s));
+        SGN_HIP_CHECK(hipMemsetAsync(tile_bins, 0, ((size_t)n_tiles * 2 + also_zero_words) * sizeof(int32_t), s));
         return 0;
     }
     SGN_ARG_CHECK(bin_records && cum_by_rank && gid_by_rank && gaussian_ids_sorted && ws, -4);
@@ -909,7 +953,7 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
         uint16_t *k16 = (uint16_t *)tkeys, *k16s = (uint16_t *)tkeys_sorted;
         sgn_timing_begin(SGN_T_MAP, s);
         hipLaunchKernelGGL(bin_emit_kernel<uint16_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
-                           recs, tiles_x, tiles_y, block_width, k16, tvals, (int)n_isect, tile_bins, 2 * n_tiles,
+                           recs, tiles_x, tiles_y, block_width, k16, tvals, (int)n_isect, tile_bins, 2 * n_tiles + also_zero_words,
                            quadrant_masks);
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);
@@ -923,7 +967,7 @@ SGN_EXPORT int sgn_bin_intersect(int n, int64_t n_isect, const float *bin_record
     } else {
         sgn_timing_begin(SGN_T_MAP, s);
         hipLaunchKernelGGL(bin_emit_kernel<uint32_t>, dim3(sgn_cdiv(n, 64)), dim3(64), 0, s, n, gid_by_rank, cum_by_rank,
-                           recs, tiles_x, tiles_y, block_width, tkeys, tvals, (int)n_isect, tile_bins, 2 * n_tiles,
+                           recs, tiles_x, tiles_y, block_width, tkeys, tvals, (int)n_isect, tile_bins, 2 * n_tiles + also_zero_words,
                            quadrant_masks);
         sgn_timing_end(SGN_T_MAP, s);
         sgn_timing_begin(SGN_T_SORT, s);

@@ -34,6 +34,12 @@ __device__ __forceinline__ void quat_to_R(float w, float x, float y, float z, fl
     R[2][2] = 1.f - 2.f * (x * x + y * y);
 }
 
+struct QuatCheck {
+    int32_t *flag;   // nullptr: no check
+    float tol;
+    int32_t stamp;   // value a failing row stores
+};
+
 // Optional fused front end (SURVEY.md §8 a8 / north star): the scene graph's per-object rigid transform
 // (sgn_splatfacto_scene_graph.py:404-417: means_w = R m + t, q_w = q_o2w (x) q), the quaternion
 // normalisation (sgn_splatfacto.py:864) and exp(log-scale) (:857) evaluated in registers on load,
@@ -96,13 +102,22 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     int n, const float *__restrict__ means, const float *__restrict__ scales,
     const float *__restrict__ quats, Cam cam, Fuse fuse, float *__restrict__ cov3d, float *__restrict__ xys,
     float *__restrict__ depths, int32_t *__restrict__ radii, float *__restrict__ conics,
-    float *__restrict__ comp, int32_t *__restrict__ num_tiles_hit) {
+    float *__restrict__ comp, int32_t *__restrict__ num_tiles_hit, QuatCheck qc) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float V[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) V[k] = cam.V[k];
     const Loaded LG = load_gaussian<FUSED>(i, means, scales, quats, cam.glob_scale, fuse);
+    if constexpr (FUSED == 0) {
+        // upstream's `quats must be normalized` assertion riding the projection (sgn_project_fwd_all): the quaternion is
+        // in registers anyway.  Same one-sided test as check_unit_quats_kernel below; a failing row STAMPS the flag
+        // (every writer stores the same value: benign race), so a flag that was zero once needs no clear per call.
+        if (qc.flag != nullptr) {
+            const float nrm = sqrtf(LG.q[0] * LG.q[0] + LG.q[1] * LG.q[1] + LG.q[2] * LG.q[2] + LG.q[3] * LG.q[3]);
+            if (!(nrm - 1.f < qc.tol)) *qc.flag = qc.stamp;
+        }
+    }
     const float p0 = LG.p[0], p1 = LG.p[1], p2 = LG.p[2];
     const float pvx = V[0] * p0 + V[1] * p1 + V[2] * p2 + V[3];
     const float pvy = V[4] * p0 + V[5] * p1 + V[6] * p2 + V[7];
@@ -362,12 +377,13 @@ Cam make_cam(const float *V, float fx, float fy, float cx, float cy, int h, int 
 
 // viewmat12 is a DEVICE pointer (the reference hands a device tensor, viewmat.squeeze()[:3,:],
 // sgn_splatfacto.py:865): the kernels read it through wave-uniform scalar loads, so no host sync.
-SGN_EXPORT int sgn_project_fwd(int n, const float *means3d, const float *scales, float glob_scale,
-                               const float *quats, const float *viewmat12, float fx, float fy,
-                               float cx, float cy, int img_h, int img_w, int block_width,
-                               float clip_thresh, float *cov3d, float *xys, float *depths,
-                               int32_t *radii, float *conics, float *compensation,
-                               int32_t *num_tiles_hit, sgn_stream_t stream) {
+int sgn_project_fwd_checked(int n, const float *means3d, const float *scales, float glob_scale,
+                            const float *quats, const float *viewmat12, float fx, float fy,
+                            float cx, float cy, int img_h, int img_w, int block_width,
+                            float clip_thresh, float *cov3d, float *xys, float *depths,
+                            int32_t *radii, float *conics, float *compensation,
+                            int32_t *num_tiles_hit, int32_t *quat_flag, float quat_tol, int32_t quat_stamp,
+                            sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
     SGN_ARG_CHECK(img_h > 0 && img_w > 0, -3);
@@ -378,10 +394,21 @@ SGN_EXPORT int sgn_project_fwd(int n, const float *means3d, const float *scales,
     sgn_timing_begin(SGN_T_PROJECT_FWD, stream);
     hipLaunchKernelGGL(project_fwd_kernel<0>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means3d, scales, quats, cam, Fuse{nullptr, nullptr}, cov3d, xys, depths, radii, conics,
-                       compensation, num_tiles_hit);
+                       compensation, num_tiles_hit, QuatCheck{quat_flag, quat_tol, quat_stamp});
     sgn_timing_end(SGN_T_PROJECT_FWD, stream);
     SGN_LAUNCH_CHECK();
     return 0;
+}
+
+SGN_EXPORT int sgn_project_fwd(int n, const float *means3d, const float *scales, float glob_scale,
+                               const float *quats, const float *viewmat12, float fx, float fy,
+                               float cx, float cy, int img_h, int img_w, int block_width,
+                               float clip_thresh, float *cov3d, float *xys, float *depths,
+                               int32_t *radii, float *conics, float *compensation,
+                               int32_t *num_tiles_hit, sgn_stream_t stream) {
+    return sgn_project_fwd_checked(n, means3d, scales, glob_scale, quats, viewmat12, fx, fy, cx, cy, img_h, img_w,
+                                   block_width, clip_thresh, cov3d, xys, depths, radii, conics, compensation,
+                                   num_tiles_hit, nullptr, 0.f, 0, stream);
 }
 
 SGN_EXPORT int sgn_project_bwd(int n, const float *means3d, const float *scales, float glob_scale,
@@ -424,7 +451,7 @@ SGN_EXPORT int sgn_project_fwd_fused(int n, const float *means_local, const floa
     sgn_timing_begin(SGN_T_PROJECT_FWD, stream);
     hipLaunchKernelGGL(project_fwd_kernel<1>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means_local, log_scales, quats_raw, cam, Fuse{object_ids, poses}, cov3d, xys, depths, radii,
-                       conics, compensation, num_tiles_hit);
+                       conics, compensation, num_tiles_hit, QuatCheck{nullptr, 0.f, 0});
     sgn_timing_end(SGN_T_PROJECT_FWD, stream);
     SGN_LAUNCH_CHECK();
     return 0;

@@ -1419,7 +1419,8 @@ static int raster_fwd_impl(int img_h, int img_w, int block_width, int n, int64_t
                            float *out_img, float *final_Ts, int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes,
                            int rows_built, const int32_t *tile_order, int32_t *tile_kmax,
                            const float *depths, float *out_depth, const int32_t *skip_flag,
-                           const sgn_raster_opts *opts, sgn_stream_t stream, const FwdGroups *groups) {
+                           const sgn_raster_opts *opts, sgn_stream_t stream, const FwdGroups *groups,
+                           int kmax_cleared = 0) {
     const sgn_raster_opts o = resolve_opts(opts);
     // group accumulations ride on the packed two-waves-per-tile forward of the gather mode only
     SGN_ARG_CHECK(groups == nullptr || (o.gather && o.waves_fwd == 2 && block_width == 16 && !window && !skip_flag), -12);
@@ -1443,7 +1444,7 @@ static int raster_fwd_impl(int img_h, int img_w, int block_width, int n, int64_t
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     const Rec *rows = (const Rec *)recs_ws;
     const Rec *stream_recs = rows + n;
-    if (tile_kmax) SGN_HIP_CHECK(hipMemsetAsync(tile_kmax, 0, sizeof(int32_t) * 2 * tiles_x * tiles_y, s));
+    if (tile_kmax && !kmax_cleared) SGN_HIP_CHECK(hipMemsetAsync(tile_kmax, 0, sizeof(int32_t) * 2 * tiles_x * tiles_y, s));
     if (groups) SGN_HIP_CHECK(hipMemsetAsync(Gv.kmax, 0, sizeof(int32_t) * 4 * tiles_x * tiles_y, s));
     sgn_timing_begin(SGN_T_RASTER_FWD, s);
 #define SGN_LAUNCH_FWD(EX, GA, Q, AD, DE)                                                                            \
@@ -1495,6 +1496,19 @@ SGN_EXPORT int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int6
                            opacities, opacity_is_logit, id_lo, id_hi, window, background3, out_img, final_Ts, final_idx,
                            recs_ws, recs_ws_bytes, rows_built, tile_order, tile_kmax, depths, out_depth, skip_flag, opts,
                            stream, nullptr);
+}
+
+// sgn_raster_fwd for a caller inside the library whose earlier launch on the same stream already cleared tile_kmax
+// (api.cpp sgn_rasterize_fwd_all: the emission clears the statistics together with the bins)
+int sgn_raster_fwd_precleared(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                              const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
+                              const float *conics, const float *colors, const float *opacities,
+                              int opacity_is_logit, const float *background3, float *out_img, float *final_Ts,
+                              int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes, const int32_t *tile_order,
+                              int32_t *tile_kmax, const sgn_raster_opts *opts, sgn_stream_t stream) {
+    return raster_fwd_impl(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                           opacities, opacity_is_logit, 0, n, 0, background3, out_img, final_Ts, final_idx, recs_ws,
+                           recs_ws_bytes, 1, tile_order, tile_kmax, nullptr, nullptr, nullptr, opts, stream, nullptr, 1);
 }
 
 // The forward with the two GROUP accumulations riding on it (FwdGroups above): besides everything sgn_raster_fwd

@@ -40,6 +40,14 @@ int sgn_fork_events(hipEvent_t *fork, hipEvent_t *join);   // api.cpp: cached pe
         }                                                                      \
     } while (0)
 
+// project.hip: sgn_project_fwd with upstream's unit-quaternion assertion riding the kernel (quat_flag nullptr: none); a
+// failing row stores quat_stamp into *quat_flag
+int sgn_project_fwd_checked(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
+                            const float *viewmat12, float fx, float fy, float cx, float cy, int img_h, int img_w,
+                            int block_width, float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii,
+                            float *conics, float *compensation, int32_t *num_tiles_hit, int32_t *quat_flag,
+                            float quat_tol, int32_t quat_stamp, sgn_stream_t stream);
+
 static inline int sgn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- replay of a fixed launch chain as a HIP graph (api.cpp).  The binning's chains are a dozen dependent 5-10 us kernels

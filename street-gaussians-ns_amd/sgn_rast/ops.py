@@ -77,6 +77,7 @@ class _State:
         self.walked_permille = None    # ... and the last value the host has seen (quadrant-mask policy)
         self.stat_skipped = 0          # binnings since the statistic was last read back (every eighth one carries it)
         self.eager_side = None         # [pinned int32[8] ring for the eager flag read-back, next slot]
+        self.quat_flag = None          # [device int32[1] zeroed once, stamp of the last call] (sgn_project_fwd_all)
         self.depth_state = {"want": False, "unused": 0, "cache": None}
         self.depth_caches = collections.OrderedDict()                  # binning key -> first pass's channel + state
         self.early = {"entry": None, "misses": 0, "pause": 0}
@@ -410,6 +411,9 @@ activation_proofs = os.environ.get("SGN_ACT_PROOFS", "1") != "0"
 activation_proof_stats = {"project": 0, "opacity": 0, "colors": 0, "window": 0}
 
 
+_QUAT_STAMP_BASE = 1 << 28
+
+
 def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
                      block_width, clip_thresh):
     """Shared by the two projection nodes: launches sgn_project_fwd, returns (outputs, tensors to save)."""
@@ -435,11 +439,18 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
         # depth ranking queued together, the wait for the check's flag last
         lib = L.load()
         S = _S()
-        flag = torch.empty(1, **i32) if plan["check"] else None
-        if plan["check"] and S.eager_side is None:
-            S.eager_side = [torch.empty(8, dtype=torch.int32).pin_memory(), 0]
-        slot = None
+        flag, stamp, slot = None, 0, None
         if plan["check"]:
+            # the device flag of this (device, stream): zeroed ONCE, stamped by a failing row with a per-call counter,
+            # so no call clears it (a launch saved per step); `eager_side`: pinned ring the flag is copied to
+            # (stamps start far above the 0 / 1 the call-by-call check copies into the same pinned ring)
+            if S.quat_flag is None or S.quat_flag[1] >= 2**31 - 2:
+                S.quat_flag = [torch.zeros(1, **i32), _QUAT_STAMP_BASE]
+                S.eager_side = None
+            S.quat_flag[1] += 1
+            flag, stamp = S.quat_flag
+            if S.eager_side is None:
+                S.eager_side = [torch.zeros(8, dtype=torch.int32).pin_memory(), 0]
             ring = S.eager_side
             slot = ring[0][ring[1] % 8:ring[1] % 8 + 1]
             ring[1] += 1
@@ -447,15 +458,16 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
         if plan["rank"]:
             gid = torch.empty(n, **i32)
             ws = L.workspace(lib.sgn_depth_rank_workspace_bytes(n), dev)
-        bad = C.c_int32(0)
         L.check(lib.sgn_project_fwd_all(
             n, L.ptr(means3d_c), L.ptr(scales_c), float(glob_scale), L.ptr(quats_c), L.ptr(viewmat_c),
             float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width), int(block_width),
             float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
-            L.ptr(compensation), L.ptr(num_tiles_hit), int(plan["check"]), 1e-6, L.ptr(flag),
+            L.ptr(compensation), L.ptr(num_tiles_hit), 2 if plan["check"] else 0, 1e-6, L.ptr(flag), int(stamp),
             slot.data_ptr() if slot is not None else None, L.ptr(gid), L.ptr(ws), ws.numel() if ws is not None else 0,
-            L.sort_rank_mode(), C.byref(bad), L.stream_ptr()), "sgn_project_fwd_all")
-        plan["done"], plan["bad"] = True, int(bad.value)
+            L.sort_rank_mode(), None, L.stream_ptr()), "sgn_project_fwd_all")
+        # (check_quats = 2: queued, not waited for — `project_gaussians` waits after autograd has wrapped the outputs:
+        # whatever the host does before the wait is off the step's critical path, the device is busy behind the flag)
+        plan["done"], plan["wait"] = True, ((slot, int(stamp)) if plan["check"] else None)
         if gid is not None:
             d, r = depths.detach(), radii.detach()
             S.early["entry"] = dict(key=(d.data_ptr(), d._version, r.data_ptr(), r._version, n, L.stream_handle()),
@@ -533,7 +545,7 @@ def _check_quats(quats: torch.Tensor):
     S = _S()
     if quat_check == "eager":
         if S.eager_side is None:
-            S.eager_side = [torch.empty(8, dtype=torch.int32).pin_memory(), 0]
+            S.eager_side = [torch.zeros(8, dtype=torch.int32).pin_memory(), 0]
         ring = S.eager_side
         slot = ring[0][ring[1] % 8:ring[1] % 8 + 1]
         ring[1] += 1
@@ -655,7 +667,7 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
     plan = None
     if (composite_forward and quat_check in ("eager", "off") and quats.is_cuda and means3d.is_cuda
             and early_rank_stream == "main" and means3d.shape[-2] >= 1 and means3d.shape[-1] == 3):
-        plan = dict(check=quat_check == "eager", rank=_early_rank_wanted(means3d.shape[-2], True), done=False, bad=0)
+        plan = dict(check=quat_check == "eager", rank=_early_rank_wanted(means3d.shape[-2], True), done=False, wait=None)
     token = _check_quats(quats) if plan is None else None
     _call_state.project_plan = plan
     ls_leaves = x = None
@@ -672,7 +684,11 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
                                       viewmat.contiguous(), fx, fy, cx, cy, img_height, img_width, block_width,
                                       clip_thresh)
     if plan is not None and plan["done"]:
-        assert plan["bad"] == 0, "quats must be normalized"          # (upstream raises from this very call)
+        if plan.get("wait") is not None:
+            slot, stamp = plan["wait"]
+            bad = C.c_int32(0)
+            L.check(L.load().sgn_project_check_wait(slot.data_ptr(), stamp, C.byref(bad)), "sgn_project_check_wait")
+            assert bad.value == 0, "quats must be normalized"        # (upstream raises from this very call)
         return out
     _start_early_rank(out[1], out[2])  # depth ranking queued behind the projection, before the host waits
     _finish_quat_check(token)          # eager mode: the projection is already queued while the host waits here
@@ -1250,9 +1266,11 @@ def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colo
     n_tiles = tx * ty
     qmask = bool(cull and int(block_width) == 16 and n < (1 << QMASK_ID_BITS) and _quadrant_masks_wanted())
     ids = torch.empty(cap, **i32)
-    tile_bins = torch.empty(n_tiles, 2, **i32)
+    # bins and tile statistics in ONE buffer, statistics right behind the bins: the emission then clears both and
+    # neither costs a clear launch of its own (sgn_rasterize_fwd_all recognises the layout)
+    bins_and_stats = torch.empty(2, n_tiles, 2, **i32)
+    tile_bins, tile_kmax = bins_and_stats[0], bins_and_stats[1]
     order = torch.empty(n_tiles + 2, **i32)
-    tile_kmax = torch.empty(n_tiles, 2, **i32)
     rows = L.workspace(lib.sgn_raster_workspace_bytes(n, 0, ro_ptr), dev)
     arena = L.workspace(lib.sgn_rasterize_arena_bytes(n, cap), dev)
     scratch = None

@@ -281,6 +281,25 @@ def test_quat_assertion_deferred_and_eager():
         ops.quat_check = "eager"
         with pytest.raises(AssertionError, match="quats must be normalized"):
             ops.project_gaussians(*args(bad))
+        # the one-call form stamps a device word that is never cleared: a failure must not outlive its call, and a
+        # later failure must be seen again (NaN fails upstream's one-sided test too)
+        nan = good.clone()
+        nan[3, 2] = float("nan")
+        for comp in (True, False):
+            old_comp, ops.composite_forward = ops.composite_forward, comp
+            try:
+                for q, fails in ((good, False), (bad, True), (good, False), (nan, True), (bad, True), (good, False)):
+                    if fails:
+                        with pytest.raises(AssertionError, match="quats must be normalized"):
+                            ops.project_gaussians(*args(q))
+                    else:
+                        exp = ops.project_gaussians(*args(q))
+                ops.quat_check = "off"
+                ref = ops.project_gaussians(*args(good))
+                ops.quat_check = "eager"
+                assert all(torch.equal(a, b) for a, b in zip(exp, ref))     # the riding check changes no output
+            finally:
+                ops.composite_forward = old_comp
         ops.quat_check = "deferred"
         xys, depths, radii, conics, _c, nth, _cov = ops.project_gaussians(*args(bad))      # no sync, no raise yet
         rgbs = torch.rand(500, 3, device="cuda")
