@@ -515,3 +515,61 @@ def test_one_call_forward_equals_the_call_by_call_path():
         torch.cuda.synchronize()
         assert ops.composite_stats["capacity_misses"] == misses + 1 and ops.binning_stats["speculative_hits"] == hits
         assert torch.equal(c[0], a[0]) and torch.equal(c[2], a[2]) and torch.equal(c[3], a[3])
+
+
+def test_project_fwd_all_at_the_c_abi_in_every_form_of_its_check():
+    """`sgn_project_fwd_all` as a non-Python host would bind it: the assertion's flag cleared by the call (flag_stamp 0,
+    device flag, pageable read-back), stamped into a device word, stamped straight into mapped pinned memory; waited
+    for inside the call (check_quats 1) or by `sgn_project_check_wait` (2); argument errors.  Outputs equal
+    `sgn_project_fwd`'s in every form."""
+    import ctypes as C
+
+    from sgn_rast import _lib as L, scenes
+    lib = L.load()
+    cam, raw = scenes.make_scene("c1", seed=2, device="cuda", n_override=4000)
+    n = 4000
+    scales = torch.exp(raw["log_scales"]).contiguous()
+    good = (raw["quats"] / raw["quats"].norm(dim=-1, keepdim=True)).contiguous()
+    bad = good.clone()
+    bad[1234] *= 1.01
+    V = cam.viewmat[:3, :].contiguous().reshape(-1)
+    f32, i32 = dict(dtype=torch.float32, device="cuda"), dict(dtype=torch.int32, device="cuda")
+
+    def outs():
+        return [torch.empty(n, 6, **f32), torch.empty(n, 2, **f32), torch.empty(n, **f32), torch.empty(n, **i32),
+                torch.empty(n, 3, **f32), torch.empty(n, **f32), torch.empty(n, **i32)]
+    ref = outs()
+    L.check(lib.sgn_project_fwd(n, L.ptr(raw["means"]), L.ptr(scales), 1.0, L.ptr(good), L.ptr(V), cam.fx, cam.fy, cam.cx,
+                                cam.cy, cam.height, cam.width, 16, 0.01, *[L.ptr(t) for t in ref], L.stream_ptr()), "fwd")
+
+    def call(q, mode, stamp, flag_dev, pinned, want_rc=0):
+        o = outs()
+        bad_host = C.c_int32(-7)
+        rc = lib.sgn_project_fwd_all(n, L.ptr(raw["means"]), L.ptr(scales), 1.0, L.ptr(q), L.ptr(V), cam.fx, cam.fy,
+                                     cam.cx, cam.cy, cam.height, cam.width, 16, 0.01, *[L.ptr(t) for t in o], mode, 1e-6,
+                                     L.ptr(flag_dev), stamp, pinned.data_ptr() if pinned is not None else None, None, None,
+                                     0, L.sort_rank_mode(), C.byref(bad_host), L.stream_ptr())
+        assert rc == want_rc, (rc, lib.sgn_last_error())
+        if rc:
+            return None
+        if mode == 2:
+            L.check(lib.sgn_project_check_wait(pinned.data_ptr(), stamp, C.byref(bad_host)), "wait")
+        torch.cuda.synchronize()
+        if q is good:
+            assert all(torch.equal(a, b) for a, b in zip(o, ref))
+        return bad_host.value
+    flag = torch.zeros(1, **i32)
+    pinned = torch.zeros(4, dtype=torch.int32).pin_memory()
+    # cleared by the call, pageable read-back
+    assert call(good, 1, 0, flag, None) == 0 and call(bad, 1, 0, flag, None) == 1 and call(good, 1, 0, flag, None) == 0
+    # stamped, pinned slot (mapped: stored straight into it), waited for inside / outside the call; no device flag needed
+    for mode in (1, 2):
+        for k, (q, want) in enumerate(((good, 0), (bad, 1), (good, 0), (bad, 1))):
+            assert call(q, mode, 100 * mode + k + 1, None, pinned[mode:mode + 1]) == want
+    assert int(pinned[1]) == 104 and int(pinned[2]) == 204          # the last failing stamps, still there: never cleared
+    # no check at all
+    assert call(bad, 0, 0, None, None) == -7
+    # argument errors
+    call(good, 3, 0, flag, None, want_rc=-3)
+    call(good, 1, 0, None, None, want_rc=-1)          # cleared form needs the device flag
+    call(good, 2, 5, flag, None, want_rc=-1)          # the split wait needs the pinned slot
