@@ -110,7 +110,7 @@ int sgn_project_fwd(int n, const float *means3d, const float *scales, float glob
 int sgn_check_unit_quats(int n, const float *quats, float tol, int32_t *flag, sgn_stream_t stream);
 
 /* `project_gaussians` as ONE call (round 5; no upstream counterpart): sgn_project_fwd with upstream's quats assertion
- * riding the projection kernel (check_quats != 0: a row of quats [n,4], 16-byte aligned, that fails `norm - 1 < quat_tol`
+ * riding the projection kernel (check_quats != 0: a row of quats [n,4] that fails `norm - 1 < quat_tol`
  * STAMPS *flag_dev; the flag is copied to flag_pinned — pinned host int32, NULL = pageable — behind the kernel), and —
  * gid_by_rank != NULL — sgn_depth_rank of the coming binning, all queued on `stream`; only then does the call wait for
  * the flag and report *quats_bad_host (1: some row failed; the host raises upstream's assertion).  flag_stamp > 0: the

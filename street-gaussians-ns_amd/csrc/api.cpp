@@ -107,7 +107,6 @@ int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float 
         const int mode = check_quats;
         if (mode != 1 && mode != 2) { sgn_set_error("sgn_project_fwd_all: check_quats must be 0, 1 or 2"); return -3; }
         if ((!flag_dev && !(flag_stamp > 0 && flag_pinned)) || (mode == 1 && !quats_bad_host) || (mode == 2 && !flag_pinned)) { sgn_set_error("sgn_project_fwd_all: check_quats needs flag_dev and quats_bad_host (1) / flag_pinned (2)"); return -1; }
-        if (n > 0 && (!quats || (reinterpret_cast<uintptr_t>(quats) & 15) != 0)) { sgn_set_error("sgn_project_fwd_all: quats must be 16-byte aligned"); return -2; }
         if (flag_stamp <= 0) {
             if (!flag_dev) { sgn_set_error("sgn_project_fwd_all: flag_stamp <= 0 needs flag_dev"); return -1; }
             const hipError_t e = hipMemsetAsync(flag_dev, 0, sizeof(int32_t), s);
@@ -220,6 +219,7 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
     // the count goes straight from the scan into count_pinned where that is mapped into the device's address space (no
     // copy command, no bubble behind it), by a copy otherwise; everything queued below runs while it travels
     int32_t *direct = mapped(count_pinned);
+    if (direct) *count_pinned = -1;            // poison: a count that has not landed when the event fires is noticed below
     int rc = sgn_bin_prepare_total(n, xys, depths, radii, do_cull ? conics : nullptr, do_cull ? opacities : nullptr,
                                    opacity_is_logit, do_cull, tiles_x, tiles_y, block_width, cum_r, gid,
                                    gid_by_rank_ready ? 1 : 0, bin_recs, ws1, ws1_bytes, sort_rank_mode, direct, stream);
@@ -245,7 +245,11 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
     if (rc) return rc;
     e = hipEventSynchronize(ev);                       // the path's one host sync (upstream: `.item()` on the count)
     if (e != hipSuccess) { sgn_set_error("sgn_rasterize_fwd_all: %s", hipGetErrorString(e)); return (int)e; }
-    const int64_t count = (int64_t)*dst;
+    if (direct && *(volatile int32_t *)dst == -1) {    // never seen; the plain copy is the safety net
+        e = hipMemcpy(dst, cum_r + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { sgn_set_error("sgn_rasterize_fwd_all: count copy: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    const int64_t count = (int64_t)*(volatile int32_t *)dst;
     *n_isect_host = count;
     if (count > isect_capacity) return SGN_E_CAPACITY;   // the list did not fit: call again with more room
     if (count < 1) return 0;                             // nothing visible: the caller writes the background image
