@@ -940,7 +940,8 @@ binning_stats = {"speculative_hits": 0, "speculative_misses": 0, "binnings": 0}
 
 tile_order_enabled = True
 tile_order_multiblock = os.environ.get("SGN_TILE_ORDER_MB", "1") != "0"   # the multi-workgroup form of sgn_tile_order
-concurrent_backward = True   # lend sgn_raster_bwd a second stream: its short-walk and long-walk kernels overlap
+# lend sgn_raster_bwd a second stream: its short-walk and long-walk kernels overlap ("0": one stream, long walks first)
+concurrent_backward = os.environ.get("SGN_BWD_CONCURRENT", "1") != "0"
 small_splat_q16 = 0       # experimental: > 0 sends tiles with < q/16 evaluated (entry, quadrant) pairs per walked entry to the 4-waves kernel (no gain measured: profiles/r02_street_balance.md)
 
 
