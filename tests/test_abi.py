@@ -88,6 +88,13 @@ def test_argument_errors_are_reported_without_a_gpu(built_lib):
         assert built_lib.opts() is priv and priv.exact_exp == 1
     assert built_lib.opts().exact_exp == 0
     assert lib.sgn_scan_workspace_bytes(5000) >= 12
+    # the one-call projection: check modes are 0 / 1 / 2, the cleared flag needs a device word, the split wait a pinned one
+    pf = lambda mode, stamp: lib.sgn_project_fwd_all(4, None, None, 1.0, None, None, 1.0, 1.0, 0.0, 0.0, 8, 8, 16, 0.01,
+                                                      None, None, None, None, None, None, None, mode, 1e-6, None, stamp,
+                                                      None, None, None, 0, 0, None, None)
+    assert pf(3, 0) == -3 and b"check_quats" in lib.sgn_last_error()
+    assert pf(1, 0) == -1 and pf(2, 7) == -1
+    assert lib.sgn_project_check_wait(None, 1, None) == -1 and b"NULL" in lib.sgn_last_error()
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
