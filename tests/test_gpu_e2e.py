@@ -477,6 +477,7 @@ def test_one_call_forward_equals_the_call_by_call_path():
         return out, keep + ({k: p.grad.clone() for k, p in P.items()},)
 
     res = {}
+    old_check, ops.quat_check = ops.quat_check, "eager"   # (a deferred check rides the call-by-call path's read-back slot)
     with L.options(exact_exp=1):
         for mode in (False, True):
             ops.composite_forward = mode
@@ -515,6 +516,7 @@ def test_one_call_forward_equals_the_call_by_call_path():
         torch.cuda.synchronize()
         assert ops.composite_stats["capacity_misses"] == misses + 1 and ops.binning_stats["speculative_hits"] == hits
         assert torch.equal(c[0], a[0]) and torch.equal(c[2], a[2]) and torch.equal(c[3], a[3])
+    ops.quat_check = old_check
 
 
 def test_project_fwd_all_at_the_c_abi_in_every_form_of_its_check():
