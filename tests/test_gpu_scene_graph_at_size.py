@@ -14,6 +14,9 @@ Both call patterns: the DROP-IN one (the reference's own aggregation in torch, s
 copies -> `ops._match_window`) and the FUSED one (`sgn_rast.fused`: rigid transform, Fourier DC, activations in the
 kernels; sub-model passes as `id_range` over the shared list).
 
+Round 5 adds the same comparison WITHOUT a band (`..._over_the_whole_image`): every pixel of all four passes weighted, the C
+oracle composites and differentiates the whole 1920x1280 image of each pass on the host's cores (~8 s).
+
 Tolerance: rel-L2 <= 1e-4 per tensor, image bands mean |err| < 1e-6.
 """
 import pytest
@@ -108,9 +111,40 @@ def expected(scene, production_defaults):
     return dict(out=exp, leaves=Mc, rows=(row_lo, row_hi))
 
 
+@pytest.fixture(scope="module")
+def expected_whole(scene, production_defaults):
+    """No band (round 5): weights on every pixel of all four passes, the C oracle composites and differentiates the whole
+    1920x1280 image of each pass (pixel rows split over the host's cores)."""
+    import os
+
+    import oracle_ops
+    from oracle import c_oracle as CO
+    from sgn_rast import step
+    cam, models, poses, idft = scene
+    w = _weights(cam, 0, cam.height)
+    Mc = [step.leaf_params(m) for m in models]
+    oracle_ops.PIXEL_ROWS = None
+    threads, CO.THREADS = CO.THREADS, max(1, min(32, (os.cpu_count() or 2) - 1))
+    try:
+        exp = step.render_scene_graph(Mc, poses, idft, cam, ops=oracle_ops)
+        _loss(exp, cam, w).backward()
+    finally:
+        CO.THREADS = threads
+    return dict(out=exp, leaves=Mc, rows=(0, cam.height))
+
+
+@pytest.mark.parametrize("path", ["dropin", "fused"])
+def test_scene_graph_step_matches_oracle_over_the_whole_image(path, scene, expected_whole, production_defaults):
+    _run_and_compare(path, 1, scene, expected_whole, production_defaults)
+
+
 @pytest.mark.parametrize("path", ["dropin", "fused"])
 @pytest.mark.parametrize("reduce_mode", [1, 0])
 def test_scene_graph_step_matches_oracle_at_size(path, reduce_mode, scene, expected, production_defaults):
+    _run_and_compare(path, reduce_mode, scene, expected, production_defaults)
+
+
+def _run_and_compare(path, reduce_mode, scene, expected, production_defaults):
     from sgn_rast import ops, scenes, step
     lib = production_defaults
     cam, models, poses, idft = scene
