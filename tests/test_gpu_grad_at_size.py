@@ -52,13 +52,13 @@ def _second_band(name, n_tile_rows, hot_lo):
             return lo
 
 
-def _hip_step(cam, raw, w_img, w_a):
+def _hip_step(cam, raw, w_img, w_a, fused=False):
     from sgn_rast import ops, scenes, step
     cam_d = scenes.Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.viewmat.to(DEV),
                           cam.cam_pos.to(DEV))
     P = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
     ops.clear_binning_cache()
-    out = step.train_step(P, cam_d, w_img.to(DEV), w_a.to(DEV))
+    out = step.train_step(P, cam_d, w_img.to(DEV), w_a.to(DEV), fused=fused)
     torch.cuda.synchronize()
     return P, out
 
@@ -218,17 +218,19 @@ def test_train_step_gradients_match_oracle_over_the_whole_image(name, production
         exp = step.train_step(Pc, cam, w_img, w_a, ops=oracle_ops)
     finally:
         CO.THREADS = threads
-    Pd, got = _hip_step(cam, raw, w_img, w_a)
-    n = exp.radii.numel()
-    assert int((got.radii.cpu() != exp.radii).sum()) <= max(2, n // 100_000)       # (torch's exp: GPU vs CPU, see above)
-    for attr in ("rgb", "alpha"):
-        err = (getattr(got, attr).detach().cpu() - getattr(exp, attr).detach()).abs()
-        assert float(err.mean()) < 1e-6 and float((err > 1e-5).float().mean()) < 2e-3, (attr, float(err.mean()))
-    assert rel_l2(got.xys.grad.cpu(), exp.xys.grad) < 1e-4
-    for k in Pd:
-        r = rel_l2(Pd[k].grad.cpu(), Pc[k].grad)
-        assert r < 1e-4, (name, k, r)
-        assert float(Pc[k].grad.abs().sum()) > 0, k
-    # rows no pixel reaches get exact zeros from both sides
-    dead = (exp.radii == 0)
-    assert float(Pd["means"].grad.cpu()[dead].abs().sum()) == 0.0
+    for fused in (False, True):      # the drop-in operators, then the fused front ends (activations / view dirs in-kernel)
+        Pd, got = _hip_step(cam, raw, w_img, w_a, fused=fused)
+        n = exp.radii.numel()
+        assert int((got.radii.cpu() != exp.radii).sum()) <= max(2, n // 100_000)   # (torch's exp: GPU vs CPU, see above)
+        for attr in ("rgb", "alpha"):
+            err = (getattr(got, attr).detach().cpu() - getattr(exp, attr).detach()).abs()
+            assert float(err.mean()) < 1e-6 and float((err > 1e-5).float().mean()) < 2e-3, (fused, attr, float(err.mean()))
+        if not fused:
+            assert rel_l2(got.xys.grad.cpu(), exp.xys.grad) < 1e-4
+        for k in Pd:
+            r = rel_l2(Pd[k].grad.cpu(), Pc[k].grad)
+            assert r < 1e-4, (name, fused, k, r)
+            assert float(Pc[k].grad.abs().sum()) > 0, k
+        # rows no pixel reaches get exact zeros from both sides
+        dead = (exp.radii == 0)
+        assert float(Pd["means"].grad.cpu()[dead].abs().sum()) == 0.0
