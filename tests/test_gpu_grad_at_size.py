@@ -234,3 +234,63 @@ def test_train_step_gradients_match_oracle_over_the_whole_image(name, production
         # rows no pixel reaches get exact zeros from both sides
         dead = (exp.radii == 0)
         assert float(Pd["means"].grad.cpu()[dead].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["dropin", "fused"])
+def test_training_configuration_matches_oracle_over_the_whole_image(fused, production_defaults):
+    """The shape of a real training step at the metric size (what `bench.py --sky --photometric` times): the sky sphere
+    blended behind the splats (`sgn_splatfacto.py:875-876, 969-972`; eval-mode rays), the reference's photometric loss —
+    (1 - l) L1 + l (1 - SSIM) over the whole 1920x1280 image (`:1084-1087`) — plus the accumulation term.  Expected: the
+    C-oracle operators, the oracle's cube-map lookup and the oracle's loss; got: HIP operators, HIP sky, HIP loss, as
+    drop-in calls and through the fused front ends (lookup + blend and clamp + loss in one kernel each)."""
+    import os
+
+    import oracle_ops
+    from oracle import c_oracle as CO, torch_oracle as TO
+    from sgn_rast import scenes, step
+    cam, raw = _scene("metric")
+    H, W = cam.height, cam.width
+    g = torch.Generator().manual_seed(31)
+    gt = torch.rand(H, W, 3, generator=g)
+    _w_img, w_a = step.loss_weights(cam, seed=17)
+    R = 128
+    f = torch.arange(6)[:, None, None].expand(6, R, R).reshape(-1)
+    iy = torch.arange(R)[None, :, None].expand(6, R, R).reshape(-1)
+    ix = torch.arange(R)[None, None, :].expand(6, R, R).reshape(-1)
+    d = torch.nn.functional.normalize(TO._cube_dir(f, (ix + 0.5) / R, (iy + 0.5) / R), dim=-1)
+    tex = (0.5 + 0.25 * torch.stack([torch.sin(2 * d[:, 0]) * d[:, 1], d[:, 2] * d[:, 0], torch.cos(3 * d[:, 1])], -1)
+           ).reshape(6, R, R, 3).contiguous()           # smooth: an ulp in a ray direction does not flip a texel
+    c2w = torch.zeros(3, 4)
+    c2w[:, :3] = cam.viewmat[:3, :3].T
+
+    def sky_fn(base, h, w, fx, fy, cx, cy, c2w_, jitter):
+        return TO.cube_texture(base, TO.env_light_directions(h, w, fx, fy, cx, cy, c2w_, jitter))
+
+    def loss_fn(rgb, gt_, lam):
+        l1, s = TO.l1_ssim_losses(rgb, gt_)
+        return (1 - lam) * l1 + lam * (1 - s)
+    Pc = step.leaf_params(raw)
+    tex_c = tex.clone().requires_grad_(True)
+    oracle_ops.PIXEL_ROWS = None
+    threads, CO.THREADS = CO.THREADS, max(1, min(32, (os.cpu_count() or 2) - 1))
+    try:
+        exp = step.train_step(Pc, cam, _w_img, w_a, ops=oracle_ops, gt=gt, loss_fn=loss_fn,
+                              sky={"base": tex_c, "c2w": c2w, "train": False, "fn": sky_fn})
+    finally:
+        CO.THREADS = threads
+    cam_d = scenes.Camera(W, H, cam.fx, cam.fy, cam.cx, cam.cy, cam.viewmat.to(DEV), cam.cam_pos.to(DEV))
+    Pd = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+    tex_d = tex.to(DEV).requires_grad_(True)
+    from sgn_rast import ops
+    ops.clear_binning_cache()
+    got = step.train_step(Pd, cam_d, _w_img.to(DEV), w_a.to(DEV), gt=gt.to(DEV), fused=fused,
+                          sky={"base": tex_d, "c2w": c2w.to(DEV), "train": False})
+    torch.cuda.synchronize()
+    assert abs(float(got.loss) - float(exp.loss)) < 2e-6 * max(1.0, abs(float(exp.loss))), (float(got.loss), float(exp.loss))
+    err = (got.rgb.detach().cpu() - exp.rgb.detach()).abs()
+    assert float(err.mean()) < 2e-6 and float((err > 2e-5).float().mean()) < 2e-3, float(err.mean())
+    for k in Pd:
+        r = rel_l2(Pd[k].grad.cpu(), Pc[k].grad)
+        assert r < 5e-4, (fused, k, r)
+    assert rel_l2(tex_d.grad.cpu(), tex_c.grad) < 2e-3
+    assert float(tex_c.grad.abs().sum()) > 0
