@@ -170,6 +170,57 @@ def test_row_exchange_over_single_rank_rccl_group():
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("name", ["metric", "street"])
+def test_row_exchange_at_the_benchmark_size_equals_the_plain_step(name):
+    """The N-rank step's default exchange at BASELINE size (1 M Gaussians, 1920x1280; the street-like content walks long
+    non-saturating lists) over a 1-rank RCCL group: the walked list holds every touched row and is no loose superset, the
+    row exchange is taken on the saturating content and the dense sequence on the street-like one (it touches more than
+    `sparse_max_fraction` of the rows), and either way the gradients equal the plain single-process step's with the same
+    exact-zero rows."""
+    import torch.distributed as dist
+    from sgn_rast import dp, ops, scenes, step
+    cam, raw = scenes.make_scene("metric")
+    if name == "street":
+        raw = scenes.make_street_gaussians(raw["means"].shape[0], cam, seed=0)
+    n = raw["means"].shape[0]
+    cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+    w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+    Pa = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+    ops.clear_binning_cache()
+    step.train_step(Pa, cam, w_img, w_a)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        Pb = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+        ex = dp.SHGradExchange(Pb["features_dc"], Pb["features_rest"], force=True).install().set_view(Pb["means"], cam.cam_pos)
+        red = dp.GradAllReducer(list(Pb.values()), big=[Pb["features_rest"]], sh_exchange=ex, force=True, sparse=True)
+        try:
+            for it in range(2):
+                ops.clear_binning_cache()
+                step.train_step(Pb, cam, w_img, w_a, reducer=red)
+        finally:
+            ex.remove()
+            red.remove()
+        torch.cuda.synchronize()
+        # saturating content: a view touches < 1 % of the rows -> the row exchange; the street-like content walks its long
+        # lists to the end and touches more than sparse_max_fraction (0.3) of them -> the dense sequence, decided per step
+        expect = "sparse_steps" if name == "metric" else "dense_steps"
+        assert red.stats[expect] == 2 and red.stats.get("outside_rows", 0) == 0, red.stats
+        touched = torch.zeros(n, dtype=torch.bool, device=DEV)
+        for k in Pa:
+            za, zb = Pa[k].grad.reshape(n, -1).abs().sum(1) == 0, Pb[k].grad.reshape(n, -1).abs().sum(1) == 0
+            assert torch.equal(za, zb), k
+            touched |= ~za
+            assert rel_l2(Pb[k].grad, Pa[k].grad) < 5e-5, (name, k)   # (two runs of one step: the atomics' order)
+        sent = int(red.stats.get("rows_sent", 0))
+        if name == "metric":
+            assert 0 < int(touched.sum()) < n // 50                 # a view touches a small part of the model ...
+        if sent:
+            assert int(touched.sum()) <= sent // 2 <= 3 * int(touched.sum()) + 64, (sent, int(touched.sum()))   # (2 steps)
+    finally:
+        dist.destroy_process_group()
+
+
 def _one_step_with_extra_loss(P, cam, w_img, w_a, reducer, extra):
     """`step.train_step`'s sequence with a loss term beside the rendered images."""
     from sgn_rast import step
