@@ -170,17 +170,21 @@ def cpu_baseline(scene: str, n_override: int, rows: int, frac: int = 8):
                    + f" -> {t_full:.1f}s/step"),
     }
     res["c_port"] = cpu_baseline_c(scene, n_override, every=int(os.environ.get("SGN_BENCH_C_EVERY", "1")))
+    # third figure (round 5): the same C port with its compositing (forward and reverse walk, the bulk of the step) split
+    # over the host's cores by pixel rows — one WHOLE step MEASURED on all cores, nothing extrapolated
+    res["c_port_all_cores"] = cpu_baseline_c(scene, n_override, every=1, threads=cores)
     # which of the two is THE baseline: BASELINE.json's north_star names "a pure-PyTorch CPU rasterizer
     # timed on the same box's host cores" — that is `value` (all cores, but extrapolated from a bounded sample, as the
     # contract's 10-30 s budget demands); `c_port` is the cross-check that is measured WHOLE (one core, nothing
     # extrapolated).  They are different programs on different core counts and are not comparable core for core.
     res["baseline_of_record"] = ("cpu_baseline.value: the pure-PyTorch rasterizer BASELINE.json names (all host cores, "
                                  "extrapolated from the bounded sample described in `sample`); cpu_baseline.c_port is a "
-                                 "second, fully measured figure (plain-C scalar port, one core, one whole step)")
+                                 "second, fully measured figure (plain-C scalar port, one core, one whole step), "
+                                 "cpu_baseline.c_port_all_cores a third (the same port with its compositing on all cores)")
     return res
 
 
-def cpu_baseline_c(scene: str, n_override: int, every: int = 1):
+def cpu_baseline_c(scene: str, n_override: int, every: int = 1, threads: int = 1):
     """Second CPU number, MEASURED: the scalar plain-C restatement (oracle/c/sgn_oracle.c, one core) runs ONE WHOLE
     train-step image — projection, SH, binning, compositing of every pixel, the full backward — on all the Gaussians
     (every = 1: nothing is sampled or extrapolated; ~14 s on the GPU box's host).  every > 1 composites only every
@@ -196,12 +200,19 @@ def cpu_baseline_c(scene: str, n_override: int, every: int = 1):
     w_img, w_a = step.loss_weights(cam, seed=7)
     n_all = raw['means'].shape[0]
     if every <= 1:
-        t0 = time.perf_counter()
-        step.train_step(P, cam, w_img, w_a, ops=oracle_ops)
-        t_full = time.perf_counter() - t0
-        return {"value": 1.0 / t_full, "unit": "images/sec", "cores": 1, "kind": "port",
-                "sample": (f"plain-C scalar oracle, scene '{scene}' {cam.width}x{cam.height}, ALL {n_all} Gaussians, every "
-                           f"pixel, fwd+bwd: one whole train-step image measured, {t_full:.1f}s/step (nothing extrapolated)")}
+        old_threads, CO.THREADS = CO.THREADS, max(1, int(threads))
+        try:
+            t0 = time.perf_counter()
+            step.train_step(P, cam, w_img, w_a, ops=oracle_ops)
+            t_full = time.perf_counter() - t0
+        finally:
+            CO.THREADS = old_threads
+        how = ("one core" if threads <= 1 else
+               f"compositing fwd+bwd on {int(threads)} threads over pixel rows, projection / SH / binning on one")
+        return {"value": 1.0 / t_full, "unit": "images/sec", "cores": max(1, int(threads)), "kind": "port",
+                "sample": (f"plain-C scalar oracle ({how}), scene '{scene}' {cam.width}x{cam.height}, ALL {n_all} Gaussians, "
+                           f"every pixel, fwd+bwd: one whole train-step image measured, {t_full:.1f}s/step (nothing "
+                           "extrapolated)")}
     rows = list(range(every // 2, tiles_y, every))
     mask = torch.zeros(cam.height, 1)
     for r in rows:
