@@ -153,6 +153,9 @@ def test_bench_cpu_baseline_leg_runs_without_a_gpu():
     d = json.loads(line)
     assert d["unit"] == "images/sec" and d["kind"] == "port" and d["value"] > 0 and d["cores"] >= 1
     assert "2500 of 10000 Gaussians" in d["sample"]
+    # the two fully measured figures of the plain-C port: one core, and its compositing on all cores
+    assert d["c_port"]["cores"] == 1 and d["c_port"]["value"] > 0 and "nothing extrapolated" in d["c_port"]["sample"]
+    assert d["c_port_all_cores"]["cores"] >= 1 and d["c_port_all_cores"]["value"] > 0
 
 
 def test_quaternion_multiply_shim_on_cpu_is_pytorch3d_formula():
