@@ -42,11 +42,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--settle", type=int, default=0,
-                    help="extra untimed steps BEFORE the W warm-up steps (same count on every rank: the steps contain "
-                         "collectives), for boxes whose clocks / allocator / RCCL channels need longer than a short "
-                         "warm-up (W=5, K=20 is a 30 ms window).  Default 0: exactly W warm-up steps, as the contract "
-                         "says; measured on two boxes, 100 settle steps made no difference (629 vs 632 images/s)")
+    ap.add_argument("--settle", type=int, default=60,
+                    help="untimed initialisation steps BEFORE the W warm-up steps (same count on every rank: the steps "
+                         "contain collectives): the library's caches, the allocator, RCCL's channels and the DEVICE'S CLOCKS "
+                         "reach their steady state.  The driver's W=5 warm-up steps are 6 ms of device work, shorter than "
+                         "the clock ramp of a device that has idled through the host-side set-up: on some boxes the first "
+                         "timed chunk of 20 steps then ran 1.66-1.72 ms/step against 1.25-1.28 for every later chunk "
+                         "(profiles/r05aa_settle_ab.log: 4 of 10 runs on one box, 1 of 1 on another), with 60 settle "
+                         "steps (~80 ms of device work) 0 of 26 runs.  The W warm-up steps and the K timed steps follow "
+                         "unchanged; the line reports `config.settle_steps`.  0: none.")
     ap.add_argument("--scene", default="metric", choices=["c1", "c2", "metric", "c4"])
     ap.add_argument("--n", "--gaussians", dest="n", type=int, default=0,
                     help="override the number of Gaussians (under torch.distributed.run spell it --gaussians: the "
@@ -471,9 +475,9 @@ def main():
 
     def measure_headline(settle):
         """W untimed steps, then EXACTLY K timed steps between barrier + synchronize pairs; max over ranks."""
-        for _ in range(max(0, settle)):
-            one_step()
-        torch.cuda.synchronize()
+        if settle > 0:
+            one_step()                     # (first call: workspaces, capacities, policies — so the collection below sees them)
+            torch.cuda.synchronize()
         # A full (generation-2) garbage collection over the ~1e6 objects that importing torch leaves behind takes ~50 ms
         # on this host and lands somewhere inside a 200-step window (profiles/r02e: one 20-step chunk at 4.07 ms/step,
         # the rest at 1.60).  Standard remedy for latency-sensitive loops: collect now and move the survivors to the
@@ -483,6 +487,9 @@ def main():
         gc.collect()
         if os.environ.get("SGN_BENCH_GC_FREEZE", "1") == "1":
             gc.freeze()
+        # the settle steps run back to back with the warm-up and the timed steps: nothing idles the device in between
+        for _ in range(max(0, settle - 1)):
+            one_step()
         for _ in range(args.warmup):
             out_ = one_step()
         barrier(); torch.cuda.synchronize()
@@ -835,12 +842,15 @@ def main():
         workload_key = ("scene_graph_" + args.path if sg is not None else "street" if args.street else
                         args.scene if not (args.n or args.translucent or args.sky) else None)
         traffic, pmc, pmc_info = None, None, {"file": "profiles/roofline_pmc.json"}
+        slots_measured = None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "roofline_pmc.json")))
             here = hashlib.sha256(open(os.path.join(ROOT, "street-gaussians-ns_amd", "csrc", "raster.hip"), "rb").read()).hexdigest()
             pmc_info.update(round=pj.get("round"), git_head=pj.get("git_head"),
                             stale=pj.get("raster_hip_sha256") != here)
             wl = (pj.get("workloads") or {}).get(workload_key) if workload_key else None
+            if wl is not None and not pmc_info["stale"]:
+                slots_measured = wl.get("slots")
             if wl is not None and dom in wl and not pmc_info["stale"]:
                 pmc = wl[dom]
                 traffic = pmc.get("hbm_traffic_bytes")
@@ -884,6 +894,13 @@ def main():
                     per_kernel[k_] = {"ms_per_step": round(ms_, 4), "launch_brackets_per_step": round(cnt_ / k_steps, 2),
                                       "alg_MB_per_step": round(alg_step[k_] / 1e6, 2),
                                       "hbm_frac": round(alg_step[k_] / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                    # measured HBM traffic of the slot's kernels (rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE, replayed from
+                    # profiles/roofline_pmc.json while its stamp matches this raster.hip): traffic above the algorithmic
+                    # bytes = re-reads
+                    m_ = (slots_measured or {}).get(k_)
+                    if m_ is not None:
+                        per_kernel[k_]["hbm_MB_measured"] = round(m_["hbm_bytes_per_step"] / 1e6, 2)
+                        per_kernel[k_]["measured_over_alg"] = round(m_["hbm_bytes_per_step"] / alg_step[k_], 3)
         measured_bound = (pmc or {}).get("bound")
         if sg is not None:
             # the scene graph's raster slots average launches over DIFFERENT lists (main pass, accumulation walks, group

@@ -66,6 +66,32 @@ def kernel_table(a, b, fs, ws):
     return sorted(rows, key=lambda r: -(r["avg_us"] or 0) * (r["calls"] or 1))
 
 
+# timing slot of bench.py (`kernels_avg_ms`) -> substrings of the kernels whose launches the slot brackets
+SLOT_KERNELS = {
+    "project_fwd": ("project_fwd_kernel",), "project_bwd": ("project_bwd_kernel",), "sh_fwd": ("sh_fwd_kernel",),
+    "sh_bwd": ("sh_bwd_",), "scan": ("scan_reduce_kernel", "scan_final_kernel", "scan_partials_kernel"),
+    "map_isect": ("bin_count_kernel", "bin_emit_kernel"), "sort": ("rs_hist_kernel", "rs_scan_kernel", "rs_scatter_kernel"),
+    "tile_bins": ("tile_bins32_kernel",), "pack_records": ("build_grec_kernel",), "unpack_grads": ("unpack_grads_kernel",),
+    "raster_fwd": ("raster_fwd_pk_kernel",), "raster_bwd": ("raster_bwd_short_kernel", "raster_bwd_kernel"),
+}
+
+
+def slot_traffic(fs, ws):
+    """HBM bytes per STEP of every timing slot, measured: sum over the slot's kernels of (2 x FETCH_SIZE + WRITE_SIZE) KiB
+    x launches per step (the two counters come from two passes with their own step counts: launches of the forward
+    raster kernel = steps of that pass)."""
+    def steps(rows):
+        return next(v["dispatches"] for k, v in rows.items() if "raster_fwd_pk_kernel" in k)
+    sf, sw = steps(fs), steps(ws)
+    out = {}
+    for slot, keys in SLOT_KERNELS.items():
+        f = sum(v["FETCH_SIZE"] * v["dispatches"] for k, v in fs.items() if any(t in k for t in keys)) / sf
+        w = sum(v["WRITE_SIZE"] * v["dispatches"] for k, v in ws.items() if any(t in k for t in keys)) / sw
+        out[slot] = {"hbm_bytes_per_step": int((2 * f + w) * 1024), "fetch_KiB_raw_per_step": round(f, 1),
+                     "write_KiB_per_step": round(w, 1)}
+    return out
+
+
 def main(tag):
     cal = table(os.path.join(P, f"{tag}_calib_pmc_a.md"))
     cost = {}
@@ -96,6 +122,9 @@ def main(tag):
         W = {"table": kernel_table(a, b, fs, ws), "source": [os.path.relpath(f, ROOT) for f in files]}
         bench = json.loads(open(bench_file).read().strip().splitlines()[-1]) if os.path.exists(bench_file) else None
         W["workload"] = bench["config"]["workload"] if bench else wkey
+        if wkey == "metric":
+            W["slots"] = slot_traffic(fs, ws)
+            W["slots_source"] = f"profiles/{tag}_pmc_fetch_size.md, {tag}_pmc_write_size.md (every kernel of the step)"
         pairs = ((bench or {}).get("roofline", {}).get("walked") or {}).get("quadrant_pairs_evaluated_fwd")
         # the per-kernel roofline entries bench.py replays belong to the benchmark scene only: there ONE kernel instance
         # serves each raster slot.  On the other workloads a slot spans several instances (short- and long-walk halves of
