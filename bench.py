@@ -641,9 +641,9 @@ def main():
                                "sigmoid folded into the kernels); not the drop-in call path"}
 
     def timed_variant(**kw):
-        for _ in range(max(2, args.warmup // 2)):
+        gc.collect()                       # (before the warm-up: nothing idles the device between it and the timed steps)
+        for _ in range(max(10, args.warmup // 2)):
             one_step(**kw)
-        gc.collect()
         barrier(); torch.cuda.synchronize()
         ts0 = time.perf_counter()
         for _ in range(args.steps):
@@ -752,7 +752,7 @@ def main():
                 return step.render(P, cam, 3, 16, with_depth=with_depth, caller_syncs=True)
 
         def time_fwd(**kw):
-            for _ in range(max(2, args.warmup // 2)):
+            for _ in range(max(20, args.warmup // 2)):      # (~20 ms of device work: see --settle)
                 fwd_only(**kw)
             barrier(); torch.cuda.synchronize()
             t0_ = time.perf_counter()
