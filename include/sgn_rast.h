@@ -39,6 +39,27 @@ typedef void *sgn_stream_t; /* hipStream_t */
 int sgn_version(void);
 const char *sgn_last_error(void);
 
+/* UPSTREAM-VARIANT SEMANTICS (round 6).  gsplat is not vendored by the reference and not installable where this library
+ * is built: three behaviours of gsplat 0.1.x are DECIDED here from recollection of upstream, not read
+ * from its source (SURVEY.md Appendix A marks them [verify] / [decide]).  Each is an ARGUMENT of the calls it touches,
+ * with the decided behaviour as the default (0), so that a mismatch found by running tests/golden/make_upstream_golden.py
+ * against the real gsplat is a flag flip in the caller, not a rewrite:
+ *   `semantics` bit SGN_SEM_BBOX_ADD_AFTER_CAST   tile bbox max side = (int)(c + r) + 1 (gsplat/_torch_impl.py
+ *        get_tile_bbox) instead of the default (int)(c + r + 1) (gsplat helpers.cuh get_bbox).  Differs only for
+ *        -1 < c + r < 0: a splat whose 3-sigma box ends within one tile LEFT of / ABOVE the image is culled by the
+ *        default and listed in tile column / row 0 by the variant.  Carried by every call that computes tile boxes:
+ *        sgn_project_fwd*, sgn_map_isect, sgn_bin_prepare, sgn_rasterize_fwd_all, sgn_rasterize_window_all.
+ *   `semantics` bit SGN_SEM_EWA_VJP_CLAMPED       the projection backward differentiates THROUGH the forward's
+ *        +-1.3 tan(fov/2) clamp of (x/z, y/z) (what autograd through gsplat/_torch_impl.py gives) instead of the
+ *        default, upstream CUDA's project_cov3d_ewa_vjp, which recomputes the Jacobian from the UN-clamped point.
+ *        Carried by sgn_project_bwd* (which then need the image size: img_h, img_w).
+ *   alpha_clamp_bwd (a float argument of sgn_raster_bwd*)   0.99f = upstream's backward clamp (default of the host
+ *        side); 0.999f = the forward's.
+ */
+#define SGN_SEM_DEFAULT 0
+#define SGN_SEM_BBOX_ADD_AFTER_CAST 1
+#define SGN_SEM_EWA_VJP_CLAMPED 2
+
 /* Kernel-selection options of the raster entry points, passed WITH EVERY CALL (NULL = the defaults): the library keeps
  * no mutable configuration of its own, so two threads / streams may rasterize with different settings.  (Round 1 had
  * process-global sgn_set_* switches here; they are gone.) */
@@ -102,7 +123,7 @@ int sgn_project_fwd(int n, const float *means3d, const float *scales, float glob
                     float cy, int img_h, int img_w, int block_width, float clip_thresh,
                     float *cov3d /*[n,6]*/, float *xys /*[n,2]*/, float *depths /*[n]*/,
                     int32_t *radii /*[n]*/, float *conics /*[n,3]*/, float *compensation /*[n]*/,
-                    int32_t *num_tiles_hit /*[n]*/, sgn_stream_t stream);
+                    int32_t *num_tiles_hit /*[n]*/, int semantics /*SGN_SEM_* bits; 0 = default*/, sgn_stream_t stream);
 
 /* gsplat's `assert (quats.norm(dim=-1) - 1 < 1e-6).all()` (project_gaussians.py) as a device-side check: *flag (device
  * int32) becomes 1 if any row of quats [n,4] (16-byte aligned) fails `norm - 1 < tol`.  The host reads the flag at its
@@ -111,25 +132,28 @@ int sgn_check_unit_quats(int n, const float *quats, float tol, int32_t *flag, sg
 
 /* `project_gaussians` as ONE call (round 5; no upstream counterpart): sgn_project_fwd with upstream's quats assertion
  * riding the projection kernel (check_quats != 0: a row of quats [n,4] that fails `norm - 1 < quat_tol`
- * STAMPS *flag_dev; the flag is copied to flag_pinned — pinned host int32, NULL = pageable — behind the kernel), and —
- * gid_by_rank != NULL — sgn_depth_rank of the coming binning, all queued on `stream`; only then does the call wait for
- * the flag and report *quats_bad_host (1: some row failed; the host raises upstream's assertion).  flag_stamp > 0: the
- * value a failing row stores; the caller guarantees *flag_dev holds no value >= flag_stamp when the kernel runs (a word
- * zeroed once, a counter per call on it), and nothing is cleared per call.  flag_stamp <= 0: the call clears the flag
- * itself (one more launch) and stamps 1.  rank_ws: sgn_depth_rank_workspace_bytes(n).
- * Where flag_pinned is mapped into the device's address space (hipHostMalloc'd memory is) and flag_stamp > 0, a failing
- * row stores the stamp straight into *flag_pinned and no copy command is queued (flag_dev may then be NULL); the slot
- * must not already hold a value >= flag_stamp.
+ * STAMPS *flag_dev; the flag is copied to flag_pinned[0] behind the kernel), and — gid_by_rank != NULL — sgn_depth_rank
+ * of the coming binning, all queued on `stream`; only then does the call wait for the flag and report *quats_bad_host
+ * (1: some row failed; the host raises upstream's assertion).
+ * flag_pinned: pinned host int32[2], or NULL (a pageable copy; check_quats = 1 only).  [0] = the stamp if a row failed,
+ * [1] = the stamp once the launch's stores have landed (round 6): the wait refuses to report "normalized" — error -8 —
+ * if [1] never shows the stamp.
+ * flag_stamp > 0: the value a failing row stores; the caller guarantees *flag_dev / the slot holds no value >= flag_stamp
+ * when the kernel runs (a word zeroed once, a counter per call on it), and nothing is cleared per call.  flag_stamp <= 0:
+ * the call clears the flag itself (one more launch) and stamps 1.  rank_ws: sgn_depth_rank_workspace_bytes(n).
+ * Where flag_pinned is mapped into the device's address space (hipHostMalloc'd memory is) and flag_stamp > 0, the kernel
+ * stores both words straight into it (system-scope atomic stores) and no copy command is queued (flag_dev may then be
+ * NULL).
  * check_quats = 2: everything is queued as above but the call does NOT wait (flag_pinned required, quats_bad_host unused):
- * the caller finishes its own host-side bookkeeping and then calls sgn_project_check_wait — same thread, same device,
- * no other call of this library in between — which waits for the flag and reports it. */
+ * the caller finishes its own host-side bookkeeping and then calls sgn_project_check_wait — same thread, same device —
+ * which waits for the check's own event and reports the flag. */
 int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
                         const float *viewmat12, float fx, float fy, float cx, float cy, int img_h, int img_w,
                         int block_width, float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii,
                         float *conics, float *compensation, int32_t *num_tiles_hit, int check_quats, float quat_tol,
                         int32_t *flag_dev, int32_t flag_stamp, int32_t *flag_pinned, int32_t *gid_by_rank,
                         void *rank_ws, size_t rank_ws_bytes, int sort_rank_mode, int32_t *quats_bad_host,
-                        sgn_stream_t stream);
+                        int semantics, sgn_stream_t stream);
 
 int sgn_project_check_wait(const int32_t *flag_pinned, int32_t flag_stamp, int32_t *quats_bad_host /*host*/);
 
@@ -143,6 +167,7 @@ int sgn_project_bwd(int n, const float *means3d, const float *scales, float glob
                     const float *compensation, const float *v_xy, const float *v_depth,
                     const float *v_conic, const float *v_compensation, float *v_cov2d,
                     float *v_cov3d, float *v_mean3d, float *v_scale, float *v_quat,
+                    int semantics /*SGN_SEM_EWA_VJP_CLAMPED: needs img_h, img_w*/, int img_h, int img_w,
                     sgn_stream_t stream);
 
 /* Fused front ends (extensions beyond gsplat's surface; SURVEY.md §8 a8, BASELINE.json north_star:
@@ -157,14 +182,14 @@ int sgn_project_fwd_fused(int n, const float *means_local, const float *log_scal
                           const float *viewmat12, float fx, float fy, float cx, float cy, int img_h,
                           int img_w, int block_width, float clip_thresh, float *cov3d, float *xys,
                           float *depths, int32_t *radii, float *conics, float *compensation,
-                          int32_t *num_tiles_hit, sgn_stream_t stream);
+                          int32_t *num_tiles_hit, int semantics, sgn_stream_t stream);
 int sgn_project_bwd_fused(int n, const float *means_local, const float *log_scales, float glob_scale,
                           const float *quats_raw, const int32_t *object_ids, const float *poses,
                           const float *viewmat12, float fx, float fy, const float *cov3d,
                           const int32_t *radii, const float *conics, const float *compensation,
                           const float *v_xy, const float *v_depth, const float *v_conic,
                           const float *v_compensation, float *v_means_local, float *v_log_scales,
-                          float *v_quats_raw, sgn_stream_t stream);
+                          float *v_quats_raw, int semantics, int img_h, int img_w, sgn_stream_t stream);
 
 /* Backward of the DROP-IN call `project_gaussians(means, scales, g, X / X.norm(dim=-1, keepdim=True))`
  * (sgn_splatfacto.py:857-873) taken one step further back than sgn_project_bwd: gradients w.r.t. the means, the
@@ -176,7 +201,8 @@ int sgn_project_bwd_act(int n, const float *means3d, const float *scales_activat
                         const float *quats_unnormalised, const float *viewmat12, float fx, float fy,
                         const float *cov3d, const int32_t *radii, const float *conics, const float *compensation,
                         const float *v_xy, const float *v_depth, const float *v_conic, const float *v_compensation,
-                        float *v_mean3d, float *v_log_scales, float *v_quats_unnormalised, sgn_stream_t stream);
+                        float *v_mean3d, float *v_log_scales, float *v_quats_unnormalised, int semantics, int img_h,
+                        int img_w, sgn_stream_t stream);
 
 /* Fourier DC fan-out (sgn_splatfacto_scene_graph.py:239-247: an object's effective DC term is
  * `sum(features_dc * idft[..., None], dim=1, keepdim=True)`): for each listed part p, rows [row0[p], row0[p] + rows[p])
@@ -243,7 +269,7 @@ int sgn_scan_i32(int n, const int32_t *in, int32_t *out_inclusive, void *ws, siz
  * emitted row-major over the tile bbox starting at cum[i-1]. */
 int sgn_map_isect(int n, const float *xys, const float *depths, const int32_t *radii,
                   const int32_t *cum_tiles_hit, int tiles_x, int tiles_y, int block_width,
-                  int64_t *isect_keys, int32_t *isect_vals, sgn_stream_t stream);
+                  int64_t *isect_keys, int32_t *isect_vals, int semantics, sgn_stream_t stream);
 
 /* torch.sort(int64) + gather in gsplat/utils.py bin_and_sort_gaussians: stable LSD radix sort
  * of (key,val) pairs over key bits [begin_bit,end_bit) (keys must be non-negative; bits outside
@@ -291,7 +317,7 @@ int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t 
                     int32_t *gid_by_rank /*[n] out; in when rank_ready*/,
                     int rank_ready /*1: gid_by_rank already holds sgn_depth_rank(n, depths, radii, ...)*/,
                     float *bin_records /*[n,8] out*/, void *ws, size_t ws_bytes, int sort_rank_mode,
-                    sgn_stream_t stream);
+                    int semantics, sgn_stream_t stream);
 /* The first stage of sgn_bin_prepare on its own: gid_by_rank[r] = id of the Gaussian of depth rank r (stable: ties by
  * id; radii <= 0 last).  It reads depths and radii only, so a caller can queue it right behind the projection — before
  * opacities and colours exist — and hand the result to sgn_bin_prepare(rank_ready = 1). */
@@ -469,7 +495,7 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
                           int32_t *tile_order, int32_t *tile_stats, void *rows, size_t rows_bytes,
                           void *order_scratch, size_t order_scratch_bytes, void *arena, size_t arena_bytes,
                           int32_t *count_pinned, const int32_t *extra_dev, int32_t *extra_pinned,
-                          int64_t *n_isect_host, int sort_rank_mode, const sgn_raster_opts *opts,
+                          int64_t *n_isect_host, int sort_rank_mode, int semantics, const sgn_raster_opts *opts,
                           sgn_stream_t stream);
 
 /* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built

@@ -71,16 +71,30 @@ static float sgo_exp(float x) { return g_exp_mode ? exp_portable(x) : expf(x); }
 
 SGO_API float sgo_exp_eval(float x) { return sgo_exp(x); }
 
+/* Upstream-variant semantics (the SGN_SEM_* bits of include/sgn_rast.h, restated: the oracle includes nothing of the
+ * product).  0 = the DECIDED behaviours; the bits select the other reading of the two [verify] items of SURVEY.md
+ * Appendix A, so that golden vectors from the real gsplat (tests/golden/make_upstream_golden.py) can settle them. */
+#define SGO_SEM_BBOX_ADD_AFTER_CAST 1 /* max side (int)(c + r) + 1 (gsplat/_torch_impl.py) instead of (int)(c + r + 1) */
+#define SGO_SEM_EWA_VJP_CLAMPED 2     /* the projection vjp differentiates through the +-1.3 tan(fov/2) clamp */
+
+static int bbox_max(float v, int sem) {
+    if (sem & SGO_SEM_BBOX_ADD_AFTER_CAST) {
+        int t = f2i(v);
+        return t == 2147483647 ? t : t + 1;
+    }
+    return f2i(v + 1.0f);
+}
+
 static void tile_bbox(float cx, float cy, float radius, int tiles_x, int tiles_y, int block,
-                      int *minx, int *miny, int *maxx, int *maxy) {
+                      int *minx, int *miny, int *maxx, int *maxy, int sem) {
     /* gsplat helpers.cuh get_tile_bbox / get_bbox: tile-space centre and radius,
-     * C truncation, "+1" added BEFORE the cast for the max side, clamp to the grid. */
+     * C truncation, "+1" added BEFORE the cast for the max side (default; see bbox_max), clamp to the grid. */
     float tcx = cx / (float)block, tcy = cy / (float)block;
     float tr = radius / (float)block;
     *minx = imin(imax(0, f2i(tcx - tr)), tiles_x);
-    *maxx = imin(imax(0, f2i(tcx + tr + 1.0f)), tiles_x);
+    *maxx = imin(imax(0, bbox_max(tcx + tr, sem)), tiles_x);
     *miny = imin(imax(0, f2i(tcy - tr)), tiles_y);
-    *maxy = imin(imax(0, f2i(tcy + tr + 1.0f)), tiles_y);
+    *maxy = imin(imax(0, bbox_max(tcy + tr, sem)), tiles_y);
 }
 
 static void quat_to_R(const float *q, float R[3][3]) {
@@ -105,7 +119,7 @@ SGO_API void sgo_project_fwd(int N, const float *means, const float *scales, flo
                              const float *quats, const float *V /*3x4 row-major*/, float fx,
                              float fy, float cx, float cy, int H, int W, int block, float clip,
                              float *cov3d, float *xys, float *depths, int *radii, float *conics,
-                             float *comp, int *num_tiles_hit) {
+                             float *comp, int *num_tiles_hit, int sem) {
     int tiles_x = (W + block - 1) / block, tiles_y = (H + block - 1) / block;
     float tan_fovx = 0.5f * (float)W / fx, tan_fovy = 0.5f * (float)H / fy;
     float lim_x = 1.3f * tan_fovx, lim_y = 1.3f * tan_fovy;
@@ -163,7 +177,7 @@ SGO_API void sgo_project_fwd(int N, const float *means, const float *scales, flo
         float rw = 1.f / (pvz + 1e-6f);
         float ux = pvx * rw * fx + cx, uy = pvy * rw * fy + cy;
         int mnx, mny, mxx, mxy;
-        tile_bbox(ux, uy, radius, tiles_x, tiles_y, block, &mnx, &mny, &mxx, &mxy);
+        tile_bbox(ux, uy, radius, tiles_x, tiles_y, block, &mnx, &mny, &mxx, &mxy, sem);
         int area = (mxx - mnx) * (mxy - mny);
         if (area <= 0) continue;
         num_tiles_hit[i] = area;
@@ -186,7 +200,10 @@ SGO_API void sgo_project_bwd(int N, const float *means, const float *scales, flo
                              const float *cov3d, const int *radii, const float *conics,
                              const float *comp, const float *v_xy, const float *v_depth,
                              const float *v_conic, const float *v_comp, float *v_cov2d,
-                             float *v_cov3d, float *v_mean, float *v_scale, float *v_quat) {
+                             float *v_cov3d, float *v_mean, float *v_scale, float *v_quat, int sem, int H,
+                             int W) {
+    /* limits of the forward's clamp: only the SGO_SEM_EWA_VJP_CLAMPED variant looks at them */
+    float lim_x = 1.3f * (0.5f * (float)W / fx), lim_y = 1.3f * (0.5f * (float)H / fy);
     for (int i = 0; i < N; ++i) {
         if (radii[i] <= 0) continue;
         const float *p = means + 3 * i;
@@ -223,9 +240,19 @@ SGO_API void sgo_project_bwd(int N, const float *means, const float *scales, flo
         }
         v_cov2d[3 * i] = vc2[0]; v_cov2d[3 * i + 1] = vc2[1]; v_cov2d[3 * i + 2] = vc2[2];
 
-        /* project_cov3d_ewa_vjp (t un-clamped) */
+        /* project_cov3d_ewa_vjp.  Default: t un-clamped (upstream CUDA).  Variant: through the forward's clamp
+         * tx = tz * clamp(pvx / tz, +-lim): where it is active d tx / d pvx = 0 and d tx / d tz = tx / tz. */
         float rz = 1.f / pvz, rz2 = rz * rz, rz3 = rz2 * rz;
-        float J00 = fx * rz, J02 = -fx * pvx * rz2, J11 = fy * rz, J12 = -fy * pvy * rz2;
+        float ex = pvx, ey = pvy;
+        int clx = 0, cly = 0;
+        if (sem & SGO_SEM_EWA_VJP_CLAMPED) {
+            float qx = pvx / pvz, qy = pvy / pvz;
+            clx = !(qx <= lim_x && qx >= -lim_x);
+            cly = !(qy <= lim_y && qy >= -lim_y);
+            ex = pvz * fminf(lim_x, fmaxf(-lim_x, qx));
+            ey = pvz * fminf(lim_y, fmaxf(-lim_y, qy));
+        }
+        float J00 = fx * rz, J02 = -fx * ex * rz2, J11 = fy * rz, J12 = -fy * ey * rz2;
         float T[2][3];
         for (int j = 0; j < 3; ++j) {
             T[0][j] = J00 * V[j] + J02 * V[8 + j];
@@ -254,9 +281,9 @@ SGO_API void sgo_project_bwd(int N, const float *means, const float *scales, flo
         float vJ02 = vT[0][0] * V[8] + vT[0][1] * V[9] + vT[0][2] * V[10];
         float vJ11 = vT[1][0] * V[4] + vT[1][1] * V[5] + vT[1][2] * V[6];
         float vJ12 = vT[1][0] * V[8] + vT[1][1] * V[9] + vT[1][2] * V[10];
-        float vt[3] = {-fx * rz2 * vJ02, -fy * rz2 * vJ12,
-                       -fx * rz2 * vJ00 + 2.f * fx * pvx * rz3 * vJ02 - fy * rz2 * vJ11 +
-                           2.f * fy * pvy * rz3 * vJ12};
+        float vt[3] = {clx ? 0.f : -fx * rz2 * vJ02, cly ? 0.f : -fy * rz2 * vJ12,
+                       -fx * rz2 * vJ00 + (clx ? 1.f : 2.f) * fx * ex * rz3 * vJ02 - fy * rz2 * vJ11 +
+                           (cly ? 1.f : 2.f) * fy * ey * rz3 * vJ12};
         for (int j = 0; j < 3; ++j) vm[j] += V[0 + j] * vt[0] + V[4 + j] * vt[1] + V[8 + j] * vt[2];
         v_mean[3 * i] = vm[0]; v_mean[3 * i + 1] = vm[1]; v_mean[3 * i + 2] = vm[2];
 
@@ -369,12 +396,12 @@ SGO_API void sgo_scan_i32(int N, const int *in, int *out) {
 
 SGO_API void sgo_map_isect(int N, const float *xys, const float *depths, const int *radii,
                            const int *cum, int tiles_x, int tiles_y, int block, int64_t *keys,
-                           int32_t *vals) {
+                           int32_t *vals, int sem) {
     for (int i = 0; i < N; ++i) {
         if (radii[i] <= 0) continue;
         int mnx, mny, mxx, mxy;
         tile_bbox(xys[2 * i], xys[2 * i + 1], (float)radii[i], tiles_x, tiles_y, block, &mnx,
-                  &mny, &mxx, &mxy);
+                  &mny, &mxx, &mxy, sem);
         int cur = (i == 0) ? 0 : cum[i - 1];
         int32_t dbits;
         memcpy(&dbits, depths + i, 4);
@@ -480,6 +507,55 @@ SGO_API void sgo_raster_fwd(int H, int W, int block, const int32_t *ids, const i
                             const float *opac, const float *bg, float *out_img, float *final_T,
                             int32_t *final_idx) {
     sgo_raster_fwd_rows(H, W, block, ids, bins, xys, conics, colors, opac, bg, out_img, final_T, final_idx, 0, H);
+}
+
+/* Which pixels of the forward sit next to one of its THRESHOLDS (test infrastructure for the at-size image bound,
+ * VERDICT r05 next #5).  The compositing loop takes two data-dependent decisions per entry — skip when alpha < 1/255,
+ * stop when T (1 - alpha) <= 1e-4 — and exp is the one step of the arithmetic contract that is not reproducible across
+ * implementations (libm's expf here, v_exp_f32 there: DESIGN.md section 3).  A pixel whose walk comes closer to a
+ * threshold than that difference can carry may legitimately take the other branch (one entry more or less composited:
+ * an error of up to alpha * T, far above any rounding bound); every other pixel takes the same walk on both sides and
+ * must agree to rounding.  adjacent[pix] = 1 iff some evaluated entry of the pixel's walk has
+ *     | alpha * 255 - 1 |      <= eps_exp                              (the skip test), or
+ *     | T (1 - alpha) / 1e-4 - 1 | <= eps_T,  eps_T = eps_exp + sum over the entries composited so far of
+ *                                              eps_exp * alpha / (1 - alpha) + 2^-23   (the stop test: the relative
+ *                                              error an exp error of eps_exp per entry can have put into T),
+ * where eps_exp bounds the RELATIVE difference of the two exp implementations on [-5.6, 0].  Same walk and arithmetic
+ * as sgo_raster_fwd_rows. */
+SGO_API void sgo_raster_threshold_adjacent_rows(int H, int W, int block, const int32_t *ids, const int32_t *bins,
+                                                const float *xys, const float *conics, const float *opac,
+                                                float eps_exp, int32_t *adjacent, int row_lo, int row_hi) {
+    int tiles_x = (W + block - 1) / block;
+    row_lo = imax(row_lo, 0); row_hi = imin(row_hi, H);
+    for (int i = row_lo; i < row_hi; ++i)
+        for (int j = 0; j < W; ++j) {
+            int tile = (i / block) * tiles_x + (j / block);
+            int start = bins[2 * tile], end = bins[2 * tile + 1];
+            float px = (float)j + 0.5f, py = (float)i + 0.5f;
+            float T = 1.f;
+            double eps_T = (double)eps_exp;
+            int flag = 0;
+            for (int k = start; k < end; ++k) {
+                int g = ids[k];
+                float dx = xys[2 * g] - px, dy = xys[2 * g + 1] - py;
+                float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
+                float s = (a * dx) * dx;
+                s = fmaf(c * dy, dy, s);
+                s = 0.5f * s;
+                float sigma = fmaf(b * dx, dy, s);
+                if (sigma < 0.f) continue;                       /* (exact on both sides: no exp involved) */
+                float raw = opac[g] * sgo_exp(-sigma);
+                if (fabs((double)raw * 255.0 - 1.0) <= (double)eps_exp) flag = 1;
+                float alpha = fminf(0.999f, raw);
+                if (alpha < 1.f / 255.f) continue;
+                float nT = T * (1.f - alpha);
+                eps_T += (double)eps_exp * (double)alpha / (double)(1.f - alpha) + 1.2e-7;
+                if (fabs((double)nT / 1e-4 - 1.0) <= eps_T) flag = 1;
+                if (nT <= 1e-4f) break;
+                T = nT;
+            }
+            adjacent[(size_t)i * W + j] = flag;
+        }
 }
 
 /* -------------------------------------------------------- rasterize backward

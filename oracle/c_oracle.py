@@ -52,7 +52,11 @@ def exp_eval(x: float) -> float:
     return float(lib().sgo_exp_eval(C.c_float(x)))
 
 
-def project_fwd(means, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block, clip=0.01):
+# upstream-variant semantics bits (sgn_oracle.c SGO_SEM_*; 0 = the decided behaviours)
+SEM_BBOX_ADD_AFTER_CAST, SEM_EWA_VJP_CLAMPED = 1, 2
+
+
+def project_fwd(means, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block, clip=0.01, semantics=0):
     means, scales, quats = _f(means), _f(scales), _f(quats)
     V = _f(viewmat).reshape(-1)[:12].contiguous()
     N = means.shape[0]
@@ -62,12 +66,12 @@ def project_fwd(means, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W,
     lib().sgo_project_fwd(C.c_int(N), _p(means), _p(scales), C.c_float(glob_scale), _p(quats), _p(V),
                           C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_int(H),
                           C.c_int(W), C.c_int(block), C.c_float(clip), _p(cov3d), _p(xys), _p(depths),
-                          _p(radii), _p(conics), _p(comp), _p(nth))
+                          _p(radii), _p(conics), _p(comp), _p(nth), C.c_int(semantics))
     return xys, depths, radii, conics, comp, nth, cov3d
 
 
 def project_bwd(means, scales, glob_scale, quats, viewmat, fx, fy, cov3d, radii, conics, comp,
-                v_xy, v_depth, v_conic, v_comp):
+                v_xy, v_depth, v_conic, v_comp, semantics=0, H=16, W=16):
     means, scales, quats = _f(means), _f(scales), _f(quats)
     V = _f(viewmat).reshape(-1)[:12].contiguous()
     N = means.shape[0]
@@ -76,7 +80,8 @@ def project_bwd(means, scales, glob_scale, quats, viewmat, fx, fy, cov3d, radii,
     lib().sgo_project_bwd(C.c_int(N), _p(means), _p(scales), C.c_float(glob_scale), _p(quats), _p(V),
                           C.c_float(fx), C.c_float(fy), _p(_f(cov3d)), _p(radii.contiguous()),
                           _p(_f(conics)), _p(_f(comp)), _p(_f(v_xy)), _p(_f(v_depth)), _p(_f(v_conic)),
-                          _p(_f(v_comp)), _p(v_cov2d), _p(v_cov3d), _p(v_mean), _p(v_scale), _p(v_quat))
+                          _p(_f(v_comp)), _p(v_cov2d), _p(v_cov3d), _p(v_mean), _p(v_scale), _p(v_quat),
+                          C.c_int(semantics), C.c_int(H), C.c_int(W))
     return v_mean, v_scale, v_quat, v_cov2d, v_cov3d
 
 
@@ -103,12 +108,12 @@ def scan_i32(x):
     return out
 
 
-def map_isect(xys, depths, radii, cum, tiles_x, tiles_y, block):
+def map_isect(xys, depths, radii, cum, tiles_x, tiles_y, block, semantics=0):
     I = int(cum[-1]) if cum.numel() else 0
     keys = torch.zeros(I, dtype=torch.int64); vals = torch.zeros(I, dtype=torch.int32)
     lib().sgo_map_isect(C.c_int(xys.shape[0]), _p(_f(xys)), _p(_f(depths)), _p(radii.contiguous()),
                         _p(cum.contiguous()), C.c_int(tiles_x), C.c_int(tiles_y), C.c_int(block),
-                        _p(keys), _p(vals))
+                        _p(keys), _p(vals), C.c_int(semantics))
     return keys, vals
 
 
@@ -124,10 +129,10 @@ def tile_bins(keys_sorted, n_tiles):
     return bins
 
 
-def bin_and_sort(xys, depths, radii, num_tiles_hit, H, W, block):
+def bin_and_sort(xys, depths, radii, num_tiles_hit, H, W, block, semantics=0):
     tiles_x, tiles_y = (W + block - 1) // block, (H + block - 1) // block
     cum = scan_i32(num_tiles_hit)
-    keys, vals = map_isect(xys, depths, radii, cum, tiles_x, tiles_y, block)
+    keys, vals = map_isect(xys, depths, radii, cum, tiles_x, tiles_y, block, semantics)
     ks, vs = sort_pairs(keys, vals)
     bins = tile_bins(ks, tiles_x * tiles_y)
     return cum, keys, vals, ks, vs, bins
@@ -168,6 +173,26 @@ def raster_fwd(H, W, block, ids, bins, xys, conics, colors, opac, bg, rows=None)
                               C.c_int(r0), C.c_int(r1))
     _run_chunks(go, _row_chunks(lo, hi))
     return out, fT, fi
+
+
+# relative difference between two correct-to-an-ulp exp implementations on the compositing's range [-5.6, 0]: 1 ulp of the
+# result each + the rounding of the argument's scaling by log2(e) (|x| 2^-24 ln 2 <= 2.3e-7); see sgn_oracle.c
+EXP_REL_EPS = 1e-6
+
+
+def raster_threshold_adjacent(H, W, block, ids, bins, xys, conics, opac, eps_exp=EXP_REL_EPS, rows=None):
+    """bool [H, W]: pixels whose forward walk comes within `eps_exp` (relative, in exp) of the 1/255 skip test or the 1e-4
+    stop test — the only pixels on which two implementations with different exp may differ by more than rounding."""
+    out = torch.zeros(H, W, dtype=torch.int32)
+    lo, hi = (0, H) if rows is None else rows
+    a = (ids.contiguous(), bins.contiguous(), _f(xys), _f(conics), _f(opac).reshape(-1))
+    L = lib()
+
+    def go(r0, r1):
+        L.sgo_raster_threshold_adjacent_rows(C.c_int(H), C.c_int(W), C.c_int(block), *[_p(t) for t in a],
+                                             C.c_float(eps_exp), _p(out), C.c_int(r0), C.c_int(r1))
+    _run_chunks(go, _row_chunks(lo, hi))
+    return out.bool()
 
 
 def raster_bwd(H, W, block, ids, bins, xys, conics, colors, opac, bg, final_T, final_idx, v_out,

@@ -80,13 +80,25 @@ def _trunc_i32(v: torch.Tensor) -> torch.Tensor:
         -2147483648, 2147483647).to(torch.int32)
 
 
+# Upstream-variant switch (the product's `ops.upstream_variant`, the C oracle's SGO_SEM_* bits):
+# False = the DECIDED reading, gsplat helpers.cuh get_bbox — `+ 1` BEFORE the cast on the max side; True = the reading of
+# gsplat/_torch_impl.py get_tile_bbox — `+ 1` AFTER the cast.  They differ only for -1 < c + r < 0.
+# (The other decided item needs no switch here: autograd through this file IS the "clamped" EWA vjp; the default,
+# un-clamped one exists only as an analytic formula, in oracle/c/sgn_oracle.c.)
+TILE_BBOX_ADD_AFTER_CAST = False
+
+
 def _tile_bbox(cx, cy, radius, tiles_x: int, tiles_y: int, block: int):
     fb = float(block)
     tcx, tcy, tr = cx / fb, cy / fb, radius / fb
     mnx = _trunc_i32(tcx - tr).clamp(0, tiles_x)
-    mxx = _trunc_i32(tcx + tr + 1).clamp(0, tiles_x)
     mny = _trunc_i32(tcy - tr).clamp(0, tiles_y)
-    mxy = _trunc_i32(tcy + tr + 1).clamp(0, tiles_y)
+    if TILE_BBOX_ADD_AFTER_CAST:
+        mxx = (_trunc_i32(tcx + tr).to(torch.int64) + 1).clamp(0, tiles_x).to(torch.int32)
+        mxy = (_trunc_i32(tcy + tr).to(torch.int64) + 1).clamp(0, tiles_y).to(torch.int32)
+    else:
+        mxx = _trunc_i32(tcx + tr + 1).clamp(0, tiles_x)
+        mxy = _trunc_i32(tcy + tr + 1).clamp(0, tiles_y)
     return mnx, mny, mxx, mxy
 
 

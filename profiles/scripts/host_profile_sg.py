@@ -44,3 +44,10 @@ print(s.getvalue()[:9000])
 s = io.StringIO()
 pstats.Stats(pr, stream=s).strip_dirs().sort_stats("cumulative").print_stats(45)
 print(s.getvalue()[:9000])
+# callees of the library's entry points (who spends the time inside each wrapper)
+for fn in ("rasterize_gaussians", "ops.py:.*forward", "_match_window", "_proven_window", "spherical_harmonics", "project_gaussians",
+           "_project_forward", "quaternion_multiply", "quat.py:.*forward", "_bin_prepare_async", "_bin_finish", "_tile_order",
+           "_list_window", "ops.py:.*backward", "one_pass", "sh_source", "_window_info"):
+    s = io.StringIO()
+    pstats.Stats(pr, stream=s).strip_dirs().sort_stats("cumulative").print_callees(fn)
+    print(s.getvalue()[:6000])

@@ -84,11 +84,47 @@ int32_t *mapped(int32_t *pinned) {
 // ranking of the coming binning is already queued, and the host waits for it last (the "eager" check of sgn_rast/ops.py,
 // which otherwise takes three calls and two more launches).  `flag_stamp` > 0: the caller guarantees that *flag_dev holds
 // no value >= flag_stamp (a word zeroed ONCE and a call counter): nothing is cleared; <= 0: the call clears the flag.
+// flag_pinned is TWO words (round 6): [0] receives the stamp from a failing row, [1] the stamp from the
+// kernel's first lane — "this launch's stores have landed where the host looks" — both as system-scope atomic stores;
+// a wait that does not find [1] == stamp drains the device once and, if the word is still missing, FAILS (a mapped write
+// that is not visible at event completion must not read as "all quaternions passed").
 int sgn_project_fwd_checked(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
                             const float *viewmat12, float fx, float fy, float cx, float cy, int img_h, int img_w,
                             int block_width, float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii,
                             float *conics, float *compensation, int32_t *num_tiles_hit, int32_t *quat_flag,
-                            float quat_tol, int32_t quat_stamp, sgn_stream_t stream);       // project.hip
+                            float quat_tol, int32_t quat_stamp, int32_t *quat_ok, int semantics,
+                            sgn_stream_t stream);       // project.hip
+
+namespace {
+int check_event(hipEvent_t *ev) {         // the quats check's OWN event per (thread, device): a deferred wait
+    struct One { int dev; hipEvent_t e; };   // (check_quats = 2) stays correct whatever the library records in between
+    static thread_local std::vector<One> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 1;
+    for (auto &p : cache)
+        if (p.dev == dev) { *ev = p.e; return 0; }
+    One o;
+    o.dev = dev;
+    if (hipEventCreateWithFlags(&o.e, hipEventDisableTiming) != hipSuccess) return 2;
+    cache.push_back(o);
+    *ev = o.e;
+    return 0;
+}
+// after the check's event: has the launch's "ok" stamp landed, and did a row fail?
+int read_quat_flag(const int32_t *flag2, int32_t stamp, int32_t *bad, const char *who) {
+    const volatile int32_t *f = flag2;
+    if (f[1] != stamp) {
+        (void)hipDeviceSynchronize();                          // cold path: never seen on this platform
+        if (f[1] != stamp) {
+            sgn_set_error("%s: the quats check's stamp never reached host memory (mapped pinned write not visible "
+                          "at event completion): refusing to report 'normalized'", who);
+            return -8;
+        }
+    }
+    *bad = (f[0] == stamp) ? 1 : 0;
+    return 0;
+}
+}  // namespace
 
 extern "C" __attribute__((visibility("default")))
 int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
@@ -97,11 +133,11 @@ int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float 
                         float *conics, float *compensation, int32_t *num_tiles_hit, int check_quats, float quat_tol,
                         int32_t *flag_dev, int32_t flag_stamp, int32_t *flag_pinned, int32_t *gid_by_rank,
                         void *rank_ws, size_t rank_ws_bytes, int sort_rank_mode, int32_t *quats_bad_host,
-                        sgn_stream_t stream) {
+                        int semantics, sgn_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     hipEvent_t ev = nullptr;
-    int32_t pageable = 0;
-    int32_t *dst = flag_pinned ? flag_pinned : &pageable;
+    int32_t pageable[2] = {0, 0};
+    int32_t *dst = flag_pinned ? flag_pinned : pageable;
     int32_t stamp = flag_stamp > 0 ? flag_stamp : 1;
     if (check_quats) {
         const int mode = check_quats;
@@ -115,15 +151,20 @@ int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float 
     }
     // flag_pinned mapped into the device's address space and stamped (flag_stamp > 0: stale slots never equal the stamp):
     // a failing row stores straight into it and the read-back needs no copy command behind the kernel
-    int32_t *direct = (check_quats && flag_stamp > 0) ? mapped(flag_pinned) : nullptr;
+    int32_t *direct = (check_quats && flag_stamp > 0 && n > 0) ? mapped(flag_pinned) : nullptr;
     int rc = sgn_project_fwd_checked(n, means3d, scales, glob_scale, quats, viewmat12, fx, fy, cx, cy, img_h, img_w,
                                      block_width, clip_thresh, cov3d, xys, depths, radii, conics, compensation,
                                      num_tiles_hit, check_quats ? (direct ? direct : flag_dev) : nullptr, quat_tol,
-                                     stamp, stream);
+                                     stamp, direct ? direct + 1 : nullptr, semantics, stream);
     if (rc) return rc;
     if (check_quats) {
-        hipError_t e = direct ? hipSuccess : hipMemcpyAsync(dst, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
-        if (e == hipSuccess && sync_event(&ev) != 0) e = hipErrorUnknown;
+        hipError_t e = hipSuccess;
+        if (!direct) {                      // the copy command is the transport: its completion is the landing
+            if (n > 0) e = hipMemcpyAsync(dst, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+            else dst[0] = 0;
+            dst[1] = stamp;
+        }
+        if (e == hipSuccess && check_event(&ev) != 0) e = hipErrorUnknown;
         if (e == hipSuccess) e = hipEventRecord(ev, s);
         if (e != hipSuccess) { sgn_set_error("sgn_project_fwd_all: flag read-back: %s", hipGetErrorString(e)); return (int)e; }
     }
@@ -134,30 +175,33 @@ int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float 
     if (check_quats == 1) {
         const hipError_t e = hipEventSynchronize(ev);      // the ranking is queued behind the projection: wait now
         if (e != hipSuccess) { sgn_set_error("sgn_project_fwd_all: %s", hipGetErrorString(e)); return (int)e; }
-        *quats_bad_host = (n > 0 && *dst == stamp) ? 1 : 0;
+        int32_t bad = 0;
+        rc = read_quat_flag(dst, stamp, &bad, "sgn_project_fwd_all");
+        if (rc) return rc;
+        *quats_bad_host = (n > 0 && bad) ? 1 : 0;
     }
     return 0;
 }
 
-// The wait of a sgn_project_fwd_all(check_quats = 2) call, made by the same thread on the same device with nothing of this
-// library in between: the caller does its own host-side bookkeeping for the projection's outputs first, while the flag
-// is still on its way (the device is busy behind it; what the host does before this wait is off the critical path).
+// The wait of a sgn_project_fwd_all(check_quats = 2) call, made by the same thread on the same device: the caller does
+// its own host-side bookkeeping for the projection's outputs first, while the flag is still on its way (the device is
+// busy behind it; what the host does before this wait is off the critical path).  The check has its own event, so other
+// calls of this library may come in between.
 extern "C" __attribute__((visibility("default")))
 int sgn_project_check_wait(const int32_t *flag_pinned, int32_t flag_stamp, int32_t *quats_bad_host) {
     if (!flag_pinned || !quats_bad_host) { sgn_set_error("sgn_project_check_wait: NULL argument"); return -1; }
     hipEvent_t ev = nullptr;
-    if (sync_event(&ev) != 0) { sgn_set_error("sgn_project_check_wait: no event"); return -2; }
+    if (check_event(&ev) != 0) { sgn_set_error("sgn_project_check_wait: no event"); return -2; }
     const hipError_t e = hipEventSynchronize(ev);
     if (e != hipSuccess) { sgn_set_error("sgn_project_check_wait: %s", hipGetErrorString(e)); return (int)e; }
-    *quats_bad_host = (*flag_pinned == (flag_stamp > 0 ? flag_stamp : 1)) ? 1 : 0;
-    return 0;
+    return read_quat_flag(flag_pinned, flag_stamp > 0 ? flag_stamp : 1, quats_bad_host, "sgn_project_check_wait");
 }
 
 int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const int32_t *radii,
                           const float *conics, const float *opacities, int opacity_is_logit, int cull,
                           int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
                           int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
-                          int sort_rank_mode, int32_t *total_host, sgn_stream_t stream);   // binning.hip
+                          int sort_rank_mode, int32_t *total_host, int semantics, sgn_stream_t stream);   // binning.hip
 int sgn_bin_intersect_zero(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                            const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
                            int32_t *gaussian_ids_sorted, int32_t *tile_bins, int quadrant_masks, void *ws,
@@ -186,7 +230,7 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
                           int32_t *tile_order, int32_t *tile_stats, void *rows, size_t rows_bytes,
                           void *order_scratch, size_t order_scratch_bytes, void *arena, size_t arena_bytes,
                           int32_t *count_pinned, const int32_t *extra_dev, int32_t *extra_pinned,
-                          int64_t *n_isect_host, int sort_rank_mode, const sgn_raster_opts *opts,
+                          int64_t *n_isect_host, int sort_rank_mode, int semantics, const sgn_raster_opts *opts,
                           sgn_stream_t stream) {
     if (n < 1 || !xys || !depths || !radii || !colors || !opacities || !background3 || !out_img || !final_Ts ||
         !final_idx || !gaussian_ids_sorted || !tile_bins || !tile_order || !tile_stats || !rows || !arena ||
@@ -222,7 +266,8 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
     if (direct) *count_pinned = -1;            // poison: a count that has not landed when the event fires is noticed below
     int rc = sgn_bin_prepare_total(n, xys, depths, radii, do_cull ? conics : nullptr, do_cull ? opacities : nullptr,
                                    opacity_is_logit, do_cull, tiles_x, tiles_y, block_width, cum_r, gid,
-                                   gid_by_rank_ready ? 1 : 0, bin_recs, ws1, ws1_bytes, sort_rank_mode, direct, stream);
+                                   gid_by_rank_ready ? 1 : 0, bin_recs, ws1, ws1_bytes, sort_rank_mode, direct, semantics,
+                                   stream);
     if (rc) return rc;
     int32_t pageable = -1;
     int32_t *dst = count_pinned ? count_pinned : &pageable;

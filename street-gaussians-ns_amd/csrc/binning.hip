@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void map_isect_kernel(int n, const float *__re
                                                         const int32_t *__restrict__ cum, int tiles_x,
                                                         int tiles_y, int block,
                                                         int64_t *__restrict__ keys,
-                                                        int32_t *__restrict__ vals) {
+                                                        int32_t *__restrict__ vals, int sem) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     int mnx = 0, mny = 0, mxx = 0, mxy = 0, cur = 0;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void map_isect_kernel(int n, const float *__re
         const int r = radii[i];
         if (r > 0) {
             live = true;
-            sgn_tile_bbox(xys[2 * i], xys[2 * i + 1], (float)r, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
+            sgn_tile_bbox(xys[2 * i], xys[2 * i + 1], (float)r, tiles_x, tiles_y, block, mnx, mny, mxx, mxy, sem);
             cur = (i == 0) ? 0 : cum[i - 1];
             depth_id = (int64_t)__float_as_int(depths[i]);  // sign-extends like upstream; depth > 0
         }
@@ -244,9 +244,11 @@ struct BinRec {
     float gx, gy;      // projected centre
     float a, b, c;     // conic
     float s;           // ln(255 o) + margin; < 0: never visible; +inf: culling off (keep every bbox tile)
-    int rad;           // radius in pixels (0: culled by projection)
+    int rad;           // radius in pixels (0: culled by projection), at most BINREC_RAD_MAX; bit 30: the tile boxes of
+                       // this binning follow SGN_SEM_BBOX_ADD_AFTER_CAST (the emission recomputes the box from the record)
     int cnt;           // kept tiles
 };
+constexpr int BINREC_RAD_MAX = (1 << 30) - 1;   // (a larger radius covers every tile of any image anyway)
 static_assert(sizeof(BinRec) == SGN_BIN_RECORD_FLOATS * 4, "bin record size");
 
 // The culling test is conservative by construction (margins: 0.01 in sigma, 1e-3 px in x), so it runs on the
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
                                                         const int32_t *__restrict__ radii, Cull cull, int tiles_x,
                                                         int tiles_y, int block, uint32_t *__restrict__ dkeys,
                                                         int32_t *__restrict__ dvals, BinRec *__restrict__ recs,
-                                                        int32_t *__restrict__ cnt_gid, int write_keys) {
+                                                        int32_t *__restrict__ cnt_gid, int write_keys, int sem) {
     __shared__ FlatScratch scratch[4];
     const int i = blockIdx.x * 256 + threadIdx.x;
     int mnx = 0, mny = 0, mxx = 0, mxy = 0;
@@ -491,11 +493,11 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
     R.gx = 0.f; R.gy = 0.f; R.a = 1.f; R.b = 0.f; R.c = 1.f; R.s = -1.f; R.rad = 0; R.cnt = 0;
     bool live = false;
     if (i < n) {
-        R.rad = radii[i];
+        R.rad = min(radii[i], BINREC_RAD_MAX);
         if (R.rad > 0) {
             live = true;
             R.gx = xys[2 * i]; R.gy = xys[2 * i + 1];
-            sgn_tile_bbox(R.gx, R.gy, (float)R.rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
+            sgn_tile_bbox(R.gx, R.gy, (float)R.rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy, sem);
             R.s = cull_threshold(cull, i);
             if (cull.enable) { R.a = cull.conics[3 * i]; R.b = cull.conics[3 * i + 1]; R.c = cull.conics[3 * i + 2]; }
         }
@@ -510,7 +512,8 @@ __global__ __launch_bounds__(256) void bin_count_kernel(int n, const float *__re
         cnt_gid[i] = R.cnt;             // dense copy: the rank-order gather below then works on 4 B/Gaussian
         float4 *o = reinterpret_cast<float4 *>(recs + i);
         o[0] = make_float4(R.gx, R.gy, R.a, R.b);
-        o[1] = make_float4(R.c, R.s, __int_as_float(R.rad), __int_as_float(R.cnt));
+        const int radw = R.rad > 0 ? (R.rad | ((sem & SGN_SEM_BBOX_ADD_AFTER_CAST) ? (1 << 30) : 0)) : R.rad;
+        o[1] = make_float4(R.c, R.s, __int_as_float(radw), __int_as_float(R.cnt));
     }
 }
 
@@ -544,11 +547,13 @@ __global__ __launch_bounds__(64) void bin_emit_kernel(int n, const int32_t *__re
         gid = gid_by_rank[r];
         const float4 *q = reinterpret_cast<const float4 *>(recs + gid);
         const float4 q0 = q[0], q1 = q[1];
-        const int rad = __float_as_int(q1.z);
+        const int radw = __float_as_int(q1.z);
+        const int rad = radw > 0 ? (radw & BINREC_RAD_MAX) : radw;
         if (rad > 0 && __float_as_int(q1.w) > 0) {
             live = true;
             gx = q0.x; gy = q0.y; a = q0.z; b = q0.w; c = q1.x; s = q1.y;
-            sgn_tile_bbox(gx, gy, (float)rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy);
+            sgn_tile_bbox(gx, gy, (float)rad, tiles_x, tiles_y, block, mnx, mny, mxx, mxy,
+                          (radw >> 30) & 1 ? SGN_SEM_BBOX_ADD_AFTER_CAST : 0);
         }
     }
     const Ellipse E = make_ellipse(gx, gy, a, b, c, s);
@@ -754,14 +759,14 @@ SGN_EXPORT int sgn_scan_i32(int n, const int32_t *in, int32_t *out, void *ws, si
 
 SGN_EXPORT int sgn_map_isect(int n, const float *xys, const float *depths, const int32_t *radii,
                              const int32_t *cum_tiles_hit, int tiles_x, int tiles_y, int block_width,
-                             int64_t *isect_keys, int32_t *isect_vals, sgn_stream_t stream) {
+                             int64_t *isect_keys, int32_t *isect_vals, int semantics, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     if (n == 0) return 0;
     SGN_ARG_CHECK(xys && depths && radii && cum_tiles_hit, -3);
     sgn_timing_begin(SGN_T_MAP, stream);
     hipLaunchKernelGGL(map_isect_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, xys,
-                       depths, radii, cum_tiles_hit, tiles_x, tiles_y, block_width, isect_keys, isect_vals);
+                       depths, radii, cum_tiles_hit, tiles_x, tiles_y, block_width, isect_keys, isect_vals, semantics);
     sgn_timing_end(SGN_T_MAP, stream);
     SGN_LAUNCH_CHECK();
     return 0;
@@ -856,23 +861,23 @@ int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const in
                           const float *conics, const float *opacities, int opacity_is_logit, int cull,
                           int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
                           int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
-                          int sort_rank_mode, int32_t *total_host, sgn_stream_t stream);
+                          int sort_rank_mode, int32_t *total_host, int semantics, sgn_stream_t stream);
 
 SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii,
                                const float *conics, const float *opacities, int opacity_is_logit, int cull,
                                int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
                                int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
-                               int sort_rank_mode, sgn_stream_t stream) {
+                               int sort_rank_mode, int semantics, sgn_stream_t stream) {
     return sgn_bin_prepare_total(n, xys, depths, radii, conics, opacities, opacity_is_logit, cull, tiles_x, tiles_y,
                                  block_width, cum_by_rank, gid_by_rank, rank_ready, bin_records, ws, ws_bytes,
-                                 sort_rank_mode, nullptr, stream);
+                                 sort_rank_mode, nullptr, semantics, stream);
 }
 
 int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const int32_t *radii,
                           const float *conics, const float *opacities, int opacity_is_logit, int cull,
                           int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
                           int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
-                          int sort_rank_mode, int32_t *total_host, sgn_stream_t stream) {
+                          int sort_rank_mode, int32_t *total_host, int semantics, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     if (n == 0) return 0;
@@ -891,7 +896,7 @@ int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const in
     BinRec *recs = reinterpret_cast<BinRec *>(bin_records);
     sgn_timing_begin(SGN_T_MAP, s);
     hipLaunchKernelGGL(bin_count_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, depths, radii, c, tiles_x,
-                       tiles_y, block_width, dkeys, dvals, recs, cnt_gid, rank_ready ? 0 : 1);
+                       tiles_y, block_width, dkeys, dvals, recs, cnt_gid, rank_ready ? 0 : 1, semantics);
     sgn_timing_end(SGN_T_MAP, s);
     if (!rank_ready) {       // rank_ready: gid_by_rank already holds sgn_depth_rank's result for these depths / radii
         sgn_timing_begin(SGN_T_SORT, s);

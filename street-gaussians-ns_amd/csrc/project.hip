@@ -20,6 +20,7 @@ struct Cam {
     float lim_x, lim_y;
     int tiles_x, tiles_y, block;
     float clip, glob_scale;
+    int sem;         // SGN_SEM_* bits (include/sgn_rast.h: upstream-variant semantics; 0 = the decided defaults)
 };
 
 __device__ __forceinline__ void quat_to_R(float w, float x, float y, float z, float R[3][3]) {
@@ -38,6 +39,7 @@ struct QuatCheck {
     int32_t *flag;   // nullptr: no check
     float tol;
     int32_t stamp;   // value a failing row stores
+    int32_t *ok;     // nullptr, or: the kernel's first lane stores the stamp here (the launch's stores are visible)
 };
 
 // Optional fused front end (SURVEY.md §8 a8 / north star): the scene graph's per-object rigid transform
@@ -115,7 +117,16 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
         // (every writer stores the same value: benign race), so a flag that was zero once needs no clear per call.
         if (qc.flag != nullptr) {
             const float nrm = sqrtf(LG.q[0] * LG.q[0] + LG.q[1] * LG.q[1] + LG.q[2] * LG.q[2] + LG.q[3] * LG.q[3]);
-            if (!(nrm - 1.f < qc.tol)) *qc.flag = qc.stamp;
+            // system scope: the flag may live in mapped pinned HOST memory (sgn_project_fwd_all), where the host reads it
+            // behind an event without a copy command (a plain store is not guaranteed to have landed)
+            if (!(nrm - 1.f < qc.tol)) {
+                __hip_atomic_store(qc.flag, qc.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __threadfence_system();
+            }
+            if (qc.ok != nullptr && i == 0) {
+                __hip_atomic_store(qc.ok, qc.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __threadfence_system();
+            }
         }
     }
     const float p0 = LG.p[0], p1 = LG.p[1], p2 = LG.p[2];
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
             const float rw = 1.f / (pvz + 1e-6f);
             const float ux = pvx * rw * cam.fx + cam.cx, uy = pvy * rw * cam.fy + cam.cy;
             int mnx, mny, mxx, mxy;
-            sgn_tile_bbox(ux, uy, radius, cam.tiles_x, cam.tiles_y, cam.block, mnx, mny, mxx, mxy);
+            sgn_tile_bbox(ux, uy, radius, cam.tiles_x, cam.tiles_y, cam.block, mnx, mny, mxx, mxy, cam.sem);
             const int area = (mxx - mnx) * (mxy - mny);
             if (area > 0) {
                 o_n = area; o_d = pvz; o_r = sgn_f2i(radius); o_x = ux; o_y = uy;
@@ -250,7 +261,19 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         o_vc2[0] = vc2[0]; o_vc2[1] = vc2[1]; o_vc2[2] = vc2[2];
 
         const float rz = 1.f / pvz, rz2 = rz * rz, rz3 = rz2 * rz;
-        const float J00 = fx * rz, J02 = -fx * pvx * rz2, J11 = fy * rz, J12 = -fy * pvy * rz2;
+        // default: upstream CUDA's project_cov3d_ewa_vjp — the Jacobian of the UN-clamped view-space point.  Variant
+        // (SGN_SEM_EWA_VJP_CLAMPED): differentiate through the forward's clamp tx = tz * clamp(pvx / tz, +-lim): where
+        // the clamp is active d tx / d pvx = 0 and d tx / d tz = tx / tz (what autograd through _torch_impl gives)
+        float ex = pvx, ey = pvy;
+        bool clx = false, cly = false;
+        if (cam.sem & SGN_SEM_EWA_VJP_CLAMPED) {
+            const float qx = pvx / pvz, qy = pvy / pvz;
+            clx = !(qx <= cam.lim_x && qx >= -cam.lim_x);
+            cly = !(qy <= cam.lim_y && qy >= -cam.lim_y);
+            ex = pvz * fminf(cam.lim_x, fmaxf(-cam.lim_x, qx));
+            ey = pvz * fminf(cam.lim_y, fmaxf(-cam.lim_y, qy));
+        }
+        const float J00 = fx * rz, J02 = -fx * ex * rz2, J11 = fy * rz, J12 = -fy * ey * rz2;
         float T[2][3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -283,9 +306,10 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
         const float vJ02 = vT[0][0] * V[8] + vT[0][1] * V[9] + vT[0][2] * V[10];
         const float vJ11 = vT[1][0] * V[4] + vT[1][1] * V[5] + vT[1][2] * V[6];
         const float vJ12 = vT[1][0] * V[8] + vT[1][1] * V[9] + vT[1][2] * V[10];
-        const float vt0 = -fx * rz2 * vJ02, vt1 = -fy * rz2 * vJ12;
-        const float vt2 = -fx * rz2 * vJ00 + 2.f * fx * pvx * rz3 * vJ02 - fy * rz2 * vJ11 +
-                          2.f * fy * pvy * rz3 * vJ12;
+        const float vt0 = clx ? 0.f : -fx * rz2 * vJ02, vt1 = cly ? 0.f : -fy * rz2 * vJ12;
+        // d J02 / d tz = 2 fx tx / tz^3 with tx free, fx tx / tz^3 with tx = tz * lim (clamped)
+        const float vt2 = -fx * rz2 * vJ00 + (clx ? 1.f : 2.f) * fx * ex * rz3 * vJ02 - fy * rz2 * vJ11 +
+                          (cly ? 1.f : 2.f) * fy * ey * rz3 * vJ12;
 #pragma unroll
         for (int j = 0; j < 3; ++j) vm[j] += V[j] * vt0 + V[4 + j] * vt1 + V[8 + j] * vt2;
         o_vm[0] = vm[0]; o_vm[1] = vm[1]; o_vm[2] = vm[2];
@@ -361,7 +385,7 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
 }
 
 Cam make_cam(const float *V, float fx, float fy, float cx, float cy, int h, int w, int block,
-             float clip, float glob_scale) {
+             float clip, float glob_scale, int semantics = 0) {
     Cam c;
     c.V = V;
     c.fx = fx; c.fy = fy; c.cx = cx; c.cy = cy;
@@ -370,7 +394,14 @@ Cam make_cam(const float *V, float fx, float fy, float cx, float cy, int h, int 
     c.block = block;
     c.tiles_x = (w + block - 1) / block; c.tiles_y = (h + block - 1) / block;
     c.clip = clip; c.glob_scale = glob_scale;
+    c.sem = semantics;
     return c;
+}
+
+// the backward's camera: the image size only matters for the clamped EWA vjp (its +-1.3 tan(fov/2) limits)
+Cam bwd_cam(const float *V, float fx, float fy, float glob_scale, int semantics, int img_h, int img_w) {
+    const bool cl = (semantics & SGN_SEM_EWA_VJP_CLAMPED) != 0;
+    return make_cam(V, fx, fy, 0.f, 0.f, cl ? img_h : 16, cl ? img_w : 16, 16, 0.f, glob_scale, semantics);
 }
 
 }  // namespace
@@ -383,18 +414,18 @@ int sgn_project_fwd_checked(int n, const float *means3d, const float *scales, fl
                             float clip_thresh, float *cov3d, float *xys, float *depths,
                             int32_t *radii, float *conics, float *compensation,
                             int32_t *num_tiles_hit, int32_t *quat_flag, float quat_tol, int32_t quat_stamp,
-                            sgn_stream_t stream) {
+                            int32_t *quat_ok, int semantics, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
     SGN_ARG_CHECK(img_h > 0 && img_w > 0, -3);
     if (n == 0) return 0;
     SGN_ARG_CHECK(means3d && scales && quats && viewmat12 && cov3d && xys && depths && radii &&
                       conics && compensation && num_tiles_hit, -4);
-    const Cam cam = make_cam(viewmat12, fx, fy, cx, cy, img_h, img_w, block_width, clip_thresh, glob_scale);
+    const Cam cam = make_cam(viewmat12, fx, fy, cx, cy, img_h, img_w, block_width, clip_thresh, glob_scale, semantics);
     sgn_timing_begin(SGN_T_PROJECT_FWD, stream);
     hipLaunchKernelGGL(project_fwd_kernel<0>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means3d, scales, quats, cam, Fuse{nullptr, nullptr}, cov3d, xys, depths, radii, conics,
-                       compensation, num_tiles_hit, QuatCheck{quat_flag, quat_tol, quat_stamp});
+                       compensation, num_tiles_hit, QuatCheck{quat_flag, quat_tol, quat_stamp, quat_ok});
     sgn_timing_end(SGN_T_PROJECT_FWD, stream);
     SGN_LAUNCH_CHECK();
     return 0;
@@ -405,10 +436,10 @@ SGN_EXPORT int sgn_project_fwd(int n, const float *means3d, const float *scales,
                                float cx, float cy, int img_h, int img_w, int block_width,
                                float clip_thresh, float *cov3d, float *xys, float *depths,
                                int32_t *radii, float *conics, float *compensation,
-                               int32_t *num_tiles_hit, sgn_stream_t stream) {
+                               int32_t *num_tiles_hit, int semantics, sgn_stream_t stream) {
     return sgn_project_fwd_checked(n, means3d, scales, glob_scale, quats, viewmat12, fx, fy, cx, cy, img_h, img_w,
                                    block_width, clip_thresh, cov3d, xys, depths, radii, conics, compensation,
-                                   num_tiles_hit, nullptr, 0.f, 0, stream);
+                                   num_tiles_hit, nullptr, 0.f, 0, nullptr, semantics, stream);
 }
 
 SGN_EXPORT int sgn_project_bwd(int n, const float *means3d, const float *scales, float glob_scale,
@@ -417,13 +448,14 @@ SGN_EXPORT int sgn_project_bwd(int n, const float *means3d, const float *scales,
                                const float *compensation, const float *v_xy, const float *v_depth,
                                const float *v_conic, const float *v_compensation, float *v_cov2d,
                                float *v_cov3d, float *v_mean3d, float *v_scale, float *v_quat,
-                               sgn_stream_t stream) {
+                               int semantics, int img_h, int img_w, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     if (n == 0) return 0;
     SGN_ARG_CHECK(means3d && scales && quats && viewmat12 && cov3d && radii && conics && v_xy &&
                       v_conic && v_mean3d && v_scale && v_quat, -4);
     SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
-    const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
+    SGN_ARG_CHECK(!(semantics & SGN_SEM_EWA_VJP_CLAMPED) || (img_h > 0 && img_w > 0), -7);
+    const Cam cam = bwd_cam(viewmat12, fx, fy, glob_scale, semantics, img_h, img_w);
     sgn_timing_begin(SGN_T_PROJECT_BWD, stream);
     hipLaunchKernelGGL(project_bwd_kernel<0>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means3d, scales, quats, cam, Fuse{nullptr, nullptr}, cov3d, radii, conics, compensation, v_xy,
@@ -439,7 +471,7 @@ SGN_EXPORT int sgn_project_fwd_fused(int n, const float *means_local, const floa
                                      const float *viewmat12, float fx, float fy, float cx, float cy, int img_h,
                                      int img_w, int block_width, float clip_thresh, float *cov3d, float *xys,
                                      float *depths, int32_t *radii, float *conics, float *compensation,
-                                     int32_t *num_tiles_hit, sgn_stream_t stream) {
+                                     int32_t *num_tiles_hit, int semantics, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
     SGN_ARG_CHECK(img_h > 0 && img_w > 0, -3);
@@ -447,11 +479,11 @@ SGN_EXPORT int sgn_project_fwd_fused(int n, const float *means_local, const floa
     SGN_ARG_CHECK(means_local && log_scales && quats_raw && viewmat12 && cov3d && xys && depths && radii && conics &&
                       compensation && num_tiles_hit, -4);
     SGN_ARG_CHECK((object_ids == nullptr) == (poses == nullptr), -5);
-    const Cam cam = make_cam(viewmat12, fx, fy, cx, cy, img_h, img_w, block_width, clip_thresh, glob_scale);
+    const Cam cam = make_cam(viewmat12, fx, fy, cx, cy, img_h, img_w, block_width, clip_thresh, glob_scale, semantics);
     sgn_timing_begin(SGN_T_PROJECT_FWD, stream);
     hipLaunchKernelGGL(project_fwd_kernel<1>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means_local, log_scales, quats_raw, cam, Fuse{object_ids, poses}, cov3d, xys, depths, radii,
-                       conics, compensation, num_tiles_hit, QuatCheck{nullptr, 0.f, 0});
+                       conics, compensation, num_tiles_hit, QuatCheck{nullptr, 0.f, 0, nullptr});
     sgn_timing_end(SGN_T_PROJECT_FWD, stream);
     SGN_LAUNCH_CHECK();
     return 0;
@@ -463,14 +495,15 @@ SGN_EXPORT int sgn_project_bwd_fused(int n, const float *means_local, const floa
                                      const int32_t *radii, const float *conics, const float *compensation,
                                      const float *v_xy, const float *v_depth, const float *v_conic,
                                      const float *v_compensation, float *v_means_local, float *v_log_scales,
-                                     float *v_quats_raw, sgn_stream_t stream) {
+                                     float *v_quats_raw, int semantics, int img_h, int img_w, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     if (n == 0) return 0;
     SGN_ARG_CHECK(means_local && log_scales && quats_raw && viewmat12 && cov3d && radii && conics && v_xy &&
                       v_conic && v_means_local && v_log_scales && v_quats_raw, -4);
     SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
     SGN_ARG_CHECK((object_ids == nullptr) == (poses == nullptr), -6);
-    const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
+    SGN_ARG_CHECK(!(semantics & SGN_SEM_EWA_VJP_CLAMPED) || (img_h > 0 && img_w > 0), -7);
+    const Cam cam = bwd_cam(viewmat12, fx, fy, glob_scale, semantics, img_h, img_w);
     sgn_timing_begin(SGN_T_PROJECT_BWD, stream);
     hipLaunchKernelGGL(project_bwd_kernel<1>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means_local, log_scales, quats_raw, cam, Fuse{object_ids, poses}, cov3d, radii, conics,
@@ -490,13 +523,15 @@ SGN_EXPORT int sgn_project_bwd_act(int n, const float *means3d, const float *sca
                                    const float *cov3d, const int32_t *radii, const float *conics,
                                    const float *compensation, const float *v_xy, const float *v_depth,
                                    const float *v_conic, const float *v_compensation, float *v_mean3d,
-                                   float *v_log_scales, float *v_quats_unnormalised, sgn_stream_t stream) {
+                                   float *v_log_scales, float *v_quats_unnormalised, int semantics, int img_h,
+                                   int img_w, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     if (n == 0) return 0;
     SGN_ARG_CHECK(means3d && scales_activated && quats_unnormalised && viewmat12 && cov3d && radii && conics && v_xy &&
                       v_conic && v_mean3d && v_log_scales && v_quats_unnormalised, -4);
     SGN_ARG_CHECK(v_compensation == nullptr || compensation != nullptr, -5);
-    const Cam cam = make_cam(viewmat12, fx, fy, 0.f, 0.f, 16, 16, 16, 0.f, glob_scale);
+    SGN_ARG_CHECK(!(semantics & SGN_SEM_EWA_VJP_CLAMPED) || (img_h > 0 && img_w > 0), -7);
+    const Cam cam = bwd_cam(viewmat12, fx, fy, glob_scale, semantics, img_h, img_w);
     sgn_timing_begin(SGN_T_PROJECT_BWD, stream);
     hipLaunchKernelGGL(project_bwd_kernel<2>, dim3(sgn_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n,
                        means3d, scales_activated, quats_unnormalised, cam, Fuse{nullptr, nullptr}, cov3d, radii, conics,

@@ -41,12 +41,13 @@ int sgn_fork_events(hipEvent_t *fork, hipEvent_t *join);   // api.cpp: cached pe
     } while (0)
 
 // project.hip: sgn_project_fwd with upstream's unit-quaternion assertion riding the kernel (quat_flag nullptr: none); a
-// failing row stores quat_stamp into *quat_flag
+// failing row stores quat_stamp into *quat_flag, and — quat_ok != nullptr — the kernel's first lane stores it into
+// *quat_ok ("this launch's stores land where the host looks"); both system-scope
 int sgn_project_fwd_checked(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
                             const float *viewmat12, float fx, float fy, float cx, float cy, int img_h, int img_w,
                             int block_width, float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii,
                             float *conics, float *compensation, int32_t *num_tiles_hit, int32_t *quat_flag,
-                            float quat_tol, int32_t quat_stamp, sgn_stream_t stream);
+                            float quat_tol, int32_t quat_stamp, int32_t *quat_ok, int semantics, sgn_stream_t stream);
 
 static inline int sgn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
@@ -71,13 +72,22 @@ __device__ __forceinline__ int sgn_f2i(float v) {
 }
 
 // gsplat helpers.cuh get_tile_bbox / get_bbox: inclusive min, exclusive max.
+// `semantics` & SGN_SEM_BBOX_ADD_AFTER_CAST: the max side is (int)(c + r) + 1 (gsplat/_torch_impl.py) instead of the
+// default (int)(c + r + 1) (gsplat helpers.cuh); include/sgn_rast.h "upstream-variant semantics".
+__device__ __forceinline__ int sgn_bbox_max(float v, int semantics) {
+    if (semantics & SGN_SEM_BBOX_ADD_AFTER_CAST) {
+        const int t = sgn_f2i(v);
+        return t == 2147483647 ? t : t + 1;
+    }
+    return sgn_f2i(v + 1.0f);
+}
 __device__ __forceinline__ void sgn_tile_bbox(float cx, float cy, float radius, int tiles_x,
                                               int tiles_y, int block, int &mnx, int &mny, int &mxx,
-                                              int &mxy) {
+                                              int &mxy, int semantics = 0) {
     const float fb = (float)block;
     const float tcx = cx / fb, tcy = cy / fb, tr = radius / fb;
     mnx = min(max(0, sgn_f2i(tcx - tr)), tiles_x);
-    mxx = min(max(0, sgn_f2i(tcx + tr + 1.0f)), tiles_x);
+    mxx = min(max(0, sgn_bbox_max(tcx + tr, semantics)), tiles_x);
     mny = min(max(0, sgn_f2i(tcy - tr)), tiles_y);
-    mxy = min(max(0, sgn_f2i(tcy + tr + 1.0f)), tiles_y);
+    mxy = min(max(0, sgn_bbox_max(tcy + tr, semantics)), tiles_y);
 }

@@ -26,15 +26,15 @@ SIGNATURES = {
     "sgn_timing_enable": (None, [_i]),
     "sgn_timing_get": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
     "sgn_project_fwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f,
-                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                             _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sgn_project_bwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                             _vp, _vp, _vp, _vp, _vp, _vp]),
+                             _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sgn_project_fwd_fused": (_i, [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f,
-                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sgn_project_bwd_fused": (_i, [_i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                   _vp, _vp, _vp, _vp]),
+                                   _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sgn_project_bwd_act": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                 _vp, _vp, _vp, _vp]),
+                                 _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sgn_fourier_dc_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_sh_fwd_fused": (_i, [_i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "sgn_sh_bwd_fused": (_i, [_i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
@@ -62,14 +62,14 @@ SIGNATURES = {
     "sgn_sh_bwd": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp]),
     "sgn_scan_workspace_bytes": (_sz, [_i]),
     "sgn_scan_i32": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
-    "sgn_map_isect": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "sgn_map_isect": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _i, _vp]),
     "sgn_sort_workspace_bytes": (_sz, [_i64]),
     "sgn_sort_pairs": (_i, [_i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "sgn_sort_selftest_workspace_bytes": (_sz, []),
     "sgn_sort_selftest": (_i, [_vp, _sz, _i, _vp, _vp]),
     "sgn_tile_bins": (_i, [_i64, _vp, _i, _vp, _vp]),
     "sgn_bin_prepare_workspace_bytes": (_sz, [_i]),
-    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _i, _vp]),
+    "sgn_bin_prepare": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _vp]),
     "sgn_depth_rank_workspace_bytes": (_sz, [_i]),
     "sgn_depth_rank": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     "sgn_bin_intersect_workspace_bytes": (_sz, [_i64]),
@@ -89,11 +89,11 @@ SIGNATURES = {
     "sgn_raster_fwd_groups": (_i, [_i, _i, _i, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _i,
                                    _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_project_fwd_all": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp,
-                                 _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp, _vp]),
+                                 _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp, _i, _vp]),
     "sgn_project_check_wait": (_i, [_vp, _i, _vp]),
     "sgn_rasterize_arena_bytes": (_sz, [_i, _i64]),
     "sgn_rasterize_fwd_all": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp,
-                                   _i64, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+                                   _i64, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "sgn_colors_match_depths": (_i, [_i, _vp, _vp, _vp, _vp]),
     "sgn_depth_reuse": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -118,6 +118,9 @@ def view_for_rank(step: int, rank: int, world: int, n_views: int, seed: int = 0)
     return int(view_permutation(n_views, seed, epoch)[pos])
 
 
+_UNCHECKABLE = 1 << 30     # `outside` count that means "this rank could not check its gradients" (rides the MAX all-reduce)
+
+
 class GradAllReducer:
     """Bucketed all-reduce of per-Gaussian gradients in ONE FIXED COLLECTIVE SEQUENCE on every rank:
 
@@ -146,7 +149,7 @@ class GradAllReducer:
     def __init__(self, params: Sequence[torch.Tensor], big: Iterable[torch.Tensor] = (),
                  average: bool = True, group=None, sh_exchange: "Optional[SHGradExchange]" = None,
                  force: bool = False, overlap: bool = False, collective_average: Optional[bool] = None,
-                 sparse: bool = False, sparse_max_fraction: float = 0.3, sparse_check=8):
+                 sparse: bool = False, sparse_max_fraction: float = 0.3, sparse_check="always"):
         self.sh_exchange = sh_exchange
         # sparse=True: the compacted row exchange (see _finish_sparse) whenever every rank can take part and the mean
         # touched fraction stays below sparse_max_fraction; the dense sequence otherwise — decided per step from
@@ -156,12 +159,17 @@ class GradAllReducer:
         # CONTRACT of the row exchange on the GPU: the rows it sends are the rows the forward WALKED, and every
         # per-Gaussian `.grad` is then REPLACED by the scattered sums — so a gradient row that does not come from the
         # rasterizer's walk (a scale / opacity regulariser on per-Gaussian parameters, any loss term beside the rendered
-        # images) would be dropped, this rank's own rows included.  `sparse_check`: on the first that-many row-exchange
-        # steps ("always": on every one; 0: never) the gradients are scanned for non-zero rows OUTSIDE the list
-        # (sgn_rows_outside, ~44 B per Gaussian, one small MAX all-reduce and a host read); one such row on any rank
-        # sends that step — and every later one — down the dense sequence, with `stats["outside_rows"]` saying why.
+        # images) would be dropped, this rank's own rows included.  `sparse_check`: "always" (DEFAULT since round 6,
+        # a term that switches on late or only every k-th step — splatfacto's scale regulariser runs at
+        # `step % 10 == 0` — misses any finite window): EVERY row-exchange step scans the gradients for non-zero rows
+        # OUTSIDE the list (sgn_rows_outside, ~44 B per Gaussian, one scalar MAX all-reduce and a host read), and a step
+        # with such a row on any rank takes the dense sequence — that step only, the next one is checked again;
+        # an integer k: the first k steps plus every k-th one afterwards, a failing step switching the row exchange off
+        # for good (later steps are not all checked); 0: never.  A step whose gradients cannot be checked (no mark
+        # buffer of the forward for this size) goes dense and is NOT counted as checked.
         self.sparse_check = sparse_check
         self._checked_steps = 0
+        self._sparse_seen = 0
         skip = sh_exchange.leaf_ids() if sh_exchange is not None else set()
         self.params = [p for p in params if id(p) not in skip]
         self.big_ids = {id(p) for p in big if id(p) not in skip}
@@ -183,7 +191,8 @@ class GradAllReducer:
         self._arrived = 0
         self._hooks = []
         self.stats = {"bucket_early": 0, "bucket_late": 0, "sparse_steps": 0, "dense_steps": 0,
-                      "touched_fraction": None, "rows_sent": 0, "outside_rows": 0, "checked_steps": 0}
+                      "touched_fraction": None, "rows_sent": 0, "outside_rows": 0, "checked_steps": 0,
+                      "outside_steps": 0, "uncheckable_steps": 0}
         # timing=True (bench.py): device events around the waits for the step's collectives, so the line can say how much
         # communication the compute stream was actually held up by (`exposed_ms()`); two event records per wait
         self.timing = False
@@ -484,7 +493,12 @@ class GradAllReducer:
 
     def _check_due(self) -> bool:
         k = self.sparse_check
-        return k == "always" or (isinstance(k, int) and self._checked_steps < k)
+        if k == "always":
+            return True
+        if not isinstance(k, int) or isinstance(k, bool) or k <= 0:
+            return False
+        self._sparse_seen += 1
+        return self._checked_steps < k or self._sparse_seen % k == 0
 
     def _rows_inside_the_list(self, rows_p, widths, c, n, dev) -> bool:
         """The checked mode of the row exchange (see `sparse_check`): False — identically on every rank — when some
@@ -493,14 +507,20 @@ class GradAllReducer:
         from . import _lib as L
         m = self._mark
         outside = torch.zeros(1, dtype=torch.int32, device=dev)
-        if m is not None and m["n"] == n and c is not None:
-            f32c = lambda t: t if (t.dtype is torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
-            srcs = [None if p.grad is None else f32c(p.grad.detach()) for p in rows_p]
-            nt = len(rows_p)
-            if any(t is not None for t in srcs):
+        f32c = lambda t: t if (t.dtype is torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
+        srcs = [None if p.grad is None else f32c(p.grad.detach()) for p in rows_p]
+        nt = len(rows_p)
+        checkable = True
+        if any(t is not None for t in srcs):
+            if m is not None and m["n"] == n and c is not None:
                 L.check(L.load().sgn_rows_outside(n, nt, (C.c_void_p * nt)(*[None if t is None else t.data_ptr() for t in srcs]),
                                                   (C.c_int32 * nt)(*widths), L.ptr(m["stamps"]), int(m["epoch"]),
                                                   L.ptr(outside), L.stream_ptr()), "sgn_rows_outside")
+            else:
+                # gradients in hand but nothing to check them against (no walked-row marks of this size, no claimed SH
+                # node): not a passed check — the step goes dense on every rank
+                checkable = False
+                outside.fill_(_UNCHECKABLE)
         worst = outside.to(torch.int64)
         if dist.get_backend(self.group) == "gloo" and worst.is_cuda:
             host = worst.cpu()
@@ -509,12 +529,23 @@ class GradAllReducer:
         else:
             dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=self.group)
         worst = int(worst.item())
-        self._checked_steps += 1
-        self.stats["checked_steps"] = self._checked_steps
+        if worst >= _UNCHECKABLE:
+            self.stats["uncheckable_steps"] += 1
+            return False
+        if checkable:
+            self._checked_steps += 1
+            self.stats["checked_steps"] = self._checked_steps
         if worst > 0:
             self.stats["outside_rows"] = worst
-            self.sparse = False
+            self.stats["outside_steps"] += 1
             import warnings
+            if self.sparse_check == "always":
+                if self.stats["outside_steps"] == 1:
+                    warnings.warn(f"GradAllReducer(sparse=True): {worst} per-Gaussian gradient row(s) are non-zero outside "
+                                  "the rows the forward walked (a loss term beside the rendered images?) — the row "
+                                  "exchange would drop them; such steps take the dense exchange (every step is checked)")
+                return False
+            self.sparse = False
             warnings.warn(f"GradAllReducer(sparse=True): {worst} per-Gaussian gradient row(s) are non-zero outside the "
                           "rows the forward walked (a loss term beside the rendered images?) — the row exchange would "
                           "drop them; using the dense exchange from now on")

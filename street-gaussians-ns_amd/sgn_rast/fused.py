@@ -143,12 +143,14 @@ class _ProjectFused(Function):
         cov3d, xys, depths = torch.empty(n, 6, **f32), torch.empty(n, 2, **f32), torch.empty(n, **f32)
         radii, conics = torch.empty(n, **i32), torch.empty(n, 3, **f32)
         comp, nth = torch.empty(n, **f32), torch.empty(n, **i32)
+        sem = _ops.semantics().flags()          # upstream-variant semantics (ops.upstream_variant), default 0
         L.check(L.load().sgn_project_fwd_fused(
             n, L.ptr(means_c), L.ptr(ls_c), float(glob_scale), L.ptr(q_c), L.ptr(oid), L.ptr(pos), L.ptr(vm),
             float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width), int(block_width),
             float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics), L.ptr(comp),
-            L.ptr(nth), L.stream_ptr()), "sgn_project_fwd_fused")
+            L.ptr(nth), sem, L.stream_ptr()), "sgn_project_fwd_fused")
         ctx.consts = (float(glob_scale), float(fx), float(fy))
+        ctx.sem, ctx.img_hw = sem, (int(img_height), int(img_width))     # the backward runs with the call's semantics
         ctx.has_obj = oid is not None
         saved = [means_c, ls_c, q_c, vm, cov3d, radii, conics, comp]
         if ctx.has_obj:
@@ -174,7 +176,8 @@ class _ProjectFused(Function):
         L.check(L.load().sgn_project_bwd_fused(
             n, L.ptr(means), L.ptr(ls), gs, L.ptr(q), L.ptr(oid), L.ptr(pos), L.ptr(vm), fx, fy, L.ptr(cov3d),
             L.ptr(radii), L.ptr(conics), L.ptr(comp), L.ptr(v_xys), L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comp),
-            L.ptr(v_m), L.ptr(v_s), L.ptr(v_q), L.stream_ptr()), "sgn_project_bwd_fused")
+            L.ptr(v_m), L.ptr(v_s), L.ptr(v_q), ctx.sem, ctx.img_hw[0], ctx.img_hw[1], L.stream_ptr()),
+            "sgn_project_bwd_fused")
         return (v_m, v_s, v_q) + (None,) * 12
 
 

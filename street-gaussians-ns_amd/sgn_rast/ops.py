@@ -15,6 +15,8 @@ arithmetic happens in the hand-written HIP kernels behind the C ABI.
 """
 from __future__ import annotations
 
+import contextlib
+import contextvars
 import ctypes as C
 import os
 import threading
@@ -27,15 +29,76 @@ from torch.autograd import Function
 from . import _lib as L
 from . import proofs
 
-# gsplat 0.1.x clamps alpha at 0.999 in rasterize_forward and 0.99 in rasterize_backward.
+# ------------------------------------------------------------- upstream-variant semantics (round 6)
+# gsplat is absent where this library is built, so three behaviours of gsplat 0.1.x are DECIDED from recollection of
+# upstream rather than read from its source (SURVEY.md Appendix A [verify] / [decide]).  Each is a
+# CALL-TIME switch with the decided behaviour as default — if tests/golden/make_upstream_golden.py, run against the real
+# gsplat, disagrees on one of them, the fix is a flag flip here, not a rewrite of a kernel:
+#   tile_bbox_add_after_cast   False: tile-box max side (int)(c + r + 1), gsplat helpers.cuh (CUDA); True: (int)(c + r) + 1,
+#                              gsplat/_torch_impl.py.  Read by project_gaussians AND by the binning inside
+#                              rasterize_gaussians (they must agree: set it around both).
+#   ewa_vjp_clamped            False: the projection backward uses the Jacobian of the UN-clamped view-space point
+#                              (upstream CUDA project_cov3d_ewa_vjp); True: it differentiates through the forward's
+#                              +-1.3 tan(fov/2) clamp (autograd through _torch_impl).  Read by project_gaussians.
+#   alpha_clamp_bwd            0.99: upstream's backward clamp (0.999 in the forward); 0.999: the self-consistent variant.
+#                              Read by rasterize_gaussians (at the call: the backward runs with the call's value).
+# `with ops.upstream_variant(tile_bbox_add_after_cast=True): ...` changes them for the current thread / context only
+# (contextvars); `ops.semantics()` is what the next call will use; the C ABI takes them as arguments (SGN_SEM_* bits
+# of include/sgn_rast.h, alpha_clamp_bwd of sgn_raster_bwd): the library holds no state.
 UPSTREAM_ALPHA_CLAMP_BWD = 0.99
-_alpha_clamp_bwd = UPSTREAM_ALPHA_CLAMP_BWD
+SEM_BBOX_ADD_AFTER_CAST, SEM_EWA_VJP_CLAMPED = 1, 2       # SGN_SEM_* of include/sgn_rast.h
+
+
+class Semantics:
+    __slots__ = ("tile_bbox_add_after_cast", "ewa_vjp_clamped", "alpha_clamp_bwd")
+
+    def __init__(self, tile_bbox_add_after_cast=False, ewa_vjp_clamped=False, alpha_clamp_bwd=UPSTREAM_ALPHA_CLAMP_BWD):
+        self.tile_bbox_add_after_cast = bool(tile_bbox_add_after_cast)
+        self.ewa_vjp_clamped = bool(ewa_vjp_clamped)
+        self.alpha_clamp_bwd = float(alpha_clamp_bwd)
+
+    def flags(self) -> int:
+        return (SEM_BBOX_ADD_AFTER_CAST if self.tile_bbox_add_after_cast else 0) | (
+            SEM_EWA_VJP_CLAMPED if self.ewa_vjp_clamped else 0)
+
+    def copy(self) -> "Semantics":
+        return Semantics(self.tile_bbox_add_after_cast, self.ewa_vjp_clamped, self.alpha_clamp_bwd)
+
+    def __repr__(self):
+        return (f"Semantics(tile_bbox_add_after_cast={self.tile_bbox_add_after_cast}, ewa_vjp_clamped="
+                f"{self.ewa_vjp_clamped}, alpha_clamp_bwd={self.alpha_clamp_bwd})")
+
+
+_process_semantics = Semantics()
+_ctx_semantics: contextvars.ContextVar = contextvars.ContextVar("sgn_semantics", default=None)
+
+
+def semantics() -> Semantics:
+    """The upstream-variant semantics the next operator call of this context carries."""
+    cur = _ctx_semantics.get()
+    return cur if cur is not None else _process_semantics
+
+
+@contextlib.contextmanager
+def upstream_variant(**kw):
+    """`with upstream_variant(tile_bbox_add_after_cast=True, ewa_vjp_clamped=True, alpha_clamp_bwd=0.999): ...` — a
+    private copy of the semantics for this thread / context (see the note above)."""
+    s = semantics().copy()
+    for k, v in kw.items():
+        if k not in Semantics.__slots__:
+            raise AttributeError(k)
+        setattr(s, k, float(v) if k == "alpha_clamp_bwd" else bool(v))
+    token = _ctx_semantics.set(s)
+    try:
+        yield s
+    finally:
+        _ctx_semantics.reset(token)
 
 
 def set_alpha_clamp_bwd(value: float) -> None:
-    """0.99 (default) reproduces upstream; 0.999 is the self-consistent variant."""
-    global _alpha_clamp_bwd
-    _alpha_clamp_bwd = float(value)
+    """0.99 (default) reproduces upstream; 0.999 is the self-consistent variant.  (Process default; inside
+    `upstream_variant` the context's own copy.)"""
+    semantics().alpha_clamp_bwd = float(value)
 
 
 def _i32c(t: torch.Tensor) -> torch.Tensor:
@@ -78,6 +141,7 @@ class _State:
         self.stat_skipped = 0          # binnings since the statistic was last read back (every eighth one carries it)
         self.eager_side = None         # [pinned int32[8] ring for the eager flag read-back, next slot]
         self.quat_flag = None          # [device int32[1] zeroed once, stamp of the last call] (sgn_project_fwd_all)
+        self.quat_ring = None          # [pinned int32[16]: eight (failed, landed) slots of that call, next slot]
         self.depth_state = {"want": False, "unused": 0, "cache": None}
         self.depth_caches = collections.OrderedDict()                  # binning key -> first pass's channel + state
         self.early = {"entry": None, "misses": 0, "pause": 0}
@@ -353,7 +417,7 @@ class _ProjectGaussians(Function):
             n, L.ptr(means3d), L.ptr(scales), ctx.glob_scale, L.ptr(quats), L.ptr(viewmat), ctx.fx, ctx.fy,
             L.ptr(cov3d), L.ptr(radii), L.ptr(conics), L.ptr(compensation), L.ptr(v_xys), L.ptr(v_depths),
             L.ptr(v_conics), L.ptr(v_comp), L.ptr(v_cov2d), None, L.ptr(v_mean), L.ptr(v_scale), L.ptr(v_quat),
-            L.stream_ptr()), "sgn_project_bwd")
+            ctx.sem, ctx.img_hw[0], ctx.img_hw[1], L.stream_ptr()), "sgn_project_bwd")
         # (means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block, clip)
         # viewmat gradient: never requested by the reference (camera optimiser "off", sgn_config.py:44: `None`, as
         # upstream returns when viewmat.requires_grad is False); when it IS requested (round 5) it is assembled on the
@@ -434,6 +498,7 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
     num_tiles_hit = torch.empty(n, **i32)
     plan = getattr(_call_state, "project_plan", None)
     _call_state.project_plan = None
+    sem = semantics().flags()
     if plan is not None:
         # ONE library call (sgn_project_fwd_all, round 5): the quats check's device pass, the projection and the early
         # depth ranking queued together, the wait for the check's flag last
@@ -446,13 +511,13 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
             # (stamps start far above the 0 / 1 the call-by-call check copies into the same pinned ring)
             if S.quat_flag is None or S.quat_flag[1] >= 2**31 - 2:
                 S.quat_flag = [torch.zeros(1, **i32), _QUAT_STAMP_BASE]
-                S.eager_side = None
+                S.quat_ring = None
             S.quat_flag[1] += 1
             flag, stamp = S.quat_flag
-            if S.eager_side is None:
-                S.eager_side = [torch.zeros(8, dtype=torch.int32).pin_memory(), 0]
-            ring = S.eager_side
-            slot = ring[0][ring[1] % 8:ring[1] % 8 + 1]
+            if S.quat_ring is None:
+                S.quat_ring = [torch.zeros(16, dtype=torch.int32).pin_memory(), 0]
+            ring = S.quat_ring             # eight slots of two words: [failed stamp, landed stamp] (include/sgn_rast.h)
+            slot = ring[0][2 * (ring[1] % 8):2 * (ring[1] % 8) + 2]
             ring[1] += 1
         gid = ws = None
         if plan["rank"]:
@@ -464,7 +529,7 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
             float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
             L.ptr(compensation), L.ptr(num_tiles_hit), 2 if plan["check"] else 0, 1e-6, L.ptr(flag), int(stamp),
             slot.data_ptr() if slot is not None else None, L.ptr(gid), L.ptr(ws), ws.numel() if ws is not None else 0,
-            L.sort_rank_mode(), None, L.stream_ptr()), "sgn_project_fwd_all")
+            L.sort_rank_mode(), None, sem, L.stream_ptr()), "sgn_project_fwd_all")
         # (check_quats = 2: queued, not waited for — `project_gaussians` waits after autograd has wrapped the outputs:
         # whatever the host does before the wait is off the step's critical path, the device is busy behind the flag)
         plan["done"], plan["wait"] = True, ((slot, int(stamp)) if plan["check"] else None)
@@ -478,8 +543,9 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
             n, L.ptr(means3d_c), L.ptr(scales_c), float(glob_scale), L.ptr(quats_c), L.ptr(viewmat_c),
             float(fx), float(fy), float(cx), float(cy), int(img_height), int(img_width), int(block_width),
             float(clip_thresh), L.ptr(cov3d), L.ptr(xys), L.ptr(depths), L.ptr(radii), L.ptr(conics),
-            L.ptr(compensation), L.ptr(num_tiles_hit), L.stream_ptr()), "sgn_project_fwd")
+            L.ptr(compensation), L.ptr(num_tiles_hit), sem, L.stream_ptr()), "sgn_project_fwd")
     ctx.glob_scale, ctx.fx, ctx.fy = float(glob_scale), float(fx), float(fy)
+    ctx.sem, ctx.img_hw = sem, (int(img_height), int(img_width))      # the backward runs with the call's semantics
     ctx.viewmat_shape = tuple(viewmat.shape)
     ctx.mark_non_differentiable(radii, num_tiles_hit)
     # seven outputs, two or three of which the loss ever reaches: without this autograd materialises a zero tensor (an
@@ -516,7 +582,7 @@ class _ProjectGaussiansAct(Function):
             n, L.ptr(means3d), L.ptr(scales), ctx.glob_scale, L.ptr(x), L.ptr(viewmat),
             ctx.fx, ctx.fy, L.ptr(cov3d), L.ptr(radii), L.ptr(conics), L.ptr(compensation), L.ptr(v_xys),
             L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comp), L.ptr(v_mean), L.ptr(v_ls), L.ptr(v_x),
-            L.stream_ptr()), "sgn_project_bwd_act")
+            ctx.sem, ctx.img_hw[0], ctx.img_hw[1], L.stream_ptr()), "sgn_project_bwd_act")
         v_leaves = (v_ls,) if len(ctx.leaf_rows) == 1 else v_ls.split(ctx.leaf_rows)
         return (v_mean, None, None, None, None, None, None, None, None, None, None, None, None, v_x) + tuple(v_leaves)
 
@@ -723,7 +789,7 @@ def map_gaussian_to_intersects(num_points, num_intersects, xys, depths, radii, c
         L.check(L.load().sgn_map_isect(
             num_points, L.ptr(_f32c(xys)), L.ptr(_f32c(depths)), L.ptr(radii.contiguous()),
             L.ptr(cum_tiles_hit.contiguous()), int(tile_bounds[0]), int(tile_bounds[1]), int(block_width),
-            L.ptr(keys), L.ptr(vals), L.stream_ptr()), "sgn_map_isect")
+            L.ptr(keys), L.ptr(vals), semantics().flags(), L.stream_ptr()), "sgn_map_isect")
     return keys, vals
 
 
@@ -838,7 +904,7 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     L.check(lib.sgn_bin_prepare(n, L.ptr(xys_c), L.ptr(_f32c(depths)), L.ptr(radii_c), L.ptr(conics_c), L.ptr(opac_c),
                                 int(bool(opacity_is_logit)), do_cull, tx, ty, int(block_width), L.ptr(cum_r),
                                 L.ptr(gid_by_rank), int(early is not None), L.ptr(bin_recs), L.ptr(ws), ws.numel(),
-                                L.sort_rank_mode(), L.stream_ptr()),
+                                L.sort_rank_mode(), semantics().flags(), L.stream_ptr()),
             "sgn_bin_prepare")
     S = _S()
     if S.side is None:
@@ -1010,7 +1076,8 @@ def clear_binning_cache() -> None:
 def _cache_key(xys, depths, radii, num_tiles_hit, tile_bounds, block_width, conics, opacity, opacity_is_logit):
     cull = tile_culling_enabled
     tensors = (xys, depths, radii, num_tiles_hit) + ((conics, opacity) if cull else ())
-    return _bin_key(tensors, tile_bounds, block_width, (bool(opacity_is_logit), cull)), tensors, cull
+    return _bin_key(tensors, tile_bounds, block_width,
+                    (bool(opacity_is_logit), cull, semantics().tile_bbox_add_after_cast)), tensors, cull
 
 
 def _drop_pending() -> None:
@@ -1301,7 +1368,7 @@ def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colo
         L.ptr(order), L.ptr(tile_kmax), L.ptr(rows), rows.numel(), L.ptr(scratch),
         4 * scratch.numel() if scratch is not None else 0, L.ptr(arena), arena.numel(), pinned[0:1].data_ptr(),
         L.ptr(walk_stat), pinned[7:8].data_ptr() if walk_stat is not None else None, C.byref(n_host),
-        L.sort_rank_mode(), ro_ptr, stream_ptr)
+        L.sort_rank_mode(), semantics().flags(), ro_ptr, stream_ptr)
     if walk_stat is not None and rc in (0, _E_CAPACITY):
         S.walked_permille = quadrant_mask_stats["walked_permille"] = int(pinned[7])
     count = int(n_host.value)
@@ -1344,6 +1411,7 @@ class _RasterizeGaussians(Function):
         # gradients go to the extra inputs instead (the activations' backward runs inside sgn_raster_bwd's unpack kernel)
         ctx.grad_to_logits, ctx.grad_to_pre = len(opacity_logits) > 0, colors_pre is not None
         ctx.logit_rows = [v.shape[0] for v in opacity_logits]
+        ctx.alpha_clamp_bwd = semantics().alpha_clamp_bwd      # the backward runs with the CALL's value
         ctx.set_materialize_grads(False)       # an unused alpha / depth output arrives as None, not as a zero image
         dev = L.require_device(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
         num_points = xys.size(0)
@@ -1623,7 +1691,7 @@ class _RasterizeGaussians(Function):
                     L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity),
                     2 if ctx.grad_to_logits else ctx.opacity_is_logit, id_range[0],
                     id_range[1], window, L.ptr(background), L.ptr(Ts),
-                    L.ptr(idx), L.ptr(v_img), L.ptr(v_alpha), _alpha_clamp_bwd, L.ptr(v_xy),
+                    L.ptr(idx), L.ptr(v_img), L.ptr(v_alpha), ctx.alpha_clamp_bwd, L.ptr(v_xy),
                     L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
                     L.ptr(gws), gws.numel(), L.ptr(order), L.ptr(pre), ro_ptr, L.stream_ptr(),
                     L.aux_stream_ptr(dev) if concurrent_backward else None)

@@ -43,3 +43,38 @@ class TorchStats(_densify.Stats):
             self.vis_counts[visible] = self.vis_counts[visible] + 1
             self.xys_grad_norm[visible] = grads[visible] + self.xys_grad_norm[visible]
         self.max_2Dsize[visible] = torch.maximum(self.max_2Dsize[visible], r[visible] / float(max_dim))
+
+
+def threshold_adjacent_pixels(exp, cam, opacities, block=16):
+    """bool [H, W] from the C oracle: the pixels of a rendered step (`exp`: the oracle's outputs of `step.render` /
+    `train_step`) whose forward walk passes within one exp-implementation difference of the 1/255 skip test or the 1e-4
+    stop test (oracle/c/sgn_oracle.c sgo_raster_threshold_adjacent_rows) — the only pixels where the HIP kernels
+    (v_exp_f32) and the oracle (libm expf) may legitimately composite one entry more or less."""
+    import os
+
+    from oracle import c_oracle as CO
+    H, W = cam.height, cam.width
+    d = lambda t: t.detach().cpu()
+    _cum, _k, _v, _ks, vs, bins = CO.bin_and_sort(d(exp.xys), d(exp.depths), d(exp.radii), d(exp.num_tiles_hit), H, W, block)
+    threads, CO.THREADS = CO.THREADS, max(1, min(32, (os.cpu_count() or 2) - 1))
+    try:
+        return CO.raster_threshold_adjacent(H, W, block, vs, bins, d(exp.xys), d(exp.conics), d(opacities))
+    finally:
+        CO.THREADS = threads
+
+
+def assert_image_bounded(got, exp, adjacent, what, max_abs=1e-4, max_adjacent_frac=5e-4):
+    """SURVEY.md section 8c's bound for BASELINE-size images — max-abs <= 1e-4 — over EVERY pixel except the
+    threshold-adjacent ones, whose number is printed and must stay tiny (the mean / fraction
+    criteria of rounds 2-5 left up to 0.2 % of the pixels unbounded)."""
+    err = (got.detach().cpu().double() - exp.detach().cpu().double()).abs()
+    if err.dim() == 3:
+        err = err.amax(dim=-1)
+    n_adj, n = int(adjacent.sum()), adjacent.numel()
+    worst = float(err[~adjacent].max()) if n_adj < n else 0.0
+    worst_adj = float(err[adjacent].max()) if n_adj else 0.0
+    print(f"[image bound] {what}: max|err| {worst:.2e} over {n - n_adj} pixels (bound {max_abs:.0e}); "
+          f"{n_adj} threshold-adjacent pixels excluded ({100.0 * n_adj / n:.4f} %), max|err| there {worst_adj:.2e}; "
+          f"mean|err| {float(err.mean()):.2e}")
+    assert n_adj <= max_adjacent_frac * n, (what, n_adj, n)
+    assert worst <= max_abs, (what, worst)

@@ -7,6 +7,7 @@ from torch.autograd import Function
 from oracle import c_oracle as CO
 
 ALPHA_CLAMP_BWD = 0.99  # gsplat 0.1.x backward clamp
+SEMANTICS = 0           # upstream-variant bits (oracle.c_oracle.SEM_*): 0 = the decided behaviours
 # (row_lo, row_hi), a list of such ranges (disjoint bands), or None: restrict the compositing (forward and backward) to
 # bands of pixel rows.  Used by the BASELINE-size gradient parity tests together with loss weights that vanish outside the
 # bands, so the bands' backward IS the full backward; image rows outside come back as zeros (not compared).
@@ -22,9 +23,10 @@ def _bands(rows):
 class _Project(Function):
     @staticmethod
     def forward(ctx, means, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block, clip):
-        out = CO.project_fwd(means, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block, clip)
+        out = CO.project_fwd(means, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, H, W, block, clip, SEMANTICS)
         xys, depths, radii, conics, comp, nth, cov3d = out
         ctx.args = (glob_scale, fx, fy)
+        ctx.sem = (SEMANTICS, H, W)
         ctx.save_for_backward(means.detach(), scales.detach(), quats.detach(), viewmat.detach(), cov3d, radii,
                               conics, comp)
         ctx.mark_non_differentiable(radii, nth)
@@ -37,7 +39,7 @@ class _Project(Function):
         n = means.shape[0]
         z = lambda t, *s: torch.zeros(*s) if t is None else t
         vm, vs, vq, _, _ = CO.project_bwd(means, scales, gs, quats, viewmat, fx, fy, cov3d, radii, conics, comp,
-                                          z(v_xys, n, 2), z(v_depths, n), z(v_conics, n, 3), z(v_comp, n))
+                                          z(v_xys, n, 2), z(v_depths, n), z(v_conics, n, 3), z(v_comp, n), *ctx.sem)
         return (vm, vs, None, vq) + (None,) * 9
 
 
@@ -67,7 +69,7 @@ def spherical_harmonics(degrees_to_use, viewdirs, coeffs, method="fast"):
 class _Raster(Function):
     @staticmethod
     def forward(ctx, xys, depths, radii, conics, nth, colors, opacity, H, W, block, background, return_alpha):
-        cum, keys, vals, ks, vs, bins = CO.bin_and_sort(xys, depths, radii, nth, H, W, block)
+        cum, keys, vals, ks, vs, bins = CO.bin_and_sort(xys, depths, radii, nth, H, W, block, SEMANTICS)
         img = fT = fi = None
         for band in _bands(PIXEL_ROWS):           # (outputs are zero outside a band: disjoint bands add up)
             o = CO.raster_fwd(H, W, block, vs, bins, xys, conics, colors, opacity, background, rows=band)
@@ -99,7 +101,38 @@ class _Raster(Function):
 
 def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
                         block_width, background=None, return_alpha=False):
+    if colors.dtype == torch.uint8:
+        colors = colors.float() / 255            # gsplat/rasterize.py: "make sure colors are float [0,1]"
+    d = colors.shape[-1]
     if background is None:
-        background = torch.ones(3)
+        background = torch.ones(d)
+    if d != 3:
+        # upstream's N-D path composites every channel with the same per-pixel walk: three channels per pass of the
+        # 3-channel oracle (zero-padded) give the same channels
+        imgs, alpha = [], None
+        for c0 in range(0, d, 3):
+            w = min(3, d - c0)
+            chunk, bg3 = colors[:, c0:c0 + w], background[c0:c0 + w]
+            if w < 3:
+                chunk = torch.cat([chunk, chunk.new_zeros(chunk.shape[0], 3 - w)], dim=1)
+                bg3 = torch.cat([bg3, bg3.new_zeros(3 - w)])
+            img, alpha = _Raster.apply(xys, depths, radii, conics, num_tiles_hit, chunk, opacity, img_height, img_width,
+                                       block_width, bg3, True)
+            imgs.append(img[..., :w])
+        out = torch.cat(imgs, dim=-1)
+        return (out, alpha) if return_alpha else out
     return _Raster.apply(xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height, img_width,
                          block_width, background, return_alpha)
+
+
+# gsplat/utils.py: the two binning helpers the parity-pin kit freezes (tests/golden/make_upstream_golden.py)
+def compute_cumulative_intersects(num_tiles_hit):
+    cum = CO.scan_i32(num_tiles_hit)
+    return (int(cum[-1]) if cum.numel() else 0), cum
+
+
+def bin_and_sort_gaussians(num_points, num_intersects, xys, depths, radii, cum_tiles_hit, tile_bounds, block_width):
+    keys, vals = CO.map_isect(xys, depths, radii, cum_tiles_hit, int(tile_bounds[0]), int(tile_bounds[1]), block_width,
+                              SEMANTICS)
+    ks, vs = CO.sort_pairs(keys, vals)
+    return keys, vals, ks, vs, CO.tile_bins(ks, int(tile_bounds[0]) * int(tile_bounds[1]))

@@ -70,7 +70,7 @@ def test_argument_errors_are_reported_without_a_gpu(built_lib):
     lib = built_lib.load()
     # block width out of range -> negative rc + message, before any launch
     rc = lib.sgn_project_fwd(4, None, None, 1.0, None, None, 1.0, 1.0, 0.0, 0.0, 8, 8, 32, 0.01,
-                             None, None, None, None, None, None, None, None)
+                             None, None, None, None, None, None, None, 0, None)
     assert rc < 0 and b"block_width" in lib.sgn_last_error()
     rc = lib.sgn_sh_fwd(4, 7, 3, None, None, None, None)
     assert rc < 0
@@ -91,10 +91,22 @@ def test_argument_errors_are_reported_without_a_gpu(built_lib):
     # the one-call projection: check modes are 0 / 1 / 2, the cleared flag needs a device word, the split wait a pinned one
     pf = lambda mode, stamp: lib.sgn_project_fwd_all(4, None, None, 1.0, None, None, 1.0, 1.0, 0.0, 0.0, 8, 8, 16, 0.01,
                                                       None, None, None, None, None, None, None, mode, 1e-6, None, stamp,
-                                                      None, None, None, 0, 0, None, None)
+                                                      None, None, None, 0, 0, None, 0, None)
     assert pf(3, 0) == -3 and b"check_quats" in lib.sgn_last_error()
     assert pf(1, 0) == -1 and pf(2, 7) == -1
     assert lib.sgn_project_check_wait(None, 1, None) == -1 and b"NULL" in lib.sgn_last_error()
+    # upstream-variant semantics are ARGUMENTS (round 6): the clamped EWA vjp needs the image size
+    pb = lambda sem, h, w: lib.sgn_project_bwd(4, 1, 1, 1.0, 1, 1, 1.0, 1.0, 1, 1, 1, None, 1, None, 1, None, None, None,
+                                               1, 1, 1, sem, h, w, None)
+    assert pb(2, 0, 0) == -7 and b"img_h" in lib.sgn_last_error()
+    from sgn_rast import ops
+    assert ops.semantics().flags() == 0 and ops.semantics().alpha_clamp_bwd == 0.99       # the decided defaults
+    with ops.upstream_variant(tile_bbox_add_after_cast=True, ewa_vjp_clamped=True, alpha_clamp_bwd=0.999) as v:
+        assert ops.semantics() is v and v.flags() == 3 and v.alpha_clamp_bwd == 0.999
+    assert ops.semantics().flags() == 0
+    with pytest.raises(AttributeError):
+        with ops.upstream_variant(no_such_switch=True):
+            pass
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -233,10 +233,12 @@ def _one_step_with_extra_loss(P, cam, w_img, w_a, reducer, extra):
         reducer.finish()
 
 
-def test_row_exchange_contract_check_catches_gradient_rows_outside_the_walk():
+@pytest.mark.parametrize("mode", ["always", 8])
+def test_row_exchange_contract_check_catches_gradient_rows_outside_the_walk(mode):
     """the GPU row exchange sends the rows the forward walked and REPLACES every per-Gaussian
-    gradient — a scale regulariser touches every row.  The checked mode (first `sparse_check` steps) must see it, send
-    that step and all later ones down the dense sequence, and the regulariser's rows must survive."""
+    gradient — a scale regulariser touches every row.  The checked mode must see it, send the step down the dense
+    sequence, and the regulariser's rows must survive.  "always" (default since round 6): every step is checked and a
+    failing step alone goes dense; an integer window: the first failing step switches the row exchange off for good."""
     import warnings
     import torch.distributed as dist
     from sgn_rast import dp, ops, scenes, step
@@ -253,8 +255,9 @@ def test_row_exchange_contract_check_catches_gradient_rows_outside_the_walk():
         _one_step_with_extra_loss(Pa, cam, w_img, w_a, None, reg)
         Pb = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
         ex = dp.SHGradExchange(Pb["features_dc"], Pb["features_rest"], force=True).install().set_view(Pb["means"], cam.cam_pos)
+        kw = {} if mode == "always" else {"sparse_check": mode}            # "always" must be the DEFAULT
         red = dp.GradAllReducer(list(Pb.values()), big=[Pb["features_rest"]], sh_exchange=ex, force=True, sparse=True,
-                                sparse_max_fraction=0.9)
+                                sparse_max_fraction=0.9, **kw)
         try:
             with warnings.catch_warnings(record=True) as caught:
                 warnings.simplefilter("always")
@@ -265,11 +268,65 @@ def test_row_exchange_contract_check_catches_gradient_rows_outside_the_walk():
             ex.remove()
             red.remove()
         torch.cuda.synchronize()
-        assert red.stats["outside_rows"] > n // 2 and red.stats["sparse_steps"] == 0 and red.stats["dense_steps"] == 1
-        assert red.sparse is False and any("outside the rows the forward walked" in str(w.message) for w in caught)
+        assert red.stats["outside_rows"] > n // 2 and red.stats["sparse_steps"] == 0, red.stats
+        if mode == "always":
+            assert red.stats["dense_steps"] == 2 and red.stats["outside_steps"] == 2 and red.sparse is True, red.stats
+        else:
+            assert red.stats["dense_steps"] == 1 and red.sparse is False, red.stats
+        assert any("outside the rows the forward walked" in str(w.message) for w in caught)
         for k in Pa:
             assert rel_l2(Pb[k].grad, Pa[k].grad) < 1e-5, k
         assert int((Pb["log_scales"].grad != 0).any(1).sum()) > n // 2          # the regulariser's rows are there
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_exchange_checks_every_step_so_a_periodic_loss_term_is_never_dropped():
+    """a loss term that is switched on only every k-th step (splatfacto's scale regulariser runs at
+    `step % 10 == 0`) or after a warm-up misses any finite check window.  With the default (`sparse_check="always"`) the
+    steps WITHOUT the term take the row exchange, every step WITH it takes the dense sequence, and every step's
+    gradients equal the plain one-process step's."""
+    import warnings
+    import torch.distributed as dist
+    from sgn_rast import dp, ops, scenes, step
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        n = 40000
+        cam, raw = scenes.make_scene("c1", n_override=n)
+        cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+        w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+        reg = lambda P: 1e-3 * (P["log_scales"] ** 2).sum()
+        none = lambda P: 0.0
+        expect = {}                                   # the plain one-process step, with and without the term (the
+        for on in (False, True):                      # parameters never change: no optimiser in this test)
+            Pa = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+            ops.clear_binning_cache()
+            _one_step_with_extra_loss(Pa, cam, w_img, w_a, None, reg if on else none)
+            expect[on] = {k: v.grad.clone() for k, v in Pa.items()}
+        Pb = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+        ex = dp.SHGradExchange(Pb["features_dc"], Pb["features_rest"], force=True).install().set_view(Pb["means"], cam.cam_pos)
+        red = dp.GradAllReducer(list(Pb.values()), big=[Pb["features_rest"]], sh_exchange=ex, force=True, sparse=True,
+                                sparse_max_fraction=0.9)
+        assert red.sparse_check == "always"
+        pattern = [False] * 10 + [True, False, False, True]                     # on for the first time at step 10
+        try:
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                for on in pattern:
+                    ops.clear_binning_cache()
+                    _one_step_with_extra_loss(Pb, cam, w_img, w_a, red, reg if on else none)
+                    for k in Pb:
+                        assert rel_l2(Pb[k].grad, expect[on][k]) < 1e-5, (k, on)
+                    if on:
+                        assert int((Pb["log_scales"].grad != 0).any(1).sum()) > n // 2
+        finally:
+            ex.remove()
+            red.remove()
+        torch.cuda.synchronize()
+        assert red.stats["sparse_steps"] == pattern.count(False), red.stats
+        assert red.stats["dense_steps"] == pattern.count(True) == red.stats["outside_steps"], red.stats
+        assert red.stats["checked_steps"] == len(pattern) and red.stats["uncheckable_steps"] == 0, red.stats
     finally:
         dist.destroy_process_group()
 
