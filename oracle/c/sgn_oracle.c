@@ -511,19 +511,34 @@ SGO_API void sgo_raster_fwd(int H, int W, int block, const int32_t *ids, const i
 
 /* Which pixels of the forward sit next to one of its THRESHOLDS (test infrastructure for the at-size image bound,
  * VERDICT r05 next #5).  The compositing loop takes two data-dependent decisions per entry — skip when alpha < 1/255,
- * stop when T (1 - alpha) <= 1e-4 — and exp is the one step of the arithmetic contract that is not reproducible across
- * implementations (libm's expf here, v_exp_f32 there: DESIGN.md section 3).  A pixel whose walk comes closer to a
- * threshold than that difference can carry may legitimately take the other branch (one entry more or less composited:
- * an error of up to alpha * T, far above any rounding bound); every other pixel takes the same walk on both sides and
- * must agree to rounding.  adjacent[pix] = 1 iff some evaluated entry of the pixel's walk has
- *     | alpha * 255 - 1 |      <= eps_exp                              (the skip test), or
- *     | T (1 - alpha) / 1e-4 - 1 | <= eps_T,  eps_T = eps_exp + sum over the entries composited so far of
- *                                              eps_exp * alpha / (1 - alpha) + 2^-23   (the stop test: the relative
- *                                              error an exp error of eps_exp per entry can have put into T),
- * where eps_exp bounds the RELATIVE difference of the two exp implementations on [-5.6, 0].  Same walk and arithmetic
- * as sgo_raster_fwd_rows. */
+ * stop when T (1 - alpha) <= 1e-4.  Two implementations take the same decisions, and then agree to rounding, unless
+ * something legitimately different between them moves a value across a threshold:
+ *   (1) exp — the one step of the arithmetic contract that is not reproducible (libm's expf here, v_exp_f32 there:
+ *       DESIGN.md section 3): eps_exp bounds the RELATIVE difference of the two on [-5.6, 0];
+ *   (2) their INPUTS, where the caller's own glue ran on different devices (torch.exp / the quaternion division / sigmoid
+ *       on the CPU for one side and on the GPU for the other differ by an ulp, which the covariance inversion amplifies
+ *       for elongated splats): the second parameter set (xys2 / conics2 / opac2; pass the first again if there is none)
+ *       is the other side's.
+ * A pixel that takes the other branch composites one entry more or less: an error of up to alpha * T, far above any
+ * rounding bound.  adjacent[pix] = 1 iff for some evaluated entry of the pixel's walk (control flow: the first set's)
+ * the threshold lies inside the interval spanned by the two sides' values, widened by the exp uncertainty:
+ *     1/255 in [min(raw1, raw2) (1 - eps_exp), max(raw1, raw2) (1 + eps_exp)]          raw = opac * exp(-sigma), or
+ *     1e-4  in [min(nT1, nT2) (1 - eps_T),     max(nT1, nT2) (1 + eps_T)],             nT = T (1 - alpha),
+ *     eps_T = eps_exp + sum over the entries composited so far of (eps_exp * alpha / (1 - alpha) + 2^-23): the relative
+ *     error an exp error of eps_exp per entry can have put into T.
+ * Same arithmetic as sgo_raster_fwd_rows. */
+static float sgo_sigma(const float *xys, const float *conics, int g, float px, float py) {
+    float dx = xys[2 * g] - px, dy = xys[2 * g + 1] - py;
+    float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
+    float s = (a * dx) * dx;
+    s = fmaf(c * dy, dy, s);
+    s = 0.5f * s;
+    return fmaf(b * dx, dy, s);
+}
+
 SGO_API void sgo_raster_threshold_adjacent_rows(int H, int W, int block, const int32_t *ids, const int32_t *bins,
                                                 const float *xys, const float *conics, const float *opac,
+                                                const float *xys2, const float *conics2, const float *opac2,
                                                 float eps_exp, int32_t *adjacent, int row_lo, int row_hi) {
     int tiles_x = (W + block - 1) / block;
     row_lo = imax(row_lo, 0); row_hi = imin(row_hi, H);
@@ -533,26 +548,28 @@ SGO_API void sgo_raster_threshold_adjacent_rows(int H, int W, int block, const i
             int start = bins[2 * tile], end = bins[2 * tile + 1];
             float px = (float)j + 0.5f, py = (float)i + 0.5f;
             float T = 1.f;
-            double eps_T = (double)eps_exp;
+            double T2 = 1.0, eps_T = (double)eps_exp;
             int flag = 0;
             for (int k = start; k < end; ++k) {
                 int g = ids[k];
-                float dx = xys[2 * g] - px, dy = xys[2 * g + 1] - py;
-                float a = conics[3 * g], b = conics[3 * g + 1], c = conics[3 * g + 2];
-                float s = (a * dx) * dx;
-                s = fmaf(c * dy, dy, s);
-                s = 0.5f * s;
-                float sigma = fmaf(b * dx, dy, s);
-                if (sigma < 0.f) continue;                       /* (exact on both sides: no exp involved) */
+                float sigma = sgo_sigma(xys, conics, g, px, py);
+                float sigma2 = sgo_sigma(xys2, conics2, g, px, py);
+                if ((sigma < 0.f) != (sigma2 < 0.f)) flag = 1;
+                if (sigma < 0.f) continue;
                 float raw = opac[g] * sgo_exp(-sigma);
-                if (fabs((double)raw * 255.0 - 1.0) <= (double)eps_exp) flag = 1;
+                double raw2 = (double)opac2[g] * exp(-(double)sigma2);
+                double lo = fmin((double)raw, raw2) * (1.0 - eps_exp), hi = fmax((double)raw, raw2) * (1.0 + eps_exp);
+                if (lo * 255.0 <= 1.0 && hi * 255.0 >= 1.0) flag = 1;
                 float alpha = fminf(0.999f, raw);
                 if (alpha < 1.f / 255.f) continue;
+                double alpha2 = fmin(0.999, raw2);
                 float nT = T * (1.f - alpha);
+                double nT2 = T2 * (1.0 - alpha2);
                 eps_T += (double)eps_exp * (double)alpha / (double)(1.f - alpha) + 1.2e-7;
-                if (fabs((double)nT / 1e-4 - 1.0) <= eps_T) flag = 1;
+                lo = fmin((double)nT, nT2) * (1.0 - eps_T); hi = fmax((double)nT, nT2) * (1.0 + eps_T);
+                if (lo <= 1e-4 && hi >= 1e-4) flag = 1;
                 if (nT <= 1e-4f) break;
-                T = nT;
+                T = nT; T2 = nT2;
             }
             adjacent[(size_t)i * W + j] = flag;
         }

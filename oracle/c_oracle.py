@@ -180,12 +180,15 @@ def raster_fwd(H, W, block, ids, bins, xys, conics, colors, opac, bg, rows=None)
 EXP_REL_EPS = 1e-6
 
 
-def raster_threshold_adjacent(H, W, block, ids, bins, xys, conics, opac, eps_exp=EXP_REL_EPS, rows=None):
-    """bool [H, W]: pixels whose forward walk comes within `eps_exp` (relative, in exp) of the 1/255 skip test or the 1e-4
-    stop test — the only pixels on which two implementations with different exp may differ by more than rounding."""
+def raster_threshold_adjacent(H, W, block, ids, bins, xys, conics, opac, eps_exp=EXP_REL_EPS, rows=None, other=None):
+    """bool [H, W]: pixels whose forward walk puts the 1/255 skip test or the 1e-4 stop test between the values of two
+    implementations — which differ by `eps_exp` (relative) in exp and, with `other = (xys, conics, opac)` of the other
+    side, by whatever their inputs differ — the only pixels where the two may differ by more than rounding."""
     out = torch.zeros(H, W, dtype=torch.int32)
     lo, hi = (0, H) if rows is None else rows
-    a = (ids.contiguous(), bins.contiguous(), _f(xys), _f(conics), _f(opac).reshape(-1))
+    first = (_f(xys), _f(conics), _f(opac).reshape(-1))
+    second = first if other is None else (_f(other[0]), _f(other[1]), _f(other[2]).reshape(-1))
+    a = (ids.contiguous(), bins.contiguous()) + first + second
     L = lib()
 
     def go(r0, r1):

@@ -189,18 +189,20 @@ __global__ __launch_bounds__(256) void map_isect_kernel(int n, const float *__re
     }
 }
 
+// (tile ids outside [0, n_tiles) — keys that are not this image's — are ignored, never written through)
 __global__ __launch_bounds__(256) void tile_bins_kernel(int64_t n_isect, const int64_t *__restrict__ keys,
-                                                        int32_t *__restrict__ bins) {
+                                                        int32_t *__restrict__ bins, int n_tiles) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_isect) return;
     const int32_t cur = (int32_t)(keys[idx] >> 32);
-    if (idx == 0) bins[2 * cur] = 0;
-    if (idx == n_isect - 1) bins[2 * cur + 1] = (int32_t)n_isect;
+    const bool cur_ok = cur >= 0 && cur < n_tiles;
+    if (idx == 0 && cur_ok) bins[2 * cur] = 0;
+    if (idx == n_isect - 1 && cur_ok) bins[2 * cur + 1] = (int32_t)n_isect;
     if (idx == 0) return;
     const int32_t prev = (int32_t)(keys[idx - 1] >> 32);
     if (prev != cur) {
-        bins[2 * prev + 1] = (int32_t)idx;
-        bins[2 * cur] = (int32_t)idx;
+        if (prev >= 0 && prev < n_tiles) bins[2 * prev + 1] = (int32_t)idx;
+        if (cur_ok) bins[2 * cur] = (int32_t)idx;
     }
 }
 
@@ -782,7 +784,7 @@ SGN_EXPORT int sgn_tile_bins(int64_t n_isect, const int64_t *keys_sorted, int n_
     SGN_ARG_CHECK(keys_sorted != nullptr, -3);
     sgn_timing_begin(SGN_T_BINS, s);
     hipLaunchKernelGGL(tile_bins_kernel, dim3(sgn_cdiv(n_isect, 256)), dim3(256), 0, s, n_isect, keys_sorted,
-                       tile_bins);
+                       tile_bins, n_tiles);
     sgn_timing_end(SGN_T_BINS, s);
     SGN_LAUNCH_CHECK();
     return 0;

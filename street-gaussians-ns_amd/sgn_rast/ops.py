@@ -783,8 +783,10 @@ def map_gaussian_to_intersects(num_points, num_intersects, xys, depths, radii, c
                                block_width):
     """gsplat/utils.py map_gaussian_to_intersects -> (isect_ids int64 [I], gaussian_ids int32 [I])."""
     dev = L.require_device(xys, depths, radii, cum_tiles_hit)
-    keys = torch.empty(num_intersects, dtype=torch.int64, device=dev)
-    vals = torch.empty(num_intersects, dtype=torch.int32, device=dev)
+    # (zero-filled, as upstream's torch.zeros: slots the emission does not reach — a `num_intersects` / `cum_tiles_hit` that
+    # does not belong to these xys / radii — then read as tile 0 / id 0 instead of as whatever the allocator left there)
+    keys = torch.zeros(num_intersects, dtype=torch.int64, device=dev)
+    vals = torch.zeros(num_intersects, dtype=torch.int32, device=dev)
     if num_intersects > 0:
         L.check(L.load().sgn_map_isect(
             num_points, L.ptr(_f32c(xys)), L.ptr(_f32c(depths)), L.ptr(radii.contiguous()),

@@ -45,20 +45,22 @@ class TorchStats(_densify.Stats):
         self.max_2Dsize[visible] = torch.maximum(self.max_2Dsize[visible], r[visible] / float(max_dim))
 
 
-def threshold_adjacent_pixels(exp, cam, opacities, block=16):
+def threshold_adjacent_pixels(exp, cam, opacities, block=16, got=None, got_opacities=None):
     """bool [H, W] from the C oracle: the pixels of a rendered step (`exp`: the oracle's outputs of `step.render` /
-    `train_step`) whose forward walk passes within one exp-implementation difference of the 1/255 skip test or the 1e-4
-    stop test (oracle/c/sgn_oracle.c sgo_raster_threshold_adjacent_rows) — the only pixels where the HIP kernels
-    (v_exp_f32) and the oracle (libm expf) may legitimately composite one entry more or less."""
+    `train_step`; `got`: the other side's, if its operator INPUTS may differ in the last bits — the caller's torch glue
+    ran on another device) whose forward walk puts the 1/255 skip test or the 1e-4 stop test between the two sides' values
+    (oracle/c/sgn_oracle.c sgo_raster_threshold_adjacent_rows): the only pixels where the HIP kernels and the oracle may
+    legitimately composite one entry more or less."""
     import os
 
     from oracle import c_oracle as CO
     H, W = cam.height, cam.width
     d = lambda t: t.detach().cpu()
     _cum, _k, _v, _ks, vs, bins = CO.bin_and_sort(d(exp.xys), d(exp.depths), d(exp.radii), d(exp.num_tiles_hit), H, W, block)
+    other = None if got is None else (d(got.xys), d(got.conics), d(opacities if got_opacities is None else got_opacities))
     threads, CO.THREADS = CO.THREADS, max(1, min(32, (os.cpu_count() or 2) - 1))
     try:
-        return CO.raster_threshold_adjacent(H, W, block, vs, bins, d(exp.xys), d(exp.conics), d(opacities))
+        return CO.raster_threshold_adjacent(H, W, block, vs, bins, d(exp.xys), d(exp.conics), d(opacities), other=other)
     finally:
         CO.THREADS = threads
 

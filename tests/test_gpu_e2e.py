@@ -542,7 +542,7 @@ def test_project_fwd_all_at_the_c_abi_in_every_form_of_its_check():
                 torch.empty(n, 3, **f32), torch.empty(n, **f32), torch.empty(n, **i32)]
     ref = outs()
     L.check(lib.sgn_project_fwd(n, L.ptr(raw["means"]), L.ptr(scales), 1.0, L.ptr(good), L.ptr(V), cam.fx, cam.fy, cam.cx,
-                                cam.cy, cam.height, cam.width, 16, 0.01, *[L.ptr(t) for t in ref], L.stream_ptr()), "fwd")
+                                cam.cy, cam.height, cam.width, 16, 0.01, *[L.ptr(t) for t in ref], 0, L.stream_ptr()), "fwd")
 
     def call(q, mode, stamp, flag_dev, pinned, want_rc=0):
         o = outs()
@@ -550,7 +550,7 @@ def test_project_fwd_all_at_the_c_abi_in_every_form_of_its_check():
         rc = lib.sgn_project_fwd_all(n, L.ptr(raw["means"]), L.ptr(scales), 1.0, L.ptr(q), L.ptr(V), cam.fx, cam.fy,
                                      cam.cx, cam.cy, cam.height, cam.width, 16, 0.01, *[L.ptr(t) for t in o], mode, 1e-6,
                                      L.ptr(flag_dev), stamp, pinned.data_ptr() if pinned is not None else None, None, None,
-                                     0, L.sort_rank_mode(), C.byref(bad_host), L.stream_ptr())
+                                     0, L.sort_rank_mode(), C.byref(bad_host), 0, L.stream_ptr())
         assert rc == want_rc, (rc, lib.sgn_last_error())
         if rc:
             return None
@@ -561,14 +561,20 @@ def test_project_fwd_all_at_the_c_abi_in_every_form_of_its_check():
             assert all(torch.equal(a, b) for a, b in zip(o, ref))
         return bad_host.value
     flag = torch.zeros(1, **i32)
-    pinned = torch.zeros(4, dtype=torch.int32).pin_memory()
+    pinned = torch.zeros(8, dtype=torch.int32).pin_memory()
     # cleared by the call, pageable read-back
     assert call(good, 1, 0, flag, None) == 0 and call(bad, 1, 0, flag, None) == 1 and call(good, 1, 0, flag, None) == 0
-    # stamped, pinned slot (mapped: stored straight into it), waited for inside / outside the call; no device flag needed
+    # stamped, pinned slot of TWO words [failed stamp, landed stamp] (mapped: the kernel stores straight into it), waited
+    # for inside / outside the call; no device flag needed
     for mode in (1, 2):
         for k, (q, want) in enumerate(((good, 0), (bad, 1), (good, 0), (bad, 1))):
-            assert call(q, mode, 100 * mode + k + 1, None, pinned[mode:mode + 1]) == want
-    assert int(pinned[1]) == 104 and int(pinned[2]) == 204          # the last failing stamps, still there: never cleared
+            assert call(q, mode, 100 * mode + k + 1, None, pinned[2 * mode:2 * mode + 2]) == want
+    # the last FAILING stamps are still there (never cleared), and so are the last calls' "landed" stamps (round 6)
+    assert int(pinned[2]) == 104 and int(pinned[4]) == 204 and int(pinned[3]) == 104 and int(pinned[5]) == 204
+    # a slot whose "landed" word never shows the stamp must not read as "all quaternions passed": the wait FAILS (-8)
+    stale = torch.zeros(2, dtype=torch.int32).pin_memory()
+    bad_host = C.c_int32(-7)
+    assert lib.sgn_project_check_wait(stale.data_ptr(), 999, C.byref(bad_host)) == -8 and b"never reached" in lib.sgn_last_error()
     # no check at all
     assert call(bad, 0, 0, None, None) == -7
     # argument errors

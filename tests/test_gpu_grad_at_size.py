@@ -218,11 +218,14 @@ def test_train_step_gradients_match_oracle_over_the_whole_image(name, production
         exp = step.train_step(Pc, cam, w_img, w_a, ops=oracle_ops)
     finally:
         CO.THREADS = threads
-    # max-abs <= 1e-4 at this size, over every pixel whose walk does not pass within one
-    # exp-implementation difference of the 1/255 / 1e-4 thresholds (counted, printed, asserted tiny)
-    adjacent = threshold_adjacent_pixels(exp, cam, torch.sigmoid(Pc["opacity_logits"]))
     for fused in (False, True):      # the drop-in operators, then the fused front ends (activations / view dirs in-kernel)
         Pd, got = _hip_step(cam, raw, w_img, w_a, fused=fused)
+        # max-abs <= 1e-4 at this size, over every pixel EXCEPT those where one of the forward's two
+        # thresholds (1/255, 1e-4) lies between the two sides' values — the sides differ in exp (libm / v_exp_f32) and, in
+        # the last bits, in the operators' inputs (the reference's exp / normalise / sigmoid glue ran on the CPU for one
+        # and on the GPU for the other).  Counted, printed, asserted tiny.
+        adjacent = threshold_adjacent_pixels(exp, cam, torch.sigmoid(Pc["opacity_logits"]), got=got,
+                                             got_opacities=torch.sigmoid(Pd["opacity_logits"].detach()))
         n = exp.radii.numel()
         assert int((got.radii.cpu() != exp.radii).sum()) <= max(2, n // 100_000)   # (torch's exp: GPU vs CPU, see above)
         for attr in ("rgb", "alpha"):
@@ -295,7 +298,8 @@ def test_training_configuration_matches_oracle_over_the_whole_image(fused, produ
     err = (got.rgb.detach().cpu() - exp.rgb.detach()).abs()
     assert float(err.mean()) < 2e-6 and float((err > 2e-5).float().mean()) < 2e-3, float(err.mean())
     # (the blended image: rgb * alpha + sky * (1 - alpha), both factors within the same bound)
-    adjacent = threshold_adjacent_pixels(exp, cam, torch.sigmoid(Pc["opacity_logits"]))
+    adjacent = threshold_adjacent_pixels(exp, cam, torch.sigmoid(Pc["opacity_logits"]), got=got,
+                                         got_opacities=torch.sigmoid(Pd["opacity_logits"].detach()))
     assert_image_bounded(got.rgb, exp.rgb, adjacent, f"training configuration {'fused' if fused else 'drop-in'} rgb")
     assert_image_bounded(got.alpha, exp.alpha, adjacent, f"training configuration {'fused' if fused else 'drop-in'} alpha")
     for k in Pd:
