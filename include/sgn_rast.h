@@ -114,6 +114,11 @@ void sgn_raster_default_opts(sgn_raster_opts *out);
 #define SGN_T_SLOTS 17
 void sgn_timing_enable(int on); /* also clears recorded spans */
 int sgn_timing_get(int slot, int *count /*host*/, float *total_ms /*host*/);
+/* Host microseconds the CALLING THREAD has spent blocked in the event waits of the one-call entries (the quats check of
+ * sgn_project_fwd_all / sgn_project_check_wait, the count of sgn_rasterize_fwd_all, the verdict of
+ * sgn_rasterize_window_all) since the last reset; *n_waits (may be NULL) = how many waits.  Always on (two clock reads
+ * per wait, thread-local): tells a profile whether a composite call's host time is its launches or its wait. */
+double sgn_timing_host_wait_us(int reset, int64_t *n_waits /*host*/);
 
 /* _C.project_gaussians_forward (gsplat/project_gaussians.py:_ProjectGaussians.forward;
  * reference call site sgn_splatfacto.py:860-873).  Every output row is written
@@ -491,12 +496,41 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
                           const float *colors, const float *opacities, int opacity_is_logit, int cull, int img_h,
                           int img_w, int block_width, const float *background3, const int32_t *gid_by_rank_ready,
                           int quadrant_masks, float *out_img, float *final_Ts, int32_t *final_idx,
+                          float *out_depth /*NULL, or [H,W]: also accumulate the depth channel (sgn_raster_fwd)*/,
                           int32_t *gaussian_ids_sorted, int64_t isect_capacity, int32_t *tile_bins,
                           int32_t *tile_order, int32_t *tile_stats, void *rows, size_t rows_bytes,
                           void *order_scratch, size_t order_scratch_bytes, void *arena, size_t arena_bytes,
                           int32_t *count_pinned, const int32_t *extra_dev, int32_t *extra_pinned,
                           int64_t *n_isect_host, int sort_rank_mode, int semantics, const sgn_raster_opts *opts,
                           sgn_stream_t stream);
+
+/* ONE call for a sub-model pass over a CACHED list (round 6; no upstream counterpart).  The scene graph renders its
+ * objects-only / background-only accumulation passes (sgn_splatfacto_scene_graph.py:364-366) from torch.cat COPIES of
+ * per-model slices of the main projection: the call's tensors (`*_w`, n_win rows) are then a row window of the scene
+ * (n_full rows) the cached list (gaussian_ids_sorted [n_isect], tile_bins) was binned for.  The call queues the
+ * comparison that proves it (sgn_rows_match over every tensor pair whose full-scene side is non-NULL, at the n_cand <= 4
+ * candidate offsets cand_lo_host), reads its verdict back (verdict_pinned: pinned host int32[4] or NULL — this path's one
+ * host sync, in place of the intersection-count read-back of the binning it saves), and on a match queues the window's
+ * rows (sgn_raster_build_rows, window form), — sub_list != 0 — its compacted sub-list (sgn_list_window into ids_out
+ * [n_isect] / tile_bins_out), the launch order (tile_order [tiles + 2] out, unless tile_order_ready hands in the shared
+ * list's and no sub-list is made) and sgn_raster_fwd(window = 1).  *matched_lo_host = the matching row offset, or -1:
+ * nothing matched and nothing was rasterized (the caller bins the tensors as a scene of their own).  With every
+ * full-scene pointer NULL nothing is compared and cand_lo_host[0] is taken as settled by the caller.  The node keeps
+ * ids_out / tile_bins_out (or the shared list), tile_order, tile_stats [tiles,2], rows (sgn_raster_workspace_bytes(n_full,
+ * 0, opts)), final_Ts, final_idx for its backward.  arena: sgn_rasterize_window_arena_bytes(tiles). */
+size_t sgn_rasterize_window_arena_bytes(int n_tiles);
+int sgn_rasterize_window_all(int n_win, int n_full, int n_cand, const int32_t *cand_lo_host, const float *xys_w,
+                             const float *depths_w, const int32_t *radii_w, const int32_t *num_tiles_hit_w,
+                             const float *conics_w, const float *colors_w, const float *opacities_w,
+                             int opacity_is_logit, const float *xys, const float *depths, const int32_t *radii,
+                             const int32_t *num_tiles_hit, const float *conics, const float *opacities,
+                             int64_t n_isect, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                             int ids_qmask, int img_h, int img_w, int block_width, const float *background3,
+                             int sub_list, const int32_t *tile_order_ready, float *out_img, float *final_Ts,
+                             int32_t *final_idx, int32_t *ids_out, int32_t *tile_bins_out, int32_t *tile_order,
+                             int32_t *tile_stats, void *rows, size_t rows_bytes, void *order_scratch,
+                             size_t order_scratch_bytes, void *arena, size_t arena_bytes, int32_t *verdict_pinned,
+                             int *matched_lo_host /*host*/, const sgn_raster_opts *opts, sgn_stream_t stream);
 
 /* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built
  * while the host waits for the intersection count (keeps the GPU busy across that sync).  Pre-built rows are used by
@@ -568,6 +602,22 @@ int sgn_raster_bwd_part(int img_h, int img_w, int block_width, int n, int64_t n_
                         void *recs_ws, size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
                         const int32_t *tile_order, const float *colors_pre_clamp, const sgn_raster_opts *opts,
                         sgn_stream_t stream, sgn_stream_t aux_stream, int first, int last);
+
+/* The backward of a rasterize node as ONE call (round 6): sgn_tile_order over the forward's tile statistics (tile_order
+ * [tiles + 2] out — NULL: no reordering, the in-kernel split of long walks —, long walks = opts->adapt_bwd, the
+ * small-splat promotion small_q16 only when stats_have_pairs) + sgn_raster_bwd (first = last = 1; window allowed) or
+ * sgn_raster_bwd_part (otherwise).  Everything else as in sgn_raster_bwd. */
+int sgn_rasterize_bwd_all(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                          const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const int32_t *tile_stats,
+                          int stats_have_pairs, const float *xys, const float *conics, const float *colors,
+                          const float *opacities, int opacity_is_logit, int id_lo, int id_hi, int window,
+                          const float *background3, const float *final_Ts, const int32_t *final_idx,
+                          const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd, float *v_xy,
+                          float *v_conic, float *v_colors, float *v_opacity, void *recs_ws, size_t recs_ws_bytes,
+                          int recs_packed, void *grad_ws, size_t grad_ws_bytes, int32_t *tile_order,
+                          void *order_scratch, size_t order_scratch_bytes, int small_q16,
+                          const float *colors_pre_clamp, const sgn_raster_opts *opts, sgn_stream_t stream,
+                          sgn_stream_t aux_stream, int first, int last);
 
 /* pytorch3d.transforms.quaternion_multiply as object2world_gs uses it (sgn_splatfacto_scene_graph.py:416): Hamilton
  * product a (x) b, real part first, result standardised to a non-negative real part.  `a` is EITHER one quaternion

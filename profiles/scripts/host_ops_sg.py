@@ -70,16 +70,64 @@ def one():
     T["backward (host)"][0] += 1; T["backward (host)"][1] += t2 - t1
 
 
-for _ in range(30):
+import ctypes as C
+from sgn_rast import _lib as L
+lib = L.load()
+# the one-call entries: host time of the call and, inside it, the time blocked in its event wait
+W = collections.defaultdict(lambda: [0, 0.0, 0.0])
+
+
+def timed_lib(name):
+    fn = getattr(lib, name)
+
+    def w(*a):
+        w0 = lib.sgn_timing_host_wait_us(0, None)
+        t = time.perf_counter()
+        try:
+            return fn(*a)
+        finally:
+            e = W[name]
+            e[0] += 1
+            e[1] += time.perf_counter() - t
+            e[2] += (lib.sgn_timing_host_wait_us(0, None) - w0) * 1e-6
+    return w
+
+
+class LibProxy:
+    def __getattr__(self, k):
+        v = timed_lib(k) if k in ("sgn_project_fwd_all", "sgn_project_check_wait", "sgn_rasterize_fwd_all",
+                                  "sgn_rasterize_window_all", "sgn_rasterize_bwd_all") else getattr(lib, k)
+        setattr(self, k, v)
+        return v
+
+
+proxy = LibProxy()
+L.load = lambda: proxy
+# the reference's own host syncs inside the replay (`radii.sum() == 0`, `(num_tiles_hit > 0).any()`: bool() of a tensor)
+_orig_bool = torch.Tensor.__bool__
+torch.Tensor.__bool__ = timed("Tensor.__bool__ (the reference's own host syncs)", _orig_bool)
+for _ in range(40):
     one()
 torch.cuda.synchronize()
+W.clear()
+K, CH = 60, 7
+chunks = []
 T.clear()
-K = 200
-t0 = time.perf_counter()
-for _ in range(K):
-    one()
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(f"step: {dt / K * 1e3:.3f} ms ({'fused' if fused else 'drop-in'} scene graph, timers on)")
+lib.sgn_timing_host_wait_us(1, None)
+for c in range(CH):
+    t0 = time.perf_counter()
+    for _ in range(K):
+        one()
+    torch.cuda.synchronize()
+    chunks.append((time.perf_counter() - t0) / K * 1e3)
+nw = C.c_int64(0)
+wait_us = lib.sgn_timing_host_wait_us(1, C.byref(nw))
+chunks.sort()
+print(f"step: median {chunks[CH // 2]:.3f} ms, min {chunks[0]:.3f}, max {chunks[-1]:.3f} over {CH} chunks of {K} steps "
+      f"({'fused' if fused else 'drop-in'} scene graph, timers on)")
+print(f"  blocked in the one-call entries' event waits: {wait_us / (K * CH) / 1e3:.4f} ms/step over {nw.value / (K * CH):.2f} waits/step")
+K = K * CH
+for k, (c, t, w) in sorted(W.items(), key=lambda kv: -kv[1][1]):
+    print(f"  [C] {k:38s} {t / K * 1e3:8.4f} ms/step   {c / K:6.2f} calls/step   {t / max(c, 1) * 1e6:8.1f} us/call, of which blocked {w / max(c, 1) * 1e6:8.1f} us")
 for k, (c, t) in sorted(T.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k:42s} {t / K * 1e3:8.4f} ms/step   {c / K:6.2f} calls/step   {t / max(c, 1) * 1e6:8.1f} us/call")

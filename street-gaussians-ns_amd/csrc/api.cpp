@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <hip/hip_runtime.h>
 
@@ -54,6 +55,19 @@ int sgn_fork_events(hipEvent_t *fork, hipEvent_t *join) {
 // wait for the count — the path's one host sync, as upstream's `.item()` — the launch order and the forward kernels.
 // Host only: it calls the library's own entry points on the caller's stream and carves its temporaries from ONE arena.
 namespace {
+// host time spent BLOCKED in the one-call entries' event waits (profiles: is a composite call's host time its launches or
+// its wait for the device?); read and reset by sgn_timing_host_wait_us
+thread_local double g_wait_us = 0.0;
+thread_local long g_wait_n = 0;
+inline hipError_t timed_event_sync(hipEvent_t ev) {
+    timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    const hipError_t e = hipEventSynchronize(ev);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    g_wait_us += (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3;
+    ++g_wait_n;
+    return e;
+}
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 int sync_event(hipEvent_t *ev) {          // one untimed event per (thread, device), like the fork / join pair above
     struct One { int dev; hipEvent_t e; };
@@ -173,7 +187,7 @@ int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float 
         if (rc) return rc;
     }
     if (check_quats == 1) {
-        const hipError_t e = hipEventSynchronize(ev);      // the ranking is queued behind the projection: wait now
+        const hipError_t e = timed_event_sync(ev);         // the ranking is queued behind the projection: wait now
         if (e != hipSuccess) { sgn_set_error("sgn_project_fwd_all: %s", hipGetErrorString(e)); return (int)e; }
         int32_t bad = 0;
         rc = read_quat_flag(dst, stamp, &bad, "sgn_project_fwd_all");
@@ -192,7 +206,7 @@ int sgn_project_check_wait(const int32_t *flag_pinned, int32_t flag_stamp, int32
     if (!flag_pinned || !quats_bad_host) { sgn_set_error("sgn_project_check_wait: NULL argument"); return -1; }
     hipEvent_t ev = nullptr;
     if (check_event(&ev) != 0) { sgn_set_error("sgn_project_check_wait: no event"); return -2; }
-    const hipError_t e = hipEventSynchronize(ev);
+    const hipError_t e = timed_event_sync(ev);
     if (e != hipSuccess) { sgn_set_error("sgn_project_check_wait: %s", hipGetErrorString(e)); return (int)e; }
     return read_quat_flag(flag_pinned, flag_stamp > 0 ? flag_stamp : 1, quats_bad_host, "sgn_project_check_wait");
 }
@@ -212,7 +226,8 @@ int sgn_raster_fwd_precleared(int img_h, int img_w, int block_width, int n, int6
                               const float *conics, const float *colors, const float *opacities,
                               int opacity_is_logit, const float *background3, float *out_img, float *final_Ts,
                               int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes, const int32_t *tile_order,
-                              int32_t *tile_kmax, const sgn_raster_opts *opts, sgn_stream_t stream);   // raster.hip
+                              int32_t *tile_kmax, const float *depths, float *out_depth, const sgn_raster_opts *opts,
+                              sgn_stream_t stream);   // raster.hip
 
 extern "C" __attribute__((visibility("default")))
 size_t sgn_rasterize_arena_bytes(int n, int64_t isect_capacity) {
@@ -225,7 +240,7 @@ extern "C" __attribute__((visibility("default")))
 int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const int32_t *radii, const float *conics,
                           const float *colors, const float *opacities, int opacity_is_logit, int cull, int img_h,
                           int img_w, int block_width, const float *background3, const int32_t *gid_by_rank_ready,
-                          int quadrant_masks, float *out_img, float *final_Ts, int32_t *final_idx,
+                          int quadrant_masks, float *out_img, float *final_Ts, int32_t *final_idx, float *out_depth,
                           int32_t *gaussian_ids_sorted, int64_t isect_capacity, int32_t *tile_bins,
                           int32_t *tile_order, int32_t *tile_stats, void *rows, size_t rows_bytes,
                           void *order_scratch, size_t order_scratch_bytes, void *arena, size_t arena_bytes,
@@ -288,7 +303,7 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
                                 gaussian_ids_sorted, tile_bins, quadrant_masks, ws2, ws2_bytes, cum_r + (n - 1),
                                 sort_rank_mode, stats_behind_bins ? 2 * n_tiles : 0, stream);
     if (rc) return rc;
-    e = hipEventSynchronize(ev);                       // the path's one host sync (upstream: `.item()` on the count)
+    e = timed_event_sync(ev);                          // the path's one host sync (upstream: `.item()` on the count)
     if (e != hipSuccess) { sgn_set_error("sgn_rasterize_fwd_all: %s", hipGetErrorString(e)); return (int)e; }
     if (direct && *(volatile int32_t *)dst == -1) {    // never seen; the plain copy is the safety net
         e = hipMemcpy(dst, cum_r + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -303,13 +318,160 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
     if (rc) return rc;
     sgn_raster_opts oo = o;
     oo.ids_qmask = quadrant_masks ? 1 : 0;
+    // out_depth: the DEPTH CHANNEL rides the colour pass (sgn_raster_fwd's depths / out_depth; the scene graph's and the
+    // reference's depth pass is then answered from it, sgn_depth_reuse)
+    const float *dch = out_depth ? depths : nullptr;
     if (stats_behind_bins)
         return sgn_raster_fwd_precleared(img_h, img_w, block_width, n, count, gaussian_ids_sorted, tile_bins, xys, conics,
                                          colors, opacities, opacity_is_logit, background3, out_img, final_Ts, final_idx,
-                                         rows, rows_bytes, tile_order, tile_stats, &oo, stream);
+                                         rows, rows_bytes, tile_order, tile_stats, dch, out_depth, &oo, stream);
     return sgn_raster_fwd(img_h, img_w, block_width, n, count, gaussian_ids_sorted, tile_bins, xys, conics, colors,
                           opacities, opacity_is_logit, 0, n, 0, background3, out_img, final_Ts, final_idx, rows,
-                          rows_bytes, 1, tile_order, tile_stats, nullptr, nullptr, nullptr, &oo, stream);
+                          rows_bytes, 1, tile_order, tile_stats, dch, out_depth, nullptr, &oo, stream);
+}
+
+// ---------------------------------------------------------------- a sub-model pass over a CACHED list, one call (round 6)
+// sgn_rasterize_window_all: the forward of a `rasterize_gaussians` call whose tensors are a ROW WINDOW of a scene that was
+// binned a moment ago (the scene graph's objects-only / background-only accumulation passes,
+// sgn_splatfacto_scene_graph.py:364-366: torch.cat copies of per-model slices of the main projection): the device-side
+// comparison that proves it (sgn_rows_match over whichever tensor pairs are given, at up to 4 candidate offsets), the
+// read-back of its verdict — this path's one host sync, in place of the intersection count's read-back of the binning it
+// saves —, the window's rows, its own compacted sub-list (sgn_list_window) when asked for, the launch order and the
+// forward kernels, on `stream`, temporaries from one arena.  *matched_lo_host = the matching offset, or -1: nothing matched,
+// nothing was rasterized, the caller bins the tensors as a scene of their own.
+size_t sgn_list_window_workspace_bytes(int n_tiles);
+
+extern "C" __attribute__((visibility("default")))
+size_t sgn_rasterize_window_arena_bytes(int n_tiles) {
+    return al256(sgn_list_window_workspace_bytes(n_tiles)) + 256 + 256;
+}
+
+extern "C" __attribute__((visibility("default")))
+int sgn_rasterize_window_all(int n_win, int n_full, int n_cand, const int32_t *cand_lo_host, const float *xys_w,
+                             const float *depths_w, const int32_t *radii_w, const int32_t *num_tiles_hit_w,
+                             const float *conics_w, const float *colors_w, const float *opacities_w,
+                             int opacity_is_logit, const float *xys, const float *depths, const int32_t *radii,
+                             const int32_t *num_tiles_hit, const float *conics, const float *opacities,
+                             int64_t n_isect, const int32_t *gaussian_ids_sorted, const int32_t *tile_bins,
+                             int ids_qmask, int img_h, int img_w, int block_width, const float *background3,
+                             int sub_list, const int32_t *tile_order_ready, float *out_img, float *final_Ts,
+                             int32_t *final_idx, int32_t *ids_out, int32_t *tile_bins_out, int32_t *tile_order,
+                             int32_t *tile_stats, void *rows, size_t rows_bytes, void *order_scratch,
+                             size_t order_scratch_bytes, void *arena, size_t arena_bytes, int32_t *verdict_pinned,
+                             int *matched_lo_host, const sgn_raster_opts *opts, sgn_stream_t stream) {
+    if (n_win < 1 || n_full < n_win || n_cand < 1 || n_cand > 4 || !cand_lo_host || !xys_w || !conics_w || !colors_w ||
+        !opacities_w || !gaussian_ids_sorted || !tile_bins || !background3 || !out_img || !final_Ts || !final_idx ||
+        !tile_stats || !rows || !arena || !matched_lo_host || n_isect < 1 || block_width < 2 || block_width > 16 ||
+        img_h < 1 || img_w < 1 || (sub_list && (!ids_out || !tile_bins_out)) || (!tile_order_ready && !tile_order)) {
+        sgn_set_error("sgn_rasterize_window_all: argument check failed");
+        return -1;
+    }
+    const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
+    const int n_tiles = tiles_x * tiles_y;
+    if (arena_bytes < sgn_rasterize_window_arena_bytes(n_tiles)) {
+        sgn_set_error("sgn_rasterize_window_all: arena too small");
+        return -2;
+    }
+    sgn_raster_opts o;
+    sgn_raster_default_opts(&o);
+    if (opts) o = *opts;
+    if (!o.gather) { sgn_set_error("sgn_rasterize_window_all: gather mode only (opts->gather = 1)"); return -3; }
+    hipStream_t s = (hipStream_t)stream;
+    char *p = (char *)arena;
+    int32_t *mismatch = (int32_t *)p; p += 256;
+    void *lw_ws = p;
+    const size_t lw_bytes = sgn_list_window_workspace_bytes(n_tiles);
+    *matched_lo_host = -1;
+    int lo = -1;
+    const bool compare = xys || depths || radii || num_tiles_hit || conics || opacities;
+    if (compare) {
+        int rc = sgn_rows_match(n_win, n_full, n_cand, cand_lo_host, xys ? xys_w : nullptr, depths ? depths_w : nullptr,
+                                radii ? radii_w : nullptr, num_tiles_hit ? num_tiles_hit_w : nullptr,
+                                conics ? conics_w : nullptr, opacities ? opacities_w : nullptr, xys, depths, radii,
+                                num_tiles_hit, conics, opacities, mismatch, stream);
+        if (rc) return rc;
+        int32_t pageable[4] = {1, 1, 1, 1};
+        int32_t *dst = verdict_pinned ? verdict_pinned : pageable;
+        hipError_t e = hipMemcpyAsync(dst, mismatch, sizeof(int32_t) * n_cand, hipMemcpyDeviceToHost, s);
+        hipEvent_t ev = nullptr;
+        if (e == hipSuccess && sync_event(&ev) != 0) e = hipErrorUnknown;
+        if (e == hipSuccess) e = hipEventRecord(ev, s);
+        if (e == hipSuccess) e = timed_event_sync(ev);
+        if (e != hipSuccess) { sgn_set_error("sgn_rasterize_window_all: verdict read-back: %s", hipGetErrorString(e)); return (int)e; }
+        for (int c = 0; c < n_cand && lo < 0; ++c)
+            if (((volatile int32_t *)dst)[c] == 0) lo = cand_lo_host[c];
+        if (lo < 0) return 0;                   // not a window of that scene: the caller re-bins
+    } else {
+        lo = cand_lo_host[0];                   // the caller has settled every tensor another way
+        if (lo < 0 || lo + n_win > n_full) { sgn_set_error("sgn_rasterize_window_all: offset out of range"); return -4; }
+    }
+    *matched_lo_host = lo;
+    const int id_lo = lo, id_hi = lo + n_win;
+    int rc = sgn_raster_build_rows(n_full, xys_w, conics_w, colors_w, opacities_w, opacity_is_logit, id_lo, id_hi, 1,
+                                   rows, rows_bytes, nullptr, stream);
+    if (rc) return rc;
+    const int32_t *ids = gaussian_ids_sorted, *bins = tile_bins;
+    const int32_t *order = tile_order_ready;
+    if (sub_list) {      // a SMALL window walks its own entries only (same relative order: same image and gradients)
+        rc = sgn_list_window(n_tiles, gaussian_ids_sorted, tile_bins, id_lo, id_hi, ids_qmask, ids_out, tile_bins_out,
+                             lw_ws, lw_bytes, stream);
+        if (rc) return rc;
+        ids = ids_out; bins = tile_bins_out;
+        order = nullptr;                        // another list: another order
+    }
+    if (!order) {
+        rc = sgn_tile_order(n_tiles, bins, nullptr, (o.waves_fwd == 2) ? (o.adapt_fwd > 0 ? o.adapt_fwd : 1024) : 0, 0,
+                            tile_order, order_scratch, order_scratch_bytes, stream);
+        if (rc) return rc;
+        order = tile_order;
+    }
+    sgn_raster_opts oo = o;
+    oo.ids_qmask = ids_qmask ? 1 : 0;
+    return sgn_raster_fwd(img_h, img_w, block_width, n_full, n_isect, ids, bins, xys_w, conics_w, colors_w, opacities_w,
+                          opacity_is_logit, id_lo, id_hi, 1, background3, out_img, final_Ts, final_idx, rows, rows_bytes,
+                          1, order, tile_stats, nullptr, nullptr, nullptr, &oo, stream);
+}
+
+// ---------------------------------------------------------------- the backward of a rasterize node, one call (round 6)
+// sgn_rasterize_bwd_all = sgn_tile_order (the reverse walks' launch order, from the forward's tile statistics) +
+// sgn_raster_bwd / sgn_raster_bwd_part.  tile_order [tiles + 2] stays the caller's (its last word is the walked / listed
+// statistic the host's quadrant-mask policy reads back later).  first / last as in sgn_raster_bwd_part; first = last = 1 is
+// the plain sgn_raster_bwd (window allowed).
+extern "C" __attribute__((visibility("default")))
+int sgn_rasterize_bwd_all(int img_h, int img_w, int block_width, int n, int64_t n_isect,
+                          const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const int32_t *tile_stats,
+                          int stats_have_pairs, const float *xys, const float *conics, const float *colors,
+                          const float *opacities, int opacity_is_logit, int id_lo, int id_hi, int window,
+                          const float *background3, const float *final_Ts, const int32_t *final_idx,
+                          const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd, float *v_xy,
+                          float *v_conic, float *v_colors, float *v_opacity, void *recs_ws, size_t recs_ws_bytes,
+                          int recs_packed, void *grad_ws, size_t grad_ws_bytes, int32_t *tile_order,
+                          void *order_scratch, size_t order_scratch_bytes, int small_q16,
+                          const float *colors_pre_clamp, const sgn_raster_opts *opts, sgn_stream_t stream,
+                          sgn_stream_t aux_stream, int first, int last) {
+    sgn_raster_opts o;
+    sgn_raster_default_opts(&o);
+    if (opts) o = *opts;
+    const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
+    const int32_t *order = nullptr;
+    if (tile_order != nullptr && n_isect > 0 && n > 0) {
+        if (!tile_bins || !tile_stats) { sgn_set_error("sgn_rasterize_bwd_all: tile_order needs tile_bins and tile_stats"); return -1; }
+        int rc = sgn_tile_order(tiles_x * tiles_y, tile_bins, tile_stats, o.adapt_bwd > 0 ? o.adapt_bwd : 256,
+                                stats_have_pairs ? small_q16 : 0, tile_order, order_scratch, order_scratch_bytes, stream);
+        if (rc) return rc;
+        order = tile_order;
+    }
+    if (first && last)
+        return sgn_raster_bwd(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                              opacities, opacity_is_logit, id_lo, id_hi, window, background3, final_Ts, final_idx,
+                              v_out_img, v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors, v_opacity, recs_ws,
+                              recs_ws_bytes, recs_packed, grad_ws, grad_ws_bytes, order, colors_pre_clamp, opts, stream,
+                              aux_stream);
+    return sgn_raster_bwd_part(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors,
+                               opacities, opacity_is_logit, id_lo, id_hi, window, background3, final_Ts, final_idx,
+                               v_out_img, v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors, v_opacity, recs_ws,
+                               recs_ws_bytes, recs_packed, grad_ws, grad_ws_bytes, order, colors_pre_clamp, opts, stream,
+                               aux_stream, first, last);
 }
 
 // ---------------------------------------------------------------- launch chains replayed as HIP graphs
@@ -408,6 +570,15 @@ void sgn_timing_end(int slot, void *stream) {
     std::lock_guard<std::mutex> lk(g_mu);
     for (size_t i = g_spans.size(); i-- > 0;)
         if (g_spans[i].slot == slot) { (void)hipEventRecord(g_spans[i].b, (hipStream_t)stream); return; }
+}
+
+// host microseconds the calling thread has spent blocked in the event waits of the one-call entries (sgn_project_fwd_all /
+// sgn_project_check_wait, sgn_rasterize_fwd_all, sgn_rasterize_window_all) since the last reset, and how many waits
+extern "C" __attribute__((visibility("default"))) double sgn_timing_host_wait_us(int reset, int64_t *n_waits) {
+    const double t = g_wait_us;
+    if (n_waits) *n_waits = g_wait_n;
+    if (reset) { g_wait_us = 0.0; g_wait_n = 0; }
+    return t;
 }
 
 extern "C" __attribute__((visibility("default"))) void sgn_timing_enable(int on) {

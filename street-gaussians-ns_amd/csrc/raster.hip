@@ -1505,10 +1505,11 @@ int sgn_raster_fwd_precleared(int img_h, int img_w, int block_width, int n, int6
                               const float *conics, const float *colors, const float *opacities,
                               int opacity_is_logit, const float *background3, float *out_img, float *final_Ts,
                               int32_t *final_idx, void *recs_ws, size_t recs_ws_bytes, const int32_t *tile_order,
-                              int32_t *tile_kmax, const sgn_raster_opts *opts, sgn_stream_t stream) {
+                              int32_t *tile_kmax, const float *depths, float *out_depth, const sgn_raster_opts *opts,
+                              sgn_stream_t stream) {
     return raster_fwd_impl(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors,
                            opacities, opacity_is_logit, 0, n, 0, background3, out_img, final_Ts, final_idx, recs_ws,
-                           recs_ws_bytes, 1, tile_order, tile_kmax, nullptr, nullptr, nullptr, opts, stream, nullptr, 1);
+                           recs_ws_bytes, 1, tile_order, tile_kmax, depths, out_depth, nullptr, opts, stream, nullptr, 1);
 }
 
 // The forward with the two GROUP accumulations riding on it (FwdGroups above): besides everything sgn_raster_fwd

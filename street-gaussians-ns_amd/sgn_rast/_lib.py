@@ -25,6 +25,7 @@ SIGNATURES = {
     "sgn_raster_default_opts": (None, [_vp]),
     "sgn_timing_enable": (None, [_i]),
     "sgn_timing_get": (_i, [_i, C.POINTER(C.c_int), C.POINTER(C.c_float)]),
+    "sgn_timing_host_wait_us": (C.c_double, [_i, _vp]),
     "sgn_project_fwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f,
                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sgn_project_bwd": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
@@ -92,7 +93,14 @@ SIGNATURES = {
                                  _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp, _i, _vp]),
     "sgn_project_check_wait": (_i, [_vp, _i, _vp]),
     "sgn_rasterize_arena_bytes": (_sz, [_i, _i64]),
-    "sgn_rasterize_fwd_all": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp,
+    "sgn_rasterize_window_arena_bytes": (_sz, [_i]),
+    "sgn_rasterize_window_all": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _i64, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp]),
+    "sgn_rasterize_bwd_all": (_i, [_i, _i, _i, _i, _i64, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp,
+                                   _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp, _sz, _vp, _vp, _sz, _i, _vp,
+                                   _vp, _vp, _vp, _i, _i]),
+    "sgn_rasterize_fwd_all": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp,
                                    _i64, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "sgn_raster_build_rows": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp, _vp]),
     "sgn_colors_match_depths": (_i, [_i, _vp, _vp, _vp, _vp]),

@@ -1313,13 +1313,14 @@ _call_state = threading.local()
 # call-by-call path below, which stays the reference for behaviour.  Same kernels, same order, same results.
 # `SGN_COMPOSITE=0` switches it off.
 composite_forward = os.environ.get("SGN_COMPOSITE", "1") != "0"
-composite_stats = {"forwards": 0, "capacity_misses": 0}
+composite_backward = composite_forward      # the node's backward as one call too (sgn_rasterize_bwd_all, round 6)
+composite_stats = {"forwards": 0, "capacity_misses": 0, "windows": 0, "backwards": 0}
 _E_CAPACITY = -100
 
 
 def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colors_c, opac_c, opacity_is_logit,
                        img_height, img_width, block_width, tile_bounds, bg_c, out_img, final_Ts, final_idx, ro, ro_ptr,
-                       logit_leaves, stream_ptr):
+                       logit_leaves, stream_ptr, out_depth=None):
     """(num_intersects, ids, tile_bins, order, tile_kmax, rows) or None (no capacity known yet / the list did not fit:
     the caller takes the call-by-call path)."""
     if not speculative_binning or depths.dtype is not torch.float32 or radii.dtype is not torch.int32:
@@ -1366,7 +1367,8 @@ def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colo
     rc = lib.sgn_rasterize_fwd_all(
         n, L.ptr(xys_c), L.ptr(_f32c(depths)), L.ptr(_i32c(radii)), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c),
         int(bool(opacity_is_logit)), int(bool(cull)), int(img_height), int(img_width), int(block_width), L.ptr(bg_c),
-        L.ptr(early), int(qmask), L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(ids), cap, L.ptr(tile_bins),
+        L.ptr(early), int(qmask), L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(out_depth), L.ptr(ids), cap,
+        L.ptr(tile_bins),
         L.ptr(order), L.ptr(tile_kmax), L.ptr(rows), rows.numel(), L.ptr(scratch),
         4 * scratch.numel() if scratch is not None else 0, L.ptr(arena), arena.numel(), pinned[0:1].data_ptr(),
         L.ptr(walk_stat), pinned[7:8].data_ptr() if walk_stat is not None else None, C.byref(n_host),
@@ -1400,6 +1402,109 @@ def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colo
         while len(oc) > 4:
             oc.popitem(last=False)
     return count, ids, tile_bins, order, tile_kmax, rows
+
+
+def _order_scratch(S, lib, n_tiles, dev):
+    """The persistent zero-filled scratch of the multi-workgroup tile order (one per stream and tile count)."""
+    if not (tile_order_enabled and tile_order_multiblock):
+        return None
+    scratch = S.order_scratch.get(n_tiles)
+    if scratch is None:
+        if len(S.order_scratch) > 8:
+            S.order_scratch.clear()
+        scratch = S.order_scratch[n_tiles] = torch.zeros(int(lib.sgn_tile_order_scratch_bytes(n_tiles)) // 4,
+                                                         dtype=torch.int32, device=dev)
+    return scratch
+
+
+def _window_candidate(S, key_tail, n, mine):
+    """Host-only pre-check of the window recognition: the most recent binning of this stream if the call's tensors COULD
+    be a row window of its scene (same tile grid / block / flags, fewer rows, same dtypes and row widths, the cached
+    aliases still holding the bytes the list was binned from) -> (candidate offsets, cached value, kept tensors)."""
+    ck, keep, val = S.bin_cache["key"], S.bin_cache["keep"], S.bin_cache["val"]
+    if ck is None or not window_matching_enabled or not binning_cache_enabled or n <= 0:
+        return None
+    if ck[len(keep):] != key_tail or val[0] < 1 or len(mine) != len(keep):
+        return None
+    n_full = keep[0].shape[0]
+    if n_full <= n:
+        return None
+    for i, (t, c) in enumerate(zip(mine, keep)):
+        if t.dtype != c.dtype or t.shape[1:] != c.shape[1:] or t.device != c.device:
+            return None
+        if t.dtype not in (torch.float32, torch.int32):        # sgn_rows_match compares 32-bit words (ADVICE r02)
+            return None
+        if c._version != ck[i][1] or c.data_ptr() != ck[i][0]:
+            return None
+    return sorted({0, n_full - n}), val, keep
+
+
+def _forward_window_composite(S, cand, n, xys_c, depths, radii, num_tiles_hit, conics_c, colors_c, opac_c,
+                              opacity_is_logit, cull, img_height, img_width, block_width, bg_c, out_img, final_Ts,
+                              final_idx, ro, ro_ptr, stream_ptr):
+    """ONE library call for a sub-model pass over the cached list (sgn_rasterize_window_all, round 6): the device-side
+    comparison of all six tensors at the head / tail offsets, the verdict's read-back, the window's rows, its sub-list,
+    the launch order and the forward kernels.  -> (lo, n_full, num_intersects, ids, bins, order, tile_kmax, rows) or None
+    (not a window of that scene: the caller bins the tensors themselves)."""
+    cands, (num_intersects, ids_full, bins_full), keep = cand
+    n_full = keep[0].shape[0]
+    dev = xys_c.device
+    lib = L.load()
+    i32 = dict(dtype=torch.int32, device=dev)
+    n_tiles = bins_full.shape[0]
+    qmask = int(bool(getattr(ids_full, "_sgn_qmask", False)))
+    ro.ids_qmask = qmask
+    sub = bool(list_window_enabled and n < list_window_max_frac * n_full)
+    order_ready = None
+    if not sub:
+        hit = S.order_cache.get((id(bins_full), _fwd_long_thresh(ro)))
+        if hit is not None and hit[0] is bins_full:
+            order_ready = hit[1]
+    ids_out = torch.empty_like(ids_full) if sub else None
+    bins_out = torch.empty_like(bins_full) if sub else None
+    order = torch.empty(n_tiles + 2, **i32) if order_ready is None else None
+    tile_kmax = torch.empty(n_tiles, 2, **i32)
+    rows = L.workspace(lib.sgn_raster_workspace_bytes(n_full, 0, ro_ptr), dev)
+    arena = L.workspace(lib.sgn_rasterize_window_arena_bytes(n_tiles), dev)
+    scratch = _order_scratch(S, lib, n_tiles, dev)
+    if S.side is None:
+        S.side = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]
+    pool = S.side
+    pinned = pool[0][pool[1] % 4]
+    pool[1] += 1
+    f = [c if c.is_contiguous() else c.contiguous() for c in keep] + [None] * (6 - len(keep))
+    if cull:
+        f[5] = f[5].reshape(-1)
+    lo_host = (C.c_int32 * len(cands))(*cands)
+    matched = C.c_int(-1)
+    window_stats["tried"] += 1
+    L.check(lib.sgn_rasterize_window_all(
+        n, n_full, len(cands), lo_host, L.ptr(xys_c), L.ptr(_f32c(depths)), L.ptr(_i32c(radii)),
+        L.ptr(_i32c(num_tiles_hit)), L.ptr(conics_c), L.ptr(colors_c), L.ptr(opac_c), int(bool(opacity_is_logit)),
+        L.ptr(f[0]), L.ptr(f[1]), L.ptr(f[2]), L.ptr(f[3]), L.ptr(f[4]), L.ptr(f[5]), int(num_intersects),
+        L.ptr(ids_full), L.ptr(bins_full), qmask, int(img_height), int(img_width), int(block_width), L.ptr(bg_c),
+        int(sub), L.ptr(order_ready), L.ptr(out_img), L.ptr(final_Ts), L.ptr(final_idx), L.ptr(ids_out),
+        L.ptr(bins_out), L.ptr(order), L.ptr(tile_kmax), L.ptr(rows), rows.numel(), L.ptr(scratch),
+        4 * scratch.numel() if scratch is not None else 0, L.ptr(arena), arena.numel(), pinned.data_ptr(),
+        C.byref(matched), ro_ptr, stream_ptr), "sgn_rasterize_window_all")
+    if S.pending_checks:
+        raise_pending_checks()             # (a host sync has just happened: deferred flags are final)
+    if matched.value < 0:
+        return None
+    window_stats["hit"] += 1
+    composite_stats["windows"] += 1
+    if sub:
+        window_stats["sub_lists"] += 1
+        ids_out._sgn_qmask = bool(qmask)
+        ids_use, bins_use = ids_out, bins_out
+    else:
+        ids_use, bins_use = ids_full, bins_full
+        if order_ready is None and tile_order_enabled:
+            oc = S.order_cache
+            oc[(id(bins_full), _fwd_long_thresh(ro))] = (bins_full, order)
+            while len(oc) > 4:
+                oc.popitem(last=False)
+    return matched.value, n_full, num_intersects, ids_use, bins_use, order_ready if order_ready is not None else order, tile_kmax, rows
 
 
 # --------------------------------------------------------------- rasterize
@@ -1442,10 +1547,26 @@ class _RasterizeGaussians(Function):
         hit = binning_cache_enabled and S.has_binning(key)
         # a sub-model's copy of a window of the cached scene?  (drop-in scene-graph path; see _match_window)
         n_full, window, win = num_points, 0, None
+        wcomp = None
         if id_range is None and not hit and _bin_pending["key"] != key:
-            win = _match_window(key[len(_t):], num_points, xys, depths, radii, num_tiles_hit, conics, opacity, cull,
-                                opacity_logits)
-        if win is not None:
+            cand = None
+            if (composite_forward and tile_order_enabled and ro.gather and group_split is None and not want_depth
+                    and depths.dtype is torch.float32 and radii.dtype is torch.int32
+                    and num_tiles_hit.dtype is torch.int32):
+                cand = _window_candidate(S, key[len(_t):], num_points, _t)
+            if cand is not None:
+                # ONE library call: comparison on the device, verdict, rows, sub-list, order, forward (round 6)
+                wcomp = _forward_window_composite(S, cand, num_points, xys_c, depths, radii, num_tiles_hit, conics_c,
+                                                  colors_c, opac_c, opacity_is_logit, cull, img_height, img_width,
+                                                  block_width, bg_c, out_img, final_Ts, final_idx, ro, ro_ptr, stream_ptr)
+            else:
+                win = _match_window(key[len(_t):], num_points, xys, depths, radii, num_tiles_hit, conics, opacity, cull,
+                                    opacity_logits)
+        if wcomp is not None:
+            lo, n_full, num_intersects, gaussian_ids_sorted, tile_bins, order, tile_kmax, recs = wcomp
+            id_lo, id_hi, window = lo, lo + num_points, 1
+            win = (lo, None, n_full)                      # (a window pass for everything below: sink, ctx)
+        elif win is not None:
             lo, cached, n_full = win
             id_lo, id_hi, window = lo, lo + num_points, 1
         else:
@@ -1470,20 +1591,33 @@ class _RasterizeGaussians(Function):
         # ONE library call for the whole node where nothing special is asked (sgn_rasterize_fwd_all, round 5): the full scene,
         # a fresh binning, no depth channel / reuse / groups, a capacity known from earlier calls
         comp = None
-        if (composite_forward and plain and not hit and not reuse and not accumulate and group_split is None
-                and not want_depth and _bin_pending["key"] != key and not S.pending_checks):
+        if (wcomp is None and composite_forward and plain and not hit and not reuse and group_split is None
+                and _bin_pending["key"] != key and not S.pending_checks):
             comp = _forward_composite(S, key, _t, cull, num_points, xys_c, depths, radii, conics_c, colors_c, opac_c,
                                       opacity_is_logit, img_height, img_width, block_width, tile_bounds, bg_c, out_img,
-                                      final_Ts, final_idx, ro, ro_ptr, opacity_logits, stream_ptr)
-        if comp is not None:
+                                      final_Ts, final_idx, ro, ro_ptr, opacity_logits, stream_ptr,
+                                      out_depth if accumulate else None)
+        if wcomp is not None:
+            pass                               # everything was queued by the one call above
+        elif comp is not None:
             num_intersects, gaussian_ids_sorted, tile_bins, order, tile_kmax, recs = comp
             if num_intersects < 1:
                 recs = None
+                out_depth = None               # never written (no forward ran): the want_depth branch below returns zeros
                 out_img = torch.ones(img_height, img_width, 3, **f32) * bg_c
                 final_Ts = torch.ones(img_height, img_width, **f32)
                 final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
                 gaussian_ids_sorted = torch.zeros(0, dtype=torch.int32, device=dev)
-            S.depth_caches.pop(key, None)      # binned again without the channel: a stale image must not answer later
+            if accumulate and num_intersects >= 1:
+                depth_stats["accumulated"] += 1
+                S.depth_caches[key] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
+                while len(S.depth_caches) > _State.BIN_ENTRIES:
+                    S.depth_caches.popitem(last=False)
+                _depth_state["unused"] += 1
+                if _depth_state["unused"] > 8 and depth_channel == "auto":   # the depth passes stopped coming
+                    _depth_state["want"], _depth_state["unused"] = False, 0
+            else:
+                S.depth_caches.pop(key, None)  # binned again without the channel: a stale image must not answer later
         else:
             # ... and the per-Gaussian rows are built between the binning's first half and its host sync, so the GPU has
             # work queued while the host wakes up (gather mode; the stream mode re-packs rows per intersection later)
@@ -1686,7 +1820,29 @@ class _RasterizeGaussians(Function):
             # benchmark scene: a late long walk is a lone-wave tail; profiles/r03f_*)
             # (a group walk's statistics hold the walk depth only — sgn_raster_fwd_groups records no per-tile pair count
             # for the head / tail groups — so the small-splat classification, which reads that count, stays off for it)
-            order = _tile_order(bins, kmax, ctx.ro.adapt_bwd, pairs_known=kmax is ctx.tile_kmax)
+            pairs_known = kmax is ctx.tile_kmax
+            if composite_backward:
+                # ONE library call: launch order + reverse walks + unpack (sgn_rasterize_bwd_all, round 6)
+                S = _S()
+                n_tiles = bins.shape[0]
+                order = torch.empty(n_tiles + 2, dtype=torch.int32, device=dev) if tile_order_enabled else None
+                scratch = _order_scratch(S, lib, n_tiles, dev) if order is not None else None
+                if order is not None and not window and id_range == (0, n):
+                    S.walk_stat = order[-1:]         # rides to the host with the next binning's count (mask policy)
+                first, last = (1, 1) if part is None else (int(part[0]), int(part[1]))
+                L.check(lib.sgn_rasterize_bwd_all(
+                    H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(ids), L.ptr(bins), L.ptr(kmax),
+                    int(pairs_known), L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity),
+                    2 if ctx.grad_to_logits else ctx.opacity_is_logit, id_range[0], id_range[1], window,
+                    L.ptr(background), L.ptr(Ts), L.ptr(idx), L.ptr(v_img), L.ptr(v_alpha), ctx.alpha_clamp_bwd,
+                    L.ptr(v_xy), L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
+                    L.ptr(gws), gws.numel(), L.ptr(order), L.ptr(scratch),
+                    4 * scratch.numel() if scratch is not None else 0, int(small_splat_q16), L.ptr(pre), ro_ptr,
+                    L.stream_ptr(), L.aux_stream_ptr(dev) if concurrent_backward else None, first, last),
+                    "sgn_rasterize_bwd_all")
+                composite_stats["backwards"] += 1
+                return out
+            order = _tile_order(bins, kmax, ctx.ro.adapt_bwd, pairs_known=pairs_known)
             if order is not None and not window and id_range == (0, n):
                 _S().walk_stat = order[-1:]          # rides to the host with the next binning's count (mask policy)
             args = (H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(ids), L.ptr(bins),

@@ -20,7 +20,7 @@ def _header_functions():
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
     out = {}
-    for m in re.finditer(r"\b(?:int|size_t|void|const char \*)\s*\*?\s*(sgn_\w+)\s*\(([^;{]*)\)\s*;", src):
+    for m in re.finditer(r"\b(?:int|size_t|void|double|const char \*)\s*\*?\s*(sgn_\w+)\s*\(([^;{]*)\)\s*;", src):
         name, args = m.group(1), m.group(2).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         out[name] = n

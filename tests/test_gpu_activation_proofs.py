@@ -164,12 +164,14 @@ def test_raster_proofs_refuse_what_they_cannot_prove(variant, expect):
     assert c is not None and o is not None
 
 
-def _scene_graph_step(on):
+def _scene_graph_step(on, one_call=True):
     """The drop-in scene-graph step (the reference's SHIPPED model, sgn_config.py:42) on a small scene: parameters are
-    row-wise concatenations over four sub-models, quaternion products, Fourier DC sums."""
+    row-wise concatenations over four sub-models, quaternion products, Fourier DC sums.  `one_call=False`: the
+    call-by-call host path (the window passes then settle four of their six tensors on the autograd graph)."""
     from sgn_rast import ops, scenes, step
-    old = (ops.activation_proofs, ops.sh_split_backward)
+    old = (ops.activation_proofs, ops.sh_split_backward, ops.composite_forward, ops.composite_backward)
     ops.activation_proofs = ops.sh_split_backward = on
+    ops.composite_forward = ops.composite_backward = one_call
     try:
         ops.clear_binning_cache()
         cam = scenes.make_camera(160, 96, 140.0)
@@ -189,16 +191,18 @@ def _scene_graph_step(on):
         fired["sh"] = ops.sh_split_stats["split"] - before[1]["split"]
         return out, Ms, fired
     finally:
-        ops.activation_proofs, ops.sh_split_backward = old
+        ops.activation_proofs, ops.sh_split_backward, ops.composite_forward, ops.composite_backward = old
 
 
-def test_scene_graph_aggregates_are_proven_and_gradients_equal_the_chain_through_torch():
-    a, Ma, fa = _scene_graph_step(True)
-    b, Mb, fb = _scene_graph_step(False)
+@pytest.mark.parametrize("one_call", [True, False], ids=["one call per node", "call by call"])
+def test_scene_graph_aggregates_are_proven_and_gradients_equal_the_chain_through_torch(one_call):
+    a, Ma, fa = _scene_graph_step(True, one_call)
+    b, Mb, fb = _scene_graph_step(False, one_call)
     # main projection; sigmoid over the concatenated logits in the rgb, depth and both sub-model passes; the SH node of
-    # the main pass and the two of each sub-model pass (scene_graph.py:285 and sgn_splatfacto.py:939); both sub-model
-    # windows settled on the host — all proven
-    assert fa["project"] == 1 and fa["opacity"] == 4 and fa["sh"] == 5 and fa["window"] == 2, fa
+    # the main pass and the two of each sub-model pass (scene_graph.py:285 and sgn_splatfacto.py:939) — all proven.  The
+    # two sub-model WINDOWS: on the call-by-call path four of their six tensors are settled on the graph; the one-call
+    # path (round 6, default) compares all six on the device inside sgn_rasterize_window_all and reads no graph
+    assert fa["project"] == 1 and fa["opacity"] == 4 and fa["sh"] == 5 and fa["window"] == (0 if one_call else 2), fa
     assert fb["project"] == 0 and fb["opacity"] == 0 and fb["sh"] == 0 and fb["window"] == 0, fb
     for name in ("rgb", "alpha", "depth", "object_acc", "background_acc"):
         assert torch.equal(getattr(a, name), getattr(b, name)), name          # forwards are the same kernels

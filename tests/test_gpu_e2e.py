@@ -519,6 +519,55 @@ def test_one_call_forward_equals_the_call_by_call_path():
     ops.quat_check = old_check
 
 
+def test_one_call_scene_graph_passes_equal_the_call_by_call_path():
+    """Round 6: EVERY raster call shape of the shipped scene-graph model is one C-ABI call per autograd node — the main
+    pass with the depth channel riding it (`sgn_rasterize_fwd_all(out_depth)`), the objects-only / background-only passes
+    recognised as row windows of the cached scene (`sgn_rasterize_window_all`: comparison on the device, verdict, rows,
+    sub-list, order, forward) and every backward (`sgn_rasterize_bwd_all`).  Same kernels in the same order as the
+    call-by-call path: the five images are BIT-EQUAL (portable exp), the gradients equal to atomics order."""
+    from sgn_rast import _lib as L, ops, scenes, step
+    cam, _raw = scenes.make_scene("c1", n_override=6000)
+    cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+    models, poses, idft = scenes.make_scene_graph(6000, cam, n_objects=4, object_frac=0.2, device=DEV)
+    w_img, w_a = step.loss_weights(cam, seed=7, device=DEV)
+
+    def one(Ms):
+        ops.clear_binning_cache()
+        out = step.render_scene_graph(Ms, poses, idft, cam, 3, 16, fused=False)
+        imgs = [t.detach().clone() for t in (out.rgb, out.alpha, out.depth, out.object_acc, out.background_acc)]
+        ((out.rgb * w_img).sum() + (out.alpha * w_a).sum() + (out.object_acc * w_a).sum()
+         + 0.1 * (out.background_acc * w_a).sum() + 1e-3 * out.depth.sum()).backward()
+        return imgs, [p.grad.clone() for m in Ms for p in m.values()]
+
+    res = {}
+    saved = (ops.composite_forward, ops.composite_backward)
+    with L.options(exact_exp=1):
+        try:
+            for mode in (False, True):
+                ops.composite_forward = ops.composite_backward = mode
+                ops._S().last_count.clear()
+                ops._depth_state.update(want=False, unused=0)
+                for it in range(3):      # step 1 learns the capacity and that a depth pass follows the colour pass
+                    Ms = [step.leaf_params(m) for m in models]
+                    before = dict(ops.composite_stats)
+                    hits0, subs0 = ops.window_stats["hit"], ops.window_stats["sub_lists"]
+                    res[mode] = one(Ms)
+                d = {k: ops.composite_stats[k] - before[k] for k in before}
+                assert ops.window_stats["hit"] - hits0 == 2 and ops.window_stats["sub_lists"] - subs0 == 1
+                if mode:     # main pass + two window passes in one call each; four backward walks (main, depth, two windows)
+                    assert d["forwards"] == 1 and d["windows"] == 2 and d["backwards"] == 4, d
+                else:
+                    assert d["forwards"] == 0 and d["windows"] == 0 and d["backwards"] == 0, d
+        finally:
+            ops.composite_forward, ops.composite_backward = saved
+            ops._depth_state.update(want=False, unused=0)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(res[False][0], res[True][0])):
+        assert torch.equal(a, b), i
+    for i, (a, b) in enumerate(zip(res[False][1], res[True][1])):
+        assert rel_l2(b, a) < 1e-5, i                               # (atomics order: not bit-reproducible run to run)
+
+
 def test_project_fwd_all_at_the_c_abi_in_every_form_of_its_check():
     """`sgn_project_fwd_all` as a non-Python host would bind it: the assertion's flag cleared by the call (flag_stamp 0,
     device flag, pageable read-back), stamped into a device word, stamped straight into mapped pinned memory; waited
