@@ -287,13 +287,18 @@ def bin_and_sort_gaussians(num_points, num_intersects, xys, depths, radii, cum_t
 def rasterize_gaussians(
     xys, depths, radii, conics, num_tiles_hit, colors, opacity, img_height: int, img_width: int,
     block_width: int, background: Optional[torch.Tensor] = None, return_alpha: bool = False,
-    return_aux: bool = False, tile_rows: Optional[Tuple[int, int]] = None,
+    return_aux: bool = False, tile_rows: Optional[Tuple[int, int]] = None, chunk: Optional[int] = None,
+    binning=None,
 ):
     """gsplat/rasterize.py rasterize_gaussians, tile-vectorised.
 
-    ``tile_rows=(r0, r1)`` renders only tile rows [r0, r1) (the bounded CPU-baseline
-    sample); the other pixels are left at the background.
-    """
+    ``tile_rows=(r0, r1)`` renders only tile rows [r0, r1) (a bounded sample); the other pixels are left at the
+    background.  ``chunk=k`` walks every tile's depth list k entries at a time and STOPS once no pixel of the tile can
+    composite any more (all transmittances <= 1e-4) — upstream's whole-tile early exit; same values as the
+    one-shot form (the running transmittance enters each chunk's cumulative product as its first factor, so the sequence
+    of multiplications is unchanged), a fraction of its work on content that saturates.  ``binning=(num_intersects,
+    gaussian_ids_sorted, tile_bins)``: the list of an earlier call on the same geometry (a caller that composites the image
+    band by band bins once).  What bench.py's cpu_baseline times (round 6: one WHOLE step, measured)."""
     assert 1 < block_width <= 16, "block_width must be between 2 and 16"
     if colors.dtype == torch.uint8:
         colors = colors.float() / 255
@@ -309,13 +314,19 @@ def rasterize_gaussians(
         raise ValueError("colors must have dimensions (N, D)")
     H, W, B = img_height, img_width, block_width
     tiles_x, tiles_y = (W + B - 1) // B, (H + B - 1) // B
-    num_intersects, cum = compute_cumulative_intersects(num_tiles_hit)
+    if binning is None:
+        num_intersects, cum = compute_cumulative_intersects(num_tiles_hit)
+    else:
+        num_intersects = int(binning[0])
     out_img = background.to(dt).expand(H, W, C).clone()
     final_T = torch.ones(H, W, dtype=dt)
     final_idx = torch.zeros(H, W, dtype=torch.int32)
     if num_intersects >= 1:
-        _, _, _, ids_sorted, tile_bins = bin_and_sort_gaussians(
-            xys.shape[0], num_intersects, xys, depths, radii, cum, (tiles_x, tiles_y, 1), B)
+        if binning is None:
+            _, _, _, ids_sorted, tile_bins = bin_and_sort_gaussians(
+                xys.shape[0], num_intersects, xys, depths, radii, cum, (tiles_x, tiles_y, 1), B)
+        else:
+            ids_sorted, tile_bins = binning[1], binning[2]
         ids64 = ids_sorted.to(torch.int64)
         opac = opacity.reshape(-1)
         r0, r1 = (0, tiles_y) if tile_rows is None else tile_rows
@@ -332,25 +343,39 @@ def rasterize_gaussians(
                     T_cols.append(torch.ones(hh, ww, dtype=dt))
                     idx_cols.append(torch.zeros(hh, ww, dtype=torch.int32))
                     continue
-                g = ids64[s:e]
                 py, px = torch.meshgrid(torch.arange(y0, y1, dtype=dt) + 0.5,
                                         torch.arange(x0, x1, dtype=dt) + 0.5, indexing="ij")
                 px, py = px.reshape(-1, 1), py.reshape(-1, 1)
-                gx, gy = xys[g, 0][None, :], xys[g, 1][None, :]
-                ca, cb, cc = conics[g, 0][None, :], conics[g, 1][None, :], conics[g, 2][None, :]
-                dx, dy = gx - px, gy - py
-                sigma = 0.5 * (ca * dx * dx + cc * dy * dy) + cb * dx * dy
-                alpha = torch.clamp(opac[g][None, :] * torch.exp(-sigma), max=0.999)
-                valid = (sigma >= 0) & (alpha >= 1.0 / 255.0)
-                om = torch.where(valid, 1.0 - alpha, torch.ones_like(alpha))
-                nT = torch.cumprod(om, dim=1)
-                Tb = torch.cat([torch.ones_like(nT[:, :1]), nT[:, :-1]], dim=1)
-                contrib = valid & (nT > 1e-4)
-                wgt = torch.where(contrib, alpha * Tb, torch.zeros_like(alpha))
-                col = wgt @ colors[g]
-                fT = torch.where(contrib, om, torch.ones_like(om)).prod(dim=1)
-                kk = torch.arange(s, e, dtype=torch.int32)[None, :].expand_as(contrib)
-                fi = torch.where(contrib, kk, torch.zeros_like(kk)).amax(dim=1)
+                step_ = (e - s) if not chunk else int(chunk)
+                T_run = col = fT = fi = None
+                for c0 in range(s, e, step_):
+                    c1 = min(c0 + step_, e)
+                    g = ids64[c0:c1]
+                    gx, gy = xys[g, 0][None, :], xys[g, 1][None, :]
+                    ca, cb, cc = conics[g, 0][None, :], conics[g, 1][None, :], conics[g, 2][None, :]
+                    dx, dy = gx - px, gy - py
+                    sigma = 0.5 * (ca * dx * dx + cc * dy * dy) + cb * dx * dy
+                    alpha = torch.clamp(opac[g][None, :] * torch.exp(-sigma), max=0.999)
+                    valid = (sigma >= 0) & (alpha >= 1.0 / 255.0)
+                    om = torch.where(valid, 1.0 - alpha, torch.ones_like(alpha))
+                    if T_run is None:
+                        nT = torch.cumprod(om, dim=1)
+                        Tb = torch.cat([torch.ones_like(nT[:, :1]), nT[:, :-1]], dim=1)
+                    else:          # the running transmittance is the cumulative product's first factor
+                        nT = torch.cumprod(torch.cat([T_run, om], dim=1), dim=1)[:, 1:]
+                        Tb = torch.cat([T_run, nT[:, :-1]], dim=1)
+                    contrib = valid & (nT > 1e-4)
+                    wgt = torch.where(contrib, alpha * Tb, torch.zeros_like(alpha))
+                    col_c = wgt @ colors[g]
+                    fT_c = torch.where(contrib, om, torch.ones_like(om)).prod(dim=1)
+                    kk = torch.arange(c0, c1, dtype=torch.int32)[None, :].expand_as(contrib)
+                    fi_c = torch.where(contrib, kk, torch.zeros_like(kk)).amax(dim=1)
+                    col = col_c if col is None else col + col_c
+                    fT = fT_c if fT is None else fT * fT_c
+                    fi = fi_c if fi is None else torch.maximum(fi, fi_c)
+                    T_run = nT[:, -1:]
+                    if chunk and c1 < e and not bool((T_run.detach() > 1e-4).any()):
+                        break      # whole-tile early exit: nothing behind this chunk can be composited
                 img_cols.append((col + fT[:, None] * background.to(dt)[None, :]).reshape(hh, ww, C))
                 T_cols.append(fT.reshape(hh, ww))
                 idx_cols.append(fi.reshape(hh, ww))

@@ -577,7 +577,13 @@ class GradAllReducer:
         if absent:
             for p in self.params:
                 if id(p) in absent and p.grad is not None:
-                    raise RuntimeError("GradAllReducer.finish: a parameter named absent received a gradient on this rank")
+                    raise RuntimeError(
+                        "GradAllReducer.finish: a parameter named absent holds a gradient on this rank.  Either its "
+                        "sub-model WAS rendered this step (then it is not absent), or the gradient is a stale one: this "
+                        "reducer installs zero gradients for registered parameters that got none, so a loop that keeps "
+                        "them (optimizer.zero_grad(set_to_none=False), or no zero_grad at all) must set `.grad = None` on "
+                        "the parameters it names absent (the reference's own loop does: set_to_none=True)")
+            self._verify_absent_set(absent)
         if self.sparse and self.active and absent:
             self._drop_announcement()
         if self.sparse and self.active and not absent and self._finish_sparse():
@@ -618,6 +624,27 @@ class GradAllReducer:
         for w, p in pending:
             if self.average and not self._avg_in_collective:
                 p.grad /= self.world
+
+    def _verify_absent_set(self, absent) -> None:
+        """`absent` MUST name the same parameters on every rank (it decides which collectives are issued): checked on the
+        first 8 steps that pass one and every 64th afterwards — the positions of the absent parameters, folded into one
+        integer, MIN- and MAX-reduced (a mismatch would otherwise deadlock or misalign the flat bucket)."""
+        if not self.active:
+            return
+        self._absent_calls = getattr(self, "_absent_calls", 0) + 1
+        if self._absent_calls > 8 and self._absent_calls % 64:
+            return
+        h = 0
+        for i, p in enumerate(self.params):
+            if id(p) in absent:
+                h = (h * 1000003 + i + 1) % 2147483629
+        dev = self.params[0].device if dist.get_backend(self.group) != "gloo" else torch.device("cpu")
+        t = torch.tensor([h, -h], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        lo_hi = t.tolist()
+        if lo_hi[0] != -lo_hi[1]:
+            raise RuntimeError("GradAllReducer.finish(absent=...): the ranks name DIFFERENT absent sets — the set must come "
+                               "from replicated information (the frame's annotations), identically on every rank")
 
     def remove(self) -> None:
         """Detach the overlap hooks and the forward sink (a reducer that is being replaced)."""

@@ -107,6 +107,10 @@ def _i32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.int32).contiguous()
 
 
+def _contig(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()      # (`.contiguous()` on a contiguous tensor still costs a dispatch)
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     if t.dtype is torch.float32 and t.is_contiguous():          # the usual case: one call instead of three
         return t.detach()
@@ -383,10 +387,10 @@ def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: tor
             _sh_memo = (weakref.ref(coeffs), src) if src is not None else None
         if src is not None:
             sh_split_stats["split"] += 1
-            return _SphericalHarmonicsSplit.apply(degrees_to_use, viewdirs.contiguous(), coeffs.detach(), src,
+            return _SphericalHarmonicsSplit.apply(degrees_to_use, _contig(viewdirs), coeffs.detach(), src,
                                                   *[p.leaf for p in src.dc], *src.rest)
     sh_split_stats["dense"] += 1
-    return _SphericalHarmonics.apply(degrees_to_use, viewdirs.contiguous(), coeffs.contiguous(), claimed)
+    return _SphericalHarmonics.apply(degrees_to_use, _contig(viewdirs), _contig(coeffs), claimed)
 
 
 # ---------------------------------------------------------------- project
@@ -1351,6 +1355,7 @@ def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colo
             if len(S.order_scratch) > 8:
                 S.order_scratch.clear()
             scratch = S.order_scratch[n_tiles] = torch.zeros(int(lib.sgn_tile_order_scratch_bytes(n_tiles)) // 4, **i32)
+    early_entry = S.early["entry"]
     early = _take_early_rank(depths, radii)
     if S.side is None:
         S.side = [torch.empty(4, 8, dtype=torch.int32).pin_memory(), 0]
@@ -1382,6 +1387,9 @@ def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colo
         binning_stats["speculative_misses"] += 1
         composite_stats["capacity_misses"] += 1
         S.no_speculation_once = True
+        if early is not None:              # the ranking is still valid for these depths / radii: the fallback takes it
+            S.early["entry"] = early_entry
+            early_rank_stats["used"] -= 1
         return None
     L.check(rc, "sgn_rasterize_fwd_all")
     binning_stats["binnings"] += 1
@@ -1591,8 +1599,9 @@ class _RasterizeGaussians(Function):
         # ONE library call for the whole node where nothing special is asked (sgn_rasterize_fwd_all, round 5): the full scene,
         # a fresh binning, no depth channel / reuse / groups, a capacity known from earlier calls
         comp = None
-        if (wcomp is None and composite_forward and plain and not hit and not reuse and group_split is None
-                and _bin_pending["key"] != key and not S.pending_checks):
+        if (wcomp is None and composite_forward and tile_order_enabled and plain and not hit and not reuse
+                and group_split is None and _bin_pending["key"] != key and not S.pending_checks):
+            _drop_pending()        # a prefetched binning of OTHER tensors will never be finished
             comp = _forward_composite(S, key, _t, cull, num_points, xys_c, depths, radii, conics_c, colors_c, opac_c,
                                       opacity_is_logit, img_height, img_width, block_width, tile_bounds, bg_c, out_img,
                                       final_Ts, final_idx, ro, ro_ptr, opacity_logits, stream_ptr,
@@ -1938,11 +1947,11 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
         activation_proof_stats["opacity"] += len(logits) > 0
         activation_proof_stats["colors"] += pre is not None
     _call_state.grad = torch.is_grad_enabled()
-    return _RasterizeGaussians.apply(xys.contiguous(), depths.contiguous(), radii.contiguous(),
-                                     conics.contiguous(), num_tiles_hit.contiguous(),
-                                     (colors.detach() if pre is not None else colors).contiguous(),
-                                     (opacity.detach() if logits else opacity).contiguous(), img_height,
-                                     img_width, block_width, background.contiguous(), return_alpha, False, None, False,
+    c = _contig
+    return _RasterizeGaussians.apply(c(xys), c(depths), c(radii), c(conics), c(num_tiles_hit),
+                                     c(colors.detach() if pre is not None else colors),
+                                     c(opacity.detach() if logits else opacity), img_height,
+                                     img_width, block_width, c(background), return_alpha, False, None, False,
                                      depth_channel != "off" and proofs.enabled() and _provably_depths(colors, depths),
                                      pre, None, *logits)
 

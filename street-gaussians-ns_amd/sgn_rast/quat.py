@@ -36,12 +36,13 @@ def standardize_quaternion(quaternions: torch.Tensor) -> torch.Tensor:
 class _QuatMul(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b):
-        L.require_device(b)
-        b_c = b.detach().to(torch.float32).contiguous()
+        # (quaternion_multiply has checked: `b` float32 [N,4] on the device; eight calls per scene-graph step, so the
+        # conversions that would be no-ops are not made)
+        b_c = b if b.is_contiguous() else b.contiguous()
         n = b_c.shape[0]
         out = torch.empty(n, 4, dtype=torch.float32, device=b.device)
         if a.numel() == 4:                                  # one quaternion for all rows, handed over by value
-            a4 = (C.c_float * 4)(*[float(v) for v in a.detach().reshape(4).tolist()])
+            a4 = (C.c_float * 4)(*a.reshape(4).tolist())
             a_rows = None
         else:
             a4, a_rows = None, a.detach().to(torch.float32).contiguous()
@@ -56,7 +57,7 @@ class _QuatMul(torch.autograd.Function):
         saved = ctx.saved_tensors
         b_c, a_rows = saved[0], (saved[1] if len(saved) > 1 else None)
         n = b_c.shape[0]
-        v = v_out.to(torch.float32).contiguous()
+        v = v_out if (v_out.dtype is torch.float32 and v_out.is_contiguous()) else v_out.to(torch.float32).contiguous()
         need_a = ctx.needs_input_grad[0] and a_rows is not None
         v_b = torch.empty_like(b_c) if ctx.needs_input_grad[1] else None
         v_a = torch.empty_like(a_rows) if need_a else None
