@@ -68,28 +68,22 @@ typedef struct sgn_raster_opts {
                            exp_portable), 0 (default) = hardware v_exp_f32 */
     int reduce_mode;    /* backward wave reduction: 1 (default) = transposed reduction on v_permlane32_swap /
                            v_permlane16_swap + DPP row adds (8 swaps + 12 DPP adds for the nine per-Gaussian sums);
-                           0 = nine butterfly reductions (54 shuffles), kept for A/B measurements and tests;
-                           2 = (round-5 experiment) the 64 -> 16 stage as nine v_mfma_f32_16x16x4_f32 column sums on the
-                           otherwise idle matrix pipe + 6 selects + 12 DPP adds */
-    int gather;         /* 1 (default): kernels chase gaussian_ids_sorted[k] -> per-Gaussian row with dependent scalar
-                           loads (no pack pass); 0: they stream a depth-ordered 48-byte record per intersection */
-    int waves_fwd;      /* forward kernel: 2 (default) = packed FP32, two waves per 16x16 tile, two pixels per lane; the
-                           first tile_order[n_tiles] tiles of the launch order (lists of >= adapt_fwd entries) get four
-                           waves instead (other tile sizes run as 4); 4 = four waves per tile, one 8x8 quadrant each;
-                           1 = one wave64 per tile, 4 pixels per lane; 0 = adaptive between 1 and 4 (split tiles whose
-                           list has >= adapt_fwd entries) */
-    int waves_bwd;      /* same for the backward; default 0 = adaptive on the reverse-walk length (>= adapt_bwd): one
-                           wave per tile means ONE gradient reduction per (tile, Gaussian), four waves mean four */
-    int adapt_fwd, adapt_bwd; /* defaults 1024 / 256; <= 0 = default */
+                           0 = nine butterfly reductions (54 shuffles): an independent second form, run by the tests */
+    int adapt_fwd, adapt_bwd; /* forward: lists of at least adapt_fwd entries (the head of the launch order) get four waves
+                                 per tile instead of two; backward: reverse walks of at least adapt_bwd entries go to the
+                                 four-waves-per-tile kernel (one wave per tile means ONE gradient reduction per (tile,
+                                 Gaussian), four waves mean four).  Defaults 1024 / 256; <= 0 = default */
     int batch_fwd, batch_bwd; /* lists / reverse walks with at least this many entries are read through 64-entry
                                  batches staged in wave-private LDS instead of the one-entry scalar look-ahead
                                  (defaults 256 / 128; <= 0 = default; a huge value disables) */
-    int xcd_swizzle;    /* 1: XCD-aware tile -> workgroup order (contiguous tile band per XCD / L2); default 0 */
     int debug_flags;    /* timing ablations for profiles/ ONLY (results become wrong): bit0 = no gradient atomics,
                            bit1 = no wave reduction; 0 = normal operation */
     int ids_qmask;      /* 1: gaussian_ids_sorted carries quadrant masks in bits 28-31 (sgn_bin_intersect with
                            quadrant_masks) — a property of the list handed in, not a tuning knob; default 0 */
 } sgn_raster_opts;
+/* (Round 6 removed what rounds 2-5 measured and lost: the "stream" mode `gather = 0`, the forced one- / four-wave shapes
+ * `waves_fwd` / `waves_bwd`, `xcd_swizzle`, and `reduce_mode = 2`, the reduction's first stages on the matrix pipe —
+ * profiles/experiments/ keeps their notes and numbers.) */
 void sgn_raster_default_opts(sgn_raster_opts *out);
 
 /* Opt-in per-kernel timing for bench.py / profiles: when enabled, each timed launch is bracketed by
@@ -422,9 +416,9 @@ int sgn_tile_order(int n_tiles, const int32_t *tile_bins, const int32_t *tile_st
                    int32_t *order, void *scratch, size_t scratch_bytes, sgn_stream_t stream);
 
 /* _C.rasterize_forward (3-channel path; reference call sites sgn_splatfacto.py:954-967,
- * :982-994).  `recs_ws` (>= sgn_raster_workspace_bytes(n, n_isect)) receives the depth-ordered
- * 48-byte record stream the kernels read through the scalar cache; keep it alive and pass
- * recs_packed=1 to sgn_raster_bwd to skip re-packing. */
+ * :982-994).  `recs_ws` (>= sgn_raster_workspace_bytes(n, n_isect, opts): one 48-byte row per Gaussian) receives the
+ * rows the kernels read through the scalar cache; keep it alive and pass recs_packed=1 to sgn_raster_bwd to skip
+ * rebuilding them. */
 size_t sgn_raster_workspace_bytes(int n, int64_t n_isect, const sgn_raster_opts *opts);
 int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                    const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
@@ -439,7 +433,7 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                                 torch.cat COPIES of per-model slices, recognised by content)*/,
                    const float *background3, float *out_img /*[H,W,3]*/, float *final_Ts /*[H,W]*/,
                    int32_t *final_idx /*[H,W]*/, void *recs_ws, size_t recs_ws_bytes,
-                   int rows_built /*1: sgn_raster_build_rows already filled recs_ws (gather mode)*/,
+                   int rows_built /*1: sgn_raster_build_rows already filled recs_ws*/,
                    const int32_t *tile_order /*NULL, or sgn_tile_order's permutation of the tiles: launch order*/,
                    int32_t *tile_stats /*NULL, or [tiles,2] out: deepest list position composited by any pixel of the tile;
                                          number of (entry, quadrant) pairs evaluated*/,
@@ -450,7 +444,7 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    float *out_depth /*[H,W]; with depths*/,
                    const int32_t *skip_flag /*NULL, or a device int: when it reads 0 every kernel of this call returns at
                                               once (the caller answers the pass with sgn_depth_reuse); needs
-                                              rows_built = 1 in gather mode*/,
+                                              rows_built = 1*/,
                    const sgn_raster_opts *opts, sgn_stream_t stream);
 /* sgn_raster_fwd with TWO GROUP ACCUMULATIONS riding on the same walk (no upstream counterpart): besides everything
  * sgn_raster_fwd writes, the final transmittance / final index / per-tile walk depth of the pass that would render only
@@ -467,8 +461,7 @@ int sgn_raster_fwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
  * sgn_list_window — the list its backward will walk): its indices are then positions of THAT list, and when it is still
  * alive after the main pass and the other group have finished (a few objects in front of a saturated background) it
  * goes on along its own list instead of dragging the shared walk to the end.  The other group's indices are positions
- * of the shared list.  Packed forward of the gather mode only (opts->gather = 1, waves_fwd = 2; 16x16 tiles; the whole
- * scene): -12 otherwise. */
+ * of the shared list.  Packed forward only (16x16 tiles; the whole scene): -12 otherwise. */
 int sgn_raster_fwd_groups(int img_h, int img_w, int n, int64_t n_isect, const int32_t *gaussian_ids_sorted,
                           const int32_t *tile_bins, const float *xys, const float *conics, const float *colors,
                           const float *opacities, int opacity_is_logit, const float *background3, float *out_img,
@@ -533,8 +526,8 @@ int sgn_rasterize_window_all(int n_win, int n_full, int n_cand, const int32_t *c
                              int *matched_lo_host /*host*/, const sgn_raster_opts *opts, sgn_stream_t stream);
 
 /* The 48-byte per-Gaussian rows the raster kernels read do not depend on the intersection list: they can be built
- * while the host waits for the intersection count (keeps the GPU busy across that sync).  Pre-built rows are used by
- * sgn_raster_fwd when opts->gather != 0 (pass rows_built = 1); in stream mode it re-packs them itself. */
+ * while the host waits for the intersection count (keeps the GPU busy across that sync); pass rows_built = 1 to
+ * sgn_raster_fwd then. */
 int sgn_raster_build_rows(int n, const float *xys, const float *conics, const float *colors, const float *opacities,
                           int opacity_is_logit, int id_lo, int id_hi, int window, void *recs_ws, size_t recs_ws_bytes,
                           const int32_t *skip_flag /*as in sgn_raster_fwd*/, sgn_stream_t stream);

@@ -14,8 +14,6 @@
 
 #include "sgn_rast.h"
 
-#define SGN_GRAPH_KEY_WORDS 12      // as in sgn_common.h (this file is built without the device headers' helpers)
-
 static thread_local char g_err[512] = "";
 
 void sgn_set_error(const char *fmt, ...) {
@@ -260,10 +258,6 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
     sgn_raster_opts o;
     sgn_raster_default_opts(&o);
     if (opts) o = *opts;
-    if (!o.gather) {
-        sgn_set_error("sgn_rasterize_fwd_all: gather mode only (opts->gather = 1)");
-        return -3;
-    }
     hipStream_t s = (hipStream_t)stream;
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     const int n_tiles = tiles_x * tiles_y;
@@ -313,7 +307,7 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
     *n_isect_host = count;
     if (count > isect_capacity) return SGN_E_CAPACITY;   // the list did not fit: call again with more room
     if (count < 1) return 0;                             // nothing visible: the caller writes the background image
-    rc = sgn_tile_order(n_tiles, tile_bins, nullptr, (o.waves_fwd == 2) ? (o.adapt_fwd > 0 ? o.adapt_fwd : 1024) : 0, 0,
+    rc = sgn_tile_order(n_tiles, tile_bins, nullptr, (block_width == 16) ? (o.adapt_fwd > 0 ? o.adapt_fwd : 1024) : 0, 0,
                         tile_order, order_scratch, order_scratch_bytes, stream);
     if (rc) return rc;
     sgn_raster_opts oo = o;
@@ -375,7 +369,6 @@ int sgn_rasterize_window_all(int n_win, int n_full, int n_cand, const int32_t *c
     sgn_raster_opts o;
     sgn_raster_default_opts(&o);
     if (opts) o = *opts;
-    if (!o.gather) { sgn_set_error("sgn_rasterize_window_all: gather mode only (opts->gather = 1)"); return -3; }
     hipStream_t s = (hipStream_t)stream;
     char *p = (char *)arena;
     int32_t *mismatch = (int32_t *)p; p += 256;
@@ -420,7 +413,7 @@ int sgn_rasterize_window_all(int n_win, int n_full, int n_cand, const int32_t *c
         order = nullptr;                        // another list: another order
     }
     if (!order) {
-        rc = sgn_tile_order(n_tiles, bins, nullptr, (o.waves_fwd == 2) ? (o.adapt_fwd > 0 ? o.adapt_fwd : 1024) : 0, 0,
+        rc = sgn_tile_order(n_tiles, bins, nullptr, (block_width == 16) ? (o.adapt_fwd > 0 ? o.adapt_fwd : 1024) : 0, 0,
                             tile_order, order_scratch, order_scratch_bytes, stream);
         if (rc) return rc;
         order = tile_order;
@@ -472,75 +465,6 @@ int sgn_rasterize_bwd_all(int img_h, int img_w, int block_width, int n, int64_t 
                                v_out_img, v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors, v_opacity, recs_ws,
                                recs_ws_bytes, recs_packed, grad_ws, grad_ws_bytes, order, colors_pre_clamp, opts, stream,
                                aux_stream, first, last);
-}
-
-// ---------------------------------------------------------------- launch chains replayed as HIP graphs
-// (sgn_common.h: sgn_graph_find / sgn_graph_capture_begin / _end.)  A resource cache per (thread, device): up to 8
-// instantiated graphs, least recently used out; one capture stream.  No configuration lives here: the key is the
-// chain's own arguments.
-namespace {
-struct GraphEntry { int dev; uint64_t key[SGN_GRAPH_KEY_WORDS]; hipGraphExec_t exec; uint64_t used; };
-struct GraphState { std::vector<GraphEntry> entries; std::vector<std::pair<int, hipStream_t>> streams; uint64_t tick = 0; };
-thread_local GraphState g_graphs;
-int graphs_on() {
-    static const int on = [] { const char *e = getenv("SGN_HIP_GRAPHS"); return (e && e[0] == '1') ? 1 : 0; }();
-    return on;
-}
-}  // namespace
-
-int sgn_timing_enabled();
-
-hipGraphExec_t sgn_graph_find(const uint64_t *key) {
-    if (!graphs_on() || sgn_timing_enabled()) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    for (auto &e : g_graphs.entries)
-        if (e.dev == dev && memcmp(e.key, key, sizeof(e.key)) == 0) { e.used = ++g_graphs.tick; return e.exec; }
-    return nullptr;
-}
-
-hipStream_t sgn_graph_capture_begin() {
-    if (!graphs_on() || sgn_timing_enabled()) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    hipStream_t cs = nullptr;
-    for (auto &p : g_graphs.streams)
-        if (p.first == dev) cs = p.second;
-    if (cs == nullptr) {
-        if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        g_graphs.streams.emplace_back(dev, cs);
-    }
-    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return cs;
-}
-
-hipGraphExec_t sgn_graph_capture_end(const uint64_t *key) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    hipStream_t cs = nullptr;
-    for (auto &p : g_graphs.streams)
-        if (p.first == dev) cs = p.second;
-    if (cs == nullptr) return nullptr;
-    hipGraph_t graph = nullptr;
-    if (hipStreamEndCapture(cs, &graph) != hipSuccess || graph == nullptr) { (void)hipGetLastError(); return nullptr; }
-    hipGraphExec_t exec = nullptr;
-    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    if (e != hipSuccess || exec == nullptr) { (void)hipGetLastError(); return nullptr; }
-    if (g_graphs.entries.size() >= 8) {
-        size_t lru = 0;
-        for (size_t i = 1; i < g_graphs.entries.size(); ++i)
-            if (g_graphs.entries[i].used < g_graphs.entries[lru].used) lru = i;
-        (void)hipGraphExecDestroy(g_graphs.entries[lru].exec);
-        g_graphs.entries.erase(g_graphs.entries.begin() + (long)lru);
-    }
-    GraphEntry ge;
-    ge.dev = dev;
-    memcpy(ge.key, key, sizeof(ge.key));
-    ge.exec = exec;
-    ge.used = ++g_graphs.tick;
-    g_graphs.entries.push_back(ge);
-    return exec;
 }
 
 // ---------------------------------------------------------------- kernel timing (bench/profiles)

@@ -818,28 +818,12 @@ SGN_EXPORT int sgn_depth_rank(int n, const float *depths, const int32_t *radii, 
     uint32_t *dkeys = (uint32_t *)p; p += al256((size_t)n * 4);
     int32_t *dvals = (int32_t *)p;   p += al256((size_t)n * 4);
     uint32_t *dkeys_sorted = (uint32_t *)p; p += al256((size_t)n * 4);
-    auto chain = [&](hipStream_t st) {      // 12 launches: four passes of histogram / scan / scatter; the first pass
-        (void)dkeys; (void)dvals;           // reads its keys from (depths, radii) itself (round 5: no key kernel)
-        sgn_sort_depth_rank_launch((uint32_t)n, depths, radii, dkeys_sorted, gid_by_rank, p, st, sort_rank_mode);
-    };
-    // the same chain on the same buffers as an earlier call (steady state of a training loop): replayed as ONE graph
-    // launch (SGN_HIP_GRAPHS=1; sgn_common.h)
-    const uint64_t key[SGN_GRAPH_KEY_WORDS] = {1u, (uint64_t)n, (uint64_t)(uintptr_t)depths, (uint64_t)(uintptr_t)radii,
-                                               (uint64_t)(uintptr_t)gid_by_rank, (uint64_t)(uintptr_t)ws,
-                                               (uint64_t)(sort_rank_mode != 0)};
-    hipGraphExec_t g = sgn_graph_find(key);
-    if (g == nullptr) {
-        if (hipStream_t cs = sgn_graph_capture_begin()) {
-            chain(cs);
-            g = sgn_graph_capture_end(key);
-        }
-    }
-    if (g != nullptr) {
-        SGN_HIP_CHECK(hipGraphLaunch(g, s));
-        return 0;
-    }
+    // 12 launches: four passes of histogram / scan / scatter; the first pass reads its keys from (depths, radii) itself
+    // (round 5: no key kernel).  (Rounds 4-5 could replay the chain as one HIP graph, opt-in: no gain on this ROCm,
+    // profiles/r04ab_hip_graphs_ab.log; removed in round 6.)
+    (void)dkeys; (void)dvals;
     sgn_timing_begin(SGN_T_SORT, s);
-    chain(s);
+    sgn_sort_depth_rank_launch((uint32_t)n, depths, radii, dkeys_sorted, gid_by_rank, p, s, sort_rank_mode);
     sgn_timing_end(SGN_T_SORT, s);
     SGN_LAUNCH_CHECK();
     return 0;

@@ -11,9 +11,10 @@
 //   * Per-Gaussian operands live in 48-byte rows (build_grec).  They are wave-uniform in the hot loop, so the
 //     wave chases gaussian_ids_sorted[k] -> row with scalar loads (s_load_dword, s_load_dwordx8 + x4) into
 //     SGPRs one entry ahead and the VALU instructions take them as scalar operands: no LDS traffic, no VGPRs,
-//     and only the (tile, Gaussian) pairs actually walked are ever fetched.  (Alternative kept for A/B:
-//     pack_records copies the rows into depth order first and the kernels stream them.)  Lists long enough to
-//     leave a lone wave latency-bound go through 64-entry batches staged in wave-private LDS instead.
+//     and only the (tile, Gaussian) pairs actually walked are ever fetched.  Lists long enough to leave a
+//     lone wave latency-bound go through 64-entry batches staged in wave-private LDS instead.  (Rounds 1-5 also
+//     carried a "stream" form — rows copied into depth order first — for A/B runs; it lost everywhere and was
+//     removed in round 6, like the forced one- / four-wave shapes, the XCD swizzle and the MFMA reduction.)
 //   * Per-quadrant wave-uniform skips (`__ballot`) give the early termination and the
 //     "nobody in this 8x8 block is touched" shortcut for free in the scalar branch unit.
 //   * Backward: the 4 pixels of a lane are accumulated in registers, so ONE wave reduction per
@@ -110,16 +111,6 @@ __global__ __launch_bounds__(256) void build_grec_kernel(int n, const float *__r
     grec[3 * g + 2] = make_float4(bl, __int_as_float(g), ex, ey);
 }
 
-__global__ __launch_bounds__(256) void pack_records_kernel(int64_t n_isect, const int32_t *__restrict__ ids,
-                                                           const float4 *__restrict__ grec,
-                                                           float4 *__restrict__ recs, int idmask) {
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;  // one float4 of one record
-    if (t >= 3 * n_isect) return;
-    const int64_t p = t / 3;
-    const int j = (int)(t - 3 * p);
-    recs[t] = grec[3 * (int64_t)(ids[p] & idmask) + j];   // idmask strips the quadrant bits of a masked list
-}
-
 __device__ __forceinline__ int wave_max_i(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
@@ -138,15 +129,6 @@ __device__ __forceinline__ void slot_pixel(int q, int lane, int B, int &ox, int 
         oy = p / B;
         in_tile = p < B * B;
     }
-}
-
-// XCD-aware tile order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md); giving XCD x the contiguous
-// tile band [x*n/8, (x+1)*n/8) keeps the per-Gaussian rows a band touches in that XCD's own 4 MiB L2
-// (neighbouring tiles share most of their Gaussians).  Bijective for any n (remainder tiles go first).
-__device__ __forceinline__ int xcd_tile(int b, int n, int enable) {
-    if (!enable) return b;
-    const int q = n >> 3, r = n & 7, x = b & 7, j = b >> 3;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }
 
 // Which of the tile's four 8x8 quadrants can this Gaussian touch?  Lanes 0..3 each test one quadrant
@@ -183,16 +165,15 @@ __device__ __forceinline__ unsigned row_quadrants(float gx, float gy, float ex, 
     return m;
 }
 
-// GATHER = false: `recs` is the depth-ordered record stream (pack_records ran first).
-// GATHER = true : `recs` is the per-Gaussian row table and `ids` the sorted id list; the wave chases
-//                 ids[k] -> row with two dependent scalar loads, the id two records ahead and the row
-//                 one record ahead, so only the (tile, Gaussian) pairs that are actually walked before
-//                 the tile terminates are ever fetched (12 % of them on the benchmark scene).
+// `recs` is the per-Gaussian row table and `ids` the sorted id list; the wave chases ids[k] -> row with two dependent
+// scalar loads, the id two records ahead and the row one record ahead, so only the (tile, Gaussian) pairs that are
+// actually walked before the tile terminates are ever fetched (12 % of them on the benchmark scene).
 // QPW = quadrants per wave: 4 -> one wave owns the whole 16x16 tile (fewest scalar fetches and, in the
 // backward, one reduction per (tile, Gaussian)); 1 -> four waves per tile, one 8x8 quadrant each (4x
 // shorter critical path per tile: for scenes whose longest depth lists dominate the kernel's tail).
-// ADAPT (with QPW = 4, grid = 4 waves per tile): a tile whose depth list is shorter than `adapt_thresh` is
-// done by its wave 0 alone (the other three exit at once); a longer one is split, one quadrant per wave.
+// ADAPT (backward only; with QPW = 4, grid = 4 waves per tile): a tile whose reverse walk is shorter than `adapt_thresh`
+// is done by its wave 0 alone (the other three exit at once); a longer one is split, one quadrant per wave.  (The forward
+// runs the packed two-waves-per-tile kernel on 16x16 tiles and QPW = 1 elsewhere and for its longest lists.)
 // DEPTH (r03): a FOURTH accumulated channel, D = sum depth_g * vis — the image the reference gets from a whole second
 // rasterization of `depths.repeat(1, 3)` (sgn_splatfacto.py:982-994) — for one more fma per evaluated pair.  The
 // per-Gaussian depth is not part of the 48-byte row: it comes from `depths[id]` with one more scalar load next to the
@@ -222,30 +203,23 @@ struct FwdGroups {
     int32_t *kmax;              // [2][n_tiles*2] deepest composited position per tile, head then tail (zero-filled by the caller)
 };
 
-template <bool EXACT, bool GATHER, int QPW, bool ADAPT, bool DEPTH, bool GROUPS = false>
+template <bool EXACT, int QPW, bool DEPTH, bool GROUPS = false>
 __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, int B, int tiles_x,
                                                 const int2 *__restrict__ bins, const Rec *__restrict__ recs,
                                                 const int32_t *__restrict__ ids, const float *__restrict__ bg,
                                                 float *__restrict__ out_img, float *__restrict__ final_T,
-                                                int32_t *__restrict__ final_idx, int adapt_thresh, int batch_thresh,
+                                                int32_t *__restrict__ final_idx, int batch_thresh,
                                                 int32_t *__restrict__ tile_kmax, float4 (*stage)[64 * 3],
                                                 const float *__restrict__ depths = nullptr,
                                                 float *__restrict__ out_depth = nullptr,
                                                 float (*stage_d)[64] = nullptr, int use_qm = 0,
                                                 const FwdGroups *Gp = nullptr) {
-    static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
-    static_assert(!GROUPS || (GATHER && !ADAPT), "group accumulations: gather mode, fixed wave shape");
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
-    const bool qm_on = GATHER && use_qm != 0 && B == 16;      // wave-uniform
-    const int idmask = qm_idmask(GATHER ? use_qm : 0);
-    int q0 = ADAPT ? 0 : wv * QPW;             // first quadrant (pixel slot) of this wave
-    int qlo = 0, qhi = QPW;                    // active slots of this wave (wave-uniform)
-    if constexpr (ADAPT) {
-        const bool split = (range.y - range.x) >= adapt_thresh;
-        if (!split && wv != 0) return;
-        if (split) { qlo = wv; qhi = wv + 1; }
-    }
+    const bool qm_on = use_qm != 0 && B == 16;      // wave-uniform
+    const int idmask = qm_idmask(use_qm);
+    const int q0 = wv * QPW;                   // first quadrant (pixel slot) of this wave
+    constexpr int qlo = 0, qhi = QPW;          // active slots of this wave
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];  // wave-uniform -> scalar loads
 
@@ -354,18 +328,17 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
     const int L = range.y - range.x;
     if (L > 0 && L < batch_thresh) {
         // short list: chase ids -> rows with scalar loads, one entry ahead (operands arrive in SGPRs)
-        int idc = GATHER ? ids[range.x] : range.x;           // raw id word (mask bits included)
+        int idc = ids[range.x];                         // raw id word (mask bits included)
         Rec cur = recs[idc & idmask];
         float dcur = 0.f;
-        if constexpr (DEPTH) dcur = depths[GATHER ? (idc & idmask) : cur.gid];
-        int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
+        if constexpr (DEPTH) dcur = depths[idc & idmask];
+        int idn = ids[min(range.x + 1, range.y - 1)];
         for (int k = range.x; k < range.y; ++k) {
-            const int kn = (k + 1 < range.y) ? k + 1 : k;
-            const Rec nxt = recs[GATHER ? (idn & idmask) : kn];  // scalar prefetch of the next record
+            const Rec nxt = recs[idn & idmask];  // scalar prefetch of the next record
             float dnxt = 0.f;
-            if constexpr (DEPTH) dnxt = depths[GATHER ? (idn & idmask) : nxt.gid];
+            if constexpr (DEPTH) dnxt = depths[idn & idmask];
             const int idnn = idn;
-            if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
+            idn = ids[min(k + 2, range.y - 1)];
             const unsigned qm = qm_on ? qm_bits(idc, cur.ex) : quadrant_mask(cur, qcx, qcy, qtest);
             bool tail; int kg;
             group_of(idc, k, tail, kg);
@@ -388,11 +361,11 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = range.x + (bidx << 6) + lane;
             if (k < range.y) {
-                rid = GATHER ? ids[k] : k;
+                rid = ids[k];
                 const int id = rid & idmask;
                 const float4 *p = reinterpret_cast<const float4 *>(recs + id);
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
-                if constexpr (DEPTH) rd = depths[GATHER ? id : __float_as_int(r2.y)];
+                if constexpr (DEPTH) rd = depths[id];
             }
         };
         auto row_mask = [&](const float4 &r0, const float4 &r2) __attribute__((always_inline)) -> unsigned {
@@ -512,32 +485,28 @@ __device__ __forceinline__ void raster_fwd_tile(int tile, int wv, int W, int H, 
     }
 }
 
-template <bool EXACT, bool GATHER, int QPW, bool ADAPT, bool DEPTH>
+template <bool EXACT, int QPW, bool DEPTH>
 __global__ __launch_bounds__(64) void raster_fwd_kernel(int W, int H, int B, int tiles_x,
                                                         const int2 *__restrict__ bins,
                                                         const Rec *__restrict__ recs,
                                                         const int32_t *__restrict__ ids,
                                                         const float *__restrict__ bg, float *__restrict__ out_img,
                                                         float *__restrict__ final_T,
-                                                        int32_t *__restrict__ final_idx, int adapt_thresh, int swz,
+                                                        int32_t *__restrict__ final_idx,
                                                         int batch_thresh, const int32_t *__restrict__ tile_order,
                                                         int32_t *__restrict__ tile_kmax,
                                                         const float *__restrict__ depths,
                                                         float *__restrict__ out_depth,
                                                         const int32_t *__restrict__ skip_flag, int use_qm) {
     if (skip_flag != nullptr && *skip_flag == 0) return;   // the caller already holds this pass's result (sgn_depth_reuse)
-    constexpr int WPT = ADAPT ? 4 : 4 / QPW;   // waves launched per tile
-    // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile) so the waves that do the
-    // work of un-split tiles are spread over all 8 XCDs (block b runs on XCD b % 8), not on every 4th block.
-    const int n_tiles_ = gridDim.x / WPT;
-    int tile = xcd_tile(ADAPT ? (int)(blockIdx.x % n_tiles_) : (int)(blockIdx.x / WPT), n_tiles_, swz);
+    constexpr int WPT = 4 / QPW;               // waves launched per tile
+    int tile = (int)(blockIdx.x / WPT);
     if (tile_order) tile = tile_order[tile];   // longest depth lists first (sgn_tile_order): no long tile starts late
-    const int wv = ADAPT ? (int)(blockIdx.x / n_tiles_) : (int)(blockIdx.x % WPT);
+    const int wv = (int)(blockIdx.x % WPT);
     __shared__ float4 stage[2][64 * 3];         // 64-entry batches of the long-list path (wave-private)
     __shared__ float stage_d[DEPTH ? 2 : 1][64];
-    raster_fwd_tile<EXACT, GATHER, QPW, ADAPT, DEPTH>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, out_img, final_T,
-                                                       final_idx, adapt_thresh, batch_thresh, tile_kmax, stage, depths,
-                                                       out_depth, stage_d, use_qm);
+    raster_fwd_tile<EXACT, QPW, DEPTH>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, out_img, final_T, final_idx,
+                                       batch_thresh, tile_kmax, stage, depths, out_depth, stage_d, use_qm);
 }
 
 // ---------------------------------------------------------------- forward, packed-FP32 form (16x16 tiles)
@@ -568,7 +537,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f splat2(float v) { return v2f{v, v}; }
 __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
-template <bool EXACT, bool GATHER, bool DEPTH, bool GROUPS>
+template <bool EXACT, bool DEPTH, bool GROUPS>
 __device__ __forceinline__ void raster_fwd_pk_body(int tile, int wv, bool is_long, int W, int H, int tiles_x, int n_tiles_,
                                                    const int2 *__restrict__ bins, const Rec *__restrict__ recs,
                                                    const int32_t *__restrict__ ids, const float *__restrict__ bg,
@@ -580,13 +549,13 @@ __device__ __forceinline__ void raster_fwd_pk_body(int tile, int wv, bool is_lon
     const int2 range = bins[tile];
     const int L = range.y - range.x;
     if (is_long) {
-        raster_fwd_tile<EXACT, GATHER, 1, false, DEPTH, GROUPS>(tile, wv, W, H, 16, tiles_x, bins, recs, ids, bg, out_img,
-                                                                final_T, final_idx, 0, batch_thresh, tile_kmax, stage,
-                                                                depths, out_depth, stage_d, use_qm, &G);
+        raster_fwd_tile<EXACT, 1, DEPTH, GROUPS>(tile, wv, W, H, 16, tiles_x, bins, recs, ids, bg, out_img, final_T,
+                                                 final_idx, batch_thresh, tile_kmax, stage, depths, out_depth, stage_d,
+                                                 use_qm, &G);
         return;
     }
-    const bool qm_on = GATHER && use_qm != 0;            // wave-uniform
-    const int idmask = qm_idmask(GATHER ? use_qm : 0);
+    const bool qm_on = use_qm != 0;            // wave-uniform
+    const int idmask = qm_idmask(use_qm);
     const unsigned shift_q = 2u * wv;                    // this wave's quadrants: bits shift_q, shift_q + 1
     const int lane = threadIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
@@ -689,18 +658,17 @@ __device__ __forceinline__ void raster_fwd_pk_body(int tile, int wv, bool is_lon
     };
 
     if (L > 0 && L < batch_thresh) {
-        int idc = GATHER ? ids[range.x] : range.x;           // raw id word (quadrant bits on top)
+        int idc = ids[range.x];                         // raw id word (quadrant bits on top)
         Rec cur = recs[idc & idmask];
         float dcur = 0.f;
-        if constexpr (DEPTH) dcur = depths[GATHER ? (idc & idmask) : cur.gid];
-        int idn = GATHER ? ids[min(range.x + 1, range.y - 1)] : 0;
+        if constexpr (DEPTH) dcur = depths[idc & idmask];
+        int idn = ids[min(range.x + 1, range.y - 1)];
         for (int k = range.x; k < range.y; ++k) {
-            const int kn = (k + 1 < range.y) ? k + 1 : k;
-            const Rec nxt = recs[GATHER ? (idn & idmask) : kn];
+            const Rec nxt = recs[idn & idmask];
             float dnxt = 0.f;
-            if constexpr (DEPTH) dnxt = depths[GATHER ? (idn & idmask) : nxt.gid];
+            if constexpr (DEPTH) dnxt = depths[idn & idmask];
             const int idnn = idn;
-            if constexpr (GATHER) idn = ids[min(k + 2, range.y - 1)];
+            idn = ids[min(k + 2, range.y - 1)];
             const unsigned m = ((qm_on ? qm_bits(idc, cur.ex) : quadrant_mask(cur, qcx, qcy, true)) >> shift_q) & 3u;
             bool tail = false; int kg = k;
             if constexpr (GROUPS) {
@@ -722,11 +690,11 @@ __device__ __forceinline__ void raster_fwd_pk_body(int tile, int wv, bool is_lon
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = range.x + (bidx << 6) + lane;
             if (k < range.y) {
-                rid = GATHER ? ids[k] : k;
+                rid = ids[k];
                 const int id = rid & idmask;
                 const float4 *p = reinterpret_cast<const float4 *>(recs + id);
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
-                if constexpr (DEPTH) rd = depths[GATHER ? id : __float_as_int(r2.y)];
+                if constexpr (DEPTH) rd = depths[id];
             }
         };
         auto row_mask = [&](const float4 &r0, const float4 &r2) __attribute__((always_inline)) -> unsigned {
@@ -843,21 +811,20 @@ __device__ __forceinline__ void raster_fwd_pk_body(int tile, int wv, bool is_lon
     }
 }
 
-template <bool EXACT, bool GATHER, bool DEPTH, bool GROUPS = false>
+template <bool EXACT, bool DEPTH, bool GROUPS = false>
 __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int tiles_x, int n_tiles_,
                                                            const int2 *__restrict__ bins,
                                                            const Rec *__restrict__ recs,
                                                            const int32_t *__restrict__ ids,
                                                            const float *__restrict__ bg, float *__restrict__ out_img,
                                                            float *__restrict__ final_T,
-                                                           int32_t *__restrict__ final_idx, int swz,
+                                                           int32_t *__restrict__ final_idx,
                                                            int batch_thresh, const int32_t *__restrict__ tile_order,
                                                            int32_t *__restrict__ tile_kmax,
                                                            const float *__restrict__ depths,
                                                            float *__restrict__ out_depth,
                                                            const int32_t *__restrict__ skip_flag, int use_qm,
                                                            const FwdGroups G) {
-    static_assert(!GROUPS || GATHER, "group accumulations: gather mode");
     if (skip_flag != nullptr && *skip_flag == 0) return;   // the caller already holds this pass's result (sgn_depth_reuse)
     __shared__ float4 stage[2][64 * 3];
     __shared__ float stage_d[DEPTH ? 2 : 1][64];
@@ -881,7 +848,7 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
         wv = (b2 >> 3) & 1;
         if (t_idx >= n_tiles_) return;
     }
-    int tile = xcd_tile(t_idx, n_tiles_, swz);
+    int tile = t_idx;
     if (tile_order) tile = tile_order[tile];
     if constexpr (GROUPS) {
         // A tile that holds NO entry of the group with its own list (most tiles: the objects cover a part of the image)
@@ -893,12 +860,12 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
             mixed = ob.y > ob.x;
         }
         if (mixed) {
-            raster_fwd_pk_body<EXACT, GATHER, DEPTH, true>(tile, wv, is_long, W, H, tiles_x, n_tiles_, bins, recs, ids, bg,
+            raster_fwd_pk_body<EXACT, DEPTH, true>(tile, wv, is_long, W, H, tiles_x, n_tiles_, bins, recs, ids, bg,
                                                            out_img, final_T, final_idx, batch_thresh, tile_kmax, depths,
                                                            out_depth, use_qm, G, stage, stage_d);
             return;
         }
-        raster_fwd_pk_body<EXACT, GATHER, DEPTH, false>(tile, wv, is_long, W, H, tiles_x, n_tiles_, bins, recs, ids, bg,
+        raster_fwd_pk_body<EXACT, DEPTH, false>(tile, wv, is_long, W, H, tiles_x, n_tiles_, bins, recs, ids, bg,
                                                         out_img, final_T, final_idx, batch_thresh, tile_kmax, depths,
                                                         out_depth, use_qm, G, stage, stage_d);
         const int lane = threadIdx.x, tx = tile % tiles_x, ty = tile / tiles_x, HW = W * H;
@@ -924,7 +891,7 @@ __global__ __launch_bounds__(64) void raster_fwd_pk_kernel(int W, int H, int til
         lm = wave_max_i(lm);
         if (lane == 0 && lm > 0) atomicMax(G.kmax + other * 2 * n_tiles_ + 2 * tile, lm);
     } else {
-        raster_fwd_pk_body<EXACT, GATHER, DEPTH, false>(tile, wv, is_long, W, H, tiles_x, n_tiles_, bins, recs, ids, bg,
+        raster_fwd_pk_body<EXACT, DEPTH, false>(tile, wv, is_long, W, H, tiles_x, n_tiles_, bins, recs, ids, bg,
                                                         out_img, final_T, final_idx, batch_thresh, tile_kmax, depths,
                                                         out_depth, use_qm, G, stage, stage_d);
     }
@@ -963,7 +930,7 @@ __device__ __forceinline__ float fold16(float a, float b) {   // rows: [a.r0+a.r
 
 // grad_ws row layout (12 floats / Gaussian): 0,1 m_x, m_y | 2,3,4 s_xx, s_xy, s_yy (raw moments; the conic is applied by
 // unpack_grads_kernel) | 5,6,7 v_rgb | 8 v_opacity
-template <bool EXACT, int REDUCE, bool GATHER, int QPW, bool ADAPT>
+template <bool EXACT, int REDUCE, int QPW, bool ADAPT>
 __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, int B, int tiles_x,
                                                 const int2 *__restrict__ bins, const Rec *__restrict__ recs,
                                                 const int32_t *__restrict__ ids, const float *__restrict__ bg,
@@ -974,8 +941,8 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
                                                 float *__restrict__ grad_ws, int dbg, int adapt_thresh,
                                                 int batch_thresh, int use_qm) {
     static_assert(!ADAPT || QPW == 4, "adaptive splitting starts from the 4-quadrant wave");
-    const bool qm_on = GATHER && use_qm != 0 && B == 16;      // wave-uniform
-    const int idmask = qm_idmask(GATHER ? use_qm : 0);
+    const bool qm_on = use_qm != 0 && B == 16;      // wave-uniform
+    const int idmask = qm_idmask(use_qm);
     const int q0 = ADAPT ? 0 : wv * QPW;
     const int lane = threadIdx.x;
     const int2 range = bins[tile];
@@ -1102,31 +1069,6 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
                 const float mine = (c == 0) ? t0 : (c == 1) ? t1 : t2;
                 if ((c < 2 || lane == 2) && !(dbg & 1))
                     unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + (c * 4 + rowmap), mine);
-            } else if constexpr (REDUCE == 2) {
-                // Round 5 experiment: the first two stages of the reduction (64 lanes -> 16 column sums) on the MATRIX
-                // pipe instead of the VALU's cross-lane network.  v_mfma_f32_16x16x4_f32 with A = ones computes
-                // D[i][j] = sum_k B[k][j]: B is one VGPR per lane, (k, j) <-> lane is a bijection, and every lane ends
-                // with the sum of "its" column j = lane % 16 in all four D registers (all rows i are equal).  The MFMA
-                // unit is idle in this kernel and issues beside the VALU of the other waves; what is left for the
-                // VALU is the packing of four values per register (row r takes value r: 6 v_cndmask) and the twelve
-                // DPP row adds.  Products are 1.0 * v (exact); the four-term sums are fp32 accumulations.
-                typedef float f32x4 __attribute__((ext_vector_type(4)));
-                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                auto colsum = [&](float v) __attribute__((always_inline)) -> float {
-                    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, v, z4, 0, 0, 0);
-                    return d[0];
-                };
-                const float d0 = colsum(m_x), d1 = colsum(m_y), d2 = colsum(s_xx), d3 = colsum(s_xy);
-                const float d4 = colsum(s_yy), d5 = colsum(g_r), d6 = colsum(g_g), d7 = colsum(g_b);
-                const float d8 = colsum(g_o);
-                const int c = lane & 15, row = lane >> 4;
-                float t0 = (row == 0) ? d0 : (row == 1) ? d1 : (row == 2) ? d2 : d3;   // grad_ws words 0..3
-                float t1 = (row == 0) ? d4 : (row == 1) ? d5 : (row == 2) ? d6 : d7;   // words 4..7
-                float t2 = d8;                                                          // word 8 (row 0 writes it)
-                t0 = row_sum_dpp(t0); t1 = row_sum_dpp(t1); t2 = row_sum_dpp(t2);
-                const float mine = (c == 0) ? t0 : (c == 1) ? t1 : t2;
-                if ((c < 2 || lane == 2) && !(dbg & 1))
-                    unsafeAtomicAdd(grad_ws + (size_t)cur.gid * SGN_RECORD_FLOATS + (c * 4 + row), mine);
             } else {
                 if (!(dbg & 2)) {          // dbg bit1: ablation only, skip the wave reduction (results are wrong)
                     m_x = wave_sum(m_x); m_y = wave_sum(m_y);
@@ -1151,14 +1093,13 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
 
     const int L = kmax - range.x + 1;   // entries of the reverse walk
     if (L < batch_thresh) {
-        int idc = GATHER ? ids[kmax] : kmax;                 // raw id word (quadrant bits on top)
+        int idc = ids[kmax];                         // raw id word (quadrant bits on top)
         Rec cur = recs[idc & idmask];
-        int idn = GATHER ? ids[max(kmax - 1, range.x)] : 0;
+        int idn = ids[max(kmax - 1, range.x)];
         for (int k = kmax; k >= range.x; --k) {
-            const int kn = (k - 1 >= range.x) ? k - 1 : k;
-            const Rec nxt = recs[GATHER ? (idn & idmask) : kn];
+            const Rec nxt = recs[idn & idmask];
             const int idnn = idn;
-            if constexpr (GATHER) idn = ids[max(k - 2, range.x)];
+            idn = ids[max(k - 2, range.x)];
             entry(cur, k, qm_on ? qm_bits(idc, cur.ex) : quadrant_mask(cur, qcx, qcy, qtest));
             cur = nxt;
             idc = idnn;
@@ -1171,7 +1112,7 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
         auto fetch = [&](int bidx, float4 &r0, float4 &r1, float4 &r2) __attribute__((always_inline)) {
             const int k = kmax - (bidx << 6) - lane;
             if (k >= range.x) {
-                rid = GATHER ? ids[k] : k;
+                rid = ids[k];
                 const float4 *p = reinterpret_cast<const float4 *>(recs + (rid & idmask));
                 r0 = p[0]; r1 = p[1]; r2 = p[2];
             }
@@ -1213,8 +1154,8 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
 }
 
 // Launch shapes of the backward.
-//   MODE 0: one workgroup per (tile, wave) in index or `tile_order` order (forced 1 / 4 waves per tile, or the legacy
-//           in-kernel adaptive split when ADAPT).
+//   MODE 0: one workgroup per (tile, wave), the in-kernel adaptive split (QPW = 4, ADAPT): callers without a launch
+//           order, tile sizes other than 16.
 //   MODE 1: "short" half of the two-kernel adaptive scheme: one wave per tile (QPW = 4); block b takes tile
 //           order[b] and leaves the first n_long = order[n_tiles] entries (the long walks) to MODE 2.  (Its own
 //           kernel, raster_bwd_short_kernel below: it carries an occupancy attribute the other shapes must not.)
@@ -1224,7 +1165,7 @@ __device__ __forceinline__ void raster_bwd_tile(int tile, int wv, int W, int H, 
 // budget and its per-slot control flow (street scene: 0.93 ms); the QPW = 1 body on the same tiles takes 0.59 ms,
 // but costs 1.6x on tiles whose walks are short (benchmark scene: 0.52 vs 0.33 ms), where one wave per tile means one
 // gradient reduction per (tile, Gaussian) instead of up to four.
-template <bool EXACT, int REDUCE, bool GATHER, int QPW, bool ADAPT, int MODE>
+template <bool EXACT, int REDUCE, int QPW, bool ADAPT, int MODE>
 __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int tiles_x, int n_tiles,
                                                         const int2 *__restrict__ bins,
                                                         const Rec *__restrict__ recs,
@@ -1235,15 +1176,16 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
                                                         const float *__restrict__ v_out,
                                                         const float *__restrict__ v_out_alpha,
                                                         float alpha_clamp, float *__restrict__ grad_ws, int dbg,
-                                                        int adapt_thresh, int swz, int batch_thresh,
+                                                        int adapt_thresh, int batch_thresh,
                                                         const int32_t *__restrict__ tile_order, int use_qm) {
     if constexpr (MODE == 0) {
-        constexpr int WPT = ADAPT ? 4 : 4 / QPW;
-        // ADAPT: wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile), see the forward kernel
-        int tile = xcd_tile(ADAPT ? (int)(blockIdx.x % n_tiles) : (int)(blockIdx.x / WPT), n_tiles, swz);
+        static_assert(QPW == 4 && ADAPT, "MODE 0 is the in-kernel adaptive split");
+        // wave-major numbering (blocks [0, n_tiles) are wave 0 of every tile): the waves that do the work of un-split
+        // tiles are spread over all 8 XCDs (block b runs on XCD b % 8), not on every 4th block
+        int tile = (int)(blockIdx.x % n_tiles);
         if (tile_order) tile = tile_order[tile];
-        const int wv = ADAPT ? (int)(blockIdx.x / n_tiles) : (int)(blockIdx.x % WPT);
-        raster_bwd_tile<EXACT, REDUCE, GATHER, QPW, ADAPT>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, final_T,
+        const int wv = (int)(blockIdx.x / n_tiles);
+        raster_bwd_tile<EXACT, REDUCE, QPW, ADAPT>(tile, wv, W, H, B, tiles_x, bins, recs, ids, bg, final_T,
                                                            final_idx, v_out, v_out_alpha, alpha_clamp, grad_ws, dbg,
                                                            adapt_thresh, batch_thresh, use_qm);
     } else {
@@ -1258,7 +1200,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
         // their SIMDs with the short-walk kernel's waves: give them the issue priority (street scene: 516 -> 537
         // images/s; two quadrants per wave here, i.e. half the reductions, made it 435: it IS the critical path).
         __builtin_amdgcn_s_setprio(3);
-        raster_bwd_tile<EXACT, REDUCE, GATHER, 1, false>(tile_order[blockIdx.x >> 2], blockIdx.x & 3, W, H, B, tiles_x,
+        raster_bwd_tile<EXACT, REDUCE, 1, false>(tile_order[blockIdx.x >> 2], blockIdx.x & 3, W, H, B, tiles_x,
                                                          bins, recs, ids, bg, final_T, final_idx, v_out, v_out_alpha,
                                                          alpha_clamp, grad_ws, dbg, adapt_thresh, batch_thresh, use_qm);
     }
@@ -1268,7 +1210,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(int W, int H, int B, int
 // without the SLP vectoriser (see the Makefile) its body needs 94 VGPRs and would run five; on the street scene the
 // extra waves take issue slots from the concurrently running long-walk kernel, which is the critical path there
 // (long-walk kernel 613 -> 768 us, step 1.97 -> 2.24 ms, profiles/experiments/r02_packed_forward_notes.md).
-template <bool EXACT, int REDUCE, bool GATHER>
+template <bool EXACT, int REDUCE>
 // (re-measured in r03 with the moment-form body, profiles/scripts/r03o.sh: 5 or 6 waves change nothing on the benchmark
 // scene — 0.276-0.279 ms — and cost the street scene 8 %: 490 vs 535-540 images/s)
 #ifndef SGN_BWD_SHORT_WAVES_MAX
@@ -1278,11 +1220,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, SGN_BWD_S
     int W, int H, int B, int tiles_x, int n_tiles, const int2 *__restrict__ bins, const Rec *__restrict__ recs,
     const int32_t *__restrict__ ids, const float *__restrict__ bg, const float *__restrict__ final_T,
     const int32_t *__restrict__ final_idx, const float *__restrict__ v_out, const float *__restrict__ v_out_alpha,
-    float alpha_clamp, float *__restrict__ grad_ws, int dbg, int adapt_thresh, int swz, int batch_thresh,
+    float alpha_clamp, float *__restrict__ grad_ws, int dbg, int adapt_thresh, int batch_thresh,
     const int32_t *__restrict__ tile_order, int use_qm) {
     const int n_long = tile_order[n_tiles];
     if ((int)blockIdx.x < n_long) return;
-    raster_bwd_tile<EXACT, REDUCE, GATHER, 4, false>(tile_order[blockIdx.x], 0, W, H, B, tiles_x, bins, recs, ids, bg,
+    raster_bwd_tile<EXACT, REDUCE, 4, false>(tile_order[blockIdx.x], 0, W, H, B, tiles_x, bins, recs, ids, bg,
                                                      final_T, final_idx, v_out, v_out_alpha, alpha_clamp, grad_ws, dbg,
                                                      adapt_thresh, batch_thresh, use_qm);
 }
@@ -1331,11 +1273,8 @@ sgn_raster_opts resolve_opts(const sgn_raster_opts *o) {
     if (o) {
         r = *o;
         r.exact_exp = r.exact_exp ? 1 : 0;
-        r.reduce_mode = (r.reduce_mode == 2) ? 2 : (r.reduce_mode ? 1 : 0);
-        r.gather = r.gather ? 1 : 0;
+        r.reduce_mode = r.reduce_mode ? 1 : 0;
         r.ids_qmask = r.ids_qmask ? 1 : 0;
-        r.waves_fwd = (r.waves_fwd == 4 || r.waves_fwd == 2 || r.waves_fwd == 1) ? r.waves_fwd : 0;
-        r.waves_bwd = (r.waves_bwd == 4 || r.waves_bwd == 1) ? r.waves_bwd : 0;
         sgn_raster_opts d;
         sgn_raster_default_opts(&d);
         if (r.adapt_fwd <= 0) r.adapt_fwd = d.adapt_fwd;
@@ -1352,41 +1291,29 @@ SGN_EXPORT void sgn_raster_default_opts(sgn_raster_opts *out) {
     if (!out) return;
     out->exact_exp = 0;        // hardware v_exp_f32
     out->reduce_mode = 1;      // transposed permlane-swap reduction
-    out->gather = 1;           // chase ids -> per-Gaussian rows
-    out->waves_fwd = 2;        // forward: packed FP32, two waves per tile (r02k: 183 -> 157 us on the uniform scene), four
-                               //          waves, one 8x8 quadrant each, for the tiles with the longest lists
-    out->waves_bwd = 0;        // backward: adaptive (one reduction per (tile, Gaussian) unless the walk is long)
     out->adapt_fwd = 1024;     // forward: lists with >= this many entries get four waves (half-octave classes)
     out->adapt_bwd = 256;      // backward: reverse walks of >= this many entries go to the four-waves-per-tile kernel
     out->batch_fwd = 256;      // forward: lists with >= this many entries go through the LDS-batched path
     out->batch_bwd = 128;      // backward: same for reverse walks
-    out->xcd_swizzle = 0;
     out->debug_flags = 0;
     out->ids_qmask = 0;        // the list carries no quadrant masks unless its builder says so
 }
 
 SGN_EXPORT size_t sgn_raster_workspace_bytes(int n, int64_t n_isect, const sgn_raster_opts *opts) {
-    // [n per-Gaussian rows][n_isect depth-ordered records (stream mode only)]
-    const size_t stream = resolve_opts(opts).gather ? 0 : (size_t)(n_isect > 0 ? n_isect : 1);
-    return ((size_t)(n > 0 ? n : 1) + stream) * sizeof(Rec);
+    (void)n_isect; (void)opts;       // one 48-byte row per Gaussian (rounds 1-5 added a depth-ordered stream in "stream" mode)
+    return (size_t)(n > 0 ? n : 1) * sizeof(Rec);
 }
 
 SGN_EXPORT size_t sgn_raster_bwd_workspace_bytes(int n) {
     return (size_t)(n > 0 ? n : 1) * SGN_RECORD_FLOATS * sizeof(float);
 }
 
-// builds the per-Gaussian rows and (stream mode) the depth-ordered record stream
-static int pack_records(int n, int64_t n_isect, const int32_t *ids, const float *xys, const float *conics,
-                        const float *colors, const float *opac, int opac_is_logit, int id_lo, int id_hi, int window,
-                        int gather, void *recs, hipStream_t s, int idmask = -1) {
-    float4 *grec = (float4 *)recs;                       // rows first,
-    float4 *stream_recs = (float4 *)recs + 3 * (size_t)n; // then the optional depth-ordered stream
+// builds the per-Gaussian rows
+static int pack_records(int n, const float *xys, const float *conics, const float *colors, const float *opac,
+                        int opac_is_logit, int id_lo, int id_hi, int window, void *recs, hipStream_t s) {
     sgn_timing_begin(SGN_T_PACK, s);
     hipLaunchKernelGGL(build_grec_kernel, dim3(sgn_cdiv(n, 256)), dim3(256), 0, s, n, xys, conics, colors, opac,
-                       opac_is_logit, id_lo, id_hi, window, grec, (const int32_t *)nullptr);
-    if (!gather)
-        hipLaunchKernelGGL(pack_records_kernel, dim3(sgn_cdiv(3 * n_isect, 256)), dim3(256), 0, s, n_isect, ids,
-                           grec, stream_recs, idmask);
+                       opac_is_logit, id_lo, id_hi, window, (float4 *)recs, (const int32_t *)nullptr);
     sgn_timing_end(SGN_T_PACK, s);
     return 0;
 }
@@ -1422,12 +1349,12 @@ static int raster_fwd_impl(int img_h, int img_w, int block_width, int n, int64_t
                            const sgn_raster_opts *opts, sgn_stream_t stream, const FwdGroups *groups,
                            int kmax_cleared = 0) {
     const sgn_raster_opts o = resolve_opts(opts);
-    // group accumulations ride on the packed two-waves-per-tile forward of the gather mode only
-    SGN_ARG_CHECK(groups == nullptr || (o.gather && o.waves_fwd == 2 && block_width == 16 && !window && !skip_flag), -12);
+    // group accumulations ride on the packed two-waves-per-tile forward (16x16 tiles, the whole scene)
+    SGN_ARG_CHECK(groups == nullptr || (block_width == 16 && !window && !skip_flag), -12);
     FwdGroups Gv = {};
     if (groups) Gv = *groups;
     SGN_ARG_CHECK((depths == nullptr) == (out_depth == nullptr), -8);
-    SGN_ARG_CHECK(skip_flag == nullptr || (rows_built && o.gather), -9);   // a skipped pass builds no rows of its own
+    SGN_ARG_CHECK(skip_flag == nullptr || rows_built, -9);                 // a skipped pass builds no rows of its own
     SGN_ARG_CHECK(!(window && depths), -10);                               // the depth channel is a whole-scene pass
     SGN_ARG_CHECK(img_h > 0 && img_w > 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16, -2);
@@ -1438,45 +1365,34 @@ static int raster_fwd_impl(int img_h, int img_w, int block_width, int n, int64_t
     SGN_ARG_CHECK(!window || (0 <= id_lo && id_lo <= id_hi && id_hi <= n), -7);
     SGN_ARG_CHECK(!o.ids_qmask || (block_width == 16 && n < SGN_QMASK_MAX_IDS), -11);
     hipStream_t s = (hipStream_t)stream;
-    if (n_isect > 0 && !(rows_built && o.gather))
-        pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi,
-                     window, o.gather, recs_ws, s, o.ids_qmask ? SGN_QMASK_MAX_IDS - 1 : -1);
+    if (n_isect > 0 && !rows_built)
+        pack_records(n, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi, window, recs_ws, s);
     const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
     const Rec *rows = (const Rec *)recs_ws;
-    const Rec *stream_recs = rows + n;
     if (tile_kmax && !kmax_cleared) SGN_HIP_CHECK(hipMemsetAsync(tile_kmax, 0, sizeof(int32_t) * 2 * tiles_x * tiles_y, s));
     if (groups) SGN_HIP_CHECK(hipMemsetAsync(Gv.kmax, 0, sizeof(int32_t) * 4 * tiles_x * tiles_y, s));
     sgn_timing_begin(SGN_T_RASTER_FWD, s);
-#define SGN_LAUNCH_FWD(EX, GA, Q, AD, DE)                                                                            \
-    hipLaunchKernelGGL((raster_fwd_kernel<EX, GA, Q, AD, DE>), dim3(tiles_x * tiles_y * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
-                       img_w, img_h, block_width, tiles_x, (const int2 *)tile_bins, GA ? rows : stream_recs,         \
-                       gaussian_ids_sorted, background3, out_img, final_Ts, final_idx, o.adapt_fwd, o.xcd_swizzle, o.batch_fwd,   \
-                       tile_order, tile_kmax, depths, out_depth, skip_flag, o.ids_qmask)
-#define SGN_LAUNCH_FWD_PKG(EX, GA, DE, GR)                                                                           \
-    hipLaunchKernelGGL((raster_fwd_pk_kernel<EX, GA, DE, GR>), dim3(((tiles_x * tiles_y + 7) / 8) * 32 + 32), dim3(64), 0, s, img_w, img_h,    \
-                       tiles_x, tiles_x * tiles_y, (const int2 *)tile_bins, GA ? rows : stream_recs, gaussian_ids_sorted, background3,  \
-                       out_img, final_Ts, final_idx, o.xcd_swizzle, o.batch_fwd, tile_order, tile_kmax, depths, out_depth, skip_flag, o.ids_qmask, Gv)
-#define SGN_LAUNCH_FWD_PK(EX, GA, DE)                                                   \
+    // Two launch shapes: 16x16 tiles run the PACKED kernel (two waves per tile, two pixels per lane; the longest lists of
+    // the launch order get four waves); every other tile size four waves per tile, one quadrant each.
+#define SGN_LAUNCH_FWD(EX, DE)                                                                                       \
+    hipLaunchKernelGGL((raster_fwd_kernel<EX, 1, DE>), dim3(tiles_x * tiles_y * 4), dim3(64), 0, s, img_w, img_h,    \
+                       block_width, tiles_x, (const int2 *)tile_bins, rows, gaussian_ids_sorted, background3, out_img, \
+                       final_Ts, final_idx, o.batch_fwd, tile_order, tile_kmax, depths, out_depth, skip_flag, o.ids_qmask)
+#define SGN_LAUNCH_FWD_PKG(EX, DE, GR)                                                                               \
+    hipLaunchKernelGGL((raster_fwd_pk_kernel<EX, DE, GR>), dim3(((tiles_x * tiles_y + 7) / 8) * 32 + 32), dim3(64), 0, s, \
+                       img_w, img_h, tiles_x, tiles_x * tiles_y, (const int2 *)tile_bins, rows, gaussian_ids_sorted, \
+                       background3, out_img, final_Ts, final_idx, o.batch_fwd, tile_order, tile_kmax, depths, out_depth, \
+                       skip_flag, o.ids_qmask, Gv)
+#define SGN_LAUNCH_FWD3(EX, DE)                                                         \
     do {                                                                                \
-        if (GA && groups) SGN_LAUNCH_FWD_PKG(EX, GA, DE, GA);                           \
-        else SGN_LAUNCH_FWD_PKG(EX, GA, DE, false);                                     \
+        if (block_width == 16) {                                                        \
+            if (groups) SGN_LAUNCH_FWD_PKG(EX, DE, true); else SGN_LAUNCH_FWD_PKG(EX, DE, false); \
+        } else SGN_LAUNCH_FWD(EX, DE);                                                  \
     } while (0)
-#define SGN_LAUNCH_FWD3(EX, GA, DE)                                                     \
-    do {                                                                                \
-        if (o.waves_fwd == 2 && block_width == 16) SGN_LAUNCH_FWD_PK(EX, GA, DE);       \
-        else if (o.waves_fwd == 4 || o.waves_fwd == 2) SGN_LAUNCH_FWD(EX, GA, 1, false, DE); \
-        else if (o.waves_fwd == 1) SGN_LAUNCH_FWD(EX, GA, 4, false, DE);                \
-        else SGN_LAUNCH_FWD(EX, GA, 4, true, DE);                                       \
-    } while (0)
-#define SGN_LAUNCH_FWD2(EX, GA) do { if (depths) SGN_LAUNCH_FWD3(EX, GA, true); else SGN_LAUNCH_FWD3(EX, GA, false); } while (0)
-    if (o.exact_exp) {
-        if (o.gather) SGN_LAUNCH_FWD2(true, true); else SGN_LAUNCH_FWD2(true, false);
-    } else {
-        if (o.gather) SGN_LAUNCH_FWD2(false, true); else SGN_LAUNCH_FWD2(false, false);
-    }
+#define SGN_LAUNCH_FWD2(EX) do { if (depths) SGN_LAUNCH_FWD3(EX, true); else SGN_LAUNCH_FWD3(EX, false); } while (0)
+    if (o.exact_exp) SGN_LAUNCH_FWD2(true); else SGN_LAUNCH_FWD2(false);
 #undef SGN_LAUNCH_FWD2
 #undef SGN_LAUNCH_FWD3
-#undef SGN_LAUNCH_FWD_PK
 #undef SGN_LAUNCH_FWD_PKG
 #undef SGN_LAUNCH_FWD
     sgn_timing_end(SGN_T_RASTER_FWD, s);
@@ -1519,7 +1435,7 @@ int sgn_raster_fwd_precleared(int img_h, int img_w, int block_width, int n, int6
 // 1 tail, -1 none) + `own_ids` / `own_bins`: ONE group may come with its own compacted list (sgn_list_window) — the one
 // its backward will walk: its final indices are then positions of that list, and it finishes its walk there.
 // group_state [4][H*W]: T_head, T_tail, (int32) idx_head, idx_tail; group_stats [2][tiles*2] like tile_stats.
-// Packed two-waves-per-tile forward of the gather mode only (opts: gather = 1, waves_fwd = 2; block_width 16), whole
+// Packed two-waves-per-tile forward (block_width 16), whole
 // scene (no id window), rows already built or built here; -12 otherwise.
 SGN_EXPORT int sgn_raster_fwd_groups(int img_h, int img_w, int n, int64_t n_isect, const int32_t *gaussian_ids_sorted,
                                      const int32_t *tile_bins, const float *xys, const float *conics,
@@ -1651,15 +1567,13 @@ static int raster_bwd_impl(int img_h, int img_w, int block_width, int n, int64_t
                           final_Ts && final_idx && v_out_alpha && recs_ws, -7);     // (v_out_img may be NULL: zeros)
         SGN_ARG_CHECK(recs_ws_bytes >= sgn_raster_workspace_bytes(n, n_isect, &o), -8);
         if (!recs_packed)
-            pack_records(n, n_isect, gaussian_ids_sorted, xys, conics, colors, opacities, logit_rows, id_lo, id_hi,
-                         window, o.gather, recs_ws, s, o.ids_qmask ? SGN_QMASK_MAX_IDS - 1 : -1);
+            pack_records(n, xys, conics, colors, opacities, logit_rows, id_lo, id_hi, window, recs_ws, s);
         const int tiles_x = (img_w + block_width - 1) / block_width, tiles_y = (img_h + block_width - 1) / block_width;
         const Rec *rows = (const Rec *)recs_ws;
-        const Rec *stream_recs = rows + n;
         const int n_tiles = tiles_x * tiles_y;
         const int long_grid = n_tiles * 4;   // the long-walk kernel: workgroups beyond 4 * n_long exit at once
         // fork: the long-walk kernel goes to the auxiliary stream (if any) behind everything queued so far
-        const bool two_kernel = o.waves_bwd == 0 && tile_order != nullptr && block_width == 16;
+        const bool two_kernel = tile_order != nullptr && block_width == 16;
         hipStream_t s2 = s;
         hipEvent_t ev_fork = nullptr, ev_join = nullptr;
         if (two_kernel && aux_stream != nullptr && (hipStream_t)aux_stream != s && sgn_fork_events(&ev_fork, &ev_join) == 0) {
@@ -1668,37 +1582,26 @@ static int raster_bwd_impl(int img_h, int img_w, int block_width, int n, int64_t
             SGN_HIP_CHECK(hipStreamWaitEvent(s2, ev_fork, 0));
         }
         sgn_timing_begin(SGN_T_RASTER_BWD, s);
-#define SGN_BWD_ARGS(GA)                                                                                         \
-    img_w, img_h, block_width, tiles_x, n_tiles, (const int2 *)tile_bins, GA ? rows : stream_recs,               \
-        gaussian_ids_sorted, background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd,          \
-        (float *)grad_ws, o.debug_flags, o.adapt_bwd, o.xcd_swizzle, o.batch_bwd, tile_order, o.ids_qmask
-#define SGN_LAUNCH_BWDQ(EX, RM, GA, Q, AD)                                                                       \
-    hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, Q, AD, 0>), dim3(n_tiles * (AD ? 4 : 4 / Q)), dim3(64), 0, s, \
-                       SGN_BWD_ARGS(GA))
-#define SGN_LAUNCH_BWD(EX, RM, GA)                                                                               \
+#define SGN_BWD_ARGS                                                                                             \
+    img_w, img_h, block_width, tiles_x, n_tiles, (const int2 *)tile_bins, rows, gaussian_ids_sorted, background3, \
+        final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, (float *)grad_ws, o.debug_flags, o.adapt_bwd, \
+        o.batch_bwd, tile_order, o.ids_qmask
+#define SGN_LAUNCH_BWD(EX, RM)                                                                                   \
     do {                                                                                                         \
-        if (o.waves_bwd == 4) SGN_LAUNCH_BWDQ(EX, RM, GA, 1, false);                                             \
-        else if (o.waves_bwd == 1) SGN_LAUNCH_BWDQ(EX, RM, GA, 4, false);                                        \
-        else if (tile_order == nullptr || block_width != 16) SGN_LAUNCH_BWDQ(EX, RM, GA, 4, true);               \
+        if (!two_kernel)     /* no launch order / tiles other than 16x16: the in-kernel adaptive split */        \
+            hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, 4, true, 0>), dim3(n_tiles * 4), dim3(64), 0, s, SGN_BWD_ARGS); \
         else {   /* two-kernel adaptive scheme: order[0..n_long) = long walks, the rest short; the two halves */ \
                  /* touch disjoint tiles and run CONCURRENTLY when the caller lends a second stream           */ \
-            hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, GA, 1, false, 2>), dim3(long_grid), dim3(64), 0, s2,   \
-                               SGN_BWD_ARGS(GA));                                                                \
-            hipLaunchKernelGGL((raster_bwd_short_kernel<EX, RM, GA>), dim3(n_tiles), dim3(64), 0, s,      \
-                               SGN_BWD_ARGS(GA));                                                                \
+            hipLaunchKernelGGL((raster_bwd_kernel<EX, RM, 1, false, 2>), dim3(long_grid), dim3(64), 0, s2, SGN_BWD_ARGS); \
+            hipLaunchKernelGGL((raster_bwd_short_kernel<EX, RM>), dim3(n_tiles), dim3(64), 0, s, SGN_BWD_ARGS);   \
         }                                                                                                        \
     } while (0)
-#define SGN_LAUNCH_BWD2(EX, RM) do { if (o.gather) SGN_LAUNCH_BWD(EX, RM, true); else SGN_LAUNCH_BWD(EX, RM, false); } while (0)
         if (o.exact_exp) {
-            if (o.reduce_mode == 2) SGN_LAUNCH_BWD2(true, 2);
-            else if (o.reduce_mode) SGN_LAUNCH_BWD2(true, 1); else SGN_LAUNCH_BWD2(true, 0);
+            if (o.reduce_mode) SGN_LAUNCH_BWD(true, 1); else SGN_LAUNCH_BWD(true, 0);
         } else {
-            if (o.reduce_mode == 2) SGN_LAUNCH_BWD2(false, 2);
-            else if (o.reduce_mode) SGN_LAUNCH_BWD2(false, 1); else SGN_LAUNCH_BWD2(false, 0);
+            if (o.reduce_mode) SGN_LAUNCH_BWD(false, 1); else SGN_LAUNCH_BWD(false, 0);
         }
-#undef SGN_LAUNCH_BWD2
 #undef SGN_LAUNCH_BWD
-#undef SGN_LAUNCH_BWDQ
 #undef SGN_BWD_ARGS
         if (s2 != s) {   // join: the unpack (and everything after) waits for the long-walk kernel
             SGN_HIP_CHECK(hipEventRecord(ev_join, s2));

@@ -51,17 +51,6 @@ int sgn_project_fwd_checked(int n, const float *means3d, const float *scales, fl
 
 static inline int sgn_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// ---- replay of a fixed launch chain as a HIP graph (api.cpp).  The binning's chains are a dozen dependent 5-10 us kernels
-// whose arguments repeat from step to step (the caller's allocator hands back the same addresses): `key` = every argument
-// of the chain as 64-bit words.  sgn_graph_find returns the instantiated graph of an earlier identical call or nullptr;
-// sgn_graph_capture_begin / _end record the launches the caller then makes on the returned CAPTURE stream (the caller's
-// own stream may be the legacy default stream, which cannot be captured; nothing executes during capture) and file the
-// graph under the key.  Disabled (always nullptr / no capture) unless SGN_HIP_GRAPHS=1, and while kernel timing is on.
-#define SGN_GRAPH_KEY_WORDS 12
-hipGraphExec_t sgn_graph_find(const uint64_t *key);
-hipStream_t sgn_graph_capture_begin();                             // nullptr: graphs are off / capture failed
-hipGraphExec_t sgn_graph_capture_end(const uint64_t *key);         // nullptr on failure (the caller launches directly)
-
 // float -> int with v_cvt_i32_f32 semantics (saturating, NaN -> 0); the C oracle spells the
 // same rule out (oracle/c/sgn_oracle.c f2i).
 __device__ __forceinline__ int sgn_f2i(float v) {

@@ -117,8 +117,8 @@ _lib = None
 
 class RasterOpts(C.Structure):
     """`sgn_raster_opts` of include/sgn_rast.h: kernel-selection options handed to the raster entry points per call."""
-    _fields_ = [(k, C.c_int) for k in ("exact_exp", "reduce_mode", "gather", "waves_fwd", "waves_bwd", "adapt_fwd", "adapt_bwd",
-                                       "batch_fwd", "batch_bwd", "xcd_swizzle", "debug_flags", "ids_qmask")]
+    _fields_ = [(k, C.c_int) for k in ("exact_exp", "reduce_mode", "adapt_fwd", "adapt_bwd", "batch_fwd", "batch_bwd",
+                                       "debug_flags", "ids_qmask")]
 
     def copy(self) -> "RasterOpts":
         out = RasterOpts()
@@ -129,8 +129,7 @@ class RasterOpts(C.Structure):
 # The library itself is stateless; the HOST keeps the options: one process-wide default object (library defaults,
 # overridable through SGN_* environment variables for A/B runs) and, inside `with options(...)`, a private copy that
 # only the current thread / context sees (contextvars), so concurrent callers cannot race on a switch.
-_ENV = dict(reduce_mode="SGN_REDUCE_MODE", gather="SGN_RASTER_GATHER", waves_fwd="SGN_WAVES_FWD", waves_bwd="SGN_WAVES_BWD",
-            batch_fwd="SGN_BATCH_FWD", batch_bwd="SGN_BATCH_BWD", xcd_swizzle="SGN_XCD_SWIZZLE",
+_ENV = dict(reduce_mode="SGN_REDUCE_MODE", batch_fwd="SGN_BATCH_FWD", batch_bwd="SGN_BATCH_BWD",
             adapt_fwd="SGN_ADAPT_FWD", adapt_bwd="SGN_ADAPT_BWD", debug_flags="SGN_DEBUG_FLAGS")
 _process_opts = None
 _ctx_opts: contextvars.ContextVar = contextvars.ContextVar("sgn_raster_opts", default=None)

@@ -386,7 +386,7 @@ def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors,
             zero = torch.zeros(img_height, img_width, dtype=torch.float32, device=xys.device)
             accs = (zero, main[1]) if s == 0 else (main[1], zero)
             return main[0], main[1], (main[2] if depth_channel else None), accs[0], accs[1]
-        if group_accumulation_enabled and ro.gather and ro.waves_fwd == 2 and block_width == 16:
+        if group_accumulation_enabled and block_width == 16:
             return _RasterizeGaussians.apply(*args, True, True, None, bool(depth_channel), False, None, s)
         main = _RasterizeGaussians.apply(*args, True, True, None, bool(depth_channel))
         accs = [_RasterizeGaussians.apply(*args, True, True, (lo, hi), False)[1] if hi > lo

@@ -1017,9 +1017,10 @@ concurrent_backward = os.environ.get("SGN_BWD_CONCURRENT", "1") != "0"
 small_splat_q16 = 0       # experimental: > 0 sends tiles with < q/16 evaluated (entry, quadrant) pairs per walked entry to the 4-waves kernel (no gain measured: profiles/r02_street_balance.md)
 
 
-def _fwd_long_thresh(ro) -> int:
-    """Forward lists with at least this many entries get four waves in the packed forward (0: no such prefix)."""
-    return int(ro.adapt_fwd if ro.adapt_fwd > 0 else 1024) if ro.waves_fwd == 2 else 0
+def _fwd_long_thresh(ro, block_width: int = 16) -> int:
+    """Forward lists with at least this many entries get four waves in the packed forward (16x16 tiles; 0: no such
+    prefix)."""
+    return int(ro.adapt_fwd if ro.adapt_fwd > 0 else 1024) if int(block_width) == 16 else 0
 
 
 def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = None, long_thresh: int = 0,
@@ -1406,7 +1407,7 @@ def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colo
         S.store_binning(key, tuple(t.detach() for t in _t), (count, ids, tile_bins), _window_info(_t, cull, logit_leaves))
     if tile_order_enabled:
         oc = S.order_cache
-        oc[(id(tile_bins), _fwd_long_thresh(ro))] = (tile_bins, order)
+        oc[(id(tile_bins), _fwd_long_thresh(ro, block_width))] = (tile_bins, order)
         while len(oc) > 4:
             oc.popitem(last=False)
     return count, ids, tile_bins, order, tile_kmax, rows
@@ -1465,7 +1466,7 @@ def _forward_window_composite(S, cand, n, xys_c, depths, radii, num_tiles_hit, c
     sub = bool(list_window_enabled and n < list_window_max_frac * n_full)
     order_ready = None
     if not sub:
-        hit = S.order_cache.get((id(bins_full), _fwd_long_thresh(ro)))
+        hit = S.order_cache.get((id(bins_full), _fwd_long_thresh(ro, block_width)))
         if hit is not None and hit[0] is bins_full:
             order_ready = hit[1]
     ids_out = torch.empty_like(ids_full) if sub else None
@@ -1509,7 +1510,7 @@ def _forward_window_composite(S, cand, n, xys_c, depths, radii, num_tiles_hit, c
         ids_use, bins_use = ids_full, bins_full
         if order_ready is None and tile_order_enabled:
             oc = S.order_cache
-            oc[(id(bins_full), _fwd_long_thresh(ro))] = (bins_full, order)
+            oc[(id(bins_full), _fwd_long_thresh(ro, block_width))] = (bins_full, order)
             while len(oc) > 4:
                 oc.popitem(last=False)
     return matched.value, n_full, num_intersects, ids_use, bins_use, order_ready if order_ready is not None else order, tile_kmax, rows
@@ -1558,7 +1559,7 @@ class _RasterizeGaussians(Function):
         wcomp = None
         if id_range is None and not hit and _bin_pending["key"] != key:
             cand = None
-            if (composite_forward and tile_order_enabled and ro.gather and group_split is None and not want_depth
+            if (composite_forward and tile_order_enabled and group_split is None and not want_depth
                     and depths.dtype is torch.float32 and radii.dtype is torch.int32
                     and num_tiles_hit.dtype is torch.int32):
                 cand = _window_candidate(S, key[len(_t):], num_points, _t)
@@ -1581,7 +1582,7 @@ class _RasterizeGaussians(Function):
             id_lo, id_hi = (0, num_points) if id_range is None else (int(id_range[0]), int(id_range[1]))
         # depth channel: is this the reference's depth pass over the geometry of the pass before it (answer it from that
         # pass's fourth channel), or a first pass that should accumulate the channel?
-        plain = win is None and id_range is None and num_points > 0 and bool(ro.gather) and cull
+        plain = win is None and id_range is None and num_points > 0 and cull
         dcache = S.depth_caches.get(key)
         reuse = (plain and hit and not want_depth and group_split is None and depth_channel != "off" and dcache is not None
                  and colors_c.shape == (num_points, 3) and dcache["D"].shape == (img_height, img_width))
@@ -1629,9 +1630,9 @@ class _RasterizeGaussians(Function):
                 S.depth_caches.pop(key, None)  # binned again without the channel: a stale image must not answer later
         else:
             # ... and the per-Gaussian rows are built between the binning's first half and its host sync, so the GPU has
-            # work queued while the host wakes up (gather mode; the stream mode re-packs rows per intersection later)
+            # work queued while the host wakes up
             recs, rows_built = None, 0
-            if num_points > 0 and ro.gather and not proved:
+            if num_points > 0 and not proved:
                 if win is None and not hit and _bin_pending["key"] != key:
                     _drop_pending()
                     _bin_pending["state"] = _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bounds,
@@ -1650,7 +1651,7 @@ class _RasterizeGaussians(Function):
                     opacity_is_logit, pre=(key, _t, cull), logit_leaves=opacity_logits)
             ro.ids_qmask = int(bool(getattr(gaussian_ids_sorted, "_sgn_qmask", False)))   # the backward runs with `ro` too
             if (num_intersects >= 1 and list_window_enabled and (id_hi - id_lo) < list_window_max_frac * n_full
-                    and (id_lo, id_hi) != (0, n_full) and ro.gather):      # (stream mode re-packs n_isect records: full list)
+                    and (id_lo, id_hi) != (0, n_full)):
                 # a SMALL window of a shared list (the scene graph's objects-only pass): walk its own entries only
                 gaussian_ids_sorted, tile_bins = _list_window(gaussian_ids_sorted, tile_bins, id_lo, id_hi, ro.ids_qmask)
                 window_stats["sub_lists"] += 1
@@ -1658,7 +1659,7 @@ class _RasterizeGaussians(Function):
                 # the depth pass, proven on the host: its image comes from the first pass's fourth channel, and its node
                 # SHARES that pass's per-pixel state and tile statistics (same geometry and opacities: same values)
                 final_Ts, final_idx, tile_kmax = dcache["T"], dcache["idx"], dcache["kmax"]
-                order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
+                order = _tile_order(tile_bins, None, _fwd_long_thresh(ro, block_width))
                 L.check(lib.sgn_depth_reuse(img_height, img_width, None, L.ptr(dcache["D"]), L.ptr(final_Ts),
                                             L.ptr(final_idx), L.ptr(bg_c), L.ptr(out_img), None, None, 0, None, None,
                                             stream_ptr), "sgn_depth_reuse")
@@ -1678,10 +1679,10 @@ class _RasterizeGaussians(Function):
                 # split, tail = the others.  The smaller group, if small enough, gets its own compacted list: its backward
                 # walks that list, so its indices are recorded in that list's positions (and its forward walk finishes
                 # there); the other one walks the shared list (with the first group's rows inert).
-                assert win is None and id_range is None and ro.gather and ro.waves_fwd == 2 and block_width == 16
+                assert win is None and id_range is None and block_width == 16
                 if not rows_built:
                     recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
-                order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
+                order = _tile_order(tile_bins, None, _fwd_long_thresh(ro, block_width))
                 n_tiles = tile_bins.shape[0]
                 tile_kmax = torch.empty(n_tiles, 2, dtype=torch.int32, device=dev)
                 split = min(max(int(group_split), 0), n_full)
@@ -1718,7 +1719,7 @@ class _RasterizeGaussians(Function):
                 if not rows_built:
                     recs = L.workspace(lib.sgn_raster_workspace_bytes(n_full, num_intersects, ro_ptr), dev)
                 # packed forward: the leading tiles of the order whose lists reach adapt_fwd entries get four waves
-                order = _tile_order(tile_bins, None, _fwd_long_thresh(ro))
+                order = _tile_order(tile_bins, None, _fwd_long_thresh(ro, block_width))
                 tile_kmax = torch.empty(tile_bins.shape[0], 2, dtype=torch.int32, device=dev)   # walk depth, pairs
                 L.check(lib.sgn_raster_fwd(
                     img_height, img_width, block_width, n_full, num_intersects, L.ptr(gaussian_ids_sorted), L.ptr(tile_bins),

@@ -78,11 +78,11 @@ def test_argument_errors_are_reported_without_a_gpu(built_lib):
     import ctypes
     o = built_lib.RasterOpts()
     lib.sgn_raster_default_opts(ctypes.byref(o))                  # options travel with each call: no setters
-    assert (o.exact_exp, o.reduce_mode, o.gather, o.waves_fwd, o.waves_bwd, o.adapt_fwd, o.adapt_bwd, o.batch_fwd,
-            o.batch_bwd, o.xcd_swizzle, o.debug_flags) == (0, 1, 1, 2, 0, 1024, 256, 256, 128, 0, 0)
-    assert lib.sgn_raster_workspace_bytes(5, 10, None) == 5 * 48  # NULL = defaults: per-Gaussian rows only
-    o.gather = 0
-    assert lib.sgn_raster_workspace_bytes(5, 10, ctypes.byref(o)) == 15 * 48   # + depth-ordered record stream
+    assert (o.exact_exp, o.reduce_mode, o.adapt_fwd, o.adapt_bwd, o.batch_fwd, o.batch_bwd, o.debug_flags,
+            o.ids_qmask) == (0, 1, 1024, 256, 256, 128, 0, 0)
+    assert ctypes.sizeof(built_lib.RasterOpts) == 8 * 4           # the struct of include/sgn_rast.h, field for field
+    assert lib.sgn_raster_workspace_bytes(5, 10, None) == 5 * 48  # one 48-byte row per Gaussian
+    assert lib.sgn_raster_workspace_bytes(5, 10, ctypes.byref(o)) == 5 * 48
     assert not [n for n in built_lib.SIGNATURES if n.startswith("sgn_set_")]   # the library has no global switches
     with built_lib.options(exact_exp=1) as priv:                  # host-side options are context-local
         assert built_lib.opts() is priv and priv.exact_exp == 1

@@ -20,9 +20,9 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.fixture(params=[dict(), dict(batch_fwd=24, batch_bwd=24), dict(waves_fwd=4), dict(waves_fwd=1),
-                        dict(waves_fwd=0, adapt_fwd=96), dict(exact_exp=1), dict(exact_exp=1, batch_fwd=24)],
-                ids=["default-packed", "packed-ldsbatch", "4waves", "1wave", "adaptive", "exact", "exact-ldsbatch"])
+@pytest.fixture(params=[dict(), dict(batch_fwd=24, batch_bwd=24), dict(adapt_fwd=96), dict(exact_exp=1),
+                        dict(exact_exp=1, batch_fwd=24)],
+                ids=["default-packed", "packed-ldsbatch", "four-wave-tiles", "exact", "exact-ldsbatch"])
 def mode(request):
     from sgn_rast import _lib as L, ops
     L.load()

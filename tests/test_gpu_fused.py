@@ -186,14 +186,16 @@ def test_id_range_pass_equals_sliced_pass(batch):
         L.set_options(batch_fwd=256, batch_bwd=128)
 
 
-@pytest.mark.parametrize("gather", [1, 0])
-def test_window_copies_reuse_the_cached_binning(gather):
+@pytest.mark.parametrize("one_call", [True, False], ids=["one call per node", "call by call"])
+def test_window_copies_reuse_the_cached_binning(one_call):
     """Drop-in scene-graph path: the sub-model passes receive torch.cat COPIES of per-model slices of the main
     projection (sgn_splatfacto_scene_graph.py:270-276).  The shim recognises them by content as the head / tail window
     of the cached scene and rasterizes over the cached depth list: bit-identical image and alpha to the re-binned
     call, equal gradients (sized like the window), no new binning; anything else falls back to re-binning."""
     from sgn_rast import _lib as L, ops, scenes, step
-    with L.options(gather=gather):
+    old_comp = (ops.composite_forward, ops.composite_backward)
+    ops.composite_forward = ops.composite_backward = one_call
+    with L.options():
         cam, raw = scenes.make_scene("c1", seed=5, device=DEV, n_override=4000)
         counts = [2500, 700, 800]
         with torch.no_grad():
@@ -249,8 +251,8 @@ def test_window_copies_reuse_the_cached_binning(gather):
             img_r, _ = ops.rasterize_gaussians(*sub, rgbs[:2500], opac[:2500], cam.height, cam.width, 16, bg, True)
             assert torch.equal(img_m, img_r)
         finally:
-            pass
             ops.window_matching_enabled = True
+            ops.composite_forward, ops.composite_backward = old_comp
             ops.clear_binning_cache()
 
 

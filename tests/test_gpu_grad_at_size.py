@@ -70,7 +70,7 @@ def production_defaults():
     L.load()
     L.reset_options()
     o = L.opts()
-    assert (o.exact_exp, o.reduce_mode, o.gather, o.waves_fwd, o.waves_bwd) == (0, 1, 1, 2, 0)
+    assert (o.exact_exp, o.reduce_mode, o.debug_flags) == (0, 1, 0)
     assert (o.adapt_fwd, o.adapt_bwd, o.batch_fwd, o.batch_bwd) == (1024, 256, 256, 128)
     yield L
     L.reset_options()
@@ -123,7 +123,7 @@ def test_train_step_gradients_match_oracle_at_size(name, production_defaults):
     finally:
         oracle_ops.PIXEL_ROWS = None
 
-    for reduce_mode in (1, 0, 2):
+    for reduce_mode in (1, 0):
         lib.set_options(reduce_mode=reduce_mode)
         Pd, got = _hip_step(cam, raw, w_img, w_a)
         # The library's projection is bit-exact on identical inputs (test_project_forward_bit_exact; at this size:

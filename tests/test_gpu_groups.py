@@ -120,19 +120,17 @@ def test_only_the_group_outputs_in_the_loss():
     assert float(first[0][:split].abs().max()) == 0.0 and float(first[0][split:].abs().max()) > 0
 
 
-def test_unsupported_kernel_options_fall_back_to_three_passes():
-    from sgn_rast import _lib as L, ops
+def test_group_accumulations_switched_off_fall_back_to_three_passes():
+    """`fused.group_accumulation_enabled = False`: the main pass and two id-range passes over the same list give the same
+    five images, and the combined walk is not used."""
+    from sgn_rast import ops
     cam, geo, colors, logits, split = _inputs(4000, 0.7, seed=2)
     ref, _ = _run(geo, colors, logits, cam, split, True)
-    for kw in (dict(waves_fwd=4), dict(gather=0)):
-        with L.options(**kw):
-            before = ops.group_stats["passes"]
-            out, _ = _run(geo, colors, logits, cam, split, True)
-            assert ops.group_stats["passes"] == before          # the combined walk was not used
-        for name, x, y in zip(("img", "alpha", "depth", "acc_head", "acc_tail"), out, ref):
-            if name == "depth" and "gather" in kw:
-                continue                              # (the depth channel is a gather-mode feature)
-            assert float((x - y).abs().max()) < 2e-5, (kw, name)
+    before = ops.group_stats["passes"]
+    out, _ = _run(geo, colors, logits, cam, split, False)
+    assert ops.group_stats["passes"] == before                  # the combined walk was not used
+    for name, x, y in zip(("img", "alpha", "depth", "acc_head", "acc_tail"), out, ref):
+        assert float((x - y).abs().max()) < 2e-5, name
 
 
 def test_odd_image_size_and_partial_tiles():

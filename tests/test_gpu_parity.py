@@ -19,20 +19,18 @@ def hip():
     return ops
 
 
-@pytest.fixture(autouse=True, params=[(0, 1, 0), (1, 1, 0), (1, 4, 0), (1, 0, 0), (1, 0, 1), (0, 1, 1), (1, 2, 0),
-                                       (1, 2, 1), (0, 2, 1)],
-                ids=["stream", "gather", "gather-4waves", "gather-adaptive", "gather-adaptive-ldsbatch",
-                     "stream-ldsbatch", "gather-packed", "gather-packed-ldsbatch", "stream-packed-ldsbatch"])
+@pytest.fixture(autouse=True, params=[(0, 0), (1, 0), (0, 1), (1, 1)],
+                ids=["scalar-chase", "ldsbatch", "scalar-chase-split", "ldsbatch-split"])
 def raster_record_mode(request):
-    """Every test in this module runs with the record-fetch modes of the raster kernels (packed depth-ordered
-    stream vs. ids -> per-Gaussian rows chased with scalar loads) with 1 / 4 / adaptive waves per tile, and with the LDS-batched
-    long-list path forced on or off."""
+    """Every test in this module runs with each code path of the raster kernels (round 6: the surviving ones — the
+    "stream" mode and the forced one- / four-wave shapes are gone): the scalar row chase or the LDS-batched long-list path
+    (forced on / forbidden through the thresholds), and launch-order thresholds small enough that these small scenes have
+    tiles on BOTH sides of them (four-wave forward tiles; the backward's long-walk kernel) or on one side only."""
     from sgn_rast import _lib as L
-    gather, wpt, batch = request.param
+    batch, split = request.param
     thr = (24, 24) if batch else (1 << 30, 1 << 30)                  # force / forbid the LDS path
-    # wpt 2: the packed-FP32 forward (two waves per tile, two pixels per lane); the backward runs adaptive
-    kw = dict(batch_fwd=thr[0], batch_bwd=thr[1], gather=gather, waves_fwd=wpt, waves_bwd=wpt if wpt != 2 else 0)
-    if wpt in (0, 2):
+    kw = dict(batch_fwd=thr[0], batch_bwd=thr[1])
+    if split:
         kw.update(adapt_fwd=96, adapt_bwd=48)                        # small scenes: make some tiles split, others not
     L.load()
     with L.options(**kw):
@@ -350,10 +348,10 @@ def test_rasterize_forward_exact_exp_mode_is_bit_exact(hip, c_oracle, block, siz
 
 @pytest.mark.parametrize("block,size", [(16, (128, 128)), (16, (130, 70)), (8, (100, 60))])
 @pytest.mark.parametrize("clamp", [0.99, 0.999])
-@pytest.mark.parametrize("reduce_mode", [0, 1, 2])
+@pytest.mark.parametrize("reduce_mode", [0, 1])
 def test_rasterize_backward(hip, c_oracle, block, size, clamp, reduce_mode):
     from sgn_rast import _lib as L, ops
-    L.set_options(reduce_mode=reduce_mode)   # 0: butterfly shuffles, 1: transposed permlane-swap reduction, 2: MFMA column sums
+    L.set_options(reduce_mode=reduce_mode)   # 0: butterfly shuffles, 1: transposed permlane-swap reduction
     cam, P = small_scene(n=3000, w=size[0], h=size[1], focal=float(size[0]))
     P["opacity_logits"][:200] = 9.0   # opacity ~0.9999: exercises the 0.999 (fwd) / 0.99 (bwd) clamps
     R = _raster_inputs(c_oracle, cam, P, block)

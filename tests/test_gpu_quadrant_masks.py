@@ -110,10 +110,9 @@ def test_masks_are_conservative_tight_and_leave_the_list_alone(shape, masks_swit
     print(f"quadrant pairs: box test {n_box}, masks {n_set}, with a valid pixel {n_true}")
 
 
-MODES = [dict(), dict(batch_fwd=24, batch_bwd=24), dict(waves_fwd=4, waves_bwd=4), dict(waves_fwd=1, waves_bwd=1),
-         dict(waves_fwd=0, adapt_fwd=96, adapt_bwd=64), dict(exact_exp=1), dict(exact_exp=1, batch_fwd=24, batch_bwd=24),
-         dict(gather=0), dict(reduce_mode=0)]
-IDS = ["default", "ldsbatch", "4waves", "1wave", "adaptive", "exact", "exact-ldsbatch", "stream-records", "butterfly"]
+MODES = [dict(), dict(batch_fwd=24, batch_bwd=24), dict(adapt_fwd=96, adapt_bwd=64), dict(exact_exp=1),
+         dict(exact_exp=1, batch_fwd=24, batch_bwd=24), dict(reduce_mode=0)]
+IDS = ["default", "ldsbatch", "split-tiles", "exact", "exact-ldsbatch", "butterfly"]
 
 
 def _render(on, mode, with_grad=True, n=5000, size=(192, 128)):

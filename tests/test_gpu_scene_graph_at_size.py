@@ -54,7 +54,7 @@ def production_defaults():
     L.load()
     L.reset_options()
     o = L.opts()
-    assert (o.exact_exp, o.reduce_mode, o.gather, o.waves_fwd, o.waves_bwd) == (0, 1, 1, 2, 0)
+    assert (o.exact_exp, o.reduce_mode, o.debug_flags) == (0, 1, 0)
     assert (o.adapt_fwd, o.adapt_bwd, o.batch_fwd, o.batch_bwd) == (1024, 256, 256, 128)
     yield L
     L.reset_options()

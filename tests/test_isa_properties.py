@@ -42,15 +42,15 @@ def test_raster_kernels_have_no_scratch_and_scalar_operands(raster_asm):
     ks = _kernels(raster_asm)
     fwd = [t for k, t in ks.items() if "raster_fwd_kernel" in k]
     bwd = [t for k, t in ks.items() if "raster_bwd_kernel" in k or "raster_bwd_short_kernel" in k]
-    # forward: exact x gather x {4 waves, 1 wave, adaptive} x {3 channels, + depth channel}; backward: exact x reduce (3) x
-    # gather x {4 waves, 1 wave, legacy in-kernel adaptive, long-walk half of the two-kernel scheme} + its short-walk
-    # half (own kernel)
-    assert len(fwd) == 24 and len(bwd) == 60
+    # (round 6: what ships is what runs — the "stream" mode, the forced one- / four-wave shapes and the MFMA reduction are
+    # gone)  forward, tile sizes other than 16: exact x {3 channels, + depth channel}; backward: exact x reduce (2) x
+    # {in-kernel adaptive split, long-walk half of the two-kernel scheme} + its short-walk half (own kernel)
+    assert len(fwd) == 4 and len(bwd) == 12
     for t in fwd + bwd:
         assert re.search(r"ScratchSize: 0\b", t), "a raster kernel spills to scratch"
         assert "s_load_dwordx8" in t and "s_load_dwordx4" in t     # 48-byte row / record in SGPRs
-    gather_fwd = [t for k, t in ks.items() if "raster_fwd_kernelILb0ELb1E" in k]
-    assert gather_fwd and all("ds_read_b128" in t for t in gather_fwd)   # LDS-batched long-list path compiled in
+    assert all("ds_read_b128" in t for t in fwd)                   # LDS-batched long-list path compiled in
+    assert "v_mfma" not in raster_asm and "pack_records_kernel" not in raster_asm
 
 
 def test_packed_forward_runs_on_the_packed_fp32_pipe(raster_asm):
@@ -58,8 +58,8 @@ def test_packed_forward_runs_on_the_packed_fp32_pipe(raster_asm):
     update and the three colour sums are v_pk_* instructions, and nothing spills."""
     ks = _kernels(raster_asm)
     pk = {k: t for k, t in ks.items() if "raster_fwd_pk_kernel" in k}
-    assert len(pk) == 12                                           # exact x gather x depth channel, + the gather ones with groups
-    groups = {k: t for k, t in pk.items() if re.search(r"pk_kernelILb[01]ELb1ELb[01]ELb1EEE", k)}
+    assert len(pk) == 8                                            # exact x depth channel x group accumulations
+    groups = {k: t for k, t in pk.items() if re.search(r"pk_kernelILb[01]ELb[01]ELb1EEE", k)}
     assert len(groups) == 4                                        # (r04) sgn_raster_fwd_groups: exact x depth channel
     for k, t in groups.items():
         # the walk with the two group accumulations AND the plain walk (tiles without an entry of the own-list group)
@@ -73,10 +73,10 @@ def test_packed_forward_runs_on_the_packed_fp32_pipe(raster_asm):
         assert "s_load_dwordx8" in t and "ds_read_b128" in t      # scalar-chase and LDS-batched paths both compiled in
         # two code paths (scalar chase, LDS batches) x (3 colour + 2 quadratic-form) packed FMAs, + the 1-px long-tile body
         assert t.count("v_pk_fma_f32") >= 10 and t.count("v_pk_mul_f32") >= 12, k
-    fast = next(t for k, t in pk.items() if "ILb0ELb1ELb0ELb0E" in k)
+    fast = next(t for k, t in pk.items() if "ILb0ELb0ELb0E" in k)
     assert fast.count("v_exp_f32") >= 4                            # hardware exp, two per entry and path
     # the depth channel (r03) is ONE more packed fma per entry and path in the two-pixel body, nothing else
-    deep = next(t for k, t in pk.items() if "ILb0ELb1ELb1ELb0E" in k)
+    deep = next(t for k, t in pk.items() if "ILb0ELb1ELb0E" in k)
     assert 0 < deep.count("v_pk_fma_f32") - fast.count("v_pk_fma_f32") <= 3
     assert re.search(r"ScratchSize: 0\b", deep)
 
@@ -87,7 +87,7 @@ def test_short_walk_backward_is_held_at_four_waves_and_not_slp_packed(raster_asm
     (it would starve the concurrently running long-walk kernel): the occupancy attribute must have taken."""
     ks = _kernels(raster_asm)
     short = {k: t for k, t in ks.items() if "raster_bwd_short_kernel" in k}
-    assert len(short) == 12
+    assert len(short) == 4
     for k, t in short.items():
         assert "v_pk_fma_f32" not in t and "v_pk_mul_f32" not in t, k
         m = re.search(r"; Occupancy: (\d+)", t)
@@ -99,15 +99,13 @@ def test_backward_uses_the_permlane_swap_reduction(raster_asm):
     for k, t in ks.items():
         if "raster_bwd_kernel" not in k and "raster_bwd_short_kernel" not in k:
             continue
-        reduce_mode = int(re.search(r"raster_bwd_(?:short_)?kernelILb[01]ELi([012])E", k).group(1))
+        reduce_mode = int(re.search(r"raster_bwd_(?:short_)?kernelILb[01]ELi([01])E", k).group(1))
         swaps = t.count("v_permlane32_swap") + t.count("v_permlane16_swap")
         if reduce_mode == 1:
             assert swaps == 16 and t.count("row_half_mirror") >= 6        # 8 swaps + 12 DPP adds per code path, 2 paths
-            assert "v_mfma" not in t
-        elif reduce_mode == 2:        # round-5 experiment: column sums on the matrix pipe, nine MFMAs per code path
-            assert swaps == 0 and t.count("v_mfma_f32_16x16x4_f32") == 18 and t.count("row_half_mirror") >= 6
         else:
-            assert swaps == 0 and "v_mfma" not in t
+            assert swaps == 0
+        assert "v_mfma" not in t
 
 
 def test_sky_backward_keeps_lds_and_global_atomics_apart(tmp_path_factory):
