@@ -776,7 +776,7 @@ def main():
             ops.quat_check = "deferred"
             deferred_extra = timed_variant()
             ops.quat_check = default_check
-            deferred_extra["note"] = ("opt-in SGN_QUAT_CHECK=deferred: upstream's quats assertion raises at the next "
+            deferred_extra["note"] = ("opt-in SGN_OPTIONS=quat_check=deferred: upstream's quats assertion raises at the next "
                                       "existing host sync (inside rasterize_gaussians) instead of from "
                                       "project_gaussians; no host sync of its own")
 
@@ -790,7 +790,7 @@ def main():
             no_proofs_extra = timed_variant()
         finally:
             ops.activation_proofs, ops.sh_split_backward = saved_p
-        no_proofs_extra["note"] = ("library defaults with SGN_ACT_PROOFS=0 SGN_SH_SPLIT_BWD=0: every operator takes its "
+        no_proofs_extra["note"] = ("library defaults with SGN_OPTIONS=graph_proofs=off: every operator takes its "
                                    "plain autograd node (gradients to the activated tensors, dense SH gradient)")
 
     # what the documented (default) sort ranking costs: the same step with the returning-atomic ranking forced, if
@@ -1069,6 +1069,8 @@ def main():
                                    "host-side set-up ran the first 20-step chunk 30 % slow on some boxes "
                                    "(profiles/r05aa_settle_ab.log); the timed region is exactly K steps between the two "
                                    "barrier + synchronize pairs, and `repeat` holds further chunks of exactly K steps")
+        from sgn_rast import config as sgn_config
+        line["config"]["options"] = sgn_config.report()        # the ONE options object: what is not at its default
         line["config"]["quat_check"] = ops.quat_check
         line["config"]["sort_ranking"] = dict(L.sort_ranking_report(), **(sort_ab or {}))
         line["config"]["speculative_binning"] = dict(enabled=bool(ops.speculative_binning), **ops.binning_stats)

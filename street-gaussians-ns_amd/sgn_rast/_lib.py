@@ -127,20 +127,20 @@ class RasterOpts(C.Structure):
 
 
 # The library itself is stateless; the HOST keeps the options: one process-wide default object (library defaults,
-# overridable through SGN_* environment variables for A/B runs) and, inside `with options(...)`, a private copy that
+# overridable through SGN_OPTIONS, sgn_rast/config.py) and, inside `with options(...)`, a private copy that
 # only the current thread / context sees (contextvars), so concurrent callers cannot race on a switch.
-_ENV = dict(reduce_mode="SGN_REDUCE_MODE", batch_fwd="SGN_BATCH_FWD", batch_bwd="SGN_BATCH_BWD",
-            adapt_fwd="SGN_ADAPT_FWD", adapt_bwd="SGN_ADAPT_BWD", debug_flags="SGN_DEBUG_FLAGS")
+_OPT_FIELDS = ("reduce_mode", "batch_fwd", "batch_bwd", "adapt_fwd", "adapt_bwd", "exact_exp", "debug_flags")
 _process_opts = None
 _ctx_opts: contextvars.ContextVar = contextvars.ContextVar("sgn_raster_opts", default=None)
 
 
 def _library_defaults() -> RasterOpts:
+    from . import config
     o = RasterOpts()
     load().sgn_raster_default_opts(C.byref(o))
-    for field, env in _ENV.items():
-        if os.environ.get(env, "") != "":
-            setattr(o, field, int(os.environ[env]))
+    for field in _OPT_FIELDS:                   # SGN_OPTIONS="batch_fwd=64,..." (sgn_rast/config.py)
+        if field in config._from_env:
+            setattr(o, field, int(config._from_env[field]))
     return o
 
 
@@ -215,10 +215,10 @@ def load() -> C.CDLL:
 # Which in-wave ranking the radix sorts use is an ARGUMENT of every sorting entry point (include/sgn_rast.h,
 # `sort_rank_mode`); the library keeps no state about it.  The host's policy, PER DEVICE:
 #   default              0 = the ballot-match ranking: documented ISA semantics only (north_star: bit-exact sort keys);
-#   SGN_SORT_RANK=atomic 1 = one returning LDS atomic per key (-7 us per binning) — but only on a device that has passed
+#   sort_rank=atomic     1 = one returning LDS atomic per key (-7 us per binning) — but only on a device that has passed
 #                        `sort_selftest_under_load` (>= 1000 probe sorts while a second instance and a GEMM run on other
 #                        streams); a device that fails stays on 0, with a warning;
-#   SGN_SORT_RANK=atomic-unchecked   1 without the probe (A/B runs).
+#   sort_rank=atomic-unchecked       1 without the probe (A/B runs).   (option `sort_rank` of sgn_rast/config.py)
 # `force_sort_rank` overrides it inside a `with` block (tests, bench.py's A/B line).
 _SORT_RANK: dict = {}          # device index -> {"mode": 0 | 1, "probe": str}
 _sort_rank_forced = None
@@ -251,19 +251,23 @@ def sort_selftest_under_load(rounds: int = 64, device=None) -> int:
         return int(bad.sum().item())
 
 
+_sort_rank_request = None      # None: what sgn_rast.config says ("ballot" unless SGN_OPTIONS="sort_rank=atomic")
+
+
 def _decide_sort_ranking(dev_index: int) -> dict:
-    want = os.environ.get("SGN_SORT_RANK", "ballot").lower()
+    from . import config
+    want = (_sort_rank_request or config.value("sort_rank")).lower()
     if want == "atomic-unchecked":
-        return {"mode": 1, "probe": "forced by SGN_SORT_RANK=atomic-unchecked (no probe)"}
+        return {"mode": 1, "probe": "forced by sort_rank=atomic-unchecked (no probe)"}
     if want != "atomic" or not torch.cuda.is_available():
         return {"mode": 0, "probe": "not needed: the documented ballot ranking is the default"}
-    rounds = int(os.environ.get("SGN_SORT_PROBE_ROUNDS", "64"))
+    rounds = 64
     bad = sort_selftest_under_load(rounds, dev_index)
     if bad == 0:
         return {"mode": 1, "probe": f"passed under load on device {dev_index}: {2 * 16 * rounds} probe sorts per ranking, "
                                     "0 mismatching pairs"}
     import warnings
-    warnings.warn(f"SGN_SORT_RANK=atomic: the probe counted {bad} mismatching pairs on device {dev_index}; staying on "
+    warnings.warn(f"sort_rank=atomic: the probe counted {bad} mismatching pairs on device {dev_index}; staying on "
                   "the documented ballot ranking there")
     return {"mode": 0, "probe": f"FAILED ({bad} mismatching pairs) on device {dev_index}: ballot ranking"}
 

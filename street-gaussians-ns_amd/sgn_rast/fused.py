@@ -152,6 +152,7 @@ class _ProjectFused(Function):
         ctx.consts = (float(glob_scale), float(fx), float(fy))
         ctx.sem, ctx.img_hw = sem, (int(img_height), int(img_width))     # the backward runs with the call's semantics
         ctx.has_obj = oid is not None
+        ctx.arena_leaves = _ops._arena_leaves(means, log_scales, quats_raw)
         saved = [means_c, ls_c, q_c, vm, cov3d, radii, conics, comp]
         if ctx.has_obj:
             saved += [oid, pos]
@@ -172,7 +173,9 @@ class _ProjectFused(Function):
         v_depths = _f32c(v_depths) if v_depths is not None else None      # NULL = zeros inside the kernel
         v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros(n, 3, **f32)
         v_comp = _f32c(v_comp) if v_comp is not None else None
-        v_m, v_s, v_q = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32)
+        al = getattr(ctx, "arena_leaves", None)       # (the DP bucket's slices, ops._grad_arena)
+        v_m, v_s, v_q = (_ops._leaf_grad(al, 0, (n, 3), f32), _ops._leaf_grad(al, 1, (n, 3), f32),
+                         _ops._leaf_grad(al, 2, (n, 4), f32))
         L.check(L.load().sgn_project_bwd_fused(
             n, L.ptr(means), L.ptr(ls), gs, L.ptr(q), L.ptr(oid), L.ptr(pos), L.ptr(vm), fx, fy, L.ptr(cov3d),
             L.ptr(radii), L.ptr(conics), L.ptr(comp), L.ptr(v_xys), L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comp),
@@ -228,6 +231,7 @@ class _SHFused(Function):
                                           L.stream_ptr()), "sgn_sh_fwd_fused")
         ctx.meta = (int(degree), k, F, int(bool(post)), features_rest is not None)
         ctx.has_obj, ctx.has_pose = oid is not None, pos is not None
+        ctx.arena_leaves = _ops._arena_leaves(features_dc)
         saved = [means_c, cam_c, idft_c, colors]
         if ctx.has_obj:
             saved.append(oid)
@@ -250,7 +254,7 @@ class _SHFused(Function):
                 v_eff = v_eff * (colors > 0)
             if _sh_exchange.tap_fused(means, cam, v_eff, degree, k, ctx.claimed):
                 return (None,) * 10      # the data-parallel exchange rebuilds the (summed) gradient itself
-        v_dc = torch.empty(n, F, 3, dtype=torch.float32, device=dev)
+        v_dc = _ops._leaf_grad(getattr(ctx, "arena_leaves", None), 0, (n, F, 3), dict(dtype=torch.float32, device=dev))
         v_rest = torch.empty(n, k - 1, 3, dtype=torch.float32, device=dev) if has_rest else None
         L.check(L.load().sgn_sh_bwd_fused(n, k, degree, L.ptr(means), L.ptr(cam), F, L.ptr(oid), L.ptr(idft), L.ptr(pos), post,
                                           L.ptr(colors), L.ptr(_f32c(v_colors)), L.ptr(v_dc), L.ptr(v_rest),
@@ -396,4 +400,5 @@ def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors,
     return _RasterizeGaussians.apply(*args, return_alpha, True, id_range, bool(depth_channel))
 
 
-group_accumulation_enabled = os.environ.get("SGN_GROUP_ACC", "1") != "0"   # A/B: "0" = the three separate passes
+from . import config as _config
+group_accumulation_enabled = bool(_config.value("group_accumulations"))   # False = the three separate passes

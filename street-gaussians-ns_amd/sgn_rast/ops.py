@@ -27,6 +27,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
+from . import config
 from . import proofs
 
 # ------------------------------------------------------------- upstream-variant semantics (round 6)
@@ -298,8 +299,8 @@ class _SphericalHarmonics(Function):
 # (proofs.sh_source; no hook on the concatenation, nobody retaining its gradient) the SH node takes the LEAVES as its
 # autograd inputs and its backward writes their gradients directly: one kernel for band 0 / the rest, one more for all
 # Fourier fan-outs; same values, no dense tensor, no copies.  Anything else takes the dense path.
-# `SGN_SH_SPLIT_BWD=0` switches it off.
-sh_split_backward = os.environ.get("SGN_SH_SPLIT_BWD", "1") != "0"
+# Option `graph_proofs` (sgn_rast/config.py) switches it off.
+sh_split_backward = bool(config.value("graph_proofs"))
 sh_split_stats = {"split": 0, "dense": 0}
 _sh_memo = None        # (weakref to the last proven coefficient tensor, its ShSource)
 
@@ -336,7 +337,9 @@ class _SphericalHarmonicsSplit(Function):
         v_colors = _f32c(v_colors)
         f32 = dict(dtype=torch.float32, device=v_colors.device)
         lib = L.load()
-        v_dc, v_rest = torch.empty(n, 1, 3, **f32), torch.empty(n, ctx.k - 1, 3, **f32)
+        one_dc = src.dc[0].leaf if (len(src.dc) == 1 and src.dc[0].weights is None) else None
+        v_dc = _leaf_grad(_arena_leaves(one_dc), 0, (n, 1, 3), f32)        # (a DP bucket member: produced in its slice)
+        v_rest = torch.empty(n, ctx.k - 1, 3, **f32)
         L.check(lib.sgn_sh_bwd_multi(n, ctx.k, ctx.degrees_to_use, 1, L.ptr(viewdirs), None, None, None, None,
                                      L.ptr(v_colors), 1.0, L.ptr(v_rest), L.ptr(v_dc), L.stream_ptr()),
                 "sgn_sh_bwd_multi")
@@ -401,6 +404,7 @@ class _ProjectGaussians(Function):
         outs, saved = _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
                                        img_width, block_width, clip_thresh)
         ctx.save_for_backward(*saved)
+        ctx.arena_leaves = _arena_leaves(means3d, scales, quats)
         return outs
 
     @staticmethod
@@ -412,9 +416,10 @@ class _ProjectGaussians(Function):
         v_depths = _f32c(v_depths) if v_depths is not None else None      # NULL = zeros inside the kernel
         v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros(n, 3, **f32)
         v_comp = _f32c(v_compensation) if v_compensation is not None else None
-        v_mean = torch.empty(n, 3, **f32)
-        v_scale = torch.empty(n, 3, **f32)
-        v_quat = torch.empty(n, 4, **f32)
+        al = getattr(ctx, "arena_leaves", None)
+        v_mean = _leaf_grad(al, 0, (n, 3), f32)
+        v_scale = _leaf_grad(al, 1, (n, 3), f32)
+        v_quat = _leaf_grad(al, 2, (n, 4), f32)
         want_viewmat = bool(ctx.needs_input_grad[4])
         v_cov2d = torch.empty(n, 3, **f32) if want_viewmat else None
         L.check(L.load().sgn_project_bwd(
@@ -474,8 +479,8 @@ def _viewmat_grad(means3d, viewmat12, fx, fy, cov3d, radii, v_mean, v_cov2d, sha
 # its autograd inputs and its backward returns their gradients from one kernel (sgn_project_bwd_act: exp and
 # normalisation differentiated inside, from the caller's activated scales and from X — nothing is recomputed from the
 # leaves' current values).  The forward still runs on the caller's activated values, bit for bit; gradients agree with
-# the chain through torch to fp32 rounding.  `SGN_ACT_PROOFS=0` switches it off.
-activation_proofs = os.environ.get("SGN_ACT_PROOFS", "1") != "0"
+# the chain through torch to fp32 rounding.  Option `graph_proofs` (sgn_rast/config.py) switches it off.
+activation_proofs = bool(config.value("graph_proofs"))
 activation_proof_stats = {"project": 0, "opacity": 0, "colors": 0, "window": 0}
 
 
@@ -569,6 +574,7 @@ class _ProjectGaussiansAct(Function):
                                        img_width, block_width, clip_thresh)
         means3d_c, scales_c, _q, viewmat_c, cov3d, radii, conics, compensation = saved
         ctx.leaf_rows = [v.shape[0] for v in log_scale_leaves]
+        ctx.arena_leaves = _arena_leaves(means3d, log_scale_leaves[0] if len(log_scale_leaves) == 1 else None, x)
         ctx.save_for_backward(means3d_c, scales_c, x, viewmat_c, cov3d, radii, conics, compensation)
         return outs
 
@@ -581,7 +587,8 @@ class _ProjectGaussiansAct(Function):
         v_depths = _f32c(v_depths) if v_depths is not None else None
         v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros(n, 3, **f32)
         v_comp = _f32c(v_compensation) if v_compensation is not None else None
-        v_mean, v_ls, v_x = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32)
+        al = getattr(ctx, "arena_leaves", None)
+        v_mean, v_ls, v_x = _leaf_grad(al, 0, (n, 3), f32), _leaf_grad(al, 1, (n, 3), f32), _leaf_grad(al, 2, (n, 4), f32)
         L.check(L.load().sgn_project_bwd_act(
             n, L.ptr(means3d), L.ptr(scales), ctx.glob_scale, L.ptr(x), L.ptr(viewmat),
             ctx.fx, ctx.fy, L.ptr(cov3d), L.ptr(radii), L.ptr(conics), L.ptr(compensation), L.ptr(v_xys),
@@ -595,10 +602,10 @@ class _ProjectGaussiansAct(Function):
 # host sync that drains the queue in the middle of the forward pass.  "eager" (DEFAULT: a drop-in replacement raises
 # where upstream raises — from the same project_gaussians call) runs the same one-sided test as ONE device pass
 # (sgn_check_unit_quats), queues the projection behind it and only then waits for the flag, so the GPU projects while
-# the host wakes up.  "deferred" is an opt-in (SGN_QUAT_CHECK=deferred, or `ops.quat_check = "deferred"` as bench.py
+# the host wakes up.  "deferred" is an opt-in (SGN_OPTIONS="quat_check=deferred", or `ops.quat_check = "deferred"` as bench.py
 # does): the flag is read at the NEXT host sync the path has anyway (the intersection-count read-back inside
 # rasterize_gaussians), raising the same AssertionError there — no sync of its own; "off" skips the test.
-quat_check = os.environ.get("SGN_QUAT_CHECK", "eager")
+quat_check = config.value("quat_check")        # (sgn_rast/config.py; SGN_OPTIONS="quat_check=deferred")
 
 
 def _check_quats(quats: torch.Tensor):
@@ -653,11 +660,11 @@ def raise_pending_checks() -> None:
 # check), and the coming `rasterize_gaussians` on these very depths / radii picks it up (sgn_bin_prepare(rank_ready)).
 # Same kernels, same results, started earlier.  Speculative: a projection that no rasterize call follows wastes the
 # ranking; after three such misses in a row the speculation pauses for 200 calls.
-early_rank = os.environ.get("SGN_EARLY_RANK", "auto")      # "auto": with the eager check; "on"; "off"
+early_rank = config.value("early_rank")                  # "auto": with the eager check; "on"; "off"
 # "main": behind the projection on the caller's stream.  "aux": on the library's second stream, forked behind the
 # projection and joined by the rasterize call — a host sync of the CALLER's stream right after the projection (the
 # reference's `radii.sum() == 0`, sgn_splatfacto.py:878) then returns while the ranking still runs
-early_rank_stream = os.environ.get("SGN_EARLY_RANK_STREAM", "main")
+early_rank_stream = "main"      # ("aux" is kept for the record: -2 % on the default step, +1 % with the caller's syncs)
 early_rank_stats = {"started": 0, "used": 0}
 
 
@@ -837,7 +844,7 @@ def bin_and_sort_gaussians(num_points, num_intersects, xys, depths, radii, cum_t
     return isect_ids, gaussian_ids, isect_ids_sorted, gaussian_ids_sorted, tile_bins
 
 
-tile_culling_enabled = True   # exact alpha-cutoff tile culling inside rasterize_gaussians (results unchanged)
+tile_culling_enabled = bool(config.value("tile_culling"))   # exact alpha-cutoff tile culling inside rasterize_gaussians (results unchanged)
 # Quadrant masks (r03): with the culling on (16x16 tiles) the emission also decides, per (tile, Gaussian) pair, which of
 # the tile's four 8x8 quadrants the Gaussian can reach and hands the four bits to the raster kernels in the top of the
 # id word (include/sgn_rast.h: sgn_bin_intersect(quadrant_masks)); results unchanged (tests/test_gpu_quadrant_masks.py).
@@ -847,7 +854,7 @@ tile_culling_enabled = True   # exact alpha-cutoff tile culling inside rasterize
 # where they do not (street-like and translucent content: 90-100 % walked) a gain of 2-3 %.  So "auto" (default) turns
 # them on when the last backward's tile order reported that at least QMASK_MIN_WALKED_PERMILLE of the listed entries
 # were walked (sgn_tile_order's statistic, read back with the next binning's count); "on" / "off" force it.
-quadrant_masks = os.environ.get("SGN_QUAD_MASKS", "auto")
+quadrant_masks = config.value("quadrant_masks")
 QMASK_MIN_WALKED_PERMILLE = 200       # break-even measured at ~150 (31 us / 8.3 M listed vs 20.5 us / 0.84 M walked)
 QMASK_ID_BITS = 28
 quadrant_mask_stats = {"binnings_with_masks": 0, "walked_permille": None}
@@ -941,7 +948,7 @@ def _bin_prepare_async(num_points, xys, depths, radii, num_tiles_hit, tile_bound
     return st
 
 
-speculative_binning = os.environ.get("SGN_SPECULATIVE_BINNING", "1") != "0"   # queue emission + tile sort behind
+speculative_binning = bool(config.value("speculative_binning"))               # queue emission + tile sort behind
                                # the count copy, sized from the previous call
 _SPEC_MARGIN = 1.3             # capacity = recent peak count of the same (n, tile grid) x this
 
@@ -1010,10 +1017,10 @@ def _bin_finish(st):
 binning_stats = {"speculative_hits": 0, "speculative_misses": 0, "binnings": 0}
 
 
-tile_order_enabled = True
-tile_order_multiblock = os.environ.get("SGN_TILE_ORDER_MB", "1") != "0"   # the multi-workgroup form of sgn_tile_order
+tile_order_enabled = bool(config.value("tile_order"))
+tile_order_multiblock = True           # the multi-workgroup form of sgn_tile_order (the single-workgroup one serves callers without scratch)
 # lend sgn_raster_bwd a second stream: its short-walk and long-walk kernels overlap ("0": one stream, long walks first)
-concurrent_backward = os.environ.get("SGN_BWD_CONCURRENT", "1") != "0"
+concurrent_backward = bool(config.value("concurrent_backward"))
 small_splat_q16 = 0       # experimental: > 0 sends tiles with < q/16 evaluated (entry, quadrant) pairs per walked entry to the 4-waves kernel (no gain measured: profiles/r02_street_balance.md)
 
 
@@ -1064,7 +1071,7 @@ def _tile_order(tile_bins: torch.Tensor, tile_kmax: Optional[torch.Tensor] = Non
 # The cache keeps detached aliases of the four geometry tensors, so their storage cannot be freed
 # and re-used by the allocator while the entry is alive: equal data_ptr + equal version counter then
 # really means "same bytes".
-binning_cache_enabled = True
+binning_cache_enabled = bool(config.value("binning_cache"))
 
 
 def _bin_key(tensors, tile_bounds, block_width, flags):
@@ -1153,7 +1160,7 @@ def _bin_gaussians_cached(num_points, xys, depths, radii, num_tiles_hit, tile_bo
 # the cached scene is compared against those two windows on the device (sgn_rows_match: one pass over the window,
 # a few MB) and, on a match, rasterized over the CACHED list with an id range: no ranking, no emission, no sort.
 # One host read-back of the verdict replaces the intersection-count read-back of the re-binning it avoids.
-window_matching_enabled = True
+window_matching_enabled = bool(config.value("window_matching"))
 window_stats = {"tried": 0, "hit": 0}
 
 
@@ -1264,7 +1271,7 @@ def _match_window(key_tail, n, xys, depths, radii, num_tiles_hit, conics, opacit
 # shared list with everything else made inert — nothing saturates then, every tile walks its whole list, 0.5 ms per step
 # at 1 M Gaussians for a pass that draws 100 k — but its own sub-list (sgn_list_window: two reads of the list, no sort,
 # same relative order, hence the same image and gradients).  Larger windows (the background: 90 %) keep the shared list.
-list_window_enabled = os.environ.get("SGN_LIST_WINDOW", "1") != "0"
+list_window_enabled = bool(config.value("list_window"))
 list_window_max_frac = 0.5
 window_stats["sub_lists"] = 0
 
@@ -1290,7 +1297,7 @@ def _list_window(ids: torch.Tensor, tile_bins: torch.Tensor, lo: int, hi: int, q
 # "auto" (default): the first pass starts accumulating once a step has been seen to make that second call (a rasterize
 # call on the very tensors of the previous one with other colours), and stops again when the calls stop coming;
 # "on" / "off" force it.  The fused API asks for the channel explicitly (rasterize_gaussians_fused(depth_channel=True)).
-depth_channel = os.environ.get("SGN_DEPTH_CHANNEL", "auto")
+depth_channel = config.value("depth_channel")
 depth_stats = {"accumulated": 0, "reused": 0, "proved_on_host": 0}
 group_stats = {"passes": 0, "backward_passes": 0}    # forwards that carried the two group accumulations; their backwards
 
@@ -1305,6 +1312,33 @@ _provably_depths = proofs.repeated_depths     # host-side proof that colours are
 # Optional hook for data-parallel training (sgn_rast.dp.GradAllReducer(sparse=True)): `after_forward(ids, bins, kmax, n,
 # qmask)` is told, right after a full (non-window) forward pass, which list entries the pass walked.  None normally.
 _touch_sink = None
+# hook for sgn_rast.dp.GradAllReducer's zero-copy bucket (round 6): `_grad_arena(leaf)` -> the slice of the reducer's flat
+# all-reduce buffer this step's gradient of `leaf` belongs in, or None.  A backward node that produces the gradient of an
+# input that IS a registered leaf writes it there instead of into a torch.empty tensor; autograd keeps the returned view as
+# `.grad` (contiguous, nobody else holds it), so the collective needs no copy in and none back.
+_grad_arena = None
+
+
+def _arena_leaves(*inputs):
+    """forward-time: the inputs of a node that are leaves wanting a gradient (what `_leaf_grad` may look up), or None."""
+    if _grad_arena is None:
+        return None
+    return tuple(t if (t is not None and t.is_leaf and t.requires_grad) else None for t in inputs)
+
+
+def _leaf_grad(leaves, i: int, shape, f32):
+    """Gradient buffer of a node's i-th candidate input: its slice of the DP bucket if it is a registered leaf, else a
+    fresh tensor.  The view handed back is a NEW tensor object (AccumulateGrad steals a gradient only when it holds the
+    last reference)."""
+    if leaves is not None and _grad_arena is not None and leaves[i] is not None:
+        sl = _grad_arena(leaves[i])
+        if sl is not None:
+            n = 1
+            for d in shape:
+                n *= int(d)
+            if sl.numel() == n and sl.is_contiguous():
+                return sl.view(*shape)
+    return torch.empty(*shape, **f32)
 # grad mode where the operator was CALLED (inside Function.forward it always reads "off", and ctx.needs_input_grad ignores
 # it): the rasterize wrappers note it just before `apply` (same thread: `apply` runs the forward synchronously)
 _call_state = threading.local()
@@ -1316,8 +1350,8 @@ _call_state = threading.local()
 # allocations driven from here.  It serves the plain case (the full scene, a fresh binning, no depth channel / reuse /
 # window / groups, a capacity known from earlier calls of the same shape); everything else, and a capacity miss, takes the
 # call-by-call path below, which stays the reference for behaviour.  Same kernels, same order, same results.
-# `SGN_COMPOSITE=0` switches it off.
-composite_forward = os.environ.get("SGN_COMPOSITE", "1") != "0"
+# Option `one_call_nodes` (sgn_rast/config.py) switches it off.
+composite_forward = bool(config.value("one_call_nodes"))
 composite_backward = composite_forward      # the node's backward as one call too (sgn_rasterize_bwd_all, round 6)
 composite_stats = {"forwards": 0, "capacity_misses": 0, "windows": 0, "backwards": 0}
 _E_CAPACITY = -100
@@ -1527,6 +1561,8 @@ class _RasterizeGaussians(Function):
         # gradients go to the extra inputs instead (the activations' backward runs inside sgn_raster_bwd's unpack kernel)
         ctx.grad_to_logits, ctx.grad_to_pre = len(opacity_logits) > 0, colors_pre is not None
         ctx.logit_rows = [v.shape[0] for v in opacity_logits]
+        ctx.arena_leaves = _arena_leaves(opacity_logits[0] if len(opacity_logits) == 1 else
+                                         (opacity if not opacity_logits else None))
         ctx.alpha_clamp_bwd = semantics().alpha_clamp_bwd      # the backward runs with the CALL's value
         ctx.set_materialize_grads(False)       # an unused alpha / depth output arrives as None, not as a zero image
         dev = L.require_device(xys, depths, radii, conics, num_tiles_hit, colors, opacity, background)
@@ -1817,7 +1853,8 @@ class _RasterizeGaussians(Function):
             # out = (v_xy, v_conic, v_colors, v_opacity, workspace) shared by the sequence, part = (first, last)
             lib = L.load()
             if out is None:
-                out = (torch.empty(n, 2, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, **f32),
+                out = (torch.empty(n, 2, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32),
+                       _leaf_grad(getattr(ctx, "arena_leaves", None), 0, (n,), f32),
                        L.workspace(lib.sgn_raster_bwd_workspace_bytes(ctx.n_full), dev))
             v_xy, v_conic, v_colors, v_opacity, gws = out
             ro_ptr = C.byref(ctx.ro)

@@ -315,7 +315,8 @@ def composite_sky(out: SimpleNamespace, cam: Camera, sky_base: torch.Tensor, c2w
 def train_step(P: Dict[str, torch.Tensor], cam: Camera, w_img: torch.Tensor, w_a: torch.Tensor,
                sh_degree_to_use: int = 3, block_width: int = 16, with_depth: bool = False, ops=_hip_ops,
                reducer=None, fused: bool = False, sky: Optional[dict] = None, gt: Optional[torch.Tensor] = None,
-               ssim_lambda: float = 0.2, loss_fn=None, caller_syncs: bool = False, **fused_kw) -> SimpleNamespace:
+               ssim_lambda: float = 0.2, loss_fn=None, caller_syncs: bool = False, zero_grad: bool = True,
+               **fused_kw) -> SimpleNamespace:
     """One "train-step image": project fwd -> SH fwd -> rasterize(return_alpha) fwd -> scalar loss ->
     full backward to means / log-scales / raw quats / opacity logits / SH coefficients (the metric's definition,
     SURVEY.md §8d: the operator sequence; ``caller_syncs=True`` adds the two host syncs of the reference's own model
@@ -323,10 +324,11 @@ def train_step(P: Dict[str, torch.Tensor], cam: Camera, w_img: torch.Tensor, w_a
     {"base": cube map leaf [6,R,R,3], "c2w": [3,4]} adds the reference's sky-sphere branch.  ``gt`` [H,W,3] swaps the
     synthetic linear image loss for the reference's photometric loss (``sgn_splatfacto.py:1084-1087``: (1-l) L1 + l
     (1 - SSIM) on ``rgb.clamp(max=1)``), through ``sgn_rast.loss`` or the ``loss_fn(rgb, gt, l)`` the tests pass."""
-    for p in P.values():
-        p.grad = None
-    if sky is not None:
-        sky["base"].grad = None
+    if zero_grad:                  # (False: the caller's loop owns the gradients — keeps and accumulates them, or resets them)
+        for p in P.values():
+            p.grad = None
+        if sky is not None:
+            sky["base"].grad = None
     if fused:
         out = render_fused(P, cam, sh_degree_to_use, block_width, with_depth=with_depth, **fused_kw)
     else:

@@ -354,3 +354,88 @@ def test_replicas_stay_bit_identical_through_densification(tmp_path):
         for kk in ("exp_avg", "exp_avg_sq"):
             assert torch.equal(s0[k][kk], s1[k][kk]), (k, kk)
             assert s0[k][kk].shape == p0[k].shape
+
+
+def _arena_worker(rank, world, port, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "street-gaussians-ns_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from sgn_rast import dp, ops
+    torch.set_num_threads(1)
+    dp.init_from_env(backend="gloo")
+
+    class Node(torch.autograd.Function):          # an operator node that produces its leaf's gradient as ops' nodes do
+        @staticmethod
+        def forward(ctx, x, c):
+            ctx.arena_leaves, ctx.c = ops._arena_leaves(x), c
+            return x * c
+
+        @staticmethod
+        def backward(ctx, g):
+            v = ops._leaf_grad(ctx.arena_leaves, 0, tuple(g.shape), dict(dtype=torch.float32, device=g.device))
+            v.copy_(g * ctx.c)
+            return v, None
+
+    torch.manual_seed(3)
+    a, b, c = (torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(7, 4)),
+               torch.nn.Parameter(torch.randn(7, 1)))
+    out = {}
+    for overlap in (False, True):
+        red = dp.GradAllReducer([a, b, c], average=True, overlap=overlap)
+        assert ops._grad_arena == red.arena_for
+        steps = []
+        for it in range(3):
+            if it != 2:                            # step 2 keeps the gradients of step 1: the node must not write over them
+                a.grad = b.grad = c.grad = None
+            k = float(rank + 1 + it)
+            # a: through the node twice (second path is ADDED by autograd); b: through the node; c: torch's own backward
+            loss = (Node.apply(a, k).sum() + Node.apply(a, 2.0).sum() * 0.5 + (Node.apply(b, k) ** 2).sum() + (c * k).sum())
+            loss.backward()
+            red.finish()
+            steps.append([p.grad.clone() for p in (a, b, c)])
+            for p in (a, b, c):
+                assert p.grad.untyped_storage().data_ptr() == red._flat.untyped_storage().data_ptr()
+        # steps 0, 1: b produced in place; c copied in; a copied in too — autograd sums the two paths into a tensor of its
+        # own before AccumulateGrad sees them (its in-place add needs sole ownership of the STORAGE, which a slice of the
+        # flat buffer never has); step 2: everything accumulates into the slices it already holds
+        assert red.stats["bucket_copies"] == 4 and red.stats["bucket_in_place"] == 5, red.stats
+        red.remove()
+        assert ops._grad_arena is None
+        out[overlap] = steps
+    torch.save(out, os.path.join(outdir, f"arena{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_zero_copy_bucket_gradients_are_produced_in_the_flat_buffer(tmp_path):
+    """dp.GradAllReducer's bucket is one persistent flat buffer whose slices ARE the `.grad` tensors: a backward node asks
+    `ops._grad_arena` for its leaf's slice and writes there (no torch.cat in, no copy back); a second path into the same
+    leaf, a kept gradient and a gradient from torch's own backward all stay correct."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_arena_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=200)
+        assert p.exitcode == 0
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"arena{r}.pt")) for r in range(world))
+    torch.manual_seed(3)
+    a, b, c = torch.randn(7, 3), torch.randn(7, 4), torch.randn(7, 1)
+    for overlap in (False, True):
+        prev = None
+        for it in range(3):
+            ks = [float(r + 1 + it) for r in range(world)]
+            ga = sum(torch.full_like(a, k + 1.0) for k in ks) / world
+            gb = sum(2 * b * k * k for k in ks) / world
+            gc = sum(torch.full_like(c, k) for k in ks) / world
+            exp = [ga, gb, gc]
+            if it == 2:       # kept: every rank adds its new gradient to the REDUCED old one, and the sum is averaged again
+                exp = [p + e for p, e in zip(prev, exp)]
+            for got0, got1, e in zip(r0[overlap][it], r1[overlap][it], exp):
+                assert torch.equal(got0, got1)
+                assert torch.allclose(got0, e, rtol=1e-6, atol=1e-6)
+            prev = exp

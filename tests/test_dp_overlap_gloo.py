@@ -213,3 +213,71 @@ def test_a_collective_nobody_joins_times_out_instead_of_hanging(tmp_path):
     v = open(os.path.join(tmp_path, "timeout0.txt")).read()
     assert v.startswith("raised after"), v
     assert float(v.split()[2][:-2]) < 10.0, v
+
+
+def _big_worker(rank, world, port, outdir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "street-gaussians-ns_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from sgn_rast import dp
+    torch.set_num_threads(1)
+    dp.init_from_env(backend="gloo", timeout_s=60)
+    results = {}
+    for overlap in (False, True):
+        g = torch.Generator().manual_seed(11)
+        means, rest_a, rest_b, sky = (torch.randn(*sh, generator=g).requires_grad_(True)
+                                      for sh in ((50, 3), (50, 15, 3), (20, 15, 3), (6, 4, 4, 3)))
+        params = [means, rest_a, rest_b, sky]
+        red = dp.GradAllReducer(params, big=[rest_a, rest_b, sky], overlap=overlap)
+        w = float(rank + 1)
+        for step_i in range(3):
+            for p in params:
+                p.grad = None
+            # step 0: every big gets a gradient; `sky` is used LAST in the forward, so its gradient arrives FIRST: it must
+            # wait for rest_a and rest_b (sequence = params order).  step 1: rank 1 never touches rest_b -> its hook never
+            # fires there: rest_b, sky and the bucket leave from finish() on rank 1, early on rank 0 — same sequence.
+            # step 2: rest_b is absent on every rank.
+            loss = (means * w).sum() + (rest_a ** 2).sum() * w
+            if step_i == 0 or (step_i == 1 and rank == 0):
+                loss = loss + (rest_b * 3.0).sum() * w
+            loss = loss + (sky * w).sum()
+            loss.backward()
+            if overlap and step_i == 0:
+                assert len(red._big_pending) == 3 and red._bucket is not None
+            if overlap and step_i == 1:
+                assert len(red._big_pending) == (3 if rank == 0 else 1) and (red._bucket is not None) == (rank == 0)
+            if overlap and step_i == 2:
+                assert len(red._big_pending) == 1 and red._bucket is None
+            red.finish(absent=[rest_b] if step_i == 2 else ())
+            results[(overlap, step_i)] = [None if p.grad is None else p.grad.clone() for p in params]
+        results[("stats", overlap)] = dict(red.stats)
+        red.remove()
+    torch.save(results, os.path.join(outdir, f"big{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_big_all_reduces_leave_from_the_backward_in_sequence_order(tmp_path):
+    """Round 6: a `big` parameter's all-reduce leaves from its post-accumulate hook as soon as every big before it (params
+    order) has left; a rank whose hook never fires sends the same sequence from finish(); an absent big is skipped by all."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_big_worker, args=(r, world, port, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=200)
+        assert p.exitcode == 0
+    r0, r1 = (torch.load(os.path.join(tmp_path, f"big{r}.pt")) for r in range(world))
+    for step_i in range(3):
+        for a, b, c in zip(r0[(False, step_i)], r0[(True, step_i)], r1[(True, step_i)]):
+            if a is None:
+                assert b is None and c is None and step_i == 2
+            else:
+                assert torch.equal(a, b) and torch.equal(b, c)
+    assert (r0[("stats", True)]["big_early"], r0[("stats", True)]["big_late"]) == (3 + 3 + 1, 0 + 0 + 1)
+    assert (r1[("stats", True)]["big_early"], r1[("stats", True)]["big_late"]) == (3 + 1 + 1, 0 + 2 + 1)
+    assert (r0[("stats", False)]["big_early"], r0[("stats", False)]["big_late"]) == (0, 8)

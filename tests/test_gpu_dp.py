@@ -66,6 +66,10 @@ def test_exchange_and_reducer_over_single_rank_rccl_group(fused):
             ex.remove()
             red.remove()
         torch.cuda.synchronize()
+        # zero-copy bucket (round 6): the four small gradients were PRODUCED inside the flat buffer by the backward nodes
+        assert red.stats["bucket_in_place"] == 4 and red.stats["bucket_copies"] == 0, red.stats
+        for k in ("means", "log_scales", "quats", "opacity_logits"):
+            assert Pb[k].grad.untyped_storage().data_ptr() == red._flat.untyped_storage().data_ptr(), k
         for k in Pa:
             scale = 1.0 if k in ("features_dc", "features_rest") else 0.5   # exchange averages over world=1
             assert rel_l2(Pb[k].grad, scale * Pa[k].grad) < 1e-5, k
@@ -77,8 +81,59 @@ def test_exchange_and_reducer_over_single_rank_rccl_group(fused):
         red.remove()
         torch.cuda.synchronize()
         assert red.stats["bucket_early"] == 1
+        assert red.stats["bucket_in_place"] == 5 and red.stats["bucket_copies"] == 0, red.stats   # (+ features_dc)
         for k in Pa:
             assert rel_l2(Pc[k].grad, Pa[k].grad) < 1e-5, k
+    finally:
+        dist.destroy_process_group()
+
+
+def test_zero_copy_bucket_over_the_ways_a_loop_resets_gradients():
+    """The flat bucket's slices ARE the `.grad` tensors (dp.GradAllReducer.arena_for).  Three loops: `.grad = None` every step
+    (the reference's, set_to_none=True) — produced in place every step; gradients KEPT and accumulated over two steps (no
+    reset) — the second backward must ADD to the reduced first, never write over it; and a model whose activations are
+    NOT proven (graph_proofs off: the gradients come out of torch's own exp / normalise / sigmoid backward) — one copy
+    in, none back.  Each against the same steps without a reducer."""
+    import torch.distributed as dist
+    from sgn_rast import config, dp, scenes, step
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        cam, raw = scenes.make_scene("c1", n_override=5000)
+        cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+        w1, a1 = step.loss_weights(cam, seed=7, device=DEV)
+        w2, a2 = step.loss_weights(cam, seed=8, device=DEV)
+        small = ("means", "log_scales", "quats", "opacity_logits")
+
+        def run(reducer_kw, keep, proofs=True):
+            P = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+            red = dp.GradAllReducer(list(P.values()), big=[P["features_rest"]], **reducer_kw) if reducer_kw is not None else None
+            got = []
+            try:
+                with config.override(graph_proofs=proofs):
+                    for w, a in ((w1, a1), (w2, a2)):
+                        if not keep:
+                            for v in P.values():
+                                v.grad = None
+                        step.train_step(P, cam, w, a, reducer=red, zero_grad=False)
+                        got.append({k: P[k].grad.clone() for k in P})
+            finally:
+                if red is not None:
+                    red.remove()
+            return got, (red.stats if red is not None else None)
+
+        for keep, proofs in ((False, True), (True, True), (False, False)):
+            ref, _ = run(None, keep, proofs)
+            for kw in (dict(force=True), dict(force=True, overlap=True)):
+                got, stats = run(kw, keep, proofs)
+                for s_ref, s_got in zip(ref, got):
+                    for k in s_ref:
+                        assert rel_l2(s_got[k], s_ref[k]) < 1e-5, (keep, proofs, kw, k)
+                # five bucket members (means, scales, quats, opacities, features_dc), two steps
+                if proofs:                   # (keep: step 2 accumulates INTO the slices autograd kept from step 1)
+                    assert stats["bucket_in_place"] == 10 and stats["bucket_copies"] == 0, stats
+                else:                        # means still comes straight from the projection node
+                    assert stats["bucket_copies"] > 0 and stats["bucket_in_place"] + stats["bucket_copies"] == 10, stats
     finally:
         dist.destroy_process_group()
 

@@ -18,12 +18,14 @@ def test_default_ranking_is_the_documented_one_and_the_probe_is_stateless():
     from sgn_rast import _lib as L
     lib = L.load()
     assert not hasattr(lib, "sgn_sort_set_rank_mode") and not hasattr(lib, "sgn_sort_rank_mode")
-    if os.environ.get("SGN_SORT_RANK", "ballot").lower() == "ballot":
+    from sgn_rast import config
+    want = config.value("sort_rank")
+    if want == "ballot":
         assert L.sort_rank_mode() == 0 and L.sort_ranking_report()["mode"] == "ballot"
     # the probe under load: >= 1000 sorts per ranking on two streams beside a GEMM chain; repeatable
     bad = L.sort_selftest_under_load(rounds=32)
     assert bad == L.sort_selftest_under_load(rounds=4) == 0, bad     # (gfx950 serves same-address lanes in lane order)
-    assert L.sort_rank_mode() == (1 if os.environ.get("SGN_SORT_RANK", "").lower().startswith("atomic") else 0)
+    assert L.sort_rank_mode() == (1 if want.startswith("atomic") else 0)
     with L.force_sort_rank("atomic"):
         assert L.sort_rank_mode() == 1 and L.sort_ranking_report()["mode"] == "atomic"
     # a too-small workspace is refused, not overrun

@@ -367,9 +367,6 @@ def test_graph_proofs_gate_on_the_torch_version(monkeypatch, caplog):
         assert not proofs.enabled() and not proofs.enabled()
     assert sum("not recognised" in r.message for r in caplog.records) == 1
     monkeypatch.setattr(proofs, "_enabled", None)
-    monkeypatch.setenv("SGN_GRAPH_PROOFS", "0")
-    assert not proofs.enabled()
-    monkeypatch.setattr(proofs, "_enabled", None)
 
 
 def test_row_exchange_counts_sub_model_passes_as_views():
@@ -411,18 +408,18 @@ def test_sort_ranking_policy_defaults_to_the_documented_form(monkeypatch):
     documented ISA semantics), the atomic form an opt-in that needs a GPU probe — without a GPU it stays 0 whatever the
     environment says; `force_sort_rank` overrides inside its block only."""
     from sgn_rast import _lib as L
+    from sgn_rast import config
     monkeypatch.setattr(L, "_SORT_RANK", {})
-    monkeypatch.delenv("SGN_SORT_RANK", raising=False)
+    monkeypatch.setattr(L, "_sort_rank_request", "ballot")
     assert L.sort_rank_mode() == 0 and L.sort_ranking_report()["mode"] == "ballot"
+    monkeypatch.setattr(L, "_sort_rank_request", None)
+    with config.override(sort_rank="atomic"):                  # (the one options object: sgn_rast/config.py)
+        if not torch.cuda.is_available():
+            assert L.sort_rank_mode() == 0             # no device to prove it on
+    with config.override(sort_rank="atomic-unchecked"):
+        assert L.sort_rank_mode() == 1 and "unchecked" in L.sort_ranking_report()["probe"]
     monkeypatch.setattr(L, "_SORT_RANK", {})
-    monkeypatch.setenv("SGN_SORT_RANK", "atomic")
-    if not torch.cuda.is_available():
-        assert L.sort_rank_mode() == 0                 # no device to prove it on
-    monkeypatch.setattr(L, "_SORT_RANK", {})
-    monkeypatch.setenv("SGN_SORT_RANK", "atomic-unchecked")
-    assert L.sort_rank_mode() == 1 and "unchecked" in L.sort_ranking_report()["probe"]
-    monkeypatch.setattr(L, "_SORT_RANK", {})
-    monkeypatch.delenv("SGN_SORT_RANK")
+    monkeypatch.setattr(L, "_sort_rank_request", "ballot")
     with L.force_sort_rank("atomic"):
         assert L.sort_rank_mode() == 1
         with L.force_sort_rank("ballot"):
@@ -481,3 +478,38 @@ def test_viewmat_gradient_assembly_from_the_backward_kernels_outputs(torch_oracl
         assert tuple(got.shape) == shape and got.dtype == torch.float32
         assert rel_l2(got[:3].double(), vm.grad) < 1e-5
         assert float(got[3:].abs().sum()) == 0.0
+
+
+def test_one_options_object_and_one_environment_variable():
+    """Round 6: every behaviour switch is a row of `sgn_rast.config.OPTIONS`, initialised from ONE
+    environment variable, `SGN_OPTIONS="name=value,..."`; unknown names / values raise; no other SGN_* variable
+    configures behaviour (three deployment variables of the launcher excepted, as the module says)."""
+    import os
+    import re
+    import subprocess
+    import sys
+    from sgn_rast import config
+    assert config._convert("quat_check", "Deferred") == "deferred" and config._convert("graph_proofs", "off") is False
+    assert config._convert("batch_fwd", "64") == 64 and config._convert("reduce_mode", "0") == 0
+    with pytest.raises(ValueError):
+        config._convert("quat_check", "sometimes")
+    with pytest.raises(ValueError):
+        config._convert("reduce_mode", "2")                # the MFMA reduction is gone
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "street-gaussians-ns_amd")
+    env = dict(os.environ, SGN_OPTIONS="quat_check=deferred, one_call_nodes=off,batch_fwd=64", PYTHONPATH=pkg)
+    out = subprocess.check_output([sys.executable, "-c",
+                                   "from sgn_rast import ops, config; print(ops.quat_check, ops.composite_forward, "
+                                   "ops.composite_backward, config.value('batch_fwd'), ops.depth_channel)"], env=env, text=True)
+    assert out.split() == ["deferred", "False", "False", "64", "auto"]
+    bad = subprocess.run([sys.executable, "-c", "import sgn_rast"], env=dict(env, SGN_OPTIONS="quat_chek=off"),
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and "unknown option" in bad.stderr
+    # no module of the package reads another SGN_* variable for behaviour
+    allowed = {"SGN_OPTIONS", "SGN_RAST_LIB", "SGN_DP_BACKEND", "SGN_DP_TIMEOUT_S"}
+    for fn in os.listdir(os.path.join(pkg, "sgn_rast")):
+        if fn.endswith(".py") and fn != "config.py":
+            txt = open(os.path.join(pkg, "sgn_rast", fn)).read()
+            for m in re.finditer(r"environ[^\n]*?[\"'](SGN_[A-Z0-9_]+)[\"']", txt):
+                assert m.group(1) in allowed, (fn, m.group(1))
+    for name, (default, allowed_v, targets, doc) in config.OPTIONS.items():
+        assert targets and doc and (allowed_v is int or default in allowed_v), name
