@@ -108,7 +108,7 @@ void sgn_raster_default_opts(sgn_raster_opts *out);
 #define SGN_T_SLOTS 17
 void sgn_timing_enable(int on); /* also clears recorded spans */
 int sgn_timing_get(int slot, int *count /*host*/, float *total_ms /*host*/);
-/* Host microseconds the CALLING THREAD has spent blocked in the event waits of the one-call entries (the quats check of
+/* Host microseconds the CALLING THREAD has spent blocked in the waits (polled words, events) of the one-call entries (the quats check of
  * sgn_project_fwd_all / sgn_project_check_wait, the count of sgn_rasterize_fwd_all, the verdict of
  * sgn_rasterize_window_all) since the last reset; *n_waits (may be NULL) = how many waits.  Always on (two clock reads
  * per wait, thread-local): tells a profile whether a composite call's host time is its launches or its wait. */
@@ -134,9 +134,11 @@ int sgn_check_unit_quats(int n, const float *quats, float tol, int32_t *flag, sg
  * STAMPS *flag_dev; the flag is copied to flag_pinned[0] behind the kernel), and — gid_by_rank != NULL — sgn_depth_rank
  * of the coming binning, all queued on `stream`; only then does the call wait for the flag and report *quats_bad_host
  * (1: some row failed; the host raises upstream's assertion).
- * flag_pinned: pinned host int32[2], or NULL (a pageable copy; check_quats = 1 only).  [0] = the stamp if a row failed,
+ * flag_pinned: pinned host int32[3], or NULL (a pageable copy; check_quats = 1 only).  [0] = the stamp if a row failed,
  * [1] = the stamp once the launch's stores have landed (round 6): the wait refuses to report "normalized" — error -8 —
- * if [1] never shows the stamp.
+ * if [1] never shows the stamp; [2] = the stamp once the projection kernel is COMPLETE, stored by a one-wave kernel
+ * queued behind it — the word the host POLLS instead of waiting for an event (no barrier packet on the stream) — or
+ * -stamp where the slot is not mapped and a copy command + event are the transport.
  * flag_stamp > 0: the value a failing row stores; the caller guarantees *flag_dev / the slot holds no value >= flag_stamp
  * when the kernel runs (a word zeroed once, a counter per call on it), and nothing is cleared per call.  flag_stamp <= 0:
  * the call clears the flag itself (one more launch) and stamps 1.  rank_ws: sgn_depth_rank_workspace_bytes(n).
@@ -145,7 +147,8 @@ int sgn_check_unit_quats(int n, const float *quats, float tol, int32_t *flag, sg
  * NULL).
  * check_quats = 2: everything is queued as above but the call does NOT wait (flag_pinned required, quats_bad_host unused):
  * the caller finishes its own host-side bookkeeping and then calls sgn_project_check_wait — same thread, same device —
- * which waits for the check's own event and reports the flag. */
+ * which polls flag_pinned[2] (or waits for the check's own event) and reports the flag; `stream`: the stream of the
+ * sgn_project_fwd_all call (drained once if the word has not arrived after 0.2 s: the cold path). */
 int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float glob_scale, const float *quats,
                         const float *viewmat12, float fx, float fy, float cx, float cy, int img_h, int img_w,
                         int block_width, float clip_thresh, float *cov3d, float *xys, float *depths, int32_t *radii,
@@ -154,7 +157,8 @@ int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float 
                         void *rank_ws, size_t rank_ws_bytes, int sort_rank_mode, int32_t *quats_bad_host,
                         int semantics, sgn_stream_t stream);
 
-int sgn_project_check_wait(const int32_t *flag_pinned, int32_t flag_stamp, int32_t *quats_bad_host /*host*/);
+int sgn_project_check_wait(const int32_t *flag_pinned, int32_t flag_stamp, int32_t *quats_bad_host /*host*/,
+                           sgn_stream_t stream);
 
 /* _C.project_gaussians_backward (_ProjectGaussians.backward).  v_compensation may be NULL
  * (treated as zeros: the reference discards compensation, sgn_splatfacto.py:860,947); v_depth may be NULL too
@@ -481,8 +485,9 @@ int sgn_raster_fwd_groups(int img_h, int img_w, int n, int64_t n_isect, const in
  * out_img / final_Ts / final_idx (tile_bins is zero-filled): the caller writes the background image.
  * gid_by_rank_ready: NULL, or sgn_depth_rank's result for these depths / radii (started earlier).  count_pinned: pinned
  * host int32 the count arrives in (NULL: a pageable copy) — written by the scan kernel itself where the word is mapped into
- * the device's address space (hipHostMalloc'd memory is: no copy command on the stream), copied otherwise.  extra_dev / extra_pinned: one more device int32 to bring
- * along in the same transfer (the host's walk statistic), or NULL.  order_scratch as in sgn_tile_order. */
+ * the device's address space (hipHostMalloc'd memory is: no copy command and — round 6 — no event on the stream; the
+ * host polls the word, poisoned with -1 before the launch), copied otherwise.  extra_dev / extra_pinned: one more
+ * device int32 to bring along (the host's walk statistic), or NULL: stored by the same thread ahead of the count.  order_scratch as in sgn_tile_order. */
 #define SGN_E_CAPACITY (-100)
 size_t sgn_rasterize_arena_bytes(int n, int64_t isect_capacity);
 int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const int32_t *radii, const float *conics,
@@ -502,7 +507,8 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
  * per-model slices of the main projection: the call's tensors (`*_w`, n_win rows) are then a row window of the scene
  * (n_full rows) the cached list (gaussian_ids_sorted [n_isect], tile_bins) was binned for.  The call queues the
  * comparison that proves it (sgn_rows_match over every tensor pair whose full-scene side is non-NULL, at the n_cand <= 4
- * candidate offsets cand_lo_host), reads its verdict back (verdict_pinned: pinned host int32[4] or NULL — this path's one
+ * candidate offsets cand_lo_host), reads its verdict back (verdict_pinned: pinned host int32[8] or NULL; [0, 4) the
+ * verdicts, [7] the word a one-wave kernel behind the comparison stores 1 into and the host polls — this path's one
  * host sync, in place of the intersection-count read-back of the binning it saves), and on a match queues the window's
  * rows (sgn_raster_build_rows, window form), — sub_list != 0 — its compacted sub-list (sgn_list_window into ids_out
  * [n_isect] / tile_bins_out), the launch order (tile_order [tiles + 2] out, unless tile_order_ready hands in the shared

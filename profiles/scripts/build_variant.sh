@@ -8,11 +8,12 @@
 # The variants are git-ignored (*.so) but travel to the GPU box with gpurun.
 set -e
 tu=$1; name=$2; shift 2
+src=$tu.hip; [ "$tu" = api ] && src=api.cpp
 cd "$(dirname "$0")/../../street-gaussians-ns_amd/csrc"
 make -j8 > /dev/null
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -munsafe-fp-atomics -Wall -Wno-unused-function -I../../include -I."
 [ "$tu" = raster ] && FL="$FL -fno-slp-vectorize"
-/opt/rocm/bin/hipcc $FL "$@" -c $tu.hip -o /tmp/${tu}_$name.o
+/opt/rocm/bin/hipcc $FL "$@" -c $src -o /tmp/${tu}_$name.o
 objs=""
 for o in project sh binning radix_sort raster cubemap loss optim quat exchange api; do
   if [ $o = $tu ]; then objs="$objs /tmp/${tu}_$name.o"; else objs="$objs $o.o"; fi

@@ -66,6 +66,40 @@ inline hipError_t timed_event_sync(hipEvent_t ev) {
     ++g_wait_n;
     return e;
 }
+// Round 6: a word of MAPPED pinned memory that a kernel stores its result into is POLLED by the host instead of being
+// waited for through an event: an event record is a barrier packet on the stream (a ~6 us bubble on the device timeline,
+// profiles/r05q_timeline_eager.md) and a host call, and its completion reaches the host later than the store itself.
+// `ready()` is evaluated on volatile reads; after SPIN_FALLBACK_US without the word the stream is drained once (the cold
+// path: a fault on the device, a platform where mapped writes are not visible before completion) and the caller checks
+// again.  Time spent here counts as blocked time (sgn_timing_host_wait_us), like the event waits.
+constexpr double SPIN_FALLBACK_US = 2.0e5;
+#ifdef SGN_AB_EVENT_WAITS            // A/B builds only (profiles/scripts/build_variant.sh api eventwaits -DSGN_AB_EVENT_WAITS)
+constexpr bool POLL_WAITS = false;   // round 5's form: an event behind the producing kernel, hipEventSynchronize
+#else
+constexpr bool POLL_WAITS = true;
+#endif
+template <class Ready>
+inline hipError_t spin_wait(Ready ready, hipStream_t s) {
+    timespec a, b;
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    hipError_t e = hipSuccess;
+    for (unsigned it = 1;; ++it) {
+        if (ready()) break;
+        __builtin_ia32_pause();
+        if ((it & 1023u) == 0) {
+            clock_gettime(CLOCK_MONOTONIC, &b);
+            if ((b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3 > SPIN_FALLBACK_US) {
+                e = hipStreamSynchronize(s);
+                break;
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+    g_wait_us += (b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3;
+    ++g_wait_n;
+    return e;
+}
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 int sync_event(hipEvent_t *ev) {          // one untimed event per (thread, device), like the fork / join pair above
     struct One { int dev; hipEvent_t e; };
@@ -106,6 +140,9 @@ int sgn_project_fwd_checked(int n, const float *means3d, const float *scales, fl
                             float *conics, float *compensation, int32_t *num_tiles_hit, int32_t *quat_flag,
                             float quat_tol, int32_t quat_stamp, int32_t *quat_ok, int semantics,
                             sgn_stream_t stream);       // project.hip
+
+int sgn_publish_words(const int32_t *src_dev, int n, int32_t *dst_mapped, int32_t *flag_mapped, int32_t flag_value,
+                      sgn_stream_t stream);     // project.hip
 
 namespace {
 int check_event(hipEvent_t *ev) {         // the quats check's OWN event per (thread, device): a deferred wait
@@ -169,15 +206,27 @@ int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float 
                                      num_tiles_hit, check_quats ? (direct ? direct : flag_dev) : nullptr, quat_tol,
                                      stamp, direct ? direct + 1 : nullptr, semantics, stream);
     if (rc) return rc;
+    // flag_pinned[2] (round 6): "the projection kernel is COMPLETE" — a one-wave kernel behind it stores the stamp there
+    // and the host polls that word; without a mapped slot (or for n = 0) an event behind a copy command does it, and
+    // the word is set to -stamp so that the wait knows which of the two to use
+    bool polled = false;
     if (check_quats) {
         hipError_t e = hipSuccess;
-        if (!direct) {                      // the copy command is the transport: its completion is the landing
-            if (n > 0) e = hipMemcpyAsync(dst, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
-            else dst[0] = 0;
-            dst[1] = stamp;
+        if (direct && POLL_WAITS) {
+            ((volatile int32_t *)flag_pinned)[2] = 0;
+            rc = sgn_publish_words(nullptr, 0, nullptr, direct + 2, stamp, stream);
+            if (rc) return rc;
+            polled = true;
+        } else {
+            if (!direct) {                  // the copy command is the transport: its completion is the landing
+                if (n > 0) e = hipMemcpyAsync(dst, flag_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+                else dst[0] = 0;
+                dst[1] = stamp;
+            }
+            if (flag_pinned) flag_pinned[2] = -stamp;
+            if (e == hipSuccess && check_event(&ev) != 0) e = hipErrorUnknown;
+            if (e == hipSuccess) e = hipEventRecord(ev, s);
         }
-        if (e == hipSuccess && check_event(&ev) != 0) e = hipErrorUnknown;
-        if (e == hipSuccess) e = hipEventRecord(ev, s);
         if (e != hipSuccess) { sgn_set_error("sgn_project_fwd_all: flag read-back: %s", hipGetErrorString(e)); return (int)e; }
     }
     if (gid_by_rank != nullptr && n > 0) {
@@ -185,7 +234,9 @@ int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float 
         if (rc) return rc;
     }
     if (check_quats == 1) {
-        const hipError_t e = timed_event_sync(ev);         // the ranking is queued behind the projection: wait now
+        // the ranking is queued behind the projection: wait now
+        const hipError_t e = polled ? spin_wait([&] { return ((volatile int32_t *)flag_pinned)[2] == stamp; }, s)
+                                    : timed_event_sync(ev);
         if (e != hipSuccess) { sgn_set_error("sgn_project_fwd_all: %s", hipGetErrorString(e)); return (int)e; }
         int32_t bad = 0;
         rc = read_quat_flag(dst, stamp, &bad, "sgn_project_fwd_all");
@@ -200,20 +251,28 @@ int sgn_project_fwd_all(int n, const float *means3d, const float *scales, float 
 // busy behind it; what the host does before this wait is off the critical path).  The check has its own event, so other
 // calls of this library may come in between.
 extern "C" __attribute__((visibility("default")))
-int sgn_project_check_wait(const int32_t *flag_pinned, int32_t flag_stamp, int32_t *quats_bad_host) {
+int sgn_project_check_wait(const int32_t *flag_pinned, int32_t flag_stamp, int32_t *quats_bad_host,
+                           sgn_stream_t stream) {
     if (!flag_pinned || !quats_bad_host) { sgn_set_error("sgn_project_check_wait: NULL argument"); return -1; }
-    hipEvent_t ev = nullptr;
-    if (check_event(&ev) != 0) { sgn_set_error("sgn_project_check_wait: no event"); return -2; }
-    const hipError_t e = timed_event_sync(ev);
+    const int32_t stamp = flag_stamp > 0 ? flag_stamp : 1;
+    hipError_t e = hipSuccess;
+    if (((const volatile int32_t *)flag_pinned)[2] == -stamp) {     // the call went the copy + event way
+        hipEvent_t ev = nullptr;
+        if (check_event(&ev) != 0) { sgn_set_error("sgn_project_check_wait: no event"); return -2; }
+        e = timed_event_sync(ev);
+    } else {                                                        // polled: the one-wave kernel behind the projection
+        e = spin_wait([&] { return ((const volatile int32_t *)flag_pinned)[2] == stamp; }, (hipStream_t)stream);
+    }
     if (e != hipSuccess) { sgn_set_error("sgn_project_check_wait: %s", hipGetErrorString(e)); return (int)e; }
-    return read_quat_flag(flag_pinned, flag_stamp > 0 ? flag_stamp : 1, quats_bad_host, "sgn_project_check_wait");
+    return read_quat_flag(flag_pinned, stamp, quats_bad_host, "sgn_project_check_wait");
 }
 
 int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const int32_t *radii,
                           const float *conics, const float *opacities, int opacity_is_logit, int cull,
                           int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
                           int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
-                          int sort_rank_mode, int32_t *total_host, int semantics, sgn_stream_t stream);   // binning.hip
+                          int sort_rank_mode, int32_t *total_host, const int32_t *extra_dev, int32_t *extra_host,
+                          int semantics, sgn_stream_t stream);   // binning.hip
 int sgn_bin_intersect_zero(int n, int64_t n_isect, const float *bin_records, const int32_t *cum_by_rank,
                            const int32_t *gid_by_rank, int tiles_x, int tiles_y, int block_width,
                            int32_t *gaussian_ids_sorted, int32_t *tile_bins, int quadrant_masks, void *ws,
@@ -270,23 +329,30 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
     int32_t *gid = gid_by_rank_ready ? const_cast<int32_t *>(gid_by_rank_ready) : gid_own;
     const int do_cull = (cull && conics && opacities) ? 1 : 0;
     // the count goes straight from the scan into count_pinned where that is mapped into the device's address space (no
-    // copy command, no bubble behind it), by a copy otherwise; everything queued below runs while it travels
+    // copy command, no event, no bubble behind it: the host POLLS the word), by a copy + event otherwise; everything
+    // queued below runs while it travels.  `extra` rides the same way (stored by the same thread, ahead of the count).
     int32_t *direct = mapped(count_pinned);
-    if (direct) *count_pinned = -1;            // poison: a count that has not landed when the event fires is noticed below
+    int32_t *extra_direct = (direct && extra_dev && extra_pinned) ? mapped(extra_pinned) : nullptr;
+    const bool polled = POLL_WAITS && direct != nullptr && (!(extra_dev && extra_pinned) || extra_direct != nullptr);
+    if (!polled) extra_direct = nullptr;
+    if (direct) *(volatile int32_t *)count_pinned = -1;            // poison: "not landed yet"
     int rc = sgn_bin_prepare_total(n, xys, depths, radii, do_cull ? conics : nullptr, do_cull ? opacities : nullptr,
                                    opacity_is_logit, do_cull, tiles_x, tiles_y, block_width, cum_r, gid,
-                                   gid_by_rank_ready ? 1 : 0, bin_recs, ws1, ws1_bytes, sort_rank_mode, direct, semantics,
-                                   stream);
+                                   gid_by_rank_ready ? 1 : 0, bin_recs, ws1, ws1_bytes, sort_rank_mode, direct,
+                                   extra_direct ? extra_dev : nullptr, extra_direct, semantics, stream);
     if (rc) return rc;
     int32_t pageable = -1;
     int32_t *dst = count_pinned ? count_pinned : &pageable;
-    hipError_t e = direct ? hipSuccess : hipMemcpyAsync(dst, cum_r + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
-    if (e == hipSuccess && extra_dev && extra_pinned)
-        e = hipMemcpyAsync(extra_pinned, extra_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+    hipError_t e = hipSuccess;
     hipEvent_t ev = nullptr;
-    if (e == hipSuccess && sync_event(&ev) != 0) e = hipErrorUnknown;
-    if (e == hipSuccess) e = hipEventRecord(ev, s);
-    if (e != hipSuccess) { sgn_set_error("sgn_rasterize_fwd_all: count read-back: %s", hipGetErrorString(e)); return (int)e; }
+    if (!polled) {
+        if (!direct) e = hipMemcpyAsync(dst, cum_r + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && extra_dev && extra_pinned && !extra_direct)
+            e = hipMemcpyAsync(extra_pinned, extra_dev, sizeof(int32_t), hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && sync_event(&ev) != 0) e = hipErrorUnknown;
+        if (e == hipSuccess) e = hipEventRecord(ev, s);
+        if (e != hipSuccess) { sgn_set_error("sgn_rasterize_fwd_all: count read-back: %s", hipGetErrorString(e)); return (int)e; }
+    }
     rc = sgn_raster_build_rows(n, xys, conics, colors, opacities, opacity_is_logit, 0, n, 0, rows, rows_bytes, nullptr,
                                stream);
     if (rc) return rc;
@@ -297,10 +363,13 @@ int sgn_rasterize_fwd_all(int n, const float *xys, const float *depths, const in
                                 gaussian_ids_sorted, tile_bins, quadrant_masks, ws2, ws2_bytes, cum_r + (n - 1),
                                 sort_rank_mode, stats_behind_bins ? 2 * n_tiles : 0, stream);
     if (rc) return rc;
-    e = timed_event_sync(ev);                          // the path's one host sync (upstream: `.item()` on the count)
+    // the path's one host sync (upstream: `.item()` on the count)
+    if (polled) e = spin_wait([&] { return *(volatile int32_t *)dst != -1; }, s);
+    else e = timed_event_sync(ev);
     if (e != hipSuccess) { sgn_set_error("sgn_rasterize_fwd_all: %s", hipGetErrorString(e)); return (int)e; }
     if (direct && *(volatile int32_t *)dst == -1) {    // never seen; the plain copy is the safety net
         e = hipMemcpy(dst, cum_r + (n - 1), sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && extra_dev && extra_pinned) e = hipMemcpy(extra_pinned, extra_dev, sizeof(int32_t), hipMemcpyDeviceToHost);
         if (e != hipSuccess) { sgn_set_error("sgn_rasterize_fwd_all: count copy: %s", hipGetErrorString(e)); return (int)e; }
     }
     const int64_t count = (int64_t)*(volatile int32_t *)dst;
@@ -383,13 +452,24 @@ int sgn_rasterize_window_all(int n_win, int n_full, int n_cand, const int32_t *c
                                 conics ? conics_w : nullptr, opacities ? opacities_w : nullptr, xys, depths, radii,
                                 num_tiles_hit, conics, opacities, mismatch, stream);
         if (rc) return rc;
-        int32_t pageable[4] = {1, 1, 1, 1};
+        int32_t pageable[8] = {1, 1, 1, 1, 0, 0, 0, 0};
         int32_t *dst = verdict_pinned ? verdict_pinned : pageable;
-        hipError_t e = hipMemcpyAsync(dst, mismatch, sizeof(int32_t) * n_cand, hipMemcpyDeviceToHost, s);
-        hipEvent_t ev = nullptr;
-        if (e == hipSuccess && sync_event(&ev) != 0) e = hipErrorUnknown;
-        if (e == hipSuccess) e = hipEventRecord(ev, s);
-        if (e == hipSuccess) e = timed_event_sync(ev);
+        int32_t *vd = POLL_WAITS ? mapped(verdict_pinned) : nullptr;      // EIGHT words: [0, 4) the verdicts, [7] "they have landed" (polled)
+        hipError_t e = hipSuccess;
+        if (vd) {
+            ((volatile int32_t *)dst)[7] = 0;
+            rc = sgn_publish_words(mismatch, n_cand, vd, vd + 7, 1, stream);
+            if (rc) return rc;
+            e = spin_wait([&] { return ((volatile int32_t *)dst)[7] == 1; }, s);
+            if (e == hipSuccess && ((volatile int32_t *)dst)[7] != 1)      // the cold path drained the stream: plain copy
+                e = hipMemcpy(dst, mismatch, sizeof(int32_t) * n_cand, hipMemcpyDeviceToHost);
+        } else {
+            e = hipMemcpyAsync(dst, mismatch, sizeof(int32_t) * n_cand, hipMemcpyDeviceToHost, s);
+            hipEvent_t ev = nullptr;
+            if (e == hipSuccess && sync_event(&ev) != 0) e = hipErrorUnknown;
+            if (e == hipSuccess) e = hipEventRecord(ev, s);
+            if (e == hipSuccess) e = timed_event_sync(ev);
+        }
         if (e != hipSuccess) { sgn_set_error("sgn_rasterize_window_all: verdict read-back: %s", hipGetErrorString(e)); return (int)e; }
         for (int c = 0; c < n_cand && lo < 0; ++c)
             if (((volatile int32_t *)dst)[c] == 0) lo = cand_lo_host[c];

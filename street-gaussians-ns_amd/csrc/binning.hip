@@ -102,7 +102,9 @@ template <bool SCANNED>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(int n, const int32_t *__restrict__ in,
                                                                   const int32_t *__restrict__ partial,
                                                                   int32_t *__restrict__ out,
-                                                                  int32_t *__restrict__ total_host) {
+                                                                  int32_t *__restrict__ total_host,
+                                                                  const int32_t *__restrict__ extra_dev = nullptr,
+                                                                  int32_t *__restrict__ extra_host = nullptr) {
     __shared__ int lds4[4];
     const int base = blockIdx.x * SCAN_CHUNK + threadIdx.x * SCAN_ITEMS;
     int v[SCAN_ITEMS];
@@ -130,9 +132,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(int n, const i
         run += v[k];
         if (base + k < n) out[base + k] = run;
         // the grand total straight into (mapped, pinned) HOST memory: the caller's read-back of out[n-1] then needs no
-        // copy command behind this kernel (a ~4 us blit and a ~6 us bubble on the stream), only its event
+        // copy command behind this kernel (a ~4 us blit and a ~6 us bubble on the stream) and — round 6 — no event
+        // either: the host polls the word.  `extra`: one more device word the caller wants on the host with the count
+        // (stored FIRST: posted writes keep their order, so a host that sees the count sees the extra word)
         if (total_host != nullptr && base + k == n - 1) {
-            __hip_atomic_store(total_host, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (extra_host != nullptr) {
+                __hip_atomic_store(extra_host, *extra_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __threadfence_system();
+            }
+            __hip_atomic_store(total_host, run, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             __threadfence_system();
         }
     }
@@ -731,7 +739,8 @@ SGN_EXPORT size_t sgn_scan_workspace_bytes(int n) {
 
 // out[i] = sum_{r <= i} in[idx ? idx[r] : r];  with idx, `gathered` (n ints) receives in[idx[r]]
 static int scan_launch(int n, const int32_t *in, const int32_t *idx, int32_t *gathered, int32_t *out, void *ws,
-                       hipStream_t s, int32_t *total_host = nullptr) {
+                       hipStream_t s, int32_t *total_host = nullptr, const int32_t *extra_dev = nullptr,
+                       int32_t *extra_host = nullptr) {
     const int nb = sgn_cdiv(n, SCAN_CHUNK);
     int32_t *partial = (int32_t *)ws;
     sgn_timing_begin(SGN_T_SCAN, s);
@@ -739,11 +748,11 @@ static int scan_launch(int n, const int32_t *in, const int32_t *idx, int32_t *ga
                        partial);
     if (nb <= 4096) {       // every workgroup adds up the chunk totals before its own (<= 16 KB of reads each)
         hipLaunchKernelGGL(scan_final_kernel<false>, dim3(nb), dim3(SCAN_THREADS), 0, s, n, idx ? gathered : in, partial,
-                           out, total_host);
+                           out, total_host, extra_dev, extra_host);
     } else {
         hipLaunchKernelGGL(scan_partials_kernel, dim3(1), dim3(SCAN_THREADS), 0, s, nb, partial);
         hipLaunchKernelGGL(scan_final_kernel<true>, dim3(nb), dim3(SCAN_THREADS), 0, s, n, idx ? gathered : in, partial,
-                           out, total_host);
+                           out, total_host, extra_dev, extra_host);
     }
     sgn_timing_end(SGN_T_SCAN, s);
     SGN_LAUNCH_CHECK();
@@ -847,7 +856,8 @@ int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const in
                           const float *conics, const float *opacities, int opacity_is_logit, int cull,
                           int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
                           int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
-                          int sort_rank_mode, int32_t *total_host, int semantics, sgn_stream_t stream);
+                          int sort_rank_mode, int32_t *total_host, const int32_t *extra_dev, int32_t *extra_host,
+                          int semantics, sgn_stream_t stream);
 
 SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, const int32_t *radii,
                                const float *conics, const float *opacities, int opacity_is_logit, int cull,
@@ -856,14 +866,15 @@ SGN_EXPORT int sgn_bin_prepare(int n, const float *xys, const float *depths, con
                                int sort_rank_mode, int semantics, sgn_stream_t stream) {
     return sgn_bin_prepare_total(n, xys, depths, radii, conics, opacities, opacity_is_logit, cull, tiles_x, tiles_y,
                                  block_width, cum_by_rank, gid_by_rank, rank_ready, bin_records, ws, ws_bytes,
-                                 sort_rank_mode, nullptr, semantics, stream);
+                                 sort_rank_mode, nullptr, nullptr, nullptr, semantics, stream);
 }
 
 int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const int32_t *radii,
                           const float *conics, const float *opacities, int opacity_is_logit, int cull,
                           int tiles_x, int tiles_y, int block_width, int32_t *cum_by_rank,
                           int32_t *gid_by_rank, int rank_ready, float *bin_records, void *ws, size_t ws_bytes,
-                          int sort_rank_mode, int32_t *total_host, int semantics, sgn_stream_t stream) {
+                          int sort_rank_mode, int32_t *total_host, const int32_t *extra_dev, int32_t *extra_host,
+                          int semantics, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0, -1);
     SGN_ARG_CHECK(block_width >= 2 && block_width <= 16 && tiles_x > 0 && tiles_y > 0, -2);
     if (n == 0) return 0;
@@ -890,7 +901,9 @@ int sgn_bin_prepare_total(int n, const float *xys, const float *depths, const in
         sgn_timing_end(SGN_T_SORT, s);
     }
     // cum_by_rank[r] = sum of the kept-tile counts of ranks <= r: the scan's first pass gathers cnt_gid[gid_by_rank[r]]
-    return scan_launch(n, cnt_gid, gid_by_rank, cnt_r, cum_by_rank, scan_ws, s, total_host);
+    return scan_launch(n, cnt_gid, gid_by_rank, cnt_r, cum_by_rank, scan_ws, s, total_host,
+                       (total_host && extra_dev && extra_host) ? extra_dev : nullptr,
+                       (total_host && extra_dev && extra_host) ? extra_host : nullptr);
 }
 
 SGN_EXPORT size_t sgn_bin_intersect_workspace_bytes(int64_t n_isect) {

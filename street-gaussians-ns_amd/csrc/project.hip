@@ -556,6 +556,33 @@ __global__ __launch_bounds__(256) void check_unit_quats_kernel(int n, const floa
 }
 }  // namespace
 
+// Round 6 — "this point of the stream has been reached, and here are a few words": ONE wave copies up to 64 device words
+// into mapped pinned host memory and then stores `flag_value` into a flag word there (system scope, after a fence: a host
+// that sees the flag sees the words, and — stream order — everything queued before this launch is complete).  The host
+// POLLS the flag (api.cpp spin_wait): no copy command, no event record (a ~6 us barrier bubble on the stream each).
+namespace {
+__global__ __launch_bounds__(64) void publish_words_kernel(const int32_t *__restrict__ src, int n,
+                                                           int32_t *__restrict__ dst_mapped,
+                                                           int32_t *__restrict__ flag_mapped, int32_t flag_value) {
+    const int i = threadIdx.x;
+    if (i < n) __hip_atomic_store(dst_mapped + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (i == 0) {
+        __hip_atomic_store(flag_mapped, flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+    }
+}
+}  // namespace
+
+int sgn_publish_words(const int32_t *src_dev, int n, int32_t *dst_mapped, int32_t *flag_mapped, int32_t flag_value,
+                      sgn_stream_t stream) {
+    SGN_ARG_CHECK(flag_mapped != nullptr && n >= 0 && n <= 64 && (n == 0 || (src_dev && dst_mapped)), -1);
+    hipLaunchKernelGGL(publish_words_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, src_dev, n, dst_mapped,
+                       flag_mapped, flag_value);
+    SGN_LAUNCH_CHECK();
+    return 0;
+}
+
 SGN_EXPORT int sgn_check_unit_quats(int n, const float *quats, float tol, int32_t *flag, sgn_stream_t stream) {
     SGN_ARG_CHECK(n >= 0 && flag != nullptr, -1);
     hipStream_t s = (hipStream_t)stream;

@@ -91,7 +91,7 @@ SIGNATURES = {
                                    _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sgn_project_fwd_all": (_i, [_i, _vp, _vp, _f, _vp, _vp, _f, _f, _f, _f, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp,
                                  _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp, _i, _vp]),
-    "sgn_project_check_wait": (_i, [_vp, _i, _vp]),
+    "sgn_project_check_wait": (_i, [_vp, _i, _vp, _vp]),
     "sgn_rasterize_arena_bytes": (_sz, [_i, _i64]),
     "sgn_rasterize_window_arena_bytes": (_sz, [_i]),
     "sgn_rasterize_window_all": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp,

@@ -146,7 +146,7 @@ class _State:
         self.stat_skipped = 0          # binnings since the statistic was last read back (every eighth one carries it)
         self.eager_side = None         # [pinned int32[8] ring for the eager flag read-back, next slot]
         self.quat_flag = None          # [device int32[1] zeroed once, stamp of the last call] (sgn_project_fwd_all)
-        self.quat_ring = None          # [pinned int32[16]: eight (failed, landed) slots of that call, next slot]
+        self.quat_ring = None          # [pinned int32[32]: eight (failed, landed, complete, -) slots of that call, next slot]
         self.depth_state = {"want": False, "unused": 0, "cache": None}
         self.depth_caches = collections.OrderedDict()                  # binning key -> first pass's channel + state
         self.early = {"entry": None, "misses": 0, "pause": 0}
@@ -524,9 +524,9 @@ def _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, c
             S.quat_flag[1] += 1
             flag, stamp = S.quat_flag
             if S.quat_ring is None:
-                S.quat_ring = [torch.zeros(16, dtype=torch.int32).pin_memory(), 0]
-            ring = S.quat_ring             # eight slots of two words: [failed stamp, landed stamp] (include/sgn_rast.h)
-            slot = ring[0][2 * (ring[1] % 8):2 * (ring[1] % 8) + 2]
+                S.quat_ring = [torch.zeros(32, dtype=torch.int32).pin_memory(), 0]
+            ring = S.quat_ring             # eight slots of four words: [failed stamp, landed stamp, complete stamp, -]
+            slot = ring[0][4 * (ring[1] % 8):4 * (ring[1] % 8) + 4]     # (include/sgn_rast.h sgn_project_fwd_all)
             ring[1] += 1
         gid = ws = None
         if plan["rank"]:
@@ -764,7 +764,8 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
         if plan.get("wait") is not None:
             slot, stamp = plan["wait"]
             bad = C.c_int32(0)
-            L.check(L.load().sgn_project_check_wait(slot.data_ptr(), stamp, C.byref(bad)), "sgn_project_check_wait")
+            L.check(L.load().sgn_project_check_wait(slot.data_ptr(), stamp, C.byref(bad), L.stream_ptr()),
+                    "sgn_project_check_wait")
             assert bad.value == 0, "quats must be normalized"        # (upstream raises from this very call)
         return out
     _start_early_rank(out[1], out[2])  # depth ranking queued behind the projection, before the host waits

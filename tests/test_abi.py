@@ -94,7 +94,7 @@ def test_argument_errors_are_reported_without_a_gpu(built_lib):
                                                       None, None, None, 0, 0, None, 0, None)
     assert pf(3, 0) == -3 and b"check_quats" in lib.sgn_last_error()
     assert pf(1, 0) == -1 and pf(2, 7) == -1
-    assert lib.sgn_project_check_wait(None, 1, None) == -1 and b"NULL" in lib.sgn_last_error()
+    assert lib.sgn_project_check_wait(None, 1, None, None) == -1 and b"NULL" in lib.sgn_last_error()
     # upstream-variant semantics are ARGUMENTS (round 6): the clamped EWA vjp needs the image size
     pb = lambda sem, h, w: lib.sgn_project_bwd(4, 1, 1, 1.0, 1, 1, 1.0, 1.0, 1, 1, 1, None, 1, None, 1, None, None, None,
                                                1, 1, 1, sem, h, w, None)

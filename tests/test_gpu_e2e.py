@@ -604,26 +604,29 @@ def test_project_fwd_all_at_the_c_abi_in_every_form_of_its_check():
         if rc:
             return None
         if mode == 2:
-            L.check(lib.sgn_project_check_wait(pinned.data_ptr(), stamp, C.byref(bad_host)), "wait")
+            L.check(lib.sgn_project_check_wait(pinned.data_ptr(), stamp, C.byref(bad_host), L.stream_ptr()), "wait")
         torch.cuda.synchronize()
         if q is good:
             assert all(torch.equal(a, b) for a, b in zip(o, ref))
         return bad_host.value
     flag = torch.zeros(1, **i32)
-    pinned = torch.zeros(8, dtype=torch.int32).pin_memory()
+    pinned = torch.zeros(16, dtype=torch.int32).pin_memory()
     # cleared by the call, pageable read-back
     assert call(good, 1, 0, flag, None) == 0 and call(bad, 1, 0, flag, None) == 1 and call(good, 1, 0, flag, None) == 0
-    # stamped, pinned slot of TWO words [failed stamp, landed stamp] (mapped: the kernel stores straight into it), waited
-    # for inside / outside the call; no device flag needed
+    # stamped, pinned slot of THREE words [failed stamp, landed stamp, complete stamp] (mapped: the kernels store straight
+    # into it and the host POLLS the third word — round 6: no event on the stream), waited for inside / outside the call;
+    # no device flag needed
     for mode in (1, 2):
         for k, (q, want) in enumerate(((good, 0), (bad, 1), (good, 0), (bad, 1))):
-            assert call(q, mode, 100 * mode + k + 1, None, pinned[2 * mode:2 * mode + 2]) == want
-    # the last FAILING stamps are still there (never cleared), and so are the last calls' "landed" stamps (round 6)
-    assert int(pinned[2]) == 104 and int(pinned[4]) == 204 and int(pinned[3]) == 104 and int(pinned[5]) == 204
-    # a slot whose "landed" word never shows the stamp must not read as "all quaternions passed": the wait FAILS (-8)
-    stale = torch.zeros(2, dtype=torch.int32).pin_memory()
+            assert call(q, mode, 100 * mode + k + 1, None, pinned[4 * mode:4 * mode + 4]) == want
+    # the last FAILING stamps are still there (never cleared), and so are the last calls' "landed" / "complete" stamps
+    assert [int(v) for v in pinned[4:7]] == [104] * 3 and [int(v) for v in pinned[8:11]] == [204] * 3
+    # a slot whose words never show the stamp must not read as "all quaternions passed": the wait gives up polling after
+    # 0.2 s, drains the stream, and FAILS (-8)
+    stale = torch.zeros(4, dtype=torch.int32).pin_memory()
     bad_host = C.c_int32(-7)
-    assert lib.sgn_project_check_wait(stale.data_ptr(), 999, C.byref(bad_host)) == -8 and b"never reached" in lib.sgn_last_error()
+    assert lib.sgn_project_check_wait(stale.data_ptr(), 999, C.byref(bad_host), L.stream_ptr()) == -8
+    assert b"never reached" in lib.sgn_last_error()
     # no check at all
     assert call(bad, 0, 0, None, None) == -7
     # argument errors
