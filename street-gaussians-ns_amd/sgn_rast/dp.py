@@ -201,7 +201,7 @@ class GradAllReducer:
         self.stats = {"bucket_early": 0, "bucket_late": 0, "sparse_steps": 0, "dense_steps": 0,
                       "touched_fraction": None, "rows_sent": 0, "outside_rows": 0, "checked_steps": 0,
                       "outside_steps": 0, "uncheckable_steps": 0, "bucket_copies": 0, "bucket_in_place": 0,
-                      "big_early": 0, "big_late": 0}
+                      "big_early": 0, "big_late": 0, "dense_overlapped_steps": 0}
         # timing=True (bench.py): device events around the waits for the step's collectives, so the line can say how much
         # communication the compute stream was actually held up by (`exposed_ms()`); two event records per wait
         self.timing = False
@@ -209,19 +209,29 @@ class GradAllReducer:
         self._exposed = {}              # label -> [sum ms, count]
         self._early = None              # (count event state) of this step's forward-time announcement
         self._mark = None               # persistent device buffers of sgn_mark_walked
+        self._check_pinned = None       # [pinned int64[4], next slot]: where the contract check's verdict lands
         if sh_exchange is not None:
             sh_exchange._span_fn = self._span
+        # ADAPTIVE (round 6): content that does not saturate its tiles (street-like: 79 % of the rows touched) sends every
+        # row-exchange step down the dense sequence — and used to do so from finish(), after the backward, because the row
+        # exchange had switched the overlap hooks off for good.  Now a step is EITHER a rows step (`_rows_now`: announce
+        # after the forward, decide at finish()) OR a dense step with the overlap hooks live; two rows steps in a row that
+        # were too dense switch to dense steps, and every `sparse_retry`-th step tries rows again.  The switch is driven
+        # by the all-gathered counts only, so every rank takes it at the same step.
+        self._want_overlap = self.overlap
+        self.sparse_retry = 16
+        self._rows_now, self._dense_streak, self._since_probe = self.sparse, 0, 0
         if self.sparse:
-            self.overlap = False        # the row exchange replaces the bucket and the early all-gathers
+            self.overlap = False        # a rows step: the row exchange replaces the bucket and the early all-gathers
             if self.active and sh_exchange.dc.is_cuda:
                 from . import ops
                 ops._touch_sink = self
-        if self.active and self.small and not self.sparse:
+        if self.active and self.small:
             from . import ops
             ops._grad_arena = self.arena_for      # backward nodes produce the small gradients inside the flat bucket
-        if self.overlap:
+        if self._want_overlap:
             if sh_exchange is not None:
-                sh_exchange.early_start = True
+                sh_exchange.early_start = self.overlap
             for p in self.small:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             for p in self._big_list:
@@ -229,12 +239,16 @@ class GradAllReducer:
 
     # -------------------------------------------------------------------------------- step 2: the flat bucket
     def _on_grad(self, _p) -> None:
+        if not self.overlap:             # (a rows step of an adaptive reducer: the hooks stay installed, idle)
+            return
         self._arrived += 1
         if self._bucket is not None:
             self._late_grad = True                               # a gradient arrived AFTER its bucket had left
         self._leave_early()
 
     def _on_big_grad(self, p) -> None:
+        if not self.overlap:
+            return
         if id(p) in self._big_ready:
             self._late_grad = True                               # a second gradient into a big that may have left
         self._big_ready.add(id(p))
@@ -280,8 +294,8 @@ class GradAllReducer:
         """ops._grad_arena: the slice of the flat bucket a backward node should write `leaf`'s gradient into, or None (not
         a bucket member; the leaf already holds a gradient — a second path into it must be ADDED by autograd, not written
         over —; the bucket of this step has left)."""
-        if not (self.active and self.zero_copy) or self._bucket is not None or not self.small:
-            return None
+        if not (self.active and self.zero_copy) or self._bucket is not None or not self.small or self._rows_now:
+            return None                    # (a rows step REPLACES the gradients by the scattered sums: no bucket)
         sl = self._slices.get(id(leaf))
         if sl is None:
             if self._flat is not None or not any(leaf is p for p in self.small):
@@ -355,7 +369,7 @@ class GradAllReducer:
         ``[count, can, degree, k]`` to the other ranks — the step's first collective — so that by the time the backward
         has run every rank knows every count without a host sync of its own."""
         ex = self.sh_exchange
-        if not (self.sparse and self.active) or ex is None or n != ex.dc.shape[0]:
+        if not (self.sparse and self.active and self._rows_now) or ex is None or n != ex.dc.shape[0]:
             return
         if self._early is not None:
             if self._early["ids_ptr"] != ids.data_ptr():
@@ -402,7 +416,7 @@ class GradAllReducer:
         """ops._touch_sink: a rasterize pass over an id range / with group accumulations ran (the scene graph's sub-model
         passes): its backward reaches rows the walked list of the full pass does not hold — counted like another view, so
         `_finish_sparse` refuses the step loudly instead of dropping gradient rows on the other ranks."""
-        if self.sparse and self.active:
+        if self.sparse and self.active and self._rows_now:
             if self._early is not None:
                 self._early["views"] += 1
             else:
@@ -493,10 +507,14 @@ class GradAllReducer:
         degs = {(int(e[2]), int(e[3])) for e in every if int(e[0]) > 0 and int(e[2]) >= 0}
         sparse = (total_ok and len(degs) <= 1 and n > 0
                   and sum(counts) <= self.sparse_max_fraction * self.world * n)
-        if sparse and hip and self._check_due():
-            sparse = self._rows_inside_the_list(rows_p, widths, c, n, dev)
+        # the contract check (`sparse_check`) is LAUNCHED here and its verdict read further down, after the whole row
+        # exchange has been queued behind it (round 6: the host read used to sit here, in front of a dozen launches that
+        # the device then waited for one by one — 0.2 ms per step at 1 M Gaussians; nothing queued below touches `.grad`
+        # before the verdict is in)
+        check = self._check_launch(rows_p, widths, c, n, dev) if (sparse and hip and self._check_due()) else None
         if not sparse:
             self.stats["dense_steps"] += 1
+            self._too_dense = True        # (decided from all-gathered values: the same on every rank)
             return False
         if c is None and degs:
             degree, k = next(iter(degs))          # a silent rank takes the step's shape from the ranks that rendered
@@ -525,8 +543,6 @@ class GradAllReducer:
                 send[1:1 + count, 0] = list32.view(torch.float32)                      # ids ride as bit patterns
                 send[1:1 + count, 1:] = torch.cat([col.index_select(0, idx) for col in cols_of()], dim=1)
         got = _all_gather_sync(send, self.group, wait=False)            # [world, 1 + maxc, 1 + W]
-        pending = [(dist.all_reduce(p.grad if p.grad is not None else _zero_grad(p), op=self._op, group=self.group,
-                                    async_op=True), p) for p in other]
         with self._span("rows_all_gather"):
             got = got()                                                 # wait (stream-ordered on RCCL)
         v_all = torch.zeros(self.world, n, 3, dtype=torch.float32, device=dev)
@@ -542,8 +558,6 @@ class GradAllReducer:
             for r in range(self.world):                                 # rank order: the same sum on every replica
                 L.check(lib.sgn_rows_scatter(counts[r], L.ptr(got[r]), row_words, ng, dsts, wid_g, float(scale), 3,
                                              L.ptr(v_all[r]), L.stream_ptr()), "sgn_rows_scatter")
-            for p, o in zip(rows_p, outs):
-                p.grad = o
         else:
             acc = torch.zeros(n, W - 3, dtype=torch.float32, device=dev)
             for r in range(self.world):                                 # rank order: the same sum on every replica
@@ -552,13 +566,19 @@ class GradAllReducer:
                     ids = got[r, 1:1 + cr, 0].contiguous().view(torch.int32).long()
                     acc.index_add_(0, ids, got[r, 1:1 + cr, 1:1 + W - 3])   # ids are unique within a rank
                     v_all[r].index_copy_(0, ids, got[r, 1:1 + cr, 1 + W - 3:])
-            off = 0
+            outs, off = [], 0
             for p, w in zip(rows_p, widths):
-                p.grad = (acc[:, off:off + w] * scale).reshape(p.shape)
+                outs.append((acc[:, off:off + w] * scale).reshape(p.shape))
                 off += w
         cams = got[:, 0, :3].contiguous()
         low = ex.multi_fn(degree, k, None, means, cams, None, None, v_all, scale)
         low = low if isinstance(low, tuple) else (low[:, 0:1, :], low[:, 1:, :])
+        if check is not None and not self._check_verdict(check):
+            return False                  # a row outside the list: the dense sequence, on the gradients as they were
+        pending = [(dist.all_reduce(p.grad if p.grad is not None else _zero_grad(p), op=self._op, group=self.group,
+                                    async_op=True), p) for p in other]
+        for p, o in zip(rows_p, outs):
+            p.grad = o
         for leaf, g in zip((ex.dc, ex.rest), low):
             g = g if g.is_contiguous() else g.contiguous()
             leaf.grad = g if g.shape == leaf.shape else g.reshape(leaf.shape)
@@ -582,9 +602,9 @@ class GradAllReducer:
         self._sparse_seen += 1
         return self._checked_steps < k or self._sparse_seen % k == 0
 
-    def _rows_inside_the_list(self, rows_p, widths, c, n, dev) -> bool:
-        """The checked mode of the row exchange (see `sparse_check`): False — identically on every rank — when some
-        rank holds a non-zero gradient row the forward did not list; the exchange is then switched off for good."""
+    def _check_launch(self, rows_p, widths, c, n, dev):
+        """The checked mode of the row exchange (see `sparse_check`), first half: one pass over the gradients against the
+        forward's marks, a MAX all-reduce of the count, its copy to pinned memory — all queued, nothing waited for."""
         import ctypes as C
         from . import _lib as L
         m = self._mark
@@ -607,14 +627,29 @@ class GradAllReducer:
         if dist.get_backend(self.group) == "gloo" and worst.is_cuda:
             host = worst.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
-            worst = host
-        else:
-            dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=self.group)
-        worst = int(worst.item())
+            return dict(host=host, checkable=checkable)
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=self.group)          # stream-ordered on RCCL: no host wait
+        if not worst.is_cuda:
+            return dict(host=worst, checkable=checkable)
+        if self._check_pinned is None:
+            self._check_pinned = [torch.zeros(4, dtype=torch.int64).pin_memory(), 0]
+        slot = self._check_pinned[0][self._check_pinned[1] % 4:self._check_pinned[1] % 4 + 1]
+        self._check_pinned[1] += 1
+        slot.copy_(worst, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return dict(host=slot, done=done, checkable=checkable, keep=(worst, outside, srcs))
+
+    def _check_verdict(self, token) -> bool:
+        """Second half: False — identically on every rank — when some rank holds a non-zero gradient row the forward did
+        not list ("always": this step goes dense; an integer k: the exchange is switched off for good)."""
+        if token.get("done") is not None:
+            token["done"].synchronize()
+        worst = int(token["host"].item())
         if worst >= _UNCHECKABLE:
             self.stats["uncheckable_steps"] += 1
             return False
-        if checkable:
+        if token["checkable"]:
             self._checked_steps += 1
             self.stats["checked_steps"] = self._checked_steps
         if worst > 0:
@@ -627,7 +662,10 @@ class GradAllReducer:
                                   "the rows the forward walked (a loss term beside the rendered images?) — the row "
                                   "exchange would drop them; such steps take the dense exchange (every step is checked)")
                 return False
-            self.sparse = False
+            self.sparse = self._rows_now = False          # from now on: dense steps, with the overlap hooks if asked for
+            self.overlap = self._want_overlap
+            if self.sh_exchange is not None and self._want_overlap:
+                self.sh_exchange.early_start = True
             warnings.warn(f"GradAllReducer(sparse=True): {worst} per-Gaussian gradient row(s) are non-zero outside the "
                           "rows the forward walked (a loss term beside the rendered images?) — the row exchange would "
                           "drop them; using the dense exchange from now on")
@@ -666,10 +704,15 @@ class GradAllReducer:
                         "them (optimizer.zero_grad(set_to_none=False), or no zero_grad at all) must set `.grad = None` on "
                         "the parameters it names absent (the reference's own loop does: set_to_none=True)")
             self._verify_absent_set(absent)
-        if self.sparse and self.active and absent:
+        rows_step = self.sparse and self.active and self._rows_now
+        self._too_dense = False
+        if rows_step and absent:
             self._drop_announcement()
-        if self.sparse and self.active and not absent and self._finish_sparse():
+        if rows_step and not absent and self._finish_sparse():
+            self._next_mode(rows_step=True)
             return
+        if self.sparse and self.active and not rows_step:
+            self.stats["dense_overlapped_steps"] += 1
         pending = []
         if self.sh_exchange is not None:
             self.sh_exchange.start()                     # 1. all-gathers (no-op if the SH backward already sent them)
@@ -708,6 +751,22 @@ class GradAllReducer:
         for w, p in pending:
             if self.average and not self._avg_in_collective:
                 p.grad /= self.world
+        if self.sparse:
+            self._next_mode(rows_step=rows_step)
+
+    def _next_mode(self, rows_step: bool) -> None:
+        """Adaptive reducer: what kind of step the NEXT one is (see __init__)."""
+        if rows_step:
+            self._dense_streak = self._dense_streak + 1 if self._too_dense else 0
+            self._since_probe = 0
+        else:
+            self._since_probe += 1
+        self._rows_now = self._dense_streak < 2 or self._since_probe >= self.sparse_retry
+        self.overlap = self._want_overlap and not self._rows_now
+        if self.sh_exchange is not None:
+            if self._want_overlap:
+                self.sh_exchange.early_start = self.overlap
+            self.sh_exchange._fwd = dict(claimed=0, other=0, degree=-1, k=0, cam=False)   # (what the next forward shows)
 
     def _verify_absent_set(self, absent) -> None:
         """`absent` MUST name the same parameters on every rank (it decides which collectives are issued): checked on the
@@ -735,7 +794,7 @@ class GradAllReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        self.overlap = False
+        self.overlap = self._want_overlap = False
         from . import ops
         if ops._touch_sink is self:
             ops._touch_sink = None
