@@ -704,7 +704,8 @@ def main():
     sg_check = None
     if sg is not None and reducer is not None:
         held, reducer = reducer, None
-        one_step()
+        with held.suspended():            # (a backward that is not a step of the reducer: its hooks stay idle)
+            one_step()
         ref = []
         for p_ in sg_leaves:
             g_ = p_.grad.detach().clone()

@@ -589,9 +589,7 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
 /* One of SEVERAL reverse walks whose gradients belong to the same tensors (the main pass of sgn_raster_fwd_groups and
  * the group accumulations that reached the loss): all of them accumulate into ONE packed gradient workspace and the last
  * one unpacks — instead of a 48 MB clear, an unpack and four tensor additions per extra walk.  Arguments as
- * sgn_raster_bwd; first = 1 clears grad_ws, first = 2 (round 6) declares it ALL ZEROS already and skips the 48 MB clear —
- * every unpack zeroes the rows it found something in, so a workspace that only these calls write and whose last sequence
- * ended with `last` is in that state —, last != 0 unpacks it (only then are v_xy / v_conic / v_colors / v_opacity
+ * sgn_raster_bwd; first != 0 clears grad_ws, last != 0 unpacks it (only then are v_xy / v_conic / v_colors / v_opacity
  * written).  Whole-tensor passes only (window = 0), all with the same conics / opacities / opacity_is_logit; -13
  * otherwise. */
 int sgn_raster_bwd_part(int img_h, int img_w, int block_width, int n, int64_t n_isect,
@@ -606,8 +604,8 @@ int sgn_raster_bwd_part(int img_h, int img_w, int block_width, int n, int64_t n_
 
 /* The backward of a rasterize node as ONE call (round 6): sgn_tile_order over the forward's tile statistics (tile_order
  * [tiles + 2] out — NULL: no reordering, the in-kernel split of long walks —, long walks = opts->adapt_bwd, the
- * small-splat promotion small_q16 only when stats_have_pairs) + sgn_raster_bwd (first = last = 1; window allowed; first
- * = 2, last = 1: the same on a workspace known to be all zeros, no clear) or sgn_raster_bwd_part (otherwise).  Everything else as in sgn_raster_bwd. */
+ * small-splat promotion small_q16 only when stats_have_pairs) + sgn_raster_bwd (first = last = 1; window allowed) or
+ * sgn_raster_bwd_part (otherwise).  Everything else as in sgn_raster_bwd. */
 int sgn_rasterize_bwd_all(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                           const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const int32_t *tile_stats,
                           int stats_have_pairs, const float *xys, const float *conics, const float *colors,

@@ -7,7 +7,7 @@ same body, so the whole-kernel mix is the loop's mix up to the prologue / epilog
 """
 import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-KERNELS = {"raster_bwd": "raster_bwd_short_kernelILb0ELi1ELb1E", "raster_fwd": "raster_fwd_pk_kernelILb0ELb1ELb0E"}
+KERNELS = {"raster_bwd": "raster_bwd_short_kernelILb0ELi1EE", "raster_fwd": "raster_fwd_pk_kernelILb0ELb0ELb0E"}   # (round 6 template parameters: <EXACT, REDUCE> / <EXACT, DEPTH, GROUPS>)
 
 CLASSES = [  # (class, regex on the mnemonic) — first match wins
     ("trans", r"v_(exp|rcp|log|sqrt|rsq)_f32"),

@@ -505,23 +505,11 @@ int sgn_rasterize_window_all(int n_win, int n_full, int n_cand, const int32_t *c
                           1, order, tile_stats, nullptr, nullptr, nullptr, &oo, stream);
 }
 
-int sgn_raster_bwd_on_clean_ws(int img_h, int img_w, int block_width, int n, int64_t n_isect,
-                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
-                               const float *conics, const float *colors, const float *opacities,
-                               int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
-                               const float *final_Ts, const int32_t *final_idx,
-                               const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd,
-                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
-                               size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
-                               const int32_t *tile_order, const float *colors_pre_clamp,
-                               const sgn_raster_opts *opts, sgn_stream_t stream, sgn_stream_t aux_stream);   // raster.hip
-
 // ---------------------------------------------------------------- the backward of a rasterize node, one call (round 6)
 // sgn_rasterize_bwd_all = sgn_tile_order (the reverse walks' launch order, from the forward's tile statistics) +
 // sgn_raster_bwd / sgn_raster_bwd_part.  tile_order [tiles + 2] stays the caller's (its last word is the walked / listed
-// statistic the host's quadrant-mask policy reads back later).  first / last as in sgn_raster_bwd_part (first = 2: the
-// workspace is known to be all zeros — every unpack leaves it so — and is not cleared); first = last = 1 is the plain
-// sgn_raster_bwd, first = 2 with last = 1 the same without the clear (window allowed in both).
+// statistic the host's quadrant-mask policy reads back later).  first / last as in sgn_raster_bwd_part; first = last = 1 is
+// the plain sgn_raster_bwd (window allowed).
 extern "C" __attribute__((visibility("default")))
 int sgn_rasterize_bwd_all(int img_h, int img_w, int block_width, int n, int64_t n_isect,
                           const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const int32_t *tile_stats,
@@ -546,12 +534,6 @@ int sgn_rasterize_bwd_all(int img_h, int img_w, int block_width, int n, int64_t 
         if (rc) return rc;
         order = tile_order;
     }
-    if (first == 2 && last)      // the workspace was left all zeros by the last unpack on it: no 48 MB clear
-        return sgn_raster_bwd_on_clean_ws(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics,
-                                          colors, opacities, opacity_is_logit, id_lo, id_hi, window, background3, final_Ts,
-                                          final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors,
-                                          v_opacity, recs_ws, recs_ws_bytes, recs_packed, grad_ws, grad_ws_bytes, order,
-                                          colors_pre_clamp, opts, stream, aux_stream);
     if (first && last)
         return sgn_raster_bwd(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors,
                               opacities, opacity_is_logit, id_lo, id_hi, window, background3, final_Ts, final_idx,

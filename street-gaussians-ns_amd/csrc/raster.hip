@@ -1229,11 +1229,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, SGN_BWD_S
                                                      adapt_thresh, batch_thresh, use_qm);
 }
 
-// rows [row0, row0 + n) of the packed gradient workspace -> the n rows of the four output arrays.  Round 6: a row that
-// holds anything is ZEROED behind the read (a view touches 0.3-2 % of the rows: a few hundred KB of stores), so the
-// workspace is all zeros again when the kernel ends and the next backward on it needs no 48 MB clear (`first = 2` of
-// sgn_rasterize_bwd_all / sgn_raster_bwd_part: "left clean by the last unpack").
-__global__ __launch_bounds__(256) void unpack_grads_kernel(int n, int row0, float *__restrict__ ws,
+// rows [row0, row0 + n) of the packed gradient workspace -> the n rows of the four output arrays
+__global__ __launch_bounds__(256) void unpack_grads_kernel(int n, int row0, const float *__restrict__ ws,
                                                            const float *__restrict__ conics,
                                                            const float *__restrict__ opac, int opac_is_logit,
                                                            const float *__restrict__ colors_pre,
@@ -1242,17 +1239,9 @@ __global__ __launch_bounds__(256) void unpack_grads_kernel(int n, int row0, floa
                                                            float *__restrict__ v_opac) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    float4 *row = reinterpret_cast<float4 *>(ws) + 3 * (size_t)(row0 + i);
-    const float4 a = row[0], b = row[1], c = row[2];
-    {
-        const uint32_t bits = (__float_as_uint(a.x) | __float_as_uint(a.y) | __float_as_uint(a.z) | __float_as_uint(a.w) |
-                               __float_as_uint(b.x) | __float_as_uint(b.y) | __float_as_uint(b.z) | __float_as_uint(b.w) |
-                               __float_as_uint(c.x) | __float_as_uint(c.y) | __float_as_uint(c.z) | __float_as_uint(c.w));
-        if (bits != 0u) {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            row[0] = z; row[1] = z; row[2] = z;
-        }
-    }
+    const float4 a = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 0];
+    const float4 b = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 1];
+    const float4 c = reinterpret_cast<const float4 *>(ws)[3 * (size_t)(row0 + i) + 2];
     // moments -> gradients with this Gaussian's conic: sigma = (A dx^2 + C dy^2) / 2 + B dx dy, so
     //   v_xy = (A m_x + B m_y, B m_x + C m_y),  v_conic = (s_xx / 2, s_xy, s_yy / 2)  ([:,1] is the TRUE dL/dB)
     const float A = conics[3 * i], B = conics[3 * i + 1], C = conics[3 * i + 2];
@@ -1625,7 +1614,7 @@ static int raster_bwd_impl(int img_h, int img_w, int block_width, int n, int64_t
         const int n_out = window ? id_hi - id_lo : n, row0 = window ? id_lo : 0;
         if (n_out > 0)
             hipLaunchKernelGGL(unpack_grads_kernel, dim3(sgn_cdiv(n_out, 256)), dim3(256), 0, s, n_out, row0,
-                               (float *)grad_ws, conics, opacities, opacity_is_logit, colors_pre_clamp, v_xy,
+                               (const float *)grad_ws, conics, opacities, opacity_is_logit, colors_pre_clamp, v_xy,
                                v_conic, v_colors, v_opacity);
     }
     sgn_timing_end(SGN_T_UNPACK, s);
@@ -1646,20 +1635,6 @@ SGN_EXPORT int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int6
     return raster_bwd_impl(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi, window, background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors, v_opacity, recs_ws, recs_ws_bytes, recs_packed, grad_ws, grad_ws_bytes, tile_order, colors_pre_clamp, opts, stream, aux_stream, 0, 0);
 }
 
-// internal (api.cpp sgn_rasterize_bwd_all, first = 2): sgn_raster_bwd on a workspace the caller knows to be all zeros
-int sgn_raster_bwd_on_clean_ws(int img_h, int img_w, int block_width, int n, int64_t n_isect,
-                               const int32_t *gaussian_ids_sorted, const int32_t *tile_bins, const float *xys,
-                               const float *conics, const float *colors, const float *opacities,
-                               int opacity_is_logit, int id_lo, int id_hi, int window, const float *background3,
-                               const float *final_Ts, const int32_t *final_idx,
-                               const float *v_out_img, const float *v_out_alpha, float alpha_clamp_bwd,
-                               float *v_xy, float *v_conic, float *v_colors, float *v_opacity, void *recs_ws,
-                               size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
-                               const int32_t *tile_order, const float *colors_pre_clamp,
-                               const sgn_raster_opts *opts, sgn_stream_t stream, sgn_stream_t aux_stream) {
-    return raster_bwd_impl(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi, window, background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors, v_opacity, recs_ws, recs_ws_bytes, recs_packed, grad_ws, grad_ws_bytes, tile_order, colors_pre_clamp, opts, stream, aux_stream, 1, 0);
-}
-
 // One of SEVERAL reverse walks whose gradients belong to the same tensors (the main pass of sgn_raster_fwd_groups and the
 // group accumulations that reached the loss): all of them accumulate into ONE packed gradient workspace and the last one
 // unpacks — instead of a 48 MB clear, an unpack and four tensor additions per extra walk.  `first` != 0 clears the
@@ -1677,6 +1652,5 @@ SGN_EXPORT int sgn_raster_bwd_part(int img_h, int img_w, int block_width, int n,
                               const sgn_raster_opts *opts, sgn_stream_t stream, sgn_stream_t aux_stream,
                                    int first, int last) {
     SGN_ARG_CHECK(!window, -13);
-    // first: 1 = clear the workspace, 2 = the caller KNOWS it is all zeros (every unpack leaves it so): no clear, 0 = keep
-    return raster_bwd_impl(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi, window, background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors, v_opacity, recs_ws, recs_ws_bytes, recs_packed, grad_ws, grad_ws_bytes, tile_order, colors_pre_clamp, opts, stream, aux_stream, first == 1 ? 0 : 1, last ? 0 : 1);
+    return raster_bwd_impl(img_h, img_w, block_width, n, n_isect, gaussian_ids_sorted, tile_bins, xys, conics, colors, opacities, opacity_is_logit, id_lo, id_hi, window, background3, final_Ts, final_idx, v_out_img, v_out_alpha, alpha_clamp_bwd, v_xy, v_conic, v_colors, v_opacity, recs_ws, recs_ws_bytes, recs_packed, grad_ws, grad_ws_bytes, tile_order, colors_pre_clamp, opts, stream, aux_stream, first ? 0 : 1, last ? 0 : 1);
 }

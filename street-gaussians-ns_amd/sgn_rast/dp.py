@@ -209,7 +209,7 @@ class GradAllReducer:
         self._exposed = {}              # label -> [sum ms, count]
         self._early = None              # (count event state) of this step's forward-time announcement
         self._mark = None               # persistent device buffers of sgn_mark_walked
-        self._check_pinned = None       # [pinned int64[4], next slot]: where the contract check's verdict lands
+        self._check_pinned = None       # [pinned int32[4, world], next slot]: where the contract check's counts land
         if sh_exchange is not None:
             sh_exchange._span_fn = self._span
         # ADAPTIVE (round 6): content that does not saturate its tiles (street-like: 79 % of the rows touched) sends every
@@ -511,7 +511,8 @@ class GradAllReducer:
         # exchange has been queued behind it (round 6: the host read used to sit here, in front of a dozen launches that
         # the device then waited for one by one — 0.2 ms per step at 1 M Gaussians; nothing queued below touches `.grad`
         # before the verdict is in)
-        check = self._check_launch(rows_p, widths, c, n, dev) if (sparse and hip and self._check_due()) else None
+        check_due = bool(sparse and hip and self._check_due())
+        check = None
         if not sparse:
             self.stats["dense_steps"] += 1
             self._too_dense = True        # (decided from all-gathered values: the same on every rank)
@@ -535,6 +536,8 @@ class GradAllReducer:
             L.check(lib.sgn_rows_pack(count if list32 is not None else 0, L.ptr(list32), nt,
                                       (C.c_void_p * nt)(*[None if t is None else t.data_ptr() for t in srcs]), wid,
                                       L.ptr(cam.contiguous()), L.ptr(send), row_words, L.stream_ptr()), "sgn_rows_pack")
+            if check_due:      # the count lands in word 3 of the header row the pack kernel has just written (spare: zero)
+                check = self._check_launch(rows_p, widths, c, n, dev, send[0, 3:4].view(torch.int32))
         else:
             send = torch.zeros(1 + maxc, row_words, dtype=torch.float32, device=dev)
             send[0, :3] = cam
@@ -545,6 +548,8 @@ class GradAllReducer:
         got = _all_gather_sync(send, self.group, wait=False)            # [world, 1 + maxc, 1 + W]
         with self._span("rows_all_gather"):
             got = got()                                                 # wait (stream-ordered on RCCL)
+        if check is not None:
+            self._check_gathered(check, got)
         v_all = torch.zeros(self.world, n, 3, dtype=torch.float32, device=dev)
         if hip:
             flat = torch.zeros(n * sum(widths), dtype=torch.float32, device=dev)       # one fill for every dense sum
@@ -574,6 +579,7 @@ class GradAllReducer:
         low = ex.multi_fn(degree, k, None, means, cams, None, None, v_all, scale)
         low = low if isinstance(low, tuple) else (low[:, 0:1, :], low[:, 1:, :])
         if check is not None and not self._check_verdict(check):
+            self.stats["dense_steps"] += 1
             return False                  # a row outside the list: the dense sequence, on the gradients as they were
         pending = [(dist.all_reduce(p.grad if p.grad is not None else _zero_grad(p), op=self._op, group=self.group,
                                     async_op=True), p) for p in other]
@@ -602,13 +608,13 @@ class GradAllReducer:
         self._sparse_seen += 1
         return self._checked_steps < k or self._sparse_seen % k == 0
 
-    def _check_launch(self, rows_p, widths, c, n, dev):
+    def _check_launch(self, rows_p, widths, c, n, dev, outside):
         """The checked mode of the row exchange (see `sparse_check`), first half: one pass over the gradients against the
-        forward's marks, a MAX all-reduce of the count, its copy to pinned memory — all queued, nothing waited for."""
+        forward's marks, counting into `outside` — an int32 view of word 3 of this rank's header row of the row
+        all-gather — queued, nothing waited for."""
         import ctypes as C
         from . import _lib as L
         m = self._mark
-        outside = torch.zeros(1, dtype=torch.int32, device=dev)
         f32c = lambda t: t if (t.dtype is torch.float32 and t.is_contiguous()) else t.to(torch.float32).contiguous()
         srcs = [None if p.grad is None else f32c(p.grad.detach()) for p in rows_p]
         nt = len(rows_p)
@@ -623,29 +629,31 @@ class GradAllReducer:
                 # node): not a passed check — the step goes dense on every rank
                 checkable = False
                 outside.fill_(_UNCHECKABLE)
-        worst = outside.to(torch.int64)
-        if dist.get_backend(self.group) == "gloo" and worst.is_cuda:
-            host = worst.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
-            return dict(host=host, checkable=checkable)
-        dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=self.group)          # stream-ordered on RCCL: no host wait
-        if not worst.is_cuda:
-            return dict(host=worst, checkable=checkable)
-        if self._check_pinned is None:
-            self._check_pinned = [torch.zeros(4, dtype=torch.int64).pin_memory(), 0]
-        slot = self._check_pinned[0][self._check_pinned[1] % 4:self._check_pinned[1] % 4 + 1]
+        # no collective of its own (round 6): the count rides in word 3 of this rank's header row of the row all-gather,
+        # and every rank takes the MAX over the gathered headers — the same verdict everywhere, one collective fewer
+        return dict(outside=outside, checkable=checkable, keep=srcs)
+
+    def _check_gathered(self, token, got) -> None:
+        """The gathered header rows hold every rank's count (word 3): stage them to pinned memory behind the all-gather."""
+        words = got[:, 0, 3].contiguous().view(torch.int32)
+        if not words.is_cuda:
+            token["host"] = words.to(torch.int64)
+            return
+        if self._check_pinned is None or self._check_pinned[0].shape[1] < self.world:
+            self._check_pinned = [torch.zeros(4, max(self.world, 1), dtype=torch.int32).pin_memory(), 0]
+        slot = self._check_pinned[0][self._check_pinned[1] % 4][: self.world]
         self._check_pinned[1] += 1
-        slot.copy_(worst, non_blocking=True)
+        slot.copy_(words, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
-        return dict(host=slot, done=done, checkable=checkable, keep=(worst, outside, srcs))
+        token.update(host=slot, done=done, keep2=words)
 
     def _check_verdict(self, token) -> bool:
         """Second half: False — identically on every rank — when some rank holds a non-zero gradient row the forward did
         not list ("always": this step goes dense; an integer k: the exchange is switched off for good)."""
         if token.get("done") is not None:
             token["done"].synchronize()
-        worst = int(token["host"].item())
+        worst = int(token["host"].max().item())
         if worst >= _UNCHECKABLE:
             self.stats["uncheckable_steps"] += 1
             return False
@@ -788,6 +796,28 @@ class GradAllReducer:
         if lo_hi[0] != -lo_hi[1]:
             raise RuntimeError("GradAllReducer.finish(absent=...): the ranks name DIFFERENT absent sets — the set must come "
                                "from replicated information (the frame's annotations), identically on every rank")
+
+    def suspended(self):
+        """Context manager: a backward pass that does NOT belong to a step of this reducer (a gradient taken for inspection,
+        a reference step of a cross-check) — the overlap hooks, the gradient arena and the forward announcement stay idle
+        inside the block.  (The contract otherwise is exactly one backward pass between two finish() calls.)"""
+        import contextlib
+        reducer = self
+
+        @contextlib.contextmanager
+        def _cm():
+            from . import ops
+            saved = (reducer.overlap, reducer.zero_copy, ops._touch_sink)
+            reducer.overlap, reducer.zero_copy = False, False
+            if ops._touch_sink is reducer:
+                ops._touch_sink = None
+            try:
+                yield reducer
+            finally:
+                reducer.overlap, reducer.zero_copy = saved[0], saved[1]
+                if saved[2] is reducer:
+                    ops._touch_sink = reducer
+        return _cm()
 
     def remove(self) -> None:
         """Detach the overlap hooks and the forward sink (a reducer that is being replaced)."""

@@ -146,7 +146,6 @@ class _State:
         self.stat_skipped = 0          # binnings since the statistic was last read back (every eighth one carries it)
         self.eager_side = None         # [pinned int32[8] ring for the eager flag read-back, next slot]
         self.quat_flag = None          # [device int32[1] zeroed once, stamp of the last call] (sgn_project_fwd_all)
-        self.gws, self.gws_clean = None, False     # persistent packed-gradient workspace of the one-call backward
         self.quat_ring = None          # [pinned int32[32]: eight (failed, landed, complete, -) slots of that call, next slot]
         self.depth_state = {"want": False, "unused": 0, "cache": None}
         self.depth_caches = collections.OrderedDict()                  # binning key -> first pass's channel + state
@@ -1449,16 +1448,6 @@ def _forward_composite(S, key, _t, cull, n, xys_c, depths, radii, conics_c, colo
     return count, ids, tile_bins, order, tile_kmax, rows
 
 
-def _clean_workspace(S, nbytes: int, dev) -> torch.Tensor:
-    """The persistent gradient workspace of this (device, stream): zero-filled once, kept all zeros by the unpack kernel
-    (it zeroes every row it finds something in), handed to the backward calls with `first = 2` while `S.gws_clean`."""
-    g = S.gws
-    if g is None or g.numel() != max(int(nbytes), 256) or g.device != dev:
-        g = S.gws = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
-        S.gws_clean = True
-    return g
-
-
 def _order_scratch(S, lib, n_tiles, dev):
     """The persistent zero-filled scratch of the multi-workgroup tile order (one per stream and tile count)."""
     if not (tile_order_enabled and tile_order_multiblock):
@@ -1864,14 +1853,10 @@ class _RasterizeGaussians(Function):
             # `out` / `part`: one walk of a sequence that accumulates into one gradient workspace (sgn_raster_bwd_part):
             # out = (v_xy, v_conic, v_colors, v_opacity, workspace) shared by the sequence, part = (first, last)
             lib = L.load()
-            fresh = out is None
-            if fresh:
-                # the packed gradient workspace: with the one-call backward a PERSISTENT buffer of this (device, stream)
-                # that every unpack leaves all zeros (round 6: no 48 MB clear per backward); a scratch tensor otherwise
-                gws = (_clean_workspace(_S(), lib.sgn_raster_bwd_workspace_bytes(ctx.n_full), dev) if composite_backward
-                       else L.workspace(lib.sgn_raster_bwd_workspace_bytes(ctx.n_full), dev))
+            if out is None:
                 out = (torch.empty(n, 2, **f32), torch.empty(n, 3, **f32), torch.empty(n, 3, **f32),
-                       _leaf_grad(getattr(ctx, "arena_leaves", None), 0, (n,), f32), gws)
+                       _leaf_grad(getattr(ctx, "arena_leaves", None), 0, (n,), f32),
+                       L.workspace(lib.sgn_raster_bwd_workspace_bytes(ctx.n_full), dev))
             v_xy, v_conic, v_colors, v_opacity, gws = out
             ro_ptr = C.byref(ctx.ro)
             packed = 1
@@ -1893,11 +1878,6 @@ class _RasterizeGaussians(Function):
                 if order is not None and not window and id_range == (0, n):
                     S.walk_stat = order[-1:]         # rides to the host with the next binning's count (mask policy)
                 first, last = (1, 1) if part is None else (int(part[0]), int(part[1]))
-                S.gws_clean = S.gws_clean if S.gws is gws else False
-                if first and S.gws is gws and S.gws_clean:
-                    first = 2                        # left all zeros by the last unpack: no clear
-                if S.gws is gws:
-                    S.gws_clean = False              # (until this sequence's unpack has been queued)
                 L.check(lib.sgn_rasterize_bwd_all(
                     H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(ids), L.ptr(bins), L.ptr(kmax),
                     int(pairs_known), L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity),
@@ -1908,8 +1888,6 @@ class _RasterizeGaussians(Function):
                     4 * scratch.numel() if scratch is not None else 0, int(small_splat_q16), L.ptr(pre), ro_ptr,
                     L.stream_ptr(), L.aux_stream_ptr(dev) if concurrent_backward else None, first, last),
                     "sgn_rasterize_bwd_all")
-                if last and S.gws is gws:
-                    S.gws_clean = True
                 composite_stats["backwards"] += 1
                 return out
             order = _tile_order(bins, kmax, ctx.ro.adapt_bwd, pairs_known=pairs_known)

@@ -401,6 +401,16 @@ def _arena_worker(rank, world, port, outdir):
         # own before AccumulateGrad sees them (its in-place add needs sole ownership of the STORAGE, which a slice of the
         # flat buffer never has); step 2: everything accumulates into the slices it already holds
         assert red.stats["bucket_copies"] == 4 and red.stats["bucket_in_place"] == 5, red.stats
+        # a backward that is NOT a step of the reducer (a gradient taken for inspection): inside `suspended()` the hooks and
+        # the arena stay idle, and the next real step is not mistaken for a second backward
+        a.grad = b.grad = c.grad = None
+        with red.suspended():
+            (Node.apply(a, 1.0).sum() + Node.apply(b, 1.0).sum() + c.sum()).backward()
+        assert red._bucket is None and a.grad.untyped_storage().data_ptr() != red._flat.untyped_storage().data_ptr()
+        a.grad = b.grad = c.grad = None
+        (Node.apply(a, 1.0).sum() + Node.apply(b, 1.0).sum() + c.sum()).backward()
+        red.finish()
+        assert torch.equal(a.grad, torch.ones_like(a)) and torch.equal(c.grad, torch.ones_like(c))
         red.remove()
         assert ops._grad_arena is None
         out[overlap] = steps

@@ -374,15 +374,18 @@ def test_row_exchange_counts_sub_model_passes_as_views():
     hold: the sink counts it as another view (and `_finish_sparse` then refuses the step instead of dropping rows)."""
     from types import SimpleNamespace
     from sgn_rast import dp
-    r = SimpleNamespace(sparse=True, active=True, _early=dict(views=1))
+    r = SimpleNamespace(sparse=True, active=True, _rows_now=True, _early=dict(views=1))
     dp.GradAllReducer.extra_pass(r)
     assert r._early["views"] == 2
-    r = SimpleNamespace(sparse=True, active=True, _early=None)
+    r = SimpleNamespace(sparse=True, active=True, _rows_now=True, _early=None)
     dp.GradAllReducer.extra_pass(r)                       # before the step's full pass: remembered for finish()
     assert r._extra_before is True
-    r = SimpleNamespace(sparse=False, active=True, _early=dict(views=1))
+    r = SimpleNamespace(sparse=False, active=True, _rows_now=False, _early=dict(views=1))
     dp.GradAllReducer.extra_pass(r)
     assert r._early["views"] == 1
+    r = SimpleNamespace(sparse=True, active=True, _rows_now=False, _early=dict(views=1))   # a DENSE step of the adaptive
+    dp.GradAllReducer.extra_pass(r)                                                         # reducer (round 6): nothing
+    assert r._early["views"] == 1                                                           # is announced, nothing counted
 
 
 def test_memo_remembers_pure_host_functions_by_value():
