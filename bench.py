@@ -963,7 +963,8 @@ def main():
             roof_extra["hbm_measured"] = {"traffic_bytes": traffic, "GBps": traffic / dur_s / 1e9,
                                           "frac": traffic / dur_s / 1e9 / HBM_PEAK_GBS, "source": pmc.get("hbm_source"),
                                           "traffic_over_processed": traffic / processed if processed else None}
-        if pmc is not None and "valu" in pmc and walk is not None and dur_s > 0:
+        if (pmc is not None and "valu" in pmc and walk is not None and dur_s > 0
+                and pmc["valu"].get("valu_insts_per_pair") is not None):
             v = pmc["valu"]
             # live part: this run's launch duration and pair count; PMC part: instructions per evaluated pair, the
             # mix-weighted issue cycles per wave-instruction (calibrated microbenchmark) and the profiled clock

@@ -115,7 +115,11 @@ def main(tag):
            "calibration": cost, "workloads": {}}
     for wkey, suf in WORKLOADS.items():
         files = [os.path.join(P, f"{tag}_pmc_{x}{suf}.md") for x in ("a", "b", "fetch_size", "write_size")]
+        # the bench line of the same workload gives the evaluated-pair count (deterministic per scene): of this tag's
+        # call, or — argv[2] — of the call whose bench set this counter campaign belongs to
         bench_file = os.path.join(P, f"{tag}_bench_{'default' if wkey == 'metric' else suf[1:]}.json.log")
+        if not os.path.exists(bench_file) and BENCH_TAG:
+            bench_file = os.path.join(P, f"{BENCH_TAG}_bench_{'default' if wkey == 'metric' else suf[1:]}.json.log")
         if not all(os.path.exists(f) for f in files):
             continue
         a, b, fs, ws = (table(f) for f in files)
@@ -180,6 +184,8 @@ def cal_frac(cal, k):
     v = find(cal, k)
     return v["SQ_ACTIVE_INST_VALU"] / (v["GRBM_GUI_ACTIVE"] / XCDS * SIMDS)
 
+
+BENCH_TAG = sys.argv[2] if len(sys.argv) > 2 else None
 
 if __name__ == "__main__":
     main(sys.argv[1] if len(sys.argv) > 1 else "r03b")
