@@ -87,6 +87,8 @@ inline hipError_t spin_wait(Ready ready, hipStream_t s) {
         if (ready()) break;
         __builtin_ia32_pause();
         if ((it & 1023u) == 0) {
+            (void)hipStreamQuery(s);          // (a runtime that batches submissions flushes on a query; a no-op otherwise)
+            (void)hipGetLastError();          // hipErrorNotReady is the expected answer: not an error of the next launch
             clock_gettime(CLOCK_MONOTONIC, &b);
             if ((b.tv_sec - a.tv_sec) * 1e6 + (b.tv_nsec - a.tv_nsec) * 1e-3 > SPIN_FALLBACK_US) {
                 e = hipStreamSynchronize(s);

@@ -391,7 +391,9 @@ def rasterize_gaussians_fused(xys, depths, radii, conics, num_tiles_hit, colors,
             accs = (zero, main[1]) if s == 0 else (main[1], zero)
             return main[0], main[1], (main[2] if depth_channel else None), accs[0], accs[1]
         if group_accumulation_enabled and block_width == 16:
-            return _RasterizeGaussians.apply(*args, True, True, None, bool(depth_channel), False, None, s)
+            out = _RasterizeGaussians.apply(*args, True, True, None, bool(depth_channel), False, None, s)
+            # (the drop-in surface's own policy — option depth_channel=on — may have accumulated the channel unasked)
+            return out[0], out[1], (out[2] if depth_channel else None), out[3], out[4]
         main = _RasterizeGaussians.apply(*args, True, True, None, bool(depth_channel))
         accs = [_RasterizeGaussians.apply(*args, True, True, (lo, hi), False)[1] if hi > lo
                 else torch.zeros(img_height, img_width, dtype=torch.float32, device=xys.device)

@@ -1594,7 +1594,9 @@ class _RasterizeGaussians(Function):
         # a sub-model's copy of a window of the cached scene?  (drop-in scene-graph path; see _match_window)
         n_full, window, win = num_points, 0, None
         wcomp = None
-        if id_range is None and not hit and _bin_pending["key"] != key:
+        if id_range is None and not hit and _bin_pending["key"] != key and not want_depth:
+            # (an explicit depth request is never served as a window of another scene: the window's tensors are
+            # window-local, the channel's depths would be read at full-scene ids — it is binned as a scene of its own)
             cand = None
             if (composite_forward and tile_order_enabled and group_split is None and not want_depth
                     and depths.dtype is torch.float32 and radii.dtype is torch.int32
@@ -1625,7 +1627,14 @@ class _RasterizeGaussians(Function):
                  and colors_c.shape == (num_points, 3) and dcache["D"].shape == (img_height, img_width))
         if plain and hit and not reuse and depth_channel == "auto" and not want_depth:
             _depth_state["want"] = True        # a second pass over the same geometry: accumulate from the next step on
-        accumulate = plain and not reuse and not hit and (want_depth or _depth_wanted())
+        # `want_depth` (the fused API's depth_channel=True) is an explicit request: the channel is accumulated whatever the
+        # binning's history — a cached list, culling switched off, an id_range pass (round 6: such calls used to get a zero
+        # image; a call that asks for depth is not matched as a window of another scene, see above).  The
+        # "auto" policy of the drop-in surface accumulates on a plain, freshly binned pass only, and only such a pass's
+        # image may answer a later depth pass (`depth_cacheable`).
+        explicit = bool(want_depth) and win is None and num_points > 0
+        accumulate = (not reuse) and (explicit or (plain and not hit and _depth_wanted()))
+        depth_cacheable = accumulate and plain and not hit
         depths_c = _f32c(depths) if (reuse or accumulate) else None
         skip_flag = None
         proved = bool(reuse and colors_are_depths)      # the host knows: no flag, no conditional launches, no copies
@@ -1655,7 +1664,7 @@ class _RasterizeGaussians(Function):
                 final_Ts = torch.ones(img_height, img_width, **f32)
                 final_idx = torch.zeros(img_height, img_width, dtype=torch.int32, device=dev)
                 gaussian_ids_sorted = torch.zeros(0, dtype=torch.int32, device=dev)
-            if accumulate and num_intersects >= 1:
+            if accumulate and num_intersects >= 1:      # (the composite serves plain fresh passes only: cacheable)
                 depth_stats["accumulated"] += 1
                 S.depth_caches[key] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
                 while len(S.depth_caches) > _State.BIN_ENTRIES:
@@ -1747,6 +1756,7 @@ class _RasterizeGaussians(Function):
                 ctx.groups = groups
                 if accumulate:
                     depth_stats["accumulated"] += 1
+                if depth_cacheable:
                     S.depth_caches[key] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)
                     while len(S.depth_caches) > _State.BIN_ENTRIES:
                         S.depth_caches.popitem(last=False)
@@ -1772,6 +1782,8 @@ class _RasterizeGaussians(Function):
                     recs = None                    # the rows were not built if the flag said "reuse": the backward packs them
                     depth_stats["reused"] += 1
                     _depth_state["unused"] = 0
+                elif accumulate and not depth_cacheable:
+                    depth_stats["accumulated"] += 1            # an explicit request on a cached list / an id range: not kept
                 elif accumulate:
                     depth_stats["accumulated"] += 1
                     S.depth_caches[key] = dict(key=key, D=out_depth, T=final_Ts, idx=final_idx, kmax=tile_kmax)

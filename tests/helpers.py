@@ -1,4 +1,6 @@
 """Shared builders for the parity tests (CPU tensors; the GPU tests move them over)."""
+import os
+
 import torch
 
 from sgn_rast import scenes
@@ -80,3 +82,15 @@ def assert_image_bounded(got, exp, adjacent, what, max_abs=1e-4, max_adjacent_fr
           f"mean|err| {float(err.mean()):.2e}")
     assert n_adj <= max_adjacent_frac * n, (what, n_adj, n)
     assert worst <= max_abs, (what, worst)
+
+
+def init_single_rank_group(backend: str = "nccl") -> None:
+    """`torch.distributed` group of ONE rank for the GPU tests of the data-parallel path, through a FILE store: a free
+    TCP port found by binding to port 0 can be taken again before the store listens on it (EADDRINUSE, seen twice in
+    the round-6 suite runs)."""
+    import tempfile
+    import torch.distributed as dist
+    fd, path = tempfile.mkstemp(prefix="sgn_pg_")
+    os.close(fd)
+    os.unlink(path)                       # the FileStore creates it
+    dist.init_process_group(backend, init_method=f"file://{path}", rank=0, world_size=1)

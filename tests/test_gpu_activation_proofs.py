@@ -194,6 +194,7 @@ def _scene_graph_step(on, one_call=True):
         ops.activation_proofs, ops.sh_split_backward, ops.composite_forward, ops.composite_backward = old
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 @pytest.mark.parametrize("one_call", [True, False], ids=["one call per node", "call by call"])
 def test_scene_graph_aggregates_are_proven_and_gradients_equal_the_chain_through_torch(one_call):
     a, Ma, fa = _scene_graph_step(True, one_call)
@@ -241,6 +242,7 @@ def test_alpha_only_pass_hands_autograd_no_colour_gradient():
     assert opac.grad is not None and float(opac.grad.abs().sum()) > 0
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 def test_hooks_placed_after_the_call_see_the_documented_outcome():
     """The proofs are evaluated when the operator is called.  A hook or `retain_grad()` placed on an
     activated tensor BEFORE the call refuses the proof (the tensor then receives its gradient as usual); one placed

@@ -16,7 +16,8 @@ import torch
 
 from helpers import rel_l2, small_scene
 
-pytestmark = pytest.mark.gpu
+# the mechanism under test (and its statistics) is the DEFAULT configuration's: under SGN_OPTIONS=... put it back
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("library_defaults")]
 DEV = "cuda"
 
 
@@ -137,3 +138,31 @@ def test_fused_api_returns_the_two_pass_depth_image(mode):
     assert torch.equal(a.rgb, b.rgb) and torch.equal(a.alpha, b.alpha)
     assert torch.equal(a.depth, b.depth)
     assert float((b.depth != 10).float().mean()) > 0.3
+
+
+@pytest.mark.parametrize("culling", [True, False])
+def test_an_explicit_depth_request_is_served_whatever_the_binning_history(culling):
+    """`rasterize_gaussians_fused(depth_channel=True)` ASKS for the depth image: it must come on a freshly binned pass, on a
+    pass over the CACHED list of the same tensors (a second call), on an `id_range` pass and with tile culling switched off
+    — each equal, bit for bit, to the second rasterization it replaces (colours = depths).  Round 6: all but the first used
+    to return a zero image (found by running the suite under `SGN_OPTIONS=tile_culling=off`)."""
+    from sgn_rast import config, fused, ops, scenes, step
+    cam, raw = scenes.make_scene("c1", n_override=5000)
+    cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
+    P = {k: v.to(DEV) for k, v in raw.items()}
+    H, W, n = cam.height, cam.width, P["means"].shape[0]
+    bg = torch.zeros(3, device=DEV)
+    with torch.no_grad(), config.override(tile_culling=culling, depth_channel="off"):
+        ops.clear_binning_cache()
+        xys, depths, radii, conics, _c, nth, _cov = fused.project_gaussians_fused(
+            P["means"], P["log_scales"], P["quats"], cam.viewmat[:3, :], cam.fx, cam.fy, cam.cx, cam.cy, H, W, 16)
+        rgbs = fused.spherical_harmonics_fused(3, P["means"], cam.cam_pos, P["features_dc"], P["features_rest"])
+        geo = (xys, depths, radii, conics, nth)
+        for id_range in (None, (n // 4, (3 * n) // 4)):
+            two_pass = fused.rasterize_gaussians_fused(*geo, depths[:, None].repeat(1, 3), P["opacity_logits"], H, W, 16,
+                                                       background=bg, return_alpha=False, id_range=id_range)[..., 0]
+            assert float(two_pass.abs().max()) > 0
+            for call in ("first", "same tensors again"):
+                img, alpha, d = fused.rasterize_gaussians_fused(*geo, rgbs, P["opacity_logits"], H, W, 16, background=bg,
+                                                                return_alpha=True, depth_channel=True, id_range=id_range)
+                assert torch.equal(d, two_pass), (culling, id_range, call)

@@ -6,7 +6,7 @@ import socket
 import pytest
 import torch
 
-from helpers import rel_l2
+from helpers import init_single_rank_group, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -40,6 +40,7 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 @pytest.mark.parametrize("fused", [False, True])
 def test_exchange_and_reducer_over_single_rank_rccl_group(fused):
     """world_size = 1 RCCL group: the collectives are trivial, but every call the 8-GPU run makes is made here
@@ -47,7 +48,7 @@ def test_exchange_and_reducer_over_single_rank_rccl_group(fused):
     import torch.distributed as dist
     from sgn_rast import dp, scenes, step
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    init_single_rank_group()
     try:
         cam, raw = scenes.make_scene("c1", n_override=5000)
         cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
@@ -88,6 +89,7 @@ def test_exchange_and_reducer_over_single_rank_rccl_group(fused):
         dist.destroy_process_group()
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 def test_zero_copy_bucket_over_the_ways_a_loop_resets_gradients():
     """The flat bucket's slices ARE the `.grad` tensors (dp.GradAllReducer.arena_for).  Three loops: `.grad = None` every step
     (the reference's, set_to_none=True) — produced in place every step; gradients KEPT and accumulated over two steps (no
@@ -97,7 +99,7 @@ def test_zero_copy_bucket_over_the_ways_a_loop_resets_gradients():
     import torch.distributed as dist
     from sgn_rast import config, dp, scenes, step
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    init_single_rank_group()
     try:
         cam, raw = scenes.make_scene("c1", n_override=5000)
         cam.viewmat, cam.cam_pos = cam.viewmat.to(DEV), cam.cam_pos.to(DEV)
@@ -190,7 +192,7 @@ def test_row_exchange_over_single_rank_rccl_group():
     import torch.distributed as dist
     from sgn_rast import dp, ops, scenes, step
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    init_single_rank_group()
     try:
         for n, frac, expect in ((40000, 0.9, "sparse"), (3000, 0.05, "dense")):
             cam, raw = scenes.make_scene("c1", n_override=n)
@@ -244,7 +246,7 @@ def test_row_exchange_at_the_benchmark_size_equals_the_plain_step(name):
     ops.clear_binning_cache()
     step.train_step(Pa, cam, w_img, w_a)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    init_single_rank_group()
     try:
         Pb = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
         ex = dp.SHGradExchange(Pb["features_dc"], Pb["features_rest"], force=True).install().set_view(Pb["means"], cam.cam_pos)
@@ -298,7 +300,7 @@ def test_row_exchange_contract_check_catches_gradient_rows_outside_the_walk(mode
     import torch.distributed as dist
     from sgn_rast import dp, ops, scenes, step
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    init_single_rank_group()
     try:
         n = 40000
         cam, raw = scenes.make_scene("c1", n_override=n)
@@ -345,7 +347,7 @@ def test_row_exchange_checks_every_step_so_a_periodic_loss_term_is_never_dropped
     import torch.distributed as dist
     from sgn_rast import dp, ops, scenes, step
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    init_single_rank_group()
     try:
         n = 40000
         cam, raw = scenes.make_scene("c1", n_override=n)
@@ -392,7 +394,7 @@ def test_row_exchange_with_a_per_gaussian_parameter_that_gets_no_gradient():
     import torch.distributed as dist
     from sgn_rast import dp, ops, scenes, step
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    init_single_rank_group()
     try:
         n = 40000
         cam, raw = scenes.make_scene("c1", n_override=n)

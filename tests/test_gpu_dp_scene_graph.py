@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import sg_dp
-from helpers import TorchStats, rel_l2
+from helpers import TorchStats, init_single_rank_group, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -24,7 +24,7 @@ def _free_port():
 def rccl_single_rank():
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("nccl", rank=0, world_size=1)
+    init_single_rank_group()
     yield dist
     dist.destroy_process_group()
 

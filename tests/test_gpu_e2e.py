@@ -163,6 +163,7 @@ def test_single_rank_dp_reducer_is_a_noop():
         assert rel_l2(P[k].grad, g[k]) < 1e-5
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 def test_binning_cache_reuse_and_invalidation():
     """RGB pass then depth pass on the same projection share one binning; a changed xys (new version
     or new tensor) must not hit the cache."""
@@ -222,6 +223,7 @@ def test_binning_cache_reuse_and_invalidation():
         ops.clear_binning_cache()
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 def test_speculative_binning_hits_misses_and_equals_the_plain_form():
     """Emission and tile sort are queued before the host knows the intersection count, into buffers sized from the
     previous call (ops._bin_finish).  The result must be the plain form's bit for bit whether the guess fits (hit,
@@ -324,6 +326,7 @@ def test_quat_assertion_deferred_and_eager():
         ops._pending_checks.clear()
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 def test_early_depth_rank_is_picked_up_and_changes_nothing():
     """`project_gaussians` queues the depth ranking behind the projection (default with the eager argument check); the
     `rasterize_gaussians` call on the same depths / radii must pick it up (`sgn_bin_prepare(rank_ready=1)`) and
@@ -369,6 +372,7 @@ def test_early_depth_rank_is_picked_up_and_changes_nothing():
         ops._early.update(entry=None, misses=0, pause=0)
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 def test_two_models_interleaved_on_one_stream_keep_their_binnings():
     """the host-side caches were one-entry module globals — two models taking turns on one stream
     re-binned on every call.  The state is now per (device, stream) with a short LRU: A, B, A-depth, B-depth must bin
@@ -454,6 +458,7 @@ def test_non_finite_gradients_on_uncovered_pixels_do_not_reach_any_gaussian():
         assert rel_l2(b, a) < 1e-5
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 def test_one_call_forward_equals_the_call_by_call_path():
     """`sgn_rasterize_fwd_all` (one C-ABI call per autograd node, round 5) runs the same kernels in the same order as the
     sequence the host otherwise drives call by call: list, bins, image, per-pixel state and gradients are BIT-EQUAL
@@ -519,6 +524,7 @@ def test_one_call_forward_equals_the_call_by_call_path():
     ops.quat_check = old_check
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 def test_one_call_scene_graph_passes_equal_the_call_by_call_path():
     """Round 6: EVERY raster call shape of the shipped scene-graph model is one C-ABI call per autograd node — the main
     pass with the depth channel riding it (`sgn_rasterize_fwd_all(out_depth)`), the objects-only / background-only passes

@@ -186,6 +186,7 @@ def test_id_range_pass_equals_sliced_pass(batch):
         L.set_options(batch_fwd=256, batch_bwd=128)
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 @pytest.mark.parametrize("one_call", [True, False], ids=["one call per node", "call by call"])
 def test_window_copies_reuse_the_cached_binning(one_call):
     """Drop-in scene-graph path: the sub-model passes receive torch.cat COPIES of per-model slices of the main

@@ -1,8 +1,8 @@
 """GPU (-m gpu): EVERY switch of the one options object (`sgn_rast.config.OPTIONS`) at every non-default value, on the
 driver's box ("parametrise the driver's pytest -m gpu over every switch that survives"; rounds 2-5
 exercised non-default configurations in builder runs only).  Per value: the reference's call-site replay of the SINGLE
-model (colour pass + the depth pass) and of the SCENE GRAPH (four raster passes, windows, Fourier DC), fwd + bwd, against
-the C oracle at the parity tolerances — a switch changes how results are computed, never what they are."""
+model (colour pass + the depth pass) and of the SCENE GRAPH (four raster passes, windows, Fourier DC), drop-in AND fused
+call patterns, fwd + bwd, against the C oracle at the parity tolerances — a switch changes how results are computed, never what they are."""
 import pytest
 import torch
 
@@ -42,13 +42,22 @@ def expected():
     sg = step.render_scene_graph(Ms, poses, idft, cam, ops=oracle_ops)
     ((sg.rgb * w_img).sum() + (sg.alpha * w_a).sum() + (sg.object_acc * w_a).sum() + 0.3 * (sg.background_acc * w_a).sum()
      + 1e-3 * sg.depth.sum()).backward()
-    return dict(cam=cam, raw=raw, w=(w_img, w_a), single=(single, P), models=models, poses=poses, idft=idft, sg=(sg, Ms))
+    # the fused API's depth image is an OUTPUT only (non-differentiable, as the reference uses it: visualisation): the fused
+    # scene-graph step is held to the oracle's step WITHOUT the depth term in the loss
+    Ms2 = [step.leaf_params(m) for m in models]
+    sg2 = step.render_scene_graph(Ms2, poses, idft, cam, ops=oracle_ops)
+    ((sg2.rgb * w_img).sum() + (sg2.alpha * w_a).sum() + (sg2.object_acc * w_a).sum()
+     + 0.3 * (sg2.background_acc * w_a).sum()).backward()
+    return dict(cam=cam, raw=raw, w=(w_img, w_a), single=(single, P), models=models, poses=poses, idft=idft, sg=(sg, Ms),
+                sg_no_depth_term=(sg2, Ms2))
 
 
 def _check_images(got, exp, names):
     for nm in names:
-        err = (getattr(got, nm).detach().cpu() - getattr(exp, nm).detach()).abs()
-        assert float(err.mean()) < 2e-6 and float((err > 1e-5).float().mean()) < 5e-3, (nm, float(err.mean()))
+        e = getattr(exp, nm).detach()
+        err = (getattr(got, nm).detach().cpu() - e).abs()
+        scale = max(1.0, float(e.abs().mean()))          # depth images hold metres (1-10), the others [0, 1]
+        assert float(err.mean()) < 2e-6 * scale and float((err > 1e-5 * scale).float().mean()) < 5e-3, (nm, float(err.mean()))
 
 
 @pytest.mark.parametrize("case", _cases(), ids=_ids)
@@ -78,6 +87,22 @@ def test_every_option_value_gives_the_oracles_results(case, expected):
             for i, (m, mc) in enumerate(zip(Ms, Mc)):
                 for k in m:
                     assert rel_l2(m[k].grad.cpu(), mc[k].grad) < 1e-4, (case, i, k)
+            # ... and the FUSED call patterns (what the integration patches make the reference call): the single model with
+            # the depth channel riding the colour pass, the scene graph with the two group accumulations on the main walk
+            # (round 6: the suite under SGN_OPTIONS=tile_culling=off found the fused depth image empty — this is its guard)
+            Pf = step.leaf_params({k: v.to(DEV) for k, v in raw.items()})
+            gotf = step.train_step(Pf, cam, w_img, w_a, with_depth=True, fused=True)
+            _check_images(gotf, exp, ("rgb", "alpha", "depth"))
+            for k in Pf:
+                assert rel_l2(Pf[k].grad.cpu(), Pc[k].grad) < 1e-4, (case, "fused", k)
+            Mf = [step.leaf_params({k: v.to(DEV) for k, v in m.items()}) for m in expected["models"]]
+            sgf = step.render_scene_graph(Mf, expected["poses"].to(DEV), expected["idft"].to(DEV), cam, fused=True)
+            ((sgf.rgb * w_img).sum() + (sgf.alpha * w_a).sum() + (sgf.object_acc * w_a).sum()
+             + 0.3 * (sgf.background_acc * w_a).sum()).backward()
+            _check_images(sgf, esg, ("rgb", "alpha", "object_acc", "background_acc", "depth"))
+            for i, (m, mc) in enumerate(zip(Mf, expected["sg_no_depth_term"][1])):
+                for k in m:
+                    assert rel_l2(m[k].grad.cpu(), mc[k].grad) < 1e-4, (case, "fused", i, k)
     torch.cuda.synchronize()
     assert config.current()[name] == config.OPTIONS[name][0] or name in config._from_env     # restored
 

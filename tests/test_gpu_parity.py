@@ -433,6 +433,7 @@ def test_uint8_colors_and_single_output(hip, c_oracle):
     assert float((img.cpu() - exp_img).abs().mean()) < 1e-6
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 @pytest.mark.parametrize("channels", [1, 2, 5, 7])
 def test_n_channel_colours_match_the_channel_generic_oracle(hip, c_oracle, torch_oracle, channels):
     """upstream's N-D rasterize path (D != 3): image, alpha and the gradients of every input against the channel-generic

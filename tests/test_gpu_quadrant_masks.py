@@ -155,6 +155,7 @@ def test_every_kernel_shape_renders_the_same_with_and_without_masks(mode, masks_
         assert rel_l2(g1[k].cpu(), g0[k].cpu()) < 1e-5, (k, rel_l2(g1[k].cpu(), g0[k].cpu()))
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 def test_window_pass_over_a_masked_list(masks_switch):
     """Scene-graph drop-in: a sub-model's tensors are rows of the scene the cached list was binned for; the pass runs over
     the cached (masked) list with the rows outside its window made inert — they must stay skipped, and the result must

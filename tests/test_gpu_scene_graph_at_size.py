@@ -133,11 +133,13 @@ def expected_whole(scene, production_defaults):
     return dict(out=exp, leaves=Mc, rows=(0, cam.height))
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 @pytest.mark.parametrize("path", ["dropin", "fused"])
 def test_scene_graph_step_matches_oracle_over_the_whole_image(path, scene, expected_whole, production_defaults):
     _run_and_compare(path, 1, scene, expected_whole, production_defaults)
 
 
+@pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
 @pytest.mark.parametrize("path", ["dropin", "fused"])
 @pytest.mark.parametrize("reduce_mode", [1, 0])
 def test_scene_graph_step_matches_oracle_at_size(path, reduce_mode, scene, expected, production_defaults):
