@@ -474,7 +474,7 @@ int sgn_raster_fwd_groups(int img_h, int img_w, int n, int64_t n_isect, const in
                           int split, int own_group, const int32_t *own_ids, const int32_t *own_bins /*[tiles,2]*/,
                           float *group_state, int32_t *group_stats, const sgn_raster_opts *opts, sgn_stream_t stream);
 /* ONE call per autograd node (round 5; no upstream counterpart: upstream's rasterize_gaussians drives its five `_C`
- * calls from Python).  The whole forward of `rasterize_gaussians` over the full scene in gather mode: sgn_bin_prepare ->
+ * calls from Python).  The whole forward of `rasterize_gaussians` over the full scene: sgn_bin_prepare ->
  * asynchronous read-back of the intersection count -> sgn_raster_build_rows -> SPECULATIVE sgn_bin_intersect (sized by
  * isect_capacity, the true count read on the device) -> wait for the count (the path's one host sync, upstream's
  * `.item()`) -> sgn_tile_order -> sgn_raster_fwd, all on `stream`, temporaries carved from ONE caller-provided arena
@@ -574,8 +574,8 @@ int sgn_raster_bwd(int img_h, int img_w, int block_width, int n, int64_t n_isect
                    float alpha_clamp_bwd, float *v_xy /*[n,2]*/, float *v_conic /*[n,3]*/,
                    float *v_colors /*[n,3]*/, float *v_opacity /*[n]*/, void *recs_ws,
                    size_t recs_ws_bytes, int recs_packed, void *grad_ws, size_t grad_ws_bytes,
-                   const int32_t *tile_order /*NULL, or sgn_tile_order(..., tile_stats, opts->adapt_bwd, ...): with
-                                               opts->waves_bwd == 0 its first n_long tiles (walks >= adapt_bwd) run four
+                   const int32_t *tile_order /*NULL, or sgn_tile_order(..., tile_stats, opts->adapt_bwd, ...): its
+                                               first n_long tiles (walks >= adapt_bwd) run four
                                                lean waves per tile, persistent and longest first, the rest one wave per
                                                tile; NULL = in-kernel split of long walks*/,
                    const float *colors_pre_clamp /*NULL, or [n,3] (window: [id_hi - id_lo, 3]): the caller's colours were
