@@ -661,6 +661,16 @@ def main():
                 "note": "chunk 1 is the line's `value` (exactly K steps, as the contract says); the others follow it"}
 
     dp_paths, safe_reducer = None, None
+    # the contract's LETTER first — exactly W warm-up steps, then K timed steps, nothing in front —
+    # reported beside the headline as `without_settle_steps`; the headline itself follows with the settle steps in front
+    # (for which this first measurement has then done part of the settling: the later figure is the steady one either way)
+    literal = None
+    if args.settle > 0 and world == 1 and not force_dp:
+        dt0, _ = measure_headline(0)
+        literal = {"value": args.steps / dt0, "unit": "images/sec", "ms_per_step": 1e3 * dt0 / args.steps,
+                   "note": f"the contract's letter: exactly {args.warmup} warm-up steps, then {args.steps} timed steps, "
+                           "straight after the host-side set-up (no settle steps): on some boxes a device that idled through "
+                           "the set-up runs this first chunk up to 30 % slow (profiles/r05aa_settle_ab.log)"}
     dt, out = measure_headline(args.settle)
     if safe_first:
         dt_safe, safe_reducer = dt, reducer
@@ -1071,6 +1081,8 @@ def main():
                                    "host-side set-up ran the first 20-step chunk 30 % slow on some boxes "
                                    "(profiles/r05aa_settle_ab.log); the timed region is exactly K steps between the two "
                                    "barrier + synchronize pairs, and `repeat` holds further chunks of exactly K steps")
+        if literal is not None:
+            line["without_settle_steps"] = literal
         from sgn_rast import config as sgn_config
         line["config"]["options"] = sgn_config.report()        # the ONE options object: what is not at its default
         line["config"]["quat_check"] = ops.quat_check
