@@ -317,6 +317,7 @@ class _SphericalHarmonicsSplit(Function):
         L.require_device(viewdirs, coeffs)
         num_points, k = coeffs.shape[0], coeffs.shape[-2]
         ctx.degrees_to_use, ctx.k, ctx.src = degrees_to_use, k, src
+        ctx.bypassed = _bypassed_refs()          # (the caller's torch.cat((dc, rest), 1) tensor)
         ctx.set_materialize_grads(False)
         deg_from_sh(k)
         viewdirs = _f32c(viewdirs)
@@ -337,6 +338,17 @@ class _SphericalHarmonicsSplit(Function):
         v_colors = _f32c(v_colors)
         f32 = dict(dtype=torch.float32, device=v_colors.device)
         lib = L.load()
+        by = getattr(ctx, "bypassed", ())
+        asked = _asked_for(by[0]) if by else None
+        if asked is not None:
+            # a hook / retain_grad placed on the concatenated coefficients AFTER the call: the dense gradient upstream
+            # returns, handed to autograd at that tensor (its hooks fire; cat / Fourier-sum backward reach the leaves)
+            v_coeffs = torch.empty(n, ctx.k, 3, **f32)
+            L.check(lib.sgn_sh_bwd(n, ctx.k, ctx.degrees_to_use, L.ptr(viewdirs), L.ptr(v_colors), L.ptr(v_coeffs),
+                                   L.stream_ptr()), "sgn_sh_bwd")
+            hooks_after_call_stats["sh"] += 1
+            torch.autograd.backward([asked], [v_coeffs.reshape(asked.shape)], retain_graph=True)
+            return (None,) * (4 + n_leaves)
         one_dc = src.dc[0].leaf if (len(src.dc) == 1 and src.dc[0].weights is None) else None
         v_dc = _leaf_grad(_arena_leaves(one_dc), 0, (n, 1, 3), f32)        # (a DP bucket member: produced in its slice)
         v_rest = torch.empty(n, ctx.k - 1, 3, **f32)
@@ -390,6 +402,7 @@ def spherical_harmonics(degrees_to_use: int, viewdirs: torch.Tensor, coeffs: tor
             _sh_memo = (weakref.ref(coeffs), src) if src is not None else None
         if src is not None:
             sh_split_stats["split"] += 1
+            _call_state.bypassed = (coeffs,)
             return _SphericalHarmonicsSplit.apply(degrees_to_use, _contig(viewdirs), coeffs.detach(), src,
                                                   *[p.leaf for p in src.dc], *src.rest)
     sh_split_stats["dense"] += 1
@@ -575,6 +588,7 @@ class _ProjectGaussiansAct(Function):
         means3d_c, scales_c, _q, viewmat_c, cov3d, radii, conics, compensation = saved
         ctx.leaf_rows = [v.shape[0] for v in log_scale_leaves]
         ctx.arena_leaves = _arena_leaves(means3d, log_scale_leaves[0] if len(log_scale_leaves) == 1 else None, x)
+        ctx.bypassed = _bypassed_refs()          # (the caller's exp(...) and normalised-quaternion tensors)
         ctx.save_for_backward(means3d_c, scales_c, x, viewmat_c, cov3d, radii, conics, compensation)
         return outs
 
@@ -587,6 +601,12 @@ class _ProjectGaussiansAct(Function):
         v_depths = _f32c(v_depths) if v_depths is not None else None
         v_conics = _f32c(v_conics) if v_conics is not None else torch.zeros(n, 3, **f32)
         v_comp = _f32c(v_compensation) if v_compensation is not None else None
+        by = getattr(ctx, "bypassed", ())
+        asked = [_asked_for(r) for r in by] if by else []
+        if any(t is not None for t in asked):
+            return _ProjectGaussiansAct._backward_through_the_callers_graph(
+                ctx, asked, (means3d, scales, x, viewmat, cov3d, radii, conics, compensation), v_xys, v_depths, v_conics,
+                v_comp)
         al = getattr(ctx, "arena_leaves", None)
         v_mean, v_ls, v_x = _leaf_grad(al, 0, (n, 3), f32), _leaf_grad(al, 1, (n, 3), f32), _leaf_grad(al, 2, (n, 4), f32)
         L.check(L.load().sgn_project_bwd_act(
@@ -595,6 +615,40 @@ class _ProjectGaussiansAct(Function):
             L.ptr(v_depths), L.ptr(v_conics), L.ptr(v_comp), L.ptr(v_mean), L.ptr(v_ls), L.ptr(v_x),
             ctx.sem, ctx.img_hw[0], ctx.img_hw[1], L.stream_ptr()), "sgn_project_bwd_act")
         v_leaves = (v_ls,) if len(ctx.leaf_rows) == 1 else v_ls.split(ctx.leaf_rows)
+        return (v_mean, None, None, None, None, None, None, None, None, None, None, None, None, v_x) + tuple(v_leaves)
+
+    @staticmethod
+    def _backward_through_the_callers_graph(ctx, asked, saved, v_xys, v_depths, v_conics, v_comp):
+        """A hook / retain_grad was placed on `scales` or `quats` AFTER the call (see `_asked_for`): the plain gradients
+        with respect to the activated values, from upstream's own backward kernel; a tensor that was asked for receives
+        its gradient through autograd (its hooks fire, the leaves behind it accumulate), the other one's activation is
+        differentiated here."""
+        means3d, scales, x, viewmat, cov3d, radii, conics, compensation = saved
+        n, dev = means3d.shape[0], means3d.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        norm = x.norm(dim=-1, keepdim=True)
+        q = asked[1].detach() if asked[1] is not None else x / norm       # the values the forward projected with
+        q = _f32c(q)
+        v_mean, v_scale, v_quat = torch.empty(n, 3, **f32), torch.empty(n, 3, **f32), torch.empty(n, 4, **f32)
+        L.check(L.load().sgn_project_bwd(
+            n, L.ptr(means3d), L.ptr(scales), ctx.glob_scale, L.ptr(q), L.ptr(viewmat), ctx.fx, ctx.fy,
+            L.ptr(cov3d), L.ptr(radii), L.ptr(conics), L.ptr(compensation), L.ptr(v_xys), L.ptr(v_depths),
+            L.ptr(v_conics), L.ptr(v_comp), None, None, L.ptr(v_mean), L.ptr(v_scale), L.ptr(v_quat),
+            ctx.sem, ctx.img_hw[0], ctx.img_hw[1], L.stream_ptr()), "sgn_project_bwd")
+        through, grads = [], []
+        if asked[0] is not None:
+            through.append(asked[0]); grads.append(v_scale.reshape(asked[0].shape))
+            v_leaves = (None,) * len(ctx.leaf_rows)
+        else:
+            v_ls = v_scale * scales                                        # d exp(l) / d l = exp(l)
+            v_leaves = (v_ls,) if len(ctx.leaf_rows) == 1 else v_ls.split(ctx.leaf_rows)
+        if asked[1] is not None:
+            through.append(asked[1]); grads.append(v_quat.reshape(asked[1].shape))
+            v_x = None
+        else:
+            v_x = (v_quat - q * (q * v_quat).sum(dim=-1, keepdim=True)) / norm       # d (x / |x|) / d x
+        hooks_after_call_stats["project"] += 1
+        torch.autograd.backward(through, grads, retain_graph=True)
         return (v_mean, None, None, None, None, None, None, None, None, None, None, None, None, v_x) + tuple(v_leaves)
 
 
@@ -753,6 +807,7 @@ def project_gaussians(means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, c
         x = proofs.normalised_source(quats) if ls_leaves is not None else None
     if x is not None:
         activation_proof_stats["project"] += 1
+        _call_state.bypassed = (scales, quats)
         out = _ProjectGaussiansAct.apply(means3d.contiguous(), scales.detach().contiguous(), glob_scale,
                                          quats.detach().contiguous(), viewmat.contiguous(), fx, fy, cx, cy,
                                          img_height, img_width, block_width, clip_thresh, x, *ls_leaves)
@@ -1313,6 +1368,32 @@ _provably_depths = proofs.repeated_depths     # host-side proof that colours are
 # Optional hook for data-parallel training (sgn_rast.dp.GradAllReducer(sparse=True)): `after_forward(ids, bins, kmax, n,
 # qmask)` is told, right after a full (non-window) forward pass, which list entries the pass walked.  None normally.
 _touch_sink = None
+# A graph proof is decided when the operator is CALLED; a hook or `retain_grad()` the caller places on the bypassed tensor
+# AFTERWARDS is found when the node's backward runs (round 6; rounds 3-5 documented that such a hook "sees nothing"):
+# the node keeps weak references to the tensors it bypassed (handed over through `_call_state.bypassed`, not as autograd
+# inputs: no edge), and if one of them has been asked for its gradient by then, the node computes the PLAIN gradient with
+# respect to that tensor and lets autograd carry it from there — `torch.autograd.backward([tensor], [gradient])`, a
+# re-entrant pass through the caller's own expression: its hooks fire, `.grad` is retained, the leaves accumulate exactly
+# what upstream's graph would have given them.  (`retain_graph=True`: nodes further back may be shared with the outer pass,
+# which still visits them — with nothing to add — and must find their saved tensors.)  The fast path pays two attribute
+# reads per bypassed tensor.
+def _bypassed_refs():
+    by = getattr(_call_state, "bypassed", ())
+    _call_state.bypassed = ()
+    return tuple(None if t is None else weakref.ref(t) for t in by)
+
+
+def _asked_for(ref) -> Optional[torch.Tensor]:
+    """The bypassed tensor, if it is alive and somebody has asked for its own gradient since the call."""
+    t = ref() if ref is not None else None
+    if t is not None and (t._backward_hooks or t.retains_grad):
+        return t
+    return None
+
+
+hooks_after_call_stats = {"project": 0, "opacity": 0, "colors": 0, "sh": 0}
+
+
 # hook for sgn_rast.dp.GradAllReducer's zero-copy bucket (round 6): `_grad_arena(leaf)` -> the slice of the reducer's flat
 # all-reduce buffer this step's gradient of `leaf` belongs in, or None.  A backward node that produces the gradient of an
 # input that IS a registered leaf writes it there instead of into a torch.empty tensor; autograd keeps the returned view as
@@ -1562,6 +1643,7 @@ class _RasterizeGaussians(Function):
         # gradients go to the extra inputs instead (the activations' backward runs inside sgn_raster_bwd's unpack kernel)
         ctx.grad_to_logits, ctx.grad_to_pre = len(opacity_logits) > 0, colors_pre is not None
         ctx.logit_rows = [v.shape[0] for v in opacity_logits]
+        ctx.bypassed = _bypassed_refs()     # (the caller's sigmoid(...) / clamp(...) tensors, where they were bypassed)
         ctx.arena_leaves = _arena_leaves(opacity_logits[0] if len(opacity_logits) == 1 else
                                          (opacity if not opacity_logits else None))
         ctx.alpha_clamp_bwd = semantics().alpha_clamp_bwd      # the backward runs with the CALL's value
@@ -1843,6 +1925,14 @@ class _RasterizeGaussians(Function):
         (gaussian_ids_sorted, tile_bins, xys, conics, colors, opacity, background, final_Ts,
          final_idx) = ctx.saved_tensors[:9]
         colors_pre = ctx.saved_tensors[9] if ctx.grad_to_pre else None
+        # a hook / retain_grad placed on the bypassed sigmoid(...) / clamp(...) tensor AFTER the call (see `_asked_for`):
+        # that activation is then differentiated by autograd, from the plain gradient this node computes for it
+        by = getattr(ctx, "bypassed", ()) or (None, None)
+        ask_o = _asked_for(by[0]) if ctx.grad_to_logits else None
+        ask_c = _asked_for(by[1]) if ctx.grad_to_pre else None
+        logit_mode = ctx.opacity_is_logit if (ask_o is not None or not ctx.grad_to_logits) else 2
+        if ask_c is not None:
+            colors_pre = None                # plain colour gradient (the clamp's mask is autograd's business then)
         dev = xys.device
         n = xys.shape[0]                     # rows of the caller's tensors (= the window's rows in window mode)
         H, W = ctx.img_height, ctx.img_width
@@ -1893,7 +1983,7 @@ class _RasterizeGaussians(Function):
                 L.check(lib.sgn_rasterize_bwd_all(
                     H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(ids), L.ptr(bins), L.ptr(kmax),
                     int(pairs_known), L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity),
-                    2 if ctx.grad_to_logits else ctx.opacity_is_logit, id_range[0], id_range[1], window,
+                    logit_mode, id_range[0], id_range[1], window,
                     L.ptr(background), L.ptr(Ts), L.ptr(idx), L.ptr(v_img), L.ptr(v_alpha), ctx.alpha_clamp_bwd,
                     L.ptr(v_xy), L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
                     L.ptr(gws), gws.numel(), L.ptr(order), L.ptr(scratch),
@@ -1907,7 +1997,7 @@ class _RasterizeGaussians(Function):
                 _S().walk_stat = order[-1:]          # rides to the host with the next binning's count (mask policy)
             args = (H, W, ctx.block_width, ctx.n_full, ctx.num_intersects, L.ptr(ids), L.ptr(bins),
                     L.ptr(xys), L.ptr(conics), L.ptr(colors), L.ptr(opacity),
-                    2 if ctx.grad_to_logits else ctx.opacity_is_logit, id_range[0],
+                    logit_mode, id_range[0],
                     id_range[1], window, L.ptr(background), L.ptr(Ts),
                     L.ptr(idx), L.ptr(v_img), L.ptr(v_alpha), ctx.alpha_clamp_bwd, L.ptr(v_xy),
                     L.ptr(v_conic), L.ptr(v_colors), L.ptr(v_opacity), L.ptr(recs), recs.numel(), packed,
@@ -1947,6 +2037,18 @@ class _RasterizeGaussians(Function):
         v_logits = ()
         if ctx.grad_to_logits:
             v_logits = (v_opacity,) if len(ctx.logit_rows) == 1 else v_opacity.split(ctx.logit_rows)
+        if ask_o is not None or ask_c is not None:
+            through, grads = [], []
+            if ask_o is not None:
+                through.append(ask_o); grads.append(v_opacity.reshape(ask_o.shape))
+                v_logits = (None,) * len(ctx.logit_rows)
+                hooks_after_call_stats["opacity"] += 1
+            if ask_c is not None and v_colors is not None:
+                through.append(ask_c); grads.append(v_colors.reshape(ask_c.shape))
+                v_colors = None
+                hooks_after_call_stats["colors"] += 1
+            if through:
+                torch.autograd.backward(through, grads, retain_graph=True)
         # (xys, depths, radii, conics, num_tiles_hit, colors, opacity, H, W, block, background, return_alpha,
         #  opacity_is_logit, id_range, want_depth, colors_are_depths, colors_pre, group_split, *opacity_logits)
         return (v_xy, None, None, v_conic, None, None if ctx.grad_to_pre else v_colors,
@@ -1998,6 +2100,7 @@ def rasterize_gaussians(xys, depths, radii, conics, num_tiles_hit, colors, opaci
         activation_proof_stats["opacity"] += len(logits) > 0
         activation_proof_stats["colors"] += pre is not None
     _call_state.grad = torch.is_grad_enabled()
+    _call_state.bypassed = (opacity if logits else None, colors if pre is not None else None)
     c = _contig
     return _RasterizeGaussians.apply(c(xys), c(depths), c(radii), c(conics), c(num_tiles_hit),
                                      c(colors.detach() if pre is not None else colors),

@@ -243,32 +243,104 @@ def test_alpha_only_pass_hands_autograd_no_colour_gradient():
 
 
 @pytest.mark.usefixtures("library_defaults")       # asserts WHICH mechanism served the calls: the defaults'
-def test_hooks_placed_after_the_call_see_the_documented_outcome():
+def test_hooks_placed_after_the_call_fire_as_upstreams_do():
     """The proofs are evaluated when the operator is called.  A hook or `retain_grad()` placed on an
-    activated tensor BEFORE the call refuses the proof (the tensor then receives its gradient as usual); one placed
-    AFTER the call is not seen: the operator's gradient goes straight to the leaf and the activated tensor's hook fires
-    with nothing from that operator.  This test pins both halves of that contract."""
+    activated tensor BEFORE the call refuses the proof (the tensor then receives its gradient as from upstream); one placed
+    AFTER the call is found when the node's backward runs (round 6; rounds 3-5: "sees nothing"): the node hands the plain
+    gradient to autograd at that tensor — the hook fires with what upstream's graph gives it, `.grad` is retained, the
+    leaves accumulate the same values.  Every bypassed tensor of the reference's call sites: exp(scales), normalised quats,
+    sigmoid(opacities), clamp(colours), cat(SH coefficients)."""
     from sgn_rast import ops
     n = 2000
     cam, P = small_scene(n=n, w=128, h=96, focal=128.0)
+    V = cam.viewmat[:3, :].to(DEV)
 
-    def run(when):
+    def run(which, when):
         ops.clear_binning_cache()
-        ls = P["log_scales"].to(DEV).requires_grad_(True)
-        rq = P["quats"].to(DEV).requires_grad_(True)
-        scales, quats = torch.exp(ls), rq / rq.norm(dim=-1, keepdim=True)
+        leaves = {k: P[k].to(DEV).requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits",
+                                                                  "features_dc", "features_rest")}
+        act = dict(scales=torch.exp(leaves["log_scales"]),
+                   quats=leaves["quats"] / leaves["quats"].norm(dim=-1, keepdim=True),
+                   opacity=torch.sigmoid(leaves["opacity_logits"]),
+                   coeffs=torch.cat((leaves["features_dc"], leaves["features_rest"]), dim=1))
         seen = []
-        if when == "before":
-            scales.register_hook(lambda g: seen.append(g))
-        outs = ops.project_gaussians(P["means"].to(DEV), scales, 1, quats, cam.viewmat[:3, :].to(DEV), cam.fx, cam.fy,
-                                     cam.cx, cam.cy, cam.height, cam.width, 16)
+        place = lambda t: (t.register_hook(lambda g: seen.append(g.detach().clone())), t.retain_grad())
+        if when == "before" and which != "colors":
+            place(act[which])
+        xys, depths, radii, conics, _c, nth, _cov = ops.project_gaussians(
+            leaves["means"], act["scales"], 1, act["quats"], V, cam.fx, cam.fy, cam.cx, cam.cy, cam.height, cam.width, 16)
+        dirs = leaves["means"].detach() - cam.cam_pos.to(DEV)
+        dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+        pre = ops.spherical_harmonics(3, dirs, act["coeffs"]) + 0.5
+        act["colors"] = torch.clamp(pre, min=0.0)
+        if when == "before" and which == "colors":
+            place(act["colors"])
+        img, alpha = ops.rasterize_gaussians(xys, depths, radii, conics, nth, act["colors"], act["opacity"], cam.height,
+                                             cam.width, 16, background=torch.zeros(3, device=DEV), return_alpha=True)
         if when == "after":
-            scales.register_hook(lambda g: seen.append(g))
-        (outs[0].sum() + outs[3].sum()).backward()
-        return seen, ls.grad
+            place(act[which])
+        w = torch.linspace(0.5, 1.5, cam.width, device=DEV)
+        ((img * w[None, :, None]).sum() + 0.3 * alpha.sum()).backward()
+        return seen, act[which].grad, {k: v.grad.detach().clone() for k, v in leaves.items()}
 
-    seen_b, g_b = run("before")
-    seen_a, g_a = run("after")
-    assert len(seen_b) == 1 and float(seen_b[0].abs().sum()) > 0         # opted out: the plain node, the hook sees it all
-    assert len(seen_a) == 0                                              # documented: bypassed
-    assert rel_l2(g_a.cpu(), g_b.cpu()) < 2e-6                           # the LEAF gradient is the same either way
+    stats0 = dict(ops.hooks_after_call_stats)
+    for which in ("scales", "quats", "opacity", "colors", "coeffs"):
+        seen_b, kept_b, g_b = run(which, "before")        # opted out at call time: upstream's own graph
+        seen_a, kept_a, g_a = run(which, "after")         # found at backward time
+        assert len(seen_b) == 1 and len(seen_a) == 1, (which, len(seen_b), len(seen_a))
+        assert float(seen_b[0].abs().sum()) > 0
+        assert rel_l2(seen_a[0], seen_b[0]) < 2e-6, which                     # the hook sees upstream's gradient
+        assert kept_a is not None and rel_l2(kept_a, kept_b) < 2e-6, which    # retain_grad() keeps it
+        for k in g_b:
+            assert rel_l2(g_a[k], g_b[k]) < 2e-6, (which, k)                  # the LEAF gradients are the same either way
+    d = {k: ops.hooks_after_call_stats[k] - stats0[k] for k in stats0}
+    assert d == {"project": 2, "opacity": 1, "colors": 1, "sh": 1}, d
+
+
+@pytest.mark.usefixtures("library_defaults")
+def test_hooks_placed_after_the_call_on_scene_graph_aggregates():
+    """The same on the scene graph's shapes: `scales = exp(cat(leaves))` of two sub-models, quaternions normalised from a
+    concatenation that holds a QUATERNION PRODUCT (a custom node further back, shared by the re-entrant pass and the outer
+    one), SH coefficients concatenated from four leaves and evaluated TWICE from the same tensor (a hook placed after
+    both calls then fires once per consuming node — upstream would sum them first; the leaves are the same)."""
+    from sgn_rast import ops, step
+    cam, P = small_scene(n=2400, w=128, h=96, focal=128.0)
+    V = cam.viewmat[:3, :].to(DEV)
+    box_q = torch.tensor([0.9659258, 0.0, 0.258819, 0.0])              # an object pose, on the host as in the reference
+    cut = 1500
+
+    def run(which, when):
+        ops.clear_binning_cache()
+        m0 = {k: v[:cut].to(DEV).requires_grad_(True) for k, v in P.items()}
+        m1 = {k: v[cut:].to(DEV).requires_grad_(True) for k, v in P.items()}
+        means = torch.cat((m0["means"], m1["means"]), 0)
+        act = dict(scales=torch.exp(torch.cat((m0["log_scales"], m1["log_scales"]), 0)),
+                   coeffs=torch.cat((torch.cat((m0["features_dc"], m1["features_dc"]), 0),
+                                     torch.cat((m0["features_rest"], m1["features_rest"]), 0)), dim=1))
+        rq = torch.cat((m0["quats"], step.quaternion_multiply(box_q, m1["quats"])), 0)
+        act["quats"] = rq / rq.norm(dim=-1, keepdim=True)
+        opac = torch.sigmoid(torch.cat((m0["opacity_logits"], m1["opacity_logits"]), 0))
+        seen = []
+        place = lambda t: t.register_hook(lambda g: seen.append(g.detach().clone()))
+        if when == "before":
+            place(act[which])
+        xys, depths, radii, conics, _c, nth, _cov = ops.project_gaussians(
+            means, act["scales"], 1, act["quats"], V, cam.fx, cam.fy, cam.cx, cam.cy, cam.height, cam.width, 16)
+        dirs = means.detach() - cam.cam_pos.to(DEV)
+        dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+        c1 = torch.clamp(ops.spherical_harmonics(3, dirs, act["coeffs"]) + 0.5, min=0.0)
+        c2 = torch.clamp(ops.spherical_harmonics(2, dirs, act["coeffs"]) + 0.5, min=0.0)     # second use of the tensor
+        img = ops.rasterize_gaussians(xys, depths, radii, conics, nth, 0.5 * (c1 + c2), opac, cam.height, cam.width, 16,
+                                      background=torch.zeros(3, device=DEV))
+        if when == "after":
+            place(act[which])
+        img.sum().backward()
+        return seen, {f"{i}.{k}": v.grad.detach().clone() for i, m in enumerate((m0, m1)) for k, v in m.items()}
+
+    for which in ("scales", "quats", "coeffs"):
+        seen_b, g_b = run(which, "before")
+        seen_a, g_a = run(which, "after")
+        assert len(seen_b) == 1 and len(seen_a) == (2 if which == "coeffs" else 1), (which, len(seen_a))
+        assert rel_l2(sum(seen_a), seen_b[0]) < 2e-6, which
+        for k in g_b:
+            assert rel_l2(g_a[k], g_b[k]) < 2e-6, (which, k)
