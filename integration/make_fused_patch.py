@@ -92,16 +92,18 @@ EDITS = [
      "            pass  # sgn_fused: sigmoid in-kernel\n"),
     ("            rgb, alpha = rasterize_gaussians(  # type: ignore\n",
      "            # sgn_fused: depth rides as a 4th channel; with group_split so do the accumulations of ids < / >= the split\n"
-     "            rgb, alpha, depth_channel, *self.sgn_group_acc = sgn_fused.rasterize_gaussians_fused(\n"),
+     "            sgn_out = sgn_fused.rasterize_gaussians_fused(\n"),
     ("                background=background,\n"
      "                return_alpha=True,\n"
      "            )  # type: ignore\n",
      "                background=background,\n"
      "                return_alpha=True,\n"
-     "                depth_channel=True,\n"
+     "                depth_channel='depth' in output_names,   # (a sub-model accumulation pass asks for no depth image)\n"
      "                id_range=id_range,\n"
      "                group_split=group_split,\n"
-     "            )  # type: ignore\n"),
+     "            )  # type: ignore\n"
+     "            rgb, alpha = sgn_out[0], sgn_out[1]   # (img, alpha[, depth][, acc_head, acc_tail])\n"
+     "            depth_channel, self.sgn_group_acc = (sgn_out[2] if len(sgn_out) > 2 else None), list(sgn_out[3:])\n"),
     ("            depth_im = rasterize_gaussians(\n"
      "                xys,\n"
      "                depths,\n"

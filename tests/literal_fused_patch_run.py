@@ -21,7 +21,7 @@ REF2OURS = dict(means="means", scales="log_scales", quats="quats", features_dc="
                 features_rest="features_rest", opacities="opacity_logits")
 ns = refhost.load("hip")
 src = open(ns.splat.__file__).read()
-assert "sgn_fused.project_gaussians_fused" in src and "depth_channel=True" in src, "the patch is not applied"
+assert "sgn_fused.project_gaussians_fused" in src and "depth_channel=" in src, "the patch is not applied"
 to_dev = lambda d: {k: v.to(DEV) for k, v in d.items()}
 
 cam = scenes.make_camera(W, H, FOCAL)
