@@ -326,6 +326,9 @@ WORKLOADS = [   # name, extra flags (each run adds --no-cpu-baseline --no-fused-
     ("scene_graph_fused", ["--scene-graph", "--path", "fused"]),
     ("train_dropin", ["--sky", "--photometric", "--adam"]),          # sky sphere + photometric loss + Adam in the step
     ("train_fused", ["--sky", "--photometric", "--adam", "--path", "fused"]),
+    # the configuration the reference SHIPS (sgn_config.py:42-69): scene graph + sky sphere, with the loss and the optimiser
+    ("scene_graph_train_dropin", ["--scene-graph", "--sky", "--photometric", "--adam"]),
+    ("scene_graph_train_fused", ["--scene-graph", "--sky", "--photometric", "--adam", "--path", "fused"]),
     ("street_force_dp", ["--street", "--force-dp", "--no-c4-extra"]),          # dense exchange (79 % of the rows touched)
     ("scene_graph_force_dp", ["--scene-graph", "--force-dp", "--no-c4-extra"]),
 ]
@@ -464,6 +467,9 @@ def main():
                                         overlap=not args.no_dp_overlap)
             reducer.timing = True
 
+    if sg is not None and (args.sky or args.photometric or args.adam) and (world > 1 or force_dp):
+        raise SystemExit("bench.py: --scene-graph with --sky / --photometric / --adam (the shipped model's training-shape "
+                         "step) is a single-GPU workload; the N-rank scene-graph line is --scene-graph alone")
     sky = None
     if args.sky:
         c2w = torch.zeros(3, 4, device=dev)
@@ -483,7 +489,10 @@ def main():
         from sgn_rast import optim
         lrs = {"means": 1.6e-4, "features_dc": 0.0025, "features_rest": 0.0025 / 20, "opacity_logits": 0.05,
                "log_scales": 0.005, "quats": 0.001}
-        adam = [optim.FusedAdam([P[k]], lr=lrs[k], eps=1e-15) for k in P]
+        if sg is not None:       # the shipped model: one optimiser group per sub-model and parameter (scene_graph.py:110-135)
+            adam = [optim.FusedAdam([m[k]], lr=lrs[k], eps=1e-15) for m in sg[0] for k in m]
+        else:
+            adam = [optim.FusedAdam([P[k]], lr=lrs[k], eps=1e-15) for k in P]
         if sky is not None:
             adam.append(optim.FusedAdam([sky["base"]], lr=0.01, eps=1e-15))
 
@@ -544,12 +553,23 @@ def main():
         for m in sg[0]:
             for p in m.values():
                 p.grad = None
+        if sky is not None:
+            sky["base"].grad = None
         out = step.render_scene_graph(sg[0], sg[1], sg[2], cam, 3, 16, fused=fused)
-        loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum() + (out.object_acc * w_a).sum()) / (
-            cam.height * cam.width)
+        n_pix = cam.height * cam.width
+        if sky is not None:          # use_sky_sphere (sgn_config.py:42-69: the configuration the reference SHIPS)
+            step.composite_sky(out, cam, sky["base"], sky["c2w"], train=True, fused=fused)
+        if gt_img is not None:       # the photometric loss (sgn_splatfacto.py:1084-1087) + linear terms on the two accumulations
+            from sgn_rast.loss import photometric_loss
+            photo = photometric_loss(out.rgb, gt_img, 0.2, clamp_max=None if sky is not None else 1.0)
+            loss = photo + ((out.alpha * w_a).sum() + (out.object_acc * w_a).sum()) / n_pix
+        else:
+            loss = ((out.rgb * w_img).sum() + (out.alpha * w_a).sum() + (out.object_acc * w_a).sum()) / n_pix
         loss.backward()
         if reducer is not None:
             reducer.finish()
+        if adam is not None:
+            optim.step_many(adam)
         return out
 
     def barrier():
