@@ -314,10 +314,10 @@ class _SphericalHarmonicsSplit(Function):
     (`src`: proofs.ShSource; the leaves follow as autograd inputs, DC parts first, then the REST leaves)."""
     @staticmethod
     def forward(ctx, degrees_to_use: int, viewdirs: torch.Tensor, coeffs: torch.Tensor, src, *leaves):
+        ctx.bypassed = _bypassed_refs()          # (the caller's torch.cat((dc, rest), 1) tensor)
         L.require_device(viewdirs, coeffs)
         num_points, k = coeffs.shape[0], coeffs.shape[-2]
         ctx.degrees_to_use, ctx.k, ctx.src = degrees_to_use, k, src
-        ctx.bypassed = _bypassed_refs()          # (the caller's torch.cat((dc, rest), 1) tensor)
         ctx.set_materialize_grads(False)
         deg_from_sh(k)
         viewdirs = _f32c(viewdirs)
@@ -583,12 +583,13 @@ class _ProjectGaussiansAct(Function):
     @staticmethod
     def forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height, img_width,
                 block_width, clip_thresh, x, *log_scale_leaves):
+        ctx.bypassed = _bypassed_refs()          # (the caller's exp(...) and normalised-quaternion tensors; taken FIRST:
+        #                                           nothing that raises below may leave them behind for another node)
         outs, saved = _project_forward(ctx, means3d, scales, glob_scale, quats, viewmat, fx, fy, cx, cy, img_height,
                                        img_width, block_width, clip_thresh)
         means3d_c, scales_c, _q, viewmat_c, cov3d, radii, conics, compensation = saved
         ctx.leaf_rows = [v.shape[0] for v in log_scale_leaves]
         ctx.arena_leaves = _arena_leaves(means3d, log_scale_leaves[0] if len(log_scale_leaves) == 1 else None, x)
-        ctx.bypassed = _bypassed_refs()          # (the caller's exp(...) and normalised-quaternion tensors)
         ctx.save_for_backward(means3d_c, scales_c, x, viewmat_c, cov3d, radii, conics, compensation)
         return outs
 
@@ -1641,9 +1642,9 @@ class _RasterizeGaussians(Function):
         # opacity_logits / colors_pre (proven by rasterize_gaussians, see proofs.sigmoid_leaves / clamp_pre): `opacity`
         # is sigmoid(cat(opacity_logits, 0)) and `colors` is clamp(colors_pre, min=0); both arrive DETACHED and the
         # gradients go to the extra inputs instead (the activations' backward runs inside sgn_raster_bwd's unpack kernel)
+        ctx.bypassed = _bypassed_refs()     # (the caller's sigmoid(...) / clamp(...) tensors, where they were bypassed)
         ctx.grad_to_logits, ctx.grad_to_pre = len(opacity_logits) > 0, colors_pre is not None
         ctx.logit_rows = [v.shape[0] for v in opacity_logits]
-        ctx.bypassed = _bypassed_refs()     # (the caller's sigmoid(...) / clamp(...) tensors, where they were bypassed)
         ctx.arena_leaves = _arena_leaves(opacity_logits[0] if len(opacity_logits) == 1 else
                                          (opacity if not opacity_logits else None))
         ctx.alpha_clamp_bwd = semantics().alpha_clamp_bwd      # the backward runs with the CALL's value
